@@ -1,0 +1,369 @@
+// attention.hip — invariant point attention core and the sequence-transformer attention.
+//
+//   attn_kernel<P, IPA=true>  : InvariantPointAttention.forward, framedipt/model/ipa_pytorch.py:251-313
+//        logits = QK^T/sqrt(3C) + b/sqrt(3) - 0.5 gamma_h sum_p |q_pt - k_pt|^2 + 1e5 (m_i m_j - 1); softmax_j;
+//        o = a v ; o_pt = R_i^T (a v_pts - t_i) ; |o_pt|.  The [N,N,H,P,3] displacement tensor is never built.
+//   attn_kernel<P, IPA=false> : nn.MultiheadAttention inside nn.TransformerEncoderLayer, ipa_pytorch.py:433-443,536-538
+//   opair_kernel              : o_pair = sum_j a[h,i,j] down_z(z[i,j]) (ipa_pytorch.py:317-322) evaluated as
+//                               down_z(sum_j a z) + b * sum_j a, so pair_z [N,N,c_z/4] is never materialised.
+//   points_kernel             : "split-thirds then stack" + Rigid.apply of the projected points (ipa_pytorch.py:213-239)
+//
+// One block = 32 query rows of one (batch, head); logits of the 32 rows stay in LDS as fp32 [32][N].
+#include "common.hpp"
+#include "kernels.hpp"
+
+
+// transposing stage: Ws[n][kk] = src[(k0+kk)*ld + n0 + n], kk < 32, n < TN (zero fill out of range)
+template <class P, int TN>
+__device__ __forceinline__ void stage_tile_T(typename P::T* dst, const float* __restrict__ src, long ld, int k0, int Kmax,
+                                             int n0, int Nmax, int tid) {
+  constexpr int LDT = P::BK + P::PAD;
+  constexpr int VPR = TN / 4;
+  for (int v = tid; v < P::BK * VPR; v += FD_THREADS) {
+    const int r = v / VPR, c4 = (v % VPR) * 4;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (k0 + r < Kmax && n0 + c4 < Nmax) x = *(const f32x4*)(src + (long)(k0 + r) * ld + n0 + c4);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) dst[(c4 + qd) * LDT + r] = P::from_f32(x[qd]);
+  }
+}
+
+template <class P, bool IPA>
+__global__ __launch_bounds__(FD_THREADS) void attn_kernel(AttnArgs a) {
+  constexpr int LDT = P::BK + P::PAD;
+  constexpr int TN = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.N;
+  const int LDS_S = a.lds_s;
+  float* S = (float*)smem;                                   // [32][LDS_S]
+  typename P::T* As = (typename P::T*)(smem + (size_t)32 * LDS_S * 4);   // [32][LDT]
+  typename P::T* Ws = As + 32 * LDT;                          // [128][LDT]
+  float* qps = (float*)(Ws + TN * LDT);                       // [32][Pq*3]   (IPA)
+  float* vps = (float*)As;                                    // [64][Pv*3]   (IPA, aliases As/Ws after the S phase)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const long rb = (long)b * N;
+  const float* qbase = a.q + rb * a.q_ld + (long)h * a.q_hs;
+  const float* kbase = a.k + rb * a.k_ld + (long)h * a.k_hs;
+  const float* vbase = a.v + rb * a.v_ld + (long)h * a.v_hs;
+  const int P3 = IPA ? a.Pq * 3 : 0;
+
+  if constexpr (IPA) {
+    for (int v = tid; v < 32 * P3; v += FD_THREADS) {
+      const int r = v / P3, c = v % P3;
+      qps[v] = (i0 + r < N) ? a.qp[((rb + i0 + r) * a.H + h) * P3 + c] : 0.f;
+    }
+  }
+  // ---------------- phase 1: logits S[32][N]
+  for (int j0 = 0; j0 < N; j0 += TN) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < a.C; k0 += P::BK) {
+      stage_tile<P, float, 32>(As, qbase, a.q_ld, i0, N, k0, a.C, tid);
+      stage_tile<P, float, TN>(Ws, kbase, a.k_ld, j0, N, k0, a.C, tid);
+      __syncthreads();
+      wave_mma<P>(acc, As + (lane & 31) * LDT, Ws + (wave * 32 + (lane & 31)) * LDT, lane);
+      __syncthreads();
+    }
+    const int j = j0 + wave * 32 + (lane & 31);
+    if (j < N) {
+      const float mj = a.res_mask[rb + j];
+      float kpv[24];
+      float gam = 0.f;
+      if constexpr (IPA) {
+        gam = -0.5f * a.gamma[h];
+#pragma unroll
+        for (int c = 0; c < 24; ++c) kpv[c] = c < P3 ? a.kp[((rb + j) * a.H + h) * P3 + c] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ir = c_row(r, lane), i = i0 + ir;
+        float s = acc[r] * a.scale;
+        if (i < N) {
+          if constexpr (IPA) {
+            s += a.bias[((rb + i) * N + j) * a.H + h];
+            float d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 24; ++c) {
+              if (c < P3) {
+                const float d = qps[ir * P3 + c] - kpv[c];
+                d2 += d * d;
+              }
+            }
+            s += gam * d2;
+            s += 1e5f * (a.res_mask[rb + i] * mj - 1.f);
+          } else {
+            if (mj == 0.f) s = -1e30f;  // key padding (torch >= 2 inference fast-path semantics)
+          }
+        }
+        S[ir * LDS_S + j] = s;
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- phase 2: softmax over j (fp32), rows owned by waves
+  for (int ir = wave; ir < 32; ir += FD_THREADS / 64) {
+    float* row = S + ir * LDS_S;
+    float v[16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int j = lane + t * 64;
+      v[t] = j < N ? row[j] : -3.0e38f;
+      mx = fmaxf(mx, v[t]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int j = lane + t * 64;
+      v[t] = j < N ? expf(v[t] - mx) : 0.f;
+      sum += v[t];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    const int i = i0 + ir;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int j = lane + t * 64;
+      if (j < N) {
+        const float p = v[t] * inv;
+        row[j] = p;
+        if (IPA && i < N) a.probs[(((long)b * a.H + h) * N + i) * N + j] = p;
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- phase 3 (IPA): o_pt = R_i^T (sum_j p v_pts - t_i), fp32 VALU
+  if constexpr (IPA) {
+    const int Pv = a.Pv, V3 = Pv * 3;
+    float ax[2] = {0.f, 0.f}, ay[2] = {0.f, 0.f}, az[2] = {0.f, 0.f};
+    for (int j0 = 0; j0 < N; j0 += 64) {
+      for (int v = tid; v < 64 * V3; v += FD_THREADS) {
+        const int r = v / V3, c = v % V3;
+        vps[v] = (j0 + r < N) ? a.vp[((rb + j0 + r) * a.H + h) * V3 + c] : 0.f;
+      }
+      __syncthreads();
+      const int jn = min(64, N - j0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * FD_THREADS;
+        if (it < 32 * Pv) {
+          const int ir = it / Pv, pt = it % Pv;
+          const float* prow = S + ir * LDS_S + j0;
+          float sx = 0.f, sy = 0.f, sz = 0.f;
+          for (int jj = 0; jj < jn; ++jj) {
+            const float p = prow[jj];
+            sx += p * vps[jj * V3 + pt * 3 + 0];
+            sy += p * vps[jj * V3 + pt * 3 + 1];
+            sz += p * vps[jj * V3 + pt * 3 + 2];
+          }
+          ax[u] += sx; ay[u] += sy; az[u] += sz;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int it = tid + u * FD_THREADS;
+      if (it < 32 * Pv) {
+        const int ir = it / Pv, pt = it % Pv, i = i0 + ir;
+        if (i < N) {
+          const float* R = a.rot + (rb + i) * 9;
+          const float* T = a.trans + (rb + i) * 3;
+          const float x = ax[u] - T[0], y = ay[u] - T[1], z = az[u] - T[2];
+          // invert_apply: R^T (p - t)   (openfold/utils/rigid_utils.py:1118-1130)
+          const float ox = R[0] * x + R[3] * y + R[6] * z;
+          const float oy = R[1] * x + R[4] * y + R[7] * z;
+          const float oz = R[2] * x + R[5] * y + R[8] * z;
+          float* o = a.out + (rb + i) * a.out_ld + a.pt_off + h * Pv + pt;
+          const int HP = a.H * Pv;
+          o[0] = ox; o[HP] = oy; o[2 * HP] = oz;
+          o[3 * HP] = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
+        }
+      }
+    }
+  }
+  // ---------------- phase 4: operand-precision copy of P in place (bf16 mode), then O = P V on MFMA
+  if constexpr (sizeof(typename P::T) == 2) {
+    for (int ir = wave; ir < 32; ir += FD_THREADS / 64) {
+      float* row = S + ir * LDS_S;
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int j = lane + t * 64;
+        v[t] = j < N ? row[j] : 0.f;
+      }
+      typename P::T* prow = (typename P::T*)row;
+      const int npad = (N + 31) & ~31;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int j = lane + t * 64;
+        if (j < npad) prow[j] = P::from_f32(v[t]);
+      }
+    }
+  } else {
+    const int npad = (N + 31) & ~31;
+    for (int v = tid; v < 32 * (npad - N); v += FD_THREADS) S[(v / (npad - N)) * LDS_S + N + v % (npad - N)] = 0.f;
+  }
+  __syncthreads();
+  const typename P::T* Pm = (const typename P::T*)S;
+  const int ldp = LDS_S * (int)(4 / sizeof(typename P::T));
+  for (int d0 = 0; d0 < a.Dv; d0 += TN) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < N; k0 += P::BK) {
+      stage_tile_T<P, TN>(Ws, vbase, a.v_ld, k0, N, d0, a.Dv, tid);
+      __syncthreads();
+      wave_mma<P>(acc, Pm + (lane & 31) * ldp + k0, Ws + (wave * 32 + (lane & 31)) * LDT, lane);
+      __syncthreads();
+    }
+    const int d = d0 + wave * 32 + (lane & 31);
+    if (d < a.Dv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + c_row(r, lane);
+        if (i < N) a.out[(rb + i) * a.out_ld + (long)h * a.Dv + d] = acc[r];
+      }
+    }
+  }
+}
+
+template <class P>
+static size_t attn_smem(int N, int Pq, int* lds_s) {
+  const int npad = (N + 63) & ~63;
+  *lds_s = npad + (sizeof(typename P::T) == 2 ? 4 : 1);
+  constexpr int LDT = P::BK + P::PAD;
+  return (size_t)32 * (*lds_s) * 4 + (size_t)(32 + 128) * LDT * sizeof(typename P::T) + (size_t)32 * Pq * 3 * 4 + 16;
+}
+
+template <class P, bool IPA>
+static int launch_attn(AttnArgs a, hipStream_t st) {
+  if (a.N > 1024 || a.Pq * 3 > 24 || a.Pv > 16 || (a.C & 3) || (a.Dv & 3)) return FDIPT_ESIZE;
+  const size_t smem = attn_smem<P>(a.N, IPA ? a.Pq : 0, &a.lds_s);
+  if (smem > 160 * 1024) return FDIPT_ESIZE;
+  static bool attr_set = false;  // idempotent: raises the dynamic-LDS cap of this kernel instance once
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attn_kernel<P, IPA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_kernel<P, IPA>), dim3(cdiv(a.N, 32), a.H, a.B), dim3(FD_THREADS), smem, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st) {
+  if (precision == FDIPT_PREC_F32) return ipa ? launch_attn<PrecF32, true>(a, st) : launch_attn<PrecF32, false>(a, st);
+  return ipa ? launch_attn<PrecBF16, true>(a, st) : launch_attn<PrecBF16, false>(a, st);
+}
+
+// ------------------------------------------------------------------ o_pair
+
+template <class ZT>
+__global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.N, H = a.H, CZ = a.CZ;
+  float* ps = (float*)smem;             // [H][N]
+  float* azs = ps + H * N;              // [2][H][CZ]
+  float* psum = azs + 2 * H * CZ;       // [H]
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x, b = blockIdx.y;
+  const long rb = (long)b * N;
+  for (int v = tid; v < H * N; v += FD_THREADS) {
+    const int hh = v / N, j = v % N;
+    ps[v] = a.probs[(((long)b * H + hh) * N + i) * N + j];
+  }
+  __syncthreads();
+  const ZT* zrow = (const ZT*)a.z + (rb + i) * N * CZ;
+  // channel c = tid % CZ; keys j interleaved over (at most two) slices so the sum order is fixed
+  const int nsl = FD_THREADS / CZ >= 2 ? 2 : 1;
+  const int c = tid % CZ, sl = tid / CZ;
+  float acc[16];
+#pragma unroll
+  for (int hh = 0; hh < 16; ++hh) acc[hh] = 0.f;
+  if (sl < nsl) {
+    for (int j = sl; j < N; j += nsl) {
+      float zv;
+      if constexpr (sizeof(ZT) == 4) zv = zrow[(long)j * CZ + c]; else zv = bf2f(zrow[(long)j * CZ + c]);
+#pragma unroll
+      for (int hh = 0; hh < 16; ++hh)
+        if (hh < H) acc[hh] += ps[hh * N + j] * zv;
+    }
+  }
+  float* red = azs;  // [nsl][H][CZ]
+  if (sl < nsl)
+    for (int hh = 0; hh < H; ++hh) red[(sl * H + hh) * CZ + c] = acc[hh];
+  __syncthreads();
+  if (nsl == 2 && sl == 0)
+    for (int hh = 0; hh < H; ++hh) red[hh * CZ + c] += red[(H + hh) * CZ + c];
+  if (tid < H) {
+    float s = 0.f;
+    for (int j = 0; j < N; ++j) s += ps[tid * N + j];
+    psum[tid] = s;
+  }
+  __syncthreads();
+  const int CD = a.CD;
+  for (int o = tid; o < H * CD; o += FD_THREADS) {
+    const int hh = o / CD, d = o % CD;
+    float s = a.bdz[d] * psum[hh];
+    const float* w = a.wdz + (long)d * CZ;
+    for (int cc = 0; cc < CZ; ++cc) s += red[hh * CZ + cc] * w[cc];
+    a.out[(rb + i) * a.out_ld + a.off + hh * CD + d] = s;
+  }
+}
+
+int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
+  if (a.H > 16 || a.CZ > FD_THREADS || (FD_THREADS % a.CZ)) return FDIPT_ESIZE;
+  const size_t smem = ((size_t)a.H * a.N + 2 * a.H * a.CZ + a.H + 4) * 4;
+  if (smem > 64 * 1024) return FDIPT_ESIZE;
+  if (precision == FDIPT_PREC_F32)
+    hipLaunchKernelGGL(opair_kernel<float>, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
+  else
+    hipLaunchKernelGGL(opair_kernel<bf16_t>, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// ------------------------------------------------------------------ projected points -> global frame
+
+__global__ void points_kernel(PointsArgs a) {
+  const long r = blockIdx.x;  // residue row b*N+i
+  const int tid = threadIdx.x;
+  const float* q = a.quat + r * 4;
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  // quat_to_rot (openfold/utils/rigid_utils.py:173-205), no normalisation
+  float R[9];
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+  R[3] = 2 * x * y + 2 * w * z; R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * y * z - 2 * w * x;
+  R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = w * w - x * x - y * y + z * z;
+  const float tx = a.trans[r * 3], ty = a.trans[r * 3 + 1], tz = a.trans[r * 3 + 2];
+  if (tid < 9) a.rot[r * 9 + tid] = R[tid];
+  const int HPq = a.H * a.Pq, Pkv = a.Pq + a.Pv, HPkv = a.H * Pkv;
+  const float* row = a.proj + r * a.ld;
+  for (int p = tid; p < HPq + HPkv; p += blockDim.x) {
+    float px, py, pz;
+    float* dst;
+    if (p < HPq) {
+      px = row[a.q_off + p]; py = row[a.q_off + HPq + p]; pz = row[a.q_off + 2 * HPq + p];
+      dst = a.qp + (r * HPq + p) * 3;
+    } else {
+      const int pp = p - HPq;
+      px = row[a.kv_off + pp]; py = row[a.kv_off + HPkv + pp]; pz = row[a.kv_off + 2 * HPkv + pp];
+      const int hh = pp / Pkv, e = pp % Pkv;
+      dst = e < a.Pq ? a.kp + ((r * a.H + hh) * a.Pq + e) * 3 : a.vp + ((r * a.H + hh) * a.Pv + (e - a.Pq)) * 3;
+    }
+    dst[0] = R[0] * px + R[1] * py + R[2] * pz + tx;
+    dst[1] = R[3] * px + R[4] * py + R[5] * pz + ty;
+    dst[2] = R[6] * px + R[7] * py + R[8] * pz + tz;
+  }
+}
+
+int fd_points(const PointsArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(points_kernel, dim3(a.B * a.N), dim3(256), 0, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

@@ -1,0 +1,597 @@
+// frames.hip — rigid-frame algebra, SO(3) exp/log (SciPy conventions), the fused reverse step,
+// IGSO(3) / R^3 scores and idealised backbone atoms.  All O(N) kernels: a few KB of state, latency-bound.
+// Reference lines are cited per function (paths relative to the reference repository root).
+#include "common.hpp"
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)  // keep the float32 evaluation order of the reference expressions
+
+// ------------------------------------------------------------------ float32 quaternion algebra
+__device__ __forceinline__ void d_quat_to_rot(const float* q, float* R) {  // openfold/utils/rigid_utils.py:173-205
+  const float a = q[0], b = q[1], c = q[2], d = q[3];
+  R[0] = a * a + b * b - c * c - d * d; R[1] = 2 * b * c - 2 * a * d; R[2] = 2 * b * d + 2 * a * c;
+  R[3] = 2 * b * c + 2 * a * d; R[4] = a * a - b * b + c * c - d * d; R[5] = 2 * c * d - 2 * a * b;
+  R[6] = 2 * b * d - 2 * a * c; R[7] = 2 * c * d + 2 * a * b; R[8] = a * a - b * b - c * c + d * d;
+}
+__device__ __forceinline__ void d_quat_mul(const float* p, const float* q, float* o) {  // rigid_utils.py:230-263
+  o[0] = p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3];
+  o[1] = p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2];
+  o[2] = p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+  o[3] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+}
+__device__ __forceinline__ void d_quat_mul_vec(const float* q, const float* v, float* o) {  // rigid_utils.py:266-279
+  o[0] = -q[1] * v[0] - q[2] * v[1] - q[3] * v[2];
+  o[1] = q[0] * v[0] + q[2] * v[2] - q[3] * v[1];
+  o[2] = q[0] * v[1] - q[1] * v[2] + q[3] * v[0];
+  o[3] = q[0] * v[2] + q[1] * v[1] - q[2] * v[0];
+}
+__device__ __forceinline__ void d_invert_quat(const float* q, float* o) {  // rigid_utils.py:282-286
+  const float n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  o[0] = q[0] / n; o[1] = -q[1] / n; o[2] = -q[2] / n; o[3] = -q[3] / n;
+}
+__device__ __forceinline__ void d_rot_vec(const float* R, const float* v, float* o) {  // rigid_utils.py:82-106
+  o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+}
+__device__ __forceinline__ void d_quat_to_rotvec(const float* qin, float* rv) {  // framedipt/data/transforms.py:53-69
+  float q[4] = {qin[0], qin[1], qin[2], qin[3]};
+  if (q[0] < 0.f) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  const float nv = sqrtf(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float angle = 2.f * atan2f(nv, q[0]);
+  const float a2 = angle * angle;
+  const float sc = (angle <= 1e-3f) ? (2.f + a2 / 12.f + 7.f * a2 * a2 / 2880.f) : (angle / sinf(angle / 2.f + 1e-6f));
+  rv[0] = sc * q[1]; rv[1] = sc * q[2]; rv[2] = sc * q[3];
+}
+
+// ------------------------------------------------------------------ SciPy Rotation conventions, float64
+// Rotation.from_rotvec(rv).as_matrix()  (framedipt/data/transforms.py:42 ; se3_diffuser.py:31)
+__device__ __forceinline__ void d_so3_exp(const double* rv, double* R) {
+  const double th2 = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
+  const double th = sqrt(th2);
+  const double sc = (th <= 1e-3) ? (0.5 - th2 / 48.0 + th2 * th2 / 3840.0) : (sin(th / 2) / th);
+  const double x = sc * rv[0], y = sc * rv[1], z = sc * rv[2], w = cos(th / 2);
+  const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+  const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+  R[0] = x2 - y2 - z2 + w2; R[3] = 2 * (xy + zw); R[6] = 2 * (xz - yw);
+  R[1] = 2 * (xy - zw); R[4] = -x2 + y2 - z2 + w2; R[7] = 2 * (yz + xw);
+  R[2] = 2 * (xz + yw); R[5] = 2 * (yz - xw); R[8] = -x2 - y2 + z2 + w2;
+}
+// Markley quaternion of a 3x3 matrix (Rotation.from_matrix, SciPy 1.7.3 = the reference pin: no SVD projection).
+// q is scalar-LAST (x,y,z,w), normalised.
+__device__ __forceinline__ void d_markley(const double* m, double* q) {
+  const double d0 = m[0], d1 = m[4], d2 = m[8], tr = d0 + d1 + d2;
+  int ch = 0;
+  double best = d0;
+  if (d1 > best) { best = d1; ch = 1; }
+  if (d2 > best) { best = d2; ch = 2; }
+  if (tr > best) { ch = 3; }
+  if (ch == 3) {
+    q[0] = m[7] - m[5]; q[1] = m[2] - m[6]; q[2] = m[3] - m[1]; q[3] = 1 + tr;
+  } else {
+    const int i = ch, j = (i + 1) % 3, k = (j + 1) % 3;
+    q[i] = 1 - tr + 2 * m[i * 3 + i];
+    q[j] = m[j * 3 + i] + m[i * 3 + j];
+    q[k] = m[k * 3 + i] + m[i * 3 + k];
+    q[3] = m[k * 3 + j] - m[j * 3 + k];
+  }
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+// Rotation.from_matrix(m).as_rotvec()  (framedipt/data/transforms.py:46 ; se3_diffuser.py:21)
+__device__ __forceinline__ void d_so3_log(const double* m, double* rv) {
+  double q[4];
+  d_markley(m, q);
+  if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  const double ang = 2 * atan2(sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]), q[3]);
+  const double a2 = ang * ang;
+  const double sc = (ang <= 1e-3) ? (2 + a2 / 12 + 7 * a2 * a2 / 2880) : (ang / sin(ang / 2));
+  rv[0] = sc * q[0]; rv[1] = sc * q[1]; rv[2] = sc * q[2];
+}
+
+// ------------------------------------------------------------------ fused reverse step (one block per sample)
+struct ReverseArgs {
+  int B, N;
+  const float* rigids_t;
+  const double* rot_score;
+  const float* trans_score;
+  const float* diffuse_mask;
+  const double *z_rot, *z_trans;
+  double t, dt, noise_scale;
+  int center, diffuse_rot, diffuse_trans;
+  double so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, cs;
+  float* rigids_out;
+  float* out_rot;
+};
+
+__global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a) {
+  __shared__ double red[4][FD_THREADS / 64];
+  __shared__ double com[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N;
+  // schedules: so3_diffuser.py:299-319, r3_diffuser.py:48-85
+  const double emax = exp(a.so3_max_sigma), emin = exp(a.so3_min_sigma);
+  const double sig = log(a.t * emax + (1 - a.t) * emin);
+  const double g_rot = sqrt(2 * (emax - emin) * sig / exp(sig));
+  const double bt = a.r3_min_b + a.t * (a.r3_max_b - a.r3_min_b);
+  const double g_tr = sqrt(bt);
+  const double sdt = sqrt(a.dt);
+  double sx = 0, sy = 0, sz = 0, sm = 0;
+  // pass 1: translations x_{t-1} before centring (r3_diffuser.py:368-378), accumulate COM sums
+  for (int i = tid; i < N; i += FD_THREADS) {
+    const long r = (long)b * N + i;
+    const double m = a.diffuse_mask ? (double)a.diffuse_mask[r] : 1.0;
+    double x1[3];
+    for (int c = 0; c < 3; ++c) {
+      const double x = (double)a.rigids_t[r * 7 + 4 + c] * a.cs;
+      const double f = -0.5 * bt * x;
+      const double z = a.noise_scale * a.z_trans[r * 3 + c];
+      double pert = (f - g_tr * g_tr * (double)a.trans_score[r * 3 + c]) * a.dt + g_tr * sdt * z;
+      pert *= m;
+      x1[c] = x - pert;
+    }
+    sx += x1[0]; sy += x1[1]; sz += x1[2]; sm += m;
+  }
+  sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz); sm = wave_sum_d(sm);
+  if (lane == 0) { red[0][wave] = sx; red[1][wave] = sy; red[2][wave] = sz; red[3][wave] = sm; }
+  __syncthreads();
+  if (tid < 4) {
+    double s = 0;
+    for (int w = 0; w < FD_THREADS / 64; ++w) s += red[tid][w];
+    com[tid] = s;
+  }
+  __syncthreads();
+  // COM quirk of the reference: sum over ALL residues divided by the number of DIFFUSED residues (r3:379-383)
+  const double cx = a.center ? com[0] / com[3] : 0.0, cy = a.center ? com[1] / com[3] : 0.0,
+               cz = a.center ? com[2] / com[3] : 0.0;
+  for (int i = tid; i < N; i += FD_THREADS) {
+    const long r = (long)b * N + i;
+    const bool has_mask = a.diffuse_mask != nullptr;
+    const double m = has_mask ? (double)a.diffuse_mask[r] : 1.0;
+    // ---- translation
+    double tr_out[3];
+    for (int c = 0; c < 3; ++c) {
+      const double xt = (double)a.rigids_t[r * 7 + 4 + c];
+      double x1 = xt;
+      if (a.diffuse_trans) {
+        const double x = xt * a.cs;
+        const double f = -0.5 * bt * x;
+        const double z = a.noise_scale * a.z_trans[r * 3 + c];
+        double pert = (f - g_tr * g_tr * (double)a.trans_score[r * 3 + c]) * a.dt + g_tr * sdt * z;
+        pert *= m;
+        x1 = x - pert;
+        x1 -= (c == 0 ? cx : (c == 1 ? cy : cz));
+        x1 = x1 / a.cs;
+      }
+      tr_out[c] = has_mask ? (m * x1 + (1 - m) * xt) : x1;  // se3_diffuser.py:397-399
+    }
+    // ---- rotation: f32 quat -> f32 matrix -> f64 rotvec (se3_diffuser.py:16-23)
+    float R32[9];
+    d_quat_to_rot(a.rigids_t + r * 7, R32);
+    double Rt[9], rv[3];
+    for (int c = 0; c < 9; ++c) Rt[c] = (double)R32[c];
+    d_so3_log(Rt, rv);
+    double rv1[3] = {rv[0], rv[1], rv[2]};
+    if (a.diffuse_rot) {
+      double pert[3], Rp[9], Rc[9];
+      for (int c = 0; c < 3; ++c)
+        pert[c] = g_rot * g_rot * a.rot_score[r * 3 + c] * a.dt + g_rot * sdt * (a.noise_scale * a.z_rot[r * 3 + c]);
+      double Re[9];
+      d_so3_exp(rv, Re);
+      d_so3_exp(pert, Rp);
+      for (int ii = 0; ii < 3; ++ii)
+        for (int jj = 0; jj < 3; ++jj)
+          Rc[ii * 3 + jj] = Re[ii * 3] * Rp[jj] + Re[ii * 3 + 1] * Rp[3 + jj] + Re[ii * 3 + 2] * Rp[6 + jj];
+      d_so3_log(Rc, rv1);  // compose_rotvec, framedipt/data/transforms.py:33-46
+    }
+    if (has_mask)
+      for (int c = 0; c < 3; ++c) rv1[c] = m * rv1[c] + (1 - m) * rv[c];
+    // ---- assemble (se3_diffuser.py:26-36): float32 rotation matrix + translation, then tensor_7
+    double Ro[9];
+    d_so3_exp(rv1, Ro);
+    float Rf[9];
+    for (int c = 0; c < 9; ++c) Rf[c] = (float)Ro[c];
+    if (a.out_rot)
+      for (int c = 0; c < 9; ++c) a.out_rot[r * 9 + c] = Rf[c];
+    double Rd[9], q[4];
+    for (int c = 0; c < 9; ++c) Rd[c] = (double)Rf[c];
+    d_markley(Rd, q);  // rot_to_quat (rigid_utils.py:208-227) up to sign; consumers are sign-invariant
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    float* o = a.rigids_out + r * 7;
+    o[0] = (float)q[3]; o[1] = (float)q[0]; o[2] = (float)q[1]; o[3] = (float)q[2];
+    o[4] = (float)tr_out[0]; o[5] = (float)tr_out[1]; o[6] = (float)tr_out[2];
+  }
+}
+
+// ------------------------------------------------------------------ IGSO(3) rotation score
+// 8 lanes per residue split the 1000-term series; float32 sin/cos of omega*(l+1/2), float64 weights and sums
+// (the dtype flow torch produces for so3_diffuser.py:68-77,180-191 on the path).
+__global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t, int ld_t,
+                                                               const float* __restrict__ quats_0, int ld_0,
+                                                               const double* __restrict__ sigma,
+                                                               const float* __restrict__ res_mask,
+                                                               double* __restrict__ score) {
+  const long gid = (long)blockIdx.x * (FD_THREADS / 8) + (threadIdx.x >> 3);
+  const int sub = threadIdx.x & 7;
+  const long total = (long)B * N;
+  const long r = gid < total ? gid : total - 1;
+  const int b = (int)(r / N);
+  float qi[4], q0t[4], rv[3];
+  d_invert_quat(quats_0 + r * ld_0, qi);
+  d_quat_mul(qi, quats_t + r * ld_t, q0t);
+  d_quat_to_rotvec(q0t, rv);
+  const float omega = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]) + 1e-6f;
+  const double sg = sigma[b];
+  const float lo = sinf(omega / 2.f), dlo = 0.5f * cosf(omega / 2.f);
+  const float den = lo * lo;
+  double f = 0, ds = 0;
+  for (int l = sub; l < 1000; l += 8) {
+    const double w = (double)(2 * l + 1) * exp(-(double)l * (double)(l + 1) * sg * sg / 2);
+    const float lh = (float)l + 0.5f;
+    const float arg = omega * lh;
+    const float hi = sinf(arg), dhi = lh * cosf(arg);
+    f += w * (double)hi / (double)lo;
+    const float num = lo * dhi - hi * dlo;
+    ds += w * (double)num / (double)den;
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    f += __shfl_xor(f, o, 64);
+    ds += __shfl_xor(ds, o, 64);
+  }
+  if (gid < total && sub < 3) {
+    const double sc = ds / (f + 1e-4);
+    const double m = res_mask ? (double)res_mask[r] : 1.0;
+    score[r * 3 + sub] = sc * (double)rv[sub] / (double)omega * m;
+  }
+}
+
+// R^3 score, float32 (r3_diffuser.py:387-440 with use_torch=True, scale=True)
+__global__ void trans_score_kernel(int B, int N, const float* __restrict__ trans_t, int ld_t,
+                                   const float* __restrict__ trans_0, int ld_0, const float* __restrict__ t,
+                                   float min_b, float max_b, float cs, const float* __restrict__ res_mask,
+                                   float* __restrict__ score) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (long)B * N) return;
+  const float tt = t[r / N];
+  const float mb = tt * min_b + 0.5f * (tt * tt) * (max_b - min_b);
+  const float e = expf(-0.5f * mb);
+  const float cv = 1.f - expf(-mb);
+  const float m = res_mask ? res_mask[r] : 1.f;
+  for (int c = 0; c < 3; ++c) {
+    const float xt = trans_t[r * ld_t + c] * cs, x0 = trans_0[r * ld_0 + c] * cs;
+    score[r * 3 + c] = -(xt - e * x0) / cv * m;
+  }
+}
+
+// ------------------------------------------------------------------ backbone atoms
+// all_atom.py:147-176 -> openfold/utils/feats.py:165-228 -> all_atom.py:108-144.  One thread per residue.
+struct BackboneTables {  // packed by framedipt_amd/residue_tables.py
+  float default_frames[21 * 8 * 16];
+  float ideal_pos[21 * 14 * 3];
+  float atom_mask[21 * 14];
+  int32_t group_idx[21 * 14];
+};
+
+__device__ __forceinline__ void d_compose(const float* R1, const float* t1, const float* R2, const float* t2, float* Ro,
+                                          float* to) {  // Rigid.compose, rigid_utils.py:1065-1079
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = R1[i * 3] * R2[j] + R1[i * 3 + 1] * R2[3 + j] + R1[i * 3 + 2] * R2[6 + j];
+  float tmp[3];
+  d_rot_vec(R1, t2, tmp);
+  to[0] = tmp[0] + t1[0]; to[1] = tmp[1] + t1[1]; to[2] = tmp[2] + t1[2];
+}
+
+__global__ void backbone_kernel(int n, const float* __restrict__ t7, const float* __restrict__ rot,
+                                const float* __restrict__ trans, int ld_trans, const float* __restrict__ psi,
+                                const int32_t* __restrict__ aatype, const BackboneTables* __restrict__ tb,
+                                float* __restrict__ atom37, float* __restrict__ atom14) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  float Rb[9], tbv[3];
+  if (rot) {
+    for (int c = 0; c < 9; ++c) Rb[c] = rot[r * 9 + c];
+    for (int c = 0; c < 3; ++c) tbv[c] = trans[r * ld_trans + c];
+  } else {
+    d_quat_to_rot(t7 + r * 7, Rb);
+    for (int c = 0; c < 3; ++c) tbv[c] = t7[r * 7 + 4 + c];
+  }
+  int aa = aatype ? aatype[r] : 0;
+  if (aa == 20) aa = 0;
+  const float s = psi[r * 2], co = psi[r * 2 + 1];
+  float FR[8][9], FT[8][3];
+  for (int g = 0; g < 8; ++g) {
+    const float* d44 = tb->default_frames + (aa * 8 + g) * 16;
+    float Rd[9], td[3], Ra[9];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Rd[i * 3 + j] = d44[i * 4 + j];
+      td[i] = d44[i * 4 + 3];
+    }
+    const float a0 = g == 0 ? 0.f : s, a1 = g == 0 ? 1.f : co;  // backbone frame: (sin,cos) = (0,1)
+    Ra[0] = 1; Ra[1] = 0; Ra[2] = 0; Ra[3] = 0; Ra[4] = a1; Ra[5] = -a0; Ra[6] = 0; Ra[7] = a0; Ra[8] = a1;
+    const float z3[3] = {0.f, 0.f, 0.f};
+    d_compose(Rd, td, Ra, z3, FR[g], FT[g]);
+  }
+  for (int g = 5; g < 8; ++g) {  // chi2..chi4 chained onto chi1 (feats.py:204-212)
+    float Rn[9], tn[3];
+    d_compose(FR[g - 1], FT[g - 1], FR[g], FT[g], Rn, tn);
+    for (int c = 0; c < 9; ++c) FR[g][c] = Rn[c];
+    for (int c = 0; c < 3; ++c) FT[g][c] = tn[c];
+  }
+  float pos[14][3];
+  for (int at = 0; at < 14; ++at) {
+    const int g = tb->group_idx[aa * 14 + at];
+    float Rg[9], tg[3], p[3];
+    d_compose(Rb, tbv, FR[g], FT[g], Rg, tg);
+    d_rot_vec(Rg, tb->ideal_pos + (aa * 14 + at) * 3, p);
+    const float mk = tb->atom_mask[aa * 14 + at];
+    for (int c = 0; c < 3; ++c) pos[at][c] = (p[c] + tg[c]) * mk;
+  }
+  if (atom14)
+    for (int at = 0; at < 14; ++at)
+      for (int c = 0; c < 3; ++c) atom14[(r * 14 + at) * 3 + c] = pos[at][c];
+  if (atom37) {
+    for (int c = 0; c < 37 * 3; ++c) atom37[r * 111 + c] = 0.f;
+    // atom14 order N,CA,C,O,CB -> atom37 order N,CA,C,CB,O (all_atom.py:168-174)
+    const int map[5] = {0, 1, 2, 4, 3};
+    for (int at = 0; at < 5; ++at)
+      for (int c = 0; c < 3; ++c) atom37[r * 111 + at * 3 + c] = pos[map[at]][c];
+  }
+}
+
+// ------------------------------------------------------------------ small per-residue kernels of the trunk
+// Rigid.compose_q_update_vec with update_mask (rigid_utils.py:587-616,1039-1063); quat [n,4] / trans [n,3] in place.
+__global__ void compose_q_update_kernel(long n, float* __restrict__ quat, float* __restrict__ trans,
+                                        const float* __restrict__ upd, int ld_upd, const float* __restrict__ mask) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float m = mask ? mask[r] : 1.f;
+  float q[4] = {quat[r * 4], quat[r * 4 + 1], quat[r * 4 + 2], quat[r * 4 + 3]};
+  float dq[4], R[9], dt[3];
+  d_quat_mul_vec(q, upd + r * ld_upd, dq);
+  d_quat_to_rot(q, R);
+  d_rot_vec(R, upd + r * ld_upd + 3, dt);
+  float nq[4];
+  for (int c = 0; c < 4; ++c) nq[c] = q[c] + dq[c] * m;
+  const float nrm = sqrtf(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+  for (int c = 0; c < 4; ++c) quat[r * 4 + c] = nq[c] / nrm;
+  for (int c = 0; c < 3; ++c) trans[r * 3 + c] = trans[r * 3 + c] + dt[c] * m;
+}
+
+int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(compose_q_update_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, quat, trans, upd, ld_upd, mask);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// IpaScore.forward prologue (ipa_pytorch.py:516-524): split tensor_7, scale translations; diffuse_mask = (1-fixed)*res.
+__global__ void split_rigids_kernel(long n, const float* __restrict__ t7, float cs, const float* __restrict__ res_mask,
+                                    const float* __restrict__ fixed_mask, float* __restrict__ quat,
+                                    float* __restrict__ trans, float* __restrict__ diffuse_mask) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int c = 0; c < 4; ++c) quat[r * 4 + c] = t7[r * 7 + c];
+  for (int c = 0; c < 3; ++c) trans[r * 3 + c] = t7[r * 7 + 4 + c] * cs;
+  diffuse_mask[r] = (1.f - fixed_mask[r]) * res_mask[r];
+}
+int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,
+                    float* trans, float* dmask, hipStream_t st) {
+  hipLaunchKernelGGL(split_rigids_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, t7, cs, res_mask, fixed_mask, quat, trans,
+                     dmask);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// Epilogue of IpaScore/ScoreNetwork.forward: unscale translations (ipa:557), tensor_7 (sn:268), psi normalisation
+// (ipa:355-362) and the fixed-residue psi merge (sn:259-260).
+__global__ void finish_kernel(long n, const float* __restrict__ quat, const float* __restrict__ trans, float cs,
+                              const float* __restrict__ psi_un, int ld_psi, const float* __restrict__ gt_psi,
+                              const float* __restrict__ fixed_mask, float* __restrict__ rigids,
+                              float* __restrict__ psi) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int c = 0; c < 4; ++c) rigids[r * 7 + c] = quat[r * 4 + c];
+  for (int c = 0; c < 3; ++c) rigids[r * 7 + 4 + c] = trans[r * 3 + c] / cs;
+  const float a = psi_un[r * ld_psi], bq = psi_un[r * ld_psi + 1];
+  const float den = sqrtf(fmaxf(a * a + bq * bq, 1e-8f));
+  const float dm = 1.f - fixed_mask[r];
+  psi[r * 2] = dm * (a / den) + (1.f - dm) * gt_psi[r * 2];
+  psi[r * 2 + 1] = dm * (bq / den) + (1.f - dm) * gt_psi[r * 2 + 1];
+}
+int fd_finish(long n, const float* quat, const float* trans, float cs, const float* psi_un, int ld_psi,
+              const float* gt_psi, const float* fixed_mask, float* rigids, float* psi, hipStream_t st) {
+  hipLaunchKernelGGL(finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, quat, trans, cs, psi_un, ld_psi, gt_psi,
+                     fixed_mask, rigids, psi);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// Node / pair first-layer input features (score_network.py:152-182): pte = [aatype one-hot?, t-embed, fixed_mask];
+// node_feat = [pte, index-embed] zero-padded to ld_node; pte zero-padded to ld_pte.
+__global__ void build_feats_kernel(int B, int N, int use_aatype, int E, const int32_t* __restrict__ aatype,
+                                   const float* __restrict__ t_emb, const float* __restrict__ t_emb_eps,
+                                   const float* __restrict__ fixed_mask, const float* __restrict__ idx_emb,
+                                   float* __restrict__ node_feat, int ld_node, float* __restrict__ pte, int ld_pte) {
+  const long r = blockIdx.x;
+  const int b = (int)(r / N);
+  const float fm = fixed_mask[r];
+  const int d1 = E + 1 + (use_aatype ? 21 : 0);
+  for (int c = threadIdx.x; c < ld_node; c += blockDim.x) {
+    float v = 0.f;
+    int cc = c;
+    if (use_aatype) {
+      if (c < 21) { v = (aatype[r] == c) ? 1.f : 0.f; cc = -1; } else cc = c - 21;
+    }
+    if (cc >= 0) {
+      if (cc < E) v = (use_aatype && fm != 0.f) ? t_emb_eps[cc] : t_emb[b * E + cc];
+      else if (cc == E) v = fm;
+      else if (cc < 2 * E + 1) v = idx_emb[r * E + (cc - E - 1)];
+    }
+    node_feat[r * ld_node + c] = v;
+    if (c < ld_pte) pte[r * ld_pte + c] = c < d1 ? v : 0.f;
+  }
+}
+int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, const float* t_emb, const float* t_emb_eps,
+                   const float* fixed_mask, const float* idx_emb, float* node_feat, int ld_node, float* pte, int ld_pte,
+                   hipStream_t st) {
+  if (use_aatype && (!aatype || !t_emb_eps)) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(build_feats_kernel, dim3(B * N), dim3(128), 0, st, B, N, use_aatype, E, aatype, t_emb, t_emb_eps,
+                     fixed_mask, idx_emb, node_feat, ld_node, pte, ld_pte);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
+                 const float* res_mask, double* score, hipStream_t st) {
+  hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / 8)), dim3(FD_THREADS), 0, st, B, N, qt, ld_t, q0,
+                     ld_0, sigma, res_mask, score);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,
+                   float max_b, float cs, const float* res_mask, float* score, hipStream_t st) {
+  hipLaunchKernelGGL(trans_score_kernel, dim3(cdiv((long)B * N, 256)), dim3(256), 0, st, B, N, tt, ld_t, t0, ld_0, t, min_b,
+                     max_b, cs, res_mask, score);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fd_backbone(int n, const float* t7, const float* rot, const float* trans, int ld_trans, const float* psi,
+                const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st) {
+  hipLaunchKernelGGL(backbone_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, n, t7, rot, trans, ld_trans, psi, aatype,
+                     (const BackboneTables*)tables, atom37, atom14);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// ------------------------------------------------------------------ elementwise exports (a8)
+#define FD_EW_KERNEL(name, ...)                                                                  \
+  __global__ void name##_k(int n, const float* __restrict__ x, const float* __restrict__ y,     \
+                           float* __restrict__ o, float* __restrict__ o2) {                     \
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;                                        \
+    if (r >= n) return;                                                                         \
+    __VA_ARGS__                                                                                 \
+  }
+FD_EW_KERNEL(quat_to_rot, d_quat_to_rot(x + r * 4, o + r * 9);)
+FD_EW_KERNEL(quat_multiply, d_quat_mul(x + r * 4, y + r * 4, o + r * 4);)
+FD_EW_KERNEL(quat_multiply_by_vec, d_quat_mul_vec(x + r * 4, y + r * 3, o + r * 4);)
+FD_EW_KERNEL(invert_quat, d_invert_quat(x + r * 4, o + r * 4);)
+FD_EW_KERNEL(quat_to_rotvec, d_quat_to_rotvec(x + r * 4, o + r * 3);)
+FD_EW_KERNEL(rigid_apply, float R[9], p[3]; d_quat_to_rot(x + r * 7, R); d_rot_vec(R, y + r * 3, p);
+             for (int c = 0; c < 3; ++c) o[r * 3 + c] = p[c] + x[r * 7 + 4 + c];)
+FD_EW_KERNEL(rigid_invert_apply, float R[9], Rt[9], d[3]; d_quat_to_rot(x + r * 7, R);
+             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = R[j * 3 + i];
+             for (int c = 0; c < 3; ++c) d[c] = y[r * 3 + c] - x[r * 7 + 4 + c];
+             d_rot_vec(Rt, d, o + r * 3);)
+FD_EW_KERNEL(rigid_compose, float R1[9], R2[9]; d_quat_to_rot(x + r * 7, R1); d_quat_to_rot(y + r * 7, R2);
+             d_compose(R1, x + r * 7 + 4, R2, y + r * 7 + 4, o + r * 9, o2 + r * 3);)
+FD_EW_KERNEL(rigid_invert, float R[9], Rt[9], p[3]; d_quat_to_rot(x + r * 7, R);
+             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = R[j * 3 + i];
+             d_rot_vec(Rt, x + r * 7 + 4, p);
+             for (int c = 0; c < 9; ++c) o[r * 9 + c] = Rt[c];
+             for (int c = 0; c < 3; ++c) o2[r * 3 + c] = -p[c];)
+FD_EW_KERNEL(rot_to_quat, double m[9], q[4]; for (int c = 0; c < 9; ++c) m[c] = (double)x[r * 9 + c]; d_markley(m, q);
+             if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+             o[r * 4] = (float)q[3]; o[r * 4 + 1] = (float)q[0]; o[r * 4 + 2] = (float)q[1]; o[r * 4 + 3] = (float)q[2];)
+
+__global__ void so3_exp_k(int n, const double* __restrict__ rv, double* __restrict__ R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) d_so3_exp(rv + r * 3, R + r * 9);
+}
+__global__ void so3_log_k(int n, const double* __restrict__ R, double* __restrict__ rv) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) d_so3_log(R + r * 9, rv + r * 3);
+}
+__global__ void cqu_t7_k(int n, const float* __restrict__ t7, const float* __restrict__ upd,
+                         const float* __restrict__ mask, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float m = mask ? mask[r] : 1.f;
+  const float* q = t7 + r * 7;
+  float dq[4], R[9], dt[3], nq[4];
+  d_quat_mul_vec(q, upd + r * 6, dq);
+  d_quat_to_rot(q, R);
+  d_rot_vec(R, upd + r * 6 + 3, dt);
+  for (int c = 0; c < 4; ++c) nq[c] = q[c] + dq[c] * m;
+  const float nrm = sqrtf(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+  for (int c = 0; c < 4; ++c) out[r * 7 + c] = nq[c] / nrm;
+  for (int c = 0; c < 3; ++c) out[r * 7 + 4 + c] = q[4 + c] + dt[c] * m;
+}
+
+#define FD_EW_EXPORT(name, X, Y, O, O2)                                                        \
+  if (n <= 0) return FDIPT_OK;                                                                 \
+  if (!(X) || !(O)) return FDIPT_EINVAL;                                                       \
+  hipLaunchKernelGGL(name##_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, X, Y, O, O2); \
+  FD_CHECK_LAUNCH();                                                                           \
+  return FDIPT_OK;
+
+extern "C" {
+int fdipt_quat_to_rot(int n, const float* quat, float* rot, fdipt_stream_t s) { FD_EW_EXPORT(quat_to_rot, quat, nullptr, rot, nullptr) }
+int fdipt_rot_to_quat(int n, const float* rot, float* quat, fdipt_stream_t s) { FD_EW_EXPORT(rot_to_quat, rot, nullptr, quat, nullptr) }
+int fdipt_quat_multiply(int n, const float* q1, const float* q2, float* out, fdipt_stream_t s) { FD_EW_EXPORT(quat_multiply, q1, q2, out, nullptr) }
+int fdipt_quat_multiply_by_vec(int n, const float* q, const float* v, float* out, fdipt_stream_t s) { FD_EW_EXPORT(quat_multiply_by_vec, q, v, out, nullptr) }
+int fdipt_invert_quat(int n, const float* q, float* out, fdipt_stream_t s) { FD_EW_EXPORT(invert_quat, q, nullptr, out, nullptr) }
+int fdipt_rigid_apply(int n, const float* t7, const float* pts, float* out, fdipt_stream_t s) { FD_EW_EXPORT(rigid_apply, t7, pts, out, nullptr) }
+int fdipt_rigid_invert_apply(int n, const float* t7, const float* pts, float* out, fdipt_stream_t s) { FD_EW_EXPORT(rigid_invert_apply, t7, pts, out, nullptr) }
+int fdipt_rigid_compose(int n, const float* a, const float* b, float* out_rot, float* out_trans, fdipt_stream_t s) { FD_EW_EXPORT(rigid_compose, a, b, out_rot, out_trans) }
+int fdipt_rigid_invert(int n, const float* t7, float* out_rot, float* out_trans, fdipt_stream_t s) { FD_EW_EXPORT(rigid_invert, t7, nullptr, out_rot, out_trans) }
+int fdipt_quat_to_rotvec(int n, const float* q, float* rotvec, fdipt_stream_t s) { FD_EW_EXPORT(quat_to_rotvec, q, nullptr, rotvec, nullptr) }
+
+int fdipt_rigid_compose_q_update(int n, const float* t7, const float* upd6, const float* mask, float* out_t7,
+                                 fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!t7 || !upd6 || !out_t7) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(cqu_t7_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, t7, upd6, mask, out_t7);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_so3_exp(int n, const double* rotvec, double* rot, fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!rotvec || !rot) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(so3_exp_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, rotvec, rot);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_so3_log(int n, const double* rot, double* rotvec, fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!rot || !rotvec) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(so3_log_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, rot, rotvec);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+int fdipt_se3_reverse_step(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
+                           const float* diffuse_mask, const double* z_rot, const double* z_trans, double t, double dt,
+                           double noise_scale, int center, int diffuse_rot, int diffuse_trans, double so3_min_sigma,
+                           double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
+                           float* rigids_out, float* out_rot, fdipt_stream_t stream) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!rigids_t || !rot_score || !trans_score || !z_rot || !z_trans || !rigids_out || !(t >= 0 && t <= 1))
+    return FDIPT_EINVAL;
+  ReverseArgs a = {B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale, center,
+                   diffuse_rot, diffuse_trans, so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling,
+                   rigids_out, out_rot};
+  hipLaunchKernelGGL(reverse_step_kernel, dim3(B), dim3(FD_THREADS), 0, (hipStream_t)stream, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+int fdipt_igso3_rot_score(int B, int N, const float* quats_t, const float* quats_0, const double* sigma,
+                          const float* res_mask, double* score, fdipt_stream_t s) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!quats_t || !quats_0 || !sigma || !score) return FDIPT_EINVAL;
+  return fd_rot_score(B, N, quats_t, 4, quats_0, 4, sigma, res_mask, score, (hipStream_t)s);
+}
+int fdipt_r3_trans_score(int B, int N, const float* trans_t, const float* trans_0, const float* t, float min_b,
+                         float max_b, float coordinate_scaling, const float* res_mask, float* score, fdipt_stream_t s) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!trans_t || !trans_0 || !t || !score) return FDIPT_EINVAL;
+  return fd_trans_score(B, N, trans_t, 3, trans_0, 3, t, min_b, max_b, coordinate_scaling, res_mask, score, (hipStream_t)s);
+}
+int fdipt_backbone_atoms(int n, const float* t7, const float* rot, const float* trans, const float* psi,
+                         const int32_t* aatype, const void* tables, float* atom37, float* atom14, fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if ((!t7 && !(rot && trans)) || !psi || !tables) return FDIPT_EINVAL;
+  return fd_backbone(n, t7, rot, trans, 3, psi, aatype, tables, atom37, atom14, (hipStream_t)s);
+}
+}  // extern "C"

@@ -1,0 +1,195 @@
+// gemm.hip — generic Linear (+bias/ReLU/mask/residual), LayerNorm and the MFMA self-test.
+// Replaces the per-residue torch.nn.Linear / LayerNorm calls of the score network
+// (framedipt/model/ipa_pytorch.py:36-58,202-239,325,386-413,531-541; score_network.py:86-96).
+#include "common.hpp"
+#include "kernels.hpp"
+
+// C[M,N] = epi(A[M,K] * W[N,K]^T): block tile 64x64, 4 waves as 2x2, each wave one 32x32 accumulator.
+template <class P, class AT, class WT>
+__global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K, const AT* __restrict__ A, int lda,
+                                                            const WT* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, int ldr,
+                                                            const float* __restrict__ rowmask, int relu,
+                                                            float* __restrict__ out, int ldo) {
+  constexpr int LDT = P::BK + P::PAD;
+  __shared__ __attribute__((aligned(16))) typename P::T As[64 * LDT];
+  __shared__ __attribute__((aligned(16))) typename P::T Ws[64 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += P::BK) {
+    stage_tile<P, AT, 64>(As, A, lda, m0, M, k0, K, tid);
+    stage_tile<P, WT, 64>(Ws, W, ldw, n0, N, k0, K, tid);
+    __syncthreads();
+    wave_mma<P>(acc, As + (wr * 32 + (lane & 31)) * LDT, Ws + (wc * 32 + (lane & 31)) * LDT, lane);
+    __syncthreads();
+  }
+  const int n = n0 + wc * 32 + (lane & 31);
+  if (n >= N) return;
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wr * 32 + c_row(r, lane);
+    if (m < M) {
+      float v = acc[r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      if (rowmask) v *= rowmask[m];
+      if (residual) v += residual[(long)m * ldr + n];
+      out[(long)m * ldo + n] = v;
+    }
+  }
+}
+
+static int launch_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw,
+                         const float* bias, const float* residual, int ldr, const float* rowmask, int relu, float* out,
+                         int ldo, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !out || (K & 7) || (lda & 3) || (ldw & 7)) return FDIPT_EINVAL;
+  dim3 grid(cdiv(M, 64), cdiv(N, 64));
+  if (precision == FDIPT_PREC_F32)
+    hipLaunchKernelGGL((linear_kernel<PrecF32, float, float>), grid, dim3(FD_THREADS), 0, st, M, N, K, A, lda,
+                       (const float*)W, ldw, bias, residual, ldr, rowmask, relu, out, ldo);
+  else
+    hipLaunchKernelGGL((linear_kernel<PrecBF16, float, bf16_t>), grid, dim3(FD_THREADS), 0, st, M, N, K, A, lda,
+                       (const bf16_t*)W, ldw, bias, residual, ldr, rowmask, relu, out, ldo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// same product with the pair representation as A (float in fp32 mode, bf16 in bf16 mode): IPA pair bias linear_b(z)
+int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,
+                hipStream_t st) {
+  if (M <= 0 || (K & 7)) return FDIPT_EINVAL;
+  dim3 grid(cdiv(M, 64), cdiv(N, 64));
+  if (precision == FDIPT_PREC_F32)
+    hipLaunchKernelGGL((linear_kernel<PrecF32, float, float>), grid, dim3(FD_THREADS), 0, st, (int)M, N, K, (const float*)A,
+                       K, (const float*)W, K, bias, nullptr, 0, nullptr, 0, out, N);
+  else
+    hipLaunchKernelGGL((linear_kernel<PrecBF16, bf16_t, bf16_t>), grid, dim3(FD_THREADS), 0, st, (int)M, N, K,
+                       (const bf16_t*)A, K, (const bf16_t*)W, K, bias, nullptr, 0, nullptr, 0, out, N);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
+              const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, hipStream_t st) {
+  return launch_linear(precision, M, N, K, A, lda, W, ldw, bias, residual, ldr, rowmask, relu, out, ldo, st);
+}
+
+// LayerNorm over the last dim (eps 1e-5, biased variance = torch.nn.LayerNorm), one wave per row, D <= 1024.
+__global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ residual, int ldr,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ rowmask,
+                                                               float* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (FD_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    float t = 0.f;
+    if (c < D) {
+      t = x[(long)row * ldx + c];
+      if (residual) t += residual[(long)row * ldr + c];
+    }
+    v[i] = t;
+    s += t;
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    if (c < D) {
+      const float d = v[i] - mu;
+      q += d * d;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+  const float rm = rowmask ? rowmask[row] : 1.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    if (c < D) out[(long)row * ldo + c] = ((v[i] - mu) * rstd * gamma[c] + beta[c]) * rm;
+  }
+}
+
+int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,
+                 const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
+  if (M <= 0 || D <= 0 || D > 1024 || !x || !gamma || !beta || !out) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, residual, ldr,
+                     gamma, beta, rowmask, out, ldo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+__global__ void f32_to_bf16_kernel(long n, const float* __restrict__ in, bf16_t* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+}
+int fd_f32_to_bf16(long n, const float* in, bf16_t* out, hipStream_t st) {
+  if (n <= 0) return FDIPT_OK;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
+                     n, in, out);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+extern "C" {
+
+int fdipt_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
+                 const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, fdipt_stream_t s) {
+  return launch_linear(precision, M, N, K, A, lda, W, ldw, bias, residual, ldr, rowmask, relu, out, ldo, (hipStream_t)s);
+}
+
+int fdipt_layernorm(int M, int D, const float* x, const float* residual, const float* gamma, const float* beta,
+                    const float* rowmask, float* out, fdipt_stream_t s) {
+  return fd_layernorm(M, D, x, D, residual, D, gamma, beta, rowmask, out, D, (hipStream_t)s);
+}
+
+// MFMA fragment-map self-test: asymmetric 96x80x72 product (exercises edge guards) against fp64 host math.
+int fdipt_selftest_mfma(int precision, double* max_err_host) {
+  const int M = 96, N = 80, K = 72;
+  float *hA = new float[M * K], *hW = new float[N * K], *hO = new float[M * N];
+  for (int i = 0; i < M * K; ++i) hA[i] = (float)((i * 37 % 101) - 50) / 64.f;
+  for (int i = 0; i < N * K; ++i) hW[i] = (float)((i * 53 % 89) - 44) / 32.f;
+  float *dA, *dW, *dO;
+  bf16_t* dWb;
+  int rc = FDIPT_OK;
+  if (hipMalloc(&dA, M * K * 4) != hipSuccess || hipMalloc(&dW, N * K * 4) != hipSuccess ||
+      hipMalloc(&dO, M * N * 4) != hipSuccess || hipMalloc(&dWb, N * K * 2) != hipSuccess)
+    return FDIPT_ELAUNCH;
+  hipMemcpy(dA, hA, M * K * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dW, hW, N * K * 4, hipMemcpyHostToDevice);
+  if (precision == FDIPT_PREC_BF16) {
+    fd_f32_to_bf16(N * K, dW, dWb, 0);
+    rc = launch_linear(precision, M, N, K, dA, K, dWb, K, nullptr, nullptr, 0, nullptr, 0, dO, N, 0);
+  } else {
+    rc = launch_linear(precision, M, N, K, dA, K, dW, K, nullptr, nullptr, 0, nullptr, 0, dO, N, 0);
+  }
+  if (hipDeviceSynchronize() != hipSuccess) rc = FDIPT_ELAUNCH;
+  hipMemcpy(hO, dO, M * N * 4, hipMemcpyDeviceToHost);
+  double me = 0;
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      double s = 0;
+      for (int k = 0; k < K; ++k) s += (double)hA[m * K + k] * (double)hW[n * K + k];
+      double e = s - hO[m * N + n];
+      if (e < 0) e = -e;
+      if (e > me) me = e;
+    }
+  if (max_err_host) *max_err_host = me;
+  hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dWb);
+  delete[] hA; delete[] hW; delete[] hO;
+  return rc;
+}
+
+const char* fdipt_version(void) { return "fdipt-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// kernels.hpp — argument blocks and host launchers shared by the translation units of libfdipt_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;
+
+struct EdgeTransArgs {
+  int B, N;
+  const void* z_in;      // [B,N,N,CZ] ZT
+  void* z_out;           // [B,N,N,CZ] ZT (may alias z_in)
+  const float* e;        // [B,N,CB] f32 initial_embed(node)
+  const void *w1, *w2, *wf;  // [H,H],[H,H],[CZ,H] operand precision, row-major (out,in)
+  const float *b1, *b2, *bf, *gamma, *beta;
+  const float* res_mask;  // [B,N]
+  float* trace;           // optional [B,N,N,CZ] f32
+};
+
+struct EdgeEmbedArgs {
+  int B, N, n_rel, rel_off, num_bins;
+  const float* pi;       // [B,N,CZ] f32: W1[:, :d1] pte_i + b1
+  const float* pj;       // [B,N,CZ] f32: W1[:, d1:2d1] pte_j
+  const float* rtab;     // [B,n_rel,CZ] f32: W1[:, 2d1:2d1+32] index_embedding(rel)
+  const float* dtab;     // [num_bins+1,CZ] f32: W1 distogram columns (+ a zero row = "no bin")
+  const float* edges;    // [num_bins] f32 lower bin edges
+  const int32_t* seq_idx;  // [B,N]
+  const float* sc_ca;    // [B,N,3]
+  const void *w2, *w3;   // [CZ,CZ] operand precision
+  const float *b2, *b3, *gamma, *beta;
+  const float* res_mask;
+  void* z_out;
+  float* trace;
+};
+
+struct AttnArgs {
+  int B, N, H;
+  const float *q, *k, *v;  // row r=(b*N+i): q + r*q_ld + h*q_hs etc.
+  long q_ld, k_ld, v_ld;
+  int q_hs, k_hs, v_hs;
+  int C, Dv;        // qk feature dim, value dim
+  float scale;      // multiplies QK^T
+  const float* bias;      // [B,N,N,H] f32 (already scaled) or NULL
+  const float* res_mask;  // [B,N]
+  // IPA only
+  const float *qp, *kp, *vp;  // [B,N,H,Pq,3], [B,N,H,Pq,3], [B,N,H,Pv,3] global-frame points (scaled units)
+  int Pq, Pv;
+  const float* gamma;  // [H] softplus(head_weights) * sqrt(1/(3*(Pq*9/2)))
+  const float *rot, *trans;  // [B,N,9], [B,N,3] current frames (scaled units)
+  float* probs;  // [B,H,N,N] f32 attention weights (consumed by opair_kernel)
+  // output
+  float* out;  // row r: out + r*out_ld ; o at h*Dv ; IPA point features at pt_off (see below)
+  long out_ld;
+  int pt_off;  // = H*C: x plane; y at +H*Pv; z at +2*H*Pv; norm at +3*H*Pv
+  int lds_s;   // S row stride in floats
+};
+
+struct OPairArgs {
+  int B, N, H, CZ, CD;   // CD = CZ/4
+  const void* z;         // [B,N,N,CZ] ZT
+  const float* probs;    // [B,H,N,N]
+  const float* wdz;      // [CD,CZ] f32
+  const float* bdz;      // [CD]
+  float* out;            // row (b*N+i): out + r*out_ld + off + h*CD + d
+  long out_ld;
+  int off;
+};
+
+struct PointsArgs {
+  int B, N, H, Pq, Pv;
+  const float* proj;  // [B*N, ld]: q_pts planes at q_off (3 x H*Pq), kv_pts planes at kv_off (3 x H*(Pq+Pv))
+  long ld;
+  int q_off, kv_off;
+  const float* quat;   // [B,N,4] current quaternion
+  const float* trans;  // [B,N,3] current translation (scaled)
+  float *qp, *kp, *vp, *rot;
+};
+
+int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
+              const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, hipStream_t st);
+int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,
+                hipStream_t st);
+int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,
+                 const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st);
+int fd_f32_to_bf16(long n, const float* in, bf16_t* out, hipStream_t st);
+int fd_edge_transition(int precision, int cz, int cb, const EdgeTransArgs& a, hipStream_t st);
+int fd_edge_embed(int precision, int cz, const EdgeEmbedArgs& a, hipStream_t st);
+int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st);
+int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
+int fd_points(const PointsArgs& a, hipStream_t st);
+int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask, hipStream_t st);
+int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,
+                    float* trans, float* dmask, hipStream_t st);
+int fd_finish(long n, const float* quat, const float* trans, float cs, const float* psi_un, int ld_psi,
+              const float* gt_psi, const float* fixed_mask, float* rigids, float* psi, hipStream_t st);
+int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, const float* t_emb, const float* t_emb_eps,
+                   const float* fixed_mask, const float* idx_emb, float* node_feat, int ld_node, float* pte, int ld_pte,
+                   hipStream_t st);
+int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
+                 const float* res_mask, double* score, hipStream_t st);
+int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,
+                   float max_b, float cs, const float* res_mask, float* score, hipStream_t st);
+int fd_backbone(int n, const float* t7, const float* rot, const float* trans, int ld_trans, const float* psi,
+                const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st);

@@ -1,0 +1,470 @@
+// model.hip — parameter inventory, derived-weight preparation and the score-network forward schedule.
+//
+// fdipt_score_forward is the device-side replacement of ScoreNetwork.forward
+// (framedipt/model/score_network.py:218-275) = Embedder.forward (:129-197) + IpaScore.forward
+// (framedipt/model/ipa_pytorch.py:509-572).  It only enqueues kernels on the caller's stream: no allocation,
+// no synchronisation, no host round-trip (the reference syncs inside the forward, so3_diffuser.py:398).
+#include <math.h>
+
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+// ------------------------------------------------------------------ inventory (== framedipt_amd/weights.py)
+struct LinW { long w, b; int out, in; };
+struct LNW { long g, b; int d; };
+#define FD_MAX_BLOCKS 8
+#define FD_MAX_TL 4
+struct TfLayer { LinW inp, outp, l1, l2; LNW n1, n2; };
+struct BlockW {
+  long head_w;
+  LinW q, kv, qp, kvp, lb, dz, out, rbf;
+  LNW ipa_ln;
+  LinW skip;
+  TfLayer tf[FD_MAX_TL];
+  LinW post, t1, t2, t3;
+  LNW tln;
+  LinW bb;
+  LinW et_init, et1, et2, etf;
+  LNW et_ln;
+};
+struct Inventory {
+  LinW ne0, ne2, ne4; LNW neln;
+  LinW ee0, ee2, ee4; LNW eeln;
+  BlockW blk[FD_MAX_BLOCKS];
+  LinW tor1, tor2, tor3, torf;
+  std::vector<long> offsets;  // per tensor, in state_dict order; back() = total
+  int d1, node_in, edge_in, d_t, cb, hid, feat_dim, proj_out;
+};
+
+static bool dims_ok(const FdiptDims* d) {
+  return d && d->num_blocks >= 1 && d->num_blocks <= FD_MAX_BLOCKS && d->tfmr_layers >= 1 && d->tfmr_layers <= FD_MAX_TL &&
+         d->c_s > 0 && (d->c_s % 8) == 0 && d->c_z > 0 && (d->c_z % 8) == 0 && d->no_heads > 0 && d->no_heads <= 16 &&
+         d->index_embed == 32 && d->num_bins > 0 && d->num_bins < 64 && (d->c_skip % 8) == 0 &&
+         (d->precision == FDIPT_PREC_F32 || d->precision == FDIPT_PREC_BF16);
+}
+
+static void build_inventory(const FdiptDims* d, Inventory& iv) {
+  long off = 0;
+  iv.offsets.clear();
+  auto push = [&](long n) { iv.offsets.push_back(off); long o = off; off += n; return o; };
+  auto lin = [&](int out, int in) { LinW l; l.out = out; l.in = in; l.w = push((long)out * in); l.b = push(out); return l; };
+  auto ln = [&](int dd) { LNW l; l.d = dd; l.g = push(dd); l.b = push(dd); return l; };
+  const int E = d->index_embed;
+  iv.d1 = E + 1 + (d->use_aatype ? 21 : 0);
+  iv.node_in = iv.d1 + E;
+  iv.edge_in = 2 * iv.d1 + E + d->num_bins;
+  const int cs = d->c_s, cz = d->c_z, H = d->no_heads, C = d->c_hidden, Pq = d->no_qk_points, Pv = d->no_v_points;
+  iv.d_t = cs + d->c_skip;
+  iv.cb = cs / 2;
+  iv.hid = 2 * iv.cb + cz;
+  iv.feat_dim = H * (cz / 4 + C + Pv * 4);
+  iv.proj_out = 3 * H * C + 3 * H * Pq + 3 * H * (Pq + Pv);
+  iv.ne0 = lin(cs, iv.node_in); iv.ne2 = lin(cs, cs); iv.ne4 = lin(cs, cs); iv.neln = ln(cs);
+  iv.ee0 = lin(cz, iv.edge_in); iv.ee2 = lin(cz, cz); iv.ee4 = lin(cz, cz); iv.eeln = ln(cz);
+  for (int b = 0; b < d->num_blocks; ++b) {
+    BlockW& k = iv.blk[b];
+    k.head_w = push(H);
+    k.q = lin(H * C, cs); k.kv = lin(2 * H * C, cs); k.qp = lin(H * Pq * 3, cs); k.kvp = lin(H * (Pq + Pv) * 3, cs);
+    k.lb = lin(H, cz); k.dz = lin(cz / 4, cz); k.out = lin(cs, iv.feat_dim); k.rbf = lin(1, 20);
+    k.ipa_ln = ln(cs);
+    k.skip = lin(d->c_skip, cs);
+    for (int l = 0; l < d->tfmr_layers; ++l) {
+      TfLayer& t = k.tf[l];
+      t.inp = lin(3 * iv.d_t, iv.d_t); t.outp = lin(iv.d_t, iv.d_t); t.l1 = lin(iv.d_t, iv.d_t); t.l2 = lin(iv.d_t, iv.d_t);
+      t.n1 = ln(iv.d_t); t.n2 = ln(iv.d_t);
+    }
+    k.post = lin(cs, iv.d_t);
+    k.t1 = lin(cs, cs); k.t2 = lin(cs, cs); k.t3 = lin(cs, cs); k.tln = ln(cs);
+    k.bb = lin(6, cs);
+    if (b < d->num_blocks - 1) {
+      k.et_init = lin(iv.cb, cs); k.et1 = lin(iv.hid, iv.hid); k.et2 = lin(iv.hid, iv.hid); k.etf = lin(cz, iv.hid);
+      k.et_ln = ln(cz);
+    }
+  }
+  iv.tor1 = lin(cs, cs); iv.tor2 = lin(cs, cs); iv.tor3 = lin(cs, cs); iv.torf = lin(2, cs);
+  iv.offsets.push_back(off);
+}
+
+// ------------------------------------------------------------------ derived blob layout
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int rup8(int x) { return (x + 7) & ~7; }
+
+struct DBlock { size_t wproj, bproj, gamma, wb, bb; };
+struct DLayout {
+  size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
+  size_t ne0_pad;     // [cs, kn_pad] operand precision
+  size_t w1i, w1j, w1r, dtab, edges, b1;  // fp32 pieces of the concat-free first edge-embedder layer
+  DBlock blk[FD_MAX_BLOCKS];
+  size_t total;
+  int kn_pad, d1_pad, esz;
+};
+
+static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
+  size_t o = 0;
+  L.esz = d->precision == FDIPT_PREC_BF16 ? 2 : 4;
+  L.kn_pad = rup8(iv.node_in);
+  L.d1_pad = rup8(iv.d1);
+  L.bf16_base = o;
+  if (d->precision == FDIPT_PREC_BF16) o = al256(o + (size_t)iv.offsets.back() * 2);
+  L.ne0_pad = o; o = al256(o + (size_t)d->c_s * L.kn_pad * L.esz);
+  L.w1i = o; o = al256(o + (size_t)d->c_z * L.d1_pad * 4);
+  L.w1j = o; o = al256(o + (size_t)d->c_z * L.d1_pad * 4);
+  L.w1r = o; o = al256(o + (size_t)d->c_z * d->index_embed * 4);
+  L.dtab = o; o = al256(o + (size_t)(d->num_bins + 1) * d->c_z * 4);
+  L.edges = o; o = al256(o + (size_t)d->num_bins * 4);
+  L.b1 = o; o = al256(o + (size_t)d->c_z * 4);
+  for (int b = 0; b < d->num_blocks; ++b) {
+    L.blk[b].wproj = o; o = al256(o + (size_t)iv.proj_out * d->c_s * L.esz);
+    L.blk[b].bproj = o; o = al256(o + (size_t)iv.proj_out * 4);
+    L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
+    L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
+    L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
+  }
+  L.total = o;
+}
+
+// ------------------------------------------------------------------ prepare kernels
+// dst[r, c] (ld_dst, operand precision) = scale * src[r, col0 + c] for c < ncols else 0
+template <class T>
+__global__ void copy_cols_kernel(int rows, int ncols, int ld_dst, const float* __restrict__ src, int ld_src, int col0,
+                                 float scale, T* __restrict__ dst) {
+  const long n = (long)rows * ld_dst;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    const float v = c < ncols ? scale * src[(long)r * ld_src + col0 + c] : 0.f;
+    if constexpr (sizeof(T) == 4) dst[i] = v; else dst[i] = f2bf(v);
+  }
+}
+static int copy_cols(int esz, int rows, int ncols, int ld_dst, const float* src, int ld_src, int col0, float scale,
+                     void* dst, hipStream_t st) {
+  const long n = (long)rows * ld_dst;
+  const unsigned g = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  if (esz == 4)
+    hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(g), dim3(256), 0, st, rows, ncols, ld_dst, src, ld_src, col0, scale,
+                       (float*)dst);
+  else
+    hipLaunchKernelGGL(copy_cols_kernel<bf16_t>, dim3(g), dim3(256), 0, st, rows, ncols, ld_dst, src, ld_src, col0, scale,
+                       (bf16_t*)dst);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+// dtab[k][c] = W1[c][col0 + k] (k < nb), dtab[nb][c] = 0 ; edges[k] = linspace(min,max,nb)[k] ; gamma
+__global__ void misc_prepare_kernel(int cz, int nb, int ld_w, int col0, const float* __restrict__ w1, float min_bin,
+                                    float max_bin, float* __restrict__ dtab, float* __restrict__ edges) {
+  const int n = (nb + 1) * cz;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int k = i / cz, c = i % cz;
+    dtab[i] = k < nb ? w1[(long)c * ld_w + col0 + k] : 0.f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < nb) {
+    const double step = ((double)max_bin - (double)min_bin) / (double)(nb - 1);
+    edges[threadIdx.x] = threadIdx.x == nb - 1 ? max_bin : (float)((double)min_bin + step * threadIdx.x);
+  }
+}
+__global__ void gamma_kernel(int H, int Pq, const float* __restrict__ head_w, float* __restrict__ gamma) {
+  const int h = threadIdx.x;
+  if (h < H) {
+    // softplus(w) * sqrt(1/(3*(Pq*9/2)))  (ipa_pytorch.py:265-271)
+    const float sp = log1pf(expf(head_w[h]));
+    gamma[h] = sp * sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
+  }
+}
+
+extern "C" {
+
+int fdipt_param_count(const FdiptDims* dims) {
+  if (!dims_ok(dims)) return FDIPT_EINVAL;
+  Inventory iv;
+  build_inventory(dims, iv);
+  return (int)iv.offsets.size() - 1;
+}
+
+int64_t fdipt_param_offset(const FdiptDims* dims, int index) {
+  if (!dims_ok(dims)) return FDIPT_EINVAL;
+  Inventory iv;
+  build_inventory(dims, iv);
+  if (index < 0 || index >= (int)iv.offsets.size()) return FDIPT_EINVAL;
+  return iv.offsets[index];
+}
+
+size_t fdipt_derived_bytes(const FdiptDims* dims) {
+  if (!dims_ok(dims)) return 0;
+  Inventory iv;
+  DLayout L;
+  build_inventory(dims, iv);
+  build_layout(dims, iv, L);
+  return L.total;
+}
+
+int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt_stream_t stream) {
+  if (!dims_ok(d) || !P || !derived) return FDIPT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  Inventory iv;
+  DLayout L;
+  build_inventory(d, iv);
+  build_layout(d, iv, L);
+  char* D = (char*)derived;
+  int rc;
+  if (d->precision == FDIPT_PREC_BF16)
+    if ((rc = fd_f32_to_bf16(iv.offsets.back(), P, (bf16_t*)(D + L.bf16_base), st))) return rc;
+  const int cs = d->c_s, cz = d->c_z, E = d->index_embed, H = d->no_heads, C = d->c_hidden;
+  if ((rc = copy_cols(L.esz, cs, iv.node_in, L.kn_pad, P + iv.ne0.w, iv.node_in, 0, 1.f, D + L.ne0_pad, st))) return rc;
+  if ((rc = copy_cols(4, cz, iv.d1, L.d1_pad, P + iv.ee0.w, iv.edge_in, 0, 1.f, D + L.w1i, st))) return rc;
+  if ((rc = copy_cols(4, cz, iv.d1, L.d1_pad, P + iv.ee0.w, iv.edge_in, iv.d1, 1.f, D + L.w1j, st))) return rc;
+  if ((rc = copy_cols(4, cz, E, E, P + iv.ee0.w, iv.edge_in, 2 * iv.d1, 1.f, D + L.w1r, st))) return rc;
+  hipLaunchKernelGGL(misc_prepare_kernel, dim3(16), dim3(256), 0, st, cz, d->num_bins, iv.edge_in, 2 * iv.d1 + E,
+                     P + iv.ee0.w, d->min_bin, d->max_bin, (float*)(D + L.dtab), (float*)(D + L.edges));
+  FD_CHECK_LAUNCH();
+  if ((rc = copy_cols(4, 1, cz, cz, P + iv.ee0.b, cz, 0, 1.f, D + L.b1, st))) return rc;
+  const float s3 = sqrtf(1.0f / 3.0f);
+  for (int b = 0; b < d->num_blocks; ++b) {
+    const BlockW& k = iv.blk[b];
+    const DBlock& db = L.blk[b];
+    // fused projection [q | kv | q_pts | kv_pts] rows (ipa_pytorch.py:202-239)
+    const LinW* parts[4] = {&k.q, &k.kv, &k.qp, &k.kvp};
+    long row = 0;
+    for (int p = 0; p < 4; ++p) {
+      if ((rc = copy_cols(L.esz, parts[p]->out, cs, cs, P + parts[p]->w, cs, 0, 1.f, D + db.wproj + row * cs * L.esz, st)))
+        return rc;
+      if ((rc = copy_cols(4, 1, parts[p]->out, parts[p]->out, P + parts[p]->b, parts[p]->out, 0, 1.f,
+                          D + db.bproj + row * 4, st)))
+        return rc;
+      row += parts[p]->out;
+    }
+    hipLaunchKernelGGL(gamma_kernel, dim3(1), dim3(64), 0, st, H, d->no_qk_points, P + k.head_w, (float*)(D + db.gamma));
+    FD_CHECK_LAUNCH();
+    // pair bias pre-scaled by sqrt(1/3) (ipa_pytorch.py:256-257)
+    if ((rc = copy_cols(L.esz, H, cz, cz, P + k.lb.w, cz, 0, s3, D + db.wb, st))) return rc;
+    if ((rc = copy_cols(4, 1, H, H, P + k.lb.b, H, 0, s3, D + db.bb, st))) return rc;
+  }
+  (void)C;
+  return FDIPT_OK;
+}
+
+size_t fdipt_setup_bytes(const FdiptDims* dims, int B, int N, int n_rel) {
+  if (!dims_ok(dims) || B <= 0 || N <= 0 || n_rel <= 0) return 0;
+  return al256((size_t)B * n_rel * dims->c_z * 4);
+}
+
+int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, int B, int N, int n_rel,
+                       const float* rel_emb, void* setup, fdipt_stream_t stream) {
+  if (!dims_ok(d) || !P || !derived || !rel_emb || !setup || B <= 0 || N <= 0 || n_rel <= 0) return FDIPT_EINVAL;
+  Inventory iv;
+  DLayout L;
+  build_inventory(d, iv);
+  build_layout(d, iv, L);
+  // R[b, r, :] = W1[:, 2*d1 : 2*d1+E] index_embedding(r - rel_off)   (fp32; constant along the trajectory)
+  return fd_linear(FDIPT_PREC_F32, B * n_rel, d->c_z, d->index_embed, rel_emb, d->index_embed,
+                   (const char*)derived + L.w1r, d->index_embed, nullptr, nullptr, 0, nullptr, 0, (float*)setup, d->c_z,
+                   (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ workspace
+struct WS {
+  size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, total;
+};
+static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
+  size_t o = 0;
+  const size_t R = (size_t)B * N, NN = R * N;
+  auto take = [&](size_t bytes) { size_t r = o; o = al256(o + bytes); return r; };
+  const int H = d->no_heads;
+  w.node_feat = take(R * L.kn_pad * 4); w.pte = take(R * L.d1_pad * 4);
+  w.pi = take(R * d->c_z * 4); w.pj = take(R * d->c_z * 4);
+  w.h_a = take(R * d->c_s * 4); w.h_b = take(R * d->c_s * 4); w.node0 = take(R * d->c_s * 4); w.node = take(R * d->c_s * 4);
+  w.z = take(NN * d->c_z * L.esz);
+  w.quat = take(R * 4 * 4); w.trans = take(R * 3 * 4); w.dmask = take(R * 4); w.rot = take(R * 9 * 4);
+  w.proj = take(R * iv.proj_out * 4);
+  w.qp = take(R * H * d->no_qk_points * 3 * 4); w.kp = take(R * H * d->no_qk_points * 3 * 4);
+  w.vp = take(R * H * d->no_v_points * 3 * 4);
+  w.bias = take(NN * H * 4); w.probs = take(NN * H * 4);
+  w.feats = take(R * iv.feat_dim * 4);
+  w.ipa_out = take(R * d->c_s * 4);
+  w.tf_in = take(R * iv.d_t * 4); w.qkv = take(R * 3 * iv.d_t * 4); w.att = take(R * iv.d_t * 4);
+  w.x_a = take(R * iv.d_t * 4); w.x_b = take(R * iv.d_t * 4); w.ff = take(R * iv.d_t * 4);
+  w.e = take(R * iv.cb * 4); w.upd = take(R * 8 * 4); w.psi_un = take(R * 8 * 4);
+  w.total = o;
+}
+
+size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N) {
+  if (!dims_ok(dims) || B <= 0 || N <= 0) return 0;
+  Inventory iv;
+  DLayout L;
+  WS w;
+  build_inventory(dims, iv);
+  build_layout(dims, iv, L);
+  build_ws(dims, iv, L, B, N, w);
+  return w.total;
+}
+
+#define RC(x)                   \
+  do {                          \
+    int rc__ = (x);             \
+    if (rc__) return rc__;      \
+  } while (0)
+
+int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived, const void* setup,
+                        const FdiptForwardArgs* a, void* workspace, size_t workspace_bytes, fdipt_stream_t stream) {
+  if (!dims_ok(d) || !P || !derived || !setup || !a || !workspace) return FDIPT_EINVAL;
+  if (a->B <= 0 || a->N <= 0 || !a->rigids_t || !a->res_mask || !a->fixed_mask || !a->sc_ca_t || !a->seq_idx ||
+      !a->idx_emb || !a->gt_psi || !a->t || !a->t_emb || !a->so3_sigma || !a->psi || !a->rot_score || !a->trans_score ||
+      !a->rigids)
+    return FDIPT_EINVAL;
+  if (d->use_aatype && (!a->aatype || !a->t_emb_eps)) return FDIPT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  Inventory iv;
+  DLayout L;
+  WS w;
+  build_inventory(d, iv);
+  build_layout(d, iv, L);
+  const int B = a->B, N = a->N, R = B * N;
+  build_ws(d, iv, L, B, N, w);
+  if (workspace_bytes < w.total) return FDIPT_ESIZE;
+  if ((long)B * N * N > 2000000000L / 1) return FDIPT_ESIZE;
+  char* W = (char*)workspace;
+  const char* D = (const char*)derived;
+  const int prec = d->precision, cs = d->c_s, cz = d->c_z, H = d->no_heads, C = d->c_hidden, Pq = d->no_qk_points,
+            Pv = d->no_v_points, E = d->index_embed, dt = iv.d_t;
+  const bool bf = prec == FDIPT_PREC_BF16;
+  const bf16_t* PB = (const bf16_t*)(D + L.bf16_base);
+  // operand-precision view of a weight matrix of the fp32 blob
+  auto WM = [&](const LinW& l) -> const void* { return bf ? (const void*)(PB + l.w) : (const void*)(P + l.w); };
+  auto F = [&](size_t off) { return (float*)(W + off); };
+  auto lin = [&](int M, const LinW& l, const float* A, int lda, const float* res, int ldr, const float* rm, int relu,
+                 float* out, int ldo) {
+    return fd_linear(prec, M, l.out, l.in, A, lda, WM(l), l.in, P + l.b, res, ldr, rm, relu, out, ldo, st);
+  };
+  auto lin32 = [&](int M, const LinW& l, const float* A, int lda, float* out, int ldo) {
+    return fd_linear(FDIPT_PREC_F32, M, l.out, l.in, A, lda, P + l.w, l.in, P + l.b, nullptr, 0, nullptr, 0, out, ldo, st);
+  };
+  const float* res_mask = a->res_mask;
+
+  // ---- Embedder (score_network.py:129-197)
+  RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
+                    L.kn_pad, F(w.pte), L.d1_pad, st));
+  RC(fd_linear(prec, R, cs, L.kn_pad, F(w.node_feat), L.kn_pad, D + L.ne0_pad, L.kn_pad, P + iv.ne0.b, nullptr, 0, nullptr, 1,
+               F(w.h_a), cs, st));
+  RC(lin(R, iv.ne2, F(w.h_a), cs, nullptr, 0, nullptr, 1, F(w.h_b), cs));
+  RC(lin(R, iv.ne4, F(w.h_b), cs, nullptr, 0, nullptr, 0, F(w.h_a), cs));
+  RC(fd_layernorm(R, cs, F(w.h_a), cs, nullptr, 0, P + iv.neln.g, P + iv.neln.b, res_mask, F(w.node0), cs, st));
+  RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1i, L.d1_pad, (const float*)(D + L.b1), nullptr, 0,
+               nullptr, 0, F(w.pi), cz, st));
+  RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1j, L.d1_pad, nullptr, nullptr, 0, nullptr, 0,
+               F(w.pj), cz, st));
+  {
+    EdgeEmbedArgs ea;
+    ea.B = B; ea.N = N; ea.n_rel = a->n_rel; ea.rel_off = a->rel_off; ea.num_bins = d->num_bins;
+    ea.pi = F(w.pi); ea.pj = F(w.pj); ea.rtab = (const float*)setup; ea.dtab = (const float*)(D + L.dtab);
+    ea.edges = (const float*)(D + L.edges); ea.seq_idx = a->seq_idx; ea.sc_ca = a->sc_ca_t;
+    ea.w2 = WM(iv.ee2); ea.w3 = WM(iv.ee4); ea.b2 = P + iv.ee2.b; ea.b3 = P + iv.ee4.b;
+    ea.gamma = P + iv.eeln.g; ea.beta = P + iv.eeln.b; ea.res_mask = res_mask; ea.z_out = W + w.z;
+    ea.trace = a->trace_edge;
+    RC(fd_edge_embed(prec, cz, ea, st));
+  }
+  if (a->trace_node)
+    if (hipMemcpyAsync(a->trace_node, F(w.node0), (size_t)R * cs * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return FDIPT_ELAUNCH;
+
+  // ---- IpaScore trunk (ipa_pytorch.py:509-551)
+  RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask, F(w.quat), F(w.trans), F(w.dmask), st));
+  const float* node_cur = F(w.node0);
+  const size_t NN = (size_t)R * N;
+  for (int b = 0; b < d->num_blocks; ++b) {
+    const BlockW& k = iv.blk[b];
+    const DBlock& db = L.blk[b];
+    // fused q | kv | q_pts | kv_pts projection
+    RC(fd_linear(prec, R, iv.proj_out, cs, node_cur, cs, D + db.wproj, cs, (const float*)(D + db.bproj), nullptr, 0, nullptr,
+                 0, F(w.proj), iv.proj_out, st));
+    {
+      PointsArgs pa;
+      pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.proj = F(w.proj); pa.ld = iv.proj_out;
+      pa.q_off = 3 * H * C; pa.kv_off = 3 * H * C + 3 * H * Pq; pa.quat = F(w.quat); pa.trans = F(w.trans);
+      pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
+      RC(fd_points(pa, st));
+    }
+    RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));
+    {
+      AttnArgs aa;
+      aa.B = B; aa.N = N; aa.H = H;
+      aa.q = F(w.proj); aa.q_ld = iv.proj_out; aa.q_hs = C;
+      aa.k = F(w.proj) + H * C; aa.k_ld = iv.proj_out; aa.k_hs = 2 * C;
+      aa.v = F(w.proj) + H * C + C; aa.v_ld = iv.proj_out; aa.v_hs = 2 * C;
+      aa.C = C; aa.Dv = C; aa.scale = sqrtf(1.0f / (3.0f * (float)C));
+      aa.bias = F(w.bias); aa.res_mask = res_mask; aa.qp = F(w.qp); aa.kp = F(w.kp); aa.vp = F(w.vp); aa.Pq = Pq; aa.Pv = Pv;
+      aa.gamma = (const float*)(D + db.gamma); aa.rot = F(w.rot); aa.trans = F(w.trans); aa.probs = F(w.probs);
+      aa.out = F(w.feats); aa.out_ld = iv.feat_dim; aa.pt_off = H * C; aa.lds_s = 0;
+      RC(fd_attention(prec, 1, aa, st));
+      OPairArgs oa;
+      oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs);
+      oa.wdz = P + k.dz.w; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
+      RC(fd_opair(prec, oa, st));
+    }
+    RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
+    // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
+    RC(fd_layernorm(R, cs, node_cur, cs, F(w.ipa_out), cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr, F(w.tf_in), dt, st));
+    RC(lin(R, k.skip, F(w.node0), cs, nullptr, 0, nullptr, 0, F(w.tf_in) + cs, dt));
+    // nn.TransformerEncoder, post-norm (ipa:433-443,536-538)
+    const float* x = F(w.tf_in);
+    for (int l = 0; l < d->tfmr_layers; ++l) {
+      const TfLayer& t = k.tf[l];
+      RC(lin(R, t.inp, x, dt, nullptr, 0, nullptr, 0, F(w.qkv), 3 * dt));
+      AttnArgs ta;
+      const int hd = dt / d->tfmr_heads;
+      ta.B = B; ta.N = N; ta.H = d->tfmr_heads;
+      ta.q = F(w.qkv); ta.k = F(w.qkv) + dt; ta.v = F(w.qkv) + 2 * dt;
+      ta.q_ld = ta.k_ld = ta.v_ld = 3 * dt; ta.q_hs = ta.k_hs = ta.v_hs = hd;
+      ta.C = hd; ta.Dv = hd; ta.scale = 1.0f / sqrtf((float)hd); ta.bias = nullptr; ta.res_mask = res_mask;
+      ta.qp = ta.kp = ta.vp = nullptr; ta.Pq = ta.Pv = 0; ta.gamma = nullptr; ta.rot = ta.trans = nullptr; ta.probs = nullptr;
+      ta.out = F(w.att); ta.out_ld = dt; ta.pt_off = 0; ta.lds_s = 0;
+      RC(fd_attention(prec, 0, ta, st));
+      RC(lin(R, t.outp, F(w.att), dt, nullptr, 0, nullptr, 0, F(w.ff), dt));
+      RC(fd_layernorm(R, dt, x, dt, F(w.ff), dt, P + t.n1.g, P + t.n1.b, nullptr, F(w.x_a), dt, st));
+      RC(lin(R, t.l1, F(w.x_a), dt, nullptr, 0, nullptr, 1, F(w.ff), dt));
+      RC(lin(R, t.l2, F(w.ff), dt, nullptr, 0, nullptr, 0, F(w.att), dt));
+      RC(fd_layernorm(R, dt, F(w.x_a), dt, F(w.att), dt, P + t.n2.g, P + t.n2.b, nullptr, F(w.x_b), dt, st));
+      x = F(w.x_b);  // next layer: norm1 reads x_b -> x_a, norm2 reads x_a/att -> x_b (no aliasing)
+    }
+    // node = node + post_tfmr(x); StructureModuleTransition; mask   (ipa:539-541, 36-58)
+    RC(lin(R, k.post, x, dt, F(w.tf_in), dt, nullptr, 0, F(w.h_a), cs));
+    RC(lin(R, k.t1, F(w.h_a), cs, nullptr, 0, nullptr, 1, F(w.h_b), cs));
+    RC(lin(R, k.t2, F(w.h_b), cs, nullptr, 0, nullptr, 1, F(w.ipa_out), cs));
+    RC(lin(R, k.t3, F(w.ipa_out), cs, F(w.h_a), cs, nullptr, 0, F(w.h_b), cs));
+    RC(fd_layernorm(R, cs, F(w.h_b), cs, nullptr, 0, P + k.tln.g, P + k.tln.b, res_mask, F(w.node), cs, st));
+    node_cur = F(w.node);
+    // BackboneUpdate + compose_q_update_vec (ipa:542-547).  bb_update(node*diffuse_mask) differs from bb_update(node)
+    // only on rows whose update is masked out below, so the input mask is not materialised.
+    RC(lin32(R, k.bb, node_cur, cs, F(w.upd), 8));
+    RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
+    if (b < d->num_blocks - 1) {
+      RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
+      EdgeTransArgs ta;
+      ta.B = B; ta.N = N; ta.z_in = W + w.z; ta.z_out = W + w.z; ta.e = F(w.e);
+      ta.w1 = WM(k.et1); ta.w2 = WM(k.et2); ta.wf = WM(k.etf); ta.b1 = P + k.et1.b; ta.b2 = P + k.et2.b; ta.bf = P + k.etf.b;
+      ta.gamma = P + k.et_ln.g; ta.beta = P + k.et_ln.b; ta.res_mask = res_mask;
+      ta.trace = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
+      RC(fd_edge_transition(prec, cz, iv.cb, ta, st));
+    }
+    if (a->trace_node)
+      if (hipMemcpyAsync(a->trace_node + (size_t)(b + 1) * R * cs, node_cur, (size_t)R * cs * 4, hipMemcpyDeviceToDevice,
+                         st) != hipSuccess)
+        return FDIPT_ELAUNCH;
+  }
+  // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
+  RC(lin(R, iv.tor1, node_cur, cs, nullptr, 0, nullptr, 1, F(w.h_a), cs));
+  RC(lin(R, iv.tor2, F(w.h_a), cs, node_cur, cs, nullptr, 0, F(w.h_b), cs));
+  RC(lin32(R, iv.torf, F(w.h_b), cs, F(w.psi_un), 8));
+  RC(fd_finish(R, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask, a->rigids, a->psi,
+               st));
+  RC(fd_rot_score(B, N, a->rigids_t, 7, F(w.quat), 4, a->so3_sigma, res_mask, a->rot_score, st));
+  RC(fd_trans_score(B, N, a->rigids_t + 4, 7, a->rigids + 4, 7, a->t, d->r3_min_b, d->r3_max_b, d->coordinate_scaling,
+                    res_mask, a->trans_score, st));
+  if (a->atom37 || a->atom14) {
+    if (!a->bb_tables) return FDIPT_EINVAL;
+    RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));
+  }
+  return FDIPT_OK;
+}
+
+}  // extern "C"

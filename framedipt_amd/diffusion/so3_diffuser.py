@@ -1,0 +1,101 @@
+"""Host side of the SO(3) diffuser: schedules, IGSO(3) table rows, x_T sampling.
+
+Mirrors ``framedipt/diffusion/so3_diffuser.py`` (SO3Diffuser :194-602) for the members the sampler path reads.
+The reference builds 1000x1000 pdf/cdf/score-norm tables at start-up (:235-283, 46 s cold); here rows are
+evaluated on demand with the same formulas (only row ``t_to_idx(1.0)`` is needed to sample x_T, plus one row per
+``score_scaling(t)`` call).  The per-step rotation score itself is a HIP kernel (``fdipt_igso3_rot_score``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def igso3_expansion(omega, eps, truncation_level: int = 1000):
+    """so3_diffuser.py:18-77 (NumPy float64 branch used for the tables)."""
+    l = np.arange(truncation_level)[None]
+    omega = np.asarray(omega)[..., None]
+    p = (2 * l + 1) * np.exp(-l * (l + 1) * eps**2 / 2) * np.sin(omega * (l + 1 / 2)) / np.sin(omega / 2)
+    return p.sum(axis=-1)
+
+
+def density(expansion, omega, marginal: bool = True):
+    """so3_diffuser.py:80-96."""
+    if marginal:
+        return expansion * (1 - np.cos(omega)) / np.pi
+    return expansion / 8 / np.pi**2
+
+
+def score(exp, omega, eps, truncation_level: int = 1000):
+    """so3_diffuser.py:122-191 (NumPy float64 branch used for the tables)."""
+    l = np.arange(truncation_level)[None]
+    omega = np.asarray(omega)[..., None]
+    hi = np.sin(omega * (l + 1 / 2))
+    dhi = (l + 1 / 2) * np.cos(omega * (l + 1 / 2))
+    lo = np.sin(omega / 2)
+    dlo = 1 / 2 * np.cos(omega / 2)
+    dsigma = ((2 * l + 1) * np.exp(-l * (l + 1) * eps**2 / 2) * (lo * dhi - hi * dlo) / lo**2).sum(axis=-1)
+    return dsigma / (exp + 1e-4)
+
+
+class SO3Diffuser:
+    def __init__(self, so3_conf) -> None:
+        self.schedule = so3_conf.schedule
+        if self.schedule != "logarithmic":
+            raise ValueError(f"Unrecognize schedule {self.schedule}")
+        self.min_sigma = so3_conf.min_sigma
+        self.max_sigma = so3_conf.max_sigma
+        self.num_sigma = so3_conf.num_sigma
+        self.num_omega = so3_conf.num_omega
+        self.use_cached_score = so3_conf.use_cached_score
+        self.discrete_omega = np.linspace(0, np.pi, so3_conf.num_omega + 1)[1:]
+        self._rows: dict = {}
+        np.random.seed(so3_conf.seed)  # so3_diffuser.py:286
+
+    @property
+    def discrete_sigma(self) -> np.ndarray:
+        return self.sigma(np.linspace(0.0, 1.0, self.num_sigma))
+
+    def sigma_idx(self, sigma):
+        return np.digitize(sigma, self.discrete_sigma) - 1
+
+    def sigma(self, t):
+        if np.any(t < 0) or np.any(t > 1):
+            raise ValueError(f"Invalid t={t}")
+        return np.log(t * np.exp(self.max_sigma) + (1 - t) * np.exp(self.min_sigma))
+
+    def diffusion_coef(self, t):
+        return np.sqrt(2 * (np.exp(self.max_sigma) - np.exp(self.min_sigma)) * self.sigma(t) / np.exp(self.sigma(t)))
+
+    def t_to_idx(self, t):
+        return self.sigma_idx(self.sigma(t))
+
+    def score_sigma(self, t_f32) -> np.ndarray:
+        """sigma snapped to the grid as ``torch_score`` does (so3_diffuser.py:398): t arrives as float32."""
+        t = np.asarray(t_f32, dtype=np.float32).astype(np.float64).reshape(-1)
+        return self.discrete_sigma[self.t_to_idx(t)]
+
+    def _row(self, idx: int):
+        idx = int(idx)
+        if idx not in self._rows:
+            sig = self.discrete_sigma[idx]
+            ev = igso3_expansion(self.discrete_omega, sig)
+            pdf = density(ev, self.discrete_omega, marginal=True)
+            cdf = pdf.cumsum() / self.num_omega * np.pi
+            self._rows[idx] = (pdf, cdf, score(ev, self.discrete_omega, sig))
+        return self._rows[idx]
+
+    def score_scaling(self, t):
+        pdf, _, sn = self._row(self.t_to_idx(t))
+        return np.sqrt(np.abs(np.sum(sn**2 * pdf, axis=-1) / np.sum(pdf, axis=-1))) / np.sqrt(3)
+
+    def sample_igso3(self, t: float, n_samples: int = 1) -> np.ndarray:
+        x = np.random.rand(n_samples)
+        return np.interp(x, self._row(self.t_to_idx(t))[1], self.discrete_omega)
+
+    def sample(self, t: float, n_samples: int = 1) -> np.ndarray:
+        x = np.random.randn(n_samples, 3)
+        x /= np.linalg.norm(x, axis=-1, keepdims=True)
+        return x * self.sample_igso3(t, n_samples=n_samples)[:, None]
+
+    def sample_ref(self, n_samples: int = 1) -> np.ndarray:
+        return self.sample(1.0, n_samples=n_samples)

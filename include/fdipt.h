@@ -1,0 +1,181 @@
+/*
+ * fdipt.h — C ABI of libfdipt_hip.so: MI355X (gfx950) kernels for the FrameDiPT sampler hot path.
+ *
+ * The reference (instadeepai/FrameDiPT) is pure Python/PyTorch and has no FFI; this ABI is the
+ * boundary a maintainer binds with ctypes.  Each entry point names the
+ * reference function(s) it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FDIPT_E* code otherwise; no exceptions,
+ *     no allocation, no global state; reentrant; one hipStream_t per call (passed as void*).
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller (PyTorch) owns
+ *     every buffer, including the workspace (query sizes with the *_bytes functions).
+ *   - layouts are row-major contiguous, residue-major.  Quaternions are scalar-first (w,x,y,z);
+ *     tensor_7 = quat(4) | translation in Angstrom (3)   (openfold/utils/rigid_utils.py:1200-1230).
+ *   - "f32"/"f64" in a parameter comment is the element type of the buffer.
+ */
+#ifndef FDIPT_H
+#define FDIPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDIPT_OK 0
+#define FDIPT_EINVAL (-1)   /* bad argument (null pointer, size out of range)            */
+#define FDIPT_ELAUNCH (-2)  /* HIP launch error (hipGetLastError != hipSuccess)          */
+#define FDIPT_ESIZE (-3)    /* workspace too small / N beyond the compiled LDS tiling     */
+
+/* GEMM operand precision of the score network (accumulation is always fp32). */
+#define FDIPT_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32, parity mode               */
+#define FDIPT_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, pair rep kept in bf16 */
+
+typedef void* fdipt_stream_t; /* hipStream_t */
+
+/* ---------------------------------------------------------------- model description -------- */
+/* Dimensions of ScoreNetwork (framedipt/model/score_network.py:200-216, config/base.yaml:55-79). */
+typedef struct FdiptDims {
+  int32_t c_s;         /* node_embed_size = ipa.c_s           (256) */
+  int32_t c_z;         /* edge_embed_size = ipa.c_z           (128) */
+  int32_t c_hidden;    /* ipa.c_hidden                         (256) */
+  int32_t c_skip;      /* ipa.c_skip                           (64)  */
+  int32_t no_heads;    /* ipa.no_heads                         (8)   */
+  int32_t no_qk_points; /* ipa.no_qk_points                    (8)   */
+  int32_t no_v_points; /* ipa.no_v_points                      (12)  */
+  int32_t tfmr_heads;  /* ipa.seq_tfmr_num_heads               (4)   */
+  int32_t tfmr_layers; /* ipa.seq_tfmr_num_layers              (2)   */
+  int32_t num_blocks;  /* ipa.num_blocks                       (4)   */
+  int32_t index_embed; /* embed.index_embed_size               (32)  */
+  int32_t num_bins;    /* embed.num_bins                       (22)  */
+  int32_t use_aatype;  /* 1: node features carry a 21-way aatype one-hot (inpainting / input_aatype) */
+  int32_t precision;   /* FDIPT_PREC_*                                                    */
+  float min_bin;       /* embed.min_bin (1e-5) */
+  float max_bin;       /* embed.max_bin (20)   */
+  float coordinate_scaling; /* ipa.coordinate_scaling = diffuser.r3.coordinate_scaling (0.1) */
+  float r3_min_b;      /* diffuser.r3.min_b (0.1) */
+  float r3_max_b;      /* diffuser.r3.max_b (20)  */
+} FdiptDims;
+
+/* Number of parameter tensors / total fp32 elements of the reference state_dict for `dims`
+ * (same order as ScoreNetwork(...).state_dict(); framedipt_amd/weights.py:param_shapes). */
+int fdipt_param_count(const FdiptDims* dims);
+int64_t fdipt_param_offset(const FdiptDims* dims, int index); /* element offset of tensor `index` in the flat blob; index==count -> total */
+
+/* Bytes of the derived-weights blob (operand-precision copies, fused / split matrices). */
+size_t fdipt_derived_bytes(const FdiptDims* dims);
+/* Build the derived blob from the flat fp32 state_dict blob (device, order above).  Once per model. */
+int fdipt_model_prepare(const FdiptDims* dims, const float* params_f32, void* derived, fdipt_stream_t stream);
+
+/* ---------------------------------------------------------------- per-batch sample setup ---- */
+/* Constant-per-trajectory tables of a batch of B samples with N residues each:
+ *   seq_idx [B,N] i32; idx_emb [B,N,index_embed] f32 = get_index_embedding(seq_idx) and
+ *   rel_emb [B,n_rel,index_embed] f32 = get_index_embedding(r - rel_off), r in [0,n_rel) — both evaluated
+ *   by the host exactly as the reference does in float32 (framedipt/model/score_network.py:17-38).
+ * Produces in `setup` the relative-position part of the first edge-embedder layer
+ * (score_network.py:98-105,184-187 restructured: concat-free first layer). */
+size_t fdipt_setup_bytes(const FdiptDims* dims, int B, int N, int n_rel);
+int fdipt_sample_setup(const FdiptDims* dims, const float* params_f32, const void* derived, int B, int N, int n_rel,
+                       const float* rel_emb, void* setup, fdipt_stream_t stream);
+
+/* ---------------------------------------------------------------- score network forward ---- */
+/* Replaces ScoreNetwork.forward (framedipt/model/score_network.py:218-275) = Embedder.forward (:129-197)
+ * + IpaScore.forward (framedipt/model/ipa_pytorch.py:509-572) + compute_backbone
+ * (framedipt/protein/all_atom.py:147-176), for a batch of B equally sized samples. */
+typedef struct FdiptForwardArgs {
+  int32_t B, N, n_rel, rel_off;   /* rel index of pair (i,j) = seq_idx[i]-seq_idx[j]+rel_off          */
+  const float* rigids_t;          /* [B,N,7] f32  input frames x_t                                     */
+  const float* res_mask;          /* [B,N]   f32                                                      */
+  const float* fixed_mask;        /* [B,N]   f32  1 = motif residue (not diffused)                    */
+  const float* sc_ca_t;           /* [B,N,3] f32  self-conditioning CA positions (Angstrom)           */
+  const int32_t* seq_idx;         /* [B,N]   i32                                                      */
+  const float* idx_emb;           /* [B,N,index_embed] f32                                            */
+  const int32_t* aatype;          /* [B,N] i32 pre-processed aatype (0..20) or NULL (de novo)         */
+  const float* gt_psi;            /* [B,N,2] f32 torsion_angles_sin_cos[...,2,:]                      */
+  const float* t;                 /* [B] f32 diffusion time                                           */
+  const float* t_emb;             /* [B,index_embed] f32 get_timestep_embedding(t)   (host, float32)  */
+  const float* t_emb_eps;         /* [index_embed]   f32 get_timestep_embedding(1e-5) (inpainting)    */
+  const double* so3_sigma;        /* [B] f64 discrete_sigma[t_to_idx(t)] (so3_diffuser.py:398)        */
+  const void* bb_tables;          /* residue tables for fdipt_backbone_atoms (needed iff atom37/atom14 != NULL) */
+  /* outputs */
+  float* psi;                     /* [B,N,2]  f32 */
+  double* rot_score;              /* [B,N,3]  f64 */
+  float* trans_score;             /* [B,N,3]  f32 */
+  float* rigids;                  /* [B,N,7]  f32 predicted x_0 frames */
+  float* atom37;                  /* [B,N,37,3] f32 or NULL */
+  float* atom14;                  /* [B,N,14,3] f32 or NULL */
+  /* optional traces for parity tests (NULL to skip): node / pair representation after each block */
+  float* trace_node;              /* [num_blocks+1,B,N,c_s] f32: [0]=embedder output               */
+  float* trace_edge;              /* [num_blocks,B,N,N,c_z] f32: [0]=embedder output, [b+1]=EdgeTransition b */
+} FdiptForwardArgs;
+
+size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
+int fdipt_score_forward(const FdiptDims* dims, const float* params_f32, const void* derived, const void* setup,
+                        const FdiptForwardArgs* args, void* workspace, size_t workspace_bytes, fdipt_stream_t stream);
+
+/* ---------------------------------------------------------------- reverse step ------------- */
+/* Replaces SE3Diffuser.reverse (framedipt/diffusion/se3_diffuser.py:346-401) with
+ * _extract_trans_rots (:16-23), SO3Diffuser.reverse (so3_diffuser.py:569-602), compose_rotvec
+ * (framedipt/data/transforms.py:33-46, SciPy Rotation conventions), R3Diffuser.reverse
+ * (r3_diffuser.py:344-385), _assemble_rigid (:26-36) and Rigid.to_tensor_7 (rigid_utils.py:1200-1212),
+ * fused, float64 internally.  z_rot/z_trans are N(0,1) draws (host noise tape; scaled by noise_scale here).
+ * out_rot (optional) receives the float32 rotation matrices of x_{t-1} as the reference's Rigid holds them. */
+int fdipt_se3_reverse_step(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
+                           const float* diffuse_mask /* [B,N] f32 or NULL */, const double* z_rot, const double* z_trans,
+                           double t, double dt, double noise_scale, int center, int diffuse_rot, int diffuse_trans,
+                           double so3_min_sigma, double so3_max_sigma, double r3_min_b, double r3_max_b,
+                           double coordinate_scaling, float* rigids_out /* [B,N,7] */, float* out_rot /* [B,N,3,3] or NULL */,
+                           fdipt_stream_t stream);
+
+/* ---------------------------------------------------------------- frame algebra (a8) ------- */
+/* openfold/utils/rigid_utils.py free functions and Rigid/Rotation methods, n independent items, f32. */
+int fdipt_quat_to_rot(int n, const float* quat, float* rot, fdipt_stream_t s);           /* :185 */
+int fdipt_rot_to_quat(int n, const float* rot, float* quat, fdipt_stream_t s);           /* :208 (sign may differ) */
+int fdipt_quat_multiply(int n, const float* q1, const float* q2, float* out, fdipt_stream_t s); /* :254 */
+int fdipt_quat_multiply_by_vec(int n, const float* q, const float* v, float* out, fdipt_stream_t s); /* :266 */
+int fdipt_invert_quat(int n, const float* q, float* out, fdipt_stream_t s);              /* :282 */
+int fdipt_rigid_apply(int n, const float* t7, const float* pts, float* out, fdipt_stream_t s);        /* :1104 */
+int fdipt_rigid_invert_apply(int n, const float* t7, const float* pts, float* out, fdipt_stream_t s); /* :1118 */
+int fdipt_rigid_compose(int n, const float* a_t7, const float* b_t7, float* out_rot, float* out_trans, fdipt_stream_t s); /* :1065 */
+int fdipt_rigid_invert(int n, const float* t7, float* out_rot, float* out_trans, fdipt_stream_t s);   /* :1132 */
+int fdipt_rigid_compose_q_update(int n, const float* t7, const float* upd6, const float* mask, float* out_t7,
+                                 fdipt_stream_t s);                                      /* :587,:1039 (fork: update_mask) */
+int fdipt_quat_to_rotvec(int n, const float* q, float* rotvec, fdipt_stream_t s);        /* framedipt/data/transforms.py:53-69 */
+/* SciPy Rotation conventions (float64): exp = from_rotvec().as_matrix(), log = from_matrix().as_rotvec() */
+int fdipt_so3_exp(int n, const double* rotvec, double* rot, fdipt_stream_t s);
+int fdipt_so3_log(int n, const double* rot, double* rotvec, fdipt_stream_t s);
+
+/* ---------------------------------------------------------------- scores / backbone -------- */
+/* SE3Diffuser.calc_rot_score (se3_diffuser.py:281-292 -> so3_diffuser.py:373-402,18-77,122-191): 1000-term IGSO(3)
+ * series; quats_t = noisy x_t, quats_0 = prediction, sigma[B] as in FdiptForwardArgs. */
+int fdipt_igso3_rot_score(int B, int N, const float* quats_t, const float* quats_0, const double* sigma,
+                          const float* res_mask, double* score, fdipt_stream_t s);
+/* SE3Diffuser.calc_trans_score(use_torch=True, scale=True) (se3_diffuser.py:269-279 -> r3_diffuser.py:410-440). */
+int fdipt_r3_trans_score(int B, int N, const float* trans_t, const float* trans_0, const float* t, float min_b,
+                         float max_b, float coordinate_scaling, const float* res_mask, float* score, fdipt_stream_t s);
+/* all_atom.compute_backbone (framedipt/protein/all_atom.py:147-176): frames given as tensor_7 (rot==NULL) or as
+ * rot [n,3,3] + trans [n,3]; tables = default_frames[21,8,4,4] | ideal_pos[21,14,3] | atom_mask[21,14] (f32) then
+ * group_idx[21,14] (i32) packed as in framedipt_amd/residue_tables.py. */
+int fdipt_backbone_atoms(int n, const float* t7, const float* rot, const float* trans, const float* psi,
+                         const int32_t* aatype, const void* tables, float* atom37, float* atom14, fdipt_stream_t s);
+
+/* ---------------------------------------------------------------- building blocks ---------- */
+/* Exposed for parity tests and for callers that assemble their own network. */
+/* out[M,N] = epilogue(A[M,K] W[N,K]^T + bias): relu, +residual, *rowmask.  K % 8 == 0, lda/ldw in elements.
+ * W is fp32 (precision F32) or bf16 (precision BF16, as produced by fdipt_model_prepare). */
+int fdipt_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
+                 const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, fdipt_stream_t s);
+int fdipt_layernorm(int M, int D, const float* x, const float* residual, const float* gamma, const float* beta,
+                    const float* rowmask, float* out, fdipt_stream_t s);
+/* self-test of the MFMA fragment maps used by every kernel: returns max |err| of a 64x64x64 product vs fp64 host math
+ * through *max_err_host (host pointer). */
+int fdipt_selftest_mfma(int precision, double* max_err_host);
+
+const char* fdipt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDIPT_H */

@@ -267,6 +267,7 @@ def traj_golden(name, cfg, n, inpainting, num_t, noise_scale=0.1, min_t=0.01):
     """Free-running reference trajectory with every per-step input captured (teacher forcing)."""
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + 1)
     diff, model, _ = build(cfg, inpainting)
+    np.random.seed(123)  # model construction consumed the global stream (truncnorm init): restart it here
     f = make_feats(n, rng, inpainting, diff)
     g = feats_np(f)
     tape, steps = [], []

@@ -1,0 +1,279 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI vs the reference goldens and the NumPy oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import kabsch_free_rmsd, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from framedipt_amd import _lib
+    return _lib.load()
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    return t.to(dtype) if dtype is not None else t
+
+
+def test_mfma_fragment_maps(lib):
+    for prec, tol in ((0, 2e-4), (1, 0.35)):
+        err = C.c_double(-1)
+        assert lib.fdipt_selftest_mfma(prec, C.byref(err)) == 0
+        assert 0 <= err.value < tol, (prec, err.value)
+
+
+def test_frame_ops_vs_reference_goldens():
+    from framedipt_amd import rigid as R
+    from framedipt_amd.diffusion import se3_diffuser as sd
+    G = load_golden("ops.npz")
+    q1, q2, t1, t2 = dev(G["q1"]), dev(G["q2"]), dev(G["t1"]), dev(G["t2"])
+    cmp = lambda a, b, tol: np.testing.assert_allclose(a.cpu().numpy(), b, atol=tol)  # noqa: E731
+    cmp(R.quat_to_rot(q1), G["quat_to_rot"], 1e-6)
+    cmp(R.quat_multiply(q1, q2), G["quat_multiply"], 1e-6)
+    cmp(R.quat_multiply_by_vec(q1, dev(G["vec"])), G["quat_multiply_by_vec"], 1e-6)
+    cmp(R.invert_quat(q1), G["invert_quat"], 1e-6)
+    cmp(R.quat_to_rot(R.rot_to_quat(R.quat_to_rot(q1))), G["rot_to_quat_rot"], 3e-6)
+    r1 = R.Rigid.from_tensor_7(torch.cat([q1, t1], -1))
+    r2 = R.Rigid.from_tensor_7(torch.cat([q2, t2], -1))
+    cmp(r1.apply(dev(G["pts"])), G["apply"], 1e-5)
+    cmp(r1.invert_apply(dev(G["pts"])), G["invert_apply"], 1e-5)
+    c = r1.compose(r2)
+    cmp(c.get_rots().get_rot_mats(), G["compose_rot"], 1e-6)
+    cmp(c.get_trans(), G["compose_trans"], 1e-5)
+    iv = r1.invert()
+    cmp(iv.get_rots().get_rot_mats(), G["invert_rot"], 1e-6)
+    cmp(iv.get_trans(), G["invert_trans"], 1e-5)
+    cu = r1.compose_q_update_vec(dev(G["upd"]), dev(G["mask"]))
+    cmp(cu.get_rots().get_quats(), G["cqu_quat"], 1e-6)
+    cmp(cu.get_trans(), G["cqu_trans"], 1e-5)
+    # SciPy conventions
+    cmp(sd.so3_exp(dev(G["rv1"])), G["rotvec_to_matrix"], 1e-13)
+    m = sd.so3_exp(dev(G["rv1"]))
+    m2 = sd.so3_exp(dev(G["rv2"]))
+    cmp(sd.so3_log(m @ m2), G["compose_rotvec"], 1e-9)
+    # float32-rounded matrices: plain Markley (SciPy 1.7.3 pin) vs the SVD-projecting SciPy 1.15 golden
+    rv = sd.so3_log(R.quat_to_rot(q1).double()).cpu().numpy()
+    ang = np.linalg.norm(G["extract_rotvec"], axis=-1)
+    ok = ang < np.pi - 1e-2
+    assert np.abs(rv - G["extract_rotvec"])[ok].max() < 5e-7
+    # quat_to_rotvec (float32 twin)
+    from framedipt_amd import _lib
+    out = torch.empty(q1.shape[0], 3, device="cuda")
+    _lib.check(_lib.load().fdipt_quat_to_rotvec(q1.shape[0], _lib.ptr(q1), _lib.ptr(out), _lib.stream_ptr()))
+    cmp(out, G["quat_to_rotvec"], 3e-6)
+
+
+def _diffuser():
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    return SE3Diffuser(config.base_config().diffuser)
+
+
+def test_scores_vs_reference_goldens():
+    from framedipt_amd.rigid import Rotation
+    from oracle import diffuser as od
+    from oracle import frames as fr
+    G = load_golden("ops.npz")
+    d = _diffuser()
+    qt = Rotation(quats=dev(G["q1"])[None], normalize_quats=False)
+    q0 = Rotation(quats=dev(G["rot_score_q0"])[None], normalize_quats=False)
+    for i, t in enumerate([0.01, 0.5, 1.0]):
+        tt = torch.tensor([t], dtype=torch.float32)
+        rs = d.calc_rot_score(qt, q0, tt).cpu().numpy()[0]
+        ref = G[f"rot_score_{i}"]
+        rv = fr.quat_to_rotvec(fr.quat_multiply(fr.invert_quat(G["rot_score_q0"]), G["q1"]).astype(np.float32))
+        sig = d._so3_diffuser.score_sigma(np.float32(t))[0]
+        f = od.igso3_expansion_np(np.linalg.norm(rv, axis=-1).astype(np.float64), sig)
+        ok = f > 1e-2  # conditioned regime of the float32 series
+        assert ok.sum() >= 3
+        err, mag = np.abs(rs - ref).max(-1), np.abs(ref).max(-1)
+        assert (err[ok] <= 2e-3 * mag[ok] + 1e-5).all(), (i, err[ok], mag[ok])
+        ts = d.calc_trans_score(dev(G["t1"])[None], dev(G["t2"])[None], tt, use_torch=True).cpu().numpy()[0]
+        np.testing.assert_allclose(ts, G[f"trans_score_{i}"], rtol=3e-6, atol=2e-6)
+
+
+def test_backbone_vs_reference_goldens():
+    from framedipt_amd import _lib, residue_tables
+    G = load_golden("ops.npz")
+    lib = _lib.load()
+    n = G["q1"].shape[0]
+    t7 = dev(np.concatenate([G["q1"], G["t1"]], -1))
+    tb = dev(residue_tables.packed_bytes())
+    for aatype, k37, k14 in ((dev(G["bb_aatype"][0].astype(np.int32)), "bb_atom37", "bb_atom14"),
+                             (None, "bb_atom37_none", "bb_atom14_none")):
+        a37, a14 = torch.empty(n, 37, 3, device="cuda"), torch.empty(n, 14, 3, device="cuda")
+        _lib.check(lib.fdipt_backbone_atoms(n, _lib.ptr(t7), None, None, _lib.ptr(dev(G["bb_psi"][0])), _lib.ptr(aatype),
+                                            _lib.ptr(tb), _lib.ptr(a37), _lib.ptr(a14), _lib.stream_ptr()))
+        np.testing.assert_allclose(a37.cpu().numpy(), G[k37][0], atol=3e-5)
+        np.testing.assert_allclose(a14.cpu().numpy(), G[k14][0], atol=3e-5)
+
+
+def test_sample_ref_vs_reference_goldens():
+    from framedipt_amd import rigid as R
+    X = load_golden("xT.npz")
+    d = _diffuser()
+    t7 = d.sample_ref(50, as_tensor_7=True)["rigids_t"]
+    np.testing.assert_allclose(R.quat_to_rot(t7[:, :4]).cpu().numpy(),
+                               R.quat_to_rot(dev(X["denovo_t7"][:, :4])).cpu().numpy(), atol=3e-6)
+    np.testing.assert_allclose(t7[:, 4:].cpu().numpy(), X["denovo_t7"][:, 4:], atol=1e-6)
+    imp = R.Rigid.from_tensor_7(dev(X["imp_t7"].astype(np.float32)))
+    r = d.sample_ref(30, impute=imp, diffuse_mask=X["imp_mask"])["rigids_t"]
+    np.testing.assert_allclose(r.get_rots().get_rot_mats().cpu().numpy(), X["inpaint_rot"], atol=2e-6)
+    np.testing.assert_allclose(r.get_trans().cpu().numpy(), X["inpaint_trans"], atol=1e-5)
+    with pytest.raises(ValueError):
+        d.sample_ref(10, diffuse_mask=np.ones(10))
+    with pytest.raises(ValueError):
+        d.sample_ref(10, impute=imp)
+
+
+@pytest.mark.parametrize("name", ["traj_small_denovo_n16_T10.npz", "traj_small_inpaint_n24_T10.npz",
+                                  "traj_full_denovo_n64_T20.npz"])
+def test_reverse_step_teacher_forced(name):
+    T = load_golden(name)
+    d = _diffuser()
+    dm = dev(((1 - T["in_fixed_mask"]) * T["in_res_mask"]).astype(np.float32))
+    dt = 1.0 / int(T["num_t"])
+    for s in range(len(T["step_t"])):
+        rot_out = torch.empty(1, dm.shape[1], 3, 3, device="cuda")
+        out = d.reverse_device(dev(T["step_rigids_t"][s]), dev(T["step_rot_score"][s]),
+                               dev(T["step_trans_score"][s].astype(np.float32)), dm, dev(T["noise_tape"][2 * s]),
+                               dev(T["noise_tape"][2 * s + 1]), float(T["step_t"][s]), dt, True, float(T["noise_scale"]),
+                               rot_out=rot_out)
+        np.testing.assert_allclose(rot_out.cpu().numpy(), T["step_out_rot"][s], atol=1e-6)
+        np.testing.assert_allclose(out[..., 4:].cpu().numpy(), T["step_out_trans"][s], atol=3e-5)
+
+
+def _conf(name):
+    from framedipt_amd import config
+    inp = "inpaint" in name
+    return (config.small_config(inp) if name.startswith("small") else config.base_config(inp)), inp
+
+
+def _net(name, G, precision):
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    conf, inp = _conf(name)
+    d = SE3Diffuser(conf.diffuser)
+    net = ScoreNetwork(conf.model, d, inpainting=inp, precision=precision)
+    net.load_synthetic(int(G["weight_seed"]), float(G["bb_gain"])).to("cuda")
+    return net, d, conf
+
+
+def _feats(G):
+    return {k[3:]: dev(G[k]) for k in G if k.startswith("in_")}
+
+
+FWD = ["small_denovo_n16", "small_inpaint_n24", "small_denovo_n16_stress", "full_denovo_n64", "full_inpaint_n40"]
+
+
+@pytest.mark.parametrize("name", FWD)
+def test_forward_fp32_vs_reference_goldens(name):
+    G = load_golden(f"fwd_{name}.npz")
+    net, _, conf = _net(name, G, "fp32")
+    out = net(_feats(G), trace=True)
+    rows = list(G["trace_rows"])
+    tn, te = out["trace_node"].cpu().numpy(), out["trace_edge"].cpu().numpy()
+    np.testing.assert_allclose(tn[0], G["tr_node_init"], atol=1e-4)
+    np.testing.assert_allclose(te[0][:, rows], G["tr_edge_init"], atol=1e-4)
+    nb = conf.model.ipa.num_blocks
+    for b in range(nb):
+        np.testing.assert_allclose(tn[b + 1], G[f"tr_node_{b}"] * G["in_res_mask"][..., None], atol=2e-4)
+        if b < nb - 1:
+            np.testing.assert_allclose(te[b + 1][:, rows], G[f"tr_edge_{b}"], atol=2e-4)
+    o = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith("trace")}
+    np.testing.assert_allclose(o["rigids"][..., 4:], G["out_rigids"][..., 4:], atol=2e-4)
+    np.testing.assert_allclose(np.abs(o["rigids"][..., :4]), np.abs(G["out_rigids"][..., :4]), atol=1e-5)
+    np.testing.assert_allclose(o["psi"], G["out_psi"], atol=2e-4)
+    np.testing.assert_allclose(o["atom37"], G["out_atom37"], atol=5e-4)
+    np.testing.assert_allclose(o["atom14"], G["out_atom14"], atol=5e-4)
+    ts = max(np.abs(G["out_trans_score"]).max(), 1.0)
+    np.testing.assert_allclose(o["trans_score"], G["out_trans_score"], atol=3e-4 * ts)
+    if "stress" not in name and name != "full_inpaint_n40":
+        rs = max(np.abs(G["out_rot_score"]).max(), 1.0)
+        np.testing.assert_allclose(o["rot_score"], G["out_rot_score"], atol=3e-3 * rs)
+    assert o["psi"].dtype == G["out_psi"].dtype and o["rot_score"].dtype == np.float64
+
+
+@pytest.mark.parametrize("name", ["small_denovo_n16", "full_denovo_n64"])
+def test_forward_bf16_vs_reference_goldens(name):
+    """bf16 GEMM operands / bf16 pair representation: separate (looser) tolerance, stated here."""
+    G = load_golden(f"fwd_{name}.npz")
+    net, _, conf = _net(name, G, "bf16")
+    out = net(_feats(G), trace=True)
+    tn = out["trace_node"].cpu().numpy()
+    nb = conf.model.ipa.num_blocks
+    for b in range(nb):
+        ref = G[f"tr_node_{b}"]
+        rel = np.linalg.norm(tn[b + 1] - ref) / np.linalg.norm(ref)
+        assert rel < 3e-2, (b, rel)
+    o = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith("trace")}
+    # frames move by bb_gain-scaled updates: CA within 0.05 A, backbone atoms within 0.1 A of the fp32 reference
+    np.testing.assert_allclose(o["rigids"][..., 4:], G["out_rigids"][..., 4:], atol=5e-2)
+    assert kabsch_free_rmsd(o["atom37"], G["out_atom37"]) < 0.1
+
+
+@pytest.mark.parametrize("name", ["small_denovo_n16_T10", "small_inpaint_n24_T10", "full_denovo_n64_T20"])
+def test_teacher_forced_steps_fp32(name):
+    """Per-step parity: reference state in -> one HIP step -> x_{t-1} backbone RMSD < 1e-3 A."""
+    from framedipt_amd import inference as inf
+    G = load_golden(f"traj_{name}.npz")
+    net, d, _ = _net(name, G, "fp32")
+    base = _feats(G)
+    num_t, min_t = int(G["num_t"]), float(G["min_t"])
+    steps = np.linspace(min_t, 1.0, num_t)[::-1]
+    rigid_traj, prot = G["res_rigid_traj"][::-1], G["res_prot_traj"][::-1]
+    inp = "inpaint" in name
+    worst = 0.0
+    for i, t in enumerate(steps):
+        f = dict(base)
+        f["rigids_t"] = dev(rigid_traj[i])
+        f["sc_ca_t"] = dev(G["sc_in"][i + 1])
+        # one-step trajectory: num_t=1 would change dt, so drive the pieces directly
+        f["t"] = torch.tensor([t], dtype=torch.float32, device="cuda")
+        out = net(f)
+        aatype = None
+        if inp:
+            from framedipt_amd.model.score_network import preprocess_aatype
+            aatype = preprocess_aatype(f["aatype"], f["fixed_mask"].float(), True, False).to(torch.int32).contiguous()
+        atom37 = torch.empty(1, f["rigids_t"].shape[1], 37, 3, device="cuda")
+        n = f["rigids_t"].shape[1]
+        if t > min_t:
+            dm = ((1 - f["fixed_mask"]) * f["res_mask"]).float().contiguous()
+            rot_out = torch.empty(1, n, 3, 3, device="cuda")
+            nxt = d.reverse_device(f["rigids_t"].float().contiguous(), out["rot_score"], out["trans_score"], dm,
+                                   dev(G["noise_tape"][2 * i]), dev(G["noise_tape"][2 * i + 1]), t, 1 / num_t, True,
+                                   float(G["noise_scale"]), rot_out=rot_out)
+            inf._backbone(net, n, None, rot_out, nxt[..., 4:].contiguous(), out["psi"].float().contiguous(), aatype, atom37)
+        else:
+            inf._backbone(net, n, out["rigids"].contiguous(), None, None, out["psi"].float().contiguous(), aatype, atom37)
+        worst = max(worst, kabsch_free_rmsd(atom37.cpu().numpy(), prot[i]))
+    assert worst < 1e-3, worst
+
+
+def test_free_running_small_fp32():
+    from framedipt_amd import inference as inf
+    G = load_golden("traj_small_denovo_n16_T10.npz")
+    net, d, _ = _net("small_denovo_n16_T10", G, "fp32")
+    n = len(G["noise_tape"]) // 2
+    tape = (np.stack([G["noise_tape"][2 * i] for i in range(n)]), np.stack([G["noise_tape"][2 * i + 1] for i in range(n)]))
+    res = inf.inference_fn(net, d, _feats(G), int(G["num_t"]), float(G["min_t"]), aux_traj=True,
+                           noise_scale=float(G["noise_scale"]), noise_tape=tape)
+    for k in ("prot_traj", "rigid_traj", "trans_traj", "rigid_0_traj"):
+        assert res[k].shape == G["res_" + k].shape, k
+    assert tuple(res["psi_pred"].shape) == tuple(G["res_psi_pred"].shape)
+    # free-running: against the reference's own thread-count divergence floor (5e-2 A at T=10)
+    assert kabsch_free_rmsd(res["prot_traj"][0], G["res_prot_traj"][0]) < 5e-2
+    assert kabsch_free_rmsd(res["rigid_0_traj"][-1], G["res_rigid_0_traj"][-1]) < 1e-3
+
+
+def test_fails_loudly_on_cpu_tensors():
+    from framedipt_amd import _lib
+    from framedipt_amd import rigid as R
+    with pytest.raises(_lib.FdiptError):
+        R.quat_to_rot(torch.zeros(4, 4))
