@@ -34,7 +34,8 @@ class ForwardArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n_rel", C.c_int32), ("rel_off", C.c_int32)] + [
         (n, _P) for n in ("rigids_t", "res_mask", "fixed_mask", "sc_ca_t", "seq_idx", "idx_emb", "aatype", "gt_psi", "t",
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
-                          "atom37", "atom14", "trace_node", "trace_edge")]
+                          "atom37", "atom14", "trace_node", "trace_edge")] + [
+        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p))]
 
 
 _lib = None
@@ -71,6 +72,10 @@ SIGNATURES = {
     "fdipt_linear": (_i, [_i, _i, _i, _i, _P, _i, _P, _i, _P, _P, _i, _P, _i, _P, _i, _P]),
     "fdipt_layernorm": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _P]),
     "fdipt_selftest_mfma": (_i, [_i, C.POINTER(_d)]),
+    "fdipt_event_create": (_i, [C.POINTER(_P)]),
+    "fdipt_event_destroy": (_i, [_P]),
+    "fdipt_event_record": (_i, [_P, _P]),
+    "fdipt_event_elapsed_ms": (_i, [_P, _P, C.POINTER(_f)]),
     "fdipt_version": (C.c_char_p, []),
 }
 

@@ -444,7 +444,9 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       ta.w1 = WM(k.et1); ta.w2 = WM(k.et2); ta.wf = WM(k.etf); ta.b1 = P + k.et1.b; ta.b2 = P + k.et2.b; ta.bf = P + k.etf.b;
       ta.gamma = P + k.et_ln.g; ta.beta = P + k.et_ln.b; ta.res_mask = res_mask;
       ta.trace = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
+      if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
       RC(fd_edge_transition(prec, cz, iv.cb, ta, st));
+      if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
     }
     if (a->trace_node)
       if (hipMemcpyAsync(a->trace_node + (size_t)(b + 1) * R * cs, node_cur, (size_t)R * cs * 4, hipMemcpyDeviceToDevice,
@@ -465,6 +467,23 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));
   }
   return FDIPT_OK;
+}
+
+int fdipt_event_create(void** ev_host) {
+  if (!ev_host) return FDIPT_EINVAL;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return FDIPT_ELAUNCH;
+  *ev_host = (void*)e;
+  return FDIPT_OK;
+}
+int fdipt_event_destroy(void* ev) { return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? FDIPT_OK : FDIPT_ELAUNCH; }
+int fdipt_event_record(void* ev, fdipt_stream_t s) {
+  return hipEventRecord((hipEvent_t)ev, (hipStream_t)s) == hipSuccess ? FDIPT_OK : FDIPT_ELAUNCH;
+}
+int fdipt_event_elapsed_ms(void* start, void* stop, float* ms_host) {
+  if (!ms_host) return FDIPT_EINVAL;
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return FDIPT_ELAUNCH;
+  return hipEventElapsedTime(ms_host, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? FDIPT_OK : FDIPT_ELAUNCH;
 }
 
 }  // extern "C"

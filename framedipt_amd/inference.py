@@ -34,84 +34,110 @@ def _backbone(net, n, t7, rot, trans, psi, aatype, atom37):
                "backbone_atoms")
 
 
+class ReverseLoop:
+    """Device-resident state of one batch of trajectories; ``prime()`` then ``step(k)`` for k = 0..num_t-1."""
+
+    def __init__(self, model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
+                 noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None):
+        self.model, self.diffuser = model, diffuser
+        dev = self.dev = model.device
+        rig0 = data_init["rigids_t"]
+        _lib.require_cuda(rig0, "inference_fn")
+        if rig0.dim() == 2:
+            raise ValueError("rigids_t needs a leading batch dimension")
+        B, N = self.B, self.N = rig0.shape[0], rig0.shape[1]
+        f32 = lambda x: x.to(device=dev, dtype=torch.float32).contiguous().clone()  # noqa: E731
+        self.res_mask, self.fixed = f32(data_init["res_mask"]), f32(data_init["fixed_mask"])
+        self.fixed_mask = self.fixed * self.res_mask
+        self.diffuse_mask = ((1 - self.fixed) * self.res_mask).contiguous()
+        aatype = preprocess_aatype(data_init.get("aatype"), self.fixed, inpainting, input_aatype)
+        self.aatype = None if aatype is None else aatype.to(device=dev, dtype=torch.int32).contiguous()
+        self.gt_tors = data_init["torsion_angles_sin_cos"]
+        self.gt_psi = f32(self.gt_tors[..., 2, :])
+        self.st = model.batch_state(data_init["seq_idx"])
+        self.num_t, self.min_t, self.dt = num_t, min_t, 1 / num_t
+        self.center, self.aux_traj, self.noise_scale = center, aux_traj, noise_scale
+        self.self_condition, self.embed_sc = self_condition, embed_self_conditioning
+        self.reverse_steps = np.linspace(min_t, 1.0, num_t)[::-1]
+        n_noisy = int(np.sum(self.reverse_steps > min_t))
+        t32, temb, sig = model.step_scalars(self.reverse_steps)
+        with torch.cuda.device(dev):
+            self.t_all = torch.as_tensor(np.repeat(t32[:, None], B, 1), device=dev)
+            self.temb_all = torch.as_tensor(np.repeat(temb[:, None, :], B, 1), device=dev)
+            self.sig_all = torch.as_tensor(np.repeat(sig[:, None], B, 1), device=dev)
+            if noise_tape is None:
+                noise_tape = draw_noise_tape(diffuser, n_noisy, B, N)
+            self.z_rot = torch.as_tensor(np.ascontiguousarray(noise_tape[0], dtype=np.float64), device=dev)
+            self.z_trans = torch.as_tensor(np.ascontiguousarray(noise_tape[1], dtype=np.float64), device=dev)
+            self.rigids_t = f32(rig0)
+            self.sc_ca = f32(data_init["sc_ca_t"])
+            self.rigid_traj = torch.empty(num_t + 1, B, N, 7, device=dev)
+            self.rigid_traj[0] = self.rigids_t
+            self.prot_traj = torch.empty(num_t, B, N, 37, 3, device=dev)
+            self.bb0_traj = torch.empty(num_t, B, N, 37, 3, device=dev) if aux_traj else None
+            self.trans_traj = torch.empty(num_t, B, N, 3, device=dev) if aux_traj else None
+            self.rot_out = torch.empty(B, N, 3, 3, device=dev)
+            self.trans_c = torch.empty(B, N, 3, device=dev)
+        self.noisy = 0
+
+    def _fwd(self, k, want_atoms):
+        self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.aatype, self.gt_psi, self.t_all[k],
+                        self.temb_all[k], self.sig_all[k], want_atoms)
+
+    def prime(self):
+        """Self-conditioning priming call (utils.py:571-578)."""
+        if self.embed_sc and self.self_condition:
+            with torch.cuda.device(self.dev):
+                self._fwd(0, False)
+                self.sc_ca.copy_(self.st.rigids[..., 4:])
+
+    def step(self, k):
+        """one_step_inference (utils.py:292-412) for reverse step k."""
+        st, t, n = self.st, self.reverse_steps[k], self.B * self.N
+        with torch.cuda.device(self.dev):
+            self._fwd(k, self.aux_traj)
+            if t > self.min_t:
+                if self.embed_sc:
+                    self.sc_ca.copy_(st.rigids[..., 4:])
+                nxt = self.rigid_traj[k + 1]
+                self.diffuser.reverse_device(self.rigids_t, st.rot_score, st.trans_score, self.diffuse_mask,
+                                             self.z_rot[self.noisy], self.z_trans[self.noisy], t, self.dt, self.center,
+                                             self.noise_scale, rigids_out=nxt, rot_out=self.rot_out)
+                self.noisy += 1
+                self.rigids_t.copy_(nxt)
+                self.trans_c.copy_(nxt[..., 4:])
+                _backbone(self.model, n, None, self.rot_out, self.trans_c, st.psi, self.aatype, self.prot_traj[k])
+            else:  # last step: take the x_0 prediction, utils.py:373-374
+                self.rigid_traj[k + 1] = st.rigids
+                self.rigids_t.copy_(st.rigids)
+                _backbone(self.model, n, self.rigids_t, None, None, st.psi, self.aatype, self.prot_traj[k])
+            if self.aux_traj:
+                self.bb0_traj[k] = st.atom37
+                self.trans_traj[k] = (self.diffuse_mask[..., None] * st.rigids[..., 4:]
+                                      + self.fixed_mask[..., None] * self.rigids_t[..., 4:])
+
+    def results(self, return_device=False):
+        st = self.st
+        psi_pred = st.psi.to(self.gt_tors.dtype).clone() if self.gt_tors.dtype == torch.float64 else st.psi.clone()
+        conv = (lambda x: torch.flip(x, (0,))) if return_device else (lambda x: np.flip(x.cpu().numpy(), (0,)))
+        ret = {"prot_traj": conv(self.prot_traj)}
+        if self.aux_traj:
+            ret["rigid_traj"] = conv(self.rigid_traj)
+            ret["trans_traj"] = conv(self.trans_traj)
+            ret["psi_pred"] = psi_pred[None]
+            ret["rigid_0_traj"] = conv(self.bb0_traj)
+        return ret
+
+
 def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None,
                  return_device=False):
     """Same arguments / returned keys as the reference.  ``noise_tape=(z_rot, z_trans)`` ([num_t-1,B,N,3] float64
     N(0,1) draws) overrides the global ``np.random`` stream (sample-sharded runs).  ``data_init`` tensors carry a
     leading batch dimension B >= 1 (the reference always passes B = 1)."""
-    dev = model.device
-    rig0 = data_init["rigids_t"]
-    _lib.require_cuda(rig0, "inference_fn")
-    if rig0.dim() == 2:
-        raise ValueError("rigids_t needs a leading batch dimension")
-    B, N = rig0.shape[0], rig0.shape[1]
-    f32 = lambda x: x.to(device=dev, dtype=torch.float32).contiguous().clone()  # noqa: E731
-    res_mask, fixed = f32(data_init["res_mask"]), f32(data_init["fixed_mask"])
-    fixed_mask = fixed * res_mask
-    diffuse_mask = ((1 - fixed) * res_mask).contiguous()
-    aatype = preprocess_aatype(data_init.get("aatype"), fixed, inpainting, input_aatype)
-    aatype_dev = None if aatype is None else aatype.to(device=dev, dtype=torch.int32).contiguous()
-    gt_tors = data_init["torsion_angles_sin_cos"]
-    gt_psi = f32(gt_tors[..., 2, :])
-    st = model.batch_state(data_init["seq_idx"])
-
-    reverse_steps = np.linspace(min_t, 1.0, num_t)[::-1]
-    dt = 1 / num_t
-    n_noisy = int(np.sum(reverse_steps > min_t))
-    t32, temb, sig = model.step_scalars(reverse_steps)
-    with torch.cuda.device(dev):
-        t_all = torch.as_tensor(np.repeat(t32[:, None], B, 1), device=dev)
-        temb_all = torch.as_tensor(np.repeat(temb[:, None, :], B, 1), device=dev)
-        sig_all = torch.as_tensor(np.repeat(sig[:, None], B, 1), device=dev)
-        if noise_tape is None:
-            noise_tape = draw_noise_tape(diffuser, n_noisy, B, N)
-        z_rot = torch.as_tensor(np.ascontiguousarray(noise_tape[0], dtype=np.float64), device=dev)
-        z_trans = torch.as_tensor(np.ascontiguousarray(noise_tape[1], dtype=np.float64), device=dev)
-        rigids_t = f32(rig0)
-        sc_ca = f32(data_init["sc_ca_t"])
-        rigid_traj = torch.empty(num_t + 1, B, N, 7, device=dev)
-        rigid_traj[0] = rigids_t
-        prot_traj = torch.empty(num_t, B, N, 37, 3, device=dev)
-        bb0_traj = torch.empty(num_t, B, N, 37, 3, device=dev) if aux_traj else None
-        trans_traj = torch.empty(num_t, B, N, 3, device=dev) if aux_traj else None
-        rot_out = torch.empty(B, N, 3, 3, device=dev)
-        trans_c = torch.empty(B, N, 3, device=dev)
-
-        def fwd(k, want_atoms):
-            st.forward(rigids_t, res_mask, fixed, sc_ca, aatype_dev, gt_psi, t_all[k], temb_all[k], sig_all[k], want_atoms)
-
-        if embed_self_conditioning and self_condition:  # priming call, utils.py:571-578
-            fwd(0, False)
-            sc_ca.copy_(st.rigids[..., 4:])
-        noisy = 0
-        for k, t in enumerate(reverse_steps):
-            fwd(k, aux_traj)
-            if t > min_t:
-                if embed_self_conditioning:
-                    sc_ca.copy_(st.rigids[..., 4:])
-                nxt = rigid_traj[k + 1]
-                diffuser.reverse_device(rigids_t, st.rot_score, st.trans_score, diffuse_mask, z_rot[noisy], z_trans[noisy],
-                                        t, dt, center, noise_scale, rigids_out=nxt, rot_out=rot_out)
-                noisy += 1
-                rigids_t.copy_(nxt)
-                trans_c.copy_(nxt[..., 4:])
-                _backbone(model, B * N, None, rot_out, trans_c, st.psi, aatype_dev, prot_traj[k])
-            else:  # last step: take the x_0 prediction, utils.py:373-374
-                rigid_traj[k + 1] = st.rigids
-                rigids_t.copy_(st.rigids)
-                _backbone(model, B * N, rigids_t, None, None, st.psi, aatype_dev, prot_traj[k])
-            if aux_traj:
-                bb0_traj[k] = st.atom37
-                trans_traj[k] = diffuse_mask[..., None] * st.rigids[..., 4:] + fixed_mask[..., None] * rigids_t[..., 4:]
-        psi_pred = st.psi.to(gt_tors.dtype).clone() if gt_tors.dtype == torch.float64 else st.psi.clone()
-        conv = (lambda x: torch.flip(x, (0,))) if return_device else (lambda x: np.flip(x.cpu().numpy(), (0,)))
-        ret = {"prot_traj": conv(prot_traj)}
-        if aux_traj:
-            ret["rigid_traj"] = conv(rigid_traj)
-            ret["trans_traj"] = conv(trans_traj)
-            ret["psi_pred"] = psi_pred[None]
-            ret["rigid_0_traj"] = conv(bb0_traj)
-        else:
-            ret["rigid_traj_final"] = rigid_traj[-1] if return_device else rigid_traj[-1].cpu().numpy()
-    return ret
+    loop = ReverseLoop(model, diffuser, data_init, num_t, min_t, center, aux_traj, self_condition, noise_scale,
+                       embed_self_conditioning, inpainting, input_aatype, noise_tape)
+    loop.prime()
+    for k in range(num_t):
+        loop.step(k)
+    return loop.results(return_device)

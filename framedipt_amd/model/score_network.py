@@ -70,6 +70,7 @@ class BatchState:
         if trace:
             self.trace_node = torch.zeros(d.num_blocks + 1, B, N, d.c_s, **f32)
             self.trace_edge = torch.zeros(d.num_blocks, B, N, N, d.c_z, **f32)
+        self.ev_start = self.ev_stop = None  # optional hipEvent pairs around the EdgeTransition launches (bench.py)
         self.t_emb_eps = torch.as_tensor(embedding.get_timestep_embedding(np.array([1e-5], dtype=np.float32), E)[0],
                                          device=dev)
 
@@ -88,6 +89,8 @@ class BatchState:
                           ("atom37", self.atom37 if want_atoms else None), ("atom14", self.atom14 if want_atoms else None),
                           ("trace_node", self.trace_node), ("trace_edge", self.trace_edge)):
             setattr(a, name, _lib.ptr(tns))
+        if self.ev_start is not None:
+            a.ev_start, a.ev_stop = self.ev_start, self.ev_stop
         _lib.check(lib.fdipt_score_forward(C.byref(net.dims), _lib.ptr(net.params), _lib.ptr(net.derived),
                                            _lib.ptr(self.setup), C.byref(a), _lib.ptr(self.ws), self.ws_bytes,
                                            _lib.stream_ptr()), "score_forward")

@@ -109,6 +109,10 @@ typedef struct FdiptForwardArgs {
   /* optional traces for parity tests (NULL to skip): node / pair representation after each block */
   float* trace_node;              /* [num_blocks+1,B,N,c_s] f32: [0]=embedder output               */
   float* trace_edge;              /* [num_blocks,B,N,N,c_z] f32: [0]=embedder output, [b+1]=EdgeTransition b */
+  /* optional profiling: hipEvent_t pairs recorded on `stream` around every EdgeTransition launch
+   * (num_blocks-1 pairs, created with fdipt_event_create); NULL to skip */
+  void** ev_start;                /* host array of events */
+  void** ev_stop;
 } FdiptForwardArgs;
 
 size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
@@ -172,6 +176,12 @@ int fdipt_layernorm(int M, int D, const float* x, const float* residual, const f
 /* self-test of the MFMA fragment maps used by every kernel: returns max |err| of a 64x64x64 product vs fp64 host math
  * through *max_err_host (host pointer). */
 int fdipt_selftest_mfma(int precision, double* max_err_host);
+
+/* HIP event helpers for bench.py (kernel timing on the stream the kernels are launched on). */
+int fdipt_event_create(void** ev_host);
+int fdipt_event_destroy(void* ev);
+int fdipt_event_record(void* ev, fdipt_stream_t s);
+int fdipt_event_elapsed_ms(void* start, void* stop, float* ms_host); /* synchronises on `stop` */
 
 const char* fdipt_version(void);
 

@@ -23,14 +23,14 @@ F32 = np.float32
 
 
 def linear(x, w, b):
-    return (x @ w.T + b).astype(F32)
+    return (x @ w.T + b).astype(F32, copy=False)
 
 
 def layer_norm(x, g, b, eps=1e-5):
-    x = x.astype(F32)
+    x = x.astype(F32, copy=False)
     mu = x.mean(-1, keepdims=True, dtype=F32)
     var = ((x - mu) ** 2).mean(-1, keepdims=True, dtype=F32)
-    return ((x - mu) / np.sqrt(var + F32(eps)) * g + b).astype(F32)
+    return ((x - mu) / np.sqrt(var + F32(eps)) * g + b).astype(F32, copy=False)
 
 
 def relu(x):
@@ -40,7 +40,7 @@ def relu(x):
 def softmax(x, axis=-1):
     m = x.max(axis=axis, keepdims=True)
     e = np.exp(x - m)
-    return (e / e.sum(axis=axis, keepdims=True)).astype(F32)
+    return (e / e.sum(axis=axis, keepdims=True)).astype(F32, copy=False)
 
 
 def softplus(x):
@@ -61,9 +61,9 @@ TIMESTEP_FREQS = np.array([float.fromhex(h) for h in (
 def index_embedding(idx, embed_size=32, max_len=2056):
     """score_network.py:17-38 (float32 arithmetic as torch evaluates it)."""
     k = np.arange(embed_size // 2)
-    denom = np.power(float(max_len), 2 * k / embed_size).astype(F32)  # == torch float32 pow for these 16 values
-    arg = ((np.asarray(idx).astype(F32)[..., None] * F32(math.pi)).astype(F32) / denom).astype(F32)
-    return np.concatenate([np.sin(arg), np.cos(arg)], axis=-1).astype(F32)
+    denom = np.power(float(max_len), 2 * k / embed_size).astype(F32, copy=False)  # == torch float32 pow for these 16 values
+    arg = ((np.asarray(idx).astype(F32, copy=False)[..., None] * F32(math.pi)).astype(F32, copy=False) / denom).astype(F32, copy=False)
+    return np.concatenate([np.sin(arg), np.cos(arg)], axis=-1).astype(F32, copy=False)
 
 
 def timestep_embedding(t, dim=32, max_positions=10000):
@@ -73,17 +73,17 @@ def timestep_embedding(t, dim=32, max_positions=10000):
     if dim == 32 and max_positions == 10000:
         emb = TIMESTEP_FREQS
     else:
-        emb = np.exp(np.arange(half, dtype=F32) * F32(-math.log(max_positions) / (half - 1))).astype(F32)
-    emb = (t[:, None] * emb[None]).astype(F32)
-    return np.concatenate([np.sin(emb), np.cos(emb)], axis=1).astype(F32)
+        emb = np.exp(np.arange(half, dtype=F32) * F32(-math.log(max_positions) / (half - 1))).astype(F32, copy=False)
+    emb = (t[:, None] * emb[None]).astype(F32, copy=False)
+    return np.concatenate([np.sin(emb), np.cos(emb)], axis=1).astype(F32, copy=False)
 
 
 def distogram(pos, min_bin, max_bin, num_bins):
     """framedipt/data/utils.py:541-550."""
     d = np.linalg.norm(pos[:, :, None, :] - pos[:, None, :, :], axis=-1)[..., None]
-    lower = np.linspace(min_bin, max_bin, num_bins, dtype=np.float64).astype(F32)
+    lower = np.linspace(min_bin, max_bin, num_bins, dtype=np.float64).astype(F32, copy=False)
     upper = np.concatenate([lower[1:], np.array([1e8], dtype=F32)])
-    return ((d > lower) * (d < upper)).astype(F32)
+    return ((d > lower) * (d < upper)).astype(F32, copy=False)
 
 
 class ScoreNetwork:
@@ -117,7 +117,7 @@ class ScoreNetwork:
         """score_network.py:129-197."""
         ec = self.mc.embed
         B, N = seq_idx.shape
-        fm = fixed_mask[..., None].astype(F32)
+        fm = fixed_mask[..., None].astype(F32, copy=False)
         te = np.tile(timestep_embedding(t, ec.index_embed_size)[:, None, :], (1, N, 1))
         if aatype is not None:
             oh = np.eye(21, dtype=F32)[aatype]
@@ -136,12 +136,12 @@ class ScoreNetwork:
             dg = distogram(sc_ca, ec.min_bin, ec.max_bin, ec.num_bins)
             pair_feats.append(dg.reshape(B, N * N, -1))
         p = "embedding_layer.node_embedder."
-        x = np.concatenate(node_feats, axis=-1).astype(F32)
+        x = np.concatenate(node_feats, axis=-1).astype(F32, copy=False)
         x = relu(self._lin(p + "0", x))
         x = relu(self._lin(p + "2", x))
         node = self._ln(p + "5", self._lin(p + "4", x))
         p = "embedding_layer.edge_embedder."
-        y = np.concatenate(pair_feats, axis=-1).astype(F32)
+        y = np.concatenate(pair_feats, axis=-1).astype(F32, copy=False)
         y = relu(self._lin(p + "0", y))
         y = relu(self._lin(p + "2", y))
         edge = self._ln(p + "5", self._lin(p + "4", y)).reshape(B, N, N, -1)
@@ -154,7 +154,7 @@ class ScoreNetwork:
         H, C, Pq, Pv = ic.no_heads, ic.c_hidden, ic.no_qk_points, ic.no_v_points
         B, N, _ = s.shape
         p = f"score_model.trunk.ipa_{b}."
-        rot = fr.quat_to_rot(quat).astype(F32)
+        rot = fr.quat_to_rot(quat).astype(F32, copy=False)
         q = self._lin(p + "linear_q", s).reshape(B, N, H, C)
         kv = self._lin(p + "linear_kv", s).reshape(B, N, H, 2 * C)
         k, v = kv[..., :C], kv[..., C:]
@@ -162,35 +162,36 @@ class ScoreNetwork:
         def pts(name, n_pts):
             x = self._lin(p + name, s)  # [B,N,H*n*3] as three planes
             x = np.stack(np.split(x, 3, axis=-1), axis=-1)  # [B,N,H*n,3]
-            x = fr.rigid_apply(rot[:, :, None], trans[:, :, None], x).astype(F32)
+            x = fr.rigid_apply(rot[:, :, None], trans[:, :, None], x).astype(F32, copy=False)
             return x.reshape(B, N, H, n_pts, 3)
 
         q_pts = pts("linear_q_points", Pq)
         kv_pts = pts("linear_kv_points", Pq + Pv)
         k_pts, v_pts = kv_pts[..., :Pq, :], kv_pts[..., Pq:, :]
         bz = self._lin(p + "linear_b", z)  # [B,N,N,H]
-        a = np.einsum("bihc,bjhc->bhij", q, k).astype(F32)
+        a = np.matmul(q.transpose(0, 2, 1, 3), k.transpose(0, 2, 3, 1)).astype(F32, copy=False)
         a = a * F32(math.sqrt(1.0 / (3 * C)))
         a = a + F32(math.sqrt(1.0 / 3)) * bz.transpose(0, 3, 1, 2)
         disp = q_pts[:, :, None] - k_pts[:, None, :]  # [B,N,N,H,Pq,3]
         pt_att = (disp**2).sum(-1)
-        hw = softplus(self.sd[p + "head_weights"]).astype(F32).reshape(1, 1, 1, H, 1)
+        hw = softplus(self.sd[p + "head_weights"]).astype(F32, copy=False).reshape(1, 1, 1, H, 1)
         hw = hw * F32(math.sqrt(1.0 / (3 * (Pq * 9.0 / 2))))
         pt_att = (pt_att * hw).sum(-1) * F32(-0.5)  # [B,N,N,H]
         sq = F32(1e5) * (mask[:, :, None] * mask[:, None, :] - 1)
         a = a + pt_att.transpose(0, 3, 1, 2) + sq[:, None]
-        a = softmax(a.astype(F32), axis=-1)  # [B,H,N,N]
-        o = np.einsum("bhij,bjhc->bihc", a, v).reshape(B, N, H * C).astype(F32)
-        o_pt = np.einsum("bhij,bjhpx->bihpx", a, v_pts).astype(F32)  # [B,N,H,Pv,3]
-        o_pt = fr.rigid_invert_apply(rot[:, :, None, None], trans[:, :, None, None], o_pt).astype(F32)
+        a = softmax(a.astype(F32, copy=False), axis=-1)  # [B,H,N,N]
+        o = np.matmul(a, v.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3).reshape(B, N, H * C).astype(F32, copy=False)
+        o_pt = np.matmul(a, v_pts.transpose(0, 2, 1, 3, 4).reshape(B, H, N, Pv * 3)).transpose(0, 2, 1, 3)
+        o_pt = o_pt.reshape(B, N, H, Pv, 3).astype(F32, copy=False)  # [B,N,H,Pv,3]
+        o_pt = fr.rigid_invert_apply(rot[:, :, None, None], trans[:, :, None, None], o_pt).astype(F32, copy=False)
         o_norm = np.sqrt((o_pt**2).sum(-1) + F32(1e-8)).reshape(B, N, H * Pv)
         o_pt = o_pt.reshape(B, N, H * Pv, 3)
         pair_z = self._lin(p + "down_z", z)  # [B,N,N,cz/4]
-        o_pair = np.einsum("bhij,bijc->bihc", a, pair_z).reshape(B, N, -1).astype(F32)
+        o_pair = np.matmul(a.transpose(0, 2, 1, 3), pair_z).reshape(B, N, -1).astype(F32, copy=False)
         feats = np.concatenate([o, o_pt[..., 0], o_pt[..., 1], o_pt[..., 2], o_norm, o_pair], axis=-1)
         if self.trace is not None:
             self.trace[f"ipa_{b}_feats"] = feats
-        return self._lin(p + "linear_out", feats.astype(F32))
+        return self._lin(p + "linear_out", feats.astype(F32, copy=False))
 
     def seq_tfmr(self, b, x, mask):
         """nn.TransformerEncoder(post-norm, ReLU, dropout 0), ipa_pytorch.py:433-443,536-538."""
@@ -203,9 +204,9 @@ class ScoreNetwork:
             p = f"score_model.trunk.seq_tfmr_{b}.layers.{l}."
             qkv = linear(x, self.sd[p + "self_attn.in_proj_weight"], self.sd[p + "self_attn.in_proj_bias"])
             q, k, v = (qkv[..., i * D:(i + 1) * D].reshape(B, N, nh, hd) for i in range(3))
-            att = np.einsum("bihd,bjhd->bhij", q, k).astype(F32) * F32(1.0 / math.sqrt(hd))
+            att = np.matmul(q.transpose(0, 2, 1, 3), k.transpose(0, 2, 3, 1)).astype(F32, copy=False) * F32(1.0 / math.sqrt(hd))
             att = softmax(att + pad, axis=-1)
-            o = np.einsum("bhij,bjhd->bihd", att, v).reshape(B, N, D).astype(F32)
+            o = np.matmul(att, v.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3).reshape(B, N, D).astype(F32, copy=False)
             o = self._lin(p + "self_attn.out_proj", o)
             x = self._ln(p + "norm1", x + o)
             f = self._lin(p + "linear2", relu(self._lin(p + "linear1", x)))
@@ -220,7 +221,7 @@ class ScoreNetwork:
         bias = np.concatenate(
             [np.tile(ne[:, :, None, :], (1, 1, N, 1)), np.tile(ne[:, None, :, :], (1, N, 1, 1))], axis=-1
         )
-        x = np.concatenate([edge, bias], axis=-1).reshape(B * N * N, -1).astype(F32)
+        x = np.concatenate([edge, bias], axis=-1).reshape(B * N * N, -1).astype(F32, copy=False)
         h = relu(self._lin(p + "trunk.0", x))
         h = relu(self._lin(p + "trunk.2", h))
         y = self._lin(p + "final_layer", h + x)
@@ -232,25 +233,25 @@ class ScoreNetwork:
         x = self._lin(p + "linear_2", relu(self._lin(p + "linear_1", s))) + s
         un = self._lin(p + "linear_final", x)
         den = np.sqrt(np.maximum((un**2).sum(-1, keepdims=True), F32(1e-8)))
-        return (un / den).astype(F32)
+        return (un / den).astype(F32, copy=False)
 
     # -------------------------------------------------------------- forward
     def __call__(self, feats):
         """score_network.py:218-275 + ipa_pytorch.py:509-572."""
         ic = self.mc.ipa
-        bb_mask = feats["res_mask"].astype(F32)
-        fixed_mask = feats["fixed_mask"].astype(F32)
+        bb_mask = feats["res_mask"].astype(F32, copy=False)
+        fixed_mask = feats["fixed_mask"].astype(F32, copy=False)
         edge_mask = bb_mask[..., None] * bb_mask[..., None, :]
         aatype = self.preprocess_aatype(feats.get("aatype"), fixed_mask)
         t = np.asarray(feats["t"], dtype=F32)
-        node0, edge = self.embed(feats["seq_idx"], t, fixed_mask, feats["sc_ca_t"].astype(F32), aatype)
+        node0, edge = self.embed(feats["seq_idx"], t, fixed_mask, feats["sc_ca_t"].astype(F32, copy=False), aatype)
         edge = edge * edge_mask[..., None]
         node0 = node0 * bb_mask[..., None]
         diffuse_mask = (1 - fixed_mask) * bb_mask
-        rig = feats["rigids_t"].astype(F32)
+        rig = feats["rigids_t"].astype(F32, copy=False)
         q_init, t_init = rig[..., :4], rig[..., 4:]
         cs = F32(ic.coordinate_scaling)
-        quat, trans = q_init.copy(), (t_init * cs).astype(F32)
+        quat, trans = q_init.copy(), (t_init * cs).astype(F32, copy=False)
         node0 = node0 * bb_mask[..., None]
         node = node0 * bb_mask[..., None]
         if self.trace is not None:
@@ -275,13 +276,13 @@ class ScoreNetwork:
                 self.trace[f"node_{b}"], self.trace[f"edge_{b}"] = node.copy(), edge.copy()
                 self.trace[f"rigid_{b}"] = np.concatenate([quat, trans], -1)
         rot_score = self.diffuser.calc_rot_score(q_init, quat, t) * bb_mask[..., None]
-        trans_u = (trans / cs).astype(F32)
+        trans_u = (trans / cs).astype(F32, copy=False)
         trans_score = self.diffuser.calc_trans_score(t_init, trans_u, t[:, None, None]) * bb_mask[..., None]
         psi = self.torsion(node)
         gt_psi = feats["torsion_angles_sin_cos"][..., 2, :]
         dm = 1 - fixed_mask[..., None]
         psi = dm * psi + (1 - dm) * gt_psi
-        rigids = np.concatenate([quat, trans_u], axis=-1).astype(F32)
+        rigids = np.concatenate([quat, trans_u], axis=-1).astype(F32, copy=False)
         atom37, atom14 = compute_backbone(quat, trans_u, psi, aatype, self.tables)
         return {"psi": psi, "rot_score": rot_score, "trans_score": trans_score, "rigids": rigids,
                 "atom37": atom37, "atom14": atom14}
@@ -294,14 +295,14 @@ def compute_backbone(quat, trans, psi, aatype, tables, rot=None):
     tables: dict(default_frames [21,8,4,4], group_idx [21,14], atom_mask [21,14], ideal_pos [21,14,3]).
     """
     if rot is None:
-        rot = fr.quat_to_rot(quat.astype(F32)).astype(F32)
-    trans = trans.astype(F32)
+        rot = fr.quat_to_rot(quat.astype(F32, copy=False)).astype(F32, copy=False)
+    trans = trans.astype(F32, copy=False)
     shp = trans.shape[:-1]
     if aatype is None:
         aatype = np.zeros(shp, dtype=np.int64)
     aatype = np.where(aatype == 20, 0, aatype)
-    alpha = np.tile(psi.astype(F32)[..., None, :], (1,) * len(shp) + (7, 1))
-    d44 = tables["default_frames"].astype(F32)[aatype]  # [*,N,8,4,4]
+    alpha = np.tile(psi.astype(F32, copy=False)[..., None, :], (1,) * len(shp) + (7, 1))
+    d44 = tables["default_frames"].astype(F32, copy=False)[aatype]  # [*,N,8,4,4]
     dr, dt = d44[..., :3, :3], d44[..., :3, 3]
     bb = np.zeros(shp + (1, 2), dtype=F32)
     bb[..., 1] = 1
@@ -312,24 +313,24 @@ def compute_backbone(quat, trans, psi, aatype, tables, rot=None):
     ar[..., 1, 2] = -al[..., 0]
     ar[..., 2, 1] = al[..., 0]
     ar[..., 2, 2] = al[..., 1]
-    fr_r = fr.rot_matmul(dr, ar).astype(F32)  # default_r.compose(all_rots); trans of all_rots = 0
+    fr_r = fr.rot_matmul(dr, ar).astype(F32, copy=False)  # default_r.compose(all_rots); trans of all_rots = 0
     fr_t = dt.copy()
     # chain chi2..chi4 onto chi1 (feats.py:204-212)
     R, T = [fr_r[..., i, :, :] for i in range(8)], [fr_t[..., i, :] for i in range(8)]
     for i in (5, 6, 7):
         r_new, t_new = fr.rigid_compose(R[i - 1], T[i - 1], R[i], T[i])
-        R[i], T[i] = r_new.astype(F32), t_new.astype(F32)
+        R[i], T[i] = r_new.astype(F32, copy=False), t_new.astype(F32, copy=False)
     fr_r, fr_t = np.stack(R, axis=-3), np.stack(T, axis=-2)
     g_r, g_t = fr.rigid_compose(rot[..., None, :, :], trans[..., None, :], fr_r, fr_t)
-    g_r, g_t = g_r.astype(F32), g_t.astype(F32)
+    g_r, g_t = g_r.astype(F32, copy=False), g_t.astype(F32, copy=False)
     gi = tables["group_idx"][aatype]  # [*,N,14]
     oh = np.eye(8, dtype=F32)[gi]  # [*,N,14,8]
-    a_r = np.einsum("...ag,...gij->...aij", oh, g_r).astype(F32)
-    a_t = np.einsum("...ag,...gi->...ai", oh, g_t).astype(F32)
-    ideal = tables["ideal_pos"].astype(F32)[aatype]
-    pos = (fr.rot_vec_mul(a_r, ideal) + a_t).astype(F32) * tables["atom_mask"].astype(F32)[aatype][..., None]
+    a_r = np.einsum("...ag,...gij->...aij", oh, g_r).astype(F32, copy=False)
+    a_t = np.einsum("...ag,...gi->...ai", oh, g_t).astype(F32, copy=False)
+    ideal = tables["ideal_pos"].astype(F32, copy=False)[aatype]
+    pos = (fr.rot_vec_mul(a_r, ideal) + a_t).astype(F32, copy=False) * tables["atom_mask"].astype(F32, copy=False)[aatype][..., None]
     a37 = np.zeros(shp + (37, 3), dtype=F32)
     a37[..., :3, :] = pos[..., :3, :]
     a37[..., 3, :] = pos[..., 4, :]
     a37[..., 4, :] = pos[..., 3, :]
-    return a37, pos.astype(F32)
+    return a37, pos.astype(F32, copy=False)
