@@ -1,0 +1,308 @@
+// edge_transition2.hip — bf16 EdgeTransition (framedipt/model/ipa_pytorch.py:84-102) with the activations of the
+// whole 3-layer MLP kept in REGISTERS (the dominant kernel: 89 % of the reference's FLOPs).
+//
+// Mapping (MI355X-first, not a GEMM-library pattern):
+//   * a wave owns 32 pair rows p = (b*N+i)*N+j for the whole MLP; a 256-thread block = 4 waves = one wave per SIMD
+//     with the full 512-register file each (activations 64+96+64 VGPRs).
+//   * every layer is computed TRANSPOSED: D[out feature, pair] = W[out, k] * X^T[k, pair] with
+//     v_mfma_f32_32x32x16_bf16, weights as the A operand (from LDS), activations as the B operand (registers).
+//     The C/D fragment of a layer (lane = pair, 16 features in registers) is exactly a B fragment of the next layer
+//     up to a fixed 16-wise permutation of k, which is folded into the weights at prepare time — so activations
+//     never touch LDS or HBM between layers.
+//   * the block's 4 waves walk one pre-swizzled, pre-permuted weight stream (640 KB, L2-resident) through a
+//     2 x 32 KB LDS double buffer: one barrier per 32-feature output tile (24-32 MFMAs per wave between barriers).
+//   * concat-free: x = [z_ij | e_i | e_j]; the e_i columns of layer 1 and of the final layer are per-residue
+//     vectors (A1[i], Af[i], tiny GEMMs done beforehand), so the [N^2,384] tensor never exists.
+//       h1 = relu(W1[:, z|ej] [z;e_j] + A1[i]);  h2 = relu(W2 h1 + b2);  y = Wf[:, h] h2 + Wf[:, z|ej] [z;e_j] + Af[i]
+//       z' = LayerNorm(y) * mask_i mask_j
+// Executed MFMA FLOPs per pair: 655,360 (reference formulation: 688,128).
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define ET2_CZ 128
+#define ET2_CB 128
+#define ET2_H 384
+// weight-stream geometry (bytes)
+#define ET2_SLAB_L1 (32 * 256 * 2)   // 16 KB : 32 out features x K=256 (z | e_j)
+#define ET2_SLAB_L2 (32 * 384 * 2)   // 24 KB : 32 out features x K=384 (h1, permuted k)
+#define ET2_SLAB_FH (128 * 32 * 2)   //  8 KB : 128 final outputs x 32 k (one h2 tile, permuted k)
+#define ET2_STREAM_BYTES (12 * ET2_SLAB_L1 + 4 * ET2_SLAB_L1 + 12 * (ET2_SLAB_L2 + ET2_SLAB_FH))
+#define ET2_BUF (ET2_SLAB_L2 + ET2_SLAB_FH)  // 32 KB per LDS buffer
+
+// logical (row, 16-byte chunk) -> byte offset inside a slab image (bank-conflict-free ds_read_b128, see T2)
+__host__ __device__ __forceinline__ int et2_off_wide(int row, int c, int row_bytes) {
+  return row * row_bytes + ((c ^ (row & 15)) << 4);
+}
+__host__ __device__ __forceinline__ int et2_off_fh(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+// position inside a 16-group of k  ->  feature offset inside the 16-group produced by the C/D fragment layout
+__host__ __device__ __forceinline__ int et2_perm16(int pos) {
+  const int hi = pos >> 3, e = pos & 7;
+  return 4 * hi + (e & 3) + 8 * (e >> 2);
+}
+
+// ------------------------------------------------------------------ prepare: build the weight stream image
+// w1 [384,384], w2 [384,384], wf [128,384] fp32 row-major (out, in); in = [z(0:128) | e_i(128:256) | e_j(256:384)].
+__global__ void et2_build_stream_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                        const float* __restrict__ wf, bf16_t* __restrict__ stream) {
+  const int n_chunks = ET2_STREAM_BYTES / 16;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_chunks; g += gridDim.x * blockDim.x) {
+    int byte = g * 16;
+    const float* src;
+    int ld = ET2_H, n = 0, kmode = 0, kbase = 0, T = 0;  // kmode 0: x columns (z|ej); 1: permuted h columns
+    int row, c;
+    if (byte < 16 * ET2_SLAB_L1) {  // L1 slabs 0..11 then FX slabs 0..3 (same geometry)
+      const int slab = byte / ET2_SLAB_L1, q = (byte % ET2_SLAB_L1) / 16;
+      row = q / 32;
+      const int cp = q % 32;
+      c = cp ^ (row & 15);
+      if (slab < 12) { src = w1; n = 32 * slab + row; } else { src = wf; n = 32 * (slab - 12) + row; }
+      kmode = 0;
+    } else {
+      byte -= 16 * ET2_SLAB_L1;
+      T = byte / ET2_BUF;
+      const int r2 = byte % ET2_BUF;
+      if (r2 < ET2_SLAB_L2) {
+        const int q = r2 / 16;
+        row = q / 48;
+        const int cp = q % 48;
+        c = (cp & ~15) | ((cp & 15) ^ (row & 15));
+        src = w2; n = 32 * T + row; kmode = 1; kbase = 0;
+      } else {
+        const int q = (r2 - ET2_SLAB_L2) / 16;
+        row = q / 4;
+        const int cp = q % 4;
+        c = cp ^ ((row >> 2) & 3);
+        src = wf; n = row; kmode = 1; kbase = 32 * T;
+      }
+    }
+    bf16_t out[8];
+    for (int e = 0; e < 8; ++e) {
+      const int k = c * 8 + e;  // logical k inside the slab
+      int col;
+      if (kmode == 0) col = k < ET2_CZ ? k : (ET2_CZ + ET2_CB) + (k - ET2_CZ);
+      else col = kbase + (k & ~15) + et2_perm16(k & 15);
+      out[e] = f2bf(src[(long)n * ld + col]);
+    }
+    for (int e = 0; e < 8; ++e) stream[(long)g * 8 + e] = out[e];
+  }
+}
+
+int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st) {
+  hipLaunchKernelGGL(et2_build_stream_kernel, dim3(160), dim3(256), 0, st, w1, w2, wf, (bf16_t*)stream);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+size_t fd_et2_stream_bytes() { return ET2_STREAM_BYTES; }
+
+// ------------------------------------------------------------------ kernel
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+  return o;
+}
+
+// copy `bytes` of the stream (contiguous image) global -> registers (issue) and registers -> LDS (commit)
+template <int BYTES>
+struct Stager {
+  static constexpr int NCH = BYTES / 16 / FD_THREADS;  // 16-byte chunks per thread
+  u16x8 r[NCH];
+  __device__ __forceinline__ void issue(const char* __restrict__ src, int tid) {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) r[u] = *(const u16x8*)(src + (size_t)(tid + u * FD_THREADS) * 16);
+  }
+  __device__ __forceinline__ void commit(char* dst, int tid) {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) *(u16x8*)(dst + (size_t)(tid + u * FD_THREADS) * 16) = r[u];
+  }
+};
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* slab, int off) {
+  return __builtin_bit_cast(bf16x8, *(const u16x8*)(slab + off));
+}
+
+__global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ET2_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, li = lane & 31;
+  const int N = a.N;
+  const long n_pairs = (long)a.B * N * N;
+  const long p_raw = (long)blockIdx.x * 128 + wave * 32 + li;
+  const bool valid = p_raw < n_pairs;
+  const long p = valid ? p_raw : n_pairs - 1;
+  const long bi = p / N;            // b*N + i
+  const int j = (int)(p - bi * N);
+  const long bj = (bi / N) * N + j;  // b*N + j
+  const char* stream = (const char*)a.stream;
+
+  // ---- B-operand fragments of x = [z_ij | e_j] (k order natural): 16 k-steps
+  bf16x8 X[16];
+  {
+    const bf16_t* zr = a.z_in + p * ET2_CZ + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) X[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(zr + 16 * s));
+    const float* er = a.e + bj * ET2_CB + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const f32x4 u0 = *(const f32x4*)(er + 16 * s), u1 = *(const f32x4*)(er + 16 * s + 4);
+      const float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+      X[8 + s] = pack8(v);
+    }
+  }
+  // prologue: first slab into buffer 0
+  {
+    Stager<ET2_SLAB_L1> sg;
+    sg.issue(stream, tid);
+    sg.commit(smem, tid);
+  }
+  __syncthreads();
+
+  bf16x8 H1[24];
+  f32x16 Y[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
+
+  const float* a1row = a.a1 + bi * ET2_H + 4 * hi;
+  size_t soff = 0;  // stream offset of the slab being computed
+  int buf = 0;
+  // ================= layer 1: 12 output tiles, K = 256
+#pragma unroll
+  for (int T = 0; T < 12; ++T) {
+    Stager<ET2_SLAB_L1> sg;  // next slab (L1 T+1, or FX 0) has the same size
+    sg.issue(stream + soff + ET2_SLAB_L1, tid);
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(a1row + 32 * T + 8 * g);
+    const char* slab = smem + buf * ET2_BUF;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 512)), X[s], acc, 0, 0, 0);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
+    H1[2 * T] = pack8(v);
+    H1[2 * T + 1] = pack8(v + 8);
+    sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
+    __syncthreads();
+    buf ^= 1;
+    soff += ET2_SLAB_L1;
+  }
+  // ================= final layer, x part: Y[t] += Wf[:, z|ej] x   (4 tiles, K = 256)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const char* slab = smem + buf * ET2_BUF;
+    if (t < 3) {
+      Stager<ET2_SLAB_L1> sg;
+      sg.issue(stream + soff + ET2_SLAB_L1, tid);
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 512)), X[s], Y[t], 0, 0, 0);
+      sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
+    } else {
+      Stager<ET2_BUF> sg;  // next: L2 slab 0 + FH slab 0
+      sg.issue(stream + soff + ET2_SLAB_L1, tid);
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 512)), X[s], Y[t], 0, 0, 0);
+      sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
+    }
+    __syncthreads();
+    buf ^= 1;
+    soff += ET2_SLAB_L1;
+  }
+  // ================= layer 2 (+ final layer h part, fused per h2 tile): 12 tiles, K = 384
+  const float* b2row = a.b2 + 4 * hi;
+#pragma unroll
+  for (int T = 0; T < 12; ++T) {
+    Stager<ET2_BUF> sg;
+    if (T < 11) sg.issue(stream + soff + ET2_BUF, tid);
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(b2row + 32 * T + 8 * g);
+    const char* slab = smem + buf * ET2_BUF;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 24; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 768)), H1[s], acc, 0, 0, 0);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
+    const bf16x8 h0 = pack8(v), h1 = pack8(v + 8);
+    const char* fh = slab + ET2_SLAB_L2;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(fh, et2_off_fh(32 * t + li, hi)), h0, Y[t], 0, 0, 0);
+      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(fh, et2_off_fh(32 * t + li, 2 + hi)), h1, Y[t], 0, 0, 0);
+    }
+    if (T < 11) {
+      sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
+      __syncthreads();
+      buf ^= 1;
+      soff += ET2_BUF;
+    }
+  }
+  // ================= epilogue: + Af[i], LayerNorm over the 128 features of each pair, mask, store
+  const float* afrow = a.af + bi * ET2_CZ + 4 * hi;
+  float s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(afrow + 32 * t + 8 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Y[t][4 * g + q] += bv[q];
+        s1 += Y[t][4 * g + q];
+      }
+    }
+  s1 += __shfl_xor(s1, 32, 64);
+  const float mu = s1 * (1.0f / ET2_CZ);
+  float s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = Y[t][r] - mu;
+      s2 += d * d;
+    }
+  s2 += __shfl_xor(s2, 32, 64);
+  const float rstd = 1.0f / sqrtf(s2 * (1.0f / ET2_CZ) + 1e-5f);
+  const float em = a.res_mask[bi] * a.res_mask[bj];
+  if (valid) {
+    bf16_t* zo = a.z_out + p * ET2_CZ + 4 * hi;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * t + 8 * g;
+        const f32x4 gm = *(const f32x4*)(a.gamma + f0 + 4 * hi), bt = *(const f32x4*)(a.beta + f0 + 4 * hi);
+        u16x4 o;
+        float of[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          of[q] = ((Y[t][4 * g + q] - mu) * rstd * gm[q] + bt[q]) * em;
+          o[q] = __builtin_bit_cast(unsigned short, (__bf16)of[q]);
+        }
+        *(u16x4*)(zo + f0) = o;
+        if (a.trace) {
+          f32x4 tv = {of[0], of[1], of[2], of[3]};
+          *(f32x4*)(a.trace + p * ET2_CZ + 4 * hi + f0) = tv;
+        }
+      }
+  }
+}
+
+int fd_edge_transition2(const ET2Args& a, hipStream_t st) {
+  const long n_pairs = (long)a.B * a.N * a.N;
+  hipLaunchKernelGGL(edge_transition2_kernel, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

@@ -75,6 +75,21 @@ struct PointsArgs {
   float *qp, *kp, *vp, *rot;
 };
 
+struct ET2Args {
+  int B, N;
+  const bf16_t* z_in;   // [B,N,N,128] bf16
+  bf16_t* z_out;        // may alias z_in
+  const float* e;       // [B*N,128] f32 initial_embed(node)
+  const float* a1;      // [B*N,384] f32: W1[:, e_i cols] e_i + b1
+  const float* af;      // [B*N,128] f32: Wf[:, e_i cols] e_i + bf
+  const void* stream;   // pre-swizzled weight stream (fd_et2_build_stream)
+  const float *b2, *gamma, *beta, *res_mask;
+  float* trace;         // optional [B,N,N,128] f32
+};
+int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
+size_t fd_et2_stream_bytes();
+int fd_edge_transition2(const ET2Args& a, hipStream_t st);
+
 int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
               const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, hipStream_t st);
 int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,

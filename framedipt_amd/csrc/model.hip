@@ -5,6 +5,7 @@
 // (framedipt/model/ipa_pytorch.py:509-572).  It only enqueues kernels on the caller's stream: no allocation,
 // no synchronisation, no host round-trip (the reference syncs inside the forward, so3_diffuser.py:398).
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -91,7 +92,7 @@ static void build_inventory(const FdiptDims* d, Inventory& iv) {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
-struct DBlock { size_t wproj, bproj, gamma, wb, bb; };
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, et2; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -100,6 +101,11 @@ struct DLayout {
   size_t total;
   int kn_pad, d1_pad, esz;
 };
+
+// register-resident bf16 EdgeTransition (edge_transition2.hip) is compiled for the reference widths only
+static bool use_et2(const FdiptDims* d) {
+  return d->precision == FDIPT_PREC_BF16 && d->c_z == 128 && d->c_s == 256 && !getenv("FDIPT_ET_V1");
+}
 
 static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   size_t o = 0;
@@ -121,6 +127,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
+    L.blk[b].et2 = o;
+    if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
   }
   L.total = o;
 }
@@ -238,6 +246,8 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     // pair bias pre-scaled by sqrt(1/3) (ipa_pytorch.py:256-257)
     if ((rc = copy_cols(L.esz, H, cz, cz, P + k.lb.w, cz, 0, s3, D + db.wb, st))) return rc;
     if ((rc = copy_cols(4, 1, H, H, P + k.lb.b, H, 0, s3, D + db.bb, st))) return rc;
+    if (use_et2(d) && b < d->num_blocks - 1)
+      if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st))) return rc;
   }
   (void)C;
   return FDIPT_OK;
@@ -264,7 +274,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -285,6 +295,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.tf_in = take(R * iv.d_t * 4); w.qkv = take(R * 3 * iv.d_t * 4); w.att = take(R * iv.d_t * 4);
   w.x_a = take(R * iv.d_t * 4); w.x_b = take(R * iv.d_t * 4); w.ff = take(R * iv.d_t * 4);
   w.e = take(R * iv.cb * 4); w.upd = take(R * 8 * 4); w.psi_un = take(R * 8 * 4);
+  w.a1 = take(R * iv.hid * 4); w.af = take(R * d->c_z * 4);
   w.total = o;
 }
 
@@ -439,14 +450,30 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
     if (b < d->num_blocks - 1) {
       RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
+      float* tr_ptr = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
+      if (use_et2(d)) {
+        // per-residue parts of the concat-free layers: A1[i] = W1[:, e_i cols] e_i + b1, Af[i] = Wf[:, e_i cols] e_i + bf
+        RC(fd_linear(prec, R, iv.hid, iv.cb, F(w.e), iv.cb, PB + k.et1.w + cz, iv.hid, P + k.et1.b, nullptr, 0, nullptr, 0,
+                     F(w.a1), iv.hid, st));
+        RC(fd_linear(prec, R, cz, iv.cb, F(w.e), iv.cb, PB + k.etf.w + cz, iv.hid, P + k.etf.b, nullptr, 0, nullptr, 0,
+                     F(w.af), cz, st));
+        ET2Args t2;
+        t2.B = B; t2.N = N; t2.z_in = (const bf16_t*)(W + w.z); t2.z_out = (bf16_t*)(W + w.z); t2.e = F(w.e);
+        t2.a1 = F(w.a1); t2.af = F(w.af); t2.stream = D + db.et2; t2.b2 = P + k.et2.b; t2.gamma = P + k.et_ln.g;
+        t2.beta = P + k.et_ln.b; t2.res_mask = res_mask; t2.trace = tr_ptr;
+        if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
+        RC(fd_edge_transition2(t2, st));
+        if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
+      } else {
       EdgeTransArgs ta;
       ta.B = B; ta.N = N; ta.z_in = W + w.z; ta.z_out = W + w.z; ta.e = F(w.e);
       ta.w1 = WM(k.et1); ta.w2 = WM(k.et2); ta.wf = WM(k.etf); ta.b1 = P + k.et1.b; ta.b2 = P + k.et2.b; ta.bf = P + k.etf.b;
       ta.gamma = P + k.et_ln.g; ta.beta = P + k.et_ln.b; ta.res_mask = res_mask;
-      ta.trace = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
+      ta.trace = tr_ptr;
       if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
       RC(fd_edge_transition(prec, cz, iv.cb, ta, st));
       if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
+      }
     }
     if (a->trace_node)
       if (hipMemcpyAsync(a->trace_node + (size_t)(b + 1) * R * cs, node_cur, (size_t)R * cs * 4, hipMemcpyDeviceToDevice,

@@ -277,3 +277,31 @@ def test_fails_loudly_on_cpu_tensors():
     from framedipt_amd import rigid as R
     with pytest.raises(_lib.FdiptError):
         R.quat_to_rot(torch.zeros(4, 4))
+
+
+def test_edge_transition_register_kernel_vs_lds_kernel():
+    """bf16 EdgeTransition: register-resident kernel (edge_transition2.hip) vs the LDS-chain kernel (pair_mlp.hip)
+    on the full-width network, and both against the fp32 reference golden."""
+    import os
+    G = load_golden("fwd_full_denovo_n64.npz")
+    rows = list(G["trace_rows"])
+    outs = {}
+    for tag, env in (("v2", None), ("v1", "1")):
+        if env is None:
+            os.environ.pop("FDIPT_ET_V1", None)
+        else:
+            os.environ["FDIPT_ET_V1"] = env
+        try:
+            net, _, conf = _net("full_denovo_n64", G, "bf16")
+            out = net(_feats(G), trace=True)
+            outs[tag] = out["trace_edge"].cpu().numpy().copy()
+        finally:
+            os.environ.pop("FDIPT_ET_V1", None)
+    for b in range(3):
+        ref = G[f"tr_edge_{b}"]
+        for tag in ("v1", "v2"):
+            got = outs[tag][b + 1][:, rows]
+            rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            assert rel < 2e-2, (tag, b, rel)
+        a, c = outs["v1"][b + 1], outs["v2"][b + 1]
+        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-2, b
