@@ -103,23 +103,36 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   return o;
 }
 
-// copy `bytes` of the stream (contiguous image) global -> registers (issue) and registers -> LDS (commit)
+// LDS-DMA copy of a contiguous piece of the weight stream: global -> LDS without passing through VGPRs
+// (global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16, so the image is simply linear).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gl_void_t;
 template <int BYTES>
-struct Stager {
-  static constexpr int NCH = BYTES / 16 / FD_THREADS;  // 16-byte chunks per thread
-  u16x8 r[NCH];
-  __device__ __forceinline__ void issue(const char* __restrict__ src, int tid) {
+__device__ __forceinline__ void dma_slab(const char* __restrict__ src, char* lds_dst, int tid) {
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) r[u] = *(const u16x8*)(src + (size_t)(tid + u * FD_THREADS) * 16);
-  }
-  __device__ __forceinline__ void commit(char* dst, int tid) {
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) *(u16x8*)(dst + (size_t)(tid + u * FD_THREADS) * 16) = r[u];
-  }
-};
+  for (int u = 0; u < BYTES / 16 / FD_THREADS; ++u)
+    __builtin_amdgcn_global_load_lds((gl_void_t*)(src + (size_t)(u * FD_THREADS + tid) * 16),
+                                     (lds_void_t*)(lds_dst + (size_t)(u * FD_THREADS + (tid & ~63)) * 16), 16, 0, 0);
+}
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* slab, int off) {
   return __builtin_bit_cast(bf16x8, *(const u16x8*)(slab + off));
+}
+
+// acc += W_slab[32 x 16*KS] * B[16*KS x 32]: A fragments stream from LDS through a DEPTH-deep register ring so that
+// every ds_read_b128 is issued DEPTH MFMAs (= DEPTH*32 cycles) ahead of its consumer.
+template <int KS, int ROWB, int DEPTH = 8>
+__device__ __forceinline__ void mma_slab(f32x16& acc, const char* slab, int li, int hi, const bf16x8* Bf) {
+  bf16x8 ring[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) ring[s] = lds_frag(slab, et2_off_wide(li, 2 * s + hi, ROWB));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % DEPTH], Bf[s], acc, 0, 0, 0);
+    if (s + DEPTH < KS) ring[s % DEPTH] = lds_frag(slab, et2_off_wide(li, 2 * (s + DEPTH) + hi, ROWB));
+    __builtin_amdgcn_sched_barrier(0);  // pin the MFMA / ds_read interleave (hipcc otherwise sinks the reads)
+  }
 }
 
 __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args a) {
@@ -151,11 +164,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     }
   }
   // prologue: first slab into buffer 0
-  {
-    Stager<ET2_SLAB_L1> sg;
-    sg.issue(stream, tid);
-    sg.commit(smem, tid);
-  }
+  dma_slab<ET2_SLAB_L1>(stream, smem, tid);
   __syncthreads();
 
   bf16x8 H1[24];
@@ -171,8 +180,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
   // ================= layer 1: 12 output tiles, K = 256
 #pragma unroll
   for (int T = 0; T < 12; ++T) {
-    Stager<ET2_SLAB_L1> sg;  // next slab (L1 T+1, or FX 0) has the same size
-    sg.issue(stream + soff + ET2_SLAB_L1, tid);
+    dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);  // next: L1 T+1 or FX 0
     f32x4 bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(a1row + 32 * T + 8 * g);
@@ -180,15 +188,12 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 512)), X[s], acc, 0, 0, 0);
+    mma_slab<16, 512>(acc, slab, li, hi, X);
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
     H1[2 * T] = pack8(v);
     H1[2 * T + 1] = pack8(v + 8);
-    sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
     __syncthreads();
     buf ^= 1;
     soff += ET2_SLAB_L1;
@@ -197,21 +202,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const char* slab = smem + buf * ET2_BUF;
-    if (t < 3) {
-      Stager<ET2_SLAB_L1> sg;
-      sg.issue(stream + soff + ET2_SLAB_L1, tid);
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 512)), X[s], Y[t], 0, 0, 0);
-      sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
-    } else {
-      Stager<ET2_BUF> sg;  // next: L2 slab 0 + FH slab 0
-      sg.issue(stream + soff + ET2_SLAB_L1, tid);
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 512)), X[s], Y[t], 0, 0, 0);
-      sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
-    }
+    if (t < 3) dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);
+    else dma_slab<ET2_BUF>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);  // next: L2 slab 0 + FH slab 0
+    mma_slab<16, 512>(Y[t], slab, li, hi, X);
     __syncthreads();
     buf ^= 1;
     soff += ET2_SLAB_L1;
@@ -220,8 +213,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
   const float* b2row = a.b2 + 4 * hi;
 #pragma unroll
   for (int T = 0; T < 12; ++T) {
-    Stager<ET2_BUF> sg;
-    if (T < 11) sg.issue(stream + soff + ET2_BUF, tid);
+    if (T < 11) dma_slab<ET2_BUF>(stream + soff + ET2_BUF, smem + (buf ^ 1) * ET2_BUF, tid);
     f32x4 bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(b2row + 32 * T + 8 * g);
@@ -229,21 +221,24 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    mma_slab<24, 768>(acc, slab, li, hi, H1);
+    const char* fh = slab + ET2_SLAB_L2;
+    bf16x8 fhf[8];  // the 8 A fragments of the fused final-layer update, fetched under the layer-2 epilogue
 #pragma unroll
-    for (int s = 0; s < 24; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(slab, et2_off_wide(li, 2 * s + hi, 768)), H1[s], acc, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      fhf[2 * t] = lds_frag(fh, et2_off_fh(32 * t + li, hi));
+      fhf[2 * t + 1] = lds_frag(fh, et2_off_fh(32 * t + li, 2 + hi));
+    }
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
     const bf16x8 h0 = pack8(v), h1 = pack8(v + 8);
-    const char* fh = slab + ET2_SLAB_L2;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(fh, et2_off_fh(32 * t + li, hi)), h0, Y[t], 0, 0, 0);
-      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(fh, et2_off_fh(32 * t + li, 2 + hi)), h1, Y[t], 0, 0, 0);
+      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t], h0, Y[t], 0, 0, 0);
+      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t + 1], h1, Y[t], 0, 0, 0);
     }
     if (T < 11) {
-      sg.commit(smem + (buf ^ 1) * ET2_BUF, tid);
       __syncthreads();
       buf ^= 1;
       soff += ET2_BUF;
