@@ -263,14 +263,20 @@ int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------ o_pair
 
-template <class ZT>
+// One block per (b, i): streams the pair row z[b,i,:,:] ONCE with 16-byte loads (HBM-bound, N*CZ*sizeof(ZT) bytes),
+// thread = (8-channel group, key slice); az[h][c] = sum_j a[h,i,j] z[i,j,c] in registers, slices folded by
+// wave shuffles then across the 4 waves through LDS; then the (c_z -> c_z/4) down-projection per head.
+template <class ZT, int CZ>
 __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int N = a.N, H = a.H, CZ = a.CZ;
-  float* ps = (float*)smem;             // [H][N]
-  float* azs = ps + H * N;              // [2][H][CZ]
-  float* psum = azs + 2 * H * CZ;       // [H]
-  const int tid = threadIdx.x;
+  constexpr int NCG = CZ / 8;              // channel groups of 8
+  constexpr int NSL = FD_THREADS / NCG;    // key slices per block
+  constexpr int SPW = 64 / NCG > 0 ? 64 / NCG : 1;  // slices inside one wave
+  const int N = a.N, H = a.H;
+  float* ps = (float*)smem;                // [H][N]
+  float* red = ps + ((H * N + 3) & ~3);    // [4 waves][8 heads][CZ]
+  float* psum = red + 4 * 8 * CZ;          // [8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = blockIdx.x, b = blockIdx.y;
   const long rb = (long)b * N;
   for (int v = tid; v < H * N; v += FD_THREADS) {
@@ -279,53 +285,79 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
   }
   __syncthreads();
   const ZT* zrow = (const ZT*)a.z + (rb + i) * N * CZ;
-  // channel c = tid % CZ; keys j interleaved over (at most two) slices so the sum order is fixed
-  const int nsl = FD_THREADS / CZ >= 2 ? 2 : 1;
-  const int c = tid % CZ, sl = tid / CZ;
-  float acc[16];
+  const int cg = tid % NCG, sl = tid / NCG;
+  float acc[8][8];
 #pragma unroll
-  for (int hh = 0; hh < 16; ++hh) acc[hh] = 0.f;
-  if (sl < nsl) {
-    for (int j = sl; j < N; j += nsl) {
-      float zv;
-      if constexpr (sizeof(ZT) == 4) zv = zrow[(long)j * CZ + c]; else zv = bf2f(zrow[(long)j * CZ + c]);
+  for (int hh = 0; hh < 8; ++hh)
 #pragma unroll
-      for (int hh = 0; hh < 16; ++hh)
-        if (hh < H) acc[hh] += ps[hh * N + j] * zv;
+    for (int c = 0; c < 8; ++c) acc[hh][c] = 0.f;
+  for (int j = sl; j < N; j += NSL) {
+    float zv[8];
+    if constexpr (sizeof(ZT) == 2) {
+      const u16x8 raw = *(const u16x8*)(zrow + (long)j * CZ + cg * 8);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) zv[c] = bf2f(raw[c]);
+    } else {
+      const f32x4 r0 = *(const f32x4*)(zrow + (long)j * CZ + cg * 8), r1 = *(const f32x4*)(zrow + (long)j * CZ + cg * 8 + 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { zv[c] = r0[c]; zv[4 + c] = r1[c]; }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+      if (hh < H) {
+        const float pv = ps[hh * N + j];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[hh][c] += pv * zv[c];
+      }
     }
   }
-  float* red = azs;  // [nsl][H][CZ]
-  if (sl < nsl)
-    for (int hh = 0; hh < H; ++hh) red[(sl * H + hh) * CZ + c] = acc[hh];
-  __syncthreads();
-  if (nsl == 2 && sl == 0)
-    for (int hh = 0; hh < H; ++hh) red[hh * CZ + c] += red[(H + hh) * CZ + c];
-  if (tid < H) {
-    float s = 0.f;
-    for (int j = 0; j < N; ++j) s += ps[tid * N + j];
-    psum[tid] = s;
+  // fold the slices that live in the same wave (lane bits above the channel-group bits)
+#pragma unroll
+  for (int o = NCG; o < 64; o <<= 1)
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[hh][c] += __shfl_xor(acc[hh][c], o, 64);
+  if (lane < NCG || NCG >= 64) {
+    if (lane < NCG)
+#pragma unroll
+      for (int hh = 0; hh < 8; ++hh)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[(wave * 8 + hh) * CZ + cg * 8 + c] = acc[hh][c];
   }
+  if (tid < H) {
+    float sacc = 0.f;
+    for (int j = 0; j < N; ++j) sacc += ps[tid * N + j];
+    psum[tid] = sacc;
+  }
+  __syncthreads();
+  for (int v = tid; v < 8 * CZ; v += FD_THREADS) red[v] = red[v] + red[8 * CZ + v] + red[16 * CZ + v] + red[24 * CZ + v];
   __syncthreads();
   const int CD = a.CD;
   for (int o = tid; o < H * CD; o += FD_THREADS) {
     const int hh = o / CD, d = o % CD;
-    float s = a.bdz[d] * psum[hh];
-    const float* w = a.wdz + (long)d * CZ;
-    for (int cc = 0; cc < CZ; ++cc) s += red[hh * CZ + cc] * w[cc];
-    a.out[(rb + i) * a.out_ld + a.off + hh * CD + d] = s;
+    float sacc = a.bdz[d] * psum[hh];
+#pragma unroll 8
+    for (int cc = 0; cc < CZ; ++cc) sacc += red[hh * CZ + cc] * a.wdz[cc * CD + d];
+    a.out[(rb + i) * a.out_ld + a.off + hh * CD + d] = sacc;
   }
+  (void)SPW; (void)NSL;
+}
+
+template <class ZT>
+static int launch_opair(const OPairArgs& a, hipStream_t st) {
+  const size_t smem = (((size_t)a.H * a.N + 3) & ~(size_t)3) * 4 + (size_t)(4 * 8 * a.CZ + 8) * 4;
+  if (smem > 64 * 1024) return FDIPT_ESIZE;
+  if (a.CZ == 128) hipLaunchKernelGGL((opair_kernel<ZT, 128>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
+  else if (a.CZ == 32) hipLaunchKernelGGL((opair_kernel<ZT, 32>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
+  else return FDIPT_EINVAL;
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
 }
 
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
-  if (a.H > 16 || a.CZ > FD_THREADS || (FD_THREADS % a.CZ)) return FDIPT_ESIZE;
-  const size_t smem = ((size_t)a.H * a.N + 2 * a.H * a.CZ + a.H + 4) * 4;
-  if (smem > 64 * 1024) return FDIPT_ESIZE;
-  if (precision == FDIPT_PREC_F32)
-    hipLaunchKernelGGL(opair_kernel<float>, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
-  else
-    hipLaunchKernelGGL(opair_kernel<bf16_t>, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
-  FD_CHECK_LAUNCH();
-  return FDIPT_OK;
+  if (a.H > 8) return FDIPT_ESIZE;
+  return precision == FDIPT_PREC_F32 ? launch_opair<float>(a, st) : launch_opair<bf16_t>(a, st);
 }
 
 // ------------------------------------------------------------------ projected points -> global frame

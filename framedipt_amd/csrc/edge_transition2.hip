@@ -135,6 +135,59 @@ __device__ __forceinline__ void mma_slab(f32x16& acc, const char* slab, int li, 
   }
 }
 
+// Y (4 tiles x 16 regs: lane = pair, features 32t + 8g + 4hi + q) += add[...]; LayerNorm over the pair's 128 features
+// (the other 64 live in lane^32); * mask; store bf16 (+ optional fp32 trace).
+__device__ __forceinline__ void ln_epilogue(f32x16 (&Y)[4], const float* __restrict__ addrow,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta, float em,
+                                            bool valid, int hi, bf16_t* __restrict__ zo_row, float* __restrict__ tr_row) {
+  float s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(addrow + 32 * t + 8 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Y[t][4 * g + q] += bv[q];
+        s1 += Y[t][4 * g + q];
+      }
+    }
+  s1 += __shfl_xor(s1, 32, 64);
+  const float mu = s1 * (1.0f / ET2_CZ);
+  float s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = Y[t][r] - mu;
+      s2 += d * d;
+    }
+  s2 += __shfl_xor(s2, 32, 64);
+  const float rstd = 1.0f / sqrtf(s2 * (1.0f / ET2_CZ) + 1e-5f);
+  if (valid) {
+    bf16_t* zo = zo_row + 4 * hi;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * t + 8 * g;
+        const f32x4 gm = *(const f32x4*)(gamma + f0 + 4 * hi), bt = *(const f32x4*)(beta + f0 + 4 * hi);
+        u16x4 o;
+        float of[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          of[q] = ((Y[t][4 * g + q] - mu) * rstd * gm[q] + bt[q]) * em;
+          o[q] = __builtin_bit_cast(unsigned short, (__bf16)of[q]);
+        }
+        *(u16x4*)(zo + f0) = o;
+        if (tr_row) {
+          f32x4 tv = {of[0], of[1], of[2], of[3]};
+          *(f32x4*)(tr_row + 4 * hi + f0) = tv;
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ET2_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -245,59 +298,127 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     }
   }
   // ================= epilogue: + Af[i], LayerNorm over the 128 features of each pair, mask, store
-  const float* afrow = a.af + bi * ET2_CZ + 4 * hi;
-  float s1 = 0.f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *(const f32x4*)(afrow + 32 * t + 8 * g);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        Y[t][4 * g + q] += bv[q];
-        s1 += Y[t][4 * g + q];
-      }
-    }
-  s1 += __shfl_xor(s1, 32, 64);
-  const float mu = s1 * (1.0f / ET2_CZ);
-  float s2 = 0.f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = Y[t][r] - mu;
-      s2 += d * d;
-    }
-  s2 += __shfl_xor(s2, 32, 64);
-  const float rstd = 1.0f / sqrtf(s2 * (1.0f / ET2_CZ) + 1e-5f);
-  const float em = a.res_mask[bi] * a.res_mask[bj];
-  if (valid) {
-    bf16_t* zo = a.z_out + p * ET2_CZ + 4 * hi;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int f0 = 32 * t + 8 * g;
-        const f32x4 gm = *(const f32x4*)(a.gamma + f0 + 4 * hi), bt = *(const f32x4*)(a.beta + f0 + 4 * hi);
-        u16x4 o;
-        float of[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          of[q] = ((Y[t][4 * g + q] - mu) * rstd * gm[q] + bt[q]) * em;
-          o[q] = __builtin_bit_cast(unsigned short, (__bf16)of[q]);
-        }
-        *(u16x4*)(zo + f0) = o;
-        if (a.trace) {
-          f32x4 tv = {of[0], of[1], of[2], of[3]};
-          *(f32x4*)(a.trace + p * ET2_CZ + 4 * hi + f0) = tv;
-        }
-      }
-  }
+  ln_epilogue(Y, a.af + bi * ET2_CZ + 4 * hi, a.gamma, a.beta, a.res_mask[bi] * a.res_mask[bj], valid, hi,
+              a.z_out + p * ET2_CZ, a.trace ? a.trace + p * ET2_CZ : nullptr);
 }
 
 int fd_edge_transition2(const ET2Args& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
   hipLaunchKernelGGL(edge_transition2_kernel, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+
+// ====================================================================================================================
+// edge_embed2_kernel — bf16 pair branch of Embedder.forward (framedipt/model/score_network.py:98-105,173-196) in the
+// same register-resident style.  Layer 1 has no GEMM: the cross-concat / relative-index / distogram features are
+// one-hot or per-residue, so h1 = relu(Pi[i] + Pj[j] + R[idx_i - idx_j] + D[bin(|ca_i - ca_j|)]) is four table rows
+// summed directly in B-fragment layout.  Layers 2 and 3 (128x128 each, 64 KB bf16 together) stay RESIDENT in LDS for
+// the whole persistent block, so there is no per-tile barrier: waves loop over 32-pair tiles independently.
+#define EE2_IMG (128 * 128 * 2)  // 32 KB per layer
+
+__global__ void ee2_build_images_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
+                                        bf16_t* __restrict__ img) {
+  const int n_chunks = 2 * EE2_IMG / 16;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_chunks; g += gridDim.x * blockDim.x) {
+    const int layer = g / (EE2_IMG / 16), q = g % (EE2_IMG / 16);
+    const int row = q / 16, cp = q % 16, c = cp ^ (row & 15);  // row = out feature (slab = row/32), 256-byte rows
+    const float* src = layer == 0 ? w2 : w3;
+    for (int e = 0; e < 8; ++e) {
+      const int k = c * 8 + e;
+      const int col = layer == 0 ? k : (k & ~15) + et2_perm16(k & 15);
+      img[(long)g * 8 + e] = f2bf(src[(long)row * 128 + col]);
+    }
+  }
+}
+int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t st) {
+  hipLaunchKernelGGL(ee2_build_images_kernel, dim3(16), dim3(256), 0, st, w2, w3, (bf16_t*)img);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+size_t fd_ee2_image_bytes() { return 2 * EE2_IMG; }
+
+__global__ __launch_bounds__(FD_THREADS, 2) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img,
+                                                                    int n_tiles) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * EE2_IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, li = lane & 31;
+  dma_slab<2 * EE2_IMG>(img, smem, tid);
+  __syncthreads();
+  const int N = a.N;
+  const long n_pairs = (long)a.B * N * N;
+  const float* b2row = a.b2 + 4 * hi;
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+    const long p_raw = (long)tile * 32 + li;
+    const bool valid = p_raw < n_pairs;
+    const long p = valid ? p_raw : n_pairs - 1;
+    const long bi = p / N;
+    const int j = (int)(p - bi * N);
+    const long bb = bi / N;
+    const long bj = bb * N + j;
+    const int rel = (int)(bb * a.n_rel) + a.seq_idx[bi] - a.seq_idx[bj] + a.rel_off;
+    int bin = a.num_bins;
+    {
+      const float dx = a.sc_ca[bi * 3 + 0] - a.sc_ca[bj * 3 + 0];
+      const float dy = a.sc_ca[bi * 3 + 1] - a.sc_ca[bj * 3 + 1];
+      const float dz = a.sc_ca[bi * 3 + 2] - a.sc_ca[bj * 3 + 2];
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      for (int k = 0; k < a.num_bins; ++k) {  // calc_distogram: strict inequalities, last upper edge 1e8
+        const float lo = a.edges[k], up = (k + 1 < a.num_bins) ? a.edges[k + 1] : 1e8f;
+        if (d > lo && d < up) bin = k;
+      }
+    }
+    const float* r1 = a.pi + bi * ET2_CZ + 8 * hi;
+    const float* r2 = a.pj + bj * ET2_CZ + 8 * hi;
+    const float* r3 = a.rtab + (long)rel * ET2_CZ + 8 * hi;
+    const float* r4 = a.dtab + (long)bin * ET2_CZ + 8 * hi;
+    bf16x8 H1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float v[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 x1 = *(const f32x4*)(r1 + 16 * s + 4 * h), x2 = *(const f32x4*)(r2 + 16 * s + 4 * h);
+        const f32x4 x3 = *(const f32x4*)(r3 + 16 * s + 4 * h), x4 = *(const f32x4*)(r4 + 16 * s + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[4 * h + q] = fmaxf(x1[q] + x2[q] + x3[q] + x4[q], 0.f);
+      }
+      H1[s] = pack8(v);
+    }
+    bf16x8 H2[8];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      f32x4 bias[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(b2row + 32 * T + 8 * g);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      mma_slab<8, 256>(acc, smem + T * 32 * 256, li, hi, H1);
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
+      H2[2 * T] = pack8(v);
+      H2[2 * T + 1] = pack8(v + 8);
+    }
+    f32x16 Y[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
+      mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
+    }
+    ln_epilogue(Y, a.b3 + 4 * hi, a.gamma, a.beta, a.res_mask[bi] * a.res_mask[bj], valid, hi,
+                (bf16_t*)a.z_out + p * ET2_CZ, a.trace ? a.trace + p * ET2_CZ : nullptr);
+  }
+}
+
+int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
+  const long n_pairs = (long)a.B * a.N * a.N;
+  const int n_tiles = cdiv(n_pairs, 32);
+  const int grid = n_tiles / 4 + 1 < 512 ? n_tiles / 4 + 1 : 512;
+  hipLaunchKernelGGL(edge_embed2_kernel, dim3(grid), dim3(FD_THREADS), 0, st, a, (const char*)img, n_tiles);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -1,46 +1,131 @@
 // gemm.hip — generic Linear (+bias/ReLU/mask/residual), LayerNorm and the MFMA self-test.
 // Replaces the per-residue torch.nn.Linear / LayerNorm calls of the score network
 // (framedipt/model/ipa_pytorch.py:36-58,202-239,325,386-413,531-541; score_network.py:86-96).
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
-// C[M,N] = epi(A[M,K] * W[N,K]^T): block tile 64x64, 4 waves as 2x2, each wave one 32x32 accumulator.
-template <class P, class AT, class WT>
+// C[M,N] = epi(A[M,K] * W[N,K]^T).  Block tile BM x BN (64x64 or 128x128), 4 waves as 2x2, BK = 64, LDS double
+// buffer, next k-tile prefetched into registers while the current one feeds the MFMAs (one barrier per k-tile).
+template <class P, class SrcT, int ROWS>
+struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading dimension ld
+  static constexpr int EPV = 16 / sizeof(SrcT);          // elements per 16-byte vector
+  static constexpr int VPR = 64 / EPV;                   // vectors per row
+  static constexpr int NV = ROWS * VPR / FD_THREADS;     // vectors per thread
+  typedef typename std::conditional<sizeof(SrcT) == 4, f32x4, u16x8>::type V;
+  V r[NV];
+  __device__ __forceinline__ void load(const SrcT* __restrict__ src, long ld, int row0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int v = tid + u * FD_THREADS, rr = v / VPR, kk = (v % VPR) * EPV;
+      V x;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) x[e] = 0;
+      if (row0 + rr < nrows && k0 + kk < K) x = *(const V*)(src + (long)(row0 + rr) * ld + k0 + kk);
+      r[u] = x;
+    }
+  }
+  __device__ __forceinline__ void store(typename P::T* dst, int tid) const {
+    constexpr int LDT = 64 + P::PAD;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int v = tid + u * FD_THREADS, rr = v / VPR, kk = (v % VPR) * EPV;
+      typename P::T* d = dst + rr * LDT + kk;
+      if constexpr (sizeof(SrcT) == 4 && sizeof(typename P::T) == 4) {
+        d[0] = r[u][0]; d[1] = r[u][1]; d[2] = r[u][2]; d[3] = r[u][3];
+      } else if constexpr (sizeof(SrcT) == 4) {
+        u16x4 h = {f2bf(r[u][0]), f2bf(r[u][1]), f2bf(r[u][2]), f2bf(r[u][3])};
+        *(u16x4*)d = h;
+      } else {
+        *(u16x8*)d = r[u];
+      }
+    }
+  }
+};
+
+template <class P, class AT, class WT, int BM, int BN>
 __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K, const AT* __restrict__ A, int lda,
                                                             const WT* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ residual, int ldr,
                                                             const float* __restrict__ rowmask, int relu,
                                                             float* __restrict__ out, int ldo) {
-  constexpr int LDT = P::BK + P::PAD;
-  __shared__ __attribute__((aligned(16))) typename P::T As[64 * LDT];
-  __shared__ __attribute__((aligned(16))) typename P::T Ws[64 * LDT];
+  constexpr int BKL = 64, LDT = BKL + P::PAD;
+  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in each direction
+  __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
+  constexpr int STAGE = (BM + BN) * LDT;  // elements per pipeline stage: A tile then W tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-  f32x16 acc;
+  const int wr = wave >> 1, wc = wave & 1, hi = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += P::BK) {
-    stage_tile<P, AT, 64>(As, A, lda, m0, M, k0, K, tid);
-    stage_tile<P, WT, 64>(Ws, W, ldw, n0, N, k0, K, tid);
-    __syncthreads();
-    wave_mma<P>(acc, As + (wr * 32 + (lane & 31)) * LDT, Ws + (wc * 32 + (lane & 31)) * LDT, lane);
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+  TilePrefetch<P, AT, BM> pa;
+  TilePrefetch<P, WT, BN> pw;
+  pa.load(A, lda, m0, M, 0, K, tid);
+  pw.load(W, ldw, n0, N, 0, K, tid);
+  pa.store(smem, tid);
+  pw.store(smem + BM * LDT, tid);
+  __syncthreads();
+  const int nk = (K + BKL - 1) / BKL;
+  for (int kt = 0; kt < nk; ++kt) {
+    const typename P::T* Ac = smem + (kt & 1) * STAGE;
+    const typename P::T* Wc = Ac + BM * LDT;
+    typename P::T* An = smem + ((kt + 1) & 1) * STAGE;
+    if (kt + 1 < nk) {
+      pa.load(A, lda, m0, M, (kt + 1) * BKL, K, tid);
+      pw.load(W, ldw, n0, N, (kt + 1) * BKL, K, tid);
+    }
+#pragma unroll
+    for (int k = 0; k < BKL; k += P::KS)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+          P::mma(acc[i][jn], Ac + ((wr * TM + i) * 32 + (lane & 31)) * LDT + k,
+                 Wc + ((wc * TN + jn) * 32 + (lane & 31)) * LDT + k, hi);
+    if (kt + 1 < nk) {
+      pa.store(An, tid);
+      pw.store(An + BM * LDT, tid);
+    }
     __syncthreads();
   }
-  const int n = n0 + wc * 32 + (lane & 31);
-  if (n >= N) return;
-  const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wr * 32 + c_row(r, lane);
-    if (m < M) {
-      float v = acc[r] + bv;
-      if (relu) v = fmaxf(v, 0.f);
-      if (rowmask) v *= rowmask[m];
-      if (residual) v += residual[(long)m * ldr + n];
-      out[(long)m * ldo + n] = v;
-    }
+  for (int jn = 0; jn < TN; ++jn) {
+    const int n = n0 + (wc * TN + jn) * 32 + (lane & 31);
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wr * TM + i) * 32 + c_row(r, lane);
+        if (m < M) {
+          float v = acc[i][jn][r] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (rowmask) v *= rowmask[m];
+          if (residual) v += residual[(long)m * ldr + n];
+          out[(long)m * ldo + n] = v;
+        }
+      }
+  }
+}
+
+template <class P, class AT, class WT>
+static void launch_tiles(int M, int N, int K, const AT* A, int lda, const WT* W, int ldw, const float* bias,
+                         const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo,
+                         hipStream_t st) {
+  if (M >= 1024 && N >= 1024) {
+    hipLaunchKernelGGL((linear_kernel<P, AT, WT, 128, 128>), dim3(cdiv(M, 128), cdiv(N, 128)), dim3(FD_THREADS), 0, st, M,
+                       N, K, A, lda, W, ldw, bias, residual, ldr, rowmask, relu, out, ldo);
+  } else {
+    hipLaunchKernelGGL((linear_kernel<P, AT, WT, 64, 64>), dim3(cdiv(M, 64), cdiv(N, 64)), dim3(FD_THREADS), 0, st, M, N, K,
+                       A, lda, W, ldw, bias, residual, ldr, rowmask, relu, out, ldo);
   }
 }
 
@@ -48,13 +133,12 @@ static int launch_linear(int precision, int M, int N, int K, const float* A, int
                          const float* bias, const float* residual, int ldr, const float* rowmask, int relu, float* out,
                          int ldo, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !out || (K & 7) || (lda & 3) || (ldw & 7)) return FDIPT_EINVAL;
-  dim3 grid(cdiv(M, 64), cdiv(N, 64));
   if (precision == FDIPT_PREC_F32)
-    hipLaunchKernelGGL((linear_kernel<PrecF32, float, float>), grid, dim3(FD_THREADS), 0, st, M, N, K, A, lda,
-                       (const float*)W, ldw, bias, residual, ldr, rowmask, relu, out, ldo);
+    launch_tiles<PrecF32, float, float>(M, N, K, A, lda, (const float*)W, ldw, bias, residual, ldr, rowmask, relu, out, ldo,
+                                        st);
   else
-    hipLaunchKernelGGL((linear_kernel<PrecBF16, float, bf16_t>), grid, dim3(FD_THREADS), 0, st, M, N, K, A, lda,
-                       (const bf16_t*)W, ldw, bias, residual, ldr, rowmask, relu, out, ldo);
+    launch_tiles<PrecBF16, float, bf16_t>(M, N, K, A, lda, (const bf16_t*)W, ldw, bias, residual, ldr, rowmask, relu, out,
+                                          ldo, st);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -63,13 +147,12 @@ static int launch_linear(int precision, int M, int N, int K, const float* A, int
 int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,
                 hipStream_t st) {
   if (M <= 0 || (K & 7)) return FDIPT_EINVAL;
-  dim3 grid(cdiv(M, 64), cdiv(N, 64));
   if (precision == FDIPT_PREC_F32)
-    hipLaunchKernelGGL((linear_kernel<PrecF32, float, float>), grid, dim3(FD_THREADS), 0, st, (int)M, N, K, (const float*)A,
-                       K, (const float*)W, K, bias, nullptr, 0, nullptr, 0, out, N);
+    launch_tiles<PrecF32, float, float>((int)M, N, K, (const float*)A, K, (const float*)W, K, bias, nullptr, 0, nullptr, 0,
+                                        out, N, st);
   else
-    hipLaunchKernelGGL((linear_kernel<PrecBF16, bf16_t, bf16_t>), grid, dim3(FD_THREADS), 0, st, (int)M, N, K,
-                       (const bf16_t*)A, K, (const bf16_t*)W, K, bias, nullptr, 0, nullptr, 0, out, N);
+    launch_tiles<PrecBF16, bf16_t, bf16_t>((int)M, N, K, (const bf16_t*)A, K, (const bf16_t*)W, K, bias, nullptr, 0, nullptr,
+                                           0, out, N, st);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

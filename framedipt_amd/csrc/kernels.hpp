@@ -39,7 +39,7 @@ struct AttnArgs {
   int q_hs, k_hs, v_hs;
   int C, Dv;        // qk feature dim, value dim
   float scale;      // multiplies QK^T
-  const float* bias;      // [B,N,N,H] f32 (already scaled) or NULL
+  const float* bias;      // f32, already scaled: [B,N,N,H] (attention.hip) or [B,H,N,N] (attention2.hip); NULL if none
   const float* res_mask;  // [B,N]
   // IPA only
   const float *qp, *kp, *vp;  // [B,N,H,Pq,3], [B,N,H,Pq,3], [B,N,H,Pv,3] global-frame points (scaled units)
@@ -58,7 +58,7 @@ struct OPairArgs {
   int B, N, H, CZ, CD;   // CD = CZ/4
   const void* z;         // [B,N,N,CZ] ZT
   const float* probs;    // [B,H,N,N]
-  const float* wdz;      // [CD,CZ] f32
+  const float* wdz;      // [CZ,CD] f32 (down_z weight, transposed)
   const float* bdz;      // [CD]
   float* out;            // row (b*N+i): out + r*out_ld + off + h*CD + d
   long out_ld;
@@ -89,6 +89,9 @@ struct ET2Args {
 int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et2_stream_bytes();
 int fd_edge_transition2(const ET2Args& a, hipStream_t st);
+int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t st);
+size_t fd_ee2_image_bytes();
+int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st);
 
 int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
               const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, hipStream_t st);
@@ -101,6 +104,9 @@ int fd_edge_transition(int precision, int cz, int cb, const EdgeTransArgs& a, hi
 int fd_edge_embed(int precision, int cz, const EdgeEmbedArgs& a, hipStream_t st);
 int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st);
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
+int fd_attention2_supported(int ipa, const AttnArgs& a);
+int fd_attention2(int ipa, const AttnArgs& a, hipStream_t st);
+int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, hipStream_t st);
 int fd_points(const PointsArgs& a, hipStream_t st);
 int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask, hipStream_t st);
 int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,

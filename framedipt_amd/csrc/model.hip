@@ -92,11 +92,12 @@ static void build_inventory(const FdiptDims* d, Inventory& iv) {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, et2; };
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, et2, wdz_t; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
   size_t w1i, w1j, w1r, dtab, edges, b1;  // fp32 pieces of the concat-free first edge-embedder layer
+  size_t ee2;         // LDS images of edge-embedder layers 2/3 (register-resident bf16 kernel)
   DBlock blk[FD_MAX_BLOCKS];
   size_t total;
   int kn_pad, d1_pad, esz;
@@ -121,12 +122,15 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   L.dtab = o; o = al256(o + (size_t)(d->num_bins + 1) * d->c_z * 4);
   L.edges = o; o = al256(o + (size_t)d->num_bins * 4);
   L.b1 = o; o = al256(o + (size_t)d->c_z * 4);
+  L.ee2 = o;
+  if (use_et2(d)) o = al256(o + fd_ee2_image_bytes());
   for (int b = 0; b < d->num_blocks; ++b) {
     L.blk[b].wproj = o; o = al256(o + (size_t)iv.proj_out * d->c_s * L.esz);
     L.blk[b].bproj = o; o = al256(o + (size_t)iv.proj_out * 4);
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
+    L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et2 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
   }
@@ -170,6 +174,11 @@ __global__ void misc_prepare_kernel(int cz, int nb, int ld_w, int col0, const fl
     const double step = ((double)max_bin - (double)min_bin) / (double)(nb - 1);
     edges[threadIdx.x] = threadIdx.x == nb - 1 ? max_bin : (float)((double)min_bin + step * threadIdx.x);
   }
+}
+// dst[c][r] = src[r][c]  (down_z weight transposed for coalesced reads in opair_kernel)
+__global__ void transpose_kernel(int rows, int cols, const float* __restrict__ src, float* __restrict__ dst) {
+  const int n = rows * cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[(i % cols) * rows + i / cols] = src[i];
 }
 __global__ void gamma_kernel(int H, int Pq, const float* __restrict__ head_w, float* __restrict__ gamma) {
   const int h = threadIdx.x;
@@ -226,6 +235,8 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
                      P + iv.ee0.w, d->min_bin, d->max_bin, (float*)(D + L.dtab), (float*)(D + L.edges));
   FD_CHECK_LAUNCH();
   if ((rc = copy_cols(4, 1, cz, cz, P + iv.ee0.b, cz, 0, 1.f, D + L.b1, st))) return rc;
+  if (use_et2(d))
+    if ((rc = fd_ee2_build_images(P + iv.ee2.w, P + iv.ee4.w, D + L.ee2, st))) return rc;
   const float s3 = sqrtf(1.0f / 3.0f);
   for (int b = 0; b < d->num_blocks; ++b) {
     const BlockW& k = iv.blk[b];
@@ -246,6 +257,8 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     // pair bias pre-scaled by sqrt(1/3) (ipa_pytorch.py:256-257)
     if ((rc = copy_cols(L.esz, H, cz, cz, P + k.lb.w, cz, 0, s3, D + db.wb, st))) return rc;
     if ((rc = copy_cols(4, 1, H, H, P + k.lb.b, H, 0, s3, D + db.bb, st))) return rc;
+    hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
+    FD_CHECK_LAUNCH();
     if (use_et2(d) && b < d->num_blocks - 1)
       if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st))) return rc;
   }
@@ -372,7 +385,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     ea.w2 = WM(iv.ee2); ea.w3 = WM(iv.ee4); ea.b2 = P + iv.ee2.b; ea.b3 = P + iv.ee4.b;
     ea.gamma = P + iv.eeln.g; ea.beta = P + iv.eeln.b; ea.res_mask = res_mask; ea.z_out = W + w.z;
     ea.trace = a->trace_edge;
-    RC(fd_edge_embed(prec, cz, ea, st));
+    if (use_et2(d)) RC(fd_edge_embed2(ea, D + L.ee2, st));
+    else RC(fd_edge_embed(prec, cz, ea, st));
   }
   if (a->trace_node)
     if (hipMemcpyAsync(a->trace_node, F(w.node0), (size_t)R * cs * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -395,7 +409,6 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
       RC(fd_points(pa, st));
     }
-    RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));
     {
       AttnArgs aa;
       aa.B = B; aa.N = N; aa.H = H;
@@ -406,10 +419,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       aa.bias = F(w.bias); aa.res_mask = res_mask; aa.qp = F(w.qp); aa.kp = F(w.kp); aa.vp = F(w.vp); aa.Pq = Pq; aa.Pv = Pv;
       aa.gamma = (const float*)(D + db.gamma); aa.rot = F(w.rot); aa.trans = F(w.trans); aa.probs = F(w.probs);
       aa.out = F(w.feats); aa.out_ld = iv.feat_dim; aa.pt_off = H * C; aa.lds_s = 0;
-      RC(fd_attention(prec, 1, aa, st));
+      if (bf && cz == 128 && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(1, aa)) {
+        RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,H,N,N]
+        RC(fd_attention2(1, aa, st));
+      } else {
+        RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
+        RC(fd_attention(prec, 1, aa, st));
+      }
       OPairArgs oa;
       oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs);
-      oa.wdz = P + k.dz.w; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
+      oa.wdz = (const float*)(D + db.wdz_t); oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
       RC(fd_opair(prec, oa, st));
     }
     RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
@@ -429,7 +448,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       ta.C = hd; ta.Dv = hd; ta.scale = 1.0f / sqrtf((float)hd); ta.bias = nullptr; ta.res_mask = res_mask;
       ta.qp = ta.kp = ta.vp = nullptr; ta.Pq = ta.Pv = 0; ta.gamma = nullptr; ta.rot = ta.trans = nullptr; ta.probs = nullptr;
       ta.out = F(w.att); ta.out_ld = dt; ta.pt_off = 0; ta.lds_s = 0;
-      RC(fd_attention(prec, 0, ta, st));
+      if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
+      else RC(fd_attention(prec, 0, ta, st));
       RC(lin(R, t.outp, F(w.att), dt, nullptr, 0, nullptr, 0, F(w.ff), dt));
       RC(fd_layernorm(R, dt, x, dt, F(w.ff), dt, P + t.n1.g, P + t.n1.b, nullptr, F(w.x_a), dt, st));
       RC(lin(R, t.l1, F(w.x_a), dt, nullptr, 0, nullptr, 1, F(w.ff), dt));

@@ -297,6 +297,10 @@ def test_edge_transition_register_kernel_vs_lds_kernel():
             outs[tag] = out["trace_edge"].cpu().numpy().copy()
         finally:
             os.environ.pop("FDIPT_ET_V1", None)
+    for tag in ("v1", "v2"):  # edge embedder (trace slot 0): edge_embed2_kernel vs edge_embed_kernel
+        rel = np.linalg.norm(outs[tag][0][:, rows] - G["tr_edge_init"]) / np.linalg.norm(G["tr_edge_init"])
+        assert rel < 1e-2, (tag, "embed", rel)
+    assert np.linalg.norm(outs["v1"][0] - outs["v2"][0]) / np.linalg.norm(outs["v1"][0]) < 1e-2
     for b in range(3):
         ref = G[f"tr_edge_{b}"]
         for tag in ("v1", "v2"):
@@ -305,3 +309,28 @@ def test_edge_transition_register_kernel_vs_lds_kernel():
             assert rel < 2e-2, (tag, b, rel)
         a, c = outs["v1"][b + 1], outs["v2"][b + 1]
         assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-2, b
+
+
+def test_register_attention_vs_lds_attention():
+    """bf16 attention kernels of attention2.hip (scores in registers) vs attention.hip (scores in LDS): node
+    representation after every block on the full-width network."""
+    import os
+    G = load_golden("fwd_full_denovo_n64.npz")
+    outs = {}
+    for tag, env in (("v2", None), ("v1", "1")):
+        if env is None:
+            os.environ.pop("FDIPT_ATTN_V1", None)
+        else:
+            os.environ["FDIPT_ATTN_V1"] = env
+        try:
+            net, _, conf = _net("full_denovo_n64", G, "bf16")
+            out = net(_feats(G), trace=True)
+            outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["rigids"].cpu().numpy().copy())
+        finally:
+            os.environ.pop("FDIPT_ATTN_V1", None)
+    for b in range(4):
+        a, c = outs["v1"][0][b + 1], outs["v2"][0][b + 1]
+        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, b
+        ref = G[f"tr_node_{b}"]
+        assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, b
+    np.testing.assert_allclose(outs["v1"][1][..., 4:], outs["v2"][1][..., 4:], atol=2e-2)
