@@ -1,0 +1,282 @@
+// attention3.hip — invariant point attention core (framedipt/model/ipa_pytorch.py:251-313), bf16, reference widths
+// (C = 256, 8 q/k points, 12 v points, H <= 8), N <= 512.
+//
+// One block = 32 queries of one (batch, head); the KEYS are dealt round-robin to the block's 4 waves in tiles of 32,
+// so every lane holds only N/8 scores.  Operands come pre-formatted from ipa_proj_kernel (gemm.hip):
+//   scalar logits    S^T[key, query] = Kb_tile * Qb^T            bf16 MFMA, A (K rows) straight from HBM/L2, B = Q regs
+//   point logits     -1/2 |q_pt - k_pt|^2 = q.k - |k|^2/2 - |q|^2/2  as a 26-deep fp32 MFMA (exact fp32 FMA chain):
+//                    A = [k_pts | -|k|^2/2 | 1] rows straight from HBM, B = [q_pts | 1 | -|q|^2/2] registers
+//   mask             m_i m_j as one more fp32 MFMA step (padded keys carry a -1e25 marker)
+//   softmax          registers + lane^32 shuffle, cross-wave max / sum through 2 x 128 floats of LDS
+//   o = a v          P fragments are exchanged through LDS once; wave w then owns d tiles {2w, 2w+1} over ALL keys,
+//                    A = Vt rows (V transposed, key-permuted) straight from HBM/L2 — no LDS staging, no reduction
+//   o_pt             fp32 VALU over the wave's own keys against broadcast LDS reads of v_pts, 4-way LDS reduction
+// LDS holds only v_pts (N x 36 fp32), the P fragments (N x 64 bf16) and the small reduction buffers.
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define A3_C 256
+#define A3_NTW 4  // key tiles per wave -> N <= 4 * 4 * 32 = 512
+
+__device__ __forceinline__ bf16x8 a3_pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+  return o;
+}
+__device__ __forceinline__ bf16x8 a3_ld(const bf16_t* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
+
+__global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.N, H = a.H, nt = (N + 31) / 32, Np = nt * 32;
+  float* vps = (float*)smem;                                 // [Np][36]
+  float* mxs = vps + Np * 36;                                // [4][32]
+  float* sms = mxs + 128;                                    // [4][32]
+  float* opr = sms + 128;                                    // [4][32][36]
+  u16x8* Pfs = (u16x8*)(opr + 4 * 32 * 36);                  // [2*nt][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long rb = (long)b * N, bh = (long)b * H + h;
+  const int i_raw = blockIdx.x * 32 + li;
+  const bool valid = i_raw < N;
+  const int i = valid ? i_raw : N - 1;
+
+  // ---- v_pts of this head -> LDS (first read after the first barrier)
+  {
+    constexpr int NVV = (A3_NTW * 4 * 32 * 9 + FD_THREADS - 1) / FD_THREADS;  // 18
+    for (int u0 = 0; u0 < NVV; u0 += 6) {
+      f32x4 tv[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int v = tid + (u0 + u) * FD_THREADS, j = v / 9, c = (v % 9) * 4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (j < N) x = *(const f32x4*)(a.vp + ((rb + j) * H + h) * 36 + c);
+        tv[u] = x;
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int v = tid + (u0 + u) * FD_THREADS;
+        if (v < Np * 9) *(f32x4*)(vps + v * 4) = tv[u];
+      }
+    }
+  }
+  // ---- query-side registers
+  bf16x8 Qf[16];
+  {
+    const bf16_t* qr = a.Qb + (bh * N + i) * A3_C + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) Qf[s] = a3_ld(qr + 16 * s);
+  }
+  float qB[13];  // B operand of the point product: k index 2s+hi
+  {
+    const float* qpr = a.qp + ((rb + i) * H + h) * 24;
+    float qn = 0.f;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) qn += qpr[c] * qpr[c];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) qB[s] = qpr[2 * s + hi];
+    qB[12] = hi ? -0.5f * qn : 1.0f;
+  }
+  const float mi = a.res_mask[rb + i];
+  const float gam = a.gamma[h];
+  const float* brow = a.bias + (bh * N + i) * N;
+
+  // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...
+  f32x16 S[A3_NTW];
+#pragma unroll
+  for (int u = 0; u < A3_NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt) {
+      const int jA_raw = 32 * t + li;          // key owned by this lane as an A-operand ROW
+      const bool vA = jA_raw < N;
+      const int jA = vA ? jA_raw : N - 1;
+      const bf16_t* kr = a.Kb + (bh * N + jA) * A3_C + 8 * hi;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld(kr + 16 * s), Qf[s], acc, 0, 0, 0);
+      // point term: A row = [k_pts(24) | -|k|^2/2 | 1]
+      float kpv[24];
+      {
+        const float* kpr = a.kp + ((rb + jA) * H + h) * 24;
+#pragma unroll
+        for (int c4 = 0; c4 < 6; ++c4) {
+          const f32x4 x = *(const f32x4*)(kpr + 4 * c4);
+          kpv[4 * c4] = x[0]; kpv[4 * c4 + 1] = x[1]; kpv[4 * c4 + 2] = x[2]; kpv[4 * c4 + 3] = x[3];
+        }
+      }
+      float kn = 0.f;
+#pragma unroll
+      for (int c = 0; c < 24; ++c) kn += kpv[c] * kpv[c];
+      f32x16 accp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 12; ++s)
+        accp = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? kpv[2 * s + 1] : kpv[2 * s], qB[s], accp, 0, 0, 0);
+      accp = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], accp, 0, 0, 0);
+      // mask product m_i m_j (padded keys: marker so that the logit becomes -1e30)
+      f32x16 accm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accm[r] = 0.f;
+      const float mA = vA ? a.res_mask[rb + jA] : -1e25f;
+      accm = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : mA, hi ? 0.f : mi, accm, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j0 = 32 * t + 8 * g + 4 * hi;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (j0 + 3 < N && (N & 3) == 0) bv = *(const f32x4*)(brow + j0);
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[q] = j0 + q < N ? brow[j0 + q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * g + q;
+          acc[r] = acc[r] + bv[q] + gam * accp[r] + 1e5f * (accm[r] - 1.f);
+        }
+      }
+      S[u] = acc;
+    }
+  }
+  // ---- phase 2: softmax over all keys (own registers -> lane^32 -> the other 3 waves through LDS)
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int u = 0; u < A3_NTW; ++u)
+    if (wave + 4 * u < nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[u][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (hi == 0) mxs[wave * 32 + li] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(mxs[li], mxs[32 + li]), fmaxf(mxs[64 + li], mxs[96 + li]));
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < A3_NTW; ++u)
+    if (wave + 4 * u < nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf(S[u][r] - mx);
+        S[u][r] = e;
+        sum += e;
+      }
+  sum += __shfl_xor(sum, 32, 64);
+  if (hi == 0) sms[wave * 32 + li] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (sms[li] + sms[32 + li] + sms[64 + li] + sms[96 + li]);
+  // ---- phase 3: normalise; attention weights -> HBM (for o_pair), P fragments -> LDS, partial o_pt
+  float op[36];
+#pragma unroll
+  for (int c = 0; c < 36; ++c) op[c] = 0.f;
+  float* prow = a.probs + (bh * N + i) * N;
+#pragma unroll
+  for (int u = 0; u < A3_NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = S[u][r] * inv;
+      if (valid) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j0 = 32 * t + 8 * g + 4 * hi;
+          if (j0 + 3 < N && (N & 3) == 0) {
+            f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            *(f32x4*)(prow + j0) = o;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (j0 + q < N) prow[j0 + q] = v[4 * g + q];
+          }
+        }
+      }
+      Pfs[(2 * t) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(v));
+      Pfs[(2 * t + 1) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(v + 8));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float* vj = vps + j * 36;
+        const float p = v[r];
+#pragma unroll
+        for (int c4 = 0; c4 < 9; ++c4) {
+          const f32x4 x = *(const f32x4*)(vj + 4 * c4);
+          op[4 * c4] += p * x[0]; op[4 * c4 + 1] += p * x[1]; op[4 * c4 + 2] += p * x[2]; op[4 * c4 + 3] += p * x[3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 36; ++c) op[c] += __shfl_xor(op[c], 32, 64);
+  if (hi == 0) {
+#pragma unroll
+    for (int c4 = 0; c4 < 9; ++c4) {
+      f32x4 o = {op[4 * c4], op[4 * c4 + 1], op[4 * c4 + 2], op[4 * c4 + 3]};
+      *(f32x4*)(opr + (wave * 32 + li) * 36 + 4 * c4) = o;
+    }
+  }
+  __syncthreads();
+  // ---- phase 4a: o_pt = R_i^T (sum - t_i) and its norm (ipa_pytorch.py:296-308), 32 queries x 12 points
+  for (int it = tid; it < 32 * 12; it += FD_THREADS) {
+    const int q = it / 12, pt = it % 12, iq = blockIdx.x * 32 + q;
+    if (iq < N) {
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float* o = opr + (w * 32 + q) * 36 + pt * 3;
+        sx += o[0]; sy += o[1]; sz += o[2];
+      }
+      const float* R = a.rot + (rb + iq) * 9;
+      const float* T = a.trans + (rb + iq) * 3;
+      const float x = sx - T[0], y = sy - T[1], z = sz - T[2];
+      const float ox = R[0] * x + R[3] * y + R[6] * z;
+      const float oy = R[1] * x + R[4] * y + R[7] * z;
+      const float oz = R[2] * x + R[5] * y + R[8] * z;
+      const int HP = H * 12;
+      float* o = a.out + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
+      o[0] = ox; o[HP] = oy; o[2 * HP] = oz;
+      o[3 * HP] = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
+    }
+  }
+  // ---- phase 4b: O^T[d, query] for d tiles {2w, 2w+1} over all keys: A = Vt rows from HBM/L2, B = P from LDS
+#pragma unroll 1
+  for (int dd = 0; dd < 2; ++dd) {
+    const int dt = 2 * wave + dd;
+    const bf16_t* vr = a.Vt + (bh * A3_C + 32 * dt + li) * a.Np + 8 * hi;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < 2 * nt; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld(vr + 16 * s), __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc,
+                                                    0, 0, 0);
+    if (valid) {
+      float* orow = a.out + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *(f32x4*)(orow + 8 * g) = o;
+      }
+    }
+  }
+}
+
+int fd_attention3_supported(const Attn3Args& a) {
+  return a.N >= 1 && a.N <= A3_NTW * 4 * 32 && a.H <= 8 && a.Np == ((a.N + 31) / 32) * 32;
+}
+
+int fd_attention3(const Attn3Args& a, hipStream_t st) {
+  const int nt = (a.N + 31) / 32, Np = nt * 32;
+  const size_t smem = (size_t)Np * 36 * 4 + 2 * 128 * 4 + (size_t)4 * 32 * 36 * 4 + (size_t)2 * nt * 64 * 16 + 16;
+  if (smem > 160 * 1024) return FDIPT_ESIZE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)ipa_attn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ipa_attn3_kernel, dim3(nt, a.H, a.B), dim3(FD_THREADS), smem, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

@@ -44,21 +44,16 @@ struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading 
   }
 };
 
+// main loop shared by every GEMM kernel: acc[TM][TN] (32x32 tiles of this wave) = A[m0.., :K] * W[n0.., :K]^T
 template <class P, class AT, class WT, int BM, int BN>
-__global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K, const AT* __restrict__ A, int lda,
-                                                            const WT* __restrict__ W, int ldw,
-                                                            const float* __restrict__ bias,
-                                                            const float* __restrict__ residual, int ldr,
-                                                            const float* __restrict__ rowmask, int relu,
-                                                            float* __restrict__ out, int ldo) {
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[BM / 64][BN / 64], int M, int N, int K,
+                                          const AT* __restrict__ A, int lda, const WT* __restrict__ W, int ldw,
+                                          typename P::T* smem, int m0, int n0, int tid) {
   constexpr int BKL = 64, LDT = BKL + P::PAD;
-  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in each direction
-  __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
+  constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int STAGE = (BM + BN) * LDT;  // elements per pipeline stage: A tile then W tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, hi = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -95,6 +90,23 @@ __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K,
     }
     __syncthreads();
   }
+}
+
+template <class P, class AT, class WT, int BM, int BN>
+__global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K, const AT* __restrict__ A, int lda,
+                                                            const WT* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, int ldr,
+                                                            const float* __restrict__ rowmask, int relu,
+                                                            float* __restrict__ out, int ldo) {
+  constexpr int LDT = 64 + P::PAD;
+  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in each direction
+  __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc[TM][TN];
+  gemm_tile<P, AT, WT, BM, BN>(acc, M, N, K, A, lda, W, ldw, smem, m0, n0, tid);
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
     const int n = n0 + (wc * TN + jn) * 32 + (lane & 31);
@@ -114,6 +126,91 @@ __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K,
         }
       }
   }
+}
+
+// ------------------------------------------------------------------ IPA projection with attention-operand epilogue
+// [q | kv | q_pts | kv_pts] = s W^T + b (ipa_pytorch.py:202-239) written directly as the operand images the
+// register attention kernel (attention3.hip) consumes:
+//   Qb [B,H,N,C]  bf16, pre-multiplied by sqrt(1/(3C))            (A/B fragments: 16-byte loads)
+//   Kb [B,H,N,C]  bf16
+//   Vt [B,H,C,Np] bf16, V transposed, keys permuted inside every 16-group (perm16: C/D fragment -> B fragment order)
+//   pts [B*N, PT] fp32, raw point projections (rotated into the global frame by points_kernel)
+__device__ __forceinline__ int g_perm16(int pos) { return 4 * (pos >> 3) + (pos & 3) + 8 * ((pos & 7) >> 2); }
+
+__global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
+  typedef PrecBF16 P;
+  constexpr int BM = 128, BN = 128, LDT = 64 + P::PAD, TM = 2, TN = 2;
+  __shared__ __attribute__((aligned(16))) P::T smem[2 * (BM + BN) * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = a.B * a.N, HC = a.H * a.C, NOUT = 3 * HC + a.PT;
+  f32x16 acc[TM][TN];
+  gemm_tile<P, float, bf16_t, BM, BN>(acc, M, NOUT, a.K, a.A, a.lda, (const bf16_t*)a.W, a.K, smem, m0, n0, tid);
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int n = n0 + (wc * TN + jn) * 32 + (lane & 31);
+    if (n >= NOUT) continue;
+    const float bv = a.bias[n];
+    // column class (uniform per lane)
+    int kind, hh = 0, cc = 0;
+    if (n < HC) { kind = 0; hh = n / a.C; cc = n % a.C; }
+    else if (n < 3 * HC) {
+      const int nn = n - HC;
+      hh = nn / (2 * a.C);
+      cc = nn % (2 * a.C);
+      kind = cc < a.C ? 1 : 2;
+      if (kind == 2) cc -= a.C;
+    } else { kind = 3; cc = n - 3 * HC; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int mg = m0 + (wr * TM + i) * 32 + 8 * g + 4 * (lane >> 5);  // 4 consecutive rows mg .. mg+3
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][jn][4 * g + q] + bv;
+        if (kind == 2 && mg + 3 < M && (a.N & 3) == 0) {
+          const int b = mg / a.N, key = mg - b * a.N;  // 4 keys of one sample (N % 4 == 0), contiguous after perm16
+          u16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          *(u16x4*)(a.Vt + (((long)b * a.H + hh) * a.C + cc) * a.Np + (key & ~15) + g_perm16(key & 15)) = o;
+          continue;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = mg + q;
+          if (m >= M) continue;
+          const int b = m / a.N, r = m - b * a.N;
+          if (kind == 0) a.Qb[(((long)b * a.H + hh) * a.N + r) * a.C + cc] = f2bf(v[q] * a.qscale);
+          else if (kind == 1) a.Kb[(((long)b * a.H + hh) * a.N + r) * a.C + cc] = f2bf(v[q]);
+          else if (kind == 2) a.Vt[(((long)b * a.H + hh) * a.C + cc) * a.Np + (r & ~15) + g_perm16(r & 15)] = f2bf(v[q]);
+          else a.pts[(long)m * a.PT + cc] = v[q];
+        }
+      }
+  }
+}
+
+// zero the padded key columns [N, Np) of Vt (P is exactly 0 there, the operand must not be NaN/Inf)
+__global__ void vt_zero_pad_kernel(long rows, int N, int Np, bf16_t* __restrict__ Vt) {
+  const int pad = Np - N;
+  const long n = rows * pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / pad;
+    const int key = N + (int)(i % pad);
+    Vt[r * Np + (key & ~15) + g_perm16(key & 15)] = 0;
+  }
+}
+
+int fd_ipa_proj(const ProjArgs& a, hipStream_t st) {
+  const int M = a.B * a.N, NOUT = 3 * a.H * a.C + a.PT;
+  if ((a.K & 7) || (a.lda & 3)) return FDIPT_EINVAL;
+  if (a.Np > a.N) {
+    const long rows = (long)a.B * a.H * a.C;
+    hipLaunchKernelGGL(vt_zero_pad_kernel, dim3(256), dim3(256), 0, st, rows, a.N, a.Np, a.Vt);
+  }
+  hipLaunchKernelGGL(ipa_proj_kernel, dim3(cdiv(M, 128), cdiv(NOUT, 128)), dim3(FD_THREADS), 0, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
 }
 
 template <class P, class AT, class WT>

@@ -93,6 +93,34 @@ int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t
 size_t fd_ee2_image_bytes();
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st);
 
+struct ProjArgs {
+  int B, N, H, C, K, PT, Np;  // K = c_s, PT = point columns (3*H*Pq + 3*H*(Pq+Pv)), Np = keys padded to 32
+  const float* A;             // [B*N, lda] node representation
+  int lda;
+  const void* W;              // [3*H*C + PT, K] bf16 fused projection weight
+  const float* bias;          // [3*H*C + PT]
+  float qscale;               // sqrt(1/(3C)) folded into Q
+  bf16_t *Qb, *Kb, *Vt;
+  float* pts;                 // [B*N, PT]
+};
+int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
+
+struct Attn3Args {
+  int B, N, H, Np;
+  const bf16_t *Qb, *Kb, *Vt;     // operand images written by ipa_proj_kernel
+  const float* bias;              // [B,H,N,N] f32, pre-scaled pair bias
+  const float* res_mask;          // [B,N]
+  const float *qp, *kp, *vp;      // [B,N,H,8,3], [B,N,H,8,3], [B,N,H,12,3] global-frame points (scaled units)
+  const float* gamma;             // [H]
+  const float *rot, *trans;       // [B,N,9], [B,N,3]
+  float* probs;                   // [B,H,N,N]
+  float* out;                     // feature rows: o at h*256, point features at pt_off
+  long out_ld;
+  int pt_off;
+};
+int fd_attention3_supported(const Attn3Args& a);
+int fd_attention3(const Attn3Args& a, hipStream_t st);
+
 int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
               const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, hipStream_t st);
 int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,

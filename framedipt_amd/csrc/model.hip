@@ -287,7 +287,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -309,6 +309,11 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.x_a = take(R * iv.d_t * 4); w.x_b = take(R * iv.d_t * 4); w.ff = take(R * iv.d_t * 4);
   w.e = take(R * iv.cb * 4); w.upd = take(R * 8 * 4); w.psi_un = take(R * 8 * 4);
   w.a1 = take(R * iv.hid * 4); w.af = take(R * d->c_z * 4);
+  {
+    const size_t Np = ((size_t)N + 31) / 32 * 32, HC = (size_t)H * d->c_hidden;
+    w.qb = take(R * HC * 2); w.kb = take(R * HC * 2); w.vt = take((size_t)B * HC * Np * 2);
+    w.pts = take(R * (size_t)(iv.proj_out - 3 * HC) * 4);
+  }
   w.total = o;
 }
 
@@ -399,17 +404,34 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   for (int b = 0; b < d->num_blocks; ++b) {
     const BlockW& k = iv.blk[b];
     const DBlock& db = L.blk[b];
-    // fused q | kv | q_pts | kv_pts projection
-    RC(fd_linear(prec, R, iv.proj_out, cs, node_cur, cs, D + db.wproj, cs, (const float*)(D + db.bproj), nullptr, 0, nullptr,
-                 0, F(w.proj), iv.proj_out, st));
-    {
-      PointsArgs pa;
-      pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.proj = F(w.proj); pa.ld = iv.proj_out;
-      pa.q_off = 3 * H * C; pa.kv_off = 3 * H * C + 3 * H * Pq; pa.quat = F(w.quat); pa.trans = F(w.trans);
-      pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
+    const int PT = iv.proj_out - 3 * H * C, Np = (N + 31) / 32 * 32;
+    Attn3Args a3;
+    a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const bf16_t*)(W + w.qb); a3.Kb = (const bf16_t*)(W + w.kb);
+    a3.Vt = (const bf16_t*)(W + w.vt); a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
+    a3.vp = F(w.vp); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
+    a3.probs = F(w.probs); a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
+    const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !getenv("FDIPT_ATTN_V1") &&
+                        !getenv("FDIPT_ATTN_V2") && fd_attention3_supported(a3);
+    PointsArgs pa;
+    pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.quat = F(w.quat); pa.trans = F(w.trans);
+    pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
+    if (use_a3) {
+      // fused projection written directly as attention operand images (Qb, Kb, Vt) + raw point columns
+      ProjArgs pj;
+      pj.B = B; pj.N = N; pj.H = H; pj.C = C; pj.K = cs; pj.PT = PT; pj.Np = Np; pj.A = node_cur; pj.lda = cs;
+      pj.W = D + db.wproj; pj.bias = (const float*)(D + db.bproj); pj.qscale = sqrtf(1.0f / (3.0f * (float)C));
+      pj.Qb = (bf16_t*)(W + w.qb); pj.Kb = (bf16_t*)(W + w.kb); pj.Vt = (bf16_t*)(W + w.vt); pj.pts = F(w.pts);
+      RC(fd_ipa_proj(pj, st));
+      pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
       RC(fd_points(pa, st));
-    }
-    {
+      RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,H,N,N]
+      RC(fd_attention3(a3, st));
+    } else {
+      // fused q | kv | q_pts | kv_pts projection (fp32 activations), then the LDS / register attention kernels
+      RC(fd_linear(prec, R, iv.proj_out, cs, node_cur, cs, D + db.wproj, cs, (const float*)(D + db.bproj), nullptr, 0,
+                   nullptr, 0, F(w.proj), iv.proj_out, st));
+      pa.proj = F(w.proj); pa.ld = iv.proj_out; pa.q_off = 3 * H * C; pa.kv_off = 3 * H * C + 3 * H * Pq;
+      RC(fd_points(pa, st));
       AttnArgs aa;
       aa.B = B; aa.N = N; aa.H = H;
       aa.q = F(w.proj); aa.q_ld = iv.proj_out; aa.q_hs = C;
@@ -426,6 +448,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
         RC(fd_attention(prec, 1, aa, st));
       }
+    }
+    {
       OPairArgs oa;
       oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs);
       oa.wdz = (const float*)(D + db.wdz_t); oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;

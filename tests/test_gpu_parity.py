@@ -317,20 +317,22 @@ def test_register_attention_vs_lds_attention():
     import os
     G = load_golden("fwd_full_denovo_n64.npz")
     outs = {}
-    for tag, env in (("v2", None), ("v1", "1")):
-        if env is None:
-            os.environ.pop("FDIPT_ATTN_V1", None)
-        else:
-            os.environ["FDIPT_ATTN_V1"] = env
+    for tag, var in (("v3", None), ("v2", "FDIPT_ATTN_V2"), ("v1", "FDIPT_ATTN_V1")):
+        for v in ("FDIPT_ATTN_V1", "FDIPT_ATTN_V2"):
+            os.environ.pop(v, None)
+        if var:
+            os.environ[var] = "1"
         try:
             net, _, conf = _net("full_denovo_n64", G, "bf16")
             out = net(_feats(G), trace=True)
             outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["rigids"].cpu().numpy().copy())
         finally:
-            os.environ.pop("FDIPT_ATTN_V1", None)
-    for b in range(4):
-        a, c = outs["v1"][0][b + 1], outs["v2"][0][b + 1]
-        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, b
-        ref = G[f"tr_node_{b}"]
-        assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, b
-    np.testing.assert_allclose(outs["v1"][1][..., 4:], outs["v2"][1][..., 4:], atol=2e-2)
+            for v in ("FDIPT_ATTN_V1", "FDIPT_ATTN_V2"):
+                os.environ.pop(v, None)
+    for tag in ("v2", "v3"):
+        for b in range(4):
+            a, c = outs["v1"][0][b + 1], outs[tag][0][b + 1]
+            assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, (tag, b)
+            ref = G[f"tr_node_{b}"]
+            assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, (tag, b)
+        np.testing.assert_allclose(outs["v1"][1][..., 4:], outs[tag][1][..., 4:], atol=2e-2)
