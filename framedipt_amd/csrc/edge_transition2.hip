@@ -16,6 +16,8 @@
 //       h1 = relu(W1[:, z|ej] [z;e_j] + A1[i]);  h2 = relu(W2 h1 + b2);  y = Wf[:, h] h2 + Wf[:, z|ej] [z;e_j] + Af[i]
 //       z' = LayerNorm(y) * mask_i mask_j
 // Executed MFMA FLOPs per pair: 655,360 (reference formulation: 688,128).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -121,7 +123,7 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* slab, int off) {
 
 // acc += W_slab[32 x 16*KS] * B[16*KS x 32]: A fragments stream from LDS through a DEPTH-deep register ring so that
 // every ds_read_b128 is issued DEPTH MFMAs (= DEPTH*32 cycles) ahead of its consumer.
-template <int KS, int ROWB, int DEPTH = 8>
+template <int KS, int ROWB, int DEPTH = 8, int ABL = 0>
 __device__ __forceinline__ void mma_slab(f32x16& acc, const char* slab, int li, int hi, const bf16x8* Bf) {
   bf16x8 ring[DEPTH];
 #pragma unroll
@@ -129,7 +131,8 @@ __device__ __forceinline__ void mma_slab(f32x16& acc, const char* slab, int li, 
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % DEPTH], Bf[s], acc, 0, 0, 0);
+    if (ABL != 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % DEPTH], Bf[s], acc, 0, 0, 0);
+    else acc[s & 15] += (float)ring[s % DEPTH][0];
     if (s + DEPTH < KS) ring[s % DEPTH] = lds_frag(slab, et2_off_wide(li, 2 * (s + DEPTH) + hi, ROWB));
     __builtin_amdgcn_sched_barrier(0);  // pin the MFMA / ds_read interleave (hipcc otherwise sinks the reads)
   }
@@ -188,6 +191,7 @@ __device__ __forceinline__ void ln_epilogue(f32x16 (&Y)[4], const float* __restr
   }
 }
 
+template <int ABL>
 __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ET2_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
   // ================= layer 1: 12 output tiles, K = 256
 #pragma unroll
   for (int T = 0; T < 12; ++T) {
-    dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);  // next: L1 T+1 or FX 0
+    if (ABL != 1) dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);  // next: L1 T+1 or FX 0
     f32x4 bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(a1row + 32 * T + 8 * g);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    mma_slab<16, 512>(acc, slab, li, hi, X);
+    mma_slab<16, 512, 8, ABL>(acc, slab, li, hi, X);
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
@@ -255,9 +259,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const char* slab = smem + buf * ET2_BUF;
-    if (t < 3) dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);
+    if (ABL == 1) {} else if (t < 3) dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);
     else dma_slab<ET2_BUF>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);  // next: L2 slab 0 + FH slab 0
-    mma_slab<16, 512>(Y[t], slab, li, hi, X);
+    mma_slab<16, 512, 8, ABL>(Y[t], slab, li, hi, X);
     __syncthreads();
     buf ^= 1;
     soff += ET2_SLAB_L1;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
   const float* b2row = a.b2 + 4 * hi;
 #pragma unroll
   for (int T = 0; T < 12; ++T) {
-    if (T < 11) dma_slab<ET2_BUF>(stream + soff + ET2_BUF, smem + (buf ^ 1) * ET2_BUF, tid);
+    if (ABL != 1 && T < 11) dma_slab<ET2_BUF>(stream + soff + ET2_BUF, smem + (buf ^ 1) * ET2_BUF, tid);
     f32x4 bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(b2row + 32 * T + 8 * g);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    mma_slab<24, 768>(acc, slab, li, hi, H1);
+    mma_slab<24, 768, 8, ABL>(acc, slab, li, hi, H1);
     const char* fh = slab + ET2_SLAB_L2;
     bf16x8 fhf[8];  // the 8 A fragments of the fused final-layer update, fetched under the layer-2 epilogue
 #pragma unroll
@@ -288,8 +292,12 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     const bf16x8 h0 = pack8(v), h1 = pack8(v + 8);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t], h0, Y[t], 0, 0, 0);
-      Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t + 1], h1, Y[t], 0, 0, 0);
+      if (ABL != 2) {
+        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t], h0, Y[t], 0, 0, 0);
+        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t + 1], h1, Y[t], 0, 0, 0);
+      } else {
+        Y[t][0] += (float)fhf[2 * t][0] + (float)h0[0] + (float)fhf[2 * t + 1][0] + (float)h1[0];
+      }
     }
     if (T < 11) {
       __syncthreads();
@@ -304,7 +312,13 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
 
 int fd_edge_transition2(const ET2Args& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
-  hipLaunchKernelGGL(edge_transition2_kernel, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
+  const char* abl = getenv("FDIPT_ET2_ABL");  // ablation builds for profiling only (wrong results): 1 = no DMA, 2 = no MFMA
+  if (abl && abl[0] == '1')
+    hipLaunchKernelGGL(edge_transition2_kernel<1>, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
+  else if (abl && abl[0] == '2')
+    hipLaunchKernelGGL(edge_transition2_kernel<2>, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
+  else
+    hipLaunchKernelGGL(edge_transition2_kernel<0>, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
