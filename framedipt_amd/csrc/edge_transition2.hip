@@ -191,138 +191,308 @@ __device__ __forceinline__ void ln_epilogue(f32x16 (&Y)[4], const float* __restr
   }
 }
 
-template <int ABL>
-__global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ET2_BUF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5, li = lane & 31;
+// Two 32-feature output tiles at once: their MFMA streams are interleaved (A, B, A, B, ...) so that consecutive MFMAs
+// never hit the same accumulator, and the epilogue of the PREVIOUS pair (bias + ReLU + bf16 pack of its 2x16
+// accumulator registers, biases read from the LDS-staged A1 rows) is spread over the MFMA slots.
+// PEND: 0 none, 1 previous pair pending (layer 1).
+#define ET2_CHUNK 65536      // bytes of weight stream per barrier (4 L1/FX slabs, or 2 x (L2 slab + FH slab))
+#define ET2_BROWS 4          // A1/Af rows (distinct b*N+i) a 128-pair tile may touch: N >= 43
+#define ET2_BROW_BYTES 2048  // one staged row: A1[384] | Af[128] fp32
+#define ET2_LDS (2 * ET2_CHUNK + 2 * ET2_BROWS * ET2_BROW_BYTES + 1536)
+
+// `aoff[e]` = LDS byte offset of this lane's fragment for k-steps s == e (mod 8) of a slab at offset 0 of the current
+// buffer (swizzle folded in, computed once per kernel); everything else is a compile-time immediate, so a fragment
+// read is ONE ds_read_b128 with an offset field and no address VALU (the stream is issue-bound: <= 5 instructions
+// fit beside each MFMA).
+template <int KS, int PEND, int SLAB_A, int SLAB_B>
+__device__ __forceinline__ void pair_stream(f32x16& accA, f32x16& accB, const char* lds, const int (&aoff)[8],
+                                            const bf16x8* Bf, const f32x16& paccA, const f32x16& paccB, const float* pbA,
+                                            const float* pbB, bf16x8* outA, bf16x8* outB) {
+  constexpr int DEPTH = 4;
+  // biases of the pending pair first (LDS, mostly broadcast): they retire with the ring prologue, never alone
+  f32x4 bA[4], bB[4];
+  if (PEND != 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bA[g] = *(const f32x4*)(pbA + 8 * g);
+      bB[g] = *(const f32x4*)(pbB + 8 * g);
+    }
+  }
+  bf16x8 ringA[DEPTH], ringB[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s) {
+    ringA[s] = lds_frag(lds, aoff[s & 7] + SLAB_A + 256 * (s >> 3));
+    ringB[s] = lds_frag(lds, aoff[s & 7] + SLAB_B + 256 * (s >> 3));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float vA[16], vB[16];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    // refill the slot consumed ONE iteration ago (a ds_read into the registers of the MFMA just issued would stall on
+    // the write-after-read hazard); the data is used DEPTH-1 iterations (>= 192 cycles) later
+    if (s + DEPTH - 1 < KS) {
+      constexpr int D1 = DEPTH - 1;
+      ringA[(s + D1) % DEPTH] = lds_frag(lds, aoff[(s + D1) & 7] + SLAB_A + 256 * ((s + D1) >> 3));
+      ringB[(s + D1) % DEPTH] = lds_frag(lds, aoff[(s + D1) & 7] + SLAB_B + 256 * ((s + D1) >> 3));
+    }
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ringA[s % DEPTH], Bf[s], accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ringB[s % DEPTH], Bf[s], accB, 0, 0, 0);
+    if (PEND != 0 && s < 16) {
+      vA[s] = fmaxf(paccA[s] + bA[s >> 2][s & 3], 0.f);
+      vB[s] = fmaxf(paccB[s] + bB[s >> 2][s & 3], 0.f);
+      if (s == 7) { outA[0] = pack8(vA); outB[0] = pack8(vB); }
+      if (s == 15) { outA[1] = pack8(vA + 8); outB[1] = pack8(vB + 8); }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // pin: 2 ds_reads, 2 MFMAs (different accumulators), 2 epilogue elements
+  }
+}
+
+// raw (unconverted) x = [z_ij | e_j] rows of one 32-pair wave tile, fetched one block tile ahead
+struct XRaw {
+  u16x8 z[8];
+  f32x4 e[16];
+};
+__device__ __forceinline__ void x_load(XRaw& r, const ET2Args& a, long p, long bj, int hi) {
+  const bf16_t* zr = a.z_in + p * ET2_CZ + 8 * hi;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) r.z[s] = *(const u16x8*)(zr + 16 * s);
+  const float* er = a.e + bj * ET2_CB + 8 * hi;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    r.e[2 * s] = *(const f32x4*)(er + 16 * s);
+    r.e[2 * s + 1] = *(const f32x4*)(er + 16 * s + 4);
+  }
+}
+// A1 | Af rows i_lo .. i_lo+3 of a block tile -> LDS (per-lane source, linear destination)
+__device__ __forceinline__ void bias_rows_dma(const ET2Args& a, long i_lo, long n_rows, char* dst, int tid) {
+#pragma unroll
+  for (int u = 0; u < ET2_BROWS * (ET2_BROW_BYTES / 16) / FD_THREADS; ++u) {
+    const int ch = u * FD_THREADS + tid, row = ch / 128, q = ch % 128;
+    long r = i_lo + row;
+    if (r >= n_rows) r = n_rows - 1;
+    const float* src = q < 96 ? a.a1 + r * ET2_H + 4 * q : a.af + r * ET2_CZ + 4 * (q - 96);
+    __builtin_amdgcn_global_load_lds((gl_void_t*)src, (lds_void_t*)(dst + (size_t)(u * FD_THREADS + (tid & ~63)) * 16), 16, 0, 0);
+  }
+}
+
+// Persistent: one block per CU walks the 128-pair tiles.  Per tile 10 chunks of the weight stream (one barrier each);
+// the next tile's x rows, bias rows and first chunk are fetched under the last chunks of the current tile, and the
+// output stores of a tile drain under the first chunk of the next one.  No ordinary load is consumed while an LDS-DMA
+// is in flight (hipcc would drain the whole DMA queue with vmcnt(0) in front of it).
+__global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args a, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* brow_lds = smem + 2 * ET2_CHUNK;                              // [2][ET2_BROWS][2048]
+  const float* b2_lds = (const float*)(brow_lds + 2 * ET2_BROWS * ET2_BROW_BYTES);  // [384]
+  const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
+  const int hi0 = lane >> 5, li0 = lane & 31;
   const int N = a.N;
-  const long n_pairs = (long)a.B * N * N;
-  const long p_raw = (long)blockIdx.x * 128 + wave * 32 + li;
-  const bool valid = p_raw < n_pairs;
-  const long p = valid ? p_raw : n_pairs - 1;
-  const long bi = p / N;            // b*N + i
-  const int j = (int)(p - bi * N);
-  const long bj = (bi / N) * N + j;  // b*N + j
+  const long n_pairs = (long)a.B * N * N, n_rows = (long)a.B * N;
   const char* stream = (const char*)a.stream;
 
-  // ---- B-operand fragments of x = [z_ij | e_j] (k order natural): 16 k-steps
-  bf16x8 X[16];
-  {
-    const bf16_t* zr = a.z_in + p * ET2_CZ + 8 * hi;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  // ---- prologue of the first tile
+  long p_raw = (long)tile * 128 + wave * 32 + li0;
+  bool valid = p_raw < n_pairs;
+  long p = valid ? p_raw : n_pairs - 1;
+  long bi = p / N;
+  long bj = (bi / N) * N + (p - bi * N);
+  long i_lo = ((long)tile * 128) / N;
+  XRaw xr;
+  x_load(xr, a, p, bj, hi0);
+  dma_slab<ET2_CHUNK>(stream, smem, tid0);
+  bias_rows_dma(a, i_lo, n_rows, brow_lds, tid0);
+  if (tid0 < 96) __builtin_amdgcn_global_load_lds((gl_void_t*)(a.b2 + 4 * tid0), (lds_void_t*)((char*)b2_lds + (tid0 & ~63) * 16), 16, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  int it = 0;
+#pragma unroll 1
+  for (; it < 1; tile += gridDim.x, ++it) {  // one tile per block (the persistent form spills: see DESIGN.md)
+    // opaque per-iteration copies: keeps hipcc from hoisting the ~200 loop-invariant LDS fragment addresses out of the
+    // tile loop (they would all stay live across the whole body and spill)
+    int li = li0, hi = hi0, tid = tid0;
+    asm volatile("" : "+v"(li), "+v"(hi), "+v"(tid));
+    int a512[2][8], a768[2][8], afh[2][2];  // swizzled fragment offsets of this lane (per LDS buffer)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) X[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(zr + 16 * s));
-    const float* er = a.e + bj * ET2_CB + 8 * hi;
+    for (int e = 0; e < 8; ++e) {
+      a512[0][e] = li * 512 + (((2 * e + hi) ^ (li & 15)) << 4);
+      a768[0][e] = li * 768 + (((2 * e + hi) ^ (li & 15)) << 4);
+      a512[1][e] = a512[0][e] + ET2_CHUNK;
+      a768[1][e] = a768[0][e] + ET2_CHUNK;
+    }
+    afh[0][0] = li * 64 + ((hi ^ ((li >> 2) & 3)) << 4);
+    afh[0][1] = li * 64 + (((2 + hi) ^ ((li >> 2) & 3)) << 4);
+    afh[1][0] = afh[0][0] + ET2_CHUNK;
+    afh[1][1] = afh[0][1] + ET2_CHUNK;
+    const char* brows = brow_lds + (it & 1) * ET2_BROWS * ET2_BROW_BYTES;
+    const float* a1l = (const float*)(brows + (bi - i_lo) * ET2_BROW_BYTES) + 4 * hi;  // this lane's A1 | Af row
+    const float* b2l = b2_lds + 4 * hi;
+    // ---- B-operand fragments of x = [z_ij | e_j] (k order natural): 16 k-steps
+    bf16x8 X[16];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const f32x4 u0 = *(const f32x4*)(er + 16 * s), u1 = *(const f32x4*)(er + 16 * s + 4);
-      const float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+      X[s] = __builtin_bit_cast(bf16x8, xr.z[s]);
+      const float v[8] = {xr.e[2 * s][0], xr.e[2 * s][1], xr.e[2 * s][2], xr.e[2 * s][3],
+                          xr.e[2 * s + 1][0], xr.e[2 * s + 1][1], xr.e[2 * s + 1][2], xr.e[2 * s + 1][3]};
       X[8 + s] = pack8(v);
     }
-  }
-  // prologue: first slab into buffer 0
-  dma_slab<ET2_SLAB_L1>(stream, smem, tid);
-  __syncthreads();
-
-  bf16x8 H1[24];
-  f32x16 Y[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
-
-  const float* a1row = a.a1 + bi * ET2_H + 4 * hi;
-  size_t soff = 0;  // stream offset of the slab being computed
-  int buf = 0;
-  // ================= layer 1: 12 output tiles, K = 256
-#pragma unroll
-  for (int T = 0; T < 12; ++T) {
-    if (ABL != 1) dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);  // next: L1 T+1 or FX 0
-    f32x4 bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(a1row + 32 * T + 8 * g);
-    const char* slab = smem + buf * ET2_BUF;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    mma_slab<16, 512, 8, ABL>(acc, slab, li, hi, X);
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
-    H1[2 * T] = pack8(v);
-    H1[2 * T + 1] = pack8(v + 8);
-    __syncthreads();
-    buf ^= 1;
-    soff += ET2_SLAB_L1;
-  }
-  // ================= final layer, x part: Y[t] += Wf[:, z|ej] x   (4 tiles, K = 256)
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const char* slab = smem + buf * ET2_BUF;
-    if (ABL == 1) {} else if (t < 3) dma_slab<ET2_SLAB_L1>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);
-    else dma_slab<ET2_BUF>(stream + soff + ET2_SLAB_L1, smem + (buf ^ 1) * ET2_BUF, tid);  // next: L2 slab 0 + FH slab 0
-    mma_slab<16, 512, 8, ABL>(Y[t], slab, li, hi, X);
-    __syncthreads();
-    buf ^= 1;
-    soff += ET2_SLAB_L1;
-  }
-  // ================= layer 2 (+ final layer h part, fused per h2 tile): 12 tiles, K = 384
-  const float* b2row = a.b2 + 4 * hi;
-#pragma unroll
-  for (int T = 0; T < 12; ++T) {
-    if (ABL != 1 && T < 11) dma_slab<ET2_BUF>(stream + soff + ET2_BUF, smem + (buf ^ 1) * ET2_BUF, tid);
-    f32x4 bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(b2row + 32 * T + 8 * g);
-    const char* slab = smem + buf * ET2_BUF;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    mma_slab<24, 768, 8, ABL>(acc, slab, li, hi, H1);
-    const char* fh = slab + ET2_SLAB_L2;
-    bf16x8 fhf[8];  // the 8 A fragments of the fused final-layer update, fetched under the layer-2 epilogue
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      fhf[2 * t] = lds_frag(fh, et2_off_fh(32 * t + li, hi));
-      fhf[2 * t + 1] = lds_frag(fh, et2_off_fh(32 * t + li, 2 + hi));
+    // identifiers of this tile (for the epilogue) and of the next one (for the prefetch)
+    const long p_cur = p;
+    const bool valid_cur = valid;
+    const float em_cur = a.res_mask[bi] * a.res_mask[bj];
+    const int ntile = tile + gridDim.x;
+    const bool has_next = false && ntile < n_tiles;
+    if (has_next) {
+      p_raw = (long)ntile * 128 + wave * 32 + li;
+      valid = p_raw < n_pairs;
+      p = valid ? p_raw : n_pairs - 1;
+      bi = p / N;
+      bj = (bi / N) * N + (p - bi * N);
+      i_lo = ((long)ntile * 128) / N;
     }
-    float v[16];
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // res_mask loads retired before the first DMA of the tile is issued
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 H1[24];
+    f32x16 Y[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
-    const bf16x8 h0 = pack8(v), h1 = pack8(v + 8);
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (ABL != 2) {
-        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t], h0, Y[t], 0, 0, 0);
-        Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhf[2 * t + 1], h1, Y[t], 0, 0, 0);
-      } else {
-        Y[t][0] += (float)fhf[2 * t][0] + (float)h0[0] + (float)fhf[2 * t + 1][0] + (float)h1[0];
+      for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
+    f32x16 paccA, paccB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { paccA[r] = 0.f; paccB[r] = 0.f; }
+    bf16x8 dummy[2];
+    int buf = 0;
+    size_t soff = 0;
+    // ================= layer 1: 3 chunks x 2 pairs of tiles, K = 256 (z | e_j)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int Pp = 2 * c + u;  // pair index: tiles 2Pp, 2Pp+1
+        dma_slab<ET2_CHUNK / 2>(stream + soff + ET2_CHUNK + u * (ET2_CHUNK / 2),
+                                smem + (buf ^ 1) * ET2_CHUNK + u * (ET2_CHUNK / 2), tid);
+        f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+        constexpr int PQ = 0;
+        (void)PQ;
+        const int (&ao)[8] = a512[(c & 1)];  // buf == c & 1 in this phase
+        if (u == 0) {
+          if (Pp == 0) pair_stream<16, 0, 0, ET2_SLAB_L1>(accA, accB, smem, ao, X, paccA, paccB, a1l, a1l, dummy, dummy);
+          else pair_stream<16, 1, 0, ET2_SLAB_L1>(accA, accB, smem, ao, X, paccA, paccB, a1l + 32 * (2 * (Pp > 0 ? Pp - 1 : 0)),
+                                                  a1l + 32 * (2 * (Pp > 0 ? Pp - 1 : 0) + 1), &H1[4 * (Pp > 0 ? Pp - 1 : 0)],
+                                                  &H1[4 * (Pp > 0 ? Pp - 1 : 0) + 2]);
+        } else {
+          pair_stream<16, 1, 2 * ET2_SLAB_L1, 3 * ET2_SLAB_L1>(accA, accB, smem, ao, X, paccA, paccB, a1l + 32 * (2 * (Pp - 1)),
+                                                               a1l + 32 * (2 * (Pp - 1) + 1), &H1[4 * (Pp - 1)],
+                                                               &H1[4 * (Pp - 1) + 2]);
+        }
+        paccA = accA;
+        paccB = accB;
       }
-    }
-    if (T < 11) {
       __syncthreads();
       buf ^= 1;
-      soff += ET2_BUF;
+      soff += ET2_CHUNK;
     }
+    // ================= final layer, x part: Y[t] += Wf[:, z|ej] x  (one chunk, 2 pairs); epilogue of L1 pair 5 inside
+    {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        dma_slab<ET2_CHUNK / 2>(stream + soff + ET2_CHUNK + u * (ET2_CHUNK / 2),
+                                smem + (buf ^ 1) * ET2_CHUNK + u * (ET2_CHUNK / 2), tid);
+        // buf == 1 here (chunk 3)
+        if (u == 0) pair_stream<16, 1, 0, ET2_SLAB_L1>(Y[0], Y[1], smem, a512[1], X, paccA, paccB, a1l + 32 * 10, a1l + 32 * 11,
+                                                       &H1[20], &H1[22]);
+        else pair_stream<16, 0, 2 * ET2_SLAB_L1, 3 * ET2_SLAB_L1>(Y[2], Y[3], smem, a512[1], X, paccA, paccB, a1l, a1l, dummy,
+                                                                  dummy);
+      }
+      __syncthreads();
+      buf ^= 1;
+      soff += ET2_CHUNK;
+    }
+    // ================= layer 2 (+ fused final layer h part): 6 chunks = 6 pairs of tiles, K = 384
+#pragma unroll
+    for (int c2 = 0; c2 < 6; ++c2) {
+      if (c2 < 5) dma_slab<ET2_CHUNK>(stream + soff + ET2_CHUNK, smem + (buf ^ 1) * ET2_CHUNK, tid);
+      else if (has_next) {  // last chunk: start the next tile (first weight chunk, bias rows, x rows)
+        dma_slab<ET2_CHUNK>(stream, smem + (buf ^ 1) * ET2_CHUNK, tid);
+        bias_rows_dma(a, i_lo, n_rows, brow_lds + ((it + 1) & 1) * ET2_BROWS * ET2_BROW_BYTES, tid);
+        x_load(xr, a, p, bj, hi);
+      }
+      f32x16 accA, accB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+      // buf == c2 & 1 in this phase (chunk 4 + c2)
+      pair_stream<24, 0, 0, ET2_BUF>(accA, accB, smem, a768[c2 & 1], H1, paccA, paccB, a1l, a1l, dummy, dummy);
+      // epilogue of the pair + its final-layer update: the 8 FH MFMAs of tile A run under the epilogue of tile B
+      bf16x8 fhA[8], fhB[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fhA[2 * t] = lds_frag(smem, afh[c2 & 1][0] + ET2_SLAB_L2 + t * 2048);
+        fhA[2 * t + 1] = lds_frag(smem, afh[c2 & 1][1] + ET2_SLAB_L2 + t * 2048);
+        fhB[2 * t] = lds_frag(smem, afh[c2 & 1][0] + ET2_BUF + ET2_SLAB_L2 + t * 2048);
+        fhB[2 * t + 1] = lds_frag(smem, afh[c2 & 1][1] + ET2_BUF + ET2_SLAB_L2 + t * 2048);
+      }
+      f32x4 bA[4], bB[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bA[g] = *(const f32x4*)(b2l + 32 * (2 * c2) + 8 * g);
+        bB[g] = *(const f32x4*)(b2l + 32 * (2 * c2 + 1) + 8 * g);
+      }
+      float vA[16], vB[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vA[r] = fmaxf(accA[r] + bA[r >> 2][r & 3], 0.f);
+      const bf16x8 hA0 = pack8(vA), hA1 = pack8(vA + 8);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        Y[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhA[q], (q & 1) ? hA1 : hA0, Y[q >> 1], 0, 0, 0);
+        vB[2 * q] = fmaxf(accB[2 * q] + bB[(2 * q) >> 2][(2 * q) & 3], 0.f);
+        vB[2 * q + 1] = fmaxf(accB[2 * q + 1] + bB[(2 * q + 1) >> 2][(2 * q + 1) & 3], 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bf16x8 hB0 = pack8(vB), hB1 = pack8(vB + 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        Y[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhB[q], (q & 1) ? hB1 : hB0, Y[q >> 1], 0, 0, 0);
+      if (c2 < 5) {
+        __syncthreads();
+        buf ^= 1;
+        soff += ET2_CHUNK;
+      }
+    }
+    // ================= epilogue: + Af[i] (LDS row), LayerNorm over the 128 features of each pair, mask, store
+    ln_epilogue(Y, a1l + ET2_H, a.gamma, a.beta, em_cur, valid_cur, hi, a.z_out + p_cur * ET2_CZ,
+                a.trace ? a.trace + p_cur * ET2_CZ : nullptr);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // next tile's DMA + x rows landed (and this tile's stores issued)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
   }
-  // ================= epilogue: + Af[i], LayerNorm over the 128 features of each pair, mask, store
-  ln_epilogue(Y, a.af + bi * ET2_CZ + 4 * hi, a.gamma, a.beta, a.res_mask[bi] * a.res_mask[bj], valid, hi,
-              a.z_out + p * ET2_CZ, a.trace ? a.trace + p * ET2_CZ : nullptr);
 }
+
+int fd_edge_transition2_supported(int N) { return N >= 43; }  // ET2_BROWS rows cover a 128-pair tile
 
 int fd_edge_transition2(const ET2Args& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
-  const char* abl = getenv("FDIPT_ET2_ABL");  // ablation builds for profiling only (wrong results): 1 = no DMA, 2 = no MFMA
-  if (abl && abl[0] == '1')
-    hipLaunchKernelGGL(edge_transition2_kernel<1>, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
-  else if (abl && abl[0] == '2')
-    hipLaunchKernelGGL(edge_transition2_kernel<2>, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL(edge_transition2_kernel<0>, dim3(cdiv(n_pairs, 128)), dim3(FD_THREADS), 0, st, a);
+  const int n_tiles = cdiv(n_pairs, 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)edge_transition2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ET2_LDS) !=
+        hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  const int grid = n_tiles;
+  hipLaunchKernelGGL(edge_transition2_kernel, dim3(grid), dim3(FD_THREADS), ET2_LDS, st, a, n_tiles);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
-
 
 // ====================================================================================================================
 // edge_embed2_kernel — bf16 pair branch of Embedder.forward (framedipt/model/score_network.py:98-105,173-196) in the

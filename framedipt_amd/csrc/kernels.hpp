@@ -89,6 +89,7 @@ struct ET2Args {
 int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et2_stream_bytes();
 int fd_edge_transition2(const ET2Args& a, hipStream_t st);
+int fd_edge_transition2_supported(int N);
 int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t st);
 size_t fd_ee2_image_bytes();
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st);

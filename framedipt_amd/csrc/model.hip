@@ -495,7 +495,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     if (b < d->num_blocks - 1) {
       RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
       float* tr_ptr = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
-      if (use_et2(d)) {
+      if (use_et2(d) && fd_edge_transition2_supported(N)) {
         // per-residue parts of the concat-free layers: A1[i] = W1[:, e_i cols] e_i + b1, Af[i] = Wf[:, e_i cols] e_i + bf
         RC(fd_linear(prec, R, iv.hid, iv.cb, F(w.e), iv.cb, PB + k.et1.w + cz, iv.hid, P + k.et1.b, nullptr, 0, nullptr, 0,
                      F(w.a1), iv.hid, st));
