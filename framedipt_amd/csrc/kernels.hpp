@@ -122,6 +122,26 @@ struct Attn3Args {
 int fd_attention3_supported(const Attn3Args& a);
 int fd_attention3(const Attn3Args& a, hipStream_t st);
 
+struct ChainArgs {
+  int M;
+  const float* in;          // [M, ld_in] fp32 input rows
+  int ld_in;
+  const void* w[3];         // weight images (fd_chain_build_image) of the layers actually present
+  const float* b[3];
+  const float* residual;    // added to the output layer (fp32) or NULL
+  int ld_res;
+  const float *gamma, *beta;     // LayerNorm parameters (kinds with LN)
+  const float* rowmask_pre;      // (W x + b) * mask before the residual, or NULL
+  const float* rowmask_post;     // final * mask, or NULL
+  float* out;
+  int ld_out;
+};
+enum { FD_CHAIN_TRANSITION, FD_CHAIN_FFN, FD_CHAIN_OUTPROJ, FD_CHAIN_POST, FD_CHAIN_INPROJ, FD_CHAIN_SKIP, FD_CHAIN_ETINIT,
+       FD_CHAIN_A1, FD_CHAIN_AF, FD_CHAIN_NODE_EMBED_72, FD_CHAIN_NODE_EMBED_88, FD_CHAIN_TORSION };
+size_t fd_chain_image_bytes(int N, int K);
+int fd_chain_build_image(const float* w, int N, int K, int ldw, int permuted, void* img, hipStream_t st);
+int fd_chain(int kind, const ChainArgs& a, hipStream_t st);
+
 int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
               const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, hipStream_t st);
 int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,

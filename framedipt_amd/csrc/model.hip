@@ -92,12 +92,16 @@ static void build_inventory(const FdiptDims* d, Inventory& iv) {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, et2, wdz_t; };
+struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
+  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3, et_init, a1, af;
+};
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, et2, wdz_t; DChain ch; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
   size_t w1i, w1j, w1r, dtab, edges, b1;  // fp32 pieces of the concat-free first edge-embedder layer
   size_t ee2;         // LDS images of edge-embedder layers 2/3 (register-resident bf16 kernel)
+  size_t ch_ne0, ch_ne2, ch_ne4, ch_tor1, ch_tor2;  // chain images: node embedder, torsion head
   DBlock blk[FD_MAX_BLOCKS];
   size_t total;
   int kn_pad, d1_pad, esz;
@@ -106,6 +110,11 @@ struct DLayout {
 // register-resident bf16 EdgeTransition (edge_transition2.hip) is compiled for the reference widths only
 static bool use_et2(const FdiptDims* d) {
   return d->precision == FDIPT_PREC_BF16 && d->c_z == 128 && d->c_s == 256 && !getenv("FDIPT_ET_V1");
+}
+
+// fused node-path chains (chain.hip) are compiled for the reference widths only
+static bool use_chain(const FdiptDims* d) {
+  return d->precision == FDIPT_PREC_BF16 && d->c_s == 256 && d->c_skip == 64 && d->c_z == 128 && !getenv("FDIPT_NO_CHAIN");
 }
 
 static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
@@ -133,6 +142,20 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et2 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
+    if (use_chain(d)) {
+      DChain& c = L.blk[b].ch;
+      auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
+      const int cs = d->c_s, dt = iv.d_t;
+      c.skip = img(d->c_skip, cs);
+      for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); }
+      c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs);
+      c.et_init = img(iv.cb, cs); c.a1 = img(iv.hid, iv.cb); c.af = img(d->c_z, iv.cb);
+    }
+  }
+  if (use_chain(d)) {
+    auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
+    L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
+    L.ch_tor1 = img(d->c_s, d->c_s); L.ch_tor2 = img(d->c_s, d->c_s);
   }
   L.total = o;
 }
@@ -261,6 +284,30 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     FD_CHECK_LAUNCH();
     if (use_et2(d) && b < d->num_blocks - 1)
       if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st))) return rc;
+    if (use_chain(d)) {
+      const DChain& c = db.ch;
+      auto bi = [&](const LinW& l, int perm, size_t off) { return fd_chain_build_image(P + l.w, l.out, l.in, l.in, perm, D + off, st); };
+      if ((rc = bi(k.skip, 0, c.skip))) return rc;
+      for (int l = 0; l < d->tfmr_layers; ++l) {
+        if ((rc = bi(k.tf[l].inp, 0, c.inp[l])) || (rc = bi(k.tf[l].outp, 0, c.outp[l])) || (rc = bi(k.tf[l].l1, 0, c.l1[l])) ||
+            (rc = bi(k.tf[l].l2, 1, c.l2[l])))
+          return rc;
+      }
+      if ((rc = bi(k.post, 0, c.post)) || (rc = bi(k.t1, 0, c.t1)) || (rc = bi(k.t2, 1, c.t2)) || (rc = bi(k.t3, 1, c.t3))) return rc;
+      if (b < d->num_blocks - 1) {
+        if ((rc = bi(k.et_init, 0, c.et_init))) return rc;
+        // e_i columns of the first / final EdgeTransition layers as [hid, cb] / [cz, cb] matrices
+        if ((rc = fd_chain_build_image(P + k.et1.w + cz, iv.hid, iv.cb, iv.hid, 0, D + c.a1, st))) return rc;
+        if ((rc = fd_chain_build_image(P + k.etf.w + cz, cz, iv.cb, iv.hid, 0, D + c.af, st))) return rc;
+      }
+    }
+  }
+  if (use_chain(d)) {
+    if ((rc = fd_chain_build_image(P + iv.ne0.w, cs, iv.node_in, iv.node_in, 0, D + L.ch_ne0, st))) return rc;
+    if ((rc = fd_chain_build_image(P + iv.ne2.w, cs, cs, cs, 1, D + L.ch_ne2, st))) return rc;
+    if ((rc = fd_chain_build_image(P + iv.ne4.w, cs, cs, cs, 1, D + L.ch_ne4, st))) return rc;
+    if ((rc = fd_chain_build_image(P + iv.tor1.w, cs, cs, cs, 0, D + L.ch_tor1, st))) return rc;
+    if ((rc = fd_chain_build_image(P + iv.tor2.w, cs, cs, cs, 1, D + L.ch_tor2, st))) return rc;
   }
   (void)C;
   return FDIPT_OK;
@@ -369,15 +416,37 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     return fd_linear(FDIPT_PREC_F32, M, l.out, l.in, A, lda, P + l.w, l.in, P + l.b, nullptr, 0, nullptr, 0, out, ldo, st);
   };
   const float* res_mask = a->res_mask;
+  const bool chn_all = use_chain(d);
+  // bit k enables fused chain kind k (FD_CHAIN_*).  Default: the kinds that beat the GEMM + LayerNorm launches they replace
+  // at B*N ~ 2400 rows on MI355X (profiles/r01_chain_vs_gemm.md): the 3-layer chains and the narrow heads; the 320-wide
+  // transformer layers (FFN, out_proj, in_proj) and skip_embed stay on the tiled GEMM, which spreads over 10x more CUs.
+  const char* cmask_s = getenv("FDIPT_CHAIN_MASK");
+  const unsigned cmask = cmask_s ? (unsigned)strtoul(cmask_s, nullptr, 0) : 0xFC9u;
+  auto con = [&](int kind) { return chn_all && ((cmask >> kind) & 1u); };
+  auto chain = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
+                   const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* pre,
+                   const float* post, float* out, int ld_out) {
+    ChainArgs c;
+    c.M = R; c.in = in; c.ld_in = ld_in; c.w[0] = w0; c.w[1] = w1; c.w[2] = w2; c.b[0] = b0; c.b[1] = b1; c.b[2] = b2;
+    c.residual = resid; c.ld_res = ld_res; c.gamma = lnw ? P + lnw->g : nullptr; c.beta = lnw ? P + lnw->b : nullptr;
+    c.rowmask_pre = pre; c.rowmask_post = post; c.out = out; c.ld_out = ld_out;
+    return fd_chain(kind, c, st);
+  };
 
   // ---- Embedder (score_network.py:129-197)
   RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
                     L.kn_pad, F(w.pte), L.d1_pad, st));
-  RC(fd_linear(prec, R, cs, L.kn_pad, F(w.node_feat), L.kn_pad, D + L.ne0_pad, L.kn_pad, P + iv.ne0.b, nullptr, 0, nullptr, 1,
-               F(w.h_a), cs, st));
-  RC(lin(R, iv.ne2, F(w.h_a), cs, nullptr, 0, nullptr, 1, F(w.h_b), cs));
-  RC(lin(R, iv.ne4, F(w.h_b), cs, nullptr, 0, nullptr, 0, F(w.h_a), cs));
-  RC(fd_layernorm(R, cs, F(w.h_a), cs, nullptr, 0, P + iv.neln.g, P + iv.neln.b, res_mask, F(w.node0), cs, st));
+  if (con(FD_CHAIN_NODE_EMBED_72) && (L.kn_pad == 72 || L.kn_pad == 88)) {
+    RC(chain(L.kn_pad == 72 ? FD_CHAIN_NODE_EMBED_72 : FD_CHAIN_NODE_EMBED_88, F(w.node_feat), L.kn_pad, D + L.ch_ne0,
+             P + iv.ne0.b, D + L.ch_ne2, P + iv.ne2.b, D + L.ch_ne4, P + iv.ne4.b, nullptr, 0, &iv.neln, nullptr, res_mask,
+             F(w.node0), cs));
+  } else {
+    RC(fd_linear(prec, R, cs, L.kn_pad, F(w.node_feat), L.kn_pad, D + L.ne0_pad, L.kn_pad, P + iv.ne0.b, nullptr, 0, nullptr, 1,
+                 F(w.h_a), cs, st));
+    RC(lin(R, iv.ne2, F(w.h_a), cs, nullptr, 0, nullptr, 1, F(w.h_b), cs));
+    RC(lin(R, iv.ne4, F(w.h_b), cs, nullptr, 0, nullptr, 0, F(w.h_a), cs));
+    RC(fd_layernorm(R, cs, F(w.h_a), cs, nullptr, 0, P + iv.neln.g, P + iv.neln.b, res_mask, F(w.node0), cs, st));
+  }
   RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1i, L.d1_pad, (const float*)(D + L.b1), nullptr, 0,
                nullptr, 0, F(w.pi), cz, st));
   RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1j, L.d1_pad, nullptr, nullptr, 0, nullptr, 0,
@@ -458,12 +527,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
     RC(fd_layernorm(R, cs, node_cur, cs, F(w.ipa_out), cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr, F(w.tf_in), dt, st));
-    RC(lin(R, k.skip, F(w.node0), cs, nullptr, 0, nullptr, 0, F(w.tf_in) + cs, dt));
+    if (con(FD_CHAIN_SKIP)) RC(chain(FD_CHAIN_SKIP, F(w.node0), cs, D + db.ch.skip, P + k.skip.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                      nullptr, nullptr, nullptr, F(w.tf_in) + cs, dt));
+    else RC(lin(R, k.skip, F(w.node0), cs, nullptr, 0, nullptr, 0, F(w.tf_in) + cs, dt));
     // nn.TransformerEncoder, post-norm (ipa:433-443,536-538)
     const float* x = F(w.tf_in);
     for (int l = 0; l < d->tfmr_layers; ++l) {
       const TfLayer& t = k.tf[l];
-      RC(lin(R, t.inp, x, dt, nullptr, 0, nullptr, 0, F(w.qkv), 3 * dt));
+      if (con(FD_CHAIN_INPROJ)) RC(chain(FD_CHAIN_INPROJ, x, dt, D + db.ch.inp[l], P + t.inp.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                        nullptr, nullptr, nullptr, F(w.qkv), 3 * dt));
+      else RC(lin(R, t.inp, x, dt, nullptr, 0, nullptr, 0, F(w.qkv), 3 * dt));
       AttnArgs ta;
       const int hd = dt / d->tfmr_heads;
       ta.B = B; ta.N = N; ta.H = d->tfmr_heads;
@@ -474,33 +547,63 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       ta.out = F(w.att); ta.out_ld = dt; ta.pt_off = 0; ta.lds_s = 0;
       if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
       else RC(fd_attention(prec, 0, ta, st));
-      RC(lin(R, t.outp, F(w.att), dt, nullptr, 0, nullptr, 0, F(w.ff), dt));
-      RC(fd_layernorm(R, dt, x, dt, F(w.ff), dt, P + t.n1.g, P + t.n1.b, nullptr, F(w.x_a), dt, st));
-      RC(lin(R, t.l1, F(w.x_a), dt, nullptr, 0, nullptr, 1, F(w.ff), dt));
-      RC(lin(R, t.l2, F(w.ff), dt, nullptr, 0, nullptr, 0, F(w.att), dt));
-      RC(fd_layernorm(R, dt, F(w.x_a), dt, F(w.att), dt, P + t.n2.g, P + t.n2.b, nullptr, F(w.x_b), dt, st));
+      // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
+      if (con(FD_CHAIN_OUTPROJ)) {
+        RC(chain(FD_CHAIN_OUTPROJ, F(w.att), dt, D + db.ch.outp[l], P + t.outp.b, nullptr, nullptr, nullptr, nullptr, x, dt,
+                 &t.n1, nullptr, nullptr, F(w.x_a), dt));
+      } else {
+        RC(lin(R, t.outp, F(w.att), dt, nullptr, 0, nullptr, 0, F(w.ff), dt));
+        RC(fd_layernorm(R, dt, x, dt, F(w.ff), dt, P + t.n1.g, P + t.n1.b, nullptr, F(w.x_a), dt, st));
+      }
+      if (con(FD_CHAIN_FFN)) {
+        RC(chain(FD_CHAIN_FFN, F(w.x_a), dt, D + db.ch.l1[l], P + t.l1.b, D + db.ch.l2[l], P + t.l2.b, nullptr, nullptr,
+                 F(w.x_a), dt, &t.n2, nullptr, nullptr, F(w.x_b), dt));
+      } else {
+        RC(lin(R, t.l1, F(w.x_a), dt, nullptr, 0, nullptr, 1, F(w.ff), dt));
+        RC(lin(R, t.l2, F(w.ff), dt, nullptr, 0, nullptr, 0, F(w.att), dt));
+        RC(fd_layernorm(R, dt, F(w.x_a), dt, F(w.att), dt, P + t.n2.g, P + t.n2.b, nullptr, F(w.x_b), dt, st));
+      }
       x = F(w.x_b);  // next layer: norm1 reads x_b -> x_a, norm2 reads x_a/att -> x_b (no aliasing)
     }
     // node = node + post_tfmr(x); StructureModuleTransition; mask   (ipa:539-541, 36-58)
-    RC(lin(R, k.post, x, dt, F(w.tf_in), dt, nullptr, 0, F(w.h_a), cs));
-    RC(lin(R, k.t1, F(w.h_a), cs, nullptr, 0, nullptr, 1, F(w.h_b), cs));
-    RC(lin(R, k.t2, F(w.h_b), cs, nullptr, 0, nullptr, 1, F(w.ipa_out), cs));
-    RC(lin(R, k.t3, F(w.ipa_out), cs, F(w.h_a), cs, nullptr, 0, F(w.h_b), cs));
-    RC(fd_layernorm(R, cs, F(w.h_b), cs, nullptr, 0, P + k.tln.g, P + k.tln.b, res_mask, F(w.node), cs, st));
+    if (con(FD_CHAIN_POST)) {
+      RC(chain(FD_CHAIN_POST, x, dt, D + db.ch.post, P + k.post.b, nullptr, nullptr, nullptr, nullptr, F(w.tf_in), dt, nullptr,
+               nullptr, nullptr, F(w.h_a), cs));
+    } else {
+      RC(lin(R, k.post, x, dt, F(w.tf_in), dt, nullptr, 0, F(w.h_a), cs));
+    }
+    if (con(FD_CHAIN_TRANSITION)) {
+      RC(chain(FD_CHAIN_TRANSITION, F(w.h_a), cs, D + db.ch.t1, P + k.t1.b, D + db.ch.t2, P + k.t2.b, D + db.ch.t3, P + k.t3.b,
+               F(w.h_a), cs, &k.tln, nullptr, res_mask, F(w.node), cs));
+    } else {
+      RC(lin(R, k.t1, F(w.h_a), cs, nullptr, 0, nullptr, 1, F(w.h_b), cs));
+      RC(lin(R, k.t2, F(w.h_b), cs, nullptr, 0, nullptr, 1, F(w.ipa_out), cs));
+      RC(lin(R, k.t3, F(w.ipa_out), cs, F(w.h_a), cs, nullptr, 0, F(w.h_b), cs));
+      RC(fd_layernorm(R, cs, F(w.h_b), cs, nullptr, 0, P + k.tln.g, P + k.tln.b, res_mask, F(w.node), cs, st));
+    }
     node_cur = F(w.node);
     // BackboneUpdate + compose_q_update_vec (ipa:542-547).  bb_update(node*diffuse_mask) differs from bb_update(node)
     // only on rows whose update is masked out below, so the input mask is not materialised.
     RC(lin32(R, k.bb, node_cur, cs, F(w.upd), 8));
     RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
     if (b < d->num_blocks - 1) {
-      RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
+      if (con(FD_CHAIN_ETINIT)) RC(chain(FD_CHAIN_ETINIT, node_cur, cs, D + db.ch.et_init, P + k.et_init.b, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, 0, nullptr, nullptr, nullptr, F(w.e), iv.cb));
+      else RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
       float* tr_ptr = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
       if (use_et2(d) && fd_edge_transition2_supported(N)) {
         // per-residue parts of the concat-free layers: A1[i] = W1[:, e_i cols] e_i + b1, Af[i] = Wf[:, e_i cols] e_i + bf
-        RC(fd_linear(prec, R, iv.hid, iv.cb, F(w.e), iv.cb, PB + k.et1.w + cz, iv.hid, P + k.et1.b, nullptr, 0, nullptr, 0,
-                     F(w.a1), iv.hid, st));
-        RC(fd_linear(prec, R, cz, iv.cb, F(w.e), iv.cb, PB + k.etf.w + cz, iv.hid, P + k.etf.b, nullptr, 0, nullptr, 0,
-                     F(w.af), cz, st));
+        if (con(FD_CHAIN_A1)) {
+          RC(chain(FD_CHAIN_A1, F(w.e), iv.cb, D + db.ch.a1, P + k.et1.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                   nullptr, nullptr, F(w.a1), iv.hid));
+          RC(chain(FD_CHAIN_AF, F(w.e), iv.cb, D + db.ch.af, P + k.etf.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                   nullptr, nullptr, F(w.af), cz));
+        } else {
+          RC(fd_linear(prec, R, iv.hid, iv.cb, F(w.e), iv.cb, PB + k.et1.w + cz, iv.hid, P + k.et1.b, nullptr, 0, nullptr, 0,
+                       F(w.a1), iv.hid, st));
+          RC(fd_linear(prec, R, cz, iv.cb, F(w.e), iv.cb, PB + k.etf.w + cz, iv.hid, P + k.etf.b, nullptr, 0, nullptr, 0,
+                       F(w.af), cz, st));
+        }
         ET2Args t2;
         t2.B = B; t2.N = N; t2.z_in = (const bf16_t*)(W + w.z); t2.z_out = (bf16_t*)(W + w.z); t2.e = F(w.e);
         t2.a1 = F(w.a1); t2.af = F(w.af); t2.stream = D + db.et2; t2.b2 = P + k.et2.b; t2.gamma = P + k.et_ln.g;
@@ -525,8 +628,13 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         return FDIPT_ELAUNCH;
   }
   // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
-  RC(lin(R, iv.tor1, node_cur, cs, nullptr, 0, nullptr, 1, F(w.h_a), cs));
-  RC(lin(R, iv.tor2, F(w.h_a), cs, node_cur, cs, nullptr, 0, F(w.h_b), cs));
+  if (con(FD_CHAIN_TORSION)) {
+    RC(chain(FD_CHAIN_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2, P + iv.tor2.b, nullptr, nullptr, node_cur,
+             cs, nullptr, nullptr, nullptr, F(w.h_b), cs));
+  } else {
+    RC(lin(R, iv.tor1, node_cur, cs, nullptr, 0, nullptr, 1, F(w.h_a), cs));
+    RC(lin(R, iv.tor2, F(w.h_a), cs, node_cur, cs, nullptr, 0, F(w.h_b), cs));
+  }
   RC(lin32(R, iv.torf, F(w.h_b), cs, F(w.psi_un), 8));
   RC(fd_finish(R, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask, a->rigids, a->psi,
                st));

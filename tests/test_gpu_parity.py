@@ -336,3 +336,71 @@ def test_register_attention_vs_lds_attention():
             ref = G[f"tr_node_{b}"]
             assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, (tag, b)
         np.testing.assert_allclose(outs["v1"][1][..., 4:], outs[tag][1][..., 4:], atol=2e-2)
+
+
+@pytest.mark.parametrize("n,B,prec,inp", [(128, 2, "bf16", False), (450, 1, "bf16", True), (800, 1, "bf16", False),
+                                          (1000, 1, "fp32", True)])
+def test_baseline_config_shapes_run(n, B, prec, inp):
+    """BASELINE.json configs (N=128 de novo bf16, N~450 / ~800 TCR-like, N=1000 fp32 inpainting): two reverse steps
+    run through every kernel variant these sizes select; outputs finite, frames orthonormal, motif kept fixed."""
+    from framedipt_amd import config, inference
+    from framedipt_amd import rigid as R
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import ConditionalSampler, UnconditionalSampler
+    conf = config.base_config(inpainting=inp)
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, inpainting=inp, precision=prec).load_synthetic(5).to("cuda")
+    rng = np.random.default_rng(n)
+    if inp:
+        q = rng.standard_normal((n, 4)); q /= np.linalg.norm(q, axis=-1, keepdims=True)
+        tr = np.cumsum(rng.standard_normal((n, 3)) * 2.0, 0); tr -= tr.mean(0)
+        dm = np.zeros(n); dm[40:90] = 1  # one diffused window of 50 (config 5)
+        n1 = n // 2
+        feats_np = {"rigids_0": np.concatenate([q, tr], -1).astype(np.float32), "diffuse_mask": dm,
+                    "aatype": rng.integers(0, 20, n), "seq_idx": np.concatenate([np.arange(n1), np.arange(n - n1) + n1 + 200]),
+                    "chain_idx": np.concatenate([np.zeros(n1), np.ones(n - n1)]),
+                    "torsion_angles_sin_cos": np.tile(np.array([0.0, 1.0]), (n, 7, 1))}
+        ds = ConditionalSampler([("synthetic", feats_np)], d, "cuda", samples_per_structure=B)
+        items = [ds[i][2] for i in range(B)]
+    else:
+        ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1,
+                                                  "samples_per_length": B}), d, "cuda")
+        items = [ds[i][2] for i in range(B)]
+    feats = {k: torch.cat([it[k] for it in items], 0) for k in items[0]}
+    res = inference.inference_fn(net, d, feats, num_t=2, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp)
+    assert res["prot_traj"].shape == (2, B, n, 37, 3) and res["rigid_traj"].shape == (3, B, n, 7)
+    for k in ("prot_traj", "rigid_traj", "trans_traj", "rigid_0_traj"):
+        assert np.isfinite(res[k]).all(), k
+    rot = R.quat_to_rot(torch.as_tensor(res["rigid_traj"][0][..., :4].copy(), device="cuda")).cpu().numpy()
+    np.testing.assert_allclose(rot @ np.swapaxes(rot, -1, -2), np.broadcast_to(np.eye(3), rot.shape), atol=1e-4)
+    if inp:  # motif residues never move (se3_diffuser.py:397-399); the last step returns the x0 prediction for all
+        fixed = feats["fixed_mask"][0].cpu().numpy().astype(bool)
+        x_T, x_1 = res["rigid_traj"][-1][0], res["rigid_traj"][1][0]
+        np.testing.assert_allclose(x_1[fixed, 4:], x_T[fixed, 4:], atol=1e-4)
+
+
+def test_fused_node_chains_vs_gemm_path():
+    """bf16 node path: every fused chain kind (chain.hip, FDIPT_CHAIN_MASK=0xfff: also the kinds that are off by
+    default) vs separate GEMM + LayerNorm launches (FDIPT_NO_CHAIN)."""
+    import os
+    G = load_golden("fwd_full_denovo_n64.npz")
+    outs = {}
+    for tag, env in (("chain", {"FDIPT_CHAIN_MASK": "0xfff"}), ("gemm", {"FDIPT_NO_CHAIN": "1"})):
+        for k in ("FDIPT_NO_CHAIN", "FDIPT_CHAIN_MASK"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            net, _, conf = _net("full_denovo_n64", G, "bf16")
+            out = net(_feats(G), trace=True)
+            outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["psi"].cpu().numpy().copy())
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    for b in range(5):
+        a, c = outs["gemm"][0][b], outs["chain"][0][b]
+        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, b
+        if b > 0:
+            ref = G[f"tr_node_{b - 1}"]
+            assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, b
+    np.testing.assert_allclose(outs["gemm"][1], outs["chain"][1], atol=3e-2)
