@@ -81,8 +81,11 @@ __device__ __forceinline__ void ch_static_for(F&& f) {
 // two output tiles of one layer, D^T[feature, row] = W X^T, from an LDS-resident fragment image of the pair:
 // [tile A: KS KB][tile B: KS KB]; the result chains into the next layer's B operand without leaving registers.
 template <int KS, bool HASB>
+#ifndef CH_DEPTH
+#define CH_DEPTH 4
+#endif
 __device__ __forceinline__ void ch_pair(f32x16& accA, f32x16& accB, const char* wp, const bf16x8* Bin, int lane) {
-  constexpr int DEPTH = 4;
+  constexpr int DEPTH = CH_DEPTH;
   const char* pa = wp + lane * 16;
   const char* pb = pa + (HASB ? KS * 1024 : 0);
   bf16x8 ringA[DEPTH], ringB[DEPTH];

@@ -28,7 +28,8 @@
 #define ET2_SLAB_L1 (32 * 256 * 2)   // 16 KB : 32 out features x K=256 (z | e_j)
 #define ET2_SLAB_L2 (32 * 384 * 2)   // 24 KB : 32 out features x K=384 (h1, permuted k)
 #define ET2_SLAB_FH (128 * 32 * 2)   //  8 KB : 128 final outputs x 32 k (one h2 tile, permuted k)
-#define ET2_STREAM_BYTES (12 * ET2_SLAB_L1 + 4 * ET2_SLAB_L1 + 12 * (ET2_SLAB_L2 + ET2_SLAB_FH))
+#define ET2_TAIL (2 * ET2_SLAB_FH)     // 16 KB: final-layer slabs of the LAST pair of layer-2 tiles
+#define ET2_STREAM_BYTES (12 * ET2_SLAB_L1 + 4 * ET2_SLAB_L1 + 12 * (ET2_SLAB_L2 + ET2_SLAB_FH) + ET2_TAIL)
 #define ET2_BUF (ET2_SLAB_L2 + ET2_SLAB_FH)  // 32 KB per LDS buffer
 
 // logical (row, 16-byte chunk) -> byte offset inside a slab image (bank-conflict-free ds_read_b128, see T2)
@@ -62,8 +63,18 @@ __global__ void et2_build_stream_kernel(const float* __restrict__ w1, const floa
       kmode = 0;
     } else {
       byte -= 16 * ET2_SLAB_L1;
-      T = byte / ET2_BUF;
-      const int r2 = byte % ET2_BUF;
+      // the FH slab that travels with layer-2 tile T belongs to tile T - 2 (the PREVIOUS pair: its final-layer update
+      // runs inside the next pair's MFMA stream); tiles 0, 1 carry zeros and the last pair's slabs form the tail
+      int fh_tile = -1, r2;
+      if (byte < 12 * ET2_BUF) {
+        T = byte / ET2_BUF;
+        r2 = byte % ET2_BUF;
+        if (r2 >= ET2_SLAB_L2) fh_tile = T - 2;
+      } else {
+        const int tb = byte - 12 * ET2_BUF;
+        fh_tile = 10 + tb / ET2_SLAB_FH;
+        r2 = ET2_SLAB_L2 + tb % ET2_SLAB_FH;
+      }
       if (r2 < ET2_SLAB_L2) {
         const int q = r2 / 16;
         row = q / 48;
@@ -75,7 +86,7 @@ __global__ void et2_build_stream_kernel(const float* __restrict__ w1, const floa
         row = q / 4;
         const int cp = q % 4;
         c = cp ^ ((row >> 2) & 3);
-        src = wf; n = row; kmode = 1; kbase = 32 * T;
+        src = fh_tile >= 0 ? wf : nullptr; n = row; kmode = 1; kbase = 32 * (fh_tile >= 0 ? fh_tile : 0);
       }
     }
     bf16_t out[8];
@@ -84,7 +95,7 @@ __global__ void et2_build_stream_kernel(const float* __restrict__ w1, const floa
       int col;
       if (kmode == 0) col = k < ET2_CZ ? k : (ET2_CZ + ET2_CB) + (k - ET2_CZ);
       else col = kbase + (k & ~15) + et2_perm16(k & 15);
-      out[e] = f2bf(src[(long)n * ld + col]);
+      out[e] = src ? f2bf(src[(long)n * ld + col]) : (bf16_t)0;
     }
     for (int e = 0; e < 8; ++e) stream[(long)g * 8 + e] = out[e];
   }
@@ -98,6 +109,7 @@ int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void*
 size_t fd_et2_stream_bytes() { return ET2_STREAM_BYTES; }
 
 // ------------------------------------------------------------------ kernel
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   bf16x8 o;
 #pragma unroll
@@ -109,12 +121,25 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // (global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16, so the image is simply linear).
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gl_void_t;
+// One 16 B-per-lane LDS-DMA (global_load_lds_dwordx4; LDS destination = wave-uniform `lds_dst` + lane * 16), written as
+// inline asm ON PURPOSE: hipcc's waitcnt pass treats the builtin as a FLAT access that is pending on both counters and
+// then forces EVERY later LDS wait to lgkmcnt(0) until the DMA has been waited for — i.e. for the whole chunk, which
+// stalled the ds_read -> MFMA stream on the full LDS latency every third k-step.  With the asm form the pass does not see
+// the DMA at all: every consumer of DMA'd data therefore sits behind an explicit et2_dma_wait() + barrier.
+__device__ __forceinline__ void et2_dma16(const void* gsrc, const char* lds_dst) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(gsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void et2_dma_wait() {  // every DMA (and ordinary vector-memory op) of this wave retired
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+}
 template <int BYTES>
 __device__ __forceinline__ void dma_slab(const char* __restrict__ src, char* lds_dst, int tid) {
 #pragma unroll
   for (int u = 0; u < BYTES / 16 / FD_THREADS; ++u)
-    __builtin_amdgcn_global_load_lds((gl_void_t*)(src + (size_t)(u * FD_THREADS + tid) * 16),
-                                     (lds_void_t*)(lds_dst + (size_t)(u * FD_THREADS + (tid & ~63)) * 16), 16, 0, 0);
+    et2_dma16(src + (size_t)(u * FD_THREADS + tid) * 16, lds_dst + (size_t)(u * FD_THREADS + (tid & ~63)) * 16);
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* slab, int off) {
@@ -191,6 +216,67 @@ __device__ __forceinline__ void ln_epilogue(f32x16 (&Y)[4], const float* __restr
   }
 }
 
+// ET2 form of the epilogue: every operand comes from LDS (Af row, gamma, beta) and the bf16 result leaves through a
+// wave-private LDS tile [32 pairs][256 B] so that the global stores are whole 256 B rows per 16 lanes — the wave's 32
+// pairs are one contiguous 8 KB span of z_out.  `stage`: 8 KB of LDS nobody else touches (a retired weight buffer).
+__device__ __forceinline__ void ln_epilogue_staged(f32x16 (&Y)[4], const float* addrow, const float* gamma_l,
+                                                   const float* beta_l, float em, int li, int hi, int lane, char* stage,
+                                                   bf16_t* __restrict__ z_out, long p0, long n_pairs,
+                                                   float* __restrict__ tr_row, bool valid) {
+  float s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(addrow + 32 * t + 8 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Y[t][4 * g + q] += bv[q];
+        s1 += Y[t][4 * g + q];
+      }
+    }
+  s1 += __shfl_xor(s1, 32, 64);
+  const float mu = s1 * (1.0f / ET2_CZ);
+  float s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = Y[t][r] - mu;
+      s2 += d * d;
+    }
+  s2 += __shfl_xor(s2, 32, 64);
+  const float rstd = 1.0f / sqrtf(s2 * (1.0f / ET2_CZ) + 1e-5f);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f0 = 32 * t + 8 * g + 4 * hi;
+      const f32x4 gm = *(const f32x4*)(gamma_l + f0), bt = *(const f32x4*)(beta_l + f0);
+      float of[4];
+      bf16x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        of[q] = ((Y[t][4 * g + q] - mu) * rstd * gm[q] + bt[q]) * em;
+        o[q] = (__bf16)of[q];
+      }
+      // features f0..f0+3 = bytes 2 f0 .. 2 f0 + 7 of the pair's row: 16 B unit 4t + g, half hi; unit u of row r at u ^ (r & 15)
+      *(bf16x4*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = o;
+      if (tr_row && valid) {
+        f32x4 tv = {of[0], of[1], of[2], of[3]};
+        *(f32x4*)(tr_row + f0) = tv;
+      }
+    }
+  // same wave wrote the tile: LDS operations of one wave execute in order, no barrier
+  const int sr = lane >> 4, sc = lane & 15;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = 4 * it + sr;
+    const u16x8 v = *(const u16x8*)(stage + r * 256 + ((sc ^ (r & 15)) << 4));
+    if (p0 + r < n_pairs) *(u16x8*)(z_out + (p0 + r) * ET2_CZ + 8 * sc) = v;
+  }
+}
+
 // Two 32-feature output tiles at once: their MFMA streams are interleaved (A, B, A, B, ...) so that consecutive MFMAs
 // never hit the same accumulator, and the epilogue of the PREVIOUS pair (bias + ReLU + bf16 pack of its 2x16
 // accumulator registers, biases read from the LDS-staged A1 rows) is spread over the MFMA slots.
@@ -198,7 +284,7 @@ __device__ __forceinline__ void ln_epilogue(f32x16 (&Y)[4], const float* __restr
 #define ET2_CHUNK 65536      // bytes of weight stream per barrier (4 L1/FX slabs, or 2 x (L2 slab + FH slab))
 #define ET2_BROWS 4          // A1/Af rows (distinct b*N+i) a 128-pair tile may touch: N >= 43
 #define ET2_BROW_BYTES 2048  // one staged row: A1[384] | Af[128] fp32
-#define ET2_LDS (2 * ET2_CHUNK + 2 * ET2_BROWS * ET2_BROW_BYTES + 1536)
+#define ET2_LDS (2 * ET2_CHUNK + 2 * ET2_BROWS * ET2_BROW_BYTES + 1536 + 1024)  // ... + b2[384] + gamma[128] + beta[128]
 
 // `aoff[e]` = LDS byte offset of this lane's fragment for k-steps s == e (mod 8) of a slab at offset 0 of the current
 // buffer (swizzle folded in, computed once per kernel); everything else is a compile-time immediate, so a fragment
@@ -247,21 +333,101 @@ __device__ __forceinline__ void pair_stream(f32x16& accA, f32x16& accB, const ch
   }
 }
 
-// raw (unconverted) x = [z_ij | e_j] rows of one 32-pair wave tile, fetched one block tile ahead
-struct XRaw {
-  u16x8 z[8];
-  f32x4 e[16];
-};
-__device__ __forceinline__ void x_load(XRaw& r, const ET2Args& a, long p, long bj, int hi) {
-  const bf16_t* zr = a.z_in + p * ET2_CZ + 8 * hi;
+// Layer-2 pair of tiles (K = 384: 24 k-steps, 48 MFMAs) with the PREVIOUS pair's tail folded into the stream: its bias +
+// ReLU + bf16 pack during k-steps 0..15 and its 16 final-layer MFMAs (Y[t] += Wf[:, h2 tile] h2, FH slabs travelling with
+// this chunk) one per k-step from k-step 8 on.  The MFMA pipe then sees 64 back-to-back MFMAs on 6 different
+// accumulators with every VALU instruction and LDS read in their shadow.
+template <bool PEND>
+__device__ __forceinline__ void pair_stream_l2(f32x16& accA, f32x16& accB, f32x16 (&Y)[4], const char* lds,
+                                               const int (&aoff)[8], const int (&afh)[2], const bf16x8* Bf,
+                                               const f32x16& paccA, const f32x16& paccB, const float* pbA, const float* pbB) {
+  constexpr int DEPTH = 4, KS = 24;
+  f32x4 bA[4], bB[4];
+  if (PEND) {
 #pragma unroll
-  for (int s = 0; s < 8; ++s) r.z[s] = *(const u16x8*)(zr + 16 * s);
-  const float* er = a.e + bj * ET2_CB + 8 * hi;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    r.e[2 * s] = *(const f32x4*)(er + 16 * s);
-    r.e[2 * s + 1] = *(const f32x4*)(er + 16 * s + 4);
+    for (int g = 0; g < 4; ++g) {
+      bA[g] = *(const f32x4*)(pbA + 8 * g);
+      bB[g] = *(const f32x4*)(pbB + 8 * g);
+    }
   }
+  bf16x8 ringA[DEPTH], ringB[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s) {
+    ringA[s] = lds_frag(lds, aoff[s & 7] + 256 * (s >> 3));
+    ringB[s] = lds_frag(lds, aoff[s & 7] + ET2_BUF + 256 * (s >> 3));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float vA[16], vB[16];
+  bf16x8 hA[2], hB[2];   // h2 fragments of the pending pair (k-steps 0, 1 of its final-layer update)
+  bf16x8 fr[4];          // FH fragment ring: the fragment of slot q is read two k-steps ahead
+  // FH MFMA slot q (0..15), issued at k-step 8 + q: kk = q >> 3 (h2 k-step), tile-of-pair = (q >> 2) & 1, output tile t = q & 3
+  auto fh_addr = [&](int q) { return afh[q >> 3] + ((q >> 2) & 1) * ET2_BUF + ET2_SLAB_L2 + (q & 3) * 2048; };
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + DEPTH - 1 < KS) {
+      constexpr int D1 = DEPTH - 1;
+      ringA[(s + D1) % DEPTH] = lds_frag(lds, aoff[(s + D1) & 7] + 256 * ((s + D1) >> 3));
+      ringB[(s + D1) % DEPTH] = lds_frag(lds, aoff[(s + D1) & 7] + ET2_BUF + 256 * ((s + D1) >> 3));
+    }
+    if (PEND && s >= 6 && s - 6 < 16) fr[(s - 6) % 4] = lds_frag(lds, fh_addr(s - 6));
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ringA[s % DEPTH], Bf[s], accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ringB[s % DEPTH], Bf[s], accB, 0, 0, 0);
+    if (PEND && s >= 8) {
+      const int q = s - 8;
+      const bf16x8 hh = ((q >> 2) & 1) ? hB[q >> 3] : hA[q >> 3];
+      Y[q & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[q % 4], hh, Y[q & 3], 0, 0, 0);
+    }
+    if (PEND && s < 16) {
+      vA[s] = fmaxf(paccA[s] + bA[s >> 2][s & 3], 0.f);
+      vB[s] = fmaxf(paccB[s] + bB[s >> 2][s & 3], 0.f);
+      if (s == 7) { hA[0] = pack8(vA); hB[0] = pack8(vB); }
+      if (s == 15) { hA[1] = pack8(vA + 8); hB[1] = pack8(vB + 8); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// x = [z_ij | e_j] rows of one 32-pair wave tile -> wave-private LDS tile -> B fragments.  Global side: every access is
+// a whole 256 B row per 16 lanes (the 16 B-per-lane fragment pattern costs 8x more TA cycles, tools/micro/io_pattern.hip):
+//   z rows (bf16, the wave's 32 pairs are ONE contiguous 8 KB span) go global -> LDS by DMA with the swizzle applied on the
+//   SOURCE side (LDS destination of a DMA is linear in the lane): unit u' of row r holds logical unit u' ^ (r & 15);
+//   e_j rows (fp32) are loaded as row segments, converted and written with the same swizzle.
+// Layout of the wave's stage: [z: 32 rows x 256 B][e: 32 rows x 256 B] = 16 KB.
+__device__ __forceinline__ void x_stage_z_dma(const ET2Args& a, long p0, int rmax, char* stage, int lane) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int r = 4 * k + (lane >> 4);
+    const int u = (lane & 15) ^ (r & 15);
+    if (r > rmax) r = rmax;
+    et2_dma16(a.z_in + (p0 + r) * ET2_CZ + 8 * u, stage + k * 1024);
+  }
+}
+// bj0 / j0: e row (b*N + j) and j of the wave's first pair.  Row r is pair (i, j0 + r) until j runs past N - 1, where it
+// wraps to (i + 1, j0 + r - N): the e row index drops by N — unless i was the sample's last row (last_i), in which case
+// the pair belongs to the next sample and the e row index simply keeps counting.
+__device__ __forceinline__ void x_stage_e(const ET2Args& a, long bj0, int j0, bool last_i, int rmax, char* stage, int lane) {
+  const int sr = lane >> 4, sc = lane & 15;
+  f32x4 v[2][8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    int r = 4 * it + sr;
+    if (r > rmax) r = rmax;
+    long bj = bj0 + r;
+    if (j0 + r >= a.N && !last_i) bj -= a.N;
+    const float* er = a.e + bj * ET2_CB + 4 * sc;
+    v[0][it] = *(const f32x4*)er;
+    v[1][it] = *(const f32x4*)(er + 64);
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = 4 * it + sr;
+      bf16x4 pk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)v[c][it][q];
+      *(bf16x4*)(stage + 8192 + r * 256 + (((8 * c + (sc >> 1)) ^ (r & 15)) << 4) + 8 * (sc & 1)) = pk;
+    }
 }
 // A1 | Af rows i_lo .. i_lo+3 of a block tile -> LDS (per-lane source, linear destination)
 __device__ __forceinline__ void bias_rows_dma(const ET2Args& a, long i_lo, long n_rows, char* dst, int tid) {
@@ -271,9 +437,18 @@ __device__ __forceinline__ void bias_rows_dma(const ET2Args& a, long i_lo, long 
     long r = i_lo + row;
     if (r >= n_rows) r = n_rows - 1;
     const float* src = q < 96 ? a.a1 + r * ET2_H + 4 * q : a.af + r * ET2_CZ + 4 * (q - 96);
-    __builtin_amdgcn_global_load_lds((gl_void_t*)src, (lds_void_t*)(dst + (size_t)(u * FD_THREADS + (tid & ~63)) * 16), 16, 0, 0);
+    et2_dma16(src, dst + (size_t)(u * FD_THREADS + (tid & ~63)) * 16);
   }
 }
+
+// Optional in-kernel phase timestamps (tools/micro/et2_bench.hip builds with -DET2_PROF): wave 0 of every block records
+// s_memtime at the phase boundaries into et2_prof[block][16].  Never enabled in the library build.
+#ifdef ET2_PROF
+__device__ unsigned long long et2_prof[8192 * 16];
+#define ET2_STAMP(k) do { if (tid0 == 0) et2_prof[(blockIdx.x & 8191) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ET2_STAMP(k) do { } while (0)
+#endif
 
 // Persistent: one block per CU walks the 128-pair tiles.  Per tile 10 chunks of the weight stream (one barrier each);
 // the next tile's x rows, bias rows and first chunk are fetched under the last chunks of the current tile, and the
@@ -291,22 +466,39 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
 
   int tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  // ---- prologue of the first tile
+  ET2_STAMP(0);
+  // ---- prologue: x rows -> wave stage (inside chunk buffer 1, free until the first chunk's barrier), first weight chunk,
+  // bias rows and the small vectors, all asynchronous; one wait + barrier for the lot
   long p_raw = (long)tile * 128 + wave * 32 + li0;
   bool valid = p_raw < n_pairs;
   long p = valid ? p_raw : n_pairs - 1;
   long bi = p / N;
   long bj = (bi / N) * N + (p - bi * N);
   long i_lo = ((long)tile * 128) / N;
-  XRaw xr;
-  x_load(xr, a, p, bj, hi0);
-  dma_slab<ET2_CHUNK>(stream, smem, tid0);
-  bias_rows_dma(a, i_lo, n_rows, brow_lds, tid0);
-  if (tid0 < 96) __builtin_amdgcn_global_load_lds((gl_void_t*)(a.b2 + 4 * tid0), (lds_void_t*)((char*)b2_lds + (tid0 & ~63) * 16), 16, 0, 0);
+  char* xstage = smem + ET2_CHUNK + wave * 16384;
+  {
+    long p0 = (long)tile * 128 + wave * 32;
+    if (p0 > n_pairs - 1) p0 = n_pairs - 1;
+    const long rem = n_pairs - 1 - p0;
+    const int rmax = rem < 31 ? (int)rem : 31;
+    const long bi0 = p0 / N;
+    const int j0 = (int)(p0 - bi0 * N);
+    const long b0 = bi0 / N;
+    const bool last_i = bi0 - b0 * N == N - 1;
+    x_stage_z_dma(a, p0, rmax, xstage, lane);
+    dma_slab<ET2_CHUNK>(stream, smem, tid0);
+    bias_rows_dma(a, i_lo, n_rows, brow_lds, tid0);
+    if (tid0 < 160) {  // b2[384] | gamma[128] | beta[128] -> LDS, 16 B per lane
+      const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
+      et2_dma16(src, (const char*)b2_lds + (tid0 & ~63) * 16);
+    }
+    x_stage_e(a, b0 * N + j0, j0, last_i, rmax, xstage, lane);
+  }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  ET2_STAMP(1);
   int it = 0;
 #pragma unroll 1
   for (; it < 1; tile += gridDim.x, ++it) {  // one tile per block (the persistent form spills: see DESIGN.md)
@@ -333,10 +525,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     bf16x8 X[16];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      X[s] = __builtin_bit_cast(bf16x8, xr.z[s]);
-      const float v[8] = {xr.e[2 * s][0], xr.e[2 * s][1], xr.e[2 * s][2], xr.e[2 * s][3],
-                          xr.e[2 * s + 1][0], xr.e[2 * s + 1][1], xr.e[2 * s + 1][2], xr.e[2 * s + 1][3]};
-      X[8 + s] = pack8(v);
+      X[s] = lds_frag(xstage, li * 256 + (((2 * s + hi) ^ (li & 15)) << 4));
+      X[8 + s] = lds_frag(xstage, 8192 + li * 256 + (((2 * s + hi) ^ (li & 15)) << 4));
     }
     // identifiers of this tile (for the epilogue) and of the next one (for the prefetch)
     const long p_cur = p;
@@ -353,8 +543,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
       i_lo = ((long)ntile * 128) / N;
     }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // res_mask loads retired before the first DMA of the tile is issued
+    __builtin_amdgcn_s_waitcnt(0x0070);  // res_mask loads and the x fragments (LDS) retired ...
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // ... in every wave, before chunk buffer 1 (the x stage) receives the second chunk
 
     bf16x8 H1[24];
     f32x16 Y[4];
@@ -395,7 +586,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
         paccA = accA;
         paccB = accB;
       }
+      et2_dma_wait();
       __syncthreads();
+      ET2_STAMP(2 + c);
       buf ^= 1;
       soff += ET2_CHUNK;
     }
@@ -411,68 +604,77 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
         else pair_stream<16, 0, 2 * ET2_SLAB_L1, 3 * ET2_SLAB_L1>(Y[2], Y[3], smem, a512[1], X, paccA, paccB, a1l, a1l, dummy,
                                                                   dummy);
       }
+      et2_dma_wait();
       __syncthreads();
+      ET2_STAMP(5);
       buf ^= 1;
       soff += ET2_CHUNK;
     }
-    // ================= layer 2 (+ fused final layer h part): 6 chunks = 6 pairs of tiles, K = 384
+    // ================= layer 2 (+ fused final layer h part): 6 chunks = 6 pairs of tiles, K = 384.  The tail of pair
+    // c2 - 1 (bias, ReLU, pack, Y += Wf[:, h2] h2) runs inside the stream of pair c2; the last pair's tail follows.
 #pragma unroll
     for (int c2 = 0; c2 < 6; ++c2) {
       if (c2 < 5) dma_slab<ET2_CHUNK>(stream + soff + ET2_CHUNK, smem + (buf ^ 1) * ET2_CHUNK, tid);
-      else if (has_next) {  // last chunk: start the next tile (first weight chunk, bias rows, x rows)
-        dma_slab<ET2_CHUNK>(stream, smem + (buf ^ 1) * ET2_CHUNK, tid);
-        bias_rows_dma(a, i_lo, n_rows, brow_lds + ((it + 1) & 1) * ET2_BROWS * ET2_BROW_BYTES, tid);
-        x_load(xr, a, p, bj, hi);
-      }
+      else dma_slab<ET2_TAIL>(stream + soff + ET2_CHUNK, smem + (buf ^ 1) * ET2_CHUNK, tid);
       f32x16 accA, accB;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
       // buf == c2 & 1 in this phase (chunk 4 + c2)
-      pair_stream<24, 0, 0, ET2_BUF>(accA, accB, smem, a768[c2 & 1], H1, paccA, paccB, a1l, a1l, dummy, dummy);
-      // epilogue of the pair + its final-layer update: the 8 FH MFMAs of tile A run under the epilogue of tile B
+      if (c2 == 0) pair_stream_l2<false>(accA, accB, Y, smem, a768[0], afh[0], H1, paccA, paccB, b2l, b2l);
+      else pair_stream_l2<true>(accA, accB, Y, smem, a768[c2 & 1], afh[c2 & 1], H1, paccA, paccB, b2l + 32 * (2 * (c2 > 0 ? c2 - 1 : 0)),
+                                b2l + 32 * (2 * (c2 > 0 ? c2 - 1 : 0) + 1));
+      paccA = accA;
+      paccB = accB;
+      et2_dma_wait();
+      __syncthreads();
+      buf ^= 1;
+      soff += ET2_CHUNK;
+      ET2_STAMP(6 + c2);
+    }
+    // tail of the last pair: its FH slabs are the 16 KB just landed in buffer 0
+    {
       bf16x8 fhA[8], fhB[8];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        fhA[2 * t] = lds_frag(smem, afh[c2 & 1][0] + ET2_SLAB_L2 + t * 2048);
-        fhA[2 * t + 1] = lds_frag(smem, afh[c2 & 1][1] + ET2_SLAB_L2 + t * 2048);
-        fhB[2 * t] = lds_frag(smem, afh[c2 & 1][0] + ET2_BUF + ET2_SLAB_L2 + t * 2048);
-        fhB[2 * t + 1] = lds_frag(smem, afh[c2 & 1][1] + ET2_BUF + ET2_SLAB_L2 + t * 2048);
+        fhA[2 * t] = lds_frag(smem, afh[0][0] + t * 2048);
+        fhA[2 * t + 1] = lds_frag(smem, afh[0][1] + t * 2048);
+        fhB[2 * t] = lds_frag(smem, afh[0][0] + ET2_SLAB_FH + t * 2048);
+        fhB[2 * t + 1] = lds_frag(smem, afh[0][1] + ET2_SLAB_FH + t * 2048);
       }
       f32x4 bA[4], bB[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bA[g] = *(const f32x4*)(b2l + 32 * (2 * c2) + 8 * g);
-        bB[g] = *(const f32x4*)(b2l + 32 * (2 * c2 + 1) + 8 * g);
+        bA[g] = *(const f32x4*)(b2l + 32 * 10 + 8 * g);
+        bB[g] = *(const f32x4*)(b2l + 32 * 11 + 8 * g);
       }
       float vA[16], vB[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) vA[r] = fmaxf(accA[r] + bA[r >> 2][r & 3], 0.f);
+      for (int r = 0; r < 16; ++r) vA[r] = fmaxf(paccA[r] + bA[r >> 2][r & 3], 0.f);
       const bf16x8 hA0 = pack8(vA), hA1 = pack8(vA + 8);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         Y[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhA[q], (q & 1) ? hA1 : hA0, Y[q >> 1], 0, 0, 0);
-        vB[2 * q] = fmaxf(accB[2 * q] + bB[(2 * q) >> 2][(2 * q) & 3], 0.f);
-        vB[2 * q + 1] = fmaxf(accB[2 * q + 1] + bB[(2 * q + 1) >> 2][(2 * q + 1) & 3], 0.f);
+        vB[2 * q] = fmaxf(paccB[2 * q] + bB[(2 * q) >> 2][(2 * q) & 3], 0.f);
+        vB[2 * q + 1] = fmaxf(paccB[2 * q + 1] + bB[(2 * q + 1) >> 2][(2 * q + 1) & 3], 0.f);
         __builtin_amdgcn_sched_barrier(0);
       }
       const bf16x8 hB0 = pack8(vB), hB1 = pack8(vB + 8);
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         Y[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fhB[q], (q & 1) ? hB1 : hB0, Y[q >> 1], 0, 0, 0);
-      if (c2 < 5) {
-        __syncthreads();
-        buf ^= 1;
-        soff += ET2_CHUNK;
-      }
     }
     // ================= epilogue: + Af[i] (LDS row), LayerNorm over the 128 features of each pair, mask, store
-    ln_epilogue(Y, a1l + ET2_H, a.gamma, a.beta, em_cur, valid_cur, hi, a.z_out + p_cur * ET2_CZ,
-                a.trace ? a.trace + p_cur * ET2_CZ : nullptr);
+    // chunk buffer 0 only holds the 16 KB tail slabs (other waves may still be reading them): its upper half stages the output rows
+    ln_epilogue_staged(Y, a1l + ET2_H, b2_lds + ET2_H, b2_lds + ET2_H + ET2_CZ, em_cur, li, hi, lane,
+                       smem + 32768 + wave * 8192, a.z_out, (long)tile * 128 + wave * 32, n_pairs,
+                       a.trace ? a.trace + p_cur * ET2_CZ : nullptr, valid_cur);
+    ET2_STAMP(12);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // next tile's DMA + x rows landed (and this tile's stores issued)
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    ET2_STAMP(13);
   }
 }
 
@@ -529,6 +731,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void edge_embed2_kernel(EdgeEmbedArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, li = lane & 31;
   dma_slab<2 * EE2_IMG>(img, smem, tid);
+  et2_dma_wait();
   __syncthreads();
   const int N = a.N;
   const long n_pairs = (long)a.B * N * N;
