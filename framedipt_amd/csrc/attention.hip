@@ -9,6 +9,8 @@
 //   points_kernel             : "split-thirds then stack" + Rigid.apply of the projected points (ipa_pytorch.py:213-239)
 //
 // One block = 32 query rows of one (batch, head); logits of the 32 rows stay in LDS as fp32 [32][N].
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -266,50 +268,83 @@ int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st) {
 // One block per (b, i): streams the pair row z[b,i,:,:] ONCE with 16-byte loads (HBM-bound, N*CZ*sizeof(ZT) bytes),
 // thread = (8-channel group, key slice); az[h][c] = sum_j a[h,i,j] z[i,j,c] in registers, slices folded by
 // wave shuffles then across the 4 waves through LDS; then the (c_z -> c_z/4) down-projection per head.
+// HBM-bound (one pass over z): the z rows of a thread are fetched in chunks of OP_CH rows, chunk c+1 in flight while
+// chunk c is consumed, and the first chunk is issued before anything else; the down-projection weights sit in LDS.
+#define OP_CH 8
 template <class ZT, int CZ>
 __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCG = CZ / 8;              // channel groups of 8
   constexpr int NSL = FD_THREADS / NCG;    // key slices per block
-  constexpr int SPW = 64 / NCG > 0 ? 64 / NCG : 1;  // slices inside one wave
-  const int N = a.N, H = a.H;
+  constexpr int EPT = sizeof(ZT) == 2 ? 1 : 2;  // 16-byte loads per row piece
+  const int N = a.N, H = a.H, CD = a.CD;
   float* ps = (float*)smem;                // [H][N]
   float* red = ps + ((H * N + 3) & ~3);    // [4 waves][8 heads][CZ]
   float* psum = red + 4 * 8 * CZ;          // [8]
+  float* wdl = psum + 8;                   // [CZ][CD] down-projection weights
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = blockIdx.x, b = blockIdx.y;
   const long rb = (long)b * N;
+  const ZT* zrow = (const ZT*)a.z + (rb + i) * N * CZ;
+  const int cg = tid % NCG, sl = tid / NCG;
+  const int nk = (N - sl + NSL - 1) / NSL;  // rows of this thread: j = sl + k * NSL, k < nk
+  f32x4 zr[2][OP_CH][EPT];
+  auto fetch = [&](int buf, int k0) {
+#pragma unroll
+    for (int u = 0; u < OP_CH; ++u) {
+      int k = k0 + u;
+      if (k >= nk) k = nk > 0 ? nk - 1 : 0;  // harmless re-read, discarded below
+      const ZT* zp = zrow + (long)(sl + k * NSL < N ? sl + k * NSL : 0) * CZ + cg * 8;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) zr[buf][u][e] = *(const f32x4*)((const char*)zp + 16 * e);
+    }
+  };
+  fetch(0, 0);
   for (int v = tid; v < H * N; v += FD_THREADS) {
     const int hh = v / N, j = v % N;
     ps[v] = a.probs[(((long)b * H + hh) * N + i) * N + j];
   }
+  for (int v = tid; v < CZ * CD; v += FD_THREADS) wdl[v] = a.wdz[v];
   __syncthreads();
-  const ZT* zrow = (const ZT*)a.z + (rb + i) * N * CZ;
-  const int cg = tid % NCG, sl = tid / NCG;
   float acc[8][8];
 #pragma unroll
   for (int hh = 0; hh < 8; ++hh)
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[hh][c] = 0.f;
-  for (int j = sl; j < N; j += NSL) {
-    float zv[8];
-    if constexpr (sizeof(ZT) == 2) {
-      const u16x8 raw = *(const u16x8*)(zrow + (long)j * CZ + cg * 8);
+  auto consume = [&](auto BUF, int k0) {
+    constexpr int bf = decltype(BUF)::value;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) zv[c] = bf2f(raw[c]);
-    } else {
-      const f32x4 r0 = *(const f32x4*)(zrow + (long)j * CZ + cg * 8), r1 = *(const f32x4*)(zrow + (long)j * CZ + cg * 8 + 4);
+    for (int u = 0; u < OP_CH; ++u) {
+      if (k0 + u < nk) {
+        const int j = sl + (k0 + u) * NSL;
+        float zv[8];
+        if constexpr (sizeof(ZT) == 2) {
+          const u16x8 raw = __builtin_bit_cast(u16x8, zr[bf][u][0]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { zv[c] = r0[c]; zv[4 + c] = r1[c]; }
-    }
+          for (int c = 0; c < 8; ++c) zv[c] = bf2f(raw[c]);
+        } else {
 #pragma unroll
-    for (int hh = 0; hh < 8; ++hh) {
-      if (hh < H) {
-        const float pv = ps[hh * N + j];
+          for (int c = 0; c < 4; ++c) {
+            zv[c] = zr[bf][u][0][c];
+            zv[4 + c] = zr[bf][u][EPT - 1][c];
+          }
+        }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[hh][c] += pv * zv[c];
+        for (int hh = 0; hh < 8; ++hh) {
+          if (hh < H) {
+            const float pv = ps[hh * N + j];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[hh][c] += pv * zv[c];
+          }
+        }
       }
     }
+  };
+  for (int k0 = 0; k0 < nk; k0 += 2 * OP_CH) {
+    if (k0 + OP_CH < nk) fetch(1, k0 + OP_CH);
+    consume(std::integral_constant<int, 0>{}, k0);
+    if (k0 + 2 * OP_CH < nk) fetch(0, k0 + 2 * OP_CH);
+    if (k0 + OP_CH < nk) consume(std::integral_constant<int, 1>{}, k0 + OP_CH);
   }
   // fold the slices that live in the same wave (lane bits above the channel-group bits)
 #pragma unroll
@@ -318,35 +353,42 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
     for (int hh = 0; hh < 8; ++hh)
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[hh][c] += __shfl_xor(acc[hh][c], o, 64);
-  if (lane < NCG || NCG >= 64) {
-    if (lane < NCG)
+  if (lane < NCG) {
 #pragma unroll
-      for (int hh = 0; hh < 8; ++hh)
+    for (int hh = 0; hh < 8; ++hh)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) red[(wave * 8 + hh) * CZ + cg * 8 + c] = acc[hh][c];
+      for (int c = 0; c < 8; ++c) red[(wave * 8 + hh) * CZ + cg * 8 + c] = acc[hh][c];
   }
-  if (tid < H) {
+  // sum_j a[h,i,j] (= 1 up to rounding and masking): 32 threads per head
+  {
+    const int hh = tid >> 5, l5 = tid & 31;
     float sacc = 0.f;
-    for (int j = 0; j < N; ++j) sacc += ps[tid * N + j];
-    psum[tid] = sacc;
+    if (hh < H)
+      for (int j = l5; j < N; j += 32) sacc += ps[hh * N + j];
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
+    if (l5 == 0 && hh < 8) psum[hh] = sacc;
   }
   __syncthreads();
   for (int v = tid; v < 8 * CZ; v += FD_THREADS) red[v] = red[v] + red[8 * CZ + v] + red[16 * CZ + v] + red[24 * CZ + v];
   __syncthreads();
-  const int CD = a.CD;
   for (int o = tid; o < H * CD; o += FD_THREADS) {
     const int hh = o / CD, d = o % CD;
-    float sacc = a.bdz[d] * psum[hh];
+    float s0 = a.bdz[d] * psum[hh], s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 8
-    for (int cc = 0; cc < CZ; ++cc) sacc += red[hh * CZ + cc] * a.wdz[cc * CD + d];
-    a.out[(rb + i) * a.out_ld + a.off + hh * CD + d] = sacc;
+    for (int cc = 0; cc < CZ; cc += 4) {
+      s0 += red[hh * CZ + cc] * wdl[cc * CD + d];
+      s1 += red[hh * CZ + cc + 1] * wdl[(cc + 1) * CD + d];
+      s2 += red[hh * CZ + cc + 2] * wdl[(cc + 2) * CD + d];
+      s3 += red[hh * CZ + cc + 3] * wdl[(cc + 3) * CD + d];
+    }
+    a.out[(rb + i) * a.out_ld + a.off + hh * CD + d] = (s0 + s1) + (s2 + s3);
   }
-  (void)SPW; (void)NSL;
 }
 
 template <class ZT>
 static int launch_opair(const OPairArgs& a, hipStream_t st) {
-  const size_t smem = (((size_t)a.H * a.N + 3) & ~(size_t)3) * 4 + (size_t)(4 * 8 * a.CZ + 8) * 4;
+  const size_t smem = (((size_t)a.H * a.N + 3) & ~(size_t)3) * 4 + (size_t)(4 * 8 * a.CZ + 8) * 4 + (size_t)a.CZ * a.CD * 4;
   if (smem > 64 * 1024) return FDIPT_ESIZE;
   if (a.CZ == 128) hipLaunchKernelGGL((opair_kernel<ZT, 128>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
   else if (a.CZ == 32) hipLaunchKernelGGL((opair_kernel<ZT, 32>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);

@@ -3,7 +3,8 @@
 //
 // One block = 32 queries of one (batch, head); the KEYS are dealt round-robin to the block's 4 waves in tiles of 32,
 // so every lane holds only N/8 scores.  Operands come pre-formatted from ipa_proj_kernel (gemm.hip):
-//   scalar logits    S^T[key, query] = Kb_tile * Qb^T            bf16 MFMA, A (K rows) straight from HBM/L2, B = Q regs
+//   scalar logits    S^T[key, query] = Kb_tile * Qb^T            bf16 MFMA, A (K fragments, 1 KB linear loads) straight
+//                    from HBM/L2, B = Q regs
 //   point logits     -1/2 |q_pt - k_pt|^2 = q.k - |k|^2/2 - |q|^2/2  as a 26-deep fp32 MFMA (exact fp32 FMA chain):
 //                    A = [k_pts | -|k|^2/2 | 1] rows straight from HBM, B = [q_pts | 1 | -|q|^2/2] registers
 //   mask             m_i m_j as one more fp32 MFMA step (padded keys carry a -1e25 marker)
@@ -36,12 +37,25 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   u16x8* Pfs = (u16x8*)(opr + 4 * 32 * 36);                  // [2*nt][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const long rb = (long)b * N, bh = (long)b * H + h;
-  const int i_raw = blockIdx.x * 32 + li;
+  // XCD-aware block -> (sample, head, query tile): consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each),
+  // so the id is split as xcd = id % 8 and all nt query tiles of one (sample, head) are given to the SAME XCD: its K, V
+  // and Q images are then fetched into one L2 instead of eight.
+  const int BH = a.B * H;
+  int bhq, qt;
+  {
+    const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+    const int per = (BH + 7) >> 3;           // (sample, head) pairs per XCD (last ones may be short)
+    bhq = xcd * per + local / nt;
+    qt = local % nt;
+    if (local >= per * nt || bhq >= BH) return;
+  }
+  const int h = bhq % H, b = bhq / H;
+  const long rb = (long)b * N, bh = bhq;
+  const int i_raw = qt * 32 + li;
   const bool valid = i_raw < N;
   const int i = valid ? i_raw : N - 1;
 
+  FD_STAMP(0);
   // ---- v_pts of this head -> LDS (first read after the first barrier)
   {
     constexpr int NVV = (A3_NTW * 4 * 32 * 9 + FD_THREADS - 1) / FD_THREADS;  // 18
@@ -64,9 +78,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   // ---- query-side registers
   bf16x8 Qf[16];
   {
-    const bf16_t* qr = a.Qb + (bh * N + i) * A3_C + 8 * hi;
+    const bf16_t* qr = a.Qb + ((bh * nt + qt) * 16 * 64 + lane) * 8;  // fragment order: 1 KB per k-step
 #pragma unroll
-    for (int s = 0; s < 16; ++s) Qf[s] = a3_ld(qr + 16 * s);
+    for (int s = 0; s < 16; ++s) Qf[s] = a3_ld(qr + s * 512);
   }
   float qB[13];  // B operand of the point product: k index 2s+hi
   {
@@ -82,30 +96,57 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   const float gam = a.gamma[h];
   const float* brow = a.bias + (bh * N + i) * N;
 
-  // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...
+  FD_STAMP(1);
+  // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...  The global operands of tile u+1 (K rows as A
+  // fragments, key points, bias row pieces, mask) are fetched while tile u runs through the matrix cores.
+  struct TileIn {
+    bf16x8 k[16];
+    f32x4 kp[6];
+    f32x4 bv[4];
+    float mA;
+  };
+  auto tile_load = [&](TileIn& ti, int t) {
+    const int jA_raw = 32 * t + li;          // key owned by this lane as an A-operand ROW
+    const bool vA = jA_raw < N;
+    const int jA = vA ? jA_raw : N - 1;
+    const bf16_t* kr = a.Kb + ((bh * nt + t) * 16 * 64 + lane) * 8;  // fragment order (padded keys are zero rows)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) ti.k[s] = a3_ld(kr + s * 512);
+    const float* kpr = a.kp + ((rb + jA) * H + h) * 24;
+#pragma unroll
+    for (int c4 = 0; c4 < 6; ++c4) ti.kp[c4] = *(const f32x4*)(kpr + 4 * c4);
+    ti.mA = vA ? a.res_mask[rb + jA] : -1e25f;   // padded keys: marker so that the logit becomes -1e30
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j0 = 32 * t + 8 * g + 4 * hi;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (j0 + 3 < N && (N & 3) == 0) bv = *(const f32x4*)(brow + j0);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = j0 + q < N ? brow[j0 + q] : 0.f;
+      }
+      ti.bv[g] = bv;
+    }
+  };
   f32x16 S[A3_NTW];
+  TileIn tin[2];
+  if (wave < nt) tile_load(tin[0], wave);
 #pragma unroll
   for (int u = 0; u < A3_NTW; ++u) {
     const int t = wave + 4 * u;
+    if (u + 1 < A3_NTW && t + 4 < nt) tile_load(tin[(u + 1) & 1], t + 4);
     if (t < nt) {
-      const int jA_raw = 32 * t + li;          // key owned by this lane as an A-operand ROW
-      const bool vA = jA_raw < N;
-      const int jA = vA ? jA_raw : N - 1;
-      const bf16_t* kr = a.Kb + (bh * N + jA) * A3_C + 8 * hi;
+      const TileIn& ti = tin[u & 1];
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld(kr + 16 * s), Qf[s], acc, 0, 0, 0);
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ti.k[s], Qf[s], acc, 0, 0, 0);
       // point term: A row = [k_pts(24) | -|k|^2/2 | 1]
       float kpv[24];
-      {
-        const float* kpr = a.kp + ((rb + jA) * H + h) * 24;
 #pragma unroll
-        for (int c4 = 0; c4 < 6; ++c4) {
-          const f32x4 x = *(const f32x4*)(kpr + 4 * c4);
-          kpv[4 * c4] = x[0]; kpv[4 * c4 + 1] = x[1]; kpv[4 * c4 + 2] = x[2]; kpv[4 * c4 + 3] = x[3];
-        }
+      for (int c4 = 0; c4 < 6; ++c4) {
+        kpv[4 * c4] = ti.kp[c4][0]; kpv[4 * c4 + 1] = ti.kp[c4][1]; kpv[4 * c4 + 2] = ti.kp[c4][2]; kpv[4 * c4 + 3] = ti.kp[c4][3];
       }
       float kn = 0.f;
 #pragma unroll
@@ -117,30 +158,22 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
       for (int s = 0; s < 12; ++s)
         accp = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? kpv[2 * s + 1] : kpv[2 * s], qB[s], accp, 0, 0, 0);
       accp = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], accp, 0, 0, 0);
-      // mask product m_i m_j (padded keys: marker so that the logit becomes -1e30)
+      // mask product m_i m_j
       f32x16 accm;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accm[r] = 0.f;
-      const float mA = vA ? a.res_mask[rb + jA] : -1e25f;
-      accm = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : mA, hi ? 0.f : mi, accm, 0, 0, 0);
+      accm = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : ti.mA, hi ? 0.f : mi, accm, 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int j0 = 32 * t + 8 * g + 4 * hi;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (j0 + 3 < N && (N & 3) == 0) bv = *(const f32x4*)(brow + j0);
-        else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bv[q] = j0 + q < N ? brow[j0 + q] : 0.f;
-        }
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = 4 * g + q;
-          acc[r] = acc[r] + bv[q] + gam * accp[r] + 1e5f * (accm[r] - 1.f);
+          acc[r] = acc[r] + ti.bv[g][q] + gam * accp[r] + 1e5f * (accm[r] - 1.f);
         }
-      }
       S[u] = acc;
     }
   }
+  FD_STAMP(2);
   // ---- phase 2: softmax over all keys (own registers -> lane^32 -> the other 3 waves through LDS)
   float mx = -3.0e38f;
 #pragma unroll
@@ -166,6 +199,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   if (hi == 0) sms[wave * 32 + li] = sum;
   __syncthreads();
   const float inv = 1.0f / (sms[li] + sms[32 + li] + sms[64 + li] + sms[96 + li]);
+  FD_STAMP(3);
   // ---- phase 3: normalise; attention weights -> HBM (for o_pair), P fragments -> LDS, partial o_pt
   float op[36];
 #pragma unroll
@@ -207,6 +241,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
       }
     }
   }
+  FD_STAMP(4);
 #pragma unroll
   for (int c = 0; c < 36; ++c) op[c] += __shfl_xor(op[c], 32, 64);
   if (hi == 0) {
@@ -217,9 +252,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
     }
   }
   __syncthreads();
+  FD_STAMP(5);
   // ---- phase 4a: o_pt = R_i^T (sum - t_i) and its norm (ipa_pytorch.py:296-308), 32 queries x 12 points
   for (int it = tid; it < 32 * 12; it += FD_THREADS) {
-    const int q = it / 12, pt = it % 12, iq = blockIdx.x * 32 + q;
+    const int q = it / 12, pt = it % 12, iq = qt * 32 + q;
     if (iq < N) {
       float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
@@ -239,27 +275,40 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
       o[3 * HP] = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
     }
   }
+  FD_STAMP(6);
   // ---- phase 4b: O^T[d, query] for d tiles {2w, 2w+1} over all keys: A = Vt rows from HBM/L2, B = P from LDS
-#pragma unroll 1
-  for (int dd = 0; dd < 2; ++dd) {
-    const int dt = 2 * wave + dd;
-    const bf16_t* vr = a.Vt + (bh * A3_C + 32 * dt + li) * a.Np + 8 * hi;
-    f32x16 acc;
+  {
+    constexpr int KSM = 2 * 4 * A3_NTW;  // k-steps of 16 keys at the maximum N
+    const int ks = 2 * nt;
+    bf16x8 Va[2][KSM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < 2 * nt; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld(vr + 16 * s), __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc,
-                                                    0, 0, 0);
-    if (valid) {
-      float* orow = a.out + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
+    for (int dd = 0; dd < 2; ++dd) {
+      const bf16_t* vr = a.Vt + (((bh * (A3_C / 32) + 2 * wave + dd) * ks) * 64 + lane) * 8;  // fragment order
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        *(f32x4*)(orow + 8 * g) = o;
+      for (int s = 0; s < KSM; ++s)
+        if (s < ks) Va[dd][s] = a3_ld(vr + s * 512);
+    }
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      const int dt = 2 * wave + dd;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KSM; ++s)
+        if (s < ks)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Va[dd][s], __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc, 0, 0, 0);
+      if (valid) {
+        float* orow = a.out + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+          *(f32x4*)(orow + 8 * g) = o;
+        }
       }
     }
   }
+  FD_STAMP(7);
 }
 
 int fd_attention3_supported(const Attn3Args& a) {
@@ -276,7 +325,8 @@ int fd_attention3(const Attn3Args& a, hipStream_t st) {
       return FDIPT_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(ipa_attn3_kernel, dim3(nt, a.H, a.B), dim3(FD_THREADS), smem, st, a);
+  const int per = (a.B * a.H + 7) / 8;  // see the block mapping in the kernel
+  hipLaunchKernelGGL(ipa_attn3_kernel, dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

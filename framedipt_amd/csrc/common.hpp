@@ -129,3 +129,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Optional in-kernel phase timestamps for the stand-alone harnesses under tools/micro (-DFD_PROF): thread 0 of every
+// block records s_memtime (shader cycles) at phase boundaries into fd_prof[block][16].  Never enabled in the library.
+#ifdef FD_PROF
+__device__ unsigned long long fd_prof[8192 * 16];
+#define FD_STAMP(k)                                                                                              \
+  do {                                                                                                           \
+    if (threadIdx.x == 0)                                                                                        \
+      fd_prof[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define FD_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
+

@@ -132,9 +132,11 @@ __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K,
 // [q | kv | q_pts | kv_pts] = s W^T + b (ipa_pytorch.py:202-239) written directly as the operand images the
 // register attention kernel (attention3.hip) consumes:
 //   Qb [B,H,N,C]  bf16, pre-multiplied by sqrt(1/(3C))            (A/B fragments: 16-byte loads)
-//   Kb [B,H,N,C]  bf16
-//   Vt [B,H,C,Np] bf16, V transposed, keys permuted inside every 16-group (perm16: C/D fragment -> B fragment order)
-//   pts [B*N, PT] fp32, raw point projections (rotated into the global frame by points_kernel)
+//   Kb [B,H,Np/32,16,64,8] bf16, MFMA FRAGMENT order: key 32t + (lane & 31), channel 16s + 8(lane >> 5) + e — one A fragment
+//      of attention3 is ONE linear 1 KB load (a row-per-lane 16 B gather costs 8x the TA cycles, tools/micro/io_pattern.hip)
+//   Qb the same with queries (B fragments);  rows >= N of Kb are zeroed (kv_zero_pad_kernel)
+//   Vt [B,H,C/32,Np/16,64,8] bf16: V transposed in fragment order, row = channel 32dt + (lane & 31), key position
+//      16s + 8(lane >> 5) + e with the keys permuted inside every 16-group (perm16: C/D fragment -> B fragment order)
 __device__ __forceinline__ int g_perm16(int pos) { return 4 * (pos >> 3) + (pos & 3) + 8 * ((pos & 7) >> 2); }
 
 __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
@@ -170,10 +172,13 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = acc[i][jn][4 * g + q] + bv;
+        const int ntl = a.Np >> 5;
         if (kind == 2 && mg + 3 < M && (a.N & 3) == 0) {
           const int b = mg / a.N, key = mg - b * a.N;  // 4 keys of one sample (N % 4 == 0), contiguous after perm16
+          const int pp = (key & ~15) + g_perm16(key & 15);
           u16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *(u16x4*)(a.Vt + (((long)b * a.H + hh) * a.C + cc) * a.Np + (key & ~15) + g_perm16(key & 15)) = o;
+          *(u16x4*)(a.Vt + ((((((long)b * a.H + hh) * (a.C >> 5) + (cc >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 +
+                             (cc & 31)) << 3) + (pp & 7)) = o;
           continue;
         }
 #pragma unroll
@@ -181,33 +186,46 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
           const int m = mg + q;
           if (m >= M) continue;
           const int b = m / a.N, r = m - b * a.N;
-          if (kind == 0) a.Qb[(((long)b * a.H + hh) * a.N + r) * a.C + cc] = f2bf(v[q] * a.qscale);
-          else if (kind == 1) a.Kb[(((long)b * a.H + hh) * a.N + r) * a.C + cc] = f2bf(v[q]);
-          else if (kind == 2) a.Vt[(((long)b * a.H + hh) * a.C + cc) * a.Np + (r & ~15) + g_perm16(r & 15)] = f2bf(v[q]);
-          else a.pts[(long)m * a.PT + cc] = v[q];
+          if (kind == 0 || kind == 1) {
+            bf16_t* dst = kind == 0 ? a.Qb : a.Kb;
+            dst[((((((long)b * a.H + hh) * ntl + (r >> 5)) * (a.C >> 4) + (cc >> 4)) * 64 + ((cc >> 3) & 1) * 32 + (r & 31)) << 3) +
+                (cc & 7)] = f2bf(kind == 0 ? v[q] * a.qscale : v[q]);
+          } else if (kind == 2) {
+            const int pp = (r & ~15) + g_perm16(r & 15);
+            a.Vt[((((((long)b * a.H + hh) * (a.C >> 5) + (cc >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (cc & 31)) << 3) +
+                 (pp & 7)] = f2bf(v[q]);
+          } else a.pts[(long)m * a.PT + cc] = v[q];
         }
       }
   }
 }
 
-// zero the padded key columns [N, Np) of Vt (P is exactly 0 there, the operand must not be NaN/Inf)
-__global__ void vt_zero_pad_kernel(long rows, int N, int Np, bf16_t* __restrict__ Vt) {
-  const int pad = Np - N;
-  const long n = rows * pad;
+// zero the padded keys [N, Np) of Kb and Vt (P is exactly 0 there and the logits are masked, but the operands must not
+// be NaN/Inf).  One thread per (bh, padded key, 8-channel group).
+__global__ void kv_zero_pad_kernel(long BH, int N, int Np, int C, bf16_t* __restrict__ Kb, bf16_t* __restrict__ Vt) {
+  const int pad = Np - N, ntl = Np >> 5, cg = C >> 3;
+  const long n = BH * pad * cg;
+  const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / pad;
-    const int key = N + (int)(i % pad);
-    Vt[r * Np + (key & ~15) + g_perm16(key & 15)] = 0;
+    const int g = (int)(i % cg);
+    const long r2 = i / cg;
+    const int key = N + (int)(r2 % pad);
+    const long bh = r2 / pad;
+    // Kb: channels 8g .. 8g+7 of this key are one 16 B unit
+    *(u16x8*)(Kb + ((((bh * ntl + (key >> 5)) * (C >> 4) + (g >> 1)) * 64 + (g & 1) * 32 + (key & 31)) << 3)) = z8;
+    // Vt: this key in channels 8g .. 8g+7
+    const int pp = (key & ~15) + g_perm16(key & 15);
+    for (int c = 8 * g; c < 8 * g + 8; ++c)
+      Vt[((((bh * (C >> 5) + (c >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (c & 31)) << 3) + (pp & 7)] = 0;
   }
 }
 
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st) {
   const int M = a.B * a.N, NOUT = 3 * a.H * a.C + a.PT;
   if ((a.K & 7) || (a.lda & 3)) return FDIPT_EINVAL;
-  if (a.Np > a.N) {
-    const long rows = (long)a.B * a.H * a.C;
-    hipLaunchKernelGGL(vt_zero_pad_kernel, dim3(256), dim3(256), 0, st, rows, a.N, a.Np, a.Vt);
-  }
+  if ((a.Np & 31) || (a.C & 31)) return FDIPT_EINVAL;
+  if (a.Np > a.N)
+    hipLaunchKernelGGL(kv_zero_pad_kernel, dim3(256), dim3(256), 0, st, (long)a.B * a.H, a.N, a.Np, a.C, a.Kb, a.Vt);
   hipLaunchKernelGGL(ipa_proj_kernel, dim3(cdiv(M, 128), cdiv(NOUT, 128)), dim3(FD_THREADS), 0, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -358,7 +358,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.a1 = take(R * iv.hid * 4); w.af = take(R * d->c_z * 4);
   {
     const size_t Np = ((size_t)N + 31) / 32 * 32, HC = (size_t)H * d->c_hidden;
-    w.qb = take(R * HC * 2); w.kb = take(R * HC * 2); w.vt = take((size_t)B * HC * Np * 2);
+    w.qb = take((size_t)B * HC * Np * 2); w.kb = take((size_t)B * HC * Np * 2); w.vt = take((size_t)B * HC * Np * 2);  // fragment-order images
     w.pts = take(R * (size_t)(iv.proj_out - 3 * HC) * 4);
   }
   w.total = o;

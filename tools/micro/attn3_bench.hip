@@ -1,0 +1,41 @@
+// Stand-alone timing + phase profile (-DFD_PROF) of ipa_attn3_kernel.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w [-DFD_PROF] tools/micro/attn3_bench.hip -o attn3_bench
+#include "../../framedipt_amd/csrc/attention3.hip"
+#include <cstdio>
+#include <vector>
+int main(int argc, char** argv) {
+  const int B = 8, H = 8, N = argc > 1 ? atoi(argv[1]) : 300, Np = (N + 31) / 32 * 32;
+  Attn3Args a;
+  a.B = B; a.N = N; a.H = H; a.Np = Np;
+  auto dz = [](size_t bytes) { void* p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
+  a.Qb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2); a.Kb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2);
+  a.Vt = (const bf16_t*)dz((size_t)B * H * 256 * Np * 2); a.bias = (const float*)dz((size_t)B * H * N * N * 4);
+  a.res_mask = (const float*)dz((size_t)B * N * 4); a.qp = (const float*)dz((size_t)B * N * H * 24 * 4);
+  a.kp = (const float*)dz((size_t)B * N * H * 24 * 4); a.vp = (const float*)dz((size_t)B * N * H * 36 * 4);
+  a.gamma = (const float*)dz(64); a.rot = (const float*)dz((size_t)B * N * 9 * 4); a.trans = (const float*)dz((size_t)B * N * 3 * 4);
+  a.probs = (float*)dz((size_t)B * H * N * N * 4); a.out_ld = 2432; a.out = (float*)dz((size_t)B * N * a.out_ld * 4); a.pt_off = H * 256;
+  if (!fd_attention3_supported(a)) { printf("unsupported\n"); return 1; }
+  hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+  for (int i = 0; i < 3; ++i) fd_attention3(a, 0);
+  (void)hipEventRecord(t0, 0);
+  const int iters = 20;
+  for (int i = 0; i < iters; ++i) fd_attention3(a, 0);
+  (void)hipEventRecord(t1, 0); (void)hipEventSynchronize(t1);
+  float ms; (void)hipEventElapsedTime(&ms, t0, t1);
+  printf("attn3 N=%d: %.1f us/launch\n", N, ms * 1000 / iters);
+#ifdef FD_PROF
+  const int nb = (Np / 32) * H * B;
+  std::vector<unsigned long long> h((size_t)nb * 16);
+  (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fd_prof), h.size() * 8);
+  const char* names[8] = {"", "prologue (v_pts, Q, q_pts)", "phase 1 logits", "phase 2 softmax", "phase 3 probs/P/o_pt", "o_pt fold + barrier", "phase 4a", "phase 4b PV"};
+  double tot = 0;
+  for (int k = 1; k < 8; ++k) {
+    double s = 0;
+    for (int b = 0; b < nb; ++b) s += (double)(h[(size_t)b * 16 + k] - h[(size_t)b * 16 + k - 1]);
+    s /= nb; tot += s;
+    printf("  %-30s %8.0f cyc\n", names[k], s);
+  }
+  printf("  %-30s %8.0f cyc (wave 0 of each block)\n", "total per block", tot);
+#endif
+  return 0;
+}
