@@ -1,0 +1,222 @@
+// attention_seq.hip — self-attention of the sequence transformer (nn.MultiheadAttention inside
+// nn.TransformerEncoderLayer, framedipt/model/ipa_pytorch.py:433-443,536-538): d_model 320, 4 heads of 80, bf16.
+//
+// Two launches per layer, no LDS, no barrier:
+//   seq_images_kernel  re-lays the fp32 in_proj output [B*N, 3*d] as bf16 MFMA FRAGMENT images (one fragment = one
+//                      linear 1 KB load; a row-per-lane gather costs 8x the TA cycles, tools/micro/io_pattern.hip):
+//                        Qi, Ki [B,h,Np/32,KS,64,8]  row 32t + (lane & 31), channel 16s + 8(lane >> 5) + e   (Q pre-scaled)
+//                        Vi     [B,h,DT,Np/16,64,8]  V transposed: row = channel 32dt + (lane & 31), key position
+//                                                    16s + 8(lane >> 5) + e, keys permuted inside every 16-group
+//                                                    (perm16: C/D fragment -> B fragment order); pads are zero
+//                      channel 80 carries the key padding mask through the matrix cores: Qi[.., 80] = 1,
+//                      Ki[key, 80] = -1e30 for masked / padded keys (channels 81..95 are zero)
+//   seq_attn_kernel    one block = 32 queries of one (sample, head); the KEYS are dealt round-robin to the 4 waves in
+//                      tiles of 32 (S^T[key, query] = Ki_tile * Q^T), softmax = registers + lane^32 shuffle + 2 x 128
+//                      floats of LDS across waves, P fragments are exchanged through LDS once and wave w < 3 then owns
+//                      channel tile w of O^T[d, query] = Vi * P^T over ALL keys.  Every global operand of a wave is
+//                      requested in its first instructions (V included), so the whole block is ONE memory round trip.
+#include <type_traits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define SA_HD 80
+#define SA_KS 6         // k-steps of 16 channels: 80 + the mask channel, padded to 96
+#define SA_DT 3         // 32-channel output tiles (80 -> 96, padded rows are zero)
+#define SA_NTW 4        // key tiles per wave -> N <= 4 * 4 * 32 = 512
+
+__host__ __device__ __forceinline__ int sa_perm16(int pos) {  // involution
+  const int hi = pos >> 3, e = pos & 7;
+  return 4 * hi + (e & 3) + 8 * (e >> 2);
+}
+
+__global__ void seq_images_kernel(int B, int N, int Np, int H, const float* __restrict__ qkv, int ld, float qscale,
+                                  const float* __restrict__ res_mask,
+                                  bf16_t* __restrict__ Qi, bf16_t* __restrict__ Ki, bf16_t* __restrict__ Vi) {
+  const int nt = Np >> 5, dm = H * SA_HD;
+  const long nqk = (long)B * H * nt * SA_KS * 64, nv = (long)B * H * SA_DT * (2 * nt) * 64;
+  for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < 2 * nqk + nv; u += (long)gridDim.x * blockDim.x) {
+    u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (u < 2 * nqk) {
+      const bool isk = u >= nqk;
+      const long v = isk ? u - nqk : u;
+      const int lane = (int)(v & 63), s = (int)((v >> 6) % SA_KS);
+      const long r2 = (v >> 6) / SA_KS;
+      const int t = (int)(r2 % nt);
+      const long bh = r2 / nt;
+      const int h = (int)(bh % H);
+      const long b = bh / H;
+      const int row = 32 * t + (lane & 31), c0 = 16 * s + 8 * (lane >> 5);
+      if (c0 < SA_HD) {
+        if (row < N) {
+          const float* src = qkv + (b * N + row) * ld + (isk ? dm : 0) + h * SA_HD + c0;
+          const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + 4);
+          const float sc = isk ? 1.f : qscale;
+          o = u16x8{f2bf(x0[0] * sc), f2bf(x0[1] * sc), f2bf(x0[2] * sc), f2bf(x0[3] * sc),
+                    f2bf(x1[0] * sc), f2bf(x1[1] * sc), f2bf(x1[2] * sc), f2bf(x1[3] * sc)};
+        }
+      } else if (c0 == SA_HD) {  // mask channel
+        if (!isk) o[0] = f2bf(1.0f);
+        else if (row >= N || res_mask[b * N + row] == 0.f) o[0] = f2bf(-1e30f);
+      }
+      *(u16x8*)((isk ? Ki : Qi) + v * 8) = o;
+    } else {
+      const long v = u - 2 * nqk;
+      const int lane = (int)(v & 63), s = (int)((v >> 6) % (2 * nt));
+      const long r2 = (v >> 6) / (2 * nt);
+      const int dt = (int)(r2 % SA_DT);
+      const long bh = r2 / SA_DT;
+      const int h = (int)(bh % H);
+      const long b = bh / H;
+      const int d = 32 * dt + (lane & 31);
+      if (d < SA_HD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int pos = 16 * s + 8 * (lane >> 5) + e, key = (pos & ~15) + sa_perm16(pos & 15);
+          if (key < N) o[e] = f2bf(qkv[(b * N + key) * ld + 2 * dm + h * SA_HD + d]);
+        }
+      }
+      *(u16x8*)(Vi + v * 8) = o;
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 sa_ld(const bf16_t* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
+__device__ __forceinline__ bf16x8 sa_pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+  return o;
+}
+
+__global__ __launch_bounds__(FD_THREADS, 1) void seq_attn_kernel(int B, int N, int Np, int H, const bf16_t* __restrict__ Qi,
+                                                                 const bf16_t* __restrict__ Ki, const bf16_t* __restrict__ Vi,
+                                                                 float* __restrict__ out, int out_ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = Np >> 5, ks = 2 * nt;
+  float* mxs = (float*)smem;              // [4][32]
+  float* sms = mxs + 128;                 // [4][32]
+  u16x8* Pfs = (u16x8*)(sms + 128);       // [2 nt][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+  // XCD-aware: all query tiles of one (sample, head) on the same XCD (see attention3.hip)
+  const int BH = B * H;
+  int bhq, qt;
+  {
+    const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+    const int per = (BH + 7) >> 3;
+    bhq = xcd * per + local / nt;
+    qt = local % nt;
+    if (local >= per * nt || bhq >= BH) return;
+  }
+  const int h = bhq % H, b = bhq / H;
+  const long bh = bhq, rb = (long)b * N;
+  const int i = 32 * qt + li;
+  // ---- every global operand of this wave, requested up front
+  bf16x8 Va[8 * SA_NTW];
+  if (wave < SA_DT) {
+    const bf16_t* vr = Vi + (((bh * SA_DT + wave) * ks) * 64 + lane) * 8;
+#pragma unroll
+    for (int s = 0; s < 8 * SA_NTW; ++s)
+      if (s < ks) Va[s] = sa_ld(vr + s * 512);
+  }
+  bf16x8 Qf[SA_KS];
+#pragma unroll
+  for (int s = 0; s < SA_KS; ++s) Qf[s] = sa_ld(Qi + (((bh * nt + qt) * SA_KS + s) * 64 + lane) * 8);
+  bf16x8 Kf[SA_NTW][SA_KS];
+#pragma unroll
+  for (int u = 0; u < SA_NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt)
+#pragma unroll
+      for (int s = 0; s < SA_KS; ++s) Kf[u][s] = sa_ld(Ki + (((bh * nt + t) * SA_KS + s) * 64 + lane) * 8);
+  }
+  // ---- scores of this wave's key tiles (mask included: channel 80)
+  f32x16 S[SA_NTW];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int u = 0; u < SA_NTW; ++u) {
+    if (wave + 4 * u < nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < SA_KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[u][s], Qf[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+      S[u] = acc;
+    }
+  }
+  // ---- softmax over all keys: own registers -> lane^32 -> the other waves through LDS
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (hi == 0) mxs[wave * 32 + li] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(mxs[li], mxs[32 + li]), fmaxf(mxs[64 + li], mxs[96 + li]));
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < SA_NTW; ++u)
+    if (wave + 4 * u < nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf(S[u][r] - mx);
+        S[u][r] = e;
+        sum += e;
+      }
+  sum += __shfl_xor(sum, 32, 64);
+  if (hi == 0) sms[wave * 32 + li] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (sms[li] + sms[32 + li] + sms[64 + li] + sms[96 + li]);
+#pragma unroll
+  for (int u = 0; u < SA_NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = S[u][r] * inv;
+      Pfs[(2 * t) * 64 + lane] = __builtin_bit_cast(u16x8, sa_pack8(v));
+      Pfs[(2 * t + 1) * 64 + lane] = __builtin_bit_cast(u16x8, sa_pack8(v + 8));
+    }
+  }
+  __syncthreads();
+  // ---- O^T[d, query] for channel tile `wave` over all keys
+  if (wave < SA_DT) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8 * SA_NTW; ++s)
+      if (s < ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Va[s], __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc, 0, 0, 0);
+    if (i < N) {
+      float* orow = out + (rb + i) * out_ld + (long)h * SA_HD + 32 * wave + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (32 * wave + 8 * g + 4 * hi < SA_HD) {
+          f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+          *(f32x4*)(orow + 8 * g) = o;
+        }
+    }
+  }
+}
+
+size_t fd_seq_attention_image_bytes(int B, int N, int H) {
+  const size_t Np = ((size_t)N + 31) / 32 * 32;
+  return (size_t)B * H * Np * (2 * SA_KS * 16 + SA_DT * 32) * 2;  // Qi + Ki + Vi
+}
+int fd_seq_attention_supported(int N, int H, int hd) { return hd == SA_HD && N >= 1 && N <= 4 * SA_NTW * 32 && H >= 1; }
+
+int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, void* images,
+                     float* out, int out_ld, hipStream_t st) {
+  if (!fd_seq_attention_supported(N, H, SA_HD) || (ld & 3) || (out_ld & 3)) return FDIPT_EINVAL;
+  const int Np = (N + 31) / 32 * 32, nt = Np / 32;
+  bf16_t* Qi = (bf16_t*)images;
+  bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
+  const long units = 2L * B * H * nt * SA_KS * 64 + (long)B * H * SA_DT * 2 * nt * 64;
+  hipLaunchKernelGGL(seq_images_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, qkv, ld, scale,
+                     res_mask, Qi, Ki, Vi);
+  FD_CHECK_LAUNCH();
+  const int per = (B * H + 7) / 8;
+  const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
+  hipLaunchKernelGGL(seq_attn_kernel, dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

@@ -122,6 +122,12 @@ struct Attn3Args {
 int fd_attention3_supported(const Attn3Args& a);
 int fd_attention3(const Attn3Args& a, hipStream_t st);
 
+// sequence-transformer self-attention (attention_seq.hip): bf16, head_dim 80, N <= 512
+size_t fd_seq_attention_image_bytes(int B, int N, int H);
+int fd_seq_attention_supported(int N, int H, int hd);
+int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, void* images,
+                     float* out, int out_ld, hipStream_t st);
+
 struct ChainArgs {
   int M;
   const float* in;          // [M, ld_in] fp32 input rows

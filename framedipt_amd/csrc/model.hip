@@ -334,7 +334,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -361,6 +361,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
     w.qb = take((size_t)B * HC * Np * 2); w.kb = take((size_t)B * HC * Np * 2); w.vt = take((size_t)B * HC * Np * 2);  // fragment-order images
     w.pts = take(R * (size_t)(iv.proj_out - 3 * HC) * 4);
   }
+  w.seqimg = take(fd_seq_attention_image_bytes(B, N, d->tfmr_heads));
   w.total = o;
 }
 
@@ -545,7 +546,9 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       ta.C = hd; ta.Dv = hd; ta.scale = 1.0f / sqrtf((float)hd); ta.bias = nullptr; ta.res_mask = res_mask;
       ta.qp = ta.kp = ta.vp = nullptr; ta.Pq = ta.Pv = 0; ta.gamma = nullptr; ta.rot = ta.trans = nullptr; ta.probs = nullptr;
       ta.out = F(w.att); ta.out_ld = dt; ta.pt_off = 0; ta.lds_s = 0;
-      if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
+      if (bf && !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && fd_seq_attention_supported(N, d->tfmr_heads, hd))
+        RC(fd_seq_attention(B, N, d->tfmr_heads, F(w.qkv), 3 * dt, ta.scale, res_mask, W + w.seqimg, F(w.att), dt, st));
+      else if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
       else RC(fd_attention(prec, 0, ta, st));
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
       if (con(FD_CHAIN_OUTPROJ)) {
