@@ -271,15 +271,15 @@ int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st) {
 // HBM-bound (one pass over z): the z rows of a thread are fetched in chunks of OP_CH rows, chunk c+1 in flight while
 // chunk c is consumed, and the first chunk is issued before anything else; the down-projection weights sit in LDS.
 #define OP_CH 8
-template <class ZT, int CZ>
+template <class ZT, int CZ, int HT>
 __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCG = CZ / 8;              // channel groups of 8
   constexpr int NSL = FD_THREADS / NCG;    // key slices per block
   constexpr int EPT = sizeof(ZT) == 2 ? 1 : 2;  // 16-byte loads per row piece
-  const int N = a.N, H = a.H, CD = a.CD;
-  float* ps = (float*)smem;                // [H][N]
-  float* red = ps + ((H * N + 3) & ~3);    // [4 waves][8 heads][CZ]
+  const int N = a.N, H = HT > 0 ? HT : a.H, CD = a.CD;
+  float* ps = (float*)smem;                // [N][8]: attention weights of the 8 heads, key-major (vector reads per row)
+  float* red = ps + 8 * N;                 // [4 waves][8 heads][CZ]
   float* psum = red + 4 * 8 * CZ;          // [8]
   float* wdl = psum + 8;                   // [CZ][CD] down-projection weights
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -299,13 +299,32 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
       for (int e = 0; e < EPT; ++e) zr[buf][u][e] = *(const f32x4*)((const char*)zp + 16 * e);
     }
   };
+  FD_STAMP(0);
+  // attention weights first (they gate the barrier), then the first z chunk, then the down-projection weights
+  constexpr int NPV = 10;  // probs values per thread: 8 heads x N <= 2560
+  float pr[NPV];
+#pragma unroll
+  for (int u = 0; u < NPV; ++u) {
+    const int v = tid + u * FD_THREADS, hh = v / N, j = v % N;
+    pr[u] = v < H * N ? a.probs[(((long)b * H + hh) * N + i) * N + j] : 0.f;
+  }
   fetch(0, 0);
-  for (int v = tid; v < H * N; v += FD_THREADS) {
+  if (H < 8) {
+    for (int v = tid; v < 8 * N; v += FD_THREADS) ps[v] = 0.f;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < NPV; ++u) {
+    const int v = tid + u * FD_THREADS, hh = v / N, j = v % N;
+    if (v < H * N) ps[j * 8 + hh] = pr[u];
+  }
+  for (int v = tid + NPV * FD_THREADS; v < H * N; v += FD_THREADS) {  // N > 320
     const int hh = v / N, j = v % N;
-    ps[v] = a.probs[(((long)b * H + hh) * N + i) * N + j];
+    ps[j * 8 + hh] = a.probs[(((long)b * H + hh) * N + i) * N + j];
   }
   for (int v = tid; v < CZ * CD; v += FD_THREADS) wdl[v] = a.wdz[v];
   __syncthreads();
+  FD_STAMP(1);
   float acc[8][8];
 #pragma unroll
   for (int hh = 0; hh < 8; ++hh)
@@ -329,10 +348,11 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
             zv[4 + c] = zr[bf][u][EPT - 1][c];
           }
         }
+        const f32x4 p0 = *(const f32x4*)(ps + j * 8), p1 = *(const f32x4*)(ps + j * 8 + 4);
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh) {
           if (hh < H) {
-            const float pv = ps[hh * N + j];
+            const float pv = hh < 4 ? p0[hh & 3] : p1[hh & 3];
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[hh][c] += pv * zv[c];
           }
@@ -346,6 +366,7 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
     if (k0 + 2 * OP_CH < nk) fetch(0, k0 + 2 * OP_CH);
     if (k0 + OP_CH < nk) consume(std::integral_constant<int, 1>{}, k0 + OP_CH);
   }
+  FD_STAMP(2);
   // fold the slices that live in the same wave (lane bits above the channel-group bits)
 #pragma unroll
   for (int o = NCG; o < 64; o <<= 1)
@@ -364,14 +385,16 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
     const int hh = tid >> 5, l5 = tid & 31;
     float sacc = 0.f;
     if (hh < H)
-      for (int j = l5; j < N; j += 32) sacc += ps[hh * N + j];
+      for (int j = l5; j < N; j += 32) sacc += ps[j * 8 + hh];
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
     if (l5 == 0 && hh < 8) psum[hh] = sacc;
   }
   __syncthreads();
+  FD_STAMP(3);
   for (int v = tid; v < 8 * CZ; v += FD_THREADS) red[v] = red[v] + red[8 * CZ + v] + red[16 * CZ + v] + red[24 * CZ + v];
   __syncthreads();
+  FD_STAMP(4);
   for (int o = tid; o < H * CD; o += FD_THREADS) {
     const int hh = o / CD, d = o % CD;
     float s0 = a.bdz[d] * psum[hh], s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -384,14 +407,16 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
     }
     a.out[(rb + i) * a.out_ld + a.off + hh * CD + d] = (s0 + s1) + (s2 + s3);
   }
+  FD_STAMP(5);
 }
 
 template <class ZT>
 static int launch_opair(const OPairArgs& a, hipStream_t st) {
-  const size_t smem = (((size_t)a.H * a.N + 3) & ~(size_t)3) * 4 + (size_t)(4 * 8 * a.CZ + 8) * 4 + (size_t)a.CZ * a.CD * 4;
+  const size_t smem = (size_t)8 * a.N * 4 + (size_t)(4 * 8 * a.CZ + 8) * 4 + (size_t)a.CZ * a.CD * 4;
   if (smem > 64 * 1024) return FDIPT_ESIZE;
-  if (a.CZ == 128) hipLaunchKernelGGL((opair_kernel<ZT, 128>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
-  else if (a.CZ == 32) hipLaunchKernelGGL((opair_kernel<ZT, 32>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
+  if (a.CZ == 128 && a.H == 8) hipLaunchKernelGGL((opair_kernel<ZT, 128, 8>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
+  else if (a.CZ == 128) hipLaunchKernelGGL((opair_kernel<ZT, 128, 0>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
+  else if (a.CZ == 32) hipLaunchKernelGGL((opair_kernel<ZT, 32, 0>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a);
   else return FDIPT_EINVAL;
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
