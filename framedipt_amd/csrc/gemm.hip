@@ -128,6 +128,38 @@ __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K,
   }
 }
 
+// Split-K variant for the "long K, few columns" products (IPA output projection: M = B*N rows, N = c_s, K = 2688): the
+// 64 x 64 tile grid alone is ~150 blocks of 42 dependent k-iterations each; blockIdx.z takes a K slice and writes its
+// partial product to parts[z] (bias added by slice 0, row mask by every slice) - the LayerNorm that follows sums them.
+template <class P, class AT, class WT>
+__global__ __launch_bounds__(FD_THREADS) void linear_splitk_kernel(int M, int N, int K, int kslice, const AT* __restrict__ A,
+                                                                   int lda, const WT* __restrict__ W, int ldw,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ rowmask,
+                                                                   float* __restrict__ parts, long part_stride, int ldo) {
+  constexpr int BM = 64, BN = 64, LDT = 64 + P::PAD;
+  __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  const int k0 = z * kslice, klen = K - k0 < kslice ? K - k0 : kslice;
+  f32x16 acc[1][1];
+  gemm_tile<P, AT, WT, BM, BN>(acc, M, N, klen, A + k0, lda, W + k0, ldw, smem, m0, n0, tid);
+  const int n = n0 + wc * 32 + (lane & 31);
+  if (n >= N) return;
+  const float bv = (bias && z == 0) ? bias[n] : 0.f;
+  float* out = parts + z * part_stride;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wr * 32 + c_row(r, lane);
+    if (m < M) {
+      float v = acc[0][0][r] + bv;
+      if (rowmask) v *= rowmask[m];
+      out[(long)m * ldo + n] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ IPA projection with attention-operand epilogue
 // [q | kv | q_pts | kv_pts] = s W^T + b (ipa_pytorch.py:202-239) written directly as the operand images the
 // register attention kernel (attention3.hip) consumes:
@@ -279,7 +311,8 @@ int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const
 
 // LayerNorm over the last dim (eps 1e-5, biased variance = torch.nn.LayerNorm), one wave per row, D <= 1024.
 __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, const float* __restrict__ x, int ldx,
-                                                               const float* __restrict__ residual, int ldr,
+                                                               const float* __restrict__ residual, int ldr, int nparts,
+                                                               long part_stride,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ rowmask,
@@ -295,7 +328,8 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
     float t = 0.f;
     if (c < D) {
       t = x[(long)row * ldx + c];
-      if (residual) t += residual[(long)row * ldr + c];
+      if (residual)
+        for (int k = 0; k < nparts; ++k) t += residual[k * part_stride + (long)row * ldr + c];  // split-K partial products
     }
     v[i] = t;
     s += t;
@@ -322,8 +356,28 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,
                  const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !gamma || !beta || !out) return FDIPT_EINVAL;
-  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, residual, ldr,
-                     gamma, beta, rowmask, out, ldo);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, residual, ldr, 1,
+                     0L, gamma, beta, rowmask, out, ldo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+// LayerNorm(x + sum_k parts[k]) for the split-K products of fd_linear_splitk
+int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
+                       const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
+  if (M <= 0 || D <= 0 || D > 1024 || !x || !parts || nparts < 1 || !gamma || !beta || !out) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, parts, ldr, nparts,
+                     part_stride, gamma, beta, rowmask, out, ldo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+// parts[z][M, ldo] = (A[:, z-th K slice] W[:, slice]^T (+ bias for z = 0)) * rowmask; bf16 operands, fp32 activations in
+int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, const void* W, int ldw, const float* bias,
+                     const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 3) || (ldw & 7)) return FDIPT_EINVAL;
+  const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
+  if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecBF16, float, bf16_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
+                     st, M, N, K, kslice, A, lda, (const bf16_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -152,6 +152,10 @@ int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const
               const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, hipStream_t st);
 int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,
                 hipStream_t st);
+int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
+                       const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st);
+int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, const void* W, int ldw, const float* bias,
+                     const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,
                  const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st);
 int fd_f32_to_bf16(long n, const float* in, bf16_t* out, hipStream_t st);

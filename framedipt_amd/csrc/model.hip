@@ -334,7 +334,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -362,6 +362,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
     w.pts = take(R * (size_t)(iv.proj_out - 3 * HC) * 4);
   }
   w.seqimg = take(fd_seq_attention_image_bytes(B, N, d->tfmr_heads));
+  w.ipa_parts = take((size_t)8 * R * d->c_s * 4);  // split-K partial products of the IPA output projection
   w.total = o;
 }
 
@@ -525,9 +526,17 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       oa.wdz = (const float*)(D + db.wdz_t); oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
       RC(fd_opair(prec, oa, st));
     }
-    RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
-    RC(fd_layernorm(R, cs, node_cur, cs, F(w.ipa_out), cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr, F(w.tf_in), dt, st));
+    if (bf && iv.feat_dim >= 1024 && !getenv("FDIPT_NO_SPLITK")) {
+      const int NS = 4;  // K = 2688: slices of 704 / 576 columns -> 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower)
+      RC(fd_linear_splitk(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b, res_mask,
+                          F(w.ipa_parts), (long)R * cs, cs, st));
+      RC(fd_layernorm_parts(R, cs, node_cur, cs, F(w.ipa_parts), cs, NS, (long)R * cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr,
+                            F(w.tf_in), dt, st));
+    } else {
+      RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
+      RC(fd_layernorm(R, cs, node_cur, cs, F(w.ipa_out), cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr, F(w.tf_in), dt, st));
+    }
     if (con(FD_CHAIN_SKIP)) RC(chain(FD_CHAIN_SKIP, F(w.node0), cs, D + db.ch.skip, P + k.skip.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                       nullptr, nullptr, nullptr, F(w.tf_in) + cs, dt));
     else RC(lin(R, k.skip, F(w.node0), cs, nullptr, 0, nullptr, 0, F(w.tf_in) + cs, dt));
