@@ -354,7 +354,8 @@ int fd_attention2(int ipa, const AttnArgs& a, hipStream_t st) {
 // straight from HBM in B-operand layout (no LDS), Wb fragments in registers.  HBM-bound: one pass over z.
 __global__ __launch_bounds__(FD_THREADS) void pair_bias2_kernel(int B, int N, int H, const bf16_t* __restrict__ z,
                                                                 const bf16_t* __restrict__ wb /* [H,128] pre-scaled */,
-                                                                const float* __restrict__ bb, float* __restrict__ out) {
+                                                                const float* __restrict__ bb, float* __restrict__ out,
+                                                                int frag /* 1: fd_bias_frag_off order (attention3) */) {
   const int lane = threadIdx.x & 63, hi = lane >> 5, li = lane & 31;
   const long NN = (long)N * N, n_pairs = (long)B * NN;
   bf16x8 Wf[8];
@@ -379,21 +380,25 @@ __global__ __launch_bounds__(FD_THREADS) void pair_bias2_kernel(int B, int N, in
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[s], zf[s], acc, 0, 0, 0);
     if (p_raw < n_pairs) {
       const long bidx = p / NN, ij = p - bidx * NN;
+      const int i = (int)(ij / N), j = (int)(ij - (long)i * N), nt = (N + 31) >> 5;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {  // rows 4hi + q (r = q): heads 0..7
         const int hh = 4 * hi + q;
-        if (hh < H) out[(bidx * H + hh) * NN + ij] = acc[q] + bb[hh];
+        if (hh < H) {
+          if (frag) out[fd_bias_frag_off(bidx * H + hh, nt, i, j)] = acc[q] + bb[hh];
+          else out[(bidx * H + hh) * NN + ij] = acc[q] + bb[hh];
+        }
       }
     }
   }
 }
 
-int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, hipStream_t st) {
+int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, int frag, hipStream_t st) {
   if (H > 8) return FDIPT_ESIZE;
   const long n_tiles = ((long)B * N * N + 31) / 32;
   const int grid = (int)(n_tiles / 4 + 1 < 2048 ? n_tiles / 4 + 1 : 2048);
   hipLaunchKernelGGL(pair_bias2_kernel, dim3(grid), dim3(FD_THREADS), 0, st, B, N, H, (const bf16_t*)z, (const bf16_t*)wb, bb,
-                     out);
+                     out, frag);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

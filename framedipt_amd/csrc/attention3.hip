@@ -94,7 +94,6 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   }
   const float mi = a.res_mask[rb + i];
   const float gam = a.gamma[h];
-  const float* brow = a.bias + (bh * N + i) * N;
 
   FD_STAMP(1);
   // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...  The global operands of tile u+1 (K rows as A
@@ -116,15 +115,14 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
 #pragma unroll
     for (int c4 = 0; c4 < 6; ++c4) ti.kp[c4] = *(const f32x4*)(kpr + 4 * c4);
     ti.mA = vA ? a.res_mask[rb + jA] : -1e25f;   // padded keys: marker so that the logit becomes -1e30
+    const float* bt = a.bias + (((bh * nt + qt) * nt + t) * 32 + li) * 32 + 4 * hi;  // fd_bias_frag_off: this query's row of the tile
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int j0 = 32 * t + 8 * g + 4 * hi;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (j0 + 3 < N && (N & 3) == 0) bv = *(const f32x4*)(brow + j0);
-      else {
+      f32x4 bv = *(const f32x4*)(bt + 8 * g);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = j0 + q < N ? brow[j0 + q] : 0.f;
-      }
+      for (int q = 0; q < 4; ++q)
+        if (j0 + q >= N) bv[q] = 0.f;  // padded keys: the slot is never written
       ti.bv[g] = bv;
     }
   };

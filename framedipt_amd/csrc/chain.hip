@@ -20,7 +20,7 @@ __host__ __device__ __forceinline__ int ch_perm16(int pos) { return 4 * (pos >> 
 // ------------------------------------------------------------------ weight image
 // img[((T*KS + s)*64 + lane)*8 + e] = W[32T + (lane&31)][k], k = 16s + 8(lane>>5) + e  (natural)  or
 //                                                             16s + perm16(8(lane>>5) + e) (permuted: layers >= 2)
-__global__ void chain_image_kernel(const float* __restrict__ w, int N, int K, int ldw, int permuted, int NT, int KS,
+__global__ void chain_image_kernel(const float* __restrict__ w, int N, int K, int ldw, int permuted, int NT, int KS, float scale,
                                    bf16_t* __restrict__ img) {
   const long n = (long)NT * KS * 64 * 8;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -29,15 +29,18 @@ __global__ void chain_image_kernel(const float* __restrict__ w, int N, int K, in
     const int s = (int)(ts % KS), T = (int)(ts / KS);
     const int row = 32 * T + (lane & 31), pos = 8 * (lane >> 5) + e;
     const int k = 16 * s + (permuted ? ch_perm16(pos) : pos);
-    img[i] = (row < N && k < K) ? f2bf(w[(long)row * ldw + k]) : (bf16_t)0;
+    img[i] = (row < N && k < K) ? f2bf(w[(long)row * ldw + k] * scale) : (bf16_t)0;
   }
 }
 size_t fd_chain_image_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 1024; }
-int fd_chain_build_image(const float* w, int N, int K, int ldw, int permuted, void* img, hipStream_t st) {
+int fd_chain_build_image_scaled(const float* w, int N, int K, int ldw, int permuted, float scale, void* img, hipStream_t st) {
   const int NT = (N + 31) / 32, KS = (K + 15) / 16;
-  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, permuted, NT, KS, (bf16_t*)img);
+  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, permuted, NT, KS, scale, (bf16_t*)img);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
+}
+int fd_chain_build_image(const float* w, int N, int K, int ldw, int permuted, void* img, hipStream_t st) {
+  return fd_chain_build_image_scaled(w, N, K, ldw, permuted, 1.0f, img, st);
 }
 
 // ------------------------------------------------------------------ device pieces

@@ -21,6 +21,9 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#ifndef ET2_BIAS_ABL
+#define ET2_BIAS_ABL 0  // timing ablations (tools/micro/et2_bench.hip): 1 no stores, 2 no DMA wait, 4 no MFMA
+#endif
 #define ET2_CZ 128
 #define ET2_CB 128
 #define ET2_H 384
@@ -219,10 +222,18 @@ __device__ __forceinline__ void ln_epilogue(f32x16 (&Y)[4], const float* __restr
 // ET2 form of the epilogue: every operand comes from LDS (Af row, gamma, beta) and the bf16 result leaves through a
 // wave-private LDS tile [32 pairs][256 B] so that the global stores are whole 256 B rows per 16 lanes — the wave's 32
 // pairs are one contiguous 8 KB span of z_out.  `stage`: 8 KB of LDS nobody else touches (a retired weight buffer).
+// Optionally (wb_lds != NULL) also emits the pair bias of the NEXT block's attention, b[h] = Wb z' + bb (pre-scaled by
+// sqrt(1/3)), from the bf16 z' fragments that are in registers anyway: 8 more MFMAs (heads = rows 0..7 of a 32-row tile,
+// Wb image with the C/D -> B k-permutation folded in, wave-private copy in LDS), stored in attention3's fragment order.
 __device__ __forceinline__ void ln_epilogue_staged(f32x16 (&Y)[4], const float* addrow, const float* gamma_l,
                                                    const float* beta_l, float em, int li, int hi, int lane, char* stage,
                                                    bf16_t* __restrict__ z_out, long p0, long n_pairs,
-                                                   float* __restrict__ tr_row, bool valid) {
+                                                   float* __restrict__ tr_row, bool valid, const char* wb_lds,
+                                                   const float* __restrict__ bb, float* __restrict__ bias_out, int H,
+                                                   long bidx, int ii, int jj, int nt) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  u32x4 zB[8];  // bf16 z' as B fragments (32-bit words: no element re-packing)
   float s1 = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -262,11 +273,32 @@ __device__ __forceinline__ void ln_epilogue_staged(f32x16 (&Y)[4], const float* 
       }
       // features f0..f0+3 = bytes 2 f0 .. 2 f0 + 7 of the pair's row: 16 B unit 4t + g, half hi; unit u of row r at u ^ (r & 15)
       *(bf16x4*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = o;
+      {  // C/D registers 4g .. 4g+3 of tile t -> words 2(g & 1), 2(g & 1) + 1 of B fragment 2t + (g >> 1)
+        const u32x2 ow = __builtin_bit_cast(u32x2, o);
+        zB[2 * t + (g >> 1)][2 * (g & 1)] = ow[0];
+        zB[2 * t + (g >> 1)][2 * (g & 1) + 1] = ow[1];
+      }
       if (tr_row && valid) {
         f32x4 tv = {of[0], of[1], of[2], of[3]};
         *(f32x4*)(tr_row + f0) = tv;
       }
     }
+  if (wb_lds) {
+    if (!(ET2_BIAS_ABL & 2)) et2_dma_wait();  // this wave's copy of the Wb image (DMA issued before the tail of the last layer-2 pair)
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (!(ET2_BIAS_ABL & 4)) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(wb_lds, s * 1024 + lane * 16), __builtin_bit_cast(bf16x8, zB[s]), accb, 0, 0, 0);
+    if (valid && !(ET2_BIAS_ABL & 1)) {
+      float* bo = bias_out + fd_bias_frag_off(bidx * H + 4 * hi, nt, ii, jj);  // 32 lanes = 32 consecutive keys: 128 B rows
+      const long hstride = (long)nt * nt * 1024;  // floats per (sample, head)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)  // D rows 4 hi + r = heads
+        if (4 * hi + r < H) bo[r * hstride] = accb[r] + bb[4 * hi + r];
+    }
+  }
   // same wave wrote the tile: LDS operations of one wave execute in order, no barrier
   const int sr = lane >> 4, sc = lane & 15;
 #pragma unroll
@@ -473,7 +505,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
   bool valid = p_raw < n_pairs;
   long p = valid ? p_raw : n_pairs - 1;
   long bi = p / N;
-  long bj = (bi / N) * N + (p - bi * N);
+  const long b_idx = bi / N;
+  long bj = b_idx * N + (p - bi * N);
+  const int i_idx = (int)(bi - b_idx * N), j_idx = (int)(p - bi * N);
   long i_lo = ((long)tile * 128) / N;
   char* xstage = smem + ET2_CHUNK + wave * 16384;
   {
@@ -631,6 +665,11 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
       soff += ET2_CHUNK;
       ET2_STAMP(6 + c2);
     }
+    // chunk buffer 1 is retired: every wave fetches its own copy of the next block's Wb image into it (no barrier needed)
+    if (a.wb_img) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) et2_dma16((const char*)a.wb_img + k * 1024 + lane * 16, smem + ET2_CHUNK + wave * 8192 + k * 1024);
+    }
     // tail of the last pair: its FH slabs are the 16 KB just landed in buffer 0
     {
       bf16x8 fhA[8], fhB[8];
@@ -668,7 +707,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_transition2_kernel(ET2Args
     // chunk buffer 0 only holds the 16 KB tail slabs (other waves may still be reading them): its upper half stages the output rows
     ln_epilogue_staged(Y, a1l + ET2_H, b2_lds + ET2_H, b2_lds + ET2_H + ET2_CZ, em_cur, li, hi, lane,
                        smem + 32768 + wave * 8192, a.z_out, (long)tile * 128 + wave * 32, n_pairs,
-                       a.trace ? a.trace + p_cur * ET2_CZ : nullptr, valid_cur);
+                       a.trace ? a.trace + p_cur * ET2_CZ : nullptr, valid_cur,
+                       a.wb_img ? smem + ET2_CHUNK + wave * 8192 : nullptr, a.bb, a.bias_out, a.H, b_idx, i_idx, j_idx, (N + 31) >> 5);
     ET2_STAMP(12);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // next tile's DMA + x rows landed (and this tile's stores issued)

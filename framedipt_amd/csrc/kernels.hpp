@@ -75,6 +75,15 @@ struct PointsArgs {
   float *qp, *kp, *vp, *rot;
 };
 
+// Pair bias of the IPA attention, tiled for BOTH sides: [sample*head][query tile][key tile][query in tile][32 keys].
+// The producers (pair_bias2_kernel, the EdgeTransition epilogue) hold one query and 32 consecutive keys per wave and write
+// whole 128 B rows; attention3's lane (query, key half) reads 16 B pieces of its own row.  (A layout that is linear in
+// attention3's lane order made the producer scatter 16 B runs over 8 lines per head: +30 us per EdgeTransition launch.)
+// Buffer size: B * H * Np * Np floats, Np = N rounded up to 32.
+__host__ __device__ __forceinline__ long fd_bias_frag_off(long bh, int nt, int i, int j) {
+  return ((((bh * nt + (i >> 5)) * nt + (j >> 5)) * 32 + (i & 31)) * 32) + (j & 31);
+}
+
 struct ET2Args {
   int B, N;
   const bf16_t* z_in;   // [B,N,N,128] bf16
@@ -85,6 +94,11 @@ struct ET2Args {
   const void* stream;   // pre-swizzled weight stream (fd_et2_build_stream)
   const float *b2, *gamma, *beta, *res_mask;
   float* trace;         // optional [B,N,N,128] f32
+  // optional: pair bias of the NEXT block's attention, linear_b(z') / sqrt(3), emitted from the LayerNorm epilogue
+  const void* wb_img;   // fd_chain_build_image_scaled(Wb, H, 128, permuted) of the next block (8 KB), or NULL
+  const float* bb;      // [H] pre-scaled bias of linear_b
+  float* bias_out;      // fragment order (fd_bias_frag_off)
+  int H;
 };
 int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et2_stream_bytes();
@@ -109,7 +123,7 @@ int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
 struct Attn3Args {
   int B, N, H, Np;
   const bf16_t *Qb, *Kb, *Vt;     // operand images written by ipa_proj_kernel
-  const float* bias;              // [B,H,N,N] f32, pre-scaled pair bias
+  const float* bias;              // pre-scaled pair bias in fd_bias_frag_off order (B*H*Np*Np floats)
   const float* res_mask;          // [B,N]
   const float *qp, *kp, *vp;      // [B,N,H,8,3], [B,N,H,8,3], [B,N,H,12,3] global-frame points (scaled units)
   const float* gamma;             // [H]
@@ -146,6 +160,7 @@ enum { FD_CHAIN_TRANSITION, FD_CHAIN_FFN, FD_CHAIN_OUTPROJ, FD_CHAIN_POST, FD_CH
        FD_CHAIN_A1, FD_CHAIN_AF, FD_CHAIN_NODE_EMBED_72, FD_CHAIN_NODE_EMBED_88, FD_CHAIN_TORSION };
 size_t fd_chain_image_bytes(int N, int K);
 int fd_chain_build_image(const float* w, int N, int K, int ldw, int permuted, void* img, hipStream_t st);
+int fd_chain_build_image_scaled(const float* w, int N, int K, int ldw, int permuted, float scale, void* img, hipStream_t st);
 int fd_chain(int kind, const ChainArgs& a, hipStream_t st);
 
 int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
@@ -165,7 +180,7 @@ int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st);
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
 int fd_attention2_supported(int ipa, const AttnArgs& a);
 int fd_attention2(int ipa, const AttnArgs& a, hipStream_t st);
-int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, hipStream_t st);
+int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, int frag, hipStream_t st);
 int fd_points(const PointsArgs& a, hipStream_t st);
 int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask, hipStream_t st);
 int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,

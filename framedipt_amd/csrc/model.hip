@@ -95,7 +95,7 @@ static inline int rup8(int x) { return (x + 7) & ~7; }
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3, et_init, a1, af;
 };
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, et2, wdz_t; DChain ch; };
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, et2, wdz_t; DChain ch; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -139,6 +139,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
+    L.blk[b].wb_img = o; o = al256(o + 8192);  // linear_b as a 32 x 128 MFMA fragment image (edge_transition2 epilogue)
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et2 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
@@ -280,6 +281,8 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     // pair bias pre-scaled by sqrt(1/3) (ipa_pytorch.py:256-257)
     if ((rc = copy_cols(L.esz, H, cz, cz, P + k.lb.w, cz, 0, s3, D + db.wb, st))) return rc;
     if ((rc = copy_cols(4, 1, H, H, P + k.lb.b, H, 0, s3, D + db.bb, st))) return rc;
+    if (cz == 128 && H <= 8)
+      if ((rc = fd_chain_build_image_scaled(P + k.lb.w, H, cz, cz, 1, s3, D + db.wb_img, st))) return rc;
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
     if (use_et2(d) && b < d->num_blocks - 1)
@@ -349,7 +352,11 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.proj = take(R * iv.proj_out * 4);
   w.qp = take(R * H * d->no_qk_points * 3 * 4); w.kp = take(R * H * d->no_qk_points * 3 * 4);
   w.vp = take(R * H * d->no_v_points * 3 * 4);
-  w.bias = take(NN * H * 4); w.probs = take(NN * H * 4);
+  {
+    const size_t Npb = ((size_t)N + 31) / 32 * 32;
+    w.bias = take((size_t)B * H * Npb * Npb * 4);  // fragment order for attention3 (>= the plain [B,H,N,N] / [B,N,N,H] forms)
+  }
+  w.probs = take(NN * H * 4);
   w.feats = take(R * iv.feat_dim * 4);
   w.ipa_out = take(R * d->c_s * 4);
   w.tf_in = take(R * iv.d_t * 4); w.qkv = take(R * 3 * iv.d_t * 4); w.att = take(R * iv.d_t * 4);
@@ -472,6 +479,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask, F(w.quat), F(w.trans), F(w.dmask), st));
   const float* node_cur = F(w.node0);
   const size_t NN = (size_t)R * N;
+  bool bias_ready = false;  // pair bias of this block's attention already written (fragment order) by EdgeTransition
   for (int b = 0; b < d->num_blocks; ++b) {
     const BlockW& k = iv.blk[b];
     const DBlock& db = L.blk[b];
@@ -495,7 +503,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       RC(fd_ipa_proj(pj, st));
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
       RC(fd_points(pa, st));
-      RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,H,N,N]
+      if (!bias_ready)  // blocks >= 1: already emitted by the previous block's EdgeTransition epilogue
+        RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), 1, st));
       RC(fd_attention3(a3, st));
     } else {
       // fused q | kv | q_pts | kv_pts projection (fp32 activations), then the LDS / register attention kernels
@@ -513,7 +522,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       aa.gamma = (const float*)(D + db.gamma); aa.rot = F(w.rot); aa.trans = F(w.trans); aa.probs = F(w.probs);
       aa.out = F(w.feats); aa.out_ld = iv.feat_dim; aa.pt_off = H * C; aa.lds_s = 0;
       if (bf && cz == 128 && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(1, aa)) {
-        RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,H,N,N]
+        RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), 0, st));  // [B,H,N,N]
         RC(fd_attention2(1, aa, st));
       } else {
         RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
@@ -603,6 +612,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
                         nullptr, 0, nullptr, nullptr, nullptr, F(w.e), iv.cb));
       else RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
       float* tr_ptr = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
+      bias_ready = false;
       if (use_et2(d) && fd_edge_transition2_supported(N)) {
         // per-residue parts of the concat-free layers: A1[i] = W1[:, e_i cols] e_i + b1, Af[i] = Wf[:, e_i cols] e_i + bf
         if (con(FD_CHAIN_A1)) {
@@ -620,6 +630,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         t2.B = B; t2.N = N; t2.z_in = (const bf16_t*)(W + w.z); t2.z_out = (bf16_t*)(W + w.z); t2.e = F(w.e);
         t2.a1 = F(w.a1); t2.af = F(w.af); t2.stream = D + db.et2; t2.b2 = P + k.et2.b; t2.gamma = P + k.et_ln.g;
         t2.beta = P + k.et_ln.b; t2.res_mask = res_mask; t2.trace = tr_ptr;
+        // the next block's attention consumes linear_b(z') in fragment order when it runs attention3
+        const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
+                               !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && N <= 512;
+        t2.wb_img = emit_bias ? D + L.blk[b + 1].wb_img : nullptr;
+        t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
+        bias_ready = emit_bias;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
         RC(fd_edge_transition2(t2, st));
         if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);

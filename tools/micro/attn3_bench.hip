@@ -9,7 +9,7 @@ int main(int argc, char** argv) {
   a.B = B; a.N = N; a.H = H; a.Np = Np;
   auto dz = [](size_t bytes) { void* p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
   a.Qb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2); a.Kb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2);
-  a.Vt = (const bf16_t*)dz((size_t)B * H * 256 * Np * 2); a.bias = (const float*)dz((size_t)B * H * N * N * 4);
+  a.Vt = (const bf16_t*)dz((size_t)B * H * 256 * Np * 2); a.bias = (const float*)dz((size_t)B * H * Np * Np * 4);
   a.res_mask = (const float*)dz((size_t)B * N * 4); a.qp = (const float*)dz((size_t)B * N * H * 24 * 4);
   a.kp = (const float*)dz((size_t)B * N * H * 24 * 4); a.vp = (const float*)dz((size_t)B * N * H * 36 * 4);
   a.gamma = (const float*)dz(64); a.rot = (const float*)dz((size_t)B * N * 9 * 4); a.trans = (const float*)dz((size_t)B * N * 3 * 4);

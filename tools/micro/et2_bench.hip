@@ -15,6 +15,11 @@ int main(int argc, char** argv) {
   (void)hipMemset(stream, 0, fd_et2_stream_bytes());
   ET2Args a; a.B = B; a.N = N; a.z_in = z; a.z_out = z; a.e = e; a.a1 = a1; a.af = af; a.stream = stream; a.b2 = b2; a.gamma = g;
   a.beta = bt; a.res_mask = rm; a.trace = nullptr;
+  {  // next block's pair bias from the epilogue (argv[2] = 0 disables)
+    void* wimg; float* bo; const long Np = (N + 31) / 32 * 32;
+    (void)hipMalloc(&wimg, 8192); (void)hipMemset(wimg, 0, 8192); (void)hipMalloc(&bo, (size_t)B * 8 * Np * Np * 4);
+    a.wb_img = (argc > 2 && atoi(argv[2]) == 0) ? nullptr : wimg; a.bb = b2; a.bias_out = bo; a.H = 8;
+  }
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
   for (int i = 0; i < 3; ++i) fd_edge_transition2(a, 0);
   (void)hipEventRecord(t0, 0);
