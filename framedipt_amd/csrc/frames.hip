@@ -204,29 +204,46 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
 }
 
 // ------------------------------------------------------------------ IGSO(3) rotation score
-// 8 lanes per residue split the 1000-term series; float32 sin/cos of omega*(l+1/2), float64 weights and sums
-// (the dtype flow torch produces for so3_diffuser.py:68-77,180-191 on the path).
+// 16 lanes per residue split the 1000-term series; float32 sin/cos of omega*(l+1/2), float64 weights and sums
+// (the dtype flow torch produces for so3_diffuser.py:68-77,180-191 on the path).  The series weights
+// (2l+1) exp(-l(l+1) sigma^2 / 2) depend on the sample only: the block builds them once in LDS for the (at most two)
+// samples its residues belong to instead of evaluating a float64 exp per residue and term.
+#define RS_L 1000
+#define RS_LANES 16
 __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t, int ld_t,
                                                                const float* __restrict__ quats_0, int ld_0,
                                                                const double* __restrict__ sigma,
                                                                const float* __restrict__ res_mask,
                                                                double* __restrict__ score) {
-  const long gid = (long)blockIdx.x * (FD_THREADS / 8) + (threadIdx.x >> 3);
-  const int sub = threadIdx.x & 7;
+  __shared__ double wtab[2][RS_L];
+  constexpr int RPB = FD_THREADS / RS_LANES;  // residues per block
   const long total = (long)B * N;
+  const long r_first = (long)blockIdx.x * RPB;
+  const int b_first = (int)((r_first < total ? r_first : total - 1) / N);
+  for (int v = threadIdx.x; v < 2 * RS_L; v += FD_THREADS) {
+    const int which = v / RS_L, l = v % RS_L;
+    const int bb = b_first + which < B ? b_first + which : B - 1;
+    const double sg = sigma[bb];
+    wtab[which][l] = (double)(2 * l + 1) * exp(-(double)l * (double)(l + 1) * sg * sg / 2);
+  }
+  __syncthreads();
+  const long gid = r_first + (threadIdx.x / RS_LANES);
+  const int sub = threadIdx.x % RS_LANES;
   const long r = gid < total ? gid : total - 1;
   const int b = (int)(r / N);
+  const bool use_tab = N >= RPB;  // a block then spans at most two samples; tiny N evaluates the weights per lane
+  const double* wt = wtab[b - b_first < 2 ? b - b_first : 1];
+  const double sg = sigma[b];
   float qi[4], q0t[4], rv[3];
   d_invert_quat(quats_0 + r * ld_0, qi);
   d_quat_mul(qi, quats_t + r * ld_t, q0t);
   d_quat_to_rotvec(q0t, rv);
   const float omega = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]) + 1e-6f;
-  const double sg = sigma[b];
   const float lo = sinf(omega / 2.f), dlo = 0.5f * cosf(omega / 2.f);
   const float den = lo * lo;
   double f = 0, ds = 0;
-  for (int l = sub; l < 1000; l += 8) {
-    const double w = (double)(2 * l + 1) * exp(-(double)l * (double)(l + 1) * sg * sg / 2);
+  for (int l = sub; l < RS_L; l += RS_LANES) {
+    const double w = use_tab ? wt[l] : (double)(2 * l + 1) * exp(-(double)l * (double)(l + 1) * sg * sg / 2);
     const float lh = (float)l + 0.5f;
     const float arg = omega * lh;
     const float hi = sinf(arg), dhi = lh * cosf(arg);
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
     ds += w * (double)num / (double)den;
   }
 #pragma unroll
-  for (int o = 1; o < 8; o <<= 1) {
+  for (int o = 1; o < RS_LANES; o <<= 1) {
     f += __shfl_xor(f, o, 64);
     ds += __shfl_xor(ds, o, 64);
   }
@@ -444,7 +461,7 @@ int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, c
 
 int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
                  const float* res_mask, double* score, hipStream_t st) {
-  hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / 8)), dim3(FD_THREADS), 0, st, B, N, qt, ld_t, q0,
+  hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, st, B, N, qt, ld_t, q0,
                      ld_0, sigma, res_mask, score);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -631,6 +631,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         t2.a1 = F(w.a1); t2.af = F(w.af); t2.stream = D + db.et2; t2.b2 = P + k.et2.b; t2.gamma = P + k.et_ln.g;
         t2.beta = P + k.et_ln.b; t2.res_mask = res_mask; t2.trace = tr_ptr;
         // the next block's attention consumes linear_b(z') in fragment order when it runs attention3
+        // (end to end +0.8 % at N = 300: the launch grows by about as much as the pair_bias2 launch it replaces, the gain
+        //  is the z re-read that disappears; FDIPT_NO_ET_BIAS restores the separate pass)
         const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
                                !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && N <= 512;
         t2.wb_img = emit_bias ? D + L.blk[b + 1].wb_img : nullptr;
