@@ -765,19 +765,31 @@ int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t
 }
 size_t fd_ee2_image_bytes() { return 2 * EE2_IMG; }
 
-__global__ __launch_bounds__(FD_THREADS, 2) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img,
-                                                                    int n_tiles) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * EE2_IMG];
+// 512-thread persistent blocks: 8 independent waves (two per SIMD) share the 64 KB weight images; every wave owns an
+// 8 KB LDS tile that transposes between "whole 512 B table rows per 32 lanes" (the global side) and MFMA fragments.
+#define EE2_THREADS 512
+#define EE2_LDS (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4)
+__global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img,
+                                                                     int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, li = lane & 31;
-  dma_slab<2 * EE2_IMG>(img, smem, tid);
+  char* stage = smem + 2 * EE2_IMG + wave * 8192;
+  float* vec = (float*)(smem + 2 * EE2_IMG + 8 * 8192);  // [b2 | b3 | gamma | beta] x 128
+  for (int u = 0; u < 2 * EE2_IMG / 16 / EE2_THREADS; ++u)
+    et2_dma16(img + (size_t)(u * EE2_THREADS + tid) * 16, smem + (size_t)(u * EE2_THREADS + (tid & ~63)) * 16);
+  if (tid < 4 * ET2_CZ) {
+    const int which = tid >> 7, c = tid & 127;
+    vec[tid] = which == 0 ? a.b2[c] : (which == 1 ? a.b3[c] : (which == 2 ? a.gamma[c] : a.beta[c]));
+  }
   et2_dma_wait();
   __syncthreads();
   const int N = a.N;
   const long n_pairs = (long)a.B * N * N;
-  const float* b2row = a.b2 + 4 * hi;
-  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-    const long p_raw = (long)tile * 32 + li;
+  const float* b2row = vec + 4 * hi;
+  for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+    const long p0 = (long)tile * 32;
+    const long p_raw = p0 + li;
     const bool valid = p_raw < n_pairs;
     const long p = valid ? p_raw : n_pairs - 1;
     const long bi = p / N;
@@ -796,23 +808,24 @@ __global__ __launch_bounds__(FD_THREADS, 2) void edge_embed2_kernel(EdgeEmbedArg
         if (d > lo && d < up) bin = k;
       }
     }
-    const float* r1 = a.pi + bi * ET2_CZ + 8 * hi;
-    const float* r2 = a.pj + bj * ET2_CZ + 8 * hi;
-    const float* r3 = a.rtab + (long)rel * ET2_CZ + 8 * hi;
-    const float* r4 = a.dtab + (long)bin * ET2_CZ + 8 * hi;
+    // ---- layer 1 has no GEMM: h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]).  Two pairs per instruction: lanes 0..31 /
+    // 32..63 read one whole 512 B row each (the row ids of pair 2 it + hi come from the lane that owns it)
+    const int ibi = (int)bi, ibj = (int)bj;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int r = 2 * it + hi;
+      const int rbi = __shfl(ibi, r, 64), rbj = __shfl(ibj, r, 64), rrel = __shfl(rel, r, 64), rbin = __shfl(bin, r, 64);
+      const f32x4 x1 = *(const f32x4*)(a.pi + (long)rbi * ET2_CZ + 4 * li), x2 = *(const f32x4*)(a.pj + (long)rbj * ET2_CZ + 4 * li);
+      const f32x4 x3 = *(const f32x4*)(a.rtab + (long)rrel * ET2_CZ + 4 * li), x4 = *(const f32x4*)(a.dtab + (long)rbin * ET2_CZ + 4 * li);
+      bf16x4 pk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)fmaxf(x1[q] + x2[q] + x3[q] + x4[q], 0.f);
+      // [32 pairs][256 B] tile, 16 B unit u of row r at u ^ (r & 15)
+      *(bf16x4*)(stage + r * 256 + (((li >> 1) ^ (r & 15)) << 4) + 8 * (li & 1)) = pk;
+    }
     bf16x8 H1[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      float v[8];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 x1 = *(const f32x4*)(r1 + 16 * s + 4 * h), x2 = *(const f32x4*)(r2 + 16 * s + 4 * h);
-        const f32x4 x3 = *(const f32x4*)(r3 + 16 * s + 4 * h), x4 = *(const f32x4*)(r4 + 16 * s + 4 * h);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[4 * h + q] = fmaxf(x1[q] + x2[q] + x3[q] + x4[q], 0.f);
-      }
-      H1[s] = pack8(v);
-    }
+    for (int s = 0; s < 8; ++s) H1[s] = lds_frag(stage, li * 256 + (((2 * s + hi) ^ (li & 15)) << 4));
     bf16x8 H2[8];
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
@@ -836,16 +849,23 @@ __global__ __launch_bounds__(FD_THREADS, 2) void edge_embed2_kernel(EdgeEmbedArg
       for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
       mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
     }
-    ln_epilogue(Y, a.b3 + 4 * hi, a.gamma, a.beta, a.res_mask[bi] * a.res_mask[bj], valid, hi,
-                (bf16_t*)a.z_out + p * ET2_CZ, a.trace ? a.trace + p * ET2_CZ : nullptr);
+    ln_epilogue_staged(Y, vec + ET2_CZ + 4 * hi, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, a.res_mask[bi] * a.res_mask[bj], li, hi, lane,
+                       stage, (bf16_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid, nullptr, nullptr,
+                       nullptr, 0, 0, 0, 0, 0);
   }
 }
 
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
   const int n_tiles = cdiv(n_pairs, 32);
-  const int grid = n_tiles / 4 + 1 < 512 ? n_tiles / 4 + 1 : 512;
-  hipLaunchKernelGGL(edge_embed2_kernel, dim3(grid), dim3(FD_THREADS), 0, st, a, (const char*)img, n_tiles);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)edge_embed2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EE2_LDS) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  const int grid = n_tiles / 8 + 1 < 256 ? n_tiles / 8 + 1 : 256;
+  hipLaunchKernelGGL(edge_embed2_kernel, dim3(grid), dim3(EE2_THREADS), EE2_LDS, st, a, (const char*)img, n_tiles);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
