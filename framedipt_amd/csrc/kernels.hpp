@@ -142,6 +142,23 @@ int fd_seq_attention_supported(int N, int H, int hd);
 int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, void* images,
                      float* out, int out_ld, hipStream_t st);
 
+// row-complete fused transformer layers (rowblock.hip): out = LayerNorm(residual + W0 in + b0) or, ffn,
+// LayerNorm(residual + W1 relu(W0 in + b0) + b1); d_model 320; weights as fd_chain_build_image(.., permuted = 0) images
+struct RowBlockArgs {
+  int M;
+  const float* in;
+  int ld_in;
+  const void *w0, *w1;
+  const float *b0, *b1;
+  const float* residual;
+  int ld_res;
+  const float *gamma, *beta;
+  float* out;
+  int ld_out;
+};
+int fd_rowblock_supported(int d_model);
+int fd_rowblock(int ffn, const RowBlockArgs& a, hipStream_t st);
+
 struct ChainArgs {
   int M;
   const float* in;          // [M, ld_in] fp32 input rows

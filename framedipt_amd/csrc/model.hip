@@ -93,7 +93,8 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
-  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3, et_init, a1, af;
+  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, et_init, a1, af;
+  // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
 struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, et2, wdz_t; DChain ch; };
 struct DLayout {
@@ -148,7 +149,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
       const int cs = d->c_s, dt = iv.d_t;
       c.skip = img(d->c_skip, cs);
-      for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); }
+      for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); c.l2n[l] = img(dt, dt); }
       c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs);
       c.et_init = img(iv.cb, cs); c.a1 = img(iv.hid, iv.cb); c.af = img(d->c_z, iv.cb);
     }
@@ -293,7 +294,7 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
       if ((rc = bi(k.skip, 0, c.skip))) return rc;
       for (int l = 0; l < d->tfmr_layers; ++l) {
         if ((rc = bi(k.tf[l].inp, 0, c.inp[l])) || (rc = bi(k.tf[l].outp, 0, c.outp[l])) || (rc = bi(k.tf[l].l1, 0, c.l1[l])) ||
-            (rc = bi(k.tf[l].l2, 1, c.l2[l])))
+            (rc = bi(k.tf[l].l2, 1, c.l2[l])) || (rc = bi(k.tf[l].l2, 0, c.l2n[l])))
           return rc;
       }
       if ((rc = bi(k.post, 0, c.post)) || (rc = bi(k.t1, 0, c.t1)) || (rc = bi(k.t2, 1, c.t2)) || (rc = bi(k.t3, 1, c.t3))) return rc;
@@ -569,6 +570,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       else if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
       else RC(fd_attention(prec, 0, ta, st));
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
+      const bool rb = use_chain(d) && fd_rowblock_supported(dt) && !getenv("FDIPT_NO_ROWBLOCK");
+      if (rb) {
+        RowBlockArgs ra;
+        ra.M = R; ra.in = F(w.att); ra.ld_in = dt; ra.w0 = D + db.ch.outp[l]; ra.b0 = P + t.outp.b; ra.w1 = nullptr; ra.b1 = nullptr;
+        ra.residual = x; ra.ld_res = dt; ra.gamma = P + t.n1.g; ra.beta = P + t.n1.b; ra.out = F(w.x_a); ra.ld_out = dt;
+        RC(fd_rowblock(0, ra, st));
+        ra.in = F(w.x_a); ra.w0 = D + db.ch.l1[l]; ra.b0 = P + t.l1.b; ra.w1 = D + db.ch.l2n[l]; ra.b1 = P + t.l2.b;
+        ra.residual = F(w.x_a); ra.gamma = P + t.n2.g; ra.beta = P + t.n2.b; ra.out = F(w.x_b);
+        RC(fd_rowblock(1, ra, st));
+      } else {
       if (con(FD_CHAIN_OUTPROJ)) {
         RC(chain(FD_CHAIN_OUTPROJ, F(w.att), dt, D + db.ch.outp[l], P + t.outp.b, nullptr, nullptr, nullptr, nullptr, x, dt,
                  &t.n1, nullptr, nullptr, F(w.x_a), dt));
@@ -583,6 +594,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         RC(lin(R, t.l1, F(w.x_a), dt, nullptr, 0, nullptr, 1, F(w.ff), dt));
         RC(lin(R, t.l2, F(w.ff), dt, nullptr, 0, nullptr, 0, F(w.att), dt));
         RC(fd_layernorm(R, dt, F(w.x_a), dt, F(w.att), dt, P + t.n2.g, P + t.n2.b, nullptr, F(w.x_b), dt, st));
+      }
       }
       x = F(w.x_b);  // next layer: norm1 reads x_b -> x_a, norm2 reads x_a/att -> x_b (no aliasing)
     }
