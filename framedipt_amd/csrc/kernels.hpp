@@ -142,22 +142,23 @@ int fd_seq_attention_supported(int N, int H, int hd);
 int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, void* images,
                      float* out, int out_ld, hipStream_t st);
 
-// row-complete fused transformer layers (rowblock.hip): out = LayerNorm(residual + W0 in + b0) or, ffn,
-// LayerNorm(residual + W1 relu(W0 in + b0) + b1); d_model 320; weights as fd_chain_build_image(.., permuted = 0) images
+// row-complete fused per-residue MLPs (rowblock.hip): 32 rows x all output columns per block, up to 3 Linear layers
+// (+ReLU) + residual + LayerNorm + row mask; weights as fd_chain_build_image(.., permuted = 0) fragment images
 struct RowBlockArgs {
   int M;
   const float* in;
   int ld_in;
-  const void *w0, *w1;
-  const float *b0, *b1;
-  const float* residual;
+  const void *w0, *w1, *w2;
+  const float *b0, *b1, *b2;
+  const float* residual;        // or NULL
   int ld_res;
-  const float *gamma, *beta;
+  const float *gamma, *beta;    // LayerNorm kinds
+  const float* rowmask_post;    // final * mask, or NULL
   float* out;
   int ld_out;
 };
-int fd_rowblock_supported(int d_model);
-int fd_rowblock(int ffn, const RowBlockArgs& a, hipStream_t st);
+enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION };
+int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 
 struct ChainArgs {
   int M;

@@ -93,7 +93,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
-  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, et_init, a1, af;
+  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
 struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, et2, wdz_t; DChain ch; };
@@ -103,6 +103,7 @@ struct DLayout {
   size_t w1i, w1j, w1r, dtab, edges, b1;  // fp32 pieces of the concat-free first edge-embedder layer
   size_t ee2;         // LDS images of edge-embedder layers 2/3 (register-resident bf16 kernel)
   size_t ch_ne0, ch_ne2, ch_ne4, ch_tor1, ch_tor2;  // chain images: node embedder, torsion head
+  size_t ch_ne2n, ch_ne4n, ch_tor2n;                // ... natural k order (rowblock.hip)
   DBlock blk[FD_MAX_BLOCKS];
   size_t total;
   int kn_pad, d1_pad, esz;
@@ -150,7 +151,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       const int cs = d->c_s, dt = iv.d_t;
       c.skip = img(d->c_skip, cs);
       for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); c.l2n[l] = img(dt, dt); }
-      c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs);
+      c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs); c.t2n = img(cs, cs); c.t3n = img(cs, cs);
       c.et_init = img(iv.cb, cs); c.a1 = img(iv.hid, iv.cb); c.af = img(d->c_z, iv.cb);
     }
   }
@@ -158,6 +159,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
     L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
     L.ch_tor1 = img(d->c_s, d->c_s); L.ch_tor2 = img(d->c_s, d->c_s);
+    L.ch_ne2n = img(d->c_s, d->c_s); L.ch_ne4n = img(d->c_s, d->c_s); L.ch_tor2n = img(d->c_s, d->c_s);
   }
   L.total = o;
 }
@@ -297,7 +299,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
             (rc = bi(k.tf[l].l2, 1, c.l2[l])) || (rc = bi(k.tf[l].l2, 0, c.l2n[l])))
           return rc;
       }
-      if ((rc = bi(k.post, 0, c.post)) || (rc = bi(k.t1, 0, c.t1)) || (rc = bi(k.t2, 1, c.t2)) || (rc = bi(k.t3, 1, c.t3))) return rc;
+      if ((rc = bi(k.post, 0, c.post)) || (rc = bi(k.t1, 0, c.t1)) || (rc = bi(k.t2, 1, c.t2)) || (rc = bi(k.t3, 1, c.t3)) ||
+          (rc = bi(k.t2, 0, c.t2n)) || (rc = bi(k.t3, 0, c.t3n)))
+        return rc;
       if (b < d->num_blocks - 1) {
         if ((rc = bi(k.et_init, 0, c.et_init))) return rc;
         // e_i columns of the first / final EdgeTransition layers as [hid, cb] / [cz, cb] matrices
@@ -312,6 +316,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     if ((rc = fd_chain_build_image(P + iv.ne4.w, cs, cs, cs, 1, D + L.ch_ne4, st))) return rc;
     if ((rc = fd_chain_build_image(P + iv.tor1.w, cs, cs, cs, 0, D + L.ch_tor1, st))) return rc;
     if ((rc = fd_chain_build_image(P + iv.tor2.w, cs, cs, cs, 1, D + L.ch_tor2, st))) return rc;
+    if ((rc = fd_chain_build_image(P + iv.ne2.w, cs, cs, cs, 0, D + L.ch_ne2n, st))) return rc;
+    if ((rc = fd_chain_build_image(P + iv.ne4.w, cs, cs, cs, 0, D + L.ch_ne4n, st))) return rc;
+    if ((rc = fd_chain_build_image(P + iv.tor2.w, cs, cs, cs, 0, D + L.ch_tor2n, st))) return rc;
   }
   (void)C;
   return FDIPT_OK;
@@ -433,6 +440,17 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   const char* cmask_s = getenv("FDIPT_CHAIN_MASK");
   const unsigned cmask = cmask_s ? (unsigned)strtoul(cmask_s, nullptr, 0) : 0xFC9u;
   auto con = [&](int kind) { return chn_all && ((cmask >> kind) & 1u); };
+  // row-complete fused MLPs (rowblock.hip) take the multi-layer kinds and the 320-wide transformer layers
+  const bool rbk = chn_all && cs == 256 && iv.d_t == 320 && !getenv("FDIPT_NO_ROWBLOCK");
+  auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
+                    const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
+                    float* out, int ld_out) {
+    RowBlockArgs r;
+    r.M = R; r.in = in; r.ld_in = ld_in; r.w0 = w0; r.w1 = w1; r.w2 = w2; r.b0 = b0; r.b1 = b1; r.b2 = b2; r.residual = resid;
+    r.ld_res = ld_res; r.gamma = lnw ? P + lnw->g : nullptr; r.beta = lnw ? P + lnw->b : nullptr; r.rowmask_post = post;
+    r.out = out; r.ld_out = ld_out;
+    return fd_rowblock(kind, r, st);
+  };
   auto chain = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                    const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* pre,
                    const float* post, float* out, int ld_out) {
@@ -446,7 +464,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   // ---- Embedder (score_network.py:129-197)
   RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
                     L.kn_pad, F(w.pte), L.d1_pad, st));
-  if (con(FD_CHAIN_NODE_EMBED_72) && (L.kn_pad == 72 || L.kn_pad == 88)) {
+  if (rbk && (L.kn_pad == 72 || L.kn_pad == 88)) {
+    RC(rblock(L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88, F(w.node_feat), L.kn_pad, D + L.ch_ne0, P + iv.ne0.b,
+              D + L.ch_ne2n, P + iv.ne2.b, D + L.ch_ne4n, P + iv.ne4.b, nullptr, 0, &iv.neln, res_mask, F(w.node0), cs));
+  } else if (con(FD_CHAIN_NODE_EMBED_72) && (L.kn_pad == 72 || L.kn_pad == 88)) {
     RC(chain(L.kn_pad == 72 ? FD_CHAIN_NODE_EMBED_72 : FD_CHAIN_NODE_EMBED_88, F(w.node_feat), L.kn_pad, D + L.ch_ne0,
              P + iv.ne0.b, D + L.ch_ne2, P + iv.ne2.b, D + L.ch_ne4, P + iv.ne4.b, nullptr, 0, &iv.neln, nullptr, res_mask,
              F(w.node0), cs));
@@ -570,15 +591,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       else if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
       else RC(fd_attention(prec, 0, ta, st));
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
-      const bool rb = use_chain(d) && fd_rowblock_supported(dt) && !getenv("FDIPT_NO_ROWBLOCK");
-      if (rb) {
-        RowBlockArgs ra;
-        ra.M = R; ra.in = F(w.att); ra.ld_in = dt; ra.w0 = D + db.ch.outp[l]; ra.b0 = P + t.outp.b; ra.w1 = nullptr; ra.b1 = nullptr;
-        ra.residual = x; ra.ld_res = dt; ra.gamma = P + t.n1.g; ra.beta = P + t.n1.b; ra.out = F(w.x_a); ra.ld_out = dt;
-        RC(fd_rowblock(0, ra, st));
-        ra.in = F(w.x_a); ra.w0 = D + db.ch.l1[l]; ra.b0 = P + t.l1.b; ra.w1 = D + db.ch.l2n[l]; ra.b1 = P + t.l2.b;
-        ra.residual = F(w.x_a); ra.gamma = P + t.n2.g; ra.beta = P + t.n2.b; ra.out = F(w.x_b);
-        RC(fd_rowblock(1, ra, st));
+      if (rbk) {
+        RC(rblock(FD_RB_OUTPROJ, F(w.att), dt, D + db.ch.outp[l], P + t.outp.b, nullptr, nullptr, nullptr, nullptr, x, dt, &t.n1,
+                  nullptr, F(w.x_a), dt));
+        RC(rblock(FD_RB_FFN, F(w.x_a), dt, D + db.ch.l1[l], P + t.l1.b, D + db.ch.l2n[l], P + t.l2.b, nullptr, nullptr, F(w.x_a),
+                  dt, &t.n2, nullptr, F(w.x_b), dt));
       } else {
       if (con(FD_CHAIN_OUTPROJ)) {
         RC(chain(FD_CHAIN_OUTPROJ, F(w.att), dt, D + db.ch.outp[l], P + t.outp.b, nullptr, nullptr, nullptr, nullptr, x, dt,
@@ -605,7 +622,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     } else {
       RC(lin(R, k.post, x, dt, F(w.tf_in), dt, nullptr, 0, F(w.h_a), cs));
     }
-    if (con(FD_CHAIN_TRANSITION)) {
+    if (rbk) {
+      RC(rblock(FD_RB_TRANSITION, F(w.h_a), cs, D + db.ch.t1, P + k.t1.b, D + db.ch.t2n, P + k.t2.b, D + db.ch.t3n, P + k.t3.b,
+                F(w.h_a), cs, &k.tln, res_mask, F(w.node), cs));
+    } else if (con(FD_CHAIN_TRANSITION)) {
       RC(chain(FD_CHAIN_TRANSITION, F(w.h_a), cs, D + db.ch.t1, P + k.t1.b, D + db.ch.t2, P + k.t2.b, D + db.ch.t3, P + k.t3.b,
                F(w.h_a), cs, &k.tln, nullptr, res_mask, F(w.node), cs));
     } else {
@@ -670,7 +690,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         return FDIPT_ELAUNCH;
   }
   // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
-  if (con(FD_CHAIN_TORSION)) {
+  if (rbk) {
+    RC(rblock(FD_RB_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
+              cs, nullptr, nullptr, F(w.h_b), cs));
+  } else if (con(FD_CHAIN_TORSION)) {
     RC(chain(FD_CHAIN_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2, P + iv.tor2.b, nullptr, nullptr, node_cur,
              cs, nullptr, nullptr, nullptr, F(w.h_b), cs));
   } else {

@@ -17,125 +17,175 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-#define RB_K 320
-#define RB_KS (RB_K / 16)
-#define RB_NT (RB_K / 32)
-#define RB_XROW 656       // bytes per activation row in LDS (320 bf16 + 16: conflict-free b128 fragment reads)
 #define RB_SROW 144       // bytes per row of a wave's 32 x 32 fp32 exchange tile
 
 typedef __bf16 rb_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 rb_ld(const char* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
+__host__ __device__ constexpr int rb_max(int a, int b) { return a > b ? a : b; }
 
-// FFN = true: two layers (W0 relu, W1) ; false: one layer (W0).  Always + residual, LayerNorm.
-template <bool FFN>
+// K0: input width (zero-padded to a multiple of 16); N1 / N2: hidden widths (0 = absent); NOUT: output width;
+// FLAGS bit0 / bit1: ReLU after hidden 1 / 2, bit2: LayerNorm.  Residual and the final row mask are optional (pointers).
+// Activation rows in LDS are [32][width bf16 + 16 B]: with widths 80..320 the 16 lanes of a b128 read hit 16 distinct
+// 16 B slots, no swizzle needed.
+template <int K0, int N1, int N2, int NOUT, int FLAGS>
+struct RBShape {
+  static constexpr int KS0 = (K0 + 15) / 16;
+  static constexpr int NL = 1 + (N1 > 0) + (N2 > 0);
+  static constexpr int KSMAX = rb_max(KS0, rb_max(N1 / 16, N2 / 16));
+  static constexpr int WMAX = rb_max(KS0 * 16, rb_max(N1, N2));          // widest activation tile
+  static constexpr int XROW = WMAX * 2 + 16;                              // bytes per LDS activation row
+  static constexpr bool LN = (FLAGS & 4) != 0;
+  static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0);     // b0 | b1 | b_out | gamma | beta
+  static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * 32 * XROW + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + 16;
+  static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 384, "tile shapes");
+};
+
+template <int K0, int N1, int N2, int NOUT, int FLAGS>
 __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a) {
+  using S = RBShape<K0, N1, N2, NOUT, FLAGS>;
+  constexpr int KS0 = S::KS0, NL = S::NL, XROW = S::XROW, KSMAX = S::KSMAX;
+  constexpr bool LN = S::LN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xs = smem;                                                  // x rows, bf16            [32][RB_XROW]
-  char* hs = xs + 32 * RB_XROW;                                     // hidden rows, bf16       [32][RB_XROW] (FFN)
-  char* st_all = hs + (FFN ? 32 * RB_XROW : 0);                     // per-wave exchange tiles [4][32][RB_SROW]
-  float* cst = (float*)(st_all + 4 * 32 * RB_SROW);                 // b0 | b1 | gamma | beta  [4][RB_K]
-  float (*red)[4][32] = (float (*)[4][32])(cst + 4 * RB_K);         // [2][4][32]
+  char* xs = smem;                                                  // activation rows (ping)  [32][XROW]
+  char* hs = xs + 32 * XROW;                                        // activation rows (pong)  [32][XROW]  (NL > 1)
+  char* st_all = hs + (NL > 1 ? 32 * XROW : 0);                     // per-wave exchange tiles [4][32][RB_SROW]
+  float* cst = (float*)(st_all + 4 * 32 * RB_SROW);                 // b0 | b1 | b_out | gamma | beta
+  float (*red)[4][32] = (float (*)[4][32])(cst + S::NCONST);        // [2][4][32]
+  float* pmask = (float*)(red + 2);                                 // [32] final row mask
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   const int row0 = blockIdx.x * 32;
   char* stg = st_all + wave * 32 * RB_SROW;
-  const char* w0 = (const char*)a.w0;
-  const char* w1 = (const char*)a.w1;
+  const char* wimg[3] = {(const char*)a.w0, (const char*)a.w1, (const char*)a.w2};
   // ---- first weight tile of this wave in flight before anything else
-  bf16x8 Wf[2][RB_KS];
-  auto w_load = [&](auto BUF, const char* img, int T) {
-    constexpr int bf = decltype(BUF)::value;
+  bf16x8 Wf[2][KSMAX];
+  auto w_load = [&](auto BUF, auto KSC, const char* img, int T) {
+    constexpr int bf = decltype(BUF)::value, KS = decltype(KSC)::value;
 #pragma unroll
-    for (int s = 0; s < RB_KS; ++s) Wf[bf][s] = rb_ld(img + ((size_t)(T * RB_KS + s) * 64 + lane) * 16);
+    for (int s = 0; s < KS; ++s) Wf[bf][s] = rb_ld(img + ((size_t)(T * KS + s) * 64 + lane) * 16);
   };
-  w_load(std::integral_constant<int, 0>{}, w0, wave);
-  // ---- x rows -> LDS (bf16), constants -> LDS
+  w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, KS0>{}, wimg[0], wave);
+  // ---- input rows -> LDS (bf16, zero-padded to 16 KS0 columns), constants -> LDS
   {
-    f32x4 xv[10];
+    constexpr int C4 = KS0 * 4;                       // float4 columns per row (padded)
+    constexpr int NV = (32 * C4 + FD_THREADS - 1) / FD_THREADS;
+    f32x4 xv[NV];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / C4, c4 = idx % C4;
       const int gr = row0 + r < a.M ? row0 + r : a.M - 1;
-      xv[k] = *(const f32x4*)(a.in + (long)gr * a.ld_in + 4 * c4);
+      xv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < 32 * C4 && 4 * c4 < K0) xv[k] = *(const f32x4*)(a.in + (long)gr * a.ld_in + 4 * c4);
     }
-    for (int v = tid; v < 4 * RB_K; v += FD_THREADS) {
-      const int which = v / RB_K, c = v % RB_K;
-      cst[v] = which == 0 ? a.b0[c] : (which == 1 ? (FFN ? a.b1[c] : 0.f) : (which == 2 ? a.gamma[c] : a.beta[c]));
+    for (int v = tid; v < S::NCONST; v += FD_THREADS) {
+      float x;
+      if (v < N1) x = a.b0[v];
+      else if (v < N1 + N2) x = a.b1[v - N1];
+      else if (v < N1 + N2 + NOUT) x = (NL == 1 ? a.b0 : (NL == 2 ? a.b1 : a.b2))[v - N1 - N2];
+      else if (v < N1 + N2 + 2 * NOUT) x = a.gamma[v - N1 - N2 - NOUT];
+      else x = a.beta[v - N1 - N2 - 2 * NOUT];
+      cst[v] = x;
     }
+    if (tid < 32) pmask[tid] = a.rowmask_post ? a.rowmask_post[row0 + tid < a.M ? row0 + tid : a.M - 1] : 1.f;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / C4, c4 = idx % C4;
       rb_bf16x4 pk;
 #pragma unroll
       for (int q = 0; q < 4; ++q) pk[q] = (__bf16)xv[k][q];
-      *(rb_bf16x4*)(xs + r * RB_XROW + 8 * c4) = pk;
+      if (idx < 32 * C4) *(rb_bf16x4*)(xs + r * XROW + 8 * c4) = pk;
     }
   }
   // residual row segments of this wave's output tiles: requested now, consumed after the last MFMA
+  constexpr int NTO = NOUT / 32;
   f32x4 rv[3][4];
+  const bool has_res = a.residual != nullptr;
 #pragma unroll
   for (int u = 0; u < 3; ++u)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int T = wave + 4 * u < RB_NT ? wave + 4 * u : wave;
+      const int T = wave + 4 * u < NTO ? wave + 4 * u : wave;
       const int r = 8 * it + (lane >> 3), gr = row0 + r < a.M ? row0 + r : a.M - 1;
-      rv[u][it] = *(const f32x4*)(a.residual + (long)gr * a.ld_res + 32 * T + 4 * (lane & 7));
+      rv[u][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has_res) rv[u][it] = *(const f32x4*)(a.residual + (long)gr * a.ld_res + 32 * T + 4 * (lane & 7));
     }
   __syncthreads();
-  bf16x8 X[RB_KS];
-#pragma unroll
-  for (int s = 0; s < RB_KS; ++s) X[s] = rb_ld(xs + li * RB_XROW + 32 * s + 16 * hi);
 
+  bf16x8 X[KSMAX];
   f32x16 acc[3];
-  // one layer: tiles wave, wave+4, wave+8 of `img` against the B fragments Bf; the first tile's fragments are in Wf[0]
-  auto layer = [&](const char* img, const bf16x8* Bf) {
+  // one layer: tiles wave, wave+4, wave+8 (< NT) of `img` against the B fragments X[0..KS); the first tile's fragments
+  // are already in Wf[0]
+  auto layer = [&](auto KSC, auto NTC, const char* img) {
+    constexpr int KS = decltype(KSC)::value, NT = decltype(NTC)::value;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int T = wave + 4 * u;
-      if (u + 1 < 3 && T + 4 < RB_NT) {
-        if (u & 1) w_load(std::integral_constant<int, 0>{}, img, T + 4);
-        else w_load(std::integral_constant<int, 1>{}, img, T + 4);
+      if (u + 1 < 3 && T + 4 < NT) {
+        if (u & 1) w_load(std::integral_constant<int, 0>{}, KSC, img, T + 4);
+        else w_load(std::integral_constant<int, 1>{}, KSC, img, T + 4);
       }
-      if (T < RB_NT) {
+      if (T < NT) {
         f32x16 c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < RB_KS; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], Bf[s], c, 0, 0, 0);
+        for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
         acc[u] = c;
       }
     }
   };
-  layer(w0, X);
-  if constexpr (FFN) {
-    // hidden = relu(acc + b0) -> bf16 -> LDS rows (natural feature order), then every wave re-reads all of it as B fragments
-    w_load(std::integral_constant<int, 0>{}, w1, wave);  // second layer's first tile: in flight across the barrier
+  // hidden = act(acc + bias) -> bf16 -> LDS rows (natural feature order); every wave then re-reads all of it
+  auto to_hidden = [&](auto NTC, auto RELU, const float* bias, char* dst) {
+    constexpr int NT = decltype(NTC)::value;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int T = wave + 4 * u;
-      if (T < RB_NT) {
+      if (T < NT) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int f0 = 32 * T + 8 * g + 4 * hi;
-          const f32x4 bv = *(const f32x4*)(cst + f0);
+          const f32x4 bv = *(const f32x4*)(bias + f0);
           rb_bf16x4 pk;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) pk[q] = (__bf16)fmaxf(acc[u][4 * g + q] + bv[q], 0.f);
-          *(rb_bf16x4*)(hs + li * RB_XROW + 2 * f0) = pk;
+          for (int q = 0; q < 4; ++q) {
+            float v = acc[u][4 * g + q] + bv[q];
+            if (decltype(RELU)::value) v = fmaxf(v, 0.f);
+            pk[q] = (__bf16)v;
+          }
+          *(rb_bf16x4*)(dst + li * XROW + 2 * f0) = pk;
         }
       }
     }
+  };
+#pragma unroll
+  for (int s = 0; s < KS0; ++s) X[s] = rb_ld(xs + li * XROW + 32 * s + 16 * hi);
+  if constexpr (NL == 1) {
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, NTO>{}, wimg[0]);
+  } else {
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0]);
+    w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N1 / 16>{}, wimg[1], wave);  // in flight across the barrier
+    to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs);
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < RB_KS; ++s) X[s] = rb_ld(hs + li * RB_XROW + 32 * s + 16 * hi);
-    layer(w1, X);
+    for (int s = 0; s < N1 / 16; ++s) X[s] = rb_ld(hs + li * XROW + 32 * s + 16 * hi);
+    if constexpr (NL == 2) {
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, NTO>{}, wimg[1]);
+    } else {
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1]);
+      w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N2 / 16>{}, wimg[2], wave);
+      to_hidden(std::integral_constant<int, N2 / 32>{}, std::integral_constant<bool, (FLAGS & 2) != 0>{}, cst + N1, xs);  // xs is free again
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < N2 / 16; ++s) X[s] = rb_ld(xs + li * XROW + 32 * s + 16 * hi);
+      layer(std::integral_constant<int, N2 / 16>{}, std::integral_constant<int, NTO>{}, wimg[2]);
+    }
   }
-  // ---- + bias + residual (fetched as 128 B row segments, turned into fragment layout through the wave's tile)
-  const float* bo = cst + (FFN ? RB_K : 0);
+  // ---- + bias + residual (row segments -> fragment layout through the wave's tile)
+  const float* bo = cst + N1 + N2;
   float s1 = 0.f;
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int T = wave + 4 * u;
-    if (T < RB_NT) {
+    if (T < NTO) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) *(f32x4*)(stg + (8 * it + (lane >> 3)) * RB_SROW + 16 * (lane & 7)) = rv[u][it];
 #pragma unroll
@@ -151,36 +201,44 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       }
     }
   }
-  // ---- LayerNorm over the row: lane-local sums, lane^32, then the 4 waves through LDS (two passes)
-  s1 += __shfl_xor(s1, 32, 64);
-  if (hi == 0) red[0][wave][li] = s1;
-  __syncthreads();
-  const float mu = (red[0][0][li] + red[0][1][li] + red[0][2][li] + red[0][3][li]) * (1.0f / RB_K);
-  float s2 = 0.f;
+  float mu = 0.f, rstd = 1.f;
+  if constexpr (LN) {  // lane-local sums, lane^32, then the 4 waves through LDS (two passes)
+    s1 += __shfl_xor(s1, 32, 64);
+    if (hi == 0) red[0][wave][li] = s1;
+    __syncthreads();
+    mu = (red[0][0][li] + red[0][1][li] + red[0][2][li] + red[0][3][li]) * (1.0f / NOUT);
+    float s2 = 0.f;
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
-    if (wave + 4 * u < RB_NT)
+    for (int u = 0; u < 3; ++u)
+      if (wave + 4 * u < NTO)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float d = acc[u][r] - mu;
-        s2 += d * d;
-      }
-  s2 += __shfl_xor(s2, 32, 64);
-  if (hi == 0) red[1][wave][li] = s2;
-  __syncthreads();
-  const float rstd = 1.0f / sqrtf((red[1][0][li] + red[1][1][li] + red[1][2][li] + red[1][3][li]) * (1.0f / RB_K) + 1e-5f);
-  // ---- normalise, back through the wave's tile, store 128 B row segments
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[u][r] - mu;
+          s2 += d * d;
+        }
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hi == 0) red[1][wave][li] = s2;
+    __syncthreads();
+    rstd = 1.0f / sqrtf((red[1][0][li] + red[1][1][li] + red[1][2][li] + red[1][3][li]) * (1.0f / NOUT) + 1e-5f);
+  }
+  const float pm = pmask[li];
+  // ---- (normalise,) mask, back through the wave's tile, store 128 B row segments
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int T = wave + 4 * u;
-    if (T < RB_NT) {
+    if (T < NTO) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * T + 8 * g + 4 * hi;
-        const f32x4 gm = *(const f32x4*)(cst + 2 * RB_K + f0), bt = *(const f32x4*)(cst + 3 * RB_K + f0);
         f32x4 o;
+        if constexpr (LN) {
+          const f32x4 gm = *(const f32x4*)(bo + NOUT + f0), bt = *(const f32x4*)(bo + 2 * NOUT + f0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = (acc[u][4 * g + q] - mu) * rstd * gm[q] + bt[q];
+          for (int q = 0; q < 4; ++q) o[q] = ((acc[u][4 * g + q] - mu) * rstd * gm[q] + bt[q]) * pm;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = acc[u][4 * g + q] * pm;
+        }
         *(f32x4*)(stg + li * RB_SROW + (8 * g + 4 * hi) * 4) = o;
       }
 #pragma unroll
@@ -193,21 +251,32 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   }
 }
 
-int fd_rowblock_supported(int d_model) { return d_model == RB_K; }
-
-int fd_rowblock(int ffn, const RowBlockArgs& a, hipStream_t st) {
-  if (a.M <= 0 || (a.ld_in & 3) || (a.ld_res & 3) || (a.ld_out & 3) || !a.residual || a.residual == a.out) return FDIPT_EINVAL;
-  const dim3 grid(cdiv(a.M, 32));
-  const size_t smem = (size_t)(ffn ? 2 : 1) * 32 * RB_XROW + 4 * 32 * RB_SROW + 4 * RB_K * 4 + 2 * 4 * 32 * 4;
+template <int K0, int N1, int N2, int NOUT, int FLAGS>
+static int rb_launch(const RowBlockArgs& a, hipStream_t st) {
+  using S = RBShape<K0, N1, N2, NOUT, FLAGS>;
+  if (a.M <= 0 || (a.ld_in & 3) || (a.residual && (a.ld_res & 3)) || (a.ld_out & 3) || (a.residual && a.residual == a.out && false))
+    return FDIPT_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rowblock_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)rowblock_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)rowblock_kernel<K0, N1, N2, NOUT, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)S::SMEM) != hipSuccess)
       return FDIPT_ELAUNCH;
     attr_set = true;
   }
-  if (ffn) hipLaunchKernelGGL((rowblock_kernel<true>), grid, dim3(FD_THREADS), smem, st, a);
-  else hipLaunchKernelGGL((rowblock_kernel<false>), grid, dim3(FD_THREADS), smem, st, a);
+  hipLaunchKernelGGL((rowblock_kernel<K0, N1, N2, NOUT, FLAGS>), dim3(cdiv(a.M, 32)), dim3(FD_THREADS), S::SMEM, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
+}
+
+// shapes of the reference network (c_s 256, d_model 320); FDIPT_EINVAL for anything else
+int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
+  switch (kind) {
+    case FD_RB_OUTPROJ: return rb_launch<320, 0, 0, 320, 4>(a, st);              // out_proj + residual, LN
+    case FD_RB_FFN: return rb_launch<320, 320, 0, 320, 1 | 4>(a, st);            // l1 relu l2 + residual, LN
+    case FD_RB_TRANSITION: return rb_launch<256, 256, 256, 256, 1 | 2 | 4>(a, st);  // t1 relu t2 relu t3 + residual, LN, mask
+    case FD_RB_NODE_EMBED_72: return rb_launch<72, 256, 256, 256, 1 | 2 | 4>(a, st);
+    case FD_RB_NODE_EMBED_88: return rb_launch<88, 256, 256, 256, 1 | 2 | 4>(a, st);
+    case FD_RB_TORSION: return rb_launch<256, 256, 0, 256, 1>(a, st);            // l1 relu l2 + residual
+    default: return FDIPT_EINVAL;
+  }
 }
