@@ -156,8 +156,12 @@ struct RowBlockArgs {
   const float* rowmask_post;    // final * mask, or NULL
   float* out;
   int ld_out;
+  // FD_RB_TRANSITION_BB: BackboneUpdate (Linear c_s -> 6, fp32) on the output rows + compose_q_update_vec, in place
+  const float *bb_w, *bb_b;     // [6, c_s], [6]
+  const float* upd_mask;        // [M] or NULL
+  float *quat, *trans;          // [M,4], [M,3]
 };
-enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION };
+enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 
 struct ChainArgs {

@@ -448,7 +448,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RowBlockArgs r;
     r.M = R; r.in = in; r.ld_in = ld_in; r.w0 = w0; r.w1 = w1; r.w2 = w2; r.b0 = b0; r.b1 = b1; r.b2 = b2; r.residual = resid;
     r.ld_res = ld_res; r.gamma = lnw ? P + lnw->g : nullptr; r.beta = lnw ? P + lnw->b : nullptr; r.rowmask_post = post;
-    r.out = out; r.ld_out = ld_out;
+    r.out = out; r.ld_out = ld_out; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
     return fd_rowblock(kind, r, st);
   };
   auto chain = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
@@ -622,9 +622,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     } else {
       RC(lin(R, k.post, x, dt, F(w.tf_in), dt, nullptr, 0, F(w.h_a), cs));
     }
+    bool bb_done = false;
     if (rbk) {
-      RC(rblock(FD_RB_TRANSITION, F(w.h_a), cs, D + db.ch.t1, P + k.t1.b, D + db.ch.t2n, P + k.t2.b, D + db.ch.t3n, P + k.t3.b,
-                F(w.h_a), cs, &k.tln, res_mask, F(w.node), cs));
+      // ... with BackboneUpdate + compose_q_update_vec fused in (the fp32 Linear c_s -> 6 is a per-row dot product)
+      RowBlockArgs r;
+      r.M = R; r.in = F(w.h_a); r.ld_in = cs; r.w0 = D + db.ch.t1; r.w1 = D + db.ch.t2n; r.w2 = D + db.ch.t3n; r.b0 = P + k.t1.b;
+      r.b1 = P + k.t2.b; r.b2 = P + k.t3.b; r.residual = F(w.h_a); r.ld_res = cs; r.gamma = P + k.tln.g; r.beta = P + k.tln.b;
+      r.rowmask_post = res_mask; r.out = F(w.node); r.ld_out = cs; r.bb_w = P + k.bb.w; r.bb_b = P + k.bb.b;
+      r.upd_mask = F(w.dmask); r.quat = F(w.quat); r.trans = F(w.trans);
+      RC(fd_rowblock(FD_RB_TRANSITION_BB, r, st));
+      bb_done = true;
     } else if (con(FD_CHAIN_TRANSITION)) {
       RC(chain(FD_CHAIN_TRANSITION, F(w.h_a), cs, D + db.ch.t1, P + k.t1.b, D + db.ch.t2, P + k.t2.b, D + db.ch.t3, P + k.t3.b,
                F(w.h_a), cs, &k.tln, nullptr, res_mask, F(w.node), cs));
@@ -637,8 +644,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     node_cur = F(w.node);
     // BackboneUpdate + compose_q_update_vec (ipa:542-547).  bb_update(node*diffuse_mask) differs from bb_update(node)
     // only on rows whose update is masked out below, so the input mask is not materialised.
-    RC(lin32(R, k.bb, node_cur, cs, F(w.upd), 8));
-    RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
+    if (!bb_done) {
+      RC(lin32(R, k.bb, node_cur, cs, F(w.upd), 8));
+      RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
+    }
     if (b < d->num_blocks - 1) {
       if (con(FD_CHAIN_ETINIT)) RC(chain(FD_CHAIN_ETINIT, node_cur, cs, D + db.ch.et_init, P + k.et_init.b, nullptr, nullptr, nullptr, nullptr,
                         nullptr, 0, nullptr, nullptr, nullptr, F(w.e), iv.cb));

@@ -17,6 +17,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#pragma clang fp contract(off)  // the fused frame update keeps the float32 evaluation order of the reference expressions
+
 #define RB_SROW 144       // bytes per row of a wave's 32 x 32 fp32 exchange tile
 
 typedef __bf16 rb_bf16x4 __attribute__((ext_vector_type(4)));
@@ -35,8 +37,9 @@ struct RBShape {
   static constexpr int WMAX = rb_max(KS0 * 16, rb_max(N1, N2));          // widest activation tile
   static constexpr int XROW = WMAX * 2 + 16;                              // bytes per LDS activation row
   static constexpr bool LN = (FLAGS & 4) != 0;
-  static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0);     // b0 | b1 | b_out | gamma | beta
-  static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * 32 * XROW + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + 16;
+  static constexpr bool BB = (FLAGS & 8) != 0;                            // fused BackboneUpdate + compose_q_update_vec
+  static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0) + (BB ? 6 * NOUT : 0);  // b0 | b1 | b_out | gamma | beta | Wbb
+  static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * 32 * XROW + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + (BB ? 4 * 32 * 8 * 4 : 0) + 16;
   static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 384, "tile shapes");
 };
 
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   float* cst = (float*)(st_all + 4 * 32 * RB_SROW);                 // b0 | b1 | b_out | gamma | beta
   float (*red)[4][32] = (float (*)[4][32])(cst + S::NCONST);        // [2][4][32]
   float* pmask = (float*)(red + 2);                                 // [32] final row mask
+  float* red3 = pmask + 32;                                         // [4][32][8] partial BackboneUpdate outputs (BB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   const int row0 = blockIdx.x * 32;
   char* stg = st_all + wave * 32 * RB_SROW;
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       else if (v < N1 + N2) x = a.b1[v - N1];
       else if (v < N1 + N2 + NOUT) x = (NL == 1 ? a.b0 : (NL == 2 ? a.b1 : a.b2))[v - N1 - N2];
       else if (v < N1 + N2 + 2 * NOUT) x = a.gamma[v - N1 - N2 - NOUT];
-      else x = a.beta[v - N1 - N2 - 2 * NOUT];
+      else if (v < N1 + N2 + 3 * NOUT) x = a.beta[v - N1 - N2 - 2 * NOUT];
+      else x = a.bb_w[v - N1 - N2 - 3 * NOUT];  // [6][NOUT] (LayerNorm kinds only)
       cst[v] = x;
     }
     if (tid < 32) pmask[tid] = a.rowmask_post ? a.rowmask_post[row0 + tid < a.M ? row0 + tid : a.M - 1] : 1.f;
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     rstd = 1.0f / sqrtf((red[1][0][li] + red[1][1][li] + red[1][2][li] + red[1][3][li]) * (1.0f / NOUT) + 1e-5f);
   }
   const float pm = pmask[li];
+  float pd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // ---- (normalise,) mask, back through the wave's tile, store 128 B row segments
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -240,6 +246,13 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
           for (int q = 0; q < 4; ++q) o[q] = acc[u][4 * g + q] * pm;
         }
         *(f32x4*)(stg + li * RB_SROW + (8 * g + 4 * hi) * 4) = o;
+        if constexpr (S::BB) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const f32x4 wv = *(const f32x4*)(bo + 3 * NOUT + k * NOUT + f0);
+            pd[k] += (o[0] * wv[0] + o[1] * wv[1]) + (o[2] * wv[2] + o[3] * wv[3]);
+          }
+        }
       }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -247,6 +260,41 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
         const f32x4 o = *(const f32x4*)(stg + r * RB_SROW + 16 * (lane & 7));
         if (row0 + r < a.M) *(f32x4*)(a.out + (long)(row0 + r) * a.ld_out + 32 * T + 4 * (lane & 7)) = o;
       }
+    }
+  }
+  if constexpr (S::BB) {
+    // BackboneUpdate (ipa_pytorch.py:542-545): 6 outputs per row = this lane's partial dots + lane^32 + the other waves
+    // through LDS, then Rigid.compose_q_update_vec with the update mask (rigid_utils.py:587-616,1039-1063) in place
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pd[k] += __shfl_xor(pd[k], 32, 64);
+    if (hi == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) red3[(wave * 32 + li) * 8 + k] = pd[k];
+    }
+    __syncthreads();
+    if (tid < 32 && row0 + tid < a.M) {
+      const long r = row0 + tid;
+      float upd[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        upd[k] = ((red3[tid * 8 + k] + red3[(32 + tid) * 8 + k]) + (red3[(64 + tid) * 8 + k] + red3[(96 + tid) * 8 + k])) + a.bb_b[k];
+      const float m = a.upd_mask ? a.upd_mask[r] : 1.f;
+      const float q0 = a.quat[r * 4], q1 = a.quat[r * 4 + 1], q2 = a.quat[r * 4 + 2], q3 = a.quat[r * 4 + 3];
+      // quat_multiply_by_vec (rigid_utils.py:266-279), quat_to_rot (:173-205), rot_vec_mul (:82-106)
+      const float dq0 = -q1 * upd[0] - q2 * upd[1] - q3 * upd[2];
+      const float dq1 = q0 * upd[0] + q2 * upd[2] - q3 * upd[1];
+      const float dq2 = q0 * upd[1] - q1 * upd[2] + q3 * upd[0];
+      const float dq3 = q0 * upd[2] + q1 * upd[1] - q2 * upd[0];
+      const float R0 = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3, R1 = 2 * q1 * q2 - 2 * q0 * q3, R2 = 2 * q1 * q3 + 2 * q0 * q2;
+      const float R3 = 2 * q1 * q2 + 2 * q0 * q3, R4 = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3, R5 = 2 * q2 * q3 - 2 * q0 * q1;
+      const float R6 = 2 * q1 * q3 - 2 * q0 * q2, R7 = 2 * q2 * q3 + 2 * q0 * q1, R8 = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+      const float d0 = R0 * upd[3] + R1 * upd[4] + R2 * upd[5];
+      const float d1 = R3 * upd[3] + R4 * upd[4] + R5 * upd[5];
+      const float d2 = R6 * upd[3] + R7 * upd[4] + R8 * upd[5];
+      const float n0 = q0 + dq0 * m, n1 = q1 + dq1 * m, n2 = q2 + dq2 * m, n3 = q3 + dq3 * m;
+      const float nrm = sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+      a.quat[r * 4] = n0 / nrm; a.quat[r * 4 + 1] = n1 / nrm; a.quat[r * 4 + 2] = n2 / nrm; a.quat[r * 4 + 3] = n3 / nrm;
+      a.trans[r * 3] += d0 * m; a.trans[r * 3 + 1] += d1 * m; a.trans[r * 3 + 2] += d2 * m;
     }
   }
 }
@@ -274,6 +322,7 @@ int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
     case FD_RB_OUTPROJ: return rb_launch<320, 0, 0, 320, 4>(a, st);              // out_proj + residual, LN
     case FD_RB_FFN: return rb_launch<320, 320, 0, 320, 1 | 4>(a, st);            // l1 relu l2 + residual, LN
     case FD_RB_TRANSITION: return rb_launch<256, 256, 256, 256, 1 | 2 | 4>(a, st);  // t1 relu t2 relu t3 + residual, LN, mask
+    case FD_RB_TRANSITION_BB: return rb_launch<256, 256, 256, 256, 1 | 2 | 4 | 8>(a, st);  // ... + BackboneUpdate + compose
     case FD_RB_NODE_EMBED_72: return rb_launch<72, 256, 256, 256, 1 | 2 | 4>(a, st);
     case FD_RB_NODE_EMBED_88: return rb_launch<88, 256, 256, 256, 1 | 2 | 4>(a, st);
     case FD_RB_TORSION: return rb_launch<256, 256, 0, 256, 1>(a, st);            // l1 relu l2 + residual
