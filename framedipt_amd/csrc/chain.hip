@@ -330,7 +330,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] *= pm;
         }
-        if ((!(CH_ABL & 1) || v[0] == 1234.5f) && rok[it] && (tiles == 2 || sc < 8)) *(f32x4*)(a.out + ooff[it] + 32 * T0) = v;
+        if ((!(CH_ABL & 1) || v[0] == 1234.5f) && rok[it] && (tiles == 2 || sc < 8)) {
+          *(f32x4*)(a.out + ooff[it] + 32 * T0) = v;
+          if (!LN && a.out_bf16) {  // optional bf16 copy of the rows (row stride NOUT): consumed by LDS-DMA in edge_transition3
+            bf16x4 hb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hb[q] = (__bf16)v[q];
+            *(bf16x4*)(a.out_bf16 + (long)(wrow0 + 4 * it + sr) * NOUT + 4 * sc + 32 * T0) = hb;
+          }
+        }
       }
     }
   });

@@ -89,6 +89,7 @@ struct ET2Args {
   const bf16_t* z_in;   // [B,N,N,128] bf16
   bf16_t* z_out;        // may alias z_in
   const float* e;       // [B*N,128] f32 initial_embed(node)
+  const bf16_t* e_bf16; // the same rows in bf16 (edge_transition3: fetched by LDS-DMA)
   const float* a1;      // [B*N,384] f32: W1[:, e_i cols] e_i + b1
   const float* af;      // [B*N,128] f32: Wf[:, e_i cols] e_i + bf
   const void* stream;   // pre-swizzled weight stream (fd_et2_build_stream)
@@ -104,6 +105,11 @@ int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void*
 size_t fd_et2_stream_bytes();
 int fd_edge_transition2(const ET2Args& a, hipStream_t st);
 int fd_edge_transition2_supported(int N);
+// second-generation kernel (edge_transition3.hip): 16-pair waves, two waves per SIMD; same arguments, its own stream image
+int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
+size_t fd_et3_stream_bytes();
+int fd_edge_transition3(const ET2Args& a, hipStream_t st);
+int fd_edge_transition3_supported(int N);
 int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t st);
 size_t fd_ee2_image_bytes();
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st);
@@ -173,6 +179,7 @@ struct ChainArgs {
   const float* residual;    // added to the output layer (fp32) or NULL
   int ld_res;
   const float *gamma, *beta;     // LayerNorm parameters (kinds with LN)
+  unsigned short* out_bf16;      // optional bf16 copy of the output rows, [M, NOUT] (kinds without LayerNorm), or NULL
   const float* rowmask_pre;      // (W x + b) * mask before the residual, or NULL
   const float* rowmask_post;     // final * mask, or NULL
   float* out;

@@ -96,7 +96,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, et2, wdz_t; DChain ch; };
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, et2, et3, wdz_t; DChain ch; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -145,6 +145,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et2 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
+    L.blk[b].et3 = o;
+    if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et3_stream_bytes());
     if (use_chain(d)) {
       DChain& c = L.blk[b].ch;
       auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
@@ -289,7 +291,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
     if (use_et2(d) && b < d->num_blocks - 1)
-      if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st))) return rc;
+      if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st)) ||
+          (rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)))
+        return rc;
     if (use_chain(d)) {
       const DChain& c = db.ch;
       auto bi = [&](const LinW& l, int perm, size_t off) { return fd_chain_build_image(P + l.w, l.out, l.in, l.in, perm, D + off, st); };
@@ -345,7 +349,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -377,7 +381,8 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
     w.pts = take(R * (size_t)(iv.proj_out - 3 * HC) * 4);
   }
   w.seqimg = take(fd_seq_attention_image_bytes(B, N, d->tfmr_heads));
-  w.ipa_parts = take((size_t)8 * R * d->c_s * 4);  // split-K partial products of the IPA output projection
+  w.ipa_parts = take((size_t)8 * R * d->c_s * 4);
+  w.e_bf = take(R * iv.cb * 2);  // bf16 copy of initial_embed(node) (edge_transition3 fetches it by LDS-DMA)  // split-K partial products of the IPA output projection
   w.total = o;
 }
 
@@ -451,13 +456,14 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     r.out = out; r.ld_out = ld_out; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
     return fd_rowblock(kind, r, st);
   };
+  unsigned short* chain_bf16 = nullptr;  // one-shot: the next chain() call also writes a bf16 copy of its output rows
   auto chain = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                    const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* pre,
                    const float* post, float* out, int ld_out) {
     ChainArgs c;
     c.M = R; c.in = in; c.ld_in = ld_in; c.w[0] = w0; c.w[1] = w1; c.w[2] = w2; c.b[0] = b0; c.b[1] = b1; c.b[2] = b2;
     c.residual = resid; c.ld_res = ld_res; c.gamma = lnw ? P + lnw->g : nullptr; c.beta = lnw ? P + lnw->b : nullptr;
-    c.rowmask_pre = pre; c.rowmask_post = post; c.out = out; c.ld_out = ld_out;
+    c.rowmask_pre = pre; c.rowmask_post = post; c.out = out; c.ld_out = ld_out; c.out_bf16 = chain_bf16; chain_bf16 = nullptr;
     return fd_chain(kind, c, st);
   };
 
@@ -649,9 +655,14 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
     }
     if (b < d->num_blocks - 1) {
-      if (con(FD_CHAIN_ETINIT)) RC(chain(FD_CHAIN_ETINIT, node_cur, cs, D + db.ch.et_init, P + k.et_init.b, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, 0, nullptr, nullptr, nullptr, F(w.e), iv.cb));
-      else RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
+      if (con(FD_CHAIN_ETINIT)) {
+        chain_bf16 = (unsigned short*)(W + w.e_bf);
+        RC(chain(FD_CHAIN_ETINIT, node_cur, cs, D + db.ch.et_init, P + k.et_init.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                 nullptr, nullptr, nullptr, F(w.e), iv.cb));
+      } else {
+        RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
+        if (bf) RC(fd_f32_to_bf16((long)R * iv.cb, F(w.e), (bf16_t*)(W + w.e_bf), st));
+      }
       float* tr_ptr = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
       bias_ready = false;
       if (use_et2(d) && fd_edge_transition2_supported(N)) {
@@ -669,18 +680,23 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         }
         ET2Args t2;
         t2.B = B; t2.N = N; t2.z_in = (const bf16_t*)(W + w.z); t2.z_out = (bf16_t*)(W + w.z); t2.e = F(w.e);
+        t2.e_bf16 = (const bf16_t*)(W + w.e_bf);
         t2.a1 = F(w.a1); t2.af = F(w.af); t2.stream = D + db.et2; t2.b2 = P + k.et2.b; t2.gamma = P + k.et_ln.g;
         t2.beta = P + k.et_ln.b; t2.res_mask = res_mask; t2.trace = tr_ptr;
         // the next block's attention consumes linear_b(z') in fragment order when it runs attention3
         // (end to end +0.8 % at N = 300: the launch grows by about as much as the pair_bias2 launch it replaces, the gain
         //  is the z re-read that disappears; FDIPT_NO_ET_BIAS restores the separate pass)
-        const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
+        // FDIPT_ET_V2 selects the first-generation register kernel (32-pair waves, one wave per SIMD)
+        const bool use_et3 = !getenv("FDIPT_ET_V2") && fd_edge_transition3_supported(N);
+        const bool emit_bias = !use_et3 && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
                                !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && N <= 512;
         t2.wb_img = emit_bias ? D + L.blk[b + 1].wb_img : nullptr;
         t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
         bias_ready = emit_bias;
+        if (use_et3) t2.stream = D + db.et3;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
-        RC(fd_edge_transition2(t2, st));
+        if (use_et3) RC(fd_edge_transition3(t2, st));
+        else RC(fd_edge_transition2(t2, st));
         if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
       } else {
       EdgeTransArgs ta;
