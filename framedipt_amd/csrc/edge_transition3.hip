@@ -35,10 +35,12 @@
 #define E3_STREAM_BYTES (E3_L1_BYTES + E3_L2_BYTES + E3_LF_BYTES)
 #define E3_BROWS 4
 #define E3_BROW_BYTES 2048
-#define E3_LDS (2 * E3_CHUNK + 2 * E3_BROWS * E3_BROW_BYTES + 1536 + 1024)
+#define E3_LDS (2 * E3_CHUNK + 2 * E3_BROWS * E3_BROW_BYTES + 1536 + 1024 + 4096)  // ... + linear_b image of the next block
 
 typedef __attribute__((ext_vector_type(4))) float e3_f32x4;
 typedef __bf16 e3_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int e3_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int e3_u32x2 __attribute__((ext_vector_type(2)));
 
 // k position (0..31) of a k-step whose B fragment is the C/D hand-off of tiles (2s, 2s+1) -> feature offset in [0, 32)
 __host__ __device__ __forceinline__ int e3_chain_feat(int pos) {
@@ -81,6 +83,22 @@ int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void*
   return FDIPT_OK;
 }
 size_t fd_et3_stream_bytes() { return E3_STREAM_BYTES; }
+
+// linear_b of the NEXT block's attention (ipa_pytorch.py:247,256-257) as 4 fragments [k-step][lane][8]: row = head (8 of 16
+// used), k in the hand-off order of the LayerNorm output tiles; `scale` = sqrt(1/3)
+__global__ void et3_bias_image_kernel(const float* __restrict__ wb, int H, float scale, bf16_t* __restrict__ img) {
+  for (int g = threadIdx.x; g < 4 * 64; g += blockDim.x) {
+    const int s = g >> 6, lane = g & 63, m = lane & 15, q = lane >> 4;
+    for (int e = 0; e < 8; ++e)
+      img[g * 8 + e] = m < H ? f2bf(wb[m * E3_CZ + 32 * s + e3_chain_feat(8 * q + e)] * scale) : (bf16_t)0;
+  }
+}
+int fd_et3_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st) {
+  if (H > 8) return FDIPT_ESIZE;
+  hipLaunchKernelGGL(et3_bias_image_kernel, dim3(1), dim3(256), 0, st, wb, H, scale, (bf16_t*)img);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 
 // ------------------------------------------------------------------ device helpers
 typedef __attribute__((address_space(3))) void e3_lds_t;
@@ -214,6 +232,7 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
       const float* src = tid < 96 ? a.b2 + 4 * tid : (tid < 128 ? a.gamma + 4 * (tid - 96) : a.beta + 4 * (tid - 128));
       e3_dma16(src, (const char*)vec + (tid & ~63) * 16);
     }
+    if (a.wb_img && tid < 256) e3_dma16((const char*)a.wb_img + tid * 16, (const char*)vec + 2560 + (tid & ~63) * 16);
   }
   E3Tile tc = e3_tile(tile, wave, n0, N, n_pairs);
   float em = a.res_mask[tc.bi] * a.res_mask[tc.bj];
@@ -352,6 +371,7 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
       s2 += __shfl_xor(s2, 16, 64);
       s2 += __shfl_xor(s2, 32, 64);
       const float rstd = 1.0f / sqrtf(s2 * (1.0f / E3_CZ) + 1e-5f);
+      e3_u32x4 zB[4];
       bf16_t* zo = a.z_out + (long)tc.p * E3_CZ + 4 * q;
       float* tr_row = a.trace ? a.trace + (long)tc.p * E3_CZ + 4 * q : nullptr;
 #pragma unroll
@@ -370,6 +390,25 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
             f32x4 tv = {of[0], of[1], of[2], of[3]};
             *(f32x4*)(tr_row + 16 * t) = tv;
           }
+        }
+        const e3_u32x2 ow = __builtin_bit_cast(e3_u32x2, o);  // C/D hand-off of tiles (2s, 2s+1) -> B fragment s of z'
+        zB[t >> 1][2 * (t & 1)] = ow[0];
+        zB[t >> 1][2 * (t & 1) + 1] = ow[1];
+      }
+      if (a.wb_img) {
+        // pair bias of the next block's attention: D[head, pair] = Wb z' (4 MFMAs), heads 4q + r live in lane groups q < 2
+        e3_f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e3_frag((const char*)vec + 2560 + s * 1024 + lane * 16),
+                                                         __builtin_bit_cast(bf16x8, zB[s]), accb, 0, 0, 0);
+        if (tc.valid && q < 2) {
+          const int b_idx = tc.bi / N, ii = tc.bi - b_idx * N, jj = tc.bj - b_idx * N, nt = (N + 31) >> 5;
+          float* bo = a.bias_out + fd_bias_frag_off((long)b_idx * a.H + 4 * q, nt, ii, jj);
+          const long hstride = (long)nt * nt * 1024;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * q + r < a.H) bo[r * hstride] = accb[r] + a.bb[4 * q + r];
         }
       }
     }

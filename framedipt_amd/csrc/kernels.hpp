@@ -109,6 +109,7 @@ int fd_edge_transition2_supported(int N);
 int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et3_stream_bytes();
 int fd_edge_transition3(const ET2Args& a, hipStream_t st);
+int fd_et3_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st);  // 4 KB, for ET2Args.wb_img
 int fd_edge_transition3_supported(int N);
 int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t st);
 size_t fd_ee2_image_bytes();

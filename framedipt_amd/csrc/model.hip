@@ -96,7 +96,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, et2, et3, wdz_t; DChain ch; };
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, wb_img3, et2, et3, wdz_t; DChain ch; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -142,6 +142,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb_img = o; o = al256(o + 8192);  // linear_b as a 32 x 128 MFMA fragment image (edge_transition2 epilogue)
+    L.blk[b].wb_img3 = o; o = al256(o + 4096);  // ... as 16 x 128 (edge_transition3 epilogue)
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et2 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
@@ -287,7 +288,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     if ((rc = copy_cols(L.esz, H, cz, cz, P + k.lb.w, cz, 0, s3, D + db.wb, st))) return rc;
     if ((rc = copy_cols(4, 1, H, H, P + k.lb.b, H, 0, s3, D + db.bb, st))) return rc;
     if (cz == 128 && H <= 8)
-      if ((rc = fd_chain_build_image_scaled(P + k.lb.w, H, cz, cz, 1, s3, D + db.wb_img, st))) return rc;
+      if ((rc = fd_chain_build_image_scaled(P + k.lb.w, H, cz, cz, 1, s3, D + db.wb_img, st)) ||
+          (rc = fd_et3_build_bias_image(P + k.lb.w, H, s3, D + db.wb_img3, st)))
+        return rc;
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
     if (use_et2(d) && b < d->num_blocks - 1)
@@ -688,9 +691,9 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         //  is the z re-read that disappears; FDIPT_NO_ET_BIAS restores the separate pass)
         // FDIPT_ET_V2 selects the first-generation register kernel (32-pair waves, one wave per SIMD)
         const bool use_et3 = !getenv("FDIPT_ET_V2") && fd_edge_transition3_supported(N);
-        const bool emit_bias = !use_et3 && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
+        const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
                                !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && N <= 512;
-        t2.wb_img = emit_bias ? D + L.blk[b + 1].wb_img : nullptr;
+        t2.wb_img = emit_bias ? D + (use_et3 ? L.blk[b + 1].wb_img3 : L.blk[b + 1].wb_img) : nullptr;
         t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
         bias_ready = emit_bias;
         if (use_et3) t2.stream = D + db.et3;
