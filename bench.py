@@ -12,7 +12,7 @@ backbone atoms); K consecutive steps of the 500-step schedule are timed after W 
 noise tape already resident in HBM.  value = B*N*K*n_gpus / max-over-ranks(time).
 
 Also reported on the same JSON line:
-  roofline     : the dominant kernel (edge_transition_kernel, 89 % of reference FLOPs) timed with HIP events on the
+  roofline     : the dominant kernel (EdgeTransition, 89 % of reference FLOPs) timed with HIP events on the
                  launch stream inside the timed region; achieved = reference-formulation FLOPs per launch / duration.
   cpu_baseline : the NumPy oracle (port of the reference loop) timed on this box's host cores on a bounded sample.
 """
@@ -32,6 +32,20 @@ sys.path.insert(0, ROOT)
 
 ET_FLOPS_PER_PAIR = 688128.0  # 2*(2*384^2 + 384*128): EdgeTransition, reference formulation
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def pmc_traffic(precision: str, n: int, b: int):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), only when the
+    bench runs the profiled configuration; the counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_edge_transition.json")) as f:
+            rec = json.load(f)
+        w = rec["workload"]
+        if (w["precision"], w["n_res"], w["samples_per_gpu"]) == (precision, n, b):
+            return rec["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def flops_per_forward(n: int) -> float:
@@ -168,7 +182,7 @@ def main():
                                    f"the T={T} schedule, noise_scale 0.1, 17.4M-param synthetic weights",
                        "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "kernel": "edge_transition_kernel",
+                         "traffic": pmc_traffic(a.precision, N, B), "kernel": "edge_transition3_kernel" if a.precision == "bf16" else "edge_transition_kernel",
                          "avg_launch_ms": et * 1e3, "flops_per_launch": et_flops,
                          "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak},
         }
