@@ -1,5 +1,6 @@
 """GPU parity tests (-m gpu): the HIP path through the C ABI vs the reference goldens and the NumPy oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -280,35 +281,65 @@ def test_fails_loudly_on_cpu_tensors():
 
 
 def test_edge_transition_register_kernel_vs_lds_kernel():
-    """bf16 EdgeTransition: register-resident kernel (edge_transition2.hip) vs the LDS-chain kernel (pair_mlp.hip)
-    on the full-width network, and both against the fp32 reference golden."""
+    """bf16 EdgeTransition: the two register-resident kernels (edge_transition3.hip: 16-pair waves, default;
+    edge_transition2.hip: 32-pair waves, FDIPT_ET_V2) vs the LDS-chain kernel (pair_mlp.hip, FDIPT_ET_V1) on the
+    full-width network, and all three against the fp32 reference golden."""
     import os
     G = load_golden("fwd_full_denovo_n64.npz")
     rows = list(G["trace_rows"])
     outs = {}
-    for tag, env in (("v2", None), ("v1", "1")):
-        if env is None:
-            os.environ.pop("FDIPT_ET_V1", None)
-        else:
-            os.environ["FDIPT_ET_V1"] = env
+    for tag, var in (("v3", None), ("v2", "FDIPT_ET_V2"), ("v1", "FDIPT_ET_V1")):
+        for v in ("FDIPT_ET_V1", "FDIPT_ET_V2"):
+            os.environ.pop(v, None)
+        if var:
+            os.environ[var] = "1"
         try:
             net, _, conf = _net("full_denovo_n64", G, "bf16")
             out = net(_feats(G), trace=True)
             outs[tag] = out["trace_edge"].cpu().numpy().copy()
         finally:
-            os.environ.pop("FDIPT_ET_V1", None)
-    for tag in ("v1", "v2"):  # edge embedder (trace slot 0): edge_embed2_kernel vs edge_embed_kernel
+            for v in ("FDIPT_ET_V1", "FDIPT_ET_V2"):
+                os.environ.pop(v, None)
+    for tag in ("v1", "v2", "v3"):  # edge embedder (trace slot 0): edge_embed2_kernel vs edge_embed_kernel
         rel = np.linalg.norm(outs[tag][0][:, rows] - G["tr_edge_init"]) / np.linalg.norm(G["tr_edge_init"])
         assert rel < 1e-2, (tag, "embed", rel)
-    assert np.linalg.norm(outs["v1"][0] - outs["v2"][0]) / np.linalg.norm(outs["v1"][0]) < 1e-2
+    assert np.linalg.norm(outs["v1"][0] - outs["v3"][0]) / np.linalg.norm(outs["v1"][0]) < 1e-2
     for b in range(3):
         ref = G[f"tr_edge_{b}"]
-        for tag in ("v1", "v2"):
+        for tag in ("v1", "v2", "v3"):
             got = outs[tag][b + 1][:, rows]
             rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
             assert rel < 2e-2, (tag, b, rel)
-        a, c = outs["v1"][b + 1], outs["v2"][b + 1]
-        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-2, b
+        for tag in ("v2", "v3"):
+            a, c = outs["v1"][b + 1], outs[tag][b + 1]
+            assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-2, (tag, b)
+
+
+def test_fused_paths_vs_separate_launches():
+    """bf16 node path with every fusion of the default path switched off (row-block kernels, split-K output projection,
+    pair bias from the EdgeTransition epilogue) vs the default: same representation after every block."""
+    import os
+    G = load_golden("fwd_full_denovo_n64.npz")
+    outs = {}
+    switches = ("FDIPT_NO_ROWBLOCK", "FDIPT_NO_SPLITK", "FDIPT_NO_ET_BIAS")
+    for tag, on in (("fused", False), ("plain", True)):
+        for v in switches:
+            os.environ.pop(v, None)
+            if on:
+                os.environ[v] = "1"
+        try:
+            net, _, conf = _net("full_denovo_n64", G, "bf16")
+            out = net(_feats(G), trace=True)
+            outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["rigids"].cpu().numpy().copy(),
+                         out["psi"].cpu().numpy().copy())
+        finally:
+            for v in switches:
+                os.environ.pop(v, None)
+    for b in range(5):
+        a, c = outs["plain"][0][b], outs["fused"][0][b]
+        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, b
+    np.testing.assert_allclose(outs["plain"][1][..., 4:], outs["fused"][1][..., 4:], atol=2e-2)
+    np.testing.assert_allclose(outs["plain"][2], outs["fused"][2], atol=3e-2)
 
 
 def test_register_attention_vs_lds_attention():
