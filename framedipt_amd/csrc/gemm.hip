@@ -256,7 +256,7 @@ int fd_ipa_proj(const ProjArgs& a, hipStream_t st) {
   const int M = a.B * a.N, NOUT = 3 * a.H * a.C + a.PT;
   if ((a.K & 7) || (a.lda & 3)) return FDIPT_EINVAL;
   if ((a.Np & 31) || (a.C & 31)) return FDIPT_EINVAL;
-  if (a.Np > a.N)
+  if (a.Np > a.N && a.zero_pads)  // the pads are never written by the epilogue: once per forward is enough
     hipLaunchKernelGGL(kv_zero_pad_kernel, dim3(256), dim3(256), 0, st, (long)a.B * a.H, a.N, a.Np, a.C, a.Kb, a.Vt);
   hipLaunchKernelGGL(ipa_proj_kernel, dim3(cdiv(M, 128), cdiv(NOUT, 128)), dim3(FD_THREADS), 0, st, a);
   FD_CHECK_LAUNCH();

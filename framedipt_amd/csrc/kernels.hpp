@@ -124,6 +124,7 @@ struct ProjArgs {
   float qscale;               // sqrt(1/(3C)) folded into Q
   bf16_t *Qb, *Kb, *Vt;
   float* pts;                 // [B*N, PT]
+  int zero_pads;              // also zero the padded keys [N, Np) of Kb / Vt (first use of the buffers in a forward)
 };
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
 
@@ -163,12 +164,15 @@ struct RowBlockArgs {
   const float* rowmask_post;    // final * mask, or NULL
   float* out;
   int ld_out;
+  float* out2;                  // optional: output columns >= split go to out2 (column - split), or NULL
+  int ld_out2, split;
+  unsigned short* hid_bf16;     // optional bf16 copy of the first hidden layer's rows [M, N1], or NULL
   // FD_RB_TRANSITION_BB: BackboneUpdate (Linear c_s -> 6, fp32) on the output rows + compose_q_update_vec, in place
   const float *bb_w, *bb_b;     // [6, c_s], [6]
   const float* upd_mask;        // [M] or NULL
   float *quat, *trans;          // [M,4], [M,3]
 };
-enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB };
+enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 
 struct ChainArgs {

@@ -93,7 +93,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
-  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af;
+  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
 struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, wb_img3, et2, et3, wdz_t; DChain ch; };
@@ -156,6 +156,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); c.l2n[l] = img(dt, dt); }
       c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs); c.t2n = img(cs, cs); c.t3n = img(cs, cs);
       c.et_init = img(iv.cb, cs); c.a1 = img(iv.hid, iv.cb); c.af = img(d->c_z, iv.cb);
+      c.a1af = img(iv.hid + d->c_z, iv.cb);                     // [W1[:, e_i]; Wf[:, e_i]] as one 512-row image (rowblock.hip)
+      c.b1f = o; o = al256(o + (size_t)(iv.hid + d->c_z) * 4);  // [b1; bf]
     }
   }
   if (use_chain(d)) {
@@ -313,6 +315,13 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
         if ((rc = bi(k.et_init, 0, c.et_init))) return rc;
         // e_i columns of the first / final EdgeTransition layers as [hid, cb] / [cz, cb] matrices
         if ((rc = fd_chain_build_image(P + k.et1.w + cz, iv.hid, iv.cb, iv.hid, 0, D + c.a1, st))) return rc;
+        // the same two matrices stacked (tile-major images: stacking = concatenation) and their biases, for the fused
+        // initial_embed -> [A1 | Af] row-block kernel
+        if ((rc = fd_chain_build_image(P + k.et1.w + cz, iv.hid, iv.cb, iv.hid, 0, D + c.a1af, st)) ||
+            (rc = fd_chain_build_image(P + k.etf.w + cz, cz, iv.cb, iv.hid, 0, D + c.a1af + fd_chain_image_bytes(iv.hid, iv.cb), st)) ||
+            (rc = copy_cols(4, 1, iv.hid, iv.hid, P + k.et1.b, iv.hid, 0, 1.f, D + c.b1f, st)) ||
+            (rc = copy_cols(4, 1, cz, cz, P + k.etf.b, cz, 0, 1.f, D + c.b1f + (size_t)iv.hid * 4, st)))
+          return rc;
         if ((rc = fd_chain_build_image(P + k.etf.w + cz, cz, iv.cb, iv.hid, 0, D + c.af, st))) return rc;
       }
     }
@@ -457,6 +466,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     r.M = R; r.in = in; r.ld_in = ld_in; r.w0 = w0; r.w1 = w1; r.w2 = w2; r.b0 = b0; r.b1 = b1; r.b2 = b2; r.residual = resid;
     r.ld_res = ld_res; r.gamma = lnw ? P + lnw->g : nullptr; r.beta = lnw ? P + lnw->b : nullptr; r.rowmask_post = post;
     r.out = out; r.ld_out = ld_out; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
+    r.out2 = nullptr; r.ld_out2 = r.split = 0; r.hid_bf16 = nullptr;
     return fd_rowblock(kind, r, st);
   };
   unsigned short* chain_bf16 = nullptr;  // one-shot: the next chain() call also writes a bf16 copy of its output rows
@@ -531,6 +541,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       pj.B = B; pj.N = N; pj.H = H; pj.C = C; pj.K = cs; pj.PT = PT; pj.Np = Np; pj.A = node_cur; pj.lda = cs;
       pj.W = D + db.wproj; pj.bias = (const float*)(D + db.bproj); pj.qscale = sqrtf(1.0f / (3.0f * (float)C));
       pj.Qb = (bf16_t*)(W + w.qb); pj.Kb = (bf16_t*)(W + w.kb); pj.Vt = (bf16_t*)(W + w.vt); pj.pts = F(w.pts);
+      pj.zero_pads = b == 0;
       RC(fd_ipa_proj(pj, st));
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
       RC(fd_points(pa, st));
@@ -638,7 +649,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       r.M = R; r.in = F(w.h_a); r.ld_in = cs; r.w0 = D + db.ch.t1; r.w1 = D + db.ch.t2n; r.w2 = D + db.ch.t3n; r.b0 = P + k.t1.b;
       r.b1 = P + k.t2.b; r.b2 = P + k.t3.b; r.residual = F(w.h_a); r.ld_res = cs; r.gamma = P + k.tln.g; r.beta = P + k.tln.b;
       r.rowmask_post = res_mask; r.out = F(w.node); r.ld_out = cs; r.bb_w = P + k.bb.w; r.bb_b = P + k.bb.b;
-      r.upd_mask = F(w.dmask); r.quat = F(w.quat); r.trans = F(w.trans);
+      r.upd_mask = F(w.dmask); r.quat = F(w.quat); r.trans = F(w.trans); r.out2 = nullptr; r.ld_out2 = r.split = 0;
+      r.hid_bf16 = nullptr;
       RC(fd_rowblock(FD_RB_TRANSITION_BB, r, st));
       bb_done = true;
     } else if (con(FD_CHAIN_TRANSITION)) {
@@ -658,7 +670,18 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
     }
     if (b < d->num_blocks - 1) {
-      if (con(FD_CHAIN_ETINIT)) {
+      // bf16 default path: e = initial_embed(node) and the per-residue rows A1[i] | Af[i] in ONE row-block launch
+      // (edge_transition3 only needs e as bf16; the 32-pair kernel reads the fp32 rows)
+      const bool et_rows_fused = rbk && iv.cb == 128 && iv.hid == 384 && cz == 128 && use_et2(d) && !getenv("FDIPT_ET_V2") &&
+                                 fd_edge_transition3_supported(N);
+      if (et_rows_fused) {
+        RowBlockArgs r;
+        r.M = R; r.in = node_cur; r.ld_in = cs; r.w0 = D + db.ch.et_init; r.b0 = P + k.et_init.b; r.w1 = D + db.ch.a1af;
+        r.b1 = (const float*)(D + db.ch.b1f); r.w2 = nullptr; r.b2 = nullptr; r.residual = nullptr; r.ld_res = 0; r.gamma = r.beta = nullptr;
+        r.rowmask_post = nullptr; r.out = F(w.a1); r.ld_out = iv.hid; r.out2 = F(w.af); r.ld_out2 = cz; r.split = iv.hid;
+        r.hid_bf16 = (unsigned short*)(W + w.e_bf); r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
+        RC(fd_rowblock(FD_RB_ET_ROWS, r, st));
+      } else if (con(FD_CHAIN_ETINIT)) {
         chain_bf16 = (unsigned short*)(W + w.e_bf);
         RC(chain(FD_CHAIN_ETINIT, node_cur, cs, D + db.ch.et_init, P + k.et_init.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                  nullptr, nullptr, nullptr, F(w.e), iv.cb));
@@ -670,7 +693,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       bias_ready = false;
       if (use_et2(d) && fd_edge_transition2_supported(N)) {
         // per-residue parts of the concat-free layers: A1[i] = W1[:, e_i cols] e_i + b1, Af[i] = Wf[:, e_i cols] e_i + bf
-        if (con(FD_CHAIN_A1)) {
+        if (et_rows_fused) {
+        } else if (con(FD_CHAIN_A1)) {
           RC(chain(FD_CHAIN_A1, F(w.e), iv.cb, D + db.ch.a1, P + k.et1.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                    nullptr, nullptr, F(w.a1), iv.hid));
           RC(chain(FD_CHAIN_AF, F(w.e), iv.cb, D + db.ch.af, P + k.etf.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,

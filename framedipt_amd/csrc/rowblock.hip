@@ -37,16 +37,18 @@ struct RBShape {
   static constexpr int WMAX = rb_max(KS0 * 16, rb_max(N1, N2));          // widest activation tile
   static constexpr int XROW = WMAX * 2 + 16;                              // bytes per LDS activation row
   static constexpr bool LN = (FLAGS & 4) != 0;
+  static constexpr int NTMAX = rb_max(NOUT / 32, rb_max(N1 / 32, N2 / 32));
+  static constexpr int NTW = (NTMAX + 3) / 4;                              // output tiles per wave
   static constexpr bool BB = (FLAGS & 8) != 0;                            // fused BackboneUpdate + compose_q_update_vec
   static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0) + (BB ? 6 * NOUT : 0);  // b0 | b1 | b_out | gamma | beta | Wbb
   static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * 32 * XROW + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + (BB ? 4 * 32 * 8 * 4 : 0) + 16;
-  static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 384, "tile shapes");
+  static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 512, "tile shapes");
 };
 
 template <int K0, int N1, int N2, int NOUT, int FLAGS>
 __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a) {
   using S = RBShape<K0, N1, N2, NOUT, FLAGS>;
-  constexpr int KS0 = S::KS0, NL = S::NL, XROW = S::XROW, KSMAX = S::KSMAX;
+  constexpr int KS0 = S::KS0, NL = S::NL, XROW = S::XROW, KSMAX = S::KSMAX, NTW = S::NTW;
   constexpr bool LN = S::LN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                                                  // activation rows (ping)  [32][XROW]
@@ -102,10 +104,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   }
   // residual row segments of this wave's output tiles: requested now, consumed after the last MFMA
   constexpr int NTO = NOUT / 32;
-  f32x4 rv[3][4];
+  f32x4 rv[NTW][4];
   const bool has_res = a.residual != nullptr;
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
+  for (int u = 0; u < NTW; ++u)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int T = wave + 4 * u < NTO ? wave + 4 * u : wave;
@@ -116,15 +118,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   __syncthreads();
 
   bf16x8 X[KSMAX];
-  f32x16 acc[3];
+  f32x16 acc[NTW];
   // one layer: tiles wave, wave+4, wave+8 (< NT) of `img` against the B fragments X[0..KS); the first tile's fragments
   // are already in Wf[0]
   auto layer = [&](auto KSC, auto NTC, const char* img) {
     constexpr int KS = decltype(KSC)::value, NT = decltype(NTC)::value;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NTW; ++u) {
       const int T = wave + 4 * u;
-      if (u + 1 < 3 && T + 4 < NT) {
+      if (u + 1 < NTW && T + 4 < NT) {
         if (u & 1) w_load(std::integral_constant<int, 0>{}, KSC, img, T + 4);
         else w_load(std::integral_constant<int, 1>{}, KSC, img, T + 4);
       }
@@ -139,10 +141,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     }
   };
   // hidden = act(acc + bias) -> bf16 -> LDS rows (natural feature order); every wave then re-reads all of it
-  auto to_hidden = [&](auto NTC, auto RELU, const float* bias, char* dst) {
+  auto to_hidden = [&](auto NTC, auto RELU, const float* bias, char* dst, unsigned short* hid_bf16, int hid_ld) {
     constexpr int NT = decltype(NTC)::value;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NTW; ++u) {
       const int T = wave + 4 * u;
       if (T < NT) {
 #pragma unroll
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
             pk[q] = (__bf16)v;
           }
           *(rb_bf16x4*)(dst + li * XROW + 2 * f0) = pk;
+          if (hid_bf16 && row0 + li < a.M) *(rb_bf16x4*)(hid_bf16 + (long)(row0 + li) * hid_ld + f0) = pk;  // optional bf16 copy of the rows
         }
       }
     }
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   } else {
     layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0]);
     w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N1 / 16>{}, wimg[1], wave);  // in flight across the barrier
-    to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs);
+    to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs, a.hid_bf16, N1);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < N1 / 16; ++s) X[s] = rb_ld(hs + li * XROW + 32 * s + 16 * hi);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     } else {
       layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1]);
       w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N2 / 16>{}, wimg[2], wave);
-      to_hidden(std::integral_constant<int, N2 / 32>{}, std::integral_constant<bool, (FLAGS & 2) != 0>{}, cst + N1, xs);  // xs is free again
+      to_hidden(std::integral_constant<int, N2 / 32>{}, std::integral_constant<bool, (FLAGS & 2) != 0>{}, cst + N1, xs, nullptr, 0);  // xs is free again
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < N2 / 16; ++s) X[s] = rb_ld(xs + li * XROW + 32 * s + 16 * hi);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   const float* bo = cst + N1 + N2;
   float s1 = 0.f;
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < NTW; ++u) {
     const int T = wave + 4 * u;
     if (T < NTO) {
 #pragma unroll
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     mu = (red[0][0][li] + red[0][1][li] + red[0][2][li] + red[0][3][li]) * (1.0f / NOUT);
     float s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < NTW; ++u)
       if (wave + 4 * u < NTO)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   float pd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // ---- (normalise,) mask, back through the wave's tile, store 128 B row segments
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < NTW; ++u) {
     const int T = wave + 4 * u;
     if (T < NTO) {
 #pragma unroll
@@ -258,7 +261,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       for (int it = 0; it < 4; ++it) {
         const int r = 8 * it + (lane >> 3);
         const f32x4 o = *(const f32x4*)(stg + r * RB_SROW + 16 * (lane & 7));
-        if (row0 + r < a.M) *(f32x4*)(a.out + (long)(row0 + r) * a.ld_out + 32 * T + 4 * (lane & 7)) = o;
+        if (row0 + r < a.M) {
+          if (a.out2 && 32 * T >= a.split) *(f32x4*)(a.out2 + (long)(row0 + r) * a.ld_out2 + 32 * T - a.split + 4 * (lane & 7)) = o;
+          else *(f32x4*)(a.out + (long)(row0 + r) * a.ld_out + 32 * T + 4 * (lane & 7)) = o;
+        }
       }
     }
   }
@@ -326,6 +332,7 @@ int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
     case FD_RB_NODE_EMBED_72: return rb_launch<72, 256, 256, 256, 1 | 2 | 4>(a, st);
     case FD_RB_NODE_EMBED_88: return rb_launch<88, 256, 256, 256, 1 | 2 | 4>(a, st);
     case FD_RB_TORSION: return rb_launch<256, 256, 0, 256, 1>(a, st);            // l1 relu l2 + residual
+    case FD_RB_ET_ROWS: return rb_launch<256, 128, 0, 512, 0>(a, st);            // e = init(node); [A1 | Af] = [W1e; Wfe] e + b
     default: return FDIPT_EINVAL;
   }
 }
