@@ -81,6 +81,136 @@ __global__ void seq_images_kernel(int B, int N, int Np, int H, const float* __re
   }
 }
 
+// ------------------------------------------------------------------ fused in_proj -> images
+// seq_images_init_kernel: everything in the images that does not depend on the layer — zeros (padded rows / keys /
+// channels 81..95), Q's mask channel = 1, K's mask channel = -1e30 for masked or padded keys.  Once per forward.
+__global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float* __restrict__ res_mask, bf16_t* __restrict__ Qi,
+                                       bf16_t* __restrict__ Ki, bf16_t* __restrict__ Vi) {
+  const int nt = Np >> 5;
+  const long nqk = (long)B * H * nt * SA_KS * 64, nv = (long)B * H * SA_DT * (2 * nt) * 64;
+  for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < 2 * nqk + nv; u += (long)gridDim.x * blockDim.x) {
+    u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (u < 2 * nqk) {
+      const bool isk = u >= nqk;
+      const long v = isk ? u - nqk : u;
+      const int lane = (int)(v & 63), s = (int)((v >> 6) % SA_KS);
+      const long r2 = (v >> 6) / SA_KS;
+      const int t = (int)(r2 % nt);
+      const long b = (r2 / nt) / H;
+      const int row = 32 * t + (lane & 31);
+      if (s == SA_KS - 1 && (lane >> 5) == 0) {  // channels 80..87: the mask channel is the first of them
+        if (!isk) o[0] = f2bf(1.0f);
+        else if (row >= N || res_mask[b * N + row] == 0.f) o[0] = f2bf(-1e30f);
+      }
+      *(u16x8*)((isk ? Ki : Qi) + v * 8) = o;
+    } else {
+      *(u16x8*)(Vi + (u - 2 * nqk) * 8) = o;
+    }
+  }
+}
+
+// seq_qkv_kernel: in_proj (Linear 320 -> 960, fp32 rows in, bf16 MFMA) whose epilogue writes the attention images
+// directly.  A block owns 32 rows and all 30 output tiles (dealt to the 4 waves); weights as a natural-order fragment image
+// (fd_chain_build_image), read straight from L2.  Q / K tiles run transposed (lane = row: 4 consecutive channels -> 8 B
+// pieces of a fragment unit); V tiles run with the operands exchanged (lane = channel, registers = rows: 4 consecutive
+// keys -> 8 B pieces of V^T).  Needs N % 4 == 0.
+#define SQ_K 320
+#define SQ_KS (SQ_K / 16)
+#define SQ_XROW (SQ_K * 2 + 16)
+typedef __bf16 sa_bf16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, int Np, int H, const float* __restrict__ x, int ld_x,
+                                                                const char* __restrict__ wimg, const float* __restrict__ bias,
+                                                                float qscale, bf16_t* __restrict__ Qi, bf16_t* __restrict__ Ki,
+                                                                bf16_t* __restrict__ Vi) {
+  __shared__ __attribute__((aligned(16))) char xs[32 * SQ_XROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+  const int M = B * N, row0 = blockIdx.x * 32, nt = Np >> 5, dm = H * SA_HD;
+  bf16x8 Wf[2][SQ_KS];
+  auto w_load = [&](auto BUF, int T) {
+    constexpr int bf = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < SQ_KS; ++s) Wf[bf][s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(wimg + ((size_t)(T * SQ_KS + s) * 64 + lane) * 16));
+  };
+  w_load(std::integral_constant<int, 0>{}, blockIdx.y * (SQ_K / 32) + wave);
+  {
+    f32x4 xv[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+      const int gr = row0 + r < M ? row0 + r : M - 1;
+      xv[k] = *(const f32x4*)(x + (long)gr * ld_x + 4 * c4);
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+      sa_bf16x4 pk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)xv[k][q];
+      *(sa_bf16x4*)(xs + r * SQ_XROW + 8 * c4) = pk;
+    }
+  }
+  __syncthreads();
+  bf16x8 X[SQ_KS];
+#pragma unroll
+  for (int s = 0; s < SQ_KS; ++s) X[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(xs + li * SQ_XROW + 32 * s + 16 * hi));
+  // this lane's row (transposed tiles) -> sample / key
+  const int m = row0 + li, mb = m < M ? m / N : 0, mr = m - mb * N;
+  // blockIdx.y = 0 / 1 / 2 takes the Q / K / V third of the 30 output tiles (3x the blocks: the kernel is latency-bound)
+  constexpr int NTP = SQ_K / 32;  // 10 tiles per part
+  const int T0 = blockIdx.y * NTP;
+#pragma unroll
+  for (int u = 0; u < (NTP + 3) / 4; ++u) {
+    const int T = T0 + wave + 4 * u;
+    if (u + 1 < (NTP + 3) / 4 && wave + 4 * (u + 1) < NTP) {
+      if (u & 1) w_load(std::integral_constant<int, 0>{}, T + 4);
+      else w_load(std::integral_constant<int, 1>{}, T + 4);
+    }
+    if (wave + 4 * u >= NTP) continue;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (T < 2 * SQ_K / 32) {  // Q or K: D^T[feature, row]
+#pragma unroll
+      for (int s = 0; s < SQ_KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], acc, 0, 0, 0);
+      if (m < M) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f = 32 * T + 8 * g + 4 * hi;  // 4 consecutive output features
+          const bool isk = f >= SQ_K;
+          const int c = isk ? f - SQ_K : f, h = c / SA_HD, cc = c - h * SA_HD;
+          const f32x4 bv = *(const f32x4*)(bias + f);
+          const float sc = isk ? 1.f : qscale;
+          sa_bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (__bf16)((acc[4 * g + q] + bv[q]) * sc);
+          bf16_t* dst = (isk ? Ki : Qi) +
+                        ((((((long)mb * H + h) * nt + (mr >> 5)) * SA_KS + (cc >> 4)) * 64 + ((cc >> 3) & 1) * 32 + (mr & 31)) << 3) + (cc & 7);
+          *(sa_bf16x4*)dst = o;
+        }
+      }
+    } else {  // V: D[row, feature], lane = feature
+#pragma unroll
+      for (int s = 0; s < SQ_KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[s], Wf[u & 1][s], acc, 0, 0, 0);
+      const int f = 32 * T + li, c = f - 2 * SQ_K, h = c / SA_HD, d = c - h * SA_HD;
+      const float bv = bias[f];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int m0 = row0 + 8 * g + 4 * hi;  // 4 consecutive rows = 4 consecutive keys of one sample (N % 4 == 0)
+        if (m0 < M) {
+          const int b0 = m0 / N, key = m0 - b0 * N;
+          const int pp = (key & ~15) + sa_perm16(key & 15);
+          sa_bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (__bf16)(acc[4 * g + q] + bv);
+          bf16_t* dst = Vi + ((((((long)b0 * H + h) * SA_DT + (d >> 5)) * (2 * nt) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (d & 31)) << 3) + (pp & 7);
+          *(sa_bf16x4*)dst = o;
+        }
+      }
+    }
+  }
+  (void)dm;
+}
+
 __device__ __forceinline__ bf16x8 sa_ld(const bf16_t* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
 __device__ __forceinline__ bf16x8 sa_pack8(const float* v) {
   bf16x8 o;
@@ -214,6 +344,44 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
   hipLaunchKernelGGL(seq_images_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, qkv, ld, scale,
                      res_mask, Qi, Ki, Vi);
   FD_CHECK_LAUNCH();
+  const int per = (B * H + 7) / 8;
+  const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
+  hipLaunchKernelGGL(seq_attn_kernel, dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// Fused path: fd_seq_images_init once per forward, then per layer fd_seq_qkv (in_proj + images) and fd_seq_attention_run.
+int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, hipStream_t st) {
+  if (!fd_seq_attention_supported(N, H, SA_HD)) return FDIPT_EINVAL;
+  const int Np = (N + 31) / 32 * 32, nt = Np / 32;
+  bf16_t* Qi = (bf16_t*)images;
+  bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
+  const long units = 2L * B * H * nt * SA_KS * 64 + (long)B * H * SA_DT * 2 * nt * 64;
+  hipLaunchKernelGGL(seq_images_init_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, res_mask, Qi, Ki, Vi);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fd_seq_qkv_supported(int N, int H, int d_model) { return d_model == SQ_K && H * SA_HD == SQ_K && (N & 3) == 0; }
+int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const float* bias, float scale, void* images,
+               hipStream_t st) {
+  if (!fd_seq_qkv_supported(N, H, SQ_K) || (ld_x & 3)) return FDIPT_EINVAL;
+  const int Np = (N + 31) / 32 * 32;
+  bf16_t* Qi = (bf16_t*)images;
+  bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
+  hipLaunchKernelGGL(seq_qkv_kernel, dim3(cdiv(B * N, 32), 3), dim3(FD_THREADS), 0, st, B, N, Np, H, x, ld_x, (const char*)wimg, bias, scale,
+                     Qi, Ki, Vi);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, hipStream_t st) {
+  if (!fd_seq_attention_supported(N, H, SA_HD) || (out_ld & 3)) return FDIPT_EINVAL;
+  const int Np = (N + 31) / 32 * 32, nt = Np / 32;
+  const bf16_t* Qi = (const bf16_t*)images;
+  const bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  const bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
   hipLaunchKernelGGL(seq_attn_kernel, dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);

@@ -150,6 +150,13 @@ int fd_seq_attention_supported(int N, int H, int hd);
 int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, void* images,
                      float* out, int out_ld, hipStream_t st);
 
+// fused form: images initialised once per forward, in_proj writes them directly (seq_qkv), then the attention kernel
+int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, hipStream_t st);
+int fd_seq_qkv_supported(int N, int H, int d_model);
+int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const float* bias, float scale, void* images,
+               hipStream_t st);
+int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, hipStream_t st);
+
 // row-complete fused per-residue MLPs (rowblock.hip): 32 rows x all output columns per block, up to 3 Linear layers
 // (+ReLU) + residual + LayerNorm + row mask; weights as fd_chain_build_image(.., permuted = 0) fragment images
 struct RowBlockArgs {

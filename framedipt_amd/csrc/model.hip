@@ -520,6 +520,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask, F(w.quat), F(w.trans), F(w.dmask), st));
   const float* node_cur = F(w.node0);
   const size_t NN = (size_t)R * N;
+  bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
   bool bias_ready = false;  // pair bias of this block's attention already written (fragment order) by EdgeTransition
   for (int b = 0; b < d->num_blocks; ++b) {
     const BlockW& k = iv.blk[b];
@@ -595,6 +596,18 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     const float* x = F(w.tf_in);
     for (int l = 0; l < d->tfmr_layers; ++l) {
       const TfLayer& t = k.tf[l];
+      const int hd0 = dt / d->tfmr_heads;
+      // default bf16 path: in_proj writes the attention operand images directly (attention_seq.hip)
+      const bool qkv_fused = rbk && !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_QKV_FUSE") &&
+                             fd_seq_attention_supported(N, d->tfmr_heads, hd0) && fd_seq_qkv_supported(N, d->tfmr_heads, dt);
+      if (qkv_fused) {
+        if (!seq_img_ready) {
+          RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, st));
+          seq_img_ready = true;
+        }
+        RC(fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));
+        RC(fd_seq_attention_run(B, N, d->tfmr_heads, W + w.seqimg, F(w.att), dt, st));
+      } else {
       if (con(FD_CHAIN_INPROJ)) RC(chain(FD_CHAIN_INPROJ, x, dt, D + db.ch.inp[l], P + t.inp.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                         nullptr, nullptr, nullptr, F(w.qkv), 3 * dt));
       else RC(lin(R, t.inp, x, dt, nullptr, 0, nullptr, 0, F(w.qkv), 3 * dt));
@@ -610,6 +623,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         RC(fd_seq_attention(B, N, d->tfmr_heads, F(w.qkv), 3 * dt, ta.scale, res_mask, W + w.seqimg, F(w.att), dt, st));
       else if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
       else RC(fd_attention(prec, 0, ta, st));
+      }
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
       if (rbk) {
         RC(rblock(FD_RB_OUTPROJ, F(w.att), dt, D + db.ch.outp[l], P + t.outp.b, nullptr, nullptr, nullptr, nullptr, x, dt, &t.n1,
