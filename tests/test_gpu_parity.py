@@ -370,10 +370,12 @@ def test_register_attention_vs_lds_attention():
 
 
 @pytest.mark.parametrize("n,B,prec,inp", [(128, 2, "bf16", False), (450, 1, "bf16", True), (800, 1, "bf16", False),
-                                          (1000, 1, "fp32", True)])
+                                          (1000, 1, "fp32", True), (77, 3, "bf16", False), (301, 2, "bf16", False),
+                                          (45, 2, "bf16", False)])
 def test_baseline_config_shapes_run(n, B, prec, inp):
-    """BASELINE.json configs (N=128 de novo bf16, N~450 / ~800 TCR-like, N=1000 fp32 inpainting): two reverse steps
-    run through every kernel variant these sizes select; outputs finite, frames orthonormal, motif kept fixed."""
+    """BASELINE.json configs (N=128 de novo bf16, N~450 / ~800 TCR-like, N=1000 fp32 inpainting) and ragged sizes (N not
+    a multiple of 4 / 32, batches whose 32-row blocks straddle samples): two reverse steps run through every kernel
+    variant these sizes select; outputs finite, frames orthonormal, motif kept fixed."""
     from framedipt_amd import config, inference
     from framedipt_amd import rigid as R
     from framedipt_amd.diffusion import SE3Diffuser
@@ -409,6 +411,40 @@ def test_baseline_config_shapes_run(n, B, prec, inp):
         fixed = feats["fixed_mask"][0].cpu().numpy().astype(bool)
         x_T, x_1 = res["rigid_traj"][-1][0], res["rigid_traj"][1][0]
         np.testing.assert_allclose(x_1[fixed, 4:], x_T[fixed, 4:], atol=1e-4)
+
+
+@pytest.mark.parametrize("n,B", [(77, 3), (301, 2), (129, 4)])
+def test_forward_bf16_vs_fp32_path_ragged_sizes(n, B):
+    """Ragged shapes (N not a multiple of 4 / 32; 32-row blocks, 128-pair tiles and key tiles that straddle samples and
+    padded keys): the bf16 kernels against the fp32 path of the same network (itself pinned to the reference goldens)."""
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    conf = config.base_config(inpainting=False)
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": B}), d, "cuda")
+    items = [ds[i][2] for i in range(B)]
+    feats = {k: torch.cat([it[k] for it in items], 0) for k in items[0]}
+    feats["res_mask"] = feats["res_mask"].clone()
+    feats["res_mask"][0, n - 3:] = 0  # a few masked residues in the first sample
+    feats["t"] = torch.full((B,), 0.4, device="cuda")
+    if "sc_ca_t" not in feats:
+        feats["sc_ca_t"] = torch.zeros(B, n, 3, device="cuda")
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        net = ScoreNetwork(conf.model, d, inpainting=False, precision=prec).load_synthetic(11).to("cuda")
+        out = net(feats, trace=True)
+        outs[prec] = {k: v.cpu().numpy().copy() for k, v in out.items()}
+    tn32, tn16 = outs["fp32"]["trace_node"], outs["bf16"]["trace_node"]
+    for b in range(1, tn32.shape[0]):
+        rel = np.linalg.norm(tn16[b] - tn32[b]) / np.linalg.norm(tn32[b])
+        assert rel < 3e-2, (b, rel)
+    np.testing.assert_allclose(outs["bf16"]["rigids"][..., 4:], outs["fp32"]["rigids"][..., 4:], atol=5e-2)
+    # psi is the unit vector of a small 2-vector (ill-conditioned where its norm is tiny): bound the outlier fraction
+    bad = np.abs(outs["bf16"]["psi"] - outs["fp32"]["psi"]).max(-1) > 0.1
+    assert bad.mean() < 0.05, bad.mean()
+    assert kabsch_free_rmsd(outs["bf16"]["atom37"], outs["fp32"]["atom37"]) < 0.1
 
 
 def test_fused_node_chains_vs_gemm_path():
