@@ -130,7 +130,7 @@ __device__ __forceinline__ void e3_dma_chunk(const char* __restrict__ src, char*
 // two 16-feature tiles (A, B) against the same B fragments: fragments of the pair are [tile A: KS KB][tile B: KS KB] at `base`
 template <int KS>
 __device__ __forceinline__ void e3_pair(e3_f32x4& accA, e3_f32x4& accB, const char* base, int lane, const bf16x8* Bf) {
-  constexpr int DEPTH = 4;  // fragments are requested DEPTH - 1 k-steps (6 MFMAs of this wave) ahead of their use
+  constexpr int DEPTH = 3;  // fragments are requested 2 k-steps (4 MFMAs of this wave) ahead of their use (4: slower, 5+: spills)
   const char* pa = base + lane * 16;
   const char* pb = pa + KS * 1024;
   bf16x8 rA[DEPTH], rB[DEPTH];
