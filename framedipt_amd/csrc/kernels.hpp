@@ -182,6 +182,16 @@ struct RowBlockArgs {
 enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 
+// post-attention half of one encoder layer in one launch (rowblock.hip): x_a = LN1(x + Wo att + bo); out = LN2(x_a + W2 relu(W1 x_a + b1) + b2)
+struct TfmrTailArgs {
+  int M, ld;                      // rows; common row stride of att / x / out (d_model = 320)
+  const float *att, *x;           // attention output rows, layer input rows (residual)
+  const void *wo, *w1, *w2;       // fragment images, natural k order (fd_chain_build_image(.., 0))
+  const float *bo, *g1, *be1, *b1, *b2, *g2, *be2;
+  float* out;                     // must not alias x
+};
+int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st);
+
 struct ChainArgs {
   int M;
   const float* in;          // [M, ld_in] fp32 input rows

@@ -625,7 +625,15 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       else RC(fd_attention(prec, 0, ta, st));
       }
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
-      if (rbk) {
+      if (rbk && !getenv("FDIPT_NO_TFMR_TAIL")) {
+        TfmrTailArgs tt;
+        tt.M = R; tt.ld = dt; tt.att = F(w.att); tt.x = x; tt.wo = D + db.ch.outp[l]; tt.w1 = D + db.ch.l1[l]; tt.w2 = D + db.ch.l2n[l];
+        tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
+        tt.be2 = P + t.n2.b; tt.out = x == F(w.x_b) ? F(w.x_a) : F(w.x_b);
+        RC(fd_tfmr_tail(tt, st));
+        x = tt.out;
+        continue;
+      } else if (rbk) {
         RC(rblock(FD_RB_OUTPROJ, F(w.att), dt, D + db.ch.outp[l], P + t.outp.b, nullptr, nullptr, nullptr, nullptr, x, dt, &t.n1,
                   nullptr, F(w.x_a), dt));
         RC(rblock(FD_RB_FFN, F(w.x_a), dt, D + db.ch.l1[l], P + t.l1.b, D + db.ch.l2n[l], P + t.l2.b, nullptr, nullptr, F(w.x_a),

@@ -305,6 +305,227 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   }
 }
 
+// ------------------------------------------------------------------ whole post-attention half of an encoder layer
+// x_a = LayerNorm1(x + W_o att + b_o);  x_b = LayerNorm2(x_a + W2 relu(W1 x_a + b1) + b2)  in ONE launch (d_model 320): x_a
+// never leaves the block — its bf16 rows go to LDS as the feed-forward input, its fp32 values stay in the accumulator
+// registers of the wave that owns the tile (the same tile ownership as the feed-forward output) and are the residual.
+#define TL_D 320
+#define TL_KS (TL_D / 16)
+#define TL_NT (TL_D / 32)
+#define TL_XROW (TL_D * 2 + 16)
+#define TL_SMEM (2 * 32 * TL_XROW + 4 * 32 * RB_SROW + 7 * TL_D * 4 + 2 * 4 * 32 * 4 + 16)
+__global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                                            // att rows, then hidden rows   [32][TL_XROW]
+  char* hs = xs + 32 * TL_XROW;                               // x_a rows                     [32][TL_XROW]
+  char* st_all = hs + 32 * TL_XROW;                           // per-wave exchange tiles      [4][32][RB_SROW]
+  float* cst = (float*)(st_all + 4 * 32 * RB_SROW);           // b_o | g1 | be1 | b1 | b2 | g2 | be2
+  float (*red)[4][32] = (float (*)[4][32])(cst + 7 * TL_D);   // [2][4][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+  const int row0 = blockIdx.x * 32;
+  char* stg = st_all + wave * 32 * RB_SROW;
+  bf16x8 Wf[2][TL_KS];
+  auto w_load = [&](auto BUF, const char* img, int T) {
+    constexpr int bf = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < TL_KS; ++s) Wf[bf][s] = rb_ld(img + ((size_t)(T * TL_KS + s) * 64 + lane) * 16);
+  };
+  w_load(std::integral_constant<int, 0>{}, (const char*)a.wo, wave);
+  {
+    f32x4 xv[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+      const int gr = row0 + r < a.M ? row0 + r : a.M - 1;
+      xv[k] = *(const f32x4*)(a.att + (long)gr * a.ld + 4 * c4);
+    }
+    for (int v = tid; v < 7 * TL_D; v += FD_THREADS) {
+      const int which = v / TL_D, c = v % TL_D;
+      const float* src = which == 0 ? a.bo : which == 1 ? a.g1 : which == 2 ? a.be1 : which == 3 ? a.b1 : which == 4 ? a.b2 : which == 5 ? a.g2 : a.be2;
+      cst[v] = src[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+      rb_bf16x4 pk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)xv[k][q];
+      *(rb_bf16x4*)(xs + r * TL_XROW + 8 * c4) = pk;
+    }
+  }
+  f32x4 rv[3][4];  // residual x: row segments of this wave's tiles
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int T = wave + 4 * u < TL_NT ? wave + 4 * u : wave;
+      const int r = 8 * it + (lane >> 3), gr = row0 + r < a.M ? row0 + r : a.M - 1;
+      rv[u][it] = *(const f32x4*)(a.x + (long)gr * a.ld + 32 * T + 4 * (lane & 7));
+    }
+  __syncthreads();
+  bf16x8 X[TL_KS];
+  f32x16 acc[3], xa[3];
+  auto layer = [&](const char* img) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int T = wave + 4 * u;
+      if (u + 1 < 3 && T + 4 < TL_NT) {
+        if (u & 1) w_load(std::integral_constant<int, 0>{}, img, T + 4);
+        else w_load(std::integral_constant<int, 1>{}, img, T + 4);
+      }
+      if (T < TL_NT) {
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < TL_KS; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
+        acc[u] = c;
+      }
+    }
+  };
+  // LayerNorm of the rows held as acc[] (lane = row, this wave's tiles) -> normalised values back in acc[]
+  auto layernorm = [&](const float* gam, const float* bet) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (wave + 4 * u < TL_NT)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1 += acc[u][r];
+    s1 += __shfl_xor(s1, 32, 64);
+    __syncthreads();  // red[] may still be read by a slower wave from the previous LayerNorm
+    if (hi == 0) red[0][wave][li] = s1;
+    __syncthreads();
+    const float mu = (red[0][0][li] + red[0][1][li] + red[0][2][li] + red[0][3][li]) * (1.0f / TL_D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (wave + 4 * u < TL_NT)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dd = acc[u][r] - mu;
+          s2 += dd * dd;
+        }
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hi == 0) red[1][wave][li] = s2;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[1][0][li] + red[1][1][li] + red[1][2][li] + red[1][3][li]) * (1.0f / TL_D) + 1e-5f);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int T = wave + 4 * u;
+      if (T < TL_NT)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f0 = 32 * T + 8 * g + 4 * hi;
+          const f32x4 gm = *(const f32x4*)(gam + f0), bt = *(const f32x4*)(bet + f0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[u][4 * g + q] = (acc[u][4 * g + q] - mu) * rstd * gm[q] + bt[q];
+        }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(xs + li * TL_XROW + 32 * s + 16 * hi);
+  // ---- stage 1: out_proj + x, LayerNorm1
+  layer((const char*)a.wo);
+  w_load(std::integral_constant<int, 0>{}, (const char*)a.w1, wave);  // first feed-forward tile: in flight across the barriers
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int T = wave + 4 * u;
+    if (T < TL_NT) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) *(f32x4*)(stg + (8 * it + (lane >> 3)) * RB_SROW + 16 * (lane & 7)) = rv[u][it];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const f32x4*)(cst + 32 * T + 8 * g + 4 * hi);
+        const f32x4 rr = *(const f32x4*)(stg + li * RB_SROW + (8 * g + 4 * hi) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[u][4 * g + q] += bv[q] + rr[q];
+      }
+    }
+  }
+  layernorm(cst + TL_D, cst + 2 * TL_D);
+  // x_a: fp32 in registers (residual of stage 2), bf16 rows -> LDS (input of stage 2)
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int T = wave + 4 * u;
+    xa[u] = acc[u];
+    if (T < TL_NT)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * T + 8 * g + 4 * hi;
+        rb_bf16x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = (__bf16)acc[u][4 * g + q];
+        *(rb_bf16x4*)(hs + li * TL_XROW + 2 * f0) = pk;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(hs + li * TL_XROW + 32 * s + 16 * hi);
+  // ---- stage 2: feed-forward
+  layer((const char*)a.w1);
+  w_load(std::integral_constant<int, 0>{}, (const char*)a.w2, wave);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int T = wave + 4 * u;
+    if (T < TL_NT)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * T + 8 * g + 4 * hi;
+        const f32x4 bv = *(const f32x4*)(cst + 3 * TL_D + f0);
+        rb_bf16x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = (__bf16)fmaxf(acc[u][4 * g + q] + bv[q], 0.f);
+        *(rb_bf16x4*)(xs + li * TL_XROW + 2 * f0) = pk;   // the att rows are dead: every wave read them before LayerNorm1's barriers
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(xs + li * TL_XROW + 32 * s + 16 * hi);
+  layer((const char*)a.w2);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int T = wave + 4 * u;
+    if (T < TL_NT)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const f32x4*)(cst + 4 * TL_D + 32 * T + 8 * g + 4 * hi);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[u][4 * g + q] += bv[q] + xa[u][4 * g + q];
+      }
+  }
+  layernorm(cst + 5 * TL_D, cst + 6 * TL_D);
+  // ---- x_b rows out through the wave's tile (128 B row segments)
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int T = wave + 4 * u;
+    if (T < TL_NT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]};
+        *(f32x4*)(stg + li * RB_SROW + (8 * g + 4 * hi) * 4) = o;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 8 * it + (lane >> 3);
+        const f32x4 o = *(const f32x4*)(stg + r * RB_SROW + 16 * (lane & 7));
+        if (row0 + r < a.M) *(f32x4*)(a.out + (long)(row0 + r) * a.ld + 32 * T + 4 * (lane & 7)) = o;
+      }
+    }
+  }
+}
+
+int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
+  if (a.M <= 0 || (a.ld & 3) || a.x == a.out) return FDIPT_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)tfmr_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tfmr_tail_kernel, dim3(cdiv(a.M, 32)), dim3(FD_THREADS), TL_SMEM, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
 template <int K0, int N1, int N2, int NOUT, int FLAGS>
 static int rb_launch(const RowBlockArgs& a, hipStream_t st) {
   using S = RBShape<K0, N1, N2, NOUT, FLAGS>;
