@@ -768,7 +768,7 @@ size_t fd_ee2_image_bytes() { return 2 * EE2_IMG; }
 // 512-thread persistent blocks: 8 independent waves (two per SIMD) share the 64 KB weight images; every wave owns an
 // 8 KB LDS tile that transposes between "whole 512 B table rows per 32 lanes" (the global side) and MFMA fragments.
 #define EE2_THREADS 512
-#define EE2_LDS (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4)
+#define EE2_LDS (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + 8192)  // ... + linear_b image of the first block
 __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img,
                                                                      int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -776,6 +776,8 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
   const int hi = lane >> 5, li = lane & 31;
   char* stage = smem + 2 * EE2_IMG + wave * 8192;
   float* vec = (float*)(smem + 2 * EE2_IMG + 8 * 8192);  // [b2 | b3 | gamma | beta] x 128
+  char* wbl = (char*)(vec + 4 * ET2_CZ);                 // 8 KB fragment image of linear_b (optional)
+  if (a.wb_img) et2_dma16((const char*)a.wb_img + tid * 16, wbl + (tid & ~63) * 16);
   for (int u = 0; u < 2 * EE2_IMG / 16 / EE2_THREADS; ++u)
     et2_dma16(img + (size_t)(u * EE2_THREADS + tid) * 16, smem + (size_t)(u * EE2_THREADS + (tid & ~63)) * 16);
   if (tid < 4 * ET2_CZ) {
@@ -850,8 +852,8 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
       mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
     }
     ln_epilogue_staged(Y, vec + ET2_CZ + 4 * hi, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, a.res_mask[bi] * a.res_mask[bj], li, hi, lane,
-                       stage, (bf16_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid, nullptr, nullptr,
-                       nullptr, 0, 0, 0, 0, 0);
+                       stage, (bf16_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid,
+                       a.wb_img ? wbl : nullptr, a.bb, a.bias_out, a.H, bb, (int)(bi - bb * N), j, (N + 31) >> 5);
   }
 }
 

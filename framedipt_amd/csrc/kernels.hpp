@@ -30,6 +30,11 @@ struct EdgeEmbedArgs {
   const float* res_mask;
   void* z_out;
   float* trace;
+  // optional (bf16 kernel): pair bias of the FIRST block's attention from the LayerNorm epilogue, as ET2Args
+  const void* wb_img;
+  const float* bb;
+  float* bias_out;
+  int H;
 };
 
 struct AttnArgs {

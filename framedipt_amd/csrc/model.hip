@@ -480,6 +480,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     return fd_chain(kind, c, st);
   };
 
+  bool ee_bias_done = false;
   // ---- Embedder (score_network.py:129-197)
   RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
                     L.kn_pad, F(w.pte), L.d1_pad, st));
@@ -509,6 +510,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     ea.w2 = WM(iv.ee2); ea.w3 = WM(iv.ee4); ea.b2 = P + iv.ee2.b; ea.b3 = P + iv.ee4.b;
     ea.gamma = P + iv.eeln.g; ea.beta = P + iv.eeln.b; ea.res_mask = res_mask; ea.z_out = W + w.z;
     ea.trace = a->trace_edge;
+    // the first block's pair bias linear_b(z)/sqrt(3) from the embedder's LayerNorm epilogue (saves a pass over z)
+    const bool ee_bias = use_et2(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 512 &&
+                         !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && !getenv("FDIPT_NO_EE_BIAS");
+    ea.wb_img = ee_bias ? D + L.blk[0].wb_img : nullptr; ea.bb = (const float*)(D + L.blk[0].bb); ea.bias_out = F(w.bias); ea.H = H;
+    ee_bias_done = ee_bias;
     if (use_et2(d)) RC(fd_edge_embed2(ea, D + L.ee2, st));
     else RC(fd_edge_embed(prec, cz, ea, st));
   }
@@ -521,7 +527,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   const float* node_cur = F(w.node0);
   const size_t NN = (size_t)R * N;
   bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
-  bool bias_ready = false;  // pair bias of this block's attention already written (fragment order) by EdgeTransition
+  bool bias_ready = ee_bias_done;  // pair bias of this block's attention already written (tiled order) by the embedder / EdgeTransition
   for (int b = 0; b < d->num_blocks; ++b) {
     const BlockW& k = iv.blk[b];
     const DBlock& db = L.blk[b];
