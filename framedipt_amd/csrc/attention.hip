@@ -9,6 +9,7 @@
 //   points_kernel             : "split-thirds then stack" + Rigid.apply of the projected points (ipa_pytorch.py:213-239)
 //
 // One block = 32 query rows of one (batch, head); logits of the 32 rows stay in LDS as fp32 [32][N].
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.hpp"
@@ -410,6 +411,126 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
   FD_STAMP(5);
 }
 
+// ------------------------------------------------------------------ o_pair on the matrix cores (bf16 z, c_z 128, 8 heads)
+// az[h, c] = sum_j a[h,i,j] z[i,j,c] is a [8 x N] x [N x 128] product per (b, i) whose contraction index j is the ROW index
+// of z in memory, while an MFMA B fragment wants 8 consecutive k per lane.  The z rows are therefore fetched as coalesced
+// 16 B pieces, 64 keys at a time, and written TRANSPOSED into an LDS tile Zt[channel][key] (2-byte stores), from which
+// B fragments are plain ds_read_b128; the attention weights are the A operand (heads = rows 0..7 of a 32-row tile, bf16,
+// from LDS).  Wave w owns channels 32w..32w+31.  The tail (sum_j a, down_z projection) is the VALU code of opair_kernel.
+#define OM_JC 64                    // keys per chunk
+#define OM_ZROW (OM_JC * 2 + 16)    // bytes per Zt row (16 lanes of a b128 read hit 16 distinct slots)
+#define OM_NK 20                    // 16-key row groups per thread: N <= 320
+__global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, int Np) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CZ = 128, H = 8, CD = 32;
+  const int N = a.N, nch = Np / OM_JC;
+  const int prow = Np * 2 + 16;                             // bytes per attention-weight row (bf16)
+  char* zt = smem;                                          // [2][CZ][OM_ZROW]
+  char* pb = zt + 2 * CZ * OM_ZROW;                         // [8][prow] bf16 attention weights of this (b, i)
+  float* red = (float*)(pb + 8 * prow);                     // [8][CZ]
+  float* psum = red + 8 * CZ;                               // [8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+  const int i = blockIdx.x, b = blockIdx.y;
+  const long rb = (long)b * N;
+  const bf16_t* zrow = (const bf16_t*)a.z + (rb + i) * N * CZ;
+  // this thread's pieces of the z rows: key PAIRS (2 jp, 2 jp + 1), jp = tid / 16 + 16 m, channels 8 (tid % 16) .. +7 — ALL
+  // requested up front (one memory round trip per block); zr[2 m + w] = key 2 jp + w
+  const int cg = tid & 15, jl0 = tid >> 4;
+  u16x8 zr[OM_NK];
+#pragma unroll
+  for (int k = 0; k < OM_NK; ++k) {
+    const int j = 2 * (jl0 + 16 * (k >> 1)) + (k & 1);
+    zr[k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (j < N) zr[k] = *(const u16x8*)(zrow + (long)j * CZ + 8 * cg);
+  }
+  // down_z as B fragments (wave 0 only): requested now, used at the very end
+  bf16x8 wdf[8];
+  if (wave == 0)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wdf[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)((const char*)a.wdz_img + (s * 64 + lane) * 16));
+  // attention weights -> bf16 rows (zero for padded keys) and sum_j a[h,i,j] (= 1 up to rounding and masking) in one pass:
+  // 32 threads per head
+  {
+    const int hh = tid >> 5, l5 = tid & 31;
+    const float* pr = a.probs + (((long)b * H + hh) * N + i) * N;
+    float sacc = 0.f;
+    for (int j = l5; j < Np; j += 32) {
+      const float pv = j < N ? pr[j] : 0.f;
+      sacc += pv;
+      *(bf16_t*)(pb + hh * prow + 2 * j) = f2bf(pv);
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
+    if (l5 == 0) psum[hh] = sacc;
+  }
+  // transposed write of chunk ch into slot, two keys per 32-bit store: channel 8 cg + e lives in Zt row 16 e + cg (with
+  // 16 B-aligned rows a stride of 8 rows would put the 16 lanes of a store on one bank; consecutive rows spread them)
+  auto scatter = [&](auto CH, int slot) {
+    constexpr int ch = decltype(CH)::value;
+    char* dst = zt + slot * CZ * OM_ZROW;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        *(unsigned*)(dst + (16 * e + cg) * OM_ZROW + 4 * (jl0 + 16 * m)) =
+            (unsigned)zr[4 * ch + 2 * m][e] | ((unsigned)zr[4 * ch + 2 * m + 1][e] << 16);
+  };
+  scatter(std::integral_constant<int, 0>{}, 0);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const char* arow = pb + (li < 8 ? li : 0) * prow + 16 * hi;  // A fragment source: row = head (lanes >= 8: zero)
+  auto chunk = [&](auto CH) {
+    constexpr int ch = decltype(CH)::value;
+    if (ch < nch) {
+      const char* zs = zt + (ch & 1) * CZ * OM_ZROW + (32 * wave + li) * OM_ZROW + 16 * hi;
+#pragma unroll
+      for (int s = 0; s < OM_JC / 16; ++s) {
+        u16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (li < 8) af = *(const u16x8*)(arow + 2 * (ch * OM_JC + 16 * s));
+        const u16x8 bfr = *(const u16x8*)(zs + 32 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc, 0, 0, 0);
+      }
+      if (ch + 1 < nch) scatter(std::integral_constant<int, (ch + 1 < OM_NK / 4 ? ch + 1 : 0)>{}, (ch + 1) & 1);
+      __syncthreads();
+    }
+  };
+  chunk(std::integral_constant<int, 0>{});
+  chunk(std::integral_constant<int, 1>{});
+  chunk(std::integral_constant<int, 2>{});
+  chunk(std::integral_constant<int, 3>{});
+  chunk(std::integral_constant<int, 4>{});
+  // D[h, Zt row]: lane (row 32 wave + li, hi) holds heads 4 hi + r in registers r < 4; row 16 e + cg = channel 8 cg + e
+  {
+    const int zrow_i = 32 * wave + li, ch_i = 8 * (zrow_i & 15) + (zrow_i >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(4 * hi + r) * CZ + ch_i] = acc[r];
+  }
+  __syncthreads();
+  // down_z (ipa_pytorch.py:317-322) on the matrix core: D[h, d] = sum_c az[h, c] Wdz[d, c], 8 k-steps, wave 0
+  if (wave == 0) {
+    f32x16 o2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o2[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (li < 8) {
+        const f32x4 x0 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi), x1 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi + 4);
+        v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3]; v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+      }
+      bf16x8 af;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) af[e] = (__bf16)v[e];
+      o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wdf[s], o2, 0, 0, 0);
+    }
+    const float bd = a.bdz[li];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.out[(rb + i) * a.out_ld + a.off + (4 * hi + r) * CD + li] = o2[r] + bd * psum[4 * hi + r];
+  }
+}
+
 template <class ZT>
 static int launch_opair(const OPairArgs& a, hipStream_t st) {
   const size_t smem = (size_t)8 * a.N * 4 + (size_t)(4 * 8 * a.CZ + 8) * 4 + (size_t)a.CZ * a.CD * 4;
@@ -424,6 +545,13 @@ static int launch_opair(const OPairArgs& a, hipStream_t st) {
 
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
   if (a.H > 8) return FDIPT_ESIZE;
+  if (precision != FDIPT_PREC_F32 && a.CZ == 128 && a.H == 8 && a.CD == 32 && a.wdz_img && a.N <= 16 * OM_NK && !getenv("FDIPT_OPAIR_VALU")) {
+    const int Np = (a.N + OM_JC - 1) / OM_JC * OM_JC;
+    const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4;
+    hipLaunchKernelGGL(opair_mfma_kernel, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+    FD_CHECK_LAUNCH();
+    return FDIPT_OK;
+  }
   return precision == FDIPT_PREC_F32 ? launch_opair<float>(a, st) : launch_opair<bf16_t>(a, st);
 }
 

@@ -64,6 +64,7 @@ struct OPairArgs {
   const void* z;         // [B,N,N,CZ] ZT
   const float* probs;    // [B,H,N,N]
   const float* wdz;      // [CZ,CD] f32 (down_z weight, transposed)
+  const void* wdz_img;   // optional: down_z weight [CD, CZ] as a bf16 fragment image (fd_chain_build_image, natural k) for the MFMA kernel
   const float* bdz;      // [CD]
   float* out;            // row (b*N+i): out + r*out_ld + off + h*CD + d
   long out_ld;

@@ -96,7 +96,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, wb_img3, et2, et3, wdz_t; DChain ch; };
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, wb_img3, et2, et3, wdz_t, wdz_img; DChain ch; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -143,6 +143,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb_img = o; o = al256(o + 8192);  // linear_b as a 32 x 128 MFMA fragment image (edge_transition2 epilogue)
     L.blk[b].wb_img3 = o; o = al256(o + 4096);  // ... as 16 x 128 (edge_transition3 epilogue)
+    L.blk[b].wdz_img = o; o = al256(o + 8192);  // down_z [c_z/4, c_z] as a bf16 fragment image (MFMA o_pair kernel)
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et2 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
@@ -295,6 +296,7 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
         return rc;
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
+    if (cz == 128 && (rc = fd_chain_build_image(P + k.dz.w, cz / 4, cz, cz, 0, D + db.wdz_img, st))) return rc;
     if (use_et2(d) && b < d->num_blocks - 1)
       if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st)) ||
           (rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)))
@@ -581,7 +583,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     {
       OPairArgs oa;
       oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs);
-      oa.wdz = (const float*)(D + db.wdz_t); oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
+      oa.wdz = (const float*)(D + db.wdz_t); oa.wdz_img = (bf && cz == 128) ? D + db.wdz_img : nullptr; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
       RC(fd_opair(prec, oa, st));
     }
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)

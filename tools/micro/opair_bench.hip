@@ -7,7 +7,7 @@ int main(int argc, char** argv) {
   auto dz = [](size_t bytes) { void* p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
   OPairArgs a;
   a.B = B; a.N = N; a.H = H; a.CZ = 128; a.CD = 32; a.z = dz((size_t)B * N * N * 128 * 2); a.probs = (const float*)dz((size_t)B * H * N * N * 4);
-  a.wdz = (const float*)dz(128 * 32 * 4); a.bdz = (const float*)dz(32 * 4); a.out_ld = 2688; a.out = (float*)dz((size_t)B * N * a.out_ld * 4);
+  a.wdz = (const float*)dz(128 * 32 * 4); a.wdz_img = dz(8192); a.bdz = (const float*)dz(32 * 4); a.out_ld = 2688; a.out = (float*)dz((size_t)B * N * a.out_ld * 4);
   a.off = 2048 + 384;
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
   for (int i = 0; i < 3; ++i) fd_opair(FDIPT_PREC_BF16, a, 0);
