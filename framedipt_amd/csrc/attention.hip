@@ -557,6 +557,8 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------ projected points -> global frame
 
+__device__ __forceinline__ int pt_perm16(int pos) { return 4 * (pos >> 3) + (pos & 3) + 8 * ((pos & 7) >> 2); }
+
 __global__ void points_kernel(PointsArgs a) {
   const long r = blockIdx.x;  // residue row b*N+i
   const int tid = threadIdx.x;
@@ -583,9 +585,28 @@ __global__ void points_kernel(PointsArgs a) {
       const int hh = pp / Pkv, e = pp % Pkv;
       dst = e < a.Pq ? a.kp + ((r * a.H + hh) * a.Pq + e) * 3 : a.vp + ((r * a.H + hh) * a.Pv + (e - a.Pq)) * 3;
     }
-    dst[0] = R[0] * px + R[1] * py + R[2] * pz + tx;
-    dst[1] = R[3] * px + R[4] * py + R[5] * pz + ty;
-    dst[2] = R[6] * px + R[7] * py + R[8] * pz + tz;
+    const float gx = R[0] * px + R[1] * py + R[2] * pz + tx;
+    const float gy = R[3] * px + R[4] * py + R[5] * pz + ty;
+    const float gz = R[6] * px + R[7] * py + R[8] * pz + tz;
+    dst[0] = gx; dst[1] = gy; dst[2] = gz;
+    if (a.vpt && p >= HPq) {
+      const int pp2 = p - HPq, hh = pp2 / Pkv, e = pp2 % Pkv;
+      if (e >= a.Pq) {  // a value point: coordinates 3 (e - Pq) + {0,1,2} of head hh, key = residue index in its sample
+        const long bidx = r / a.N;
+        const int key = (int)(r - bidx * a.N), pos = (key & ~15) + pt_perm16(key & 15), ks = a.Np >> 4;
+        const float g3[3] = {gx, gy, gz};
+        for (int c = 0; c < 3; ++c) {
+          const int row = 3 * (e - a.Pq) + c;
+          const unsigned short vh = f2bf(g3[c]);
+          const unsigned short vl = f2bf(g3[c] - bf2f(vh));
+          const long base = (bidx * a.H + hh) * 3;
+          // rows < 36 (tile 0 and the first 4 rows of tile 1): high parts; rows 36..71: low parts
+          const int rh = row, rl = 36 + row;
+          a.vpt[((((base + (rh >> 5)) * ks + (pos >> 4)) * 64 + ((pos >> 3) & 1) * 32 + (rh & 31)) << 3) + (pos & 7)] = vh;
+          a.vpt[((((base + (rl >> 5)) * ks + (pos >> 4)) * 64 + ((pos >> 3) & 1) * 32 + (rl & 31)) << 3) + (pos & 7)] = vl;
+        }
+      }
+    }
   }
 }
 

@@ -11,8 +11,11 @@
 //   softmax          registers + lane^32 shuffle, cross-wave max / sum through 2 x 128 floats of LDS
 //   o = a v          P fragments are exchanged through LDS once; wave w then owns d tiles {2w, 2w+1} over ALL keys,
 //                    A = Vt rows (V transposed, key-permuted) straight from HBM/L2 — no LDS staging, no reduction
-//   o_pt             fp32 VALU over the wave's own keys against broadcast LDS reads of v_pts, 4-way LDS reduction
-// LDS holds only v_pts (N x 36 fp32), the P fragments (N x 64 bf16) and the small reduction buffers.
+//   o_pt             one more 32-row tile of the same P.V product: v_pts as bf16 high + low parts (points_kernel writes the
+//                    fragment image), fp32 accumulate; rotated into the local frame from a 32 x 96 LDS tile
+// LDS holds only the P fragments (N x 64 bf16), the o_pt tile and the small reduction buffers.
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -30,11 +33,10 @@ __device__ __forceinline__ bf16x8 a3_ld(const bf16_t* p) { return __builtin_bit_
 __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a.N, H = a.H, nt = (N + 31) / 32, Np = nt * 32;
-  float* vps = (float*)smem;                                 // [Np][36]
-  float* mxs = vps + Np * 36;                                // [4][32]
+  float* mxs = (float*)smem;                                 // [4][32]
   float* sms = mxs + 128;                                    // [4][32]
-  float* opr = sms + 128;                                    // [4][32][36]
-  u16x8* Pfs = (u16x8*)(opr + 4 * 32 * 36);                  // [2*nt][64]
+  float* opr = sms + 128;                                    // [32 queries][96]: o_pt sums, high parts then low parts
+  u16x8* Pfs = (u16x8*)(opr + 32 * 96);                      // [2*nt][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   // XCD-aware block -> (sample, head, query tile): consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each),
@@ -56,25 +58,6 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   const int i = valid ? i_raw : N - 1;
 
   FD_STAMP(0);
-  // ---- v_pts of this head -> LDS (first read after the first barrier)
-  {
-    constexpr int NVV = (A3_NTW * 4 * 32 * 9 + FD_THREADS - 1) / FD_THREADS;  // 18
-    for (int u0 = 0; u0 < NVV; u0 += 6) {
-      f32x4 tv[6];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int v = tid + (u0 + u) * FD_THREADS, j = v / 9, c = (v % 9) * 4;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (j < N) x = *(const f32x4*)(a.vp + ((rb + j) * H + h) * 36 + c);
-        tv[u] = x;
-      }
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int v = tid + (u0 + u) * FD_THREADS;
-        if (v < Np * 9) *(f32x4*)(vps + v * 4) = tv[u];
-      }
-    }
-  }
   // ---- query-side registers
   bf16x8 Qf[16];
   {
@@ -198,10 +181,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   __syncthreads();
   const float inv = 1.0f / (sms[li] + sms[32 + li] + sms[64 + li] + sms[96 + li]);
   FD_STAMP(3);
-  // ---- phase 3: normalise; attention weights -> HBM (for o_pair), P fragments -> LDS, partial o_pt
-  float op[36];
-#pragma unroll
-  for (int c = 0; c < 36; ++c) op[c] = 0.f;
+  // ---- phase 3: normalise; attention weights -> HBM (for o_pair), P fragments -> LDS
   float* prow = a.probs + (bh * N + i) * N;
 #pragma unroll
   for (int u = 0; u < A3_NTW; ++u) {
@@ -226,76 +206,34 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
       }
       Pfs[(2 * t) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(v));
       Pfs[(2 * t + 1) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(v + 8));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float* vj = vps + j * 36;
-        const float p = v[r];
-#pragma unroll
-        for (int c4 = 0; c4 < 9; ++c4) {
-          const f32x4 x = *(const f32x4*)(vj + 4 * c4);
-          op[4 * c4] += p * x[0]; op[4 * c4 + 1] += p * x[1]; op[4 * c4 + 2] += p * x[2]; op[4 * c4 + 3] += p * x[3];
-        }
-      }
     }
   }
   FD_STAMP(4);
-#pragma unroll
-  for (int c = 0; c < 36; ++c) op[c] += __shfl_xor(op[c], 32, 64);
-  if (hi == 0) {
-#pragma unroll
-    for (int c4 = 0; c4 < 9; ++c4) {
-      f32x4 o = {op[4 * c4], op[4 * c4 + 1], op[4 * c4 + 2], op[4 * c4 + 3]};
-      *(f32x4*)(opr + (wave * 32 + li) * 36 + 4 * c4) = o;
-    }
-  }
   __syncthreads();
   FD_STAMP(5);
-  // ---- phase 4a: o_pt = R_i^T (sum - t_i) and its norm (ipa_pytorch.py:296-308), 32 queries x 12 points
-  for (int it = tid; it < 32 * 12; it += FD_THREADS) {
-    const int q = it / 12, pt = it % 12, iq = qt * 32 + q;
-    if (iq < N) {
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float* o = opr + (w * 32 + q) * 36 + pt * 3;
-        sx += o[0]; sy += o[1]; sz += o[2];
-      }
-      const float* R = a.rot + (rb + iq) * 9;
-      const float* T = a.trans + (rb + iq) * 3;
-      const float x = sx - T[0], y = sy - T[1], z = sz - T[2];
-      const float ox = R[0] * x + R[3] * y + R[6] * z;
-      const float oy = R[1] * x + R[4] * y + R[7] * z;
-      const float oz = R[2] * x + R[5] * y + R[8] * z;
-      const int HP = H * 12;
-      float* o = a.out + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
-      o[0] = ox; o[HP] = oy; o[2 * HP] = oz;
-      o[3 * HP] = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
-    }
-  }
   FD_STAMP(6);
-  // ---- phase 4b: O^T[d, query] for d tiles {2w, 2w+1} over all keys: A = Vt rows from HBM/L2, B = P from LDS
+  // ---- phase 4: O^T[d, query] for d tiles {2w, 2w+1} over all keys (A = Vt fragments from HBM/L2, B = P from LDS); waves
+  // 0..2 also take one 32-row tile of the v_pts image (rows = point coordinates as bf16 high + low parts): o_pt on the
+  // matrix core, sum_j a v_pts_j to ~2^-17 relative in v_pts (the weights are the same bf16 P as for o)
   {
     constexpr int KSM = 2 * 4 * A3_NTW;  // k-steps of 16 keys at the maximum N
     const int ks = 2 * nt;
     bf16x8 Va[2][KSM];
-#pragma unroll
-    for (int dd = 0; dd < 2; ++dd) {
-      const bf16_t* vr = a.Vt + (((bh * (A3_C / 32) + 2 * wave + dd) * ks) * 64 + lane) * 8;  // fragment order
+    auto v_load = [&](auto BUF, const bf16_t* base) {
+      constexpr int bf = decltype(BUF)::value;
 #pragma unroll
       for (int s = 0; s < KSM; ++s)
-        if (s < ks) Va[dd][s] = a3_ld(vr + s * 512);
-    }
-#pragma unroll
-    for (int dd = 0; dd < 2; ++dd) {
-      const int dt = 2 * wave + dd;
-      f32x16 acc;
+        if (s < ks) Va[bf][s] = a3_ld(base + ((size_t)s * 64 + lane) * 8);
+    };
+    auto v_mma = [&](auto BUF, f32x16& acc) {
+      constexpr int bf = decltype(BUF)::value;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < KSM; ++s)
-        if (s < ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Va[dd][s], __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc, 0, 0, 0);
+        if (s < ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Va[bf][s], __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc, 0, 0, 0);
+    };
+    auto o_store = [&](const f32x16& acc, int dt) {
       if (valid) {
         float* orow = a.out + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
 #pragma unroll
@@ -304,18 +242,54 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
           *(f32x4*)(orow + 8 * g) = o;
         }
       }
+    };
+    v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave) * ks) * 512);
+    v_load(std::integral_constant<int, 1>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
+    f32x16 acc;
+    v_mma(std::integral_constant<int, 0>{}, acc);
+    if (wave < 3) v_load(std::integral_constant<int, 0>{}, a.vpt + ((bh * 3 + wave) * ks) * 512);  // points tile, under tile 1
+    o_store(acc, 2 * wave);
+    v_mma(std::integral_constant<int, 1>{}, acc);
+    o_store(acc, 2 * wave + 1);
+    if (wave < 3) {
+      v_mma(std::integral_constant<int, 0>{}, acc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // D rows 32 wave + 8g + 4hi + q of query li
+        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *(f32x4*)(opr + li * 96 + 32 * wave + 8 * g + 4 * hi) = o;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- o_pt = R_i^T (sum - t_i) and its norm (ipa_pytorch.py:296-308), 32 queries x 12 points
+  for (int it = tid; it < 32 * 12; it += FD_THREADS) {
+    const int q = it / 12, pt = it % 12, iq = qt * 32 + q;
+    if (iq < N) {
+      const float* o = opr + q * 96 + pt * 3;
+      const float sx = o[0] + o[36], sy = o[1] + o[37], sz = o[2] + o[38];
+      const float* R = a.rot + (rb + iq) * 9;
+      const float* T = a.trans + (rb + iq) * 3;
+      const float x = sx - T[0], y = sy - T[1], z = sz - T[2];
+      const float ox = R[0] * x + R[3] * y + R[6] * z;
+      const float oy = R[1] * x + R[4] * y + R[7] * z;
+      const float oz = R[2] * x + R[5] * y + R[8] * z;
+      const int HP = H * 12;
+      float* oo = a.out + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
+      oo[0] = ox; oo[HP] = oy; oo[2 * HP] = oz;
+      oo[3 * HP] = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
     }
   }
   FD_STAMP(7);
 }
 
 int fd_attention3_supported(const Attn3Args& a) {
-  return a.N >= 1 && a.N <= A3_NTW * 4 * 32 && a.H <= 8 && a.Np == ((a.N + 31) / 32) * 32;
+  return a.N >= 1 && a.N <= A3_NTW * 4 * 32 && a.H <= 8 && a.Np == ((a.N + 31) / 32) * 32 && a.vpt != nullptr;
 }
 
 int fd_attention3(const Attn3Args& a, hipStream_t st) {
   const int nt = (a.N + 31) / 32, Np = nt * 32;
-  const size_t smem = (size_t)Np * 36 * 4 + 2 * 128 * 4 + (size_t)4 * 32 * 36 * 4 + (size_t)2 * nt * 64 * 16 + 16;
+  const size_t smem = 2 * 128 * 4 + (size_t)32 * 96 * 4 + (size_t)2 * nt * 64 * 16 + 16;
+  (void)Np;
   if (smem > 160 * 1024) return FDIPT_ESIZE;
   static bool attr_set = false;
   if (!attr_set) {

@@ -79,6 +79,11 @@ struct PointsArgs {
   const float* quat;   // [B,N,4] current quaternion
   const float* trans;  // [B,N,3] current translation (scaled)
   float *qp, *kp, *vp, *rot;
+  // optional: v_pts as a bf16 hi/lo fragment image for the MFMA o_pt of attention3 (needs Pv == 12): [B*H][3 tiles][Np/16]
+  // [64][8]; row 32 dt + (lane & 31) = coordinate (< 36: high part, 36..71: low part = v - bf16(v), else 0), key position
+  // 16 s + 8 (lane >> 5) + e with the keys permuted inside every 16-group; pads must be zeroed by the caller once
+  unsigned short* vpt;
+  int Np;
 };
 
 // Pair bias of the IPA attention, tiled for BOTH sides: [sample*head][query tile][key tile][query in tile][32 keys].
@@ -140,6 +145,7 @@ struct Attn3Args {
   const float* bias;              // pre-scaled pair bias in fd_bias_frag_off order (B*H*Np*Np floats)
   const float* res_mask;          // [B,N]
   const float *qp, *kp, *vp;      // [B,N,H,8,3], [B,N,H,8,3], [B,N,H,12,3] global-frame points (scaled units)
+  const bf16_t* vpt;              // v_pts hi/lo fragment image (PointsArgs.vpt)
   const float* gamma;             // [H]
   const float *rot, *trans;       // [B,N,9], [B,N,3]
   float* probs;                   // [B,H,N,N]

@@ -363,7 +363,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -396,6 +396,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   }
   w.seqimg = take(fd_seq_attention_image_bytes(B, N, d->tfmr_heads));
   w.ipa_parts = take((size_t)8 * R * d->c_s * 4);
+  w.vpt = take((size_t)B * H * 96 * (((size_t)N + 31) / 32 * 32) * 2);  // v_pts hi/lo fragment image (attention3 o_pt)
   w.e_bf = take(R * iv.cb * 2);  // bf16 copy of initial_embed(node) (edge_transition3 fetches it by LDS-DMA)  // split-K partial products of the IPA output projection
   w.total = o;
 }
@@ -537,13 +538,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     Attn3Args a3;
     a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const bf16_t*)(W + w.qb); a3.Kb = (const bf16_t*)(W + w.kb);
     a3.Vt = (const bf16_t*)(W + w.vt); a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
-    a3.vp = F(w.vp); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
+    a3.vp = F(w.vp); a3.vpt = (const bf16_t*)(W + w.vpt); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
     a3.probs = F(w.probs); a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
     const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !getenv("FDIPT_ATTN_V1") &&
                         !getenv("FDIPT_ATTN_V2") && fd_attention3_supported(a3);
     PointsArgs pa;
     pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.quat = F(w.quat); pa.trans = F(w.trans);
     pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
+    pa.vpt = (use_a3 && Pv == 12) ? (unsigned short*)(W + w.vpt) : nullptr; pa.Np = Np;
+    if (pa.vpt && b == 0)  // padded keys and rows 72..95 of the image are never written: zero once per forward
+      if (hipMemsetAsync(W + w.vpt, 0, (size_t)B * H * 96 * Np * 2, st) != hipSuccess) return FDIPT_ELAUNCH;
     if (use_a3) {
       // fused projection written directly as attention operand images (Qb, Kb, Vt) + raw point columns
       ProjArgs pj;

@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
   a.Vt = (const bf16_t*)dz((size_t)B * H * 256 * Np * 2); a.bias = (const float*)dz((size_t)B * H * Np * Np * 4);
   a.res_mask = (const float*)dz((size_t)B * N * 4); a.qp = (const float*)dz((size_t)B * N * H * 24 * 4);
   a.kp = (const float*)dz((size_t)B * N * H * 24 * 4); a.vp = (const float*)dz((size_t)B * N * H * 36 * 4);
+  a.vpt = (const bf16_t*)dz((size_t)B * H * 96 * Np * 2);
   a.gamma = (const float*)dz(64); a.rot = (const float*)dz((size_t)B * N * 9 * 4); a.trans = (const float*)dz((size_t)B * N * 3 * 4);
   a.probs = (float*)dz((size_t)B * H * N * N * 4); a.out_ld = 2432; a.out = (float*)dz((size_t)B * N * a.out_ld * 4); a.pt_off = H * 256;
   if (!fd_attention3_supported(a)) { printf("unsupported\n"); return 1; }
@@ -27,7 +28,7 @@ int main(int argc, char** argv) {
   const int nb = (Np / 32) * H * B;
   std::vector<unsigned long long> h((size_t)nb * 16);
   (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fd_prof), h.size() * 8);
-  const char* names[8] = {"", "prologue (v_pts, Q, q_pts)", "phase 1 logits", "phase 2 softmax", "phase 3 probs/P/o_pt", "o_pt fold + barrier", "phase 4a", "phase 4b PV"};
+  const char* names[8] = {"", "prologue (Q, q_pts)", "phase 1 logits", "phase 2 softmax", "phase 3 probs/P", "barrier", "-", "phase 4 PV + o_pt"};
   double tot = 0;
   for (int k = 1; k < 8; ++k) {
     double s = 0;
