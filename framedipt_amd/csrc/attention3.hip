@@ -20,7 +20,7 @@
 #include "kernels.hpp"
 
 #define A3_C 256
-#define A3_NTW 4  // key tiles per wave -> N <= 4 * 4 * 32 = 512
+#define A3_NTW_MAX 4  // key tiles per wave -> N <= 4 * 4 * 32 = 512
 
 __device__ __forceinline__ bf16x8 a3_pack8(const float* v) {
   bf16x8 o;
@@ -30,7 +30,11 @@ __device__ __forceinline__ bf16x8 a3_pack8(const float* v) {
 }
 __device__ __forceinline__ bf16x8 a3_ld(const bf16_t* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
 
-__global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
+// NTW: key tiles per wave (N <= 128 NTW).  NTW = 3 (N <= 384): 234 registers -> launch bound 2 -> TWO blocks per CU hide each
+// other's memory latency, so the operands of a tile are simply fetched when needed (DB = false).  NTW = 4: one block per
+// CU with all 512 registers, next tile's operands / second V tile in flight under the current one (DB = true).
+template <int A3_NTW, int LB, bool DB>
+__global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a.N, H = a.H, nt = (N + 31) / 32, Np = nt * 32;
   float* mxs = (float*)smem;                                 // [4][32]
@@ -65,20 +69,18 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) Qf[s] = a3_ld(qr + s * 512);
   }
-  float qB[13];  // B operand of the point product: k index 2s+hi
+  const float mi = a.res_mask[rb + i];
+  const float gam = a.gamma[h];
+  float qB[13];  // B operand of the point product (k index 2s+hi), pre-multiplied by the head's point weight gamma
   {
     const float* qpr = a.qp + ((rb + i) * H + h) * 24;
     float qn = 0.f;
 #pragma unroll
     for (int c = 0; c < 24; ++c) qn += qpr[c] * qpr[c];
 #pragma unroll
-    for (int s = 0; s < 12; ++s) qB[s] = qpr[2 * s + hi];
-    qB[12] = hi ? -0.5f * qn : 1.0f;
+    for (int s = 0; s < 12; ++s) qB[s] = gam * qpr[2 * s + hi];
+    qB[12] = gam * (hi ? -0.5f * qn : 1.0f);
   }
-  const float mi = a.res_mask[rb + i];
-  const float gam = a.gamma[h];
-
-  FD_STAMP(1);
   // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...  The global operands of tile u+1 (K rows as A
   // fragments, key points, bias row pieces, mask) are fetched while tile u runs through the matrix cores.
   struct TileIn {
@@ -110,20 +112,22 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
     }
   };
   f32x16 S[A3_NTW];
-  TileIn tin[2];
-  if (wave < nt) tile_load(tin[0], wave);
+  TileIn tin[DB ? 2 : 1];
+  if (DB && wave < nt) tile_load(tin[0], wave);
 #pragma unroll
   for (int u = 0; u < A3_NTW; ++u) {
     const int t = wave + 4 * u;
-    if (u + 1 < A3_NTW && t + 4 < nt) tile_load(tin[(u + 1) & 1], t + 4);
+    if (DB && u + 1 < A3_NTW && t + 4 < nt) tile_load(tin[(u + 1) & 1], t + 4);
     if (t < nt) {
-      const TileIn& ti = tin[u & 1];
+      if (!DB) tile_load(tin[0], t);
+      const TileIn& ti = tin[DB ? (u & 1) : 0];
+      // ONE accumulator for the three terms: it starts at -1e5, the mask product 1e5 m_i m_j brings an unmasked pair back
+      // to exactly 0 (a masked one stays at -1e5, a padded key goes to -1e30) BEFORE the small terms are added, so nothing
+      // is lost to the large constant; then gamma * (q.k - |k|^2/2 - |q|^2/2) as a 26-deep fp32 MFMA chain, then Q K^T
       f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ti.k[s], Qf[s], acc, 0, 0, 0);
-      // point term: A row = [k_pts(24) | -|k|^2/2 | 1]
+      for (int r = 0; r < 16; ++r) acc[r] = -1e5f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : ti.mA, hi ? 0.f : 1e5f * mi, acc, 0, 0, 0);
       float kpv[24];
 #pragma unroll
       for (int c4 = 0; c4 < 6; ++c4) {
@@ -132,25 +136,16 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
       float kn = 0.f;
 #pragma unroll
       for (int c = 0; c < 24; ++c) kn += kpv[c] * kpv[c];
-      f32x16 accp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accp[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 12; ++s)
-        accp = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? kpv[2 * s + 1] : kpv[2 * s], qB[s], accp, 0, 0, 0);
-      accp = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], accp, 0, 0, 0);
-      // mask product m_i m_j
-      f32x16 accm;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? kpv[2 * s + 1] : kpv[2 * s], qB[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], acc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accm[r] = 0.f;
-      accm = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : ti.mA, hi ? 0.f : mi, accm, 0, 0, 0);
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ti.k[s], Qf[s], acc, 0, 0, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * g + q;
-          acc[r] = acc[r] + ti.bv[g][q] + gam * accp[r] + 1e5f * (accm[r] - 1.f);
-        }
+        for (int q = 0; q < 4; ++q) acc[4 * g + q] += ti.bv[g][q];
       S[u] = acc;
     }
   }
@@ -218,7 +213,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
   {
     constexpr int KSM = 2 * 4 * A3_NTW;  // k-steps of 16 keys at the maximum N
     const int ks = 2 * nt;
-    bf16x8 Va[2][KSM];
+    bf16x8 Va[DB ? 2 : 1][KSM];
     auto v_load = [&](auto BUF, const bf16_t* base) {
       constexpr int bf = decltype(BUF)::value;
 #pragma unroll
@@ -243,14 +238,24 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
         }
       }
     };
-    v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave) * ks) * 512);
-    v_load(std::integral_constant<int, 1>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
     f32x16 acc;
-    v_mma(std::integral_constant<int, 0>{}, acc);
-    if (wave < 3) v_load(std::integral_constant<int, 0>{}, a.vpt + ((bh * 3 + wave) * ks) * 512);  // points tile, under tile 1
-    o_store(acc, 2 * wave);
-    v_mma(std::integral_constant<int, 1>{}, acc);
-    o_store(acc, 2 * wave + 1);
+    if constexpr (DB) {
+      v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave) * ks) * 512);
+      v_load(std::integral_constant<int, 1>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
+      v_mma(std::integral_constant<int, 0>{}, acc);
+      if (wave < 3) v_load(std::integral_constant<int, 0>{}, a.vpt + ((bh * 3 + wave) * ks) * 512);  // points tile, under tile 1
+      o_store(acc, 2 * wave);
+      v_mma(std::integral_constant<int, 1>{}, acc);
+      o_store(acc, 2 * wave + 1);
+    } else {
+      v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave) * ks) * 512);
+      v_mma(std::integral_constant<int, 0>{}, acc);
+      v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
+      o_store(acc, 2 * wave);
+      v_mma(std::integral_constant<int, 0>{}, acc);
+      if (wave < 3) v_load(std::integral_constant<int, 0>{}, a.vpt + ((bh * 3 + wave) * ks) * 512);
+      o_store(acc, 2 * wave + 1);
+    }
     if (wave < 3) {
       v_mma(std::integral_constant<int, 0>{}, acc);
 #pragma unroll
@@ -283,22 +288,17 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_attn3_kernel(Attn3Args a) {
 }
 
 int fd_attention3_supported(const Attn3Args& a) {
-  return a.N >= 1 && a.N <= A3_NTW * 4 * 32 && a.H <= 8 && a.Np == ((a.N + 31) / 32) * 32 && a.vpt != nullptr;
+  return a.N >= 1 && a.N <= A3_NTW_MAX * 4 * 32 && a.H <= 8 && a.Np == ((a.N + 31) / 32) * 32 && a.vpt != nullptr;
 }
 
 int fd_attention3(const Attn3Args& a, hipStream_t st) {
   const int nt = (a.N + 31) / 32, Np = nt * 32;
   const size_t smem = 2 * 128 * 4 + (size_t)32 * 96 * 4 + (size_t)2 * nt * 64 * 16 + 16;
   (void)Np;
-  if (smem > 160 * 1024) return FDIPT_ESIZE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)ipa_attn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return FDIPT_ELAUNCH;
-    attr_set = true;
-  }
+  if (smem > 64 * 1024) return FDIPT_ESIZE;  // 1 KB + 12 KB + 64 B per key: 45 KB at N = 512
   const int per = (a.B * a.H + 7) / 8;  // see the block mapping in the kernel
-  hipLaunchKernelGGL(ipa_attn3_kernel, dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
+  if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
+  else hipLaunchKernelGGL((ipa_attn3_kernel<4, 1, true>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
