@@ -23,7 +23,7 @@
 #define SA_HD 80
 #define SA_KS 6         // k-steps of 16 channels: 80 + the mask channel, padded to 96
 #define SA_DT 3         // 32-channel output tiles (80 -> 96, padded rows are zero)
-#define SA_NTW 4        // key tiles per wave -> N <= 4 * 4 * 32 = 512
+#define SA_NTW_MAX 4    // key tiles per wave -> N <= 4 * 4 * 32 = 512
 
 __host__ __device__ __forceinline__ int sa_perm16(int pos) {  // involution
   const int hi = pos >> 3, e = pos & 7;
@@ -219,7 +219,9 @@ __device__ __forceinline__ bf16x8 sa_pack8(const float* v) {
   return o;
 }
 
-__global__ __launch_bounds__(FD_THREADS, 1) void seq_attn_kernel(int B, int N, int Np, int H, const bf16_t* __restrict__ Qi,
+// SA_NTW: key tiles per wave (N <= 128 SA_NTW); with 3 the kernel fits 256 registers and two blocks share a CU (LB = 2)
+template <int SA_NTW, int LB>
+__global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, int Np, int H, const bf16_t* __restrict__ Qi,
                                                                  const bf16_t* __restrict__ Ki, const bf16_t* __restrict__ Vi,
                                                                  float* __restrict__ out, int out_ld) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -331,7 +333,7 @@ size_t fd_seq_attention_image_bytes(int B, int N, int H) {
   const size_t Np = ((size_t)N + 31) / 32 * 32;
   return (size_t)B * H * Np * (2 * SA_KS * 16 + SA_DT * 32) * 2;  // Qi + Ki + Vi
 }
-int fd_seq_attention_supported(int N, int H, int hd) { return hd == SA_HD && N >= 1 && N <= 4 * SA_NTW * 32 && H >= 1; }
+int fd_seq_attention_supported(int N, int H, int hd) { return hd == SA_HD && N >= 1 && N <= 4 * SA_NTW_MAX * 32 && H >= 1; }
 
 int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, void* images,
                      float* out, int out_ld, hipStream_t st) {
@@ -346,7 +348,8 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
   FD_CHECK_LAUNCH();
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
-  hipLaunchKernelGGL(seq_attn_kernel, dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -384,7 +387,8 @@ int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, in
   const bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
-  hipLaunchKernelGGL(seq_attn_kernel, dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
