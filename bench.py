@@ -182,7 +182,7 @@ def main():
                                    f"the T={T} schedule, noise_scale 0.1, 17.4M-param synthetic weights",
                        "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(a.precision, N, B), "kernel": "edge_transition3_kernel" if a.precision == "bf16" else "edge_transition_kernel",
+                         "traffic": pmc_traffic(a.precision, N, B), "kernel": "edge_transition4_kernel" if a.precision == "bf16" else "edge_transition_kernel",
                          "avg_launch_ms": et * 1e3, "flops_per_launch": et_flops,
                          "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak},
         }

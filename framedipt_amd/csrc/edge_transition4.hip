@@ -1,0 +1,607 @@
+// edge_transition4.hip — bf16 EdgeTransition (framedipt/model/ipa_pytorch.py:84-102), third generation.
+//
+// edge_transition3 (16-pair waves, v_mfma_f32_16x16x32_bf16) needs a fresh 1 KB weight fragment from LDS for every 16-cycle
+// MFMA: at full matrix rate the four SIMDs ask for exactly the 256 B/clk the LDS delivers, and the kernel sits on that
+// limit (42 % MFMA utilisation).  This generation halves the LDS bytes per FLOP and removes a fifth of the FLOPs:
+//   * a wave owns 32 pairs and works with v_mfma_f32_32x32x16_bf16 (32 cycles per 1 KB fragment), still TWO waves per SIMD:
+//     the activations fit 256 registers because x is no longer held — the z fragments are re-read from the wave's LDS rows
+//     for the final layer, and e_j is gone from the matrix products altogether (next point);
+//   * a wave's 32 pairs are a patch of 8 rows i x 4 columns j of one sample.  Everything in the first and final layers that
+//     depends on one residue only — W[:, e_i cols] e_i + b (rows A1[i], Af[i]) AND W[:, e_j cols] e_j (rows B1[j], Bf[j])
+//     — enters the accumulator through ONE extra k-step per output tile: A = [A1 rows of the 8 i | B1 rows of the 4 j] as
+//     a bf16 fragment straight from L2, B = a constant 0/1 selection matrix (pair p picks i = p >> 2 and j = p & 3).
+//     Layer 1 shrinks from K = 256 to 128 + 16, the final layer from 640 to 512 + 16: 536 MFMA x 32 cycles per 32 pairs
+//     instead of 644 x 16 per 16 pairs (-17 % matrix cycles, -60 % LDS fragment bytes);
+//   * same transposed scheme and register hand-off: D^T[feature, pair]; the C/D registers 8u .. 8u+7 of a 32-feature tile
+//     are the B fragment of k-step 2T + u of the next layer, k position (half, e) = feature 32 T + e4_chain_feat(u, half, e),
+//     folded into the weight stream;
+//   * weight stream 512 KB per 256 pairs (edge_transition3: 640 KB per 128), 20 chunks through a 2 x 32 KB LDS ring.
+// Needs N % 4 == 0; other sizes run edge_transition3.
+#include <type_traits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+#ifndef E4_ABL
+#define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA
+#endif
+#ifndef E4_D1
+#define E4_D1 3   // weight-fragment ring depths: layer 1, layer 2, final layer
+#endif
+#ifndef E4_D2
+#define E4_D2 4
+#endif
+#ifndef E4_DF
+#define E4_DF 6
+#endif
+#define E4_CZ 128
+#define E4_H 384
+#define E4_THREADS 512
+#define E4_BUF 32768
+#define E4_L1_FR (12 * 8)    // fragments (1 KB): layer 1, 12 tiles x 8 k-steps (K = 128: z)
+#define E4_L2_FR (12 * 24)   // layer 2, 12 tiles x 24 k-steps
+#define E4_LF_FR (32 * 4)    // final layer, k-major: 32 k-steps (8 z + 24 h2) x 4 tiles
+#define E4_STREAM_BYTES ((E4_L1_FR + E4_L2_FR + E4_LF_FR) * 1024)
+#define E4_ZOFF (2 * E4_BUF)                 // per-wave z rows [8][32 rows x 256 B]
+#define E4_VOFF (E4_ZOFF + 8 * 8192)         // b2[384] | gamma[128] | beta[128] f32, then linear_b image (8 KB)
+#define E4_SOFF (E4_VOFF + 1536 + 1024 + 8192)  // per-wave output staging [8][32 rows x 64 B]
+#define E4_LDS (E4_SOFF + 8 * 2048)
+
+// phase profile (-DE4_PROF, tools/micro/et4_bench.hip): cycle differences accumulate in scalar registers over all tiles of a
+// block and are written once at the end (FD_STAMP's per-stamp vector store costs registers this kernel does not have)
+#ifdef E4_PROF
+__device__ unsigned e4_prof[256 * 8];
+#define E4_STAMP(k)                                              \
+  do {                                                           \
+    const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+    ph[k] += t_ - tlast;                                         \
+    tlast = t_;                                                  \
+  } while (0)
+#else
+#define E4_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
+typedef __bf16 e4_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int e4_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int e4_u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short e4_s16x2 __attribute__((ext_vector_type(2)));
+
+// C/D register 8u + e of lane half `half` of a 32-feature tile holds feature (offset in the tile):
+__host__ __device__ __forceinline__ int e4_chain_feat(int u, int half, int e) { return (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * half; }
+
+// ------------------------------------------------------------------ prepare: weight stream image
+// w1 [384,384], w2 [384,384], wf [128,384] fp32 row-major (out, in); in = [z(0:128) | e_i(128:256) | e_j(256:384)]
+__global__ void et4_build_stream_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                        const float* __restrict__ wf, bf16_t* __restrict__ stream) {
+  const int n_units = E4_STREAM_BYTES / 16;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_units; g += gridDim.x * blockDim.x) {
+    int frag = g >> 6;
+    const int lane = g & 63, f = lane & 31, half = lane >> 5;
+    const float* src;
+    int n, s;
+    bool chained;
+    if (frag < E4_L1_FR) { src = w1; n = 32 * (frag / 8) + f; s = frag % 8; chained = false; }
+    else if (frag < E4_L1_FR + E4_L2_FR) { frag -= E4_L1_FR; src = w2; n = 32 * (frag / 24) + f; s = frag % 24; chained = true; }
+    else {
+      frag -= E4_L1_FR + E4_L2_FR;
+      src = wf; n = 32 * (frag & 3) + f; s = frag >> 2;
+      chained = s >= 8;
+      if (chained) s -= 8;
+    }
+    bf16_t out[8];
+    for (int e = 0; e < 8; ++e) {
+      const int col = chained ? 32 * (s >> 1) + e4_chain_feat(s & 1, half, e) : 16 * s + 8 * half + e;  // z columns are 0..127
+      out[e] = f2bf(src[(long)n * E4_H + col]);
+    }
+    for (int e = 0; e < 8; ++e) stream[(long)g * 8 + e] = out[e];
+  }
+}
+int fd_et4_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st) {
+  hipLaunchKernelGGL(et4_build_stream_kernel, dim3(128), dim3(256), 0, st, w1, w2, wf, (bf16_t*)stream);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+size_t fd_et4_stream_bytes() { return E4_STREAM_BYTES; }
+
+// linear_b of the NEXT block's attention (ipa_pytorch.py:247,256-257) as 8 fragments [k-step][lane][8]: row = head (H of 32
+// used), k in the hand-off order of the LayerNorm output tiles; `scale` = sqrt(1/3)
+__global__ void et4_bias_image_kernel(const float* __restrict__ wb, int H, float scale, bf16_t* __restrict__ img) {
+  for (int g = threadIdx.x; g < 8 * 64; g += blockDim.x) {
+    const int s = g >> 6, lane = g & 63, f = lane & 31, half = lane >> 5;
+    for (int e = 0; e < 8; ++e)
+      img[g * 8 + e] = f < H ? f2bf(wb[f * E4_CZ + 32 * (s >> 1) + e4_chain_feat(s & 1, half, e)] * scale) : (bf16_t)0;
+  }
+}
+int fd_et4_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st) {
+  if (H > 8) return FDIPT_ESIZE;
+  hipLaunchKernelGGL(et4_bias_image_kernel, dim3(1), dim3(256), 0, st, wb, H, scale, (bf16_t*)img);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// ------------------------------------------------------------------ per-forward: residue rows -> fold fragments
+// rows [B*N][1024] f32 = [A1 (384) | Af (128) | B1 (384) | Bf (128)]   (A*: e_i columns + bias, B*: e_j columns)
+// a_img [ceil(B*N/8)][16 feature tiles][32 f][8]: element e = flattened residue row 8 rt + e (0 beyond B*N)
+// b_img [B][N/4][16][32 f][8]: element e < 4 = row j = 4 jt + e of sample b, e >= 4 = row 4 jt + e - 4 of sample b + 1
+//                             (for the rows of a patch that straddles two samples; 0 for the last sample)
+__global__ void et4_row_images_kernel(const float* __restrict__ rows, int B, int N, bf16_t* __restrict__ a_img,
+                                      bf16_t* __restrict__ b_img) {
+  const int M = B * N, MT8 = (M + 7) >> 3, NJ4 = N >> 2;
+  const long na = (long)MT8 * 512, nb = (long)B * NJ4 * 512;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < na + nb; g += (long)gridDim.x * blockDim.x) {
+    const bool is_b = g >= na;
+    const long u = is_b ? g - na : g;
+    const int c = (int)(u & 511);                 // column 32 ft + f of the 512-wide half
+    const long t = u >> 9;
+    const int b = is_b ? (int)(t / NJ4) : 0, jt = is_b ? (int)(t - (long)b * NJ4) : 0;
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      long r;
+      bool ok;
+      if (is_b) { const int bb = b + (e >> 2); ok = bb < B; r = (long)bb * N + 4 * jt + (e & 3); }
+      else { r = 8 * t + e; ok = r < M; }
+      o[e] = ok ? f2bf(rows[r * 1024 + (is_b ? 512 : 0) + c]) : (bf16_t)0;
+    }
+    *(u16x8*)((is_b ? b_img : a_img) + u * 8) = o;
+  }
+}
+size_t fd_et4_a_image_bytes(int B, int N) { return (size_t)((B * N + 7) / 8) * 8192; }
+size_t fd_et4_b_image_bytes(int B, int N) { return (size_t)B * (N / 4) * 8192; }
+int fd_et4_row_images(const float* rows, int B, int N, void* a_img, void* b_img, hipStream_t st) {
+  const long units = ((long)(B * N + 7) / 8 + (long)B * (N / 4)) * 512;
+  hipLaunchKernelGGL(et4_row_images_kernel, dim3((unsigned)cdiv(units, 256)), dim3(256), 0, st, rows, B, N, (bf16_t*)a_img, (bf16_t*)b_img);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// ------------------------------------------------------------------ device helpers
+// 16 B-per-lane LDS-DMA as inline asm (see edge_transition2.hip: the builtin makes hipcc force lgkmcnt(0) everywhere)
+// LDS is addressed by 32-bit byte offsets into the dynamic segment (the only LDS of the kernel, so it starts at 0): no
+// generic pointers, no address-space casts with their null checks
+typedef const __attribute__((address_space(3))) u16x8* e4_lds_u16x8;
+typedef const __attribute__((address_space(3))) f32x4* e4_lds_f32x4;
+__device__ __forceinline__ void e4_dma16(const void* gsrc, unsigned lds_dst) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(gsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void e4_dma_wait() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 e4_frag(unsigned off) { return __builtin_bit_cast(bf16x8, *(e4_lds_u16x8)(unsigned long)off); }
+__device__ __forceinline__ f32x4 e4_ldsf4(unsigned off) { return *(e4_lds_f32x4)(unsigned long)off; }
+__device__ __forceinline__ bf16x8 e4_gfrag(const char* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
+template <int BYTES>
+__device__ __forceinline__ void e4_dma_chunk(const char* __restrict__ src, unsigned dst, int tid) {
+  static_assert(BYTES % (E4_THREADS * 16) == 0, "whole DMA instructions");
+#pragma unroll
+  for (int u = 0; u < BYTES / (E4_THREADS * 16); ++u)
+    if (!(E4_ABL & 4)) e4_dma16(src + (size_t)(u * E4_THREADS + tid) * 16, dst + (unsigned)(u * E4_THREADS + (tid & ~63)) * 16);
+}
+__device__ __forceinline__ f32x16 e4_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if (E4_ABL & 2) { c[0] += (float)a[0]; return c; }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// two fp32 -> one word of two bf16 (round to nearest even): a 2-vector conversion, which hipcc selects as ONE
+// v_cvt_pk_bf16_f32 (element-wise conversions + bit casts become two conversions and a v_perm_b32).  Not inline asm: the
+// hazard recognizer does not see asm operands, and an MFMA result read too early is stale.
+typedef __bf16 e4_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned e4_cvt_pk(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, e4_bf16x2));
+}
+// relu + bf16: C/D of one tile -> the two B fragments it hands to the next layer.  ReLU runs after the conversion, on the
+// bf16 bit patterns as signed 16-bit integers (negative values have the sign bit set): one v_pk_max_i16 per two values.
+__device__ __forceinline__ void e4_hand_off(const f32x16& acc, bf16x8& h0, bf16x8& h1) {
+  e4_u32x4 w0, w1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w0[k] = e4_cvt_pk(acc[2 * k], acc[2 * k + 1]);
+    w1[k] = e4_cvt_pk(acc[8 + 2 * k], acc[8 + 2 * k + 1]);
+  }
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  h0 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w0), zero));
+  h1 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w1), zero));
+  __builtin_amdgcn_sched_barrier(0);  // the hand-off of a tile happens here, not batched with later tiles' (register pressure)
+}
+
+// one 32-feature tile: KS weight fragments at `pa` (this lane's 16 B of fragment 0) against B fragments Bf[0..KS)
+template <int KS, int DEPTH>
+__device__ __forceinline__ void e4_tile(f32x16& acc, unsigned pa, const bf16x8* Bf) {
+  bf16x8 r[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s) r[s] = e4_frag(pa + s * 1024);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + DEPTH - 1 < KS) r[(s + DEPTH - 1) % DEPTH] = e4_frag(pa + (s + DEPTH - 1) * 1024);
+    acc = e4_mfma(r[s % DEPTH], Bf[s], acc);
+    __builtin_amdgcn_sched_barrier(0);  // pin: one ds_read, one MFMA per k-step (hipcc otherwise sinks every read to its use)
+  }
+}
+
+// selection fragment of the fold k-step (B operand): k = 8 half + e; half 0 picks row k = p >> 2 of the patch, half 1 picks
+// column j = p & 3 — of the patch's first sample (e < 4) or, for rows >= ns of a patch that straddles two samples, of the
+// next one (e >= 4).  Rebuilt where it is used (a few VALU instructions) instead of living through layer 2.
+__device__ __forceinline__ bf16x8 e4_sel(int lane, int ns) {
+  asm volatile("" : "+v"(lane));
+  const int p = lane & 31, want = (lane >> 5) ? (p & 3) + ((p >> 2) >= ns ? 4 : 0) : (p >> 2);
+  const unsigned one = (want & 1) ? 0x3F800000u : 0x00003F80u;  // bf16 1.0 in the odd / even half of a word
+  e4_u32x4 w;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = (want >> 1) == k ? one : 0u;
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+// ------------------------------------------------------------------ kernel
+// A wave's patch: rows 8 rt .. +7 of the flattened [B*N] residue rows (row = b N + i) x columns 4 jt .. +3.  When N % 8 != 0
+// a patch can straddle two samples: rows k >= ns belong to sample b0 + 1.  All fields are wave-uniform.
+struct E4Tile {
+  int rt, jt, b0, ns;
+  bool valid;
+};
+__device__ __forceinline__ E4Tile e4_tile_of(int w, int n_wt, int N, int NJ4) {
+  E4Tile t;
+  t.valid = w < n_wt;
+  if (!t.valid) w = n_wt - 1;
+  w = __builtin_amdgcn_readfirstlane(w);
+  t.rt = w / NJ4;
+  t.jt = w - t.rt * NJ4;
+  t.b0 = (8 * t.rt) / N;
+  const int left = (t.b0 + 1) * N - 8 * t.rt;
+  t.ns = left < 8 ? left : 8;
+  return t;
+}
+
+// z rows of the wave's patch -> its LDS rows (row p = 4 k + (j - 4 jt), 256 B, unit u of row p at u ^ (p & 15)):
+// 8 DMA instructions, one per residue row k (4 pairs = 1 KB contiguous in HBM), swizzle applied on the source side
+__device__ __forceinline__ void e4_request_z(const ET2Args& a, const E4Tile& t, int lane, unsigned zst, int M) {
+  const int N = a.N;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    int row = 8 * t.rt + r;
+    if (row > M - 1) row = M - 1;
+    const int lrow = 4 * r + (lane >> 4);
+    const int u = (lane & 15) ^ (lrow & 15);
+    const long pair = ((long)row * N + 4 * t.jt) + (lane >> 4);
+    e4_dma16(a.z_in + pair * E4_CZ + 8 * u, zst + r * 1024);
+  }
+}
+
+// The LayerNorm epilogue, in slices (statistics, four 32-feature tiles, pair bias)
+struct E4Epi {
+  f32x16 Y[4];        // final-layer output of the finished tile: feature 32 t + 8 g + 4 half + q in Y[t][4 g + q]
+  E4Tile t;
+  float em;           // res_mask[i] * res_mask[j]
+};
+struct E4EpiTmp {     // lives inside one epilogue run only
+  f32x16 accb;        // pair bias of the next block, accumulated tile by tile
+  f32x2 sa, sc;       // rstd, -mu * rstd (both halves equal)
+  float s1, s2;
+  long prow;          // this lane's pair (row of z)
+  long srow[2];       // the pairs whose 64 B row segments this lane stores (rows (lane >> 2) and 16 + (lane >> 2) of the patch)
+  bool valid, svalid[2], all_one;
+};
+typedef __attribute__((address_space(3))) e4_u32x2* e4_lds_w64;
+template <int SLOT>
+__device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M) {
+  const int p = lane & 31, half = lane >> 5;
+  if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math)
+    f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 y = {E.Y[t][r], E.Y[t][r + 1]};
+        u1 += y;
+        u2 = __builtin_elementwise_fma(y, y, u2);
+      }
+    X.s1 = u1[0] + u1[1];
+    X.s2 = u2[0] + u2[1];
+  } else if constexpr (SLOT == 1) {
+    const float s1 = X.s1 + __shfl_xor(X.s1, 32, 64), s2 = X.s2 + __shfl_xor(X.s2, 32, 64);
+    const float mu = s1 * (1.0f / E4_CZ);
+    const float var = fmaxf(s2 * (1.0f / E4_CZ) - mu * mu, 0.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    X.sa = f32x2{rstd, rstd};
+    X.sc = f32x2{-mu * rstd, -mu * rstd};
+    const int row = 8 * E.t.rt + (p >> 2);
+    X.valid = E.t.valid && row < M;
+    X.prow = (long)(row < M ? row : M - 1) * a.N + 4 * E.t.jt + (p & 3);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // patch row 16 k + (lane >> 2) = pair (i = that >> 2, j = that & 3)
+      const int pr = 16 * k + (lane >> 2), r2 = 8 * E.t.rt + (pr >> 2);
+      X.svalid[k] = E.t.valid && r2 < M;
+      X.srow[k] = (long)(r2 < M ? r2 : M - 1) * a.N + 4 * E.t.jt + (pr & 3);
+    }
+    X.all_one = __builtin_amdgcn_ballot_w64(E.em != 1.0f) == 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X.accb[r] = 0.f;
+  } else if constexpr (SLOT >= 2 && SLOT < 6) {  // one 32-feature tile: normalise, mask, bf16, store, its share of the pair bias
+    constexpr int t = SLOT - 2;
+    const unsigned gml = vec + 4 * (E4_H + 4 * half + 32 * t);
+    const unsigned btl = gml + 4 * E4_CZ;
+    e4_u32x4 zB[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {  // two halves of the tile: their gamma / beta first, then the math (no control flow between)
+      f32x4 gm[2], bt[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        gm[k] = e4_ldsf4(gml + 32 * (2 * h2 + k));
+        bt[k] = e4_ldsf4(btl + 32 * (2 * h2 + k));
+      }
+      f32x2 o[4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int g = 2 * h2 + k;
+        f32x2 o0 = {E.Y[t][4 * g], E.Y[t][4 * g + 1]}, o1 = {E.Y[t][4 * g + 2], E.Y[t][4 * g + 3]};
+        o0 = __builtin_elementwise_fma(o0, X.sa, X.sc);
+        o1 = __builtin_elementwise_fma(o1, X.sa, X.sc);
+        o[2 * k] = __builtin_elementwise_fma(o0, f32x2{gm[k][0], gm[k][1]}, f32x2{bt[k][0], bt[k][1]});
+        o[2 * k + 1] = __builtin_elementwise_fma(o1, f32x2{gm[k][2], gm[k][3]}, f32x2{bt[k][2], bt[k][3]});
+      }
+      if (!X.all_one) {  // wave-uniform; the usual case (no padding) skips the mask multiply
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] *= f32x2{E.em, E.em};
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int g = 2 * h2 + k;
+        const e4_u32x2 ow = {e4_cvt_pk(o[2 * k][0], o[2 * k][1]), e4_cvt_pk(o[2 * k + 1][0], o[2 * k + 1][1])};
+        // registers 4 g .. 4 g + 3 of tile t -> B fragment 2 t + (g >> 1) of z'
+        zB[h2][2 * k] = ow[0];
+        zB[h2][2 * k + 1] = ow[1];
+        // staging row p (64 B = this tile's 32 features), 16 B chunk g at g ^ ((p >> 2) & 3), 8 B half
+        *(e4_lds_w64)(unsigned long)(stg + p * 64 + ((g ^ ((p >> 2) & 3)) << 4) + 8 * half) = ow;
+      }
+      if (a.trace && X.valid) {
+        float* tr_row = a.trace + X.prow * E4_CZ + 4 * half + 32 * t + 16 * h2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *(f32x4*)(tr_row + 8 * k) = f32x4{o[2 * k][0], o[2 * k][1], o[2 * k + 1][0], o[2 * k + 1][1]};
+      }
+    }
+    if (a.wb_img) {  // D[head, pair] += Wb[:, this tile's features] z'
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+        X.accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e4_frag(wbi + (2 * t + h2) * 1024 + lane * 16), __builtin_bit_cast(bf16x8, zB[h2]), X.accb, 0, 0, 0);
+    }
+    // read the staged tile back as 64 B row segments (the LDS operations of one wave execute in order: no barrier) and store
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pr = 16 * k + (lane >> 2);
+      const u16x8 v = *(e4_lds_u16x8)(unsigned long)(stg + pr * 64 + (((lane & 3) ^ ((pr >> 2) & 3)) << 4));
+      if (X.svalid[k] && (!(E4_ABL & 8) || X.prow == -12345)) *(u16x8*)(a.z_out + X.srow[k] * E4_CZ + 32 * t + 8 * (lane & 3)) = v;
+    }
+  } else if constexpr (SLOT == 6) {
+    if (a.wb_img) {
+      // pair bias of the next block's attention: head 4 half + r in register r < 4
+      const int row = 8 * E.t.rt + (p >> 2), jj = 4 * E.t.jt + (p & 3);
+      if (E.t.valid && row < M && (!(E4_ABL & 8) || row == -12345)) {
+        const int b = row / a.N, ii = row - b * a.N, nt = (a.N + 31) >> 5;
+        float* bo = a.bias_out + fd_bias_frag_off((long)b * a.H + 4 * half, nt, ii, jj);
+        const long hstride = (long)nt * nt * 1024;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * half + r < a.H) bo[r * hstride] = X.accb[r] + a.bb[4 * half + r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args a, int n_tiles, int n_wt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+  const unsigned vec = lds0 + E4_VOFF;          // b2[384] | gamma[128] | beta[128] (f32)
+  const unsigned wbi = lds0 + E4_VOFF + 2560;   // linear_b fragments of the next block
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = tid0 >> 6;
+  const int N = a.N, NJ4 = N >> 2, M = a.B * N;
+  const char* stream = (const char*)a.stream;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+#ifdef E4_PROF
+  unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  E4Tile tc = e4_tile_of(tile * 8 + wave, n_wt, N, NJ4);
+  // ---- first tile: z rows, first weight chunk, small vectors
+  e4_request_z(a, tc, lane0, lds0 + E4_ZOFF + wave * 8192, M);
+  e4_dma_chunk<24576>(stream, lds0, tid0);
+  if (tid0 < 160) {
+    const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
+    e4_dma16(src, vec + (tid0 & ~63) * 16);
+  }
+  if (a.wb_img) e4_dma16((const char*)a.wb_img + tid0 * 16, wbi + (tid0 & ~63) * 16);
+  // fold fragments of the first layer-1 chunk (tiles 0..2): lanes < 32 read the row image, lanes >= 32 the column image
+  auto fold_ptr = [&](const E4Tile& t, int lane) {
+    return (lane >> 5) ? (const char*)a.b1_img + ((size_t)(t.b0 * NJ4 + t.jt) * 16) * 512 + (lane & 31) * 16
+                       : (const char*)a.a1_img + ((size_t)t.rt * 16) * 512 + (lane & 31) * 16;
+  };
+  auto mask_of = [&](const E4Tile& t, int lane) {
+    int row = 8 * t.rt + ((lane & 31) >> 2);
+    if (row > M - 1) row = M - 1;
+    return a.res_mask[row] * a.res_mask[(row / N) * N + 4 * t.jt + (lane & 3)];
+  };
+  const char* fold_base = fold_ptr(tc, lane0);
+  bf16x8 FA[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) FA[k] = e4_gfrag(fold_base + k * 512);
+  float em_cur = mask_of(tc, lane0);
+  E4Epi E;
+  e4_dma_wait();
+  __syncthreads();
+  E4_STAMP(0);
+#pragma unroll 1
+  for (;;) {
+    // opaque per-iteration copies: keep hipcc from hoisting the loop-invariant LDS / global address arithmetic of the whole
+    // tile body out of the loop (hundreds of values that would stay live across it and spill)
+    int lane = lane0, tid = tid0;
+    asm volatile("" : "+v"(lane), "+v"(tid));
+    const int p = lane & 31, half = lane >> 5;
+    const unsigned zst = lds0 + E4_ZOFF + (tid >> 6) * 8192;
+    const unsigned zrow = zst + p * 256;
+
+    bf16x8 H1[24], H2[24];
+    size_t soff = 0;
+    // ================= layer 1: 4 chunks x 3 tiles, K = 128 (+ fold)
+    {
+      const bf16x8 SEL = e4_sel(lane, tc.ns);
+      bf16x8 Zf[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) Zf[s] = e4_frag(zrow + (((2 * s) ^ (half ^ (p & 15))) << 4));
+      bf16x8 FC = FA[0];   // fold fragment of the current tile; the next one is requested a tile ahead
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((cc + 1) & 1) * E4_BUF, tid);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int T = 3 * cc + u;
+          bf16x8 FNx = FC;
+          if (T + 1 < 12) FNx = T + 1 < 3 ? FA[T + 1] : e4_gfrag(fold_base + (T + 1) * 512);
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          acc = e4_mfma(FC, SEL, acc);
+          e4_tile<8, E4_D1>(acc, lds0 + (cc & 1) * E4_BUF + u * 8192 + lane * 16, Zf);
+          e4_hand_off(acc, H1[2 * T], H1[2 * T + 1]);
+          FC = FNx;
+        }
+        e4_dma_wait();
+        __syncthreads();
+        soff += 24576;
+      }
+    }
+    E4_STAMP(1);
+    // ================= layer 2: 12 chunks x 1 tile, K = 384; the accumulator starts as b2
+#pragma unroll
+    for (int T = 0; T < 12; ++T) {
+      if (T < 11) e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid);
+      else e4_dma_chunk<32768>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid);  // first final-layer chunk
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = e4_ldsf4(vec + 4 * (32 * T + 8 * g + 4 * half));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 * g + q] = bv[q];
+      }
+      e4_tile<24, E4_D2>(acc, lds0 + (T & 1) * E4_BUF + lane * 16, H1);
+      e4_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
+      e4_dma_wait();
+      __syncthreads();
+      soff += 24576;
+    }
+    E4_STAMP(2);
+    // ================= final layer, k-major over the 4 output tiles: 8 k-steps of z (fragments re-read from the wave's LDS
+    // rows), 24 of h2, then the fold step (Af[i] + Bf[j]); 4 chunks x 8 k-steps
+    const int ntile = tile + gridDim.x;
+    const bool has_next = ntile < n_tiles;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) E.Y[t][r] = 0.f;
+    bf16x8 FL[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      if (cc < 3) e4_dma_chunk<32768>(stream + soff + 32768, lds0 + ((cc + 1) & 1) * E4_BUF, tid);
+      else if (has_next) e4_dma_chunk<24576>(stream, lds0, tid);  // the next tile's first chunk: buffer 0 is free since chunk 18
+      if (cc == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) FL[k] = e4_gfrag(fold_base + (12 + k) * 512);
+      }
+      const unsigned pa = lds0 + (cc & 1) * E4_BUF + lane * 16;
+      constexpr int NF = 32, DEPTH = E4_DF;  // flat ring over the chunk's 32 fragments
+      bf16x8 r[DEPTH];
+      bf16x8 zb[2];
+      unsigned zrow2 = 0, zx = 0;  // the z row address again, from an opaque copy (otherwise the 8 layer-1 addresses stay live)
+      if (cc == 0) {
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        zrow2 = lds0 + E4_ZOFF + (tid >> 6) * 8192 + (l2 & 31) * 256;
+        zx = (l2 >> 5) ^ (l2 & 15);
+        zb[0] = e4_frag(zrow2 + (zx << 4));
+      }
+#pragma unroll
+      for (int m = 0; m < DEPTH - 1; ++m) r[m] = e4_frag(pa + m * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < NF; ++m) {
+        const int s = m >> 2, t = m & 3;
+        if (m + DEPTH - 1 < NF) r[(m + DEPTH - 1) % DEPTH] = e4_frag(pa + (m + DEPTH - 1) * 1024);
+        if (cc == 0 && t == 0 && s + 1 < 8) zb[(s + 1) & 1] = e4_frag(zrow2 + (((2 * (s + 1)) ^ zx) << 4));
+        E.Y[t] = e4_mfma(r[m % DEPTH], cc == 0 ? zb[s & 1] : H2[8 * (cc - 1) + s], E.Y[t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (cc < 3) {
+        e4_dma_wait();
+        __syncthreads();
+        soff += 32768;
+      }
+    }
+    {
+      const bf16x8 SEL = e4_sel(lane, tc.ns);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) E.Y[t] = e4_mfma(FL[t], SEL, E.Y[t]);
+    }
+    E4_STAMP(3);
+    // ================= tile boundary (no barrier: the z rows and the store staging are wave-private): the next tile's operands
+    // are requested, THEN the LayerNorm epilogue of this tile runs under their latency
+    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * 8 + (tid >> 6), n_wt, N, NJ4);
+    if (has_next) e4_request_z(a, tn, lane, zst, M);
+    fold_base = fold_ptr(tn, lane);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) FA[k] = e4_gfrag(fold_base + k * 512);  // (the last tile re-reads its own: no branch, no phi)
+    E.t = tc;
+    E.em = em_cur;
+    em_cur = mask_of(tn, lane);
+    if (!(E4_ABL & 1)) {
+      E4EpiTmp X;
+      const unsigned stg = lds0 + E4_SOFF + (tid >> 6) * 2048;
+      e4_epi<0>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<1>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<2>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<3>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<4>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<5>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<6>(E, X, a, lane, vec, wbi, stg, M);
+    } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
+    E4_STAMP(4);
+    if (!has_next) break;
+    tile = ntile;
+    tc = tn;
+    e4_dma_wait();
+    __syncthreads();
+    E4_STAMP(5);
+  }
+#ifdef E4_PROF
+  if (tid0 == 0 && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) e4_prof[blockIdx.x * 8 + k] = ph[k];
+#endif
+}
+
+int fd_edge_transition4_supported(int N) { return N >= 8 && N <= 2048 && N % 4 == 0; }
+
+int fd_edge_transition4(const ET2Args& a, hipStream_t st) {
+  const long n_pairs = (long)a.B * a.N * a.N;
+  if (n_pairs >= (1L << 31) - 256 || !a.a1_img || !a.b1_img || a.N % 4) return FDIPT_EINVAL;  // 32-bit pair indices in the kernel
+  const int n_wt = ((a.B * a.N + 7) / 8) * (a.N / 4);
+  const int n_tiles = cdiv(n_wt, 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)edge_transition4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDIPT_ELAUNCH;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int grid = n_tiles < n_cu ? n_tiles : n_cu;  // persistent: one block per CU
+  hipLaunchKernelGGL(edge_transition4_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

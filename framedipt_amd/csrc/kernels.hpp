@@ -111,6 +111,9 @@ struct ET2Args {
   const float* bb;      // [H] pre-scaled bias of linear_b
   float* bias_out;      // fragment order (fd_bias_frag_off)
   int H;
+  // edge_transition4: per-residue rows as fold fragments (fd_et4_row_images)
+  const void* a1_img;   // [ceil(B*N/8)][16][32][8] bf16: A1 | Af rows of 8 consecutive (flattened) residue rows
+  const void* b1_img;   // [B][N/4][16][32][8] bf16: B1 | Bf rows (e_j columns) of 4 consecutive j (+ the next sample's)
 };
 int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et2_stream_bytes();
@@ -122,6 +125,16 @@ size_t fd_et3_stream_bytes();
 int fd_edge_transition3(const ET2Args& a, hipStream_t st);
 int fd_et3_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st);  // 4 KB, for ET2Args.wb_img
 int fd_edge_transition3_supported(int N);
+// third generation (edge_transition4.hip): 32-pair waves (8 i x 4 j patches), e_i / e_j parts folded into one k-step
+int fd_et4_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
+size_t fd_et4_stream_bytes();
+int fd_et4_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st);  // 8 KB, for ET2Args.wb_img
+size_t fd_et4_a_image_bytes(int B, int N);
+size_t fd_et4_b_image_bytes(int B, int N);
+// rows [B*N][1024] f32 = [A1 | Af | B1 | Bf] -> ET2Args.a1_img / b1_img
+int fd_et4_row_images(const float* rows, int B, int N, void* a_img, void* b_img, hipStream_t st);
+int fd_edge_transition4(const ET2Args& a, hipStream_t st);
+int fd_edge_transition4_supported(int N);
 int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t st);
 size_t fd_ee2_image_bytes();
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st);
@@ -191,7 +204,7 @@ struct RowBlockArgs {
   const float* upd_mask;        // [M] or NULL
   float *quat, *trans;          // [M,4], [M,3]
 };
-enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS };
+enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 
 // post-attention half of one encoder layer in one launch (rowblock.hip): x_a = LN1(x + Wo att + bo); out = LN2(x_a + W2 relu(W1 x_a + b1) + b2)

@@ -93,10 +93,10 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
-  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f;
+  size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, wb_img3, et2, et3, wdz_t, wdz_img; DChain ch; };
+struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et2, et3, et4, wdz_t, wdz_img; DChain ch; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -143,12 +143,15 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb_img = o; o = al256(o + 8192);  // linear_b as a 32 x 128 MFMA fragment image (edge_transition2 epilogue)
     L.blk[b].wb_img3 = o; o = al256(o + 4096);  // ... as 16 x 128 (edge_transition3 epilogue)
+    L.blk[b].wb_img4 = o; o = al256(o + 8192);  // ... as 32 x 128 in edge_transition4's hand-off order
     L.blk[b].wdz_img = o; o = al256(o + 8192);  // down_z [c_z/4, c_z] as a bf16 fragment image (MFMA o_pair kernel)
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et2 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
     L.blk[b].et3 = o;
     if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et3_stream_bytes());
+    L.blk[b].et4 = o;
+    if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et4_stream_bytes());
     if (use_chain(d)) {
       DChain& c = L.blk[b].ch;
       auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
@@ -159,6 +162,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       c.et_init = img(iv.cb, cs); c.a1 = img(iv.hid, iv.cb); c.af = img(d->c_z, iv.cb);
       c.a1af = img(iv.hid + d->c_z, iv.cb);                     // [W1[:, e_i]; Wf[:, e_i]] as one 512-row image (rowblock.hip)
       c.b1f = o; o = al256(o + (size_t)(iv.hid + d->c_z) * 4);  // [b1; bf]
+      c.r4w = img(2 * (iv.hid + d->c_z), iv.cb);                // [W1[:, e_i]; Wf[:, e_i]; W1[:, e_j]; Wf[:, e_j]] (edge_transition4 rows)
+      c.r4b = o; o = al256(o + (size_t)2 * (iv.hid + d->c_z) * 4);  // [b1; bf; 0; 0]
     }
   }
   if (use_chain(d)) {
@@ -292,14 +297,16 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     if ((rc = copy_cols(4, 1, H, H, P + k.lb.b, H, 0, s3, D + db.bb, st))) return rc;
     if (cz == 128 && H <= 8)
       if ((rc = fd_chain_build_image_scaled(P + k.lb.w, H, cz, cz, 1, s3, D + db.wb_img, st)) ||
-          (rc = fd_et3_build_bias_image(P + k.lb.w, H, s3, D + db.wb_img3, st)))
+          (rc = fd_et3_build_bias_image(P + k.lb.w, H, s3, D + db.wb_img3, st)) ||
+          (rc = fd_et4_build_bias_image(P + k.lb.w, H, s3, D + db.wb_img4, st)))
         return rc;
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
     if (cz == 128 && (rc = fd_chain_build_image(P + k.dz.w, cz / 4, cz, cz, 0, D + db.wdz_img, st))) return rc;
     if (use_et2(d) && b < d->num_blocks - 1)
       if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st)) ||
-          (rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)))
+          (rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)) ||
+          (rc = fd_et4_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et4, st)))
         return rc;
     if (use_chain(d)) {
       const DChain& c = db.ch;
@@ -325,6 +332,17 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
             (rc = copy_cols(4, 1, cz, cz, P + k.etf.b, cz, 0, 1.f, D + c.b1f + (size_t)iv.hid * 4, st)))
           return rc;
         if ((rc = fd_chain_build_image(P + k.etf.w + cz, cz, iv.cb, iv.hid, 0, D + c.af, st))) return rc;
+        {  // edge_transition4 rows: e_i columns (+ bias) then e_j columns of the first / final layers, one 1024-row image
+          const size_t i1 = fd_chain_image_bytes(iv.hid, iv.cb), i2 = fd_chain_image_bytes(cz, iv.cb);
+          if ((rc = fd_chain_build_image(P + k.et1.w + cz, iv.hid, iv.cb, iv.hid, 0, D + c.r4w, st)) ||
+              (rc = fd_chain_build_image(P + k.etf.w + cz, cz, iv.cb, iv.hid, 0, D + c.r4w + i1, st)) ||
+              (rc = fd_chain_build_image(P + k.et1.w + cz + iv.cb, iv.hid, iv.cb, iv.hid, 0, D + c.r4w + i1 + i2, st)) ||
+              (rc = fd_chain_build_image(P + k.etf.w + cz + iv.cb, cz, iv.cb, iv.hid, 0, D + c.r4w + 2 * i1 + i2, st)) ||
+              (rc = copy_cols(4, 1, iv.hid, iv.hid, P + k.et1.b, iv.hid, 0, 1.f, D + c.r4b, st)) ||
+              (rc = copy_cols(4, 1, cz, cz, P + k.etf.b, cz, 0, 1.f, D + c.r4b + (size_t)iv.hid * 4, st)))
+            return rc;
+          if (hipMemsetAsync(D + c.r4b + (size_t)(iv.hid + cz) * 4, 0, (size_t)(iv.hid + cz) * 4, st) != hipSuccess) return FDIPT_ELAUNCH;
+        }
       }
     }
   }
@@ -363,7 +381,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -398,6 +416,9 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.ipa_parts = take((size_t)8 * R * d->c_s * 4);
   w.vpt = take((size_t)B * H * 96 * (((size_t)N + 31) / 32 * 32) * 2);  // v_pts hi/lo fragment image (attention3 o_pt)
   w.e_bf = take(R * iv.cb * 2);  // bf16 copy of initial_embed(node) (edge_transition3 fetches it by LDS-DMA)  // split-K partial products of the IPA output projection
+  w.r4 = take(R * (size_t)1024 * 4);  // edge_transition4: [A1 | Af | B1 | Bf] rows, then their fold-fragment images
+  w.a1img = take(fd_et4_a_image_bytes(B, N));
+  w.b1img = take(fd_et4_b_image_bytes(B, N));
   w.total = o;
 }
 
@@ -708,7 +729,17 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       // (edge_transition3 only needs e as bf16; the 32-pair kernel reads the fp32 rows)
       const bool et_rows_fused = rbk && iv.cb == 128 && iv.hid == 384 && cz == 128 && use_et2(d) && !getenv("FDIPT_ET_V2") &&
                                  fd_edge_transition3_supported(N);
-      if (et_rows_fused) {
+      // edge_transition4 (N % 4 == 0; FDIPT_ET_V3 keeps the 16-pair kernel): the same launch also produces the e_j rows
+      const bool use_et4 = et_rows_fused && !getenv("FDIPT_ET_V3") && fd_edge_transition4_supported(N);
+      if (use_et4) {
+        RowBlockArgs r;
+        r.M = R; r.in = node_cur; r.ld_in = cs; r.w0 = D + db.ch.et_init; r.b0 = P + k.et_init.b; r.w1 = D + db.ch.r4w;
+        r.b1 = (const float*)(D + db.ch.r4b); r.w2 = nullptr; r.b2 = nullptr; r.residual = nullptr; r.ld_res = 0; r.gamma = r.beta = nullptr;
+        r.rowmask_post = nullptr; r.out = F(w.r4); r.ld_out = 1024; r.out2 = nullptr; r.ld_out2 = 0; r.split = 0;
+        r.hid_bf16 = nullptr; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
+        RC(fd_rowblock(FD_RB_ET4_ROWS, r, st));
+        RC(fd_et4_row_images(F(w.r4), B, N, W + w.a1img, W + w.b1img, st));
+      } else if (et_rows_fused) {
         RowBlockArgs r;
         r.M = R; r.in = node_cur; r.ld_in = cs; r.w0 = D + db.ch.et_init; r.b0 = P + k.et_init.b; r.w1 = D + db.ch.a1af;
         r.b1 = (const float*)(D + db.ch.b1f); r.w2 = nullptr; r.b2 = nullptr; r.residual = nullptr; r.ld_res = 0; r.gamma = r.beta = nullptr;
@@ -751,12 +782,15 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         const bool use_et3 = !getenv("FDIPT_ET_V2") && fd_edge_transition3_supported(N);
         const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
                                !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && N <= 512;
-        t2.wb_img = emit_bias ? D + (use_et3 ? L.blk[b + 1].wb_img3 : L.blk[b + 1].wb_img) : nullptr;
+        t2.wb_img = emit_bias ? D + (use_et4 ? L.blk[b + 1].wb_img4 : use_et3 ? L.blk[b + 1].wb_img3 : L.blk[b + 1].wb_img) : nullptr;
+        t2.a1_img = W + w.a1img; t2.b1_img = W + w.b1img;
         t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
         bias_ready = emit_bias;
         if (use_et3) t2.stream = D + db.et3;
+        if (use_et4) t2.stream = D + db.et4;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
-        if (use_et3) RC(fd_edge_transition3(t2, st));
+        if (use_et4) RC(fd_edge_transition4(t2, st));
+        else if (use_et3) RC(fd_edge_transition3(t2, st));
         else RC(fd_edge_transition2(t2, st));
         if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
       } else {

@@ -42,7 +42,7 @@ struct RBShape {
   static constexpr bool BB = (FLAGS & 8) != 0;                            // fused BackboneUpdate + compose_q_update_vec
   static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0) + (BB ? 6 * NOUT : 0);  // b0 | b1 | b_out | gamma | beta | Wbb
   static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * 32 * XROW + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + (BB ? 4 * 32 * 8 * 4 : 0) + 16;
-  static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 512, "tile shapes");
+  static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 1024, "tile shapes");
 };
 
 template <int K0, int N1, int N2, int NOUT, int FLAGS>
@@ -554,6 +554,7 @@ int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
     case FD_RB_NODE_EMBED_88: return rb_launch<88, 256, 256, 256, 1 | 2 | 4>(a, st);
     case FD_RB_TORSION: return rb_launch<256, 256, 0, 256, 1>(a, st);            // l1 relu l2 + residual
     case FD_RB_ET_ROWS: return rb_launch<256, 128, 0, 512, 0>(a, st);            // e = init(node); [A1 | Af] = [W1e; Wfe] e + b
+    case FD_RB_ET4_ROWS: return rb_launch<256, 128, 0, 1024, 0>(a, st);          // ... [A1 | Af | B1 | Bf]: e_i and e_j columns
     default: return FDIPT_EINVAL;
   }
 }

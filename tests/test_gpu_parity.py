@@ -281,15 +281,16 @@ def test_fails_loudly_on_cpu_tensors():
 
 
 def test_edge_transition_register_kernel_vs_lds_kernel():
-    """bf16 EdgeTransition: the two register-resident kernels (edge_transition3.hip: 16-pair waves, default;
+    """bf16 EdgeTransition: the three register-resident kernels (edge_transition4.hip: 8x4-pair patches with the e_i / e_j
+    parts folded into one k-step, default for N % 4 == 0; edge_transition3.hip: 16-pair waves, FDIPT_ET_V3;
     edge_transition2.hip: 32-pair waves, FDIPT_ET_V2) vs the LDS-chain kernel (pair_mlp.hip, FDIPT_ET_V1) on the
-    full-width network, and all three against the fp32 reference golden."""
+    full-width network, and all four against the fp32 reference golden."""
     import os
     G = load_golden("fwd_full_denovo_n64.npz")
     rows = list(G["trace_rows"])
     outs = {}
-    for tag, var in (("v3", None), ("v2", "FDIPT_ET_V2"), ("v1", "FDIPT_ET_V1")):
-        for v in ("FDIPT_ET_V1", "FDIPT_ET_V2"):
+    for tag, var in (("v4", None), ("v3", "FDIPT_ET_V3"), ("v2", "FDIPT_ET_V2"), ("v1", "FDIPT_ET_V1")):
+        for v in ("FDIPT_ET_V1", "FDIPT_ET_V2", "FDIPT_ET_V3"):
             os.environ.pop(v, None)
         if var:
             os.environ[var] = "1"
@@ -298,19 +299,19 @@ def test_edge_transition_register_kernel_vs_lds_kernel():
             out = net(_feats(G), trace=True)
             outs[tag] = out["trace_edge"].cpu().numpy().copy()
         finally:
-            for v in ("FDIPT_ET_V1", "FDIPT_ET_V2"):
+            for v in ("FDIPT_ET_V1", "FDIPT_ET_V2", "FDIPT_ET_V3"):
                 os.environ.pop(v, None)
-    for tag in ("v1", "v2", "v3"):  # edge embedder (trace slot 0): edge_embed2_kernel vs edge_embed_kernel
+    for tag in ("v1", "v2", "v3", "v4"):  # edge embedder (trace slot 0): edge_embed2_kernel vs edge_embed_kernel
         rel = np.linalg.norm(outs[tag][0][:, rows] - G["tr_edge_init"]) / np.linalg.norm(G["tr_edge_init"])
         assert rel < 1e-2, (tag, "embed", rel)
     assert np.linalg.norm(outs["v1"][0] - outs["v3"][0]) / np.linalg.norm(outs["v1"][0]) < 1e-2
     for b in range(3):
         ref = G[f"tr_edge_{b}"]
-        for tag in ("v1", "v2", "v3"):
+        for tag in ("v1", "v2", "v3", "v4"):
             got = outs[tag][b + 1][:, rows]
             rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
             assert rel < 2e-2, (tag, b, rel)
-        for tag in ("v2", "v3"):
+        for tag in ("v2", "v3", "v4"):
             a, c = outs["v1"][b + 1], outs[tag][b + 1]
             assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-2, (tag, b)
 

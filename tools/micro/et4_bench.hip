@@ -1,0 +1,51 @@
+// Stand-alone timing + in-kernel phase profile of edge_transition4_kernel (build with -DFD_PROF for the profile).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w [-DFD_PROF] [-DE4_ABL=k] tools/micro/et4_bench.hip -o et4_bench
+#include "../../framedipt_amd/csrc/edge_transition4.hip"
+#include <cstdio>
+#include <vector>
+int main(int argc, char** argv) {
+  const int B = 8, N = argc > 1 ? atoi(argv[1]) : 300;
+  const long P = (long)B * N * N, R = (long)B * N;
+  bf16_t* z; float *e, *a1, *af, *b2, *g, *bt, *rm; void* stream;
+  (void)hipMalloc(&z, P * 128 * 2); (void)hipMalloc(&e, R * 128 * 4); (void)hipMalloc(&a1, R * 384 * 4); (void)hipMalloc(&af, R * 128 * 4);
+  (void)hipMalloc(&b2, 384 * 4); (void)hipMalloc(&g, 128 * 4); (void)hipMalloc(&bt, 128 * 4); (void)hipMalloc(&rm, R * 4);
+  (void)hipMalloc(&stream, fd_et4_stream_bytes());
+  (void)hipMemset(z, 0, P * 128 * 2); (void)hipMemset(e, 0, R * 128 * 4); (void)hipMemset(a1, 0, R * 384 * 4); (void)hipMemset(af, 0, R * 128 * 4);
+  (void)hipMemset(b2, 0, 384 * 4); (void)hipMemset(g, 0, 128 * 4); (void)hipMemset(bt, 0, 128 * 4); (void)hipMemset(rm, 0, R * 4);
+  (void)hipMemset(stream, 0, fd_et4_stream_bytes());
+  ET2Args a; a.B = B; a.N = N; a.z_in = z; a.z_out = z; a.e = e; a.a1 = a1; a.af = af; a.stream = stream; a.b2 = b2; a.gamma = g;
+  a.beta = bt; a.res_mask = rm; a.trace = nullptr;
+  { void *ai, *bi; (void)hipMalloc(&ai, fd_et4_a_image_bytes(B, N)); (void)hipMemset(ai, 0, fd_et4_a_image_bytes(B, N));
+    (void)hipMalloc(&bi, fd_et4_b_image_bytes(B, N)); (void)hipMemset(bi, 0, fd_et4_b_image_bytes(B, N)); a.a1_img = ai; a.b1_img = bi; a.e_bf16 = nullptr; }
+  {  // next block's pair bias from the epilogue (argv[2] = 0 disables)
+    void* wimg; float* bo; const long Np = (N + 31) / 32 * 32;
+    (void)hipMalloc(&wimg, 8192); (void)hipMemset(wimg, 0, 8192); (void)hipMalloc(&bo, (size_t)B * 8 * Np * Np * 4);
+    a.wb_img = (argc > 2 && atoi(argv[2]) == 0) ? nullptr : wimg; a.bb = b2; a.bias_out = bo; a.H = 8;
+  }
+  hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+  for (int i = 0; i < 3; ++i) fd_edge_transition4(a, 0);
+  (void)hipEventRecord(t0, 0);
+  const int iters = 20;
+  for (int i = 0; i < iters; ++i) fd_edge_transition4(a, 0);
+  (void)hipEventRecord(t1, 0); (void)hipEventSynchronize(t1);
+  float ms; (void)hipEventElapsedTime(&ms, t0, t1);
+  const double flops = 655360.0 * P;
+  printf("ET4 N=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 2500)\n", N, ms / iters, flops / (ms / iters) / 1e9, flops / (ms / iters) / 1e9 / 25.0);
+#ifdef E4_PROF
+  {
+    std::vector<unsigned> h(256 * 8);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(e4_prof), h.size() * 4);
+    const char* names[6] = {"kernel prologue", "layer 1 (4 chunks, 108 MFMA/wave)", "layer 2 (12 chunks, 288)", "final (4 chunks, 132)", "request + LN epilogue + stores", "tile-end wait + barrier"};
+    const int n_wt = B * ((N + 7) / 8) * (N / 4), n_tiles = (n_wt + 7) / 8;
+    double tot = 0;
+    for (int k = 0; k < 6; ++k) {
+      double s = 0;
+      for (int b = 0; b < 256; ++b) s += h[b * 8 + k];
+      s /= 256.0; tot += s;
+      printf("  %-36s %9.0f cyc per block-launch, %7.0f per tile\n", names[k], s, s / (n_tiles / 256.0));
+    }
+    printf("  %-36s %9.0f cyc (wave 0)\n", "total", tot);
+  }
+#endif
+  return 0;
+}
