@@ -45,7 +45,8 @@ struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading 
 };
 
 // main loop shared by every GEMM kernel: acc[TM][TN] (32x32 tiles of this wave) = A[m0.., :K] * W[n0.., :K]^T
-template <class P, class AT, class WT, int BM, int BN>
+// SWAP: the MFMA operands exchanged -> the tiles come out transposed (lane = row m, registers = 4-runs of columns n)
+template <class P, class AT, class WT, int BM, int BN, bool SWAP = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[BM / 64][BN / 64], int M, int N, int K,
                                           const AT* __restrict__ A, int lda, const WT* __restrict__ W, int ldw,
                                           typename P::T* smem, int m0, int n0, int tid) {
@@ -82,8 +83,12 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[BM / 64][BN / 64], int M
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
-          P::mma(acc[i][jn], Ac + ((wr * TM + i) * 32 + (lane & 31)) * LDT + k,
-                 Wc + ((wc * TN + jn) * 32 + (lane & 31)) * LDT + k, hi);
+          if constexpr (SWAP)
+            P::mma(acc[i][jn], Wc + ((wc * TN + jn) * 32 + (lane & 31)) * LDT + k,
+                   Ac + ((wr * TM + i) * 32 + (lane & 31)) * LDT + k, hi);
+          else
+            P::mma(acc[i][jn], Ac + ((wr * TM + i) * 32 + (lane & 31)) * LDT + k,
+                   Wc + ((wc * TN + jn) * 32 + (lane & 31)) * LDT + k, hi);
     if (kt + 1 < nk) {
       pa.store(An, tid);
       pw.store(An + BM * LDT, tid);
@@ -180,6 +185,39 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int M = a.B * a.N, HC = a.H * a.C, NOUT = 3 * HC + a.PT;
   f32x16 acc[TM][TN];
+  const int ntl_ = a.Np >> 5;
+  // Q and K column blocks (uniform per block: H*C and 2C are multiples of 128) run with the MFMA operands exchanged: a lane
+  // then owns a row and 4-runs of channels, i.e. 8 B pieces of the fragment-order images; the two lane halves and the 32 rows
+  // of a tile make 512 contiguous bytes per store instruction (the untransposed epilogue wrote single bf16 values)
+  const bool qk_block = (HC % BN) == 0 && (a.C % BN) == 0 && (n0 < HC || (n0 < 3 * HC && ((n0 - HC) % (2 * a.C)) < a.C));
+  if (qk_block) {
+    gemm_tile<P, float, bf16_t, BM, BN, true>(acc, M, NOUT, a.K, a.A, a.lda, (const bf16_t*)a.W, a.K, smem, m0, n0, tid);
+    const bool isq = n0 < HC;
+    const int nn0 = isq ? n0 : n0 - HC, hh = isq ? nn0 / a.C : nn0 / (2 * a.C), cb = isq ? nn0 % a.C : nn0 % (2 * a.C);
+    bf16_t* dst0 = isq ? a.Qb : a.Kb;
+    const float sc = isq ? a.qscale : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wr * TM + i) * 32 + (lane & 31);
+      if (m >= M) continue;
+      const int b = m / a.N, r = m - b * a.N;
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int ct = cb + (wc * TN + jn) * 32;  // first channel of this 32-channel tile (within the head)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cc = ct + 8 * g + 4 * (lane >> 5);
+          const f32x4 bv = *(const f32x4*)(a.bias + n0 + (wc * TN + jn) * 32 + 8 * g + 4 * (lane >> 5));
+          u16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = f2bf((acc[i][jn][4 * g + q] + bv[q]) * sc);
+          *(u16x4*)(dst0 + ((((((long)b * a.H + hh) * ntl_ + (r >> 5)) * (a.C >> 4) + (cc >> 4)) * 64 + ((cc >> 3) & 1) * 32 + (r & 31)) << 3) +
+                    (cc & 7)) = o;
+        }
+      }
+    }
+    return;
+  }
   gemm_tile<P, float, bf16_t, BM, BN>(acc, M, NOUT, a.K, a.A, a.lda, (const bf16_t*)a.W, a.K, smem, m0, n0, tid);
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
@@ -252,6 +290,12 @@ __global__ void kv_zero_pad_kernel(long BH, int N, int Np, int C, bf16_t* __rest
   }
 }
 
+// zero the padded keys of Kb / Vt (once per forward), for callers that run the projection elsewhere (ipa_proj2.hip)
+int fd_ipa_proj_zero_pads(const ProjArgs& a, hipStream_t st) {
+  if (a.Np > a.N) hipLaunchKernelGGL(kv_zero_pad_kernel, dim3(256), dim3(256), 0, st, (long)a.B * a.H, a.N, a.Np, a.C, a.Kb, a.Vt);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st) {
   const int M = a.B * a.N, NOUT = 3 * a.H * a.C + a.PT;
   if ((a.K & 7) || (a.lda & 3)) return FDIPT_EINVAL;

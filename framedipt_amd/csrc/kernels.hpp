@@ -144,6 +144,7 @@ struct ProjArgs {
   const float* A;             // [B*N, lda] node representation
   int lda;
   const void* W;              // [3*H*C + PT, K] bf16 fused projection weight
+  const void* W_img;          // the same as a fragment image, zero-padded to whole 128-column blocks (ipa_proj2.hip), or NULL
   const float* bias;          // [3*H*C + PT]
   float qscale;               // sqrt(1/(3C)) folded into Q
   bf16_t *Qb, *Kb, *Vt;
@@ -151,6 +152,9 @@ struct ProjArgs {
   int zero_pads;              // also zero the padded keys [N, Np) of Kb / Vt (first use of the buffers in a forward)
 };
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
+int fd_ipa_proj_zero_pads(const ProjArgs& a, hipStream_t st);
+int fd_ipa_proj2_supported(const ProjArgs& a);
+int fd_ipa_proj2(const ProjArgs& a, hipStream_t st);  // second generation (ipa_proj2.hip): same outputs
 
 struct Attn3Args {
   int B, N, H, Np;

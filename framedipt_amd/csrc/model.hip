@@ -96,7 +96,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et2, et3, et4, wdz_t, wdz_img; DChain ch; };
+struct DBlock { size_t wproj, wproj_img, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et2, et3, et4, wdz_t, wdz_img; DChain ch; };
 struct DLayout {
   size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -137,6 +137,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   if (use_et2(d)) o = al256(o + fd_ee2_image_bytes());
   for (int b = 0; b < d->num_blocks; ++b) {
     L.blk[b].wproj = o; o = al256(o + (size_t)iv.proj_out * d->c_s * L.esz);
+    L.blk[b].wproj_img = o;  // the same matrix as a fragment image, zero-padded to whole 128-column blocks (ipa_proj2.hip)
+    if (L.esz == 2 && d->c_s == 256) o = al256(o + (size_t)((iv.proj_out + 127) / 128) * 65536);
     L.blk[b].bproj = o; o = al256(o + (size_t)iv.proj_out * 4);
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
@@ -282,7 +284,13 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     // fused projection [q | kv | q_pts | kv_pts] rows (ipa_pytorch.py:202-239)
     const LinW* parts[4] = {&k.q, &k.kv, &k.qp, &k.kvp};
     long row = 0;
+    const bool proj_img = L.esz == 2 && cs == 256;
+    if (proj_img && hipMemsetAsync(D + db.wproj_img, 0, (size_t)((iv.proj_out + 127) / 128) * 65536, st) != hipSuccess) return FDIPT_ELAUNCH;
     for (int p = 0; p < 4; ++p) {
+      // (tile-major images: stacking row blocks of 32 = concatenation)
+      if (proj_img && (parts[p]->out % 32 || (rc = fd_chain_build_image(P + parts[p]->w, parts[p]->out, cs, cs, 0,
+                                                                         D + db.wproj_img + (size_t)(row / 32) * (cs / 16) * 1024, st))))
+        return rc ? rc : FDIPT_ESIZE;
       if ((rc = copy_cols(L.esz, parts[p]->out, cs, cs, P + parts[p]->w, cs, 0, 1.f, D + db.wproj + row * cs * L.esz, st)))
         return rc;
       if ((rc = copy_cols(4, 1, parts[p]->out, parts[p]->out, P + parts[p]->b, parts[p]->out, 0, 1.f,
@@ -576,7 +584,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       pj.W = D + db.wproj; pj.bias = (const float*)(D + db.bproj); pj.qscale = sqrtf(1.0f / (3.0f * (float)C));
       pj.Qb = (bf16_t*)(W + w.qb); pj.Kb = (bf16_t*)(W + w.kb); pj.Vt = (bf16_t*)(W + w.vt); pj.pts = F(w.pts);
       pj.zero_pads = b == 0;
-      RC(fd_ipa_proj(pj, st));
+      pj.W_img = (cs == 256 && !getenv("FDIPT_PROJ_V1")) ? D + db.wproj_img : nullptr;
+      // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
+      if (fd_ipa_proj2_supported(pj)) {
+        if (pj.zero_pads && Np > N) { ProjArgs pz = pj; pz.W_img = nullptr; RC(fd_ipa_proj_zero_pads(pz, st)); }
+        RC(fd_ipa_proj2(pj, st));
+      } else RC(fd_ipa_proj(pj, st));
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
       RC(fd_points(pa, st));
       if (!bias_ready)  // blocks >= 1: already emitted by the previous block's EdgeTransition epilogue

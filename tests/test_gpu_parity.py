@@ -414,10 +414,11 @@ def test_baseline_config_shapes_run(n, B, prec, inp):
         np.testing.assert_allclose(x_1[fixed, 4:], x_T[fixed, 4:], atol=1e-4)
 
 
-@pytest.mark.parametrize("n,B", [(77, 3), (301, 2), (129, 4)])
+@pytest.mark.parametrize("n,B", [(77, 3), (301, 2), (129, 4), (44, 3), (100, 2)])
 def test_forward_bf16_vs_fp32_path_ragged_sizes(n, B):
     """Ragged shapes (N not a multiple of 4 / 32; 32-row blocks, 128-pair tiles and key tiles that straddle samples and
-    padded keys): the bf16 kernels against the fp32 path of the same network (itself pinned to the reference goldens)."""
+    padded keys; N % 8 == 4: the 8 x 4 patches of edge_transition4 straddle two samples): the bf16 kernels against the
+    fp32 path of the same network (itself pinned to the reference goldens)."""
     from framedipt_amd import config
     from framedipt_amd.diffusion import SE3Diffuser
     from framedipt_amd.model import ScoreNetwork
@@ -441,6 +442,10 @@ def test_forward_bf16_vs_fp32_path_ragged_sizes(n, B):
     for b in range(1, tn32.shape[0]):
         rel = np.linalg.norm(tn16[b] - tn32[b]) / np.linalg.norm(tn32[b])
         assert rel < 3e-2, (b, rel)
+    te32, te16 = outs["fp32"]["trace_edge"], outs["bf16"]["trace_edge"]
+    for b in range(te32.shape[0]):  # edge embedder, then the EdgeTransition of every block but the last
+        rel = np.linalg.norm(te16[b] - te32[b]) / np.linalg.norm(te32[b])
+        assert rel < 3e-2, ("edge", b, rel)
     np.testing.assert_allclose(outs["bf16"]["rigids"][..., 4:], outs["fp32"]["rigids"][..., 4:], atol=5e-2)
     # psi is the unit vector of a small 2-vector (ill-conditioned where its norm is tiny): bound the outlier fraction
     bad = np.abs(outs["bf16"]["psi"] - outs["fp32"]["psi"]).max(-1) > 0.1
