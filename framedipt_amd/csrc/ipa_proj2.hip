@@ -19,9 +19,15 @@
 #define P2_K 256
 #define P2_KS (P2_K / 16)
 #define P2_WBLK (4 * P2_KS * 1024)          // one 128-column block of the weight image: 64 KB
-#define P2_XROW (P2_K * 2 + 16)             // bf16 activation row in LDS (+16 B: conflict-free b128 reads)
+#define P2_XROW (P2_K * 2)                  // bf16 activation row in LDS: 128 rows = exactly one weight buffer (buffer 1)
 #define P2_LDS (2 * P2_WBLK)
 
+typedef __bf16 p2_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned p2_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned p2_cvt_pk(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(p2_f32x2{lo, hi}, p2_bf16x2));
+}
 __device__ __forceinline__ int p2_perm16(int pos) { return 4 * (pos >> 3) + (pos & 3) + 8 * ((pos & 7) >> 2); }
 __device__ __forceinline__ void p2_dma16(const void* gsrc, unsigned lds_dst) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
@@ -39,25 +45,6 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
   const int M = a.B * a.N, HC = a.H * a.C, NOUT = 3 * HC + a.PT, ntl = a.Np >> 5;
   const int m0 = blockIdx.x * 128;
   const char* wimg = (const char*)a.W_img;
-  // ---- activation rows: fp32 -> bf16 -> LDS (both weight buffers' space), once
-  {
-#pragma unroll 16
-    for (int it = 0; it < 32; ++it) {  // 128 rows x 64 float4
-      const int idx = tid + it * FD_THREADS, r = idx >> 6, c4 = idx & 63;
-      const int gr = m0 + r < M ? m0 + r : M - 1;
-      const f32x4 x = *(const f32x4*)(a.A + (long)gr * a.lda + 4 * c4);
-      const u16x4 h = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
-      *(u16x4*)(smem + r * P2_XROW + 8 * c4) = h;
-    }
-  }
-  __syncthreads();
-  bf16x8 Af[2][P2_KS];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int s = 0; s < P2_KS; ++s) Af[i][s] = p2_frag(lds0 + ((wr * 2 + i) * 32 + li) * P2_XROW + 32 * s + 16 * hi);
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers before the buffer is overwritten
-  __syncthreads();
   // ---- column blocks of this block's class, in class order: k-th Q/K block / k-th V-or-point block -> column block index
   const int nq = HC / 128, per_head = (2 * a.C) / 128, n_class = QK ? 2 * nq : n_cblk - 2 * nq;
   auto cblk_of = [&](int k) {
@@ -72,7 +59,29 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
     for (int u = 0; u < P2_WBLK / (FD_THREADS * 16); ++u)
       p2_dma16(src + (size_t)(u * FD_THREADS + tid) * 16, lds0 + buf * P2_WBLK + (unsigned)(u * FD_THREADS + (tid & ~63)) * 16);
   };
-  if (kb < n_class) request(cblk_of(kb), 0);
+  if (kb < n_class) request(cblk_of(kb), 0);  // the first weight block is on its way while the activations are staged
+  // ---- activation rows: fp32 -> bf16 -> LDS (buffer 1: 128 rows x 512 B, 16 B chunk c of row r at c ^ (r & 15)), once
+  {
+    char* xs = smem + P2_WBLK;
+#pragma unroll 16
+    for (int it = 0; it < 32; ++it) {  // 128 rows x 64 float4
+      const int idx = tid + it * FD_THREADS, r = idx >> 6, c4 = idx & 63;
+      const int gr = m0 + r < M ? m0 + r : M - 1;
+      const f32x4 x = *(const f32x4*)(a.A + (long)gr * a.lda + 4 * c4);
+      const u16x4 h = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+      *(u16x4*)(xs + r * P2_XROW + (((c4 >> 1) ^ (r & 15)) << 4) + 8 * (c4 & 1)) = h;
+    }
+  }
+  __syncthreads();
+  bf16x8 Af[2][P2_KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s = 0; s < P2_KS; ++s) {
+      const int r = (wr * 2 + i) * 32 + li;
+      Af[i][s] = p2_frag(lds0 + P2_WBLK + r * P2_XROW + (((2 * s + hi) ^ (r & 15)) << 4));
+    }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers before the buffer is overwritten
   // ---- store addressing, split into a part that depends on the row(s) of a register group (computed once) and a part that
   // depends on the column block (once per block): an epilogue unit adds the two and a compile-time constant
   //   Q / K images (lane = row): element ((((b H + h) ntl + (r >> 5)) (C >> 4) + (cc >> 4)) 64 + ((cc >> 3) & 1) 32 + (r & 31)) 8 + (cc & 7)
@@ -104,12 +113,11 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       if (qk_row[i] < 0) return;
       const f32x4 bv = bq[j][g];
       const float sc = kind == 0 ? a.qscale : 1.f;
-      u16x4 o;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = f2bf((acc[i][j][4 * g + q] + bv[q]) * sc);
+      const p2_u32x2 o = {p2_cvt_pk((acc[i][j][4 * g] + bv[0]) * sc, (acc[i][j][4 * g + 1] + bv[1]) * sc),
+                          p2_cvt_pk((acc[i][j][4 * g + 2] + bv[2]) * sc, (acc[i][j][4 * g + 3] + bv[3]) * sc)};
       // cc = cbase + (2 wc + j) 32 + 8 g + 4 hi: cc >> 4 = (cbase >> 4) + 2 (2 wc + j) + (g >> 1), (cc >> 3) & 1 = g & 1, cc & 7 = 4 hi
       bf16_t* dst = (kind == 0 ? a.Qb : a.Kb) + (long)qk_row[i] + cpart[0] + ((2 * j + (g >> 1)) * 64 + (g & 1) * 32) * 8;
-      *(u16x4*)dst = o;
+      *(p2_u32x2*)dst = o;
     } else {
       if (cpart[j] < 0) return;
       const float bv = bq[j][0][0];
@@ -118,8 +126,8 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + bv;
       if (kind == 2) {
         if (v_row[i][g] < 0) return;
-        const u16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *(u16x4*)(a.Vt + (long)v_row[i][g] + cpart[j]) = o;
+        const p2_u32x2 o = {p2_cvt_pk(v[0], v[1]), p2_cvt_pk(v[2], v[3])};
+        *(p2_u32x2*)(a.Vt + (long)v_row[i][g] + cpart[j]) = o;
       } else {
         if (p_row[i][g] < 0) return;
         float* dst = a.pts + (long)p_row[i][g] + cpart[j];
@@ -179,23 +187,36 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
         for (int r = 0; r < 16; ++r) accN[i][j][r] = 0.f;
     (void)k;
     const unsigned wb = lds0 + bufc * P2_WBLK + (wc * 2) * (P2_KS * 1024) + lane * 16;
+    // weight fragments two k-steps ahead of their MFMAs (one wave per SIMD: nothing else hides the LDS latency); pinned
+    constexpr int DEPTH = 3;
+    bf16x8 w0[DEPTH], w1[DEPTH];
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s) {
+      w0[s] = p2_frag(wb + s * 1024);
+      w1[s] = p2_frag(wb + (P2_KS + s) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < P2_KS; ++s) {
-      const bf16x8 w0 = p2_frag(wb + s * 1024), w1 = p2_frag(wb + (P2_KS + s) * 1024);
+      if (s + DEPTH - 1 < P2_KS) {
+        w0[(s + DEPTH - 1) % DEPTH] = p2_frag(wb + (s + DEPTH - 1) * 1024);
+        w1[(s + DEPTH - 1) % DEPTH] = p2_frag(wb + (P2_KS + s + DEPTH - 1) * 1024);
+      }
       if constexpr (QK) {  // operands exchanged: lane = row
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          accN[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, Af[i][s], accN[i][0], 0, 0, 0);
-          accN[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, Af[i][s], accN[i][1], 0, 0, 0);
+          accN[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s % DEPTH], Af[i][s], accN[i][0], 0, 0, 0);
+          accN[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s % DEPTH], Af[i][s], accN[i][1], 0, 0, 0);
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          accN[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][s], w0, accN[i][0], 0, 0, 0);
-          accN[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][s], w1, accN[i][1], 0, 0, 0);
+          accN[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][s], w0[s % DEPTH], accN[i][0], 0, 0, 0);
+          accN[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][s], w1[s % DEPTH], accN[i][1], 0, 0, 0);
         }
       }
       if (has_prev) epi_unit(accP, bqP, cpP, kindP, s >> 3, (s >> 2) & 1, s & 3);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   f32x16 acc0[2][2], acc1[2][2];
