@@ -29,7 +29,7 @@
 #define E4_D1 3   // weight-fragment ring depths: layer 1, layer 2, final layer
 #endif
 #ifndef E4_D2
-#define E4_D2 4
+#define E4_D2 3
 #endif
 #ifndef E4_DF
 #define E4_DF 6
@@ -290,7 +290,12 @@ typedef __attribute__((address_space(3))) e4_u32x2* e4_lds_w64;
 template <int SLOT>
 __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M) {
   const int p = lane & 31, half = lane >> 5;
-  if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math)
+  if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math); the pair mask is requested here
+    {
+      int row = 8 * E.t.rt + (p >> 2);
+      if (row > M - 1) row = M - 1;
+      E.em = a.res_mask[row] * a.res_mask[(row / a.N) * a.N + 4 * E.t.jt + (p & 3)];
+    }
     f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -397,7 +402,15 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
   const unsigned vec = lds0 + E4_VOFF;          // b2[384] | gamma[128] | beta[128] (f32)
   const unsigned wbi = lds0 + E4_VOFF + 2560;   // linear_b fragments of the next block
-  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = tid0 >> 6;
+  // the lane index is recomputed where needed (v_mbcnt: no register carried through the tile), the wave index is scalar:
+  // every register that stays live through layer 2 is a spill, and a spilled dword is 256 B of HBM traffic per wave and tile
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto lane_id = [] {
+    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  const int lane0 = lane_id(), tid0 = wave * 64 + lane0;
   const int N = a.N, NJ4 = N >> 2, M = a.B * N;
   const char* stream = (const char*)a.stream;
   int tile = blockIdx.x;
@@ -419,16 +432,10 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     return (lane >> 5) ? (const char*)a.b1_img + ((size_t)(t.b0 * NJ4 + t.jt) * 16) * 512 + (lane & 31) * 16
                        : (const char*)a.a1_img + ((size_t)t.rt * 16) * 512 + (lane & 31) * 16;
   };
-  auto mask_of = [&](const E4Tile& t, int lane) {
-    int row = 8 * t.rt + ((lane & 31) >> 2);
-    if (row > M - 1) row = M - 1;
-    return a.res_mask[row] * a.res_mask[(row / N) * N + 4 * t.jt + (lane & 3)];
-  };
   const char* fold_base = fold_ptr(tc, lane0);
   bf16x8 FA[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) FA[k] = e4_gfrag(fold_base + k * 512);
-  float em_cur = mask_of(tc, lane0);
   E4Epi E;
   e4_dma_wait();
   __syncthreads();
@@ -437,10 +444,9 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
   for (;;) {
     // opaque per-iteration copies: keep hipcc from hoisting the loop-invariant LDS / global address arithmetic of the whole
     // tile body out of the loop (hundreds of values that would stay live across it and spill)
-    int lane = lane0, tid = tid0;
-    asm volatile("" : "+v"(lane), "+v"(tid));
+    const int lane = lane_id(), tid = wave * 64 + lane;
     const int p = lane & 31, half = lane >> 5;
-    const unsigned zst = lds0 + E4_ZOFF + (tid >> 6) * 8192;
+    const unsigned zst = lds0 + E4_ZOFF + wave * 8192;
     const unsigned zrow = zst + p * 256;
 
     bf16x8 H1[24], H2[24];
@@ -516,9 +522,8 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
       bf16x8 zb[2];
       unsigned zrow2 = 0, zx = 0;  // the z row address again, from an opaque copy (otherwise the 8 layer-1 addresses stay live)
       if (cc == 0) {
-        int l2 = lane;
-        asm volatile("" : "+v"(l2));
-        zrow2 = lds0 + E4_ZOFF + (tid >> 6) * 8192 + (l2 & 31) * 256;
+        const int l2 = lane_id();
+        zrow2 = lds0 + E4_ZOFF + wave * 8192 + (l2 & 31) * 256;
         zx = (l2 >> 5) ^ (l2 & 15);
         zb[0] = e4_frag(zrow2 + (zx << 4));
       }
@@ -547,17 +552,15 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     E4_STAMP(3);
     // ================= tile boundary (no barrier: the z rows and the store staging are wave-private): the next tile's operands
     // are requested, THEN the LayerNorm epilogue of this tile runs under their latency
-    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * 8 + (tid >> 6), n_wt, N, NJ4);
+    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * 8 + wave, n_wt, N, NJ4);
     if (has_next) e4_request_z(a, tn, lane, zst, M);
     fold_base = fold_ptr(tn, lane);
 #pragma unroll
     for (int k = 0; k < 3; ++k) FA[k] = e4_gfrag(fold_base + k * 512);  // (the last tile re-reads its own: no branch, no phi)
     E.t = tc;
-    E.em = em_cur;
-    em_cur = mask_of(tn, lane);
     if (!(E4_ABL & 1)) {
       E4EpiTmp X;
-      const unsigned stg = lds0 + E4_SOFF + (tid >> 6) * 2048;
+      const unsigned stg = lds0 + E4_SOFF + wave * 2048;
       e4_epi<0>(E, X, a, lane, vec, wbi, stg, M);
       e4_epi<1>(E, X, a, lane, vec, wbi, stg, M);
       e4_epi<2>(E, X, a, lane, vec, wbi, stg, M);
