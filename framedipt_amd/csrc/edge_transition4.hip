@@ -176,11 +176,11 @@ __device__ __forceinline__ bf16x8 e4_frag(unsigned off) { return __builtin_bit_c
 __device__ __forceinline__ f32x4 e4_ldsf4(unsigned off) { return *(e4_lds_f32x4)(unsigned long)off; }
 __device__ __forceinline__ bf16x8 e4_gfrag(const char* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
 template <int BYTES>
-__device__ __forceinline__ void e4_dma_chunk(const char* __restrict__ src, unsigned dst, int tid) {
+__device__ __forceinline__ void e4_dma_chunk(const char* __restrict__ src, unsigned dst, int tid, int wave) {
   static_assert(BYTES % (E4_THREADS * 16) == 0, "whole DMA instructions");
 #pragma unroll
   for (int u = 0; u < BYTES / (E4_THREADS * 16); ++u)
-    if (!(E4_ABL & 4)) e4_dma16(src + (size_t)(u * E4_THREADS + tid) * 16, dst + (unsigned)(u * E4_THREADS + (tid & ~63)) * 16);
+    if (!(E4_ABL & 4)) e4_dma16(src + (size_t)(u * E4_THREADS + tid) * 16, dst + (unsigned)(u * E4_THREADS + wave * 64) * 16);  // (scalar destination)
 }
 __device__ __forceinline__ f32x16 e4_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   if (E4_ABL & 2) { c[0] += (float)a[0]; return c; }
@@ -421,21 +421,24 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
   E4Tile tc = e4_tile_of(tile * 8 + wave, n_wt, N, NJ4);
   // ---- first tile: z rows, first weight chunk, small vectors
   e4_request_z(a, tc, lane0, lds0 + E4_ZOFF + wave * 8192, M);
-  e4_dma_chunk<24576>(stream, lds0, tid0);
+  e4_dma_chunk<24576>(stream, lds0, tid0, wave);
   if (tid0 < 160) {
     const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
     e4_dma16(src, vec + (tid0 & ~63) * 16);
   }
   if (a.wb_img) e4_dma16((const char*)a.wb_img + tid0 * 16, wbi + (tid0 & ~63) * 16);
   // fold fragments of the first layer-1 chunk (tiles 0..2): lanes < 32 read the row image, lanes >= 32 the column image
+  // 32-bit byte offset from the row image (the column image follows it in the same workspace): one register, scalar base
   auto fold_ptr = [&](const E4Tile& t, int lane) {
-    return (lane >> 5) ? (const char*)a.b1_img + ((size_t)(t.b0 * NJ4 + t.jt) * 16) * 512 + (lane & 31) * 16
-                       : (const char*)a.a1_img + ((size_t)t.rt * 16) * 512 + (lane & 31) * 16;
+    const unsigned fold_b1 = (unsigned)((const char*)a.b1_img - (const char*)a.a1_img);
+    const unsigned ob = fold_b1 + (unsigned)((t.b0 * NJ4 + t.jt) * 16) * 512u, oa = (unsigned)(t.rt * 16) * 512u;  // scalar
+    return oa + (unsigned)(lane >> 5) * (ob - oa) + (lane & 31) * 16;
   };
-  const char* fold_base = fold_ptr(tc, lane0);
+  auto fold_ld = [&](unsigned off) { return e4_gfrag((const char*)a.a1_img + off); };
+  unsigned fold_base = fold_ptr(tc, lane0);
   bf16x8 FA[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) FA[k] = e4_gfrag(fold_base + k * 512);
+  for (int k = 0; k < 3; ++k) FA[k] = fold_ld(fold_base + k * 512);
   E4Epi E;
   e4_dma_wait();
   __syncthreads();
@@ -460,12 +463,12 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
       bf16x8 FC = FA[0];   // fold fragment of the current tile; the next one is requested a tile ahead
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((cc + 1) & 1) * E4_BUF, tid);
+        e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((cc + 1) & 1) * E4_BUF, tid, wave);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int T = 3 * cc + u;
           bf16x8 FNx = FC;
-          if (T + 1 < 12) FNx = T + 1 < 3 ? FA[T + 1] : e4_gfrag(fold_base + (T + 1) * 512);
+          if (T + 1 < 12) FNx = T + 1 < 3 ? FA[T + 1] : fold_ld(fold_base + (T + 1) * 512);
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -483,8 +486,8 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     // ================= layer 2: 12 chunks x 1 tile, K = 384; the accumulator starts as b2
 #pragma unroll
     for (int T = 0; T < 12; ++T) {
-      if (T < 11) e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid);
-      else e4_dma_chunk<32768>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid);  // first final-layer chunk
+      if (T < 11) e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid, wave);
+      else e4_dma_chunk<32768>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid, wave);  // first final-layer chunk
       f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -510,11 +513,12 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     bf16x8 FL[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      if (cc < 3) e4_dma_chunk<32768>(stream + soff + 32768, lds0 + ((cc + 1) & 1) * E4_BUF, tid);
-      else if (has_next) e4_dma_chunk<24576>(stream, lds0, tid);  // the next tile's first chunk: buffer 0 is free since chunk 18
+      if (cc < 3) e4_dma_chunk<32768>(stream + soff + 32768, lds0 + ((cc + 1) & 1) * E4_BUF, tid, wave);
+      else if (has_next) e4_dma_chunk<24576>(stream, lds0, tid, wave);  // the next tile's first chunk: buffer 0 is free since chunk 18
       if (cc == 2) {
+        const unsigned fb = fold_ptr(tc, lane_id());  // recomputed: carried through layer 2 it would be a spilled register
 #pragma unroll
-        for (int k = 0; k < 4; ++k) FL[k] = e4_gfrag(fold_base + (12 + k) * 512);
+        for (int k = 0; k < 4; ++k) FL[k] = fold_ld(fb + (12 + k) * 512);
       }
       const unsigned pa = lds0 + (cc & 1) * E4_BUF + lane * 16;
       constexpr int NF = 32, DEPTH = E4_DF;  // flat ring over the chunk's 32 fragments
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     if (has_next) e4_request_z(a, tn, lane, zst, M);
     fold_base = fold_ptr(tn, lane);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) FA[k] = e4_gfrag(fold_base + k * 512);  // (the last tile re-reads its own: no branch, no phi)
+    for (int k = 0; k < 3; ++k) FA[k] = fold_ld(fold_base + k * 512);  // (the last tile re-reads its own: no branch, no phi)
     E.t = tc;
     if (!(E4_ABL & 1)) {
       E4EpiTmp X;
