@@ -284,7 +284,7 @@ struct E4EpiTmp {     // lives inside one epilogue run only
   float s1, s2;
   long prow;          // this lane's pair (row of z)
   long srow[2];       // the pairs whose 64 B row segments this lane stores (rows (lane >> 2) and 16 + (lane >> 2) of the patch)
-  bool valid, svalid[2], all_one;
+  bool valid, svalid[2];
 };
 typedef __attribute__((address_space(3))) e4_u32x2* e4_lds_w64;
 template <int SLOT>
@@ -323,7 +323,6 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
       X.svalid[k] = E.t.valid && r2 < M;
       X.srow[k] = (long)(r2 < M ? r2 : M - 1) * a.N + 4 * E.t.jt + (pr & 3);
     }
-    X.all_one = __builtin_amdgcn_ballot_w64(E.em != 1.0f) == 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) X.accb[r] = 0.f;
   } else if constexpr (SLOT >= 2 && SLOT < 6) {  // one 32-feature tile: normalise, mask, bf16, store, its share of the pair bias
@@ -349,10 +348,8 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
         o[2 * k] = __builtin_elementwise_fma(o0, f32x2{gm[k][0], gm[k][1]}, f32x2{bt[k][0], bt[k][1]});
         o[2 * k + 1] = __builtin_elementwise_fma(o1, f32x2{gm[k][2], gm[k][3]}, f32x2{bt[k][2], bt[k][3]});
       }
-      if (!X.all_one) {  // wave-uniform; the usual case (no padding) skips the mask multiply
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] *= f32x2{E.em, E.em};
-      }
+      for (int k = 0; k < 4; ++k) o[k] *= f32x2{E.em, E.em};  // (a wave-uniform "all ones" test gets if-converted into selects: dearer)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int g = 2 * h2 + k;
@@ -592,6 +589,10 @@ int fd_edge_transition4_supported(int N) { return N >= 8 && N <= 2048 && N % 4 =
 int fd_edge_transition4(const ET2Args& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
   if (n_pairs >= (1L << 31) - 256 || !a.a1_img || !a.b1_img || a.N % 4) return FDIPT_EINVAL;  // 32-bit pair indices in the kernel
+  {  // the kernel addresses both fold images with 32-bit offsets from a1_img
+    const long d = (const char*)a.b1_img - (const char*)a.a1_img;
+    if (d < 0 || d + (long)fd_et4_b_image_bytes(a.B, a.N) >= (1L << 32)) return FDIPT_EINVAL;
+  }
   const int n_wt = ((a.B * a.N + 7) / 8) * (a.N / 4);
   const int n_tiles = cdiv(n_wt, 8);
   static bool attr_set = false;

@@ -15,8 +15,8 @@ int main(int argc, char** argv) {
   (void)hipMemset(stream, 0, fd_et4_stream_bytes());
   ET2Args a; a.B = B; a.N = N; a.z_in = z; a.z_out = z; a.e = e; a.a1 = a1; a.af = af; a.stream = stream; a.b2 = b2; a.gamma = g;
   a.beta = bt; a.res_mask = rm; a.trace = nullptr;
-  { void *ai, *bi; (void)hipMalloc(&ai, fd_et4_a_image_bytes(B, N)); (void)hipMemset(ai, 0, fd_et4_a_image_bytes(B, N));
-    (void)hipMalloc(&bi, fd_et4_b_image_bytes(B, N)); (void)hipMemset(bi, 0, fd_et4_b_image_bytes(B, N)); a.a1_img = ai; a.b1_img = bi; a.e_bf16 = nullptr; }
+  { char* ai; const size_t na = fd_et4_a_image_bytes(B, N), nb = fd_et4_b_image_bytes(B, N);  // one allocation: 32-bit offsets between the images
+    (void)hipMalloc(&ai, na + nb); (void)hipMemset(ai, 0, na + nb); a.a1_img = ai; a.b1_img = ai + na; a.e_bf16 = nullptr; }
   {  // next block's pair bias from the epilogue (argv[2] = 0 disables)
     void* wimg; float* bo; const long Np = (N + 31) / 32 * 32;
     (void)hipMalloc(&wimg, 8192); (void)hipMemset(wimg, 0, 8192); (void)hipMalloc(&bo, (size_t)B * 8 * Np * Np * 4);
