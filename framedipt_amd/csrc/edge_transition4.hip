@@ -45,7 +45,9 @@
 #define E4_ZOFF (2 * E4_BUF)                 // per-wave z rows [8][32 rows x 256 B]
 #define E4_VOFF (E4_ZOFF + 8 * 8192)         // b2[384] | gamma[128] | beta[128] f32, then linear_b image (8 KB)
 #define E4_SOFF (E4_VOFF + 1536 + 1024 + 8192)  // per-wave output staging [8][32 rows x 64 B]
-#define E4_LDS (E4_SOFF + 8 * 2048)
+#define E4_MOFF (E4_SOFF + 8 * 2048)          // per-lane pair masks of the current tile [512] f32
+#define E4_BOFF (E4_MOFF + 2048)              // bias of linear_b [8] f32
+#define E4_LDS (E4_BOFF + 32)
 
 // phase profile (-DE4_PROF, tools/micro/et4_bench.hip): cycle differences accumulate in scalar registers over all tiles of a
 // block and are written once at the end (FD_STAMP's per-stamp vector store costs registers this kernel does not have)
@@ -285,17 +287,24 @@ struct E4EpiTmp {     // lives inside one epilogue run only
   long prow;          // this lane's pair (row of z)
   long srow[2];       // the pairs whose 64 B row segments this lane stores (rows (lane >> 2) and 16 + (lane >> 2) of the patch)
   bool valid, svalid[2];
+  unsigned moff;      // LDS address of this lane's pair mask
+  unsigned boff;      // LDS address of the linear_b bias
 };
 typedef __attribute__((address_space(3))) e4_u32x2* e4_lds_w64;
+// x(lane) + x(lane ^ 32).  ds_bpermute with the partner address computed on the spot from the caller's (opaque) lane index:
+// __shfl_xor computes its own lane id, which hipcc hoists out of the tile loop and spills — and the reload is a vmcnt wait
+// that drains the whole DMA queue of the next tile.  (v_permlane32_swap would avoid LDS, but hipcc mis-handles its second
+// result when the operands are equal or constant: tools/micro/permlane_test.hip.)
+__device__ __forceinline__ float e4_both_halves(float x, int lane) {
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x)));
+}
 template <int SLOT>
 __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M) {
   const int p = lane & 31, half = lane >> 5;
   if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math); the pair mask is requested here
-    {
-      int row = 8 * E.t.rt + (p >> 2);
-      if (row > M - 1) row = M - 1;
-      E.em = a.res_mask[row] * a.res_mask[(row / a.N) * a.N + 4 * E.t.jt + (p & 3)];
-    }
+    // the pair mask comes from LDS (parked there at the start of the tile): a global load here would be waited for with
+    // vmcnt, i.e. together with the z rows and weights of the next tile requested just before the epilogue
+    E.em = *(const __attribute__((address_space(3))) float*)(unsigned long)(X.moff);
     f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -308,7 +317,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
     X.s1 = u1[0] + u1[1];
     X.s2 = u2[0] + u2[1];
   } else if constexpr (SLOT == 1) {
-    const float s1 = X.s1 + __shfl_xor(X.s1, 32, 64), s2 = X.s2 + __shfl_xor(X.s2, 32, 64);
+    const float s1 = e4_both_halves(X.s1, lane), s2 = e4_both_halves(X.s2, lane);
     const float mu = s1 * (1.0f / E4_CZ);
     const float var = fmaxf(s2 * (1.0f / E4_CZ) - mu * mu, 0.f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
@@ -381,14 +390,16 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
   } else if constexpr (SLOT == 6) {
     if (a.wb_img) {
       // pair bias of the next block's attention: head 4 half + r in register r < 4
+      const unsigned bbo = X.boff;
       const int row = 8 * E.t.rt + (p >> 2), jj = 4 * E.t.jt + (p & 3);
       if (E.t.valid && row < M && (!(E4_ABL & 8) || row == -12345)) {
         const int b = row / a.N, ii = row - b * a.N, nt = (a.N + 31) >> 5;
         float* bo = a.bias_out + fd_bias_frag_off((long)b * a.H + 4 * half, nt, ii, jj);
         const long hstride = (long)nt * nt * 1024;
+        const f32x4 bbv = e4_ldsf4(bbo + 16 * half);  // (from LDS: a global load here would be a vmcnt(0) drain per head)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * half + r < a.H) bo[r * hstride] = X.accb[r] + a.bb[4 * half + r];
+          if (4 * half + r < a.H) bo[r * hstride] = X.accb[r] + bbv[r];
       }
     }
   }
@@ -433,11 +444,21 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
   };
   auto fold_ld = [&](unsigned off) { return e4_gfrag((const char*)a.a1_img + off); };
   unsigned fold_base = fold_ptr(tc, lane0);
-  bf16x8 FA[3];
+  // all 12 layer-1 fold fragments are requested a tile ahead: a global load inside a chunk would make the compiler wait for
+  // it with vmcnt, and vmcnt being in order that is a wait for the whole weight DMA of the chunk issued just before
+  bf16x8 FA[12];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) FA[k] = fold_ld(fold_base + k * 512);
+  for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
+  auto mask_of = [&](const E4Tile& t, int lane) {
+    int row = 8 * t.rt + ((lane & 31) >> 2);
+    if (row > M - 1) row = M - 1;
+    return a.res_mask[row] * a.res_mask[(row / N) * N + 4 * t.jt + (lane & 3)];
+  };
+  if (tid0 < 8) *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_BOFF + tid0 * 4) = (a.wb_img && tid0 < a.H) ? a.bb[tid0] : 0.f;
+  float em_req = mask_of(tc, lane0);  // requested with the tile's operands, parked in LDS after the tile-start wait
   E4Epi E;
   e4_dma_wait();
+  *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid0 * 4) = em_req;
   __syncthreads();
   E4_STAMP(0);
 #pragma unroll 1
@@ -457,22 +478,18 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
       bf16x8 Zf[8];
 #pragma unroll
       for (int s = 0; s < 8; ++s) Zf[s] = e4_frag(zrow + (((2 * s) ^ (half ^ (p & 15))) << 4));
-      bf16x8 FC = FA[0];   // fold fragment of the current tile; the next one is requested a tile ahead
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((cc + 1) & 1) * E4_BUF, tid, wave);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int T = 3 * cc + u;
-          bf16x8 FNx = FC;
-          if (T + 1 < 12) FNx = T + 1 < 3 ? FA[T + 1] : fold_ld(fold_base + (T + 1) * 512);
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          acc = e4_mfma(FC, SEL, acc);
+          acc = e4_mfma(FA[T], SEL, acc);
           e4_tile<8, E4_D1>(acc, lds0 + (cc & 1) * E4_BUF + u * 8192 + lane * 16, Zf);
           e4_hand_off(acc, H1[2 * T], H1[2 * T + 1]);
-          FC = FNx;
         }
         e4_dma_wait();
         __syncthreads();
@@ -503,6 +520,7 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     // rows), 24 of h2, then the fold step (Af[i] + Bf[j]); 4 chunks x 8 k-steps
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < n_tiles;
+    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * 8 + wave, n_wt, N, NJ4);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -512,6 +530,11 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     for (int cc = 0; cc < 4; ++cc) {
       if (cc < 3) e4_dma_chunk<32768>(stream + soff + 32768, lds0 + ((cc + 1) & 1) * E4_BUF, tid, wave);
       else if (has_next) e4_dma_chunk<24576>(stream, lds0, tid, wave);  // the next tile's first chunk: buffer 0 is free since chunk 18
+      // The z rows of the NEXT tile are requested here, two chunks before the tile ends (the wave's LDS rows are free since the
+      // z part of this layer, chunk 0): all CUs reach their tile boundary together, and 16 MB of z requested there arrive as
+      // one HBM burst of several microseconds.  Always issued (the last tile re-requests its own rows) so that the wait
+      // below can count on exactly 8 younger DMA instructions.
+      if (cc == 1) e4_request_z(a, tn, lane_id(), lds0 + E4_ZOFF + wave * 8192, M);
       if (cc == 2) {
         const unsigned fb = fold_ptr(tc, lane_id());  // recomputed: carried through layer 2 it would be a spilled register
 #pragma unroll
@@ -540,7 +563,13 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
         __builtin_amdgcn_sched_barrier(0);
       }
       if (cc < 3) {
-        e4_dma_wait();
+        if (cc == 1) {  // the weight chunk issued at the top of this chunk, not the 8 z DMAs behind it: vmcnt(8)
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_waitcnt(0x0F78);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          e4_dma_wait();
+        }
         __syncthreads();
         soff += 32768;
       }
@@ -553,14 +582,15 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     E4_STAMP(3);
     // ================= tile boundary (no barrier: the z rows and the store staging are wave-private): the next tile's operands
     // are requested, THEN the LayerNorm epilogue of this tile runs under their latency
-    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * 8 + wave, n_wt, N, NJ4);
-    if (has_next) e4_request_z(a, tn, lane, zst, M);
     fold_base = fold_ptr(tn, lane);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) FA[k] = fold_ld(fold_base + k * 512);  // (the last tile re-reads its own: no branch, no phi)
+    for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);  // (the last tile re-reads its own: no branch, no phi)
     E.t = tc;
+    em_req = mask_of(tn, lane);
     if (!(E4_ABL & 1)) {
       E4EpiTmp X;
+      X.moff = lds0 + E4_MOFF + tid * 4;
+      X.boff = lds0 + E4_BOFF;
       const unsigned stg = lds0 + E4_SOFF + wave * 2048;
       e4_epi<0>(E, X, a, lane, vec, wbi, stg, M);
       e4_epi<1>(E, X, a, lane, vec, wbi, stg, M);
@@ -575,6 +605,7 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     tile = ntile;
     tc = tn;
     e4_dma_wait();
+    *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid * 4) = em_req;  // (this lane's own slot)
     __syncthreads();
     E4_STAMP(5);
   }
