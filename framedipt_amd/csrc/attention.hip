@@ -450,7 +450,20 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
     for (int s = 0; s < 8; ++s) wdf[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)((const char*)a.wdz_img + (s * 64 + lane) * 16));
   // attention weights -> bf16 rows (zero for padded keys) and sum_j a[h,i,j] (= 1 up to rounding and masking) in one pass:
   // 32 threads per head
-  {
+  if (a.probs_bf16) {  // already bf16 rows [b, i, h, probs_np] (attention3): 4 keys (8 B) per load, 32 threads per head
+    const int hh = tid >> 5, l5 = tid & 31;
+    const bf16_t* pr = a.probs_bf16 + (((long)b * N + i) * H + hh) * a.probs_np;
+    float sacc = 0.f;
+    for (int j = 4 * l5; j < Np; j += 128) {
+      u16x4 pv = {0, 0, 0, 0};
+      if (j < a.probs_np) pv = *(const u16x4*)(pr + j);
+      sacc += (bf2f(pv[0]) + bf2f(pv[1])) + (bf2f(pv[2]) + bf2f(pv[3]));
+      *(u16x4*)(pb + hh * prow + 2 * j) = pv;
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
+    if (l5 == 0) psum[hh] = sacc;
+  } else {
     const int hh = tid >> 5, l5 = tid & 31;
     const float* pr = a.probs + (((long)b * H + hh) * N + i) * N;
     float sacc = 0.f;
@@ -543,15 +556,20 @@ static int launch_opair(const OPairArgs& a, hipStream_t st) {
   return FDIPT_OK;
 }
 
+int fd_opair_mfma_eligible(int precision, const OPairArgs& a) {
+  return precision != FDIPT_PREC_F32 && a.CZ == 128 && a.H == 8 && a.CD == 32 && a.wdz_img && a.N <= 16 * OM_NK && !getenv("FDIPT_OPAIR_VALU");
+}
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
   if (a.H > 8) return FDIPT_ESIZE;
-  if (precision != FDIPT_PREC_F32 && a.CZ == 128 && a.H == 8 && a.CD == 32 && a.wdz_img && a.N <= 16 * OM_NK && !getenv("FDIPT_OPAIR_VALU")) {
+  if (fd_opair_mfma_eligible(precision, a)) {
+    if (a.probs_bf16 && (a.probs_np & 3)) return FDIPT_EINVAL;
     const int Np = (a.N + OM_JC - 1) / OM_JC * OM_JC;
     const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4;
     hipLaunchKernelGGL(opair_mfma_kernel, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
     FD_CHECK_LAUNCH();
     return FDIPT_OK;
   }
+  if (a.probs_bf16) return FDIPT_EINVAL;  // the VALU kernels read fp32 weights
   return precision == FDIPT_PREC_F32 ? launch_opair<float>(a, st) : launch_opair<bf16_t>(a, st);
 }
 

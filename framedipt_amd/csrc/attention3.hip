@@ -178,6 +178,9 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   FD_STAMP(3);
   // ---- phase 3: normalise; attention weights -> HBM (for o_pair), P fragments -> LDS
   float* prow = a.probs + (bh * N + i) * N;
+  // bf16 hand-over to the MFMA o_pair kernel: row (b, i) = the 8 heads' weights back to back, Np keys each (zero beyond N)
+  const long bq = bh / a.H;
+  bf16_t* prow16 = a.probs_bf16 ? a.probs_bf16 + ((bq * N + i) * a.H + (bh - bq * a.H)) * (long)a.Np : nullptr;
 #pragma unroll
   for (int u = 0; u < A3_NTW; ++u) {
     const int t = wave + 4 * u;
@@ -185,7 +188,13 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = S[u][r] * inv;
-      if (valid) {
+      if (valid && prow16) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u16x4 o = {f2bf(v[4 * g]), f2bf(v[4 * g + 1]), f2bf(v[4 * g + 2]), f2bf(v[4 * g + 3])};
+          *(u16x4*)(prow16 + 32 * t + 8 * g + 4 * hi) = o;  // (masked / padded keys carry exact zeros)
+        }
+      } else if (valid) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int j0 = 32 * t + 8 * g + 4 * hi;

@@ -63,6 +63,8 @@ struct OPairArgs {
   int B, N, H, CZ, CD;   // CD = CZ/4
   const void* z;         // [B,N,N,CZ] ZT
   const float* probs;    // [B,H,N,N]
+  const bf16_t* probs_bf16;  // optional (MFMA kernel): the same weights as bf16 rows [B,N,H,probs_np], zero beyond N; else NULL
+  int probs_np;
   const float* wdz;      // [CZ,CD] f32 (down_z weight, transposed)
   const void* wdz_img;   // optional: down_z weight [CD, CZ] as a bf16 fragment image (fd_chain_build_image, natural k) for the MFMA kernel
   const float* bdz;      // [CD]
@@ -166,6 +168,7 @@ struct Attn3Args {
   const float* gamma;             // [H]
   const float *rot, *trans;       // [B,N,9], [B,N,3]
   float* probs;                   // [B,H,N,N]
+  bf16_t* probs_bf16;             // if set: written INSTEAD, as bf16 rows [B,N,H,Np] (what the MFMA o_pair kernel consumes)
   float* out;                     // feature rows: o at h*256, point features at pt_off
   long out_ld;
   int pt_off;
@@ -258,6 +261,7 @@ int fd_edge_transition(int precision, int cz, int cb, const EdgeTransArgs& a, hi
 int fd_edge_embed(int precision, int cz, const EdgeEmbedArgs& a, hipStream_t st);
 int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st);
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
+int fd_opair_mfma_eligible(int precision, const OPairArgs& a);  // the MFMA kernel will run (it can take probs_bf16)
 int fd_attention2_supported(int ipa, const AttnArgs& a);
 int fd_attention2(int ipa, const AttnArgs& a, hipStream_t st);
 int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, int frag, hipStream_t st);
