@@ -540,7 +540,11 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
     }
     const float bd = a.bdz[li];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a.out[(rb + i) * a.out_ld + a.off + (4 * hi + r) * CD + li] = o2[r] + bd * psum[4 * hi + r];
+    for (int r = 0; r < 4; ++r) {
+      const float v = o2[r] + bd * psum[4 * hi + r];
+      if (a.out_bf16) a.out_bf16[(rb + i) * a.out_ld + a.off + (4 * hi + r) * CD + li] = f2bf(v);
+      else a.out[(rb + i) * a.out_ld + a.off + (4 * hi + r) * CD + li] = v;
+    }
   }
 }
 
@@ -569,7 +573,7 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
     FD_CHECK_LAUNCH();
     return FDIPT_OK;
   }
-  if (a.probs_bf16) return FDIPT_EINVAL;  // the VALU kernels read fp32 weights
+  if (a.probs_bf16 || a.out_bf16) return FDIPT_EINVAL;  // the VALU kernels read fp32 weights and write fp32 features
   return precision == FDIPT_PREC_F32 ? launch_opair<float>(a, st) : launch_opair<bf16_t>(a, st);
 }
 

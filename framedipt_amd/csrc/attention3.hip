@@ -238,7 +238,14 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
         if (s < ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Va[bf][s], __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc, 0, 0, 0);
     };
     auto o_store = [&](const f32x16& acc, int dt) {
-      if (valid) {
+      if (valid && a.out_bf16) {  // bf16 features: exactly what the output projection's bf16 GEMM would round them to
+        bf16_t* orow = a.out_bf16 + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u16x4 o = {f2bf(acc[4 * g]), f2bf(acc[4 * g + 1]), f2bf(acc[4 * g + 2]), f2bf(acc[4 * g + 3])};
+          *(u16x4*)(orow + 8 * g) = o;
+        }
+      } else if (valid) {
         float* orow = a.out + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -288,9 +295,15 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       const float oy = R[1] * x + R[4] * y + R[7] * z;
       const float oz = R[2] * x + R[5] * y + R[8] * z;
       const int HP = H * 12;
-      float* oo = a.out + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
-      oo[0] = ox; oo[HP] = oy; oo[2 * HP] = oz;
-      oo[3 * HP] = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
+      const float on = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
+      if (a.out_bf16) {
+        bf16_t* oo = a.out_bf16 + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
+        oo[0] = f2bf(ox); oo[HP] = f2bf(oy); oo[2 * HP] = f2bf(oz); oo[3 * HP] = f2bf(on);
+      } else {
+        float* oo = a.out + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
+        oo[0] = ox; oo[HP] = oy; oo[2 * HP] = oz;
+        oo[3 * HP] = on;
+      }
     }
   }
   FD_STAMP(7);

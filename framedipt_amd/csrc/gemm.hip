@@ -425,6 +425,16 @@ int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, c
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const bf16_t* A, int lda, const void* W, int ldw, const float* bias,
+                     const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 7) || (ldw & 7)) return FDIPT_EINVAL;
+  const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
+  if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecBF16, bf16_t, bf16_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
+                     st, M, N, K, kslice, A, lda, (const bf16_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 
 __global__ void f32_to_bf16_kernel(long n, const float* __restrict__ in, bf16_t* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);

@@ -69,6 +69,7 @@ struct OPairArgs {
   const void* wdz_img;   // optional: down_z weight [CD, CZ] as a bf16 fragment image (fd_chain_build_image, natural k) for the MFMA kernel
   const float* bdz;      // [CD]
   float* out;            // row (b*N+i): out + r*out_ld + off + h*CD + d
+  bf16_t* out_bf16;      // MFMA kernel: if set, bf16 rows (same out_ld, in elements) INSTEAD of out
   long out_ld;
   int off;
 };
@@ -168,6 +169,7 @@ struct Attn3Args {
   const float* gamma;             // [H]
   const float *rot, *trans;       // [B,N,9], [B,N,3]
   float* probs;                   // [B,H,N,N]
+  bf16_t* out_bf16;               // if set: the output features are written as bf16 rows (same out_ld, in elements) INSTEAD of out
   bf16_t* probs_bf16;             // if set: written INSTEAD, as bf16 rows [B,N,H,Np] (what the MFMA o_pair kernel consumes)
   float* out;                     // feature rows: o at h*256, point features at pt_off
   long out_ld;
@@ -252,6 +254,9 @@ int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* 
                 hipStream_t st);
 int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
                        const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st);
+// the same with bf16 activation rows (what the bf16 GEMM would round them to anyway)
+int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const bf16_t* A, int lda, const void* W, int ldw, const float* bias,
+                         const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, const void* W, int ldw, const float* bias,
                      const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,

@@ -568,10 +568,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const bf16_t*)(W + w.qb); a3.Kb = (const bf16_t*)(W + w.kb);
     a3.Vt = (const bf16_t*)(W + w.vt); a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
     a3.vp = F(w.vp); a3.vpt = (const bf16_t*)(W + w.vpt); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
-    a3.probs = F(w.probs); a3.probs_bf16 = nullptr; a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
+    a3.probs = F(w.probs); a3.probs_bf16 = nullptr; a3.out_bf16 = nullptr; a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
     OPairArgs oa;
-    oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_bf16 = nullptr; oa.probs_np = 0;
+    oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_bf16 = nullptr; oa.probs_np = 0; oa.out_bf16 = nullptr;
     oa.wdz = (const float*)(D + db.wdz_t); oa.wdz_img = (bf && cz == 128) ? D + db.wdz_img : nullptr; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
+    bool feats_bf16 = false;
     const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !getenv("FDIPT_ATTN_V1") &&
                         !getenv("FDIPT_ATTN_V2") && fd_attention3_supported(a3);
     PointsArgs pa;
@@ -599,6 +600,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), 1, st));
       // the attention weights go to the MFMA o_pair kernel as bf16 rows [b, i, h, Np] (half the bytes, no conversion pass;
       // the fp32 buffer is reused: B N H Np bf16 <= B H N N fp32); FDIPT_PROBS_F32 keeps the fp32 [B,H,N,N] hand-over
+      // ... and both kernels write the attention features as bf16 rows when the output projection is the bf16 split-K GEMM
+      // (the values it would round them to anyway: identical results, half the bytes, no conversion in its staging)
+      feats_bf16 = fd_opair_mfma_eligible(prec, oa) && iv.feat_dim >= 1024 && (iv.feat_dim & 7) == 0 && !getenv("FDIPT_NO_SPLITK") &&
+                   !getenv("FDIPT_FEATS_F32");
+      if (feats_bf16) { a3.out_bf16 = (bf16_t*)(W + w.feats); oa.out_bf16 = a3.out_bf16; }
       if (fd_opair_mfma_eligible(prec, oa) && 2 * Np <= 4 * N && !getenv("FDIPT_PROBS_F32")) {
         a3.probs_bf16 = (bf16_t*)(W + w.probs); oa.probs_bf16 = a3.probs_bf16; oa.probs_np = Np;
       }
@@ -630,8 +636,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
     if (bf && iv.feat_dim >= 1024 && !getenv("FDIPT_NO_SPLITK")) {
       const int NS = 4;  // K = 2688: slices of 704 / 576 columns -> 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower)
-      RC(fd_linear_splitk(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b, res_mask,
-                          F(w.ipa_parts), (long)R * cs, cs, st));
+      if (feats_bf16)
+        RC(fd_linear_splitk_a16(R, cs, iv.feat_dim, NS, (const bf16_t*)(W + w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b,
+                                res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
+      else
+        RC(fd_linear_splitk(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b, res_mask,
+                            F(w.ipa_parts), (long)R * cs, cs, st));
       RC(fd_layernorm_parts(R, cs, node_cur, cs, F(w.ipa_parts), cs, NS, (long)R * cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr,
                             F(w.tf_in), dt, st));
     } else {

@@ -5,7 +5,7 @@
 #include <vector>
 int main(int argc, char** argv) {
   const int B = 8, H = 8, N = argc > 1 ? atoi(argv[1]) : 300, Np = (N + 31) / 32 * 32;
-  Attn3Args a; a.probs_bf16 = nullptr;
+  Attn3Args a; a.probs_bf16 = nullptr; a.out_bf16 = nullptr;
   a.B = B; a.N = N; a.H = H; a.Np = Np;
   auto dz = [](size_t bytes) { void* p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
   a.Qb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2); a.Kb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2);

@@ -5,7 +5,7 @@
 int main(int argc, char** argv) {
   const int B = 8, H = 8, N = argc > 1 ? atoi(argv[1]) : 300;
   auto dz = [](size_t bytes) { void* p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
-  OPairArgs a; a.probs_bf16 = nullptr; a.probs_np = 0;
+  OPairArgs a; a.probs_bf16 = nullptr; a.probs_np = 0; a.out_bf16 = nullptr;
   a.B = B; a.N = N; a.H = H; a.CZ = 128; a.CD = 32; a.z = dz((size_t)B * N * N * 128 * 2); a.probs = (const float*)dz((size_t)B * H * N * N * 4);
   a.wdz = (const float*)dz(128 * 32 * 4); a.wdz_img = dz(8192); a.bdz = (const float*)dz(32 * 4); a.out_ld = 2688; a.out = (float*)dz((size_t)B * N * a.out_ld * 4);
   a.off = 2048 + 384;
