@@ -215,7 +215,12 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
           accN[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][s], w1[s % DEPTH], accN[i][1], 0, 0, 0);
         }
       }
-      if (has_prev) epi_unit(accP, bqP, cpP, kindP, s >> 3, (s >> 2) & 1, s & 3);
+      // (two units per k-step in the first half of the block: their stores then have the second half to retire before the
+      //  vmcnt(0) at the top of the next block, which cannot tell them from the weight DMA it is waiting for)
+      if (has_prev && s < 8) {
+        epi_unit(accP, bqP, cpP, kindP, (2 * s) >> 3, ((2 * s) >> 2) & 1, (2 * s) & 3);
+        epi_unit(accP, bqP, cpP, kindP, (2 * s + 1) >> 3, ((2 * s + 1) >> 2) & 1, (2 * s + 1) & 3);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
