@@ -208,12 +208,15 @@ struct RowBlockArgs {
   float* out2;                  // optional: output columns >= split go to out2 (column - split), or NULL
   int ld_out2, split;
   unsigned short* hid_bf16;     // optional bf16 copy of the first hidden layer's rows [M, N1], or NULL
+  // FD_RB_ET4_IMAGES: the 1024 output columns [A1 | Af | B1 | Bf] leave as edge_transition4's fold-fragment images (bf16)
+  void *img_a, *img_b;          // fd_et4_row_images layouts
+  int img_B, img_N;
   // FD_RB_TRANSITION_BB: BackboneUpdate (Linear c_s -> 6, fp32) on the output rows + compose_q_update_vec, in place
   const float *bb_w, *bb_b;     // [6, c_s], [6]
   const float* upd_mask;        // [M] or NULL
   float *quat, *trans;          // [M,4], [M,3]
 };
-enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS };
+enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS, FD_RB_ET4_IMAGES };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 
 // post-attention half of one encoder layer in one launch (rowblock.hip): x_a = LN1(x + Wo att + bo); out = LN2(x_a + W2 relu(W1 x_a + b1) + b2)

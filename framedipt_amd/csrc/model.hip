@@ -763,8 +763,13 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         r.b1 = (const float*)(D + db.ch.r4b); r.w2 = nullptr; r.b2 = nullptr; r.residual = nullptr; r.ld_res = 0; r.gamma = r.beta = nullptr;
         r.rowmask_post = nullptr; r.out = F(w.r4); r.ld_out = 1024; r.out2 = nullptr; r.ld_out2 = 0; r.split = 0;
         r.hid_bf16 = nullptr; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
-        RC(fd_rowblock(FD_RB_ET4_ROWS, r, st));
-        RC(fd_et4_row_images(F(w.r4), B, N, W + w.a1img, W + w.b1img, st));
+        r.img_a = W + w.a1img; r.img_b = W + w.b1img; r.img_B = B; r.img_N = N;
+        if (!getenv("FDIPT_ET4_ROWS_UNFUSED")) {  // the row-block epilogue writes the fold-fragment images itself
+          RC(fd_rowblock(FD_RB_ET4_IMAGES, r, st));
+        } else {
+          RC(fd_rowblock(FD_RB_ET4_ROWS, r, st));
+          RC(fd_et4_row_images(F(w.r4), B, N, W + w.a1img, W + w.b1img, st));
+        }
       } else if (et_rows_fused) {
         RowBlockArgs r;
         r.M = R; r.in = node_cur; r.ld_in = cs; r.w0 = D + db.ch.et_init; r.b0 = P + k.et_init.b; r.w1 = D + db.ch.a1af;

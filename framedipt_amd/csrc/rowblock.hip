@@ -40,6 +40,7 @@ struct RBShape {
   static constexpr int NTMAX = rb_max(NOUT / 32, rb_max(N1 / 32, N2 / 32));
   static constexpr int NTW = (NTMAX + 3) / 4;                              // output tiles per wave
   static constexpr bool BB = (FLAGS & 8) != 0;                            // fused BackboneUpdate + compose_q_update_vec
+  static constexpr bool IMG = (FLAGS & 16) != 0;                          // output = edge_transition4 fold-fragment images
   static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0) + (BB ? 6 * NOUT : 0);  // b0 | b1 | b_out | gamma | beta | Wbb
   static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * 32 * XROW + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + (BB ? 4 * 32 * 8 * 4 : 0) + 16;
   static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 1024, "tile shapes");
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   f32x16 acc[NTW];
   // one layer: tiles wave, wave+4, wave+8 (< NT) of `img` against the B fragments X[0..KS); the first tile's fragments
   // are already in Wf[0]
-  auto layer = [&](auto KSC, auto NTC, const char* img) {
+  auto layer = [&](auto KSC, auto NTC, const char* img, auto SWAPC) {
     constexpr int KS = decltype(KSC)::value, NT = decltype(NTC)::value;
+    constexpr bool SWAP = decltype(SWAPC)::value;  // operands exchanged: lane = output feature, registers = rows
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
       const int T = wave + 4 * u;
@@ -135,7 +137,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
+        for (int s = 0; s < KS; ++s)
+          c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[s], Wf[u & 1][s], c, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
         acc[u] = c;
       }
     }
@@ -167,25 +171,58 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
 #pragma unroll
   for (int s = 0; s < KS0; ++s) X[s] = rb_ld(xs + li * XROW + 32 * s + 16 * hi);
   if constexpr (NL == 1) {
-    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, NTO>{}, wimg[0]);
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, NTO>{}, wimg[0], std::false_type{});
   } else {
-    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0]);
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0], std::false_type{});
     w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N1 / 16>{}, wimg[1], wave);  // in flight across the barrier
     to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs, a.hid_bf16, N1);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < N1 / 16; ++s) X[s] = rb_ld(hs + li * XROW + 32 * s + 16 * hi);
     if constexpr (NL == 2) {
-      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, NTO>{}, wimg[1]);
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, NTO>{}, wimg[1], std::integral_constant<bool, S::IMG>{});
     } else {
-      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1]);
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1], std::false_type{});
       w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N2 / 16>{}, wimg[2], wave);
       to_hidden(std::integral_constant<int, N2 / 32>{}, std::integral_constant<bool, (FLAGS & 2) != 0>{}, cst + N1, xs, nullptr, 0);  // xs is free again
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < N2 / 16; ++s) X[s] = rb_ld(xs + li * XROW + 32 * s + 16 * hi);
-      layer(std::integral_constant<int, N2 / 16>{}, std::integral_constant<int, NTO>{}, wimg[2]);
+      layer(std::integral_constant<int, N2 / 16>{}, std::integral_constant<int, NTO>{}, wimg[2], std::false_type{});
     }
+  }
+  if constexpr (S::IMG) {
+    // ---- edge_transition4 fold-fragment images straight from the accumulators (lane = output column, registers = 4-runs of
+    // rows): columns 0..511 = [A1 | Af] of 8 consecutive flattened rows -> a_img[row / 8][column / 32][column % 32][row % 8];
+    // columns 512..1023 = [B1 | Bf] of 4 consecutive residues j of sample b -> b_img[b][j / 4][..][0..3], and the same 8 bytes
+    // as elements 4..7 of sample b - 1 (the rows of a patch that straddles two samples); elements 4..7 of the last sample are
+    // zeros (finite: they meet zeros of the selection matrix).  Needs img_N % 4 == 0.
+    static_assert(NL == 2 && NOUT == 1024, "ET4 image kind");
+    const float* bo = cst + N1 + N2;
+    const int NJ4 = a.img_N >> 2;
+    bf16_t* ia = (bf16_t*)a.img_a;
+    bf16_t* ib = (bf16_t*)a.img_b;
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+      const int T = wave + 4 * u;
+      const float bv = bo[32 * T + li];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r0 = row0 + 8 * g + 4 * hi;  // rows r0 .. r0 + 3 (M % 4 == 0: all four valid or none)
+        u16x4 o = {0, 0, 0, 0};
+        if (r0 < a.M) o = u16x4{f2bf(acc[u][4 * g] + bv), f2bf(acc[u][4 * g + 1] + bv), f2bf(acc[u][4 * g + 2] + bv), f2bf(acc[u][4 * g + 3] + bv)};
+        if (T < 16) {
+          if ((r0 >> 3) < ((a.M + 7) >> 3)) *(u16x4*)(ia + ((((long)(r0 >> 3) * 16 + T) * 32 + li) << 3) + (r0 & 4)) = o;  // (rows beyond M: zeros; the image is padded to 8 rows)
+        } else if (r0 < a.M) {
+          const int b = r0 / a.img_N, jt = (r0 - b * a.img_N) >> 2, ft = T - 16;
+          bf16_t* dst = ib + ((((long)b * NJ4 + jt) * 16 + ft) * 32 + li) * 8;
+          *(u16x4*)dst = o;
+          if (b > 0) *(u16x4*)(dst - (long)NJ4 * 16 * 32 * 8 + 4) = o;
+          if (b == a.img_B - 1) *(u16x4*)(dst + 4) = u16x4{0, 0, 0, 0};
+        }
+      }
+    }
+    return;
   }
   // ---- + bias + residual (row segments -> fragment layout through the wave's tile)
   const float* bo = cst + N1 + N2;
@@ -555,6 +592,9 @@ int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
     case FD_RB_TORSION: return rb_launch<256, 256, 0, 256, 1>(a, st);            // l1 relu l2 + residual
     case FD_RB_ET_ROWS: return rb_launch<256, 128, 0, 512, 0>(a, st);            // e = init(node); [A1 | Af] = [W1e; Wfe] e + b
     case FD_RB_ET4_ROWS: return rb_launch<256, 128, 0, 1024, 0>(a, st);          // ... [A1 | Af | B1 | Bf]: e_i and e_j columns
+    case FD_RB_ET4_IMAGES:                                                        // ... written as edge_transition4's fold fragments
+      if (!a.img_a || !a.img_b || (a.img_N & 3) || a.M != a.img_B * a.img_N) return FDIPT_EINVAL;
+      return rb_launch<256, 128, 0, 1024, 16>(a, st);
     default: return FDIPT_EINVAL;
   }
 }
