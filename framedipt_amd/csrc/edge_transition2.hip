@@ -737,6 +737,92 @@ int fd_edge_transition2(const ET2Args& a, hipStream_t st) {
 }
 
 // ====================================================================================================================
+// ---- VALU-lean pieces for the embedder (its waves are issue-bound: ~1500 VALU instructions per 32-pair tile before) ----
+typedef float ee_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ee_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ee_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ee_u32x4 __attribute__((ext_vector_type(4)));
+typedef short ee_s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned ee_cvt_pk(float lo, float hi) {  // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(ee_f32x2{lo, hi}, ee_bf16x2));
+}
+// relu + bf16 of an accumulator tile (bias already in it): conversion first, then max(x, 0) on the bf16 bit patterns as signed
+// 16-bit integers (negative values have the sign bit set): 8 + 8 instructions instead of 16 + 16 + 8
+__device__ __forceinline__ void ee_hand_off(const f32x16& acc, bf16x8& h0, bf16x8& h1) {
+  ee_u32x4 w0, w1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w0[k] = ee_cvt_pk(acc[2 * k], acc[2 * k + 1]);
+    w1[k] = ee_cvt_pk(acc[8 + 2 * k], acc[8 + 2 * k + 1]);
+  }
+  const ee_s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  h0 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(ee_s16x8, w0), zero));
+  h1 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(ee_s16x8, w1), zero));
+}
+// LayerNorm epilogue of the embedder in packed fp32 math (one pass: sum and sum of squares; the layer bias is already in Y):
+// same staging / stores / pair-bias emission as ln_epilogue_staged
+__device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamma_l, const float* beta_l, float em, int li, int hi,
+                                               int lane, char* stage, bf16_t* __restrict__ z_out, long p0, long n_pairs,
+                                               float* __restrict__ tr_row, bool valid, const char* wb_lds, const f32x4 bbv,
+                                               float* __restrict__ bias_out, int H, long bidx, int ii, int jj, int nt) {
+  ee_f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const ee_f32x2 y = {Y[t][r], Y[t][r + 1]};
+      u1 += y;
+      u2 = __builtin_elementwise_fma(y, y, u2);
+    }
+  float s1 = u1[0] + u1[1], s2 = u2[0] + u2[1];
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  const float mu = s1 * (1.0f / ET2_CZ);
+  const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / ET2_CZ) - mu * mu, 0.f) + 1e-5f);
+  const ee_f32x2 sa = {rstd, rstd}, sc = {-mu * rstd, -mu * rstd}, em2 = {em, em};
+  ee_u32x4 zB[8];  // bf16 z' as B fragments
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f0 = 32 * t + 8 * g + 4 * hi;
+      const f32x4 gm = *(const f32x4*)(gamma_l + f0), bt = *(const f32x4*)(beta_l + f0);
+      ee_f32x2 o0 = {Y[t][4 * g], Y[t][4 * g + 1]}, o1 = {Y[t][4 * g + 2], Y[t][4 * g + 3]};
+      o0 = __builtin_elementwise_fma(o0, sa, sc);
+      o1 = __builtin_elementwise_fma(o1, sa, sc);
+      o0 = __builtin_elementwise_fma(o0, ee_f32x2{gm[0], gm[1]}, ee_f32x2{bt[0], bt[1]}) * em2;
+      o1 = __builtin_elementwise_fma(o1, ee_f32x2{gm[2], gm[3]}, ee_f32x2{bt[2], bt[3]}) * em2;
+      const ee_u32x2 ow = {ee_cvt_pk(o0[0], o0[1]), ee_cvt_pk(o1[0], o1[1])};
+      // features f0..f0+3 = bytes 2 f0 .. 2 f0 + 7 of the pair's row: 16 B unit 4t + g, half hi; unit u of row r at u ^ (r & 15)
+      *(ee_u32x2*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = ow;
+      zB[2 * t + (g >> 1)][2 * (g & 1)] = ow[0];
+      zB[2 * t + (g >> 1)][2 * (g & 1) + 1] = ow[1];
+      if (tr_row && valid) *(f32x4*)(tr_row + f0) = f32x4{o0[0], o0[1], o1[0], o1[1]};
+    }
+  if (wb_lds) {
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(wb_lds, s * 1024 + lane * 16), __builtin_bit_cast(bf16x8, zB[s]), accb, 0, 0, 0);
+    if (valid) {
+      float* bo = bias_out + fd_bias_frag_off(bidx * H + 4 * hi, nt, ii, jj);  // 32 lanes = 32 consecutive keys: 128 B rows
+      const long hstride = (long)nt * nt * 1024;  // floats per (sample, head)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * hi + r < H) bo[r * hstride] = accb[r] + bbv[r];
+    }
+  }
+  const int sr = lane >> 4, sc16 = lane & 15;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = 4 * it + sr;
+    const u16x8 v = *(const u16x8*)(stage + r * 256 + ((sc16 ^ (r & 15)) << 4));
+    if (p0 + r < n_pairs) *(u16x8*)(z_out + (p0 + r) * ET2_CZ + 8 * sc16) = v;
+  }
+}
+
 // edge_embed2_kernel — bf16 pair branch of Embedder.forward (framedipt/model/score_network.py:98-105,173-196) in the
 // same register-resident style.  Layer 1 has no GEMM: the cross-concat / relative-index / distogram features are
 // one-hot or per-residue, so h1 = relu(Pi[i] + Pj[j] + R[idx_i - idx_j] + D[bin(|ca_i - ca_j|)]) is four table rows
@@ -789,6 +875,7 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
   const int N = a.N;
   const long n_pairs = (long)a.B * N * N;
   const float* b2row = vec + 4 * hi;
+  const f32x4 bbv = a.wb_img ? f32x4{a.bb[4 * hi], a.bb[4 * hi + 1], a.bb[4 * hi + 2], a.bb[4 * hi + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
   for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
     const long p0 = (long)tile * 32;
     const long p_raw = p0 + li;
@@ -819,11 +906,14 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
       const int rbi = __shfl(ibi, r, 64), rbj = __shfl(ibj, r, 64), rrel = __shfl(rel, r, 64), rbin = __shfl(bin, r, 64);
       const f32x4 x1 = *(const f32x4*)(a.pi + (long)rbi * ET2_CZ + 4 * li), x2 = *(const f32x4*)(a.pj + (long)rbj * ET2_CZ + 4 * li);
       const f32x4 x3 = *(const f32x4*)(a.rtab + (long)rrel * ET2_CZ + 4 * li), x4 = *(const f32x4*)(a.dtab + (long)rbin * ET2_CZ + 4 * li);
-      bf16x4 pk;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)fmaxf(x1[q] + x2[q] + x3[q] + x4[q], 0.f);
+      // packed adds, conversion, then relu on the bf16 bit patterns (v_pk_max_i16)
+      const ee_f32x2 sA = (ee_f32x2{x1[0], x1[1]} + ee_f32x2{x2[0], x2[1]}) + (ee_f32x2{x3[0], x3[1]} + ee_f32x2{x4[0], x4[1]});
+      const ee_f32x2 sB = (ee_f32x2{x1[2], x1[3]} + ee_f32x2{x2[2], x2[3]}) + (ee_f32x2{x3[2], x3[3]} + ee_f32x2{x4[2], x4[3]});
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      const ee_u32x2 cw = {ee_cvt_pk(sA[0], sA[1]), ee_cvt_pk(sB[0], sB[1])};
+      const ee_u32x2 pk = __builtin_bit_cast(ee_u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, cw), s16x4{0, 0, 0, 0}));
       // [32 pairs][256 B] tile, 16 B unit u of row r at u ^ (r & 15)
-      *(bf16x4*)(stage + r * 256 + (((li >> 1) ^ (r & 15)) << 4) + 8 * (li & 1)) = pk;
+      *(ee_u32x2*)(stage + r * 256 + (((li >> 1) ^ (r & 15)) << 4) + 8 * (li & 1)) = pk;
     }
     bf16x8 H1[8];
 #pragma unroll
@@ -831,29 +921,30 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
     bf16x8 H2[8];
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
-      f32x4 bias[4];
+      f32x16 acc;  // starts as the layer bias (LDS reads straight into the accumulator: no VALU)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4*)(b2row + 32 * T + 8 * g);
-      f32x16 acc;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const f32x4*)(b2row + 32 * T + 8 * g);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int q = 0; q < 4; ++q) acc[4 * g + q] = bv[q];
+      }
       mma_slab<8, 256>(acc, smem + T * 32 * 256, li, hi, H1);
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bias[r >> 2][r & 3], 0.f);
-      H2[2 * T] = pack8(v);
-      H2[2 * T + 1] = pack8(v + 8);
+      ee_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
     }
     f32x16 Y[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
+      for (int g = 0; g < 4; ++g) {  // starts as the layer bias b3
+        const f32x4 bv = *(const f32x4*)(vec + ET2_CZ + 4 * hi + 32 * t + 8 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y[t][4 * g + q] = bv[q];
+      }
       mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
     }
-    ln_epilogue_staged(Y, vec + ET2_CZ + 4 * hi, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, a.res_mask[bi] * a.res_mask[bj], li, hi, lane,
-                       stage, (bf16_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid,
-                       a.wb_img ? wbl : nullptr, a.bb, a.bias_out, a.H, bb, (int)(bi - bb * N), j, (N + 31) >> 5);
+    ee_ln_epilogue(Y, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, a.res_mask[bi] * a.res_mask[bj], li, hi, lane,
+                   stage, (bf16_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid,
+                   a.wb_img ? wbl : nullptr, bbv, a.bias_out, a.H, bb, (int)(bi - bb * N), j, (N + 31) >> 5);
   }
 }
 
