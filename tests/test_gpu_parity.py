@@ -414,7 +414,7 @@ def test_baseline_config_shapes_run(n, B, prec, inp):
         np.testing.assert_allclose(x_1[fixed, 4:], x_T[fixed, 4:], atol=1e-4)
 
 
-@pytest.mark.parametrize("n,B", [(77, 3), (301, 2), (129, 4), (44, 3), (100, 2)])
+@pytest.mark.parametrize("n,B", [(77, 3), (301, 2), (129, 4), (44, 3), (100, 2), (300, 2)])
 def test_forward_bf16_vs_fp32_path_ragged_sizes(n, B):
     """Ragged shapes (N not a multiple of 4 / 32; 32-row blocks, 128-pair tiles and key tiles that straddle samples and
     padded keys; N % 8 == 4: the 8 x 4 patches of edge_transition4 straddle two samples): the bf16 kernels against the
