@@ -41,6 +41,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   float* sms = mxs + 128;                                    // [4][32]
   float* opr = sms + 128;                                    // [32 queries][96]: o_pt sums, high parts then low parts
   u16x8* Pfs = (u16x8*)(opr + 32 * 96);                      // [2*nt][64]
+  u16x8* Qs = Pfs + 2 * nt * 64;                             // LB == 3: the Q fragments of the query tile [16][64] (16 KB)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   // XCD-aware block -> (sample, head, query tile): consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each),
@@ -63,11 +64,19 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
 
   FD_STAMP(0);
   // ---- query-side registers
-  bf16x8 Qf[16];
+  // LB == 2: Q fragments in registers.  LB == 3 (three blocks per CU: B H nt blocks then fit one round of the 256 CUs): the 64
+  // registers are not affordable; the four waves need the same fragments, so they go to LDS once and are read per k-step
+  bf16x8 Qf[LB == 3 ? 1 : 16];
   {
     const bf16_t* qr = a.Qb + ((bh * nt + qt) * 16 * 64 + lane) * 8;  // fragment order: 1 KB per k-step
+    if constexpr (LB == 3) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) Qf[s] = a3_ld(qr + s * 512);
+      for (int s = 0; s < 4; ++s) Qs[(4 * s + wave) * 64 + lane] = *(const u16x8*)(qr + (4 * s + wave) * 512);
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) Qf[s] = a3_ld(qr + s * 512);
+    }
   }
   const float mi = a.res_mask[rb + i];
   const float gam = a.gamma[h];
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? kpv[2 * s + 1] : kpv[2 * s], qB[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], acc, 0, 0, 0);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ti.k[s], Qf[s], acc, 0, 0, 0);
+      for (int s = 0; s < 16; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ti.k[s], LB == 3 ? __builtin_bit_cast(bf16x8, Qs[s * 64 + lane]) : Qf[LB == 3 ? 0 : s], acc, 0, 0, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -319,7 +329,8 @@ int fd_attention3(const Attn3Args& a, hipStream_t st) {
   (void)Np;
   if (smem > 64 * 1024) return FDIPT_ESIZE;  // 1 KB + 12 KB + 64 B per key: 45 KB at N = 512
   const int per = (a.B * a.H + 7) / 8;  // see the block mapping in the kernel
-  if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
+  if (a.N <= 3 * 4 * 32 && !getenv("FDIPT_A3_LB2")) hipLaunchKernelGGL((ipa_attn3_kernel<3, 3, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem + 16384, st, a);
+  else if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
   else hipLaunchKernelGGL((ipa_attn3_kernel<4, 1, true>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
