@@ -83,15 +83,24 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       xv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (idx < 32 * C4 && 4 * c4 < K0) xv[k] = *(const f32x4*)(a.in + (long)gr * a.ld_in + 4 * c4);
     }
-    for (int v = tid; v < S::NCONST; v += FD_THREADS) {
-      float x;
-      if (v < N1) x = a.b0[v];
-      else if (v < N1 + N2) x = a.b1[v - N1];
-      else if (v < N1 + N2 + NOUT) x = (NL == 1 ? a.b0 : (NL == 2 ? a.b1 : a.b2))[v - N1 - N2];
-      else if (v < N1 + N2 + 2 * NOUT) x = a.gamma[v - N1 - N2 - NOUT];
-      else if (v < N1 + N2 + 3 * NOUT) x = a.beta[v - N1 - N2 - 2 * NOUT];
-      else x = a.bb_w[v - N1 - N2 - 3 * NOUT];  // [6][NOUT] (LayerNorm kinds only)
-      cst[v] = x;
+    {  // constants: all loads of a thread in flight together (a rolled loop is one dependent L2 round trip per iteration)
+      constexpr int NCV = (S::NCONST + FD_THREADS - 1) / FD_THREADS;
+      float cv[NCV];
+#pragma unroll
+      for (int k = 0; k < NCV; ++k) {
+        const int v = tid + k * FD_THREADS;
+        float x = 0.f;
+        if (v < N1) x = a.b0[v];
+        else if (v < N1 + N2) x = a.b1[v - N1];
+        else if (v < N1 + N2 + NOUT) x = (NL == 1 ? a.b0 : (NL == 2 ? a.b1 : a.b2))[v - N1 - N2];
+        else if (v < N1 + N2 + 2 * NOUT) { if (S::LN) x = a.gamma[v - N1 - N2 - NOUT]; }
+        else if (v < N1 + N2 + 3 * NOUT) { if (S::LN) x = a.beta[v - N1 - N2 - 2 * NOUT]; }
+        else if (v < S::NCONST) { if (S::BB) x = a.bb_w[v - N1 - N2 - 3 * NOUT]; }  // [6][NOUT]
+        cv[k] = x;
+      }
+#pragma unroll
+      for (int k = 0; k < NCV; ++k)
+        if (tid + k * FD_THREADS < S::NCONST) cst[tid + k * FD_THREADS] = cv[k];
     }
     if (tid < 32) pmask[tid] = a.rowmask_post ? a.rowmask_post[row0 + tid < a.M ? row0 + tid : a.M - 1] : 1.f;
 #pragma unroll
@@ -361,6 +370,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   const int row0 = blockIdx.x * 32;
   char* stg = st_all + wave * 32 * RB_SROW;
+  FD_STAMP(0);
   bf16x8 Wf[2][TL_KS];
   auto w_load = [&](auto BUF, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value;
@@ -376,10 +386,18 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       const int gr = row0 + r < a.M ? row0 + r : a.M - 1;
       xv[k] = *(const f32x4*)(a.att + (long)gr * a.ld + 4 * c4);
     }
-    for (int v = tid; v < 7 * TL_D; v += FD_THREADS) {
-      const int which = v / TL_D, c = v % TL_D;
-      const float* src = which == 0 ? a.bo : which == 1 ? a.g1 : which == 2 ? a.be1 : which == 3 ? a.b1 : which == 4 ? a.b2 : which == 5 ? a.g2 : a.be2;
-      cst[v] = src[c];
+    {  // the 7 x 320 constants: all 9 loads of a thread in flight together (a rolled loop is 9 dependent L2 round trips)
+      constexpr int NCV = (7 * TL_D + FD_THREADS - 1) / FD_THREADS;
+      float cv[NCV];
+#pragma unroll
+      for (int k = 0; k < NCV; ++k) {
+        const int v = tid + k * FD_THREADS, which = v / TL_D, c = v % TL_D;
+        const float* src = which == 0 ? a.bo : which == 1 ? a.g1 : which == 2 ? a.be1 : which == 3 ? a.b1 : which == 4 ? a.b2 : which == 5 ? a.g2 : a.be2;
+        cv[k] = v < 7 * TL_D ? src[c] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NCV; ++k)
+        if (tid + k * FD_THREADS < 7 * TL_D) cst[tid + k * FD_THREADS] = cv[k];
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -400,6 +418,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       rv[u][it] = *(const f32x4*)(a.x + (long)gr * a.ld + 32 * T + 4 * (lane & 7));
     }
   __syncthreads();
+  FD_STAMP(1);
   bf16x8 X[TL_KS];
   f32x16 acc[3], xa[3];
   auto layer = [&](const char* img) {
@@ -422,30 +441,27 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   };
   // LayerNorm of the rows held as acc[] (lane = row, this wave's tiles) -> normalised values back in acc[]
   auto layernorm = [&](const float* gam, const float* bet) {
-    float s1 = 0.f;
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-      if (wave + 4 * u < TL_NT)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s1 += acc[u][r];
-    s1 += __shfl_xor(s1, 32, 64);
-    __syncthreads();  // red[] may still be read by a slower wave from the previous LayerNorm
-    if (hi == 0) red[0][wave][li] = s1;
-    __syncthreads();
-    const float mu = (red[0][0][li] + red[0][1][li] + red[0][2][li] + red[0][3][li]) * (1.0f / TL_D);
-    float s2 = 0.f;
+    // one pass: sum and sum of squares together -> ONE exchange between the lane halves and the four waves
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int u = 0; u < 3; ++u)
       if (wave + 4 * u < TL_NT)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float dd = acc[u][r] - mu;
-          s2 += dd * dd;
+          s1 += acc[u][r];
+          s2 += acc[u][r] * acc[u][r];
         }
+    s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
-    if (hi == 0) red[1][wave][li] = s2;
+    __syncthreads();  // red[] may still be read by a slower wave from the previous LayerNorm
+    if (hi == 0) {
+      red[0][wave][li] = s1;
+      red[1][wave][li] = s2;
+    }
     __syncthreads();
-    const float rstd = 1.0f / sqrtf((red[1][0][li] + red[1][1][li] + red[1][2][li] + red[1][3][li]) * (1.0f / TL_D) + 1e-5f);
+    const float mu = (red[0][0][li] + red[0][1][li] + red[0][2][li] + red[0][3][li]) * (1.0f / TL_D);
+    const float ex2 = (red[1][0][li] + red[1][1][li] + red[1][2][li] + red[1][3][li]) * (1.0f / TL_D);
+    const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mu * mu, 0.f) + 1e-5f);
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int T = wave + 4 * u;
@@ -463,6 +479,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(xs + li * TL_XROW + 32 * s + 16 * hi);
   // ---- stage 1: out_proj + x, LayerNorm1
   layer((const char*)a.wo);
+  FD_STAMP(2);
   w_load(std::integral_constant<int, 0>{}, (const char*)a.w1, wave);  // first feed-forward tile: in flight across the barriers
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -480,6 +497,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
     }
   }
   layernorm(cst + TL_D, cst + 2 * TL_D);
+  FD_STAMP(3);
   // x_a: fp32 in registers (residual of stage 2), bf16 rows -> LDS (input of stage 2)
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -499,7 +517,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
   for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(hs + li * TL_XROW + 32 * s + 16 * hi);
   // ---- stage 2: feed-forward
+  FD_STAMP(4);
   layer((const char*)a.w1);
+  FD_STAMP(5);
   w_load(std::integral_constant<int, 0>{}, (const char*)a.w2, wave);
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -518,7 +538,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(xs + li * TL_XROW + 32 * s + 16 * hi);
+  FD_STAMP(6);
   layer((const char*)a.w2);
+  FD_STAMP(7);
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int T = wave + 4 * u;
@@ -531,6 +553,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       }
   }
   layernorm(cst + 5 * TL_D, cst + 6 * TL_D);
+  FD_STAMP(8);
   // ---- x_b rows out through the wave's tile (128 B row segments)
 #pragma unroll
   for (int u = 0; u < 3; ++u) {

@@ -1,0 +1,36 @@
+// Stand-alone timing + phase profile (-DFD_PROF) of tfmr_tail_kernel (rowblock.hip), zero inputs, M = 2400 rows.
+#include "../../framedipt_amd/csrc/rowblock.hip"
+#include <cstdio>
+#include <vector>
+int main() {
+  const int M = 2400, D = 320;
+  float *att, *x, *out, *vec; void* w;
+  (void)hipMalloc(&att, (size_t)M * D * 4); (void)hipMalloc(&x, (size_t)M * D * 4); (void)hipMalloc(&out, (size_t)M * D * 4);
+  (void)hipMalloc(&vec, 7 * D * 4); (void)hipMalloc(&w, 3 * (size_t)D * D * 2);
+  (void)hipMemset(att, 0, (size_t)M * D * 4); (void)hipMemset(x, 0, (size_t)M * D * 4); (void)hipMemset(vec, 0, 7 * D * 4); (void)hipMemset(w, 0, 3 * (size_t)D * D * 2);
+  TfmrTailArgs a; a.M = M; a.ld = D; a.att = att; a.x = x; a.out = out;
+  a.wo = w; a.w1 = (char*)w + (size_t)D * D * 2; a.w2 = (char*)w + 2 * (size_t)D * D * 2;
+  a.bo = vec; a.g1 = vec + D; a.be1 = vec + 2 * D; a.b1 = vec + 3 * D; a.b2 = vec + 4 * D; a.g2 = vec + 5 * D; a.be2 = vec + 6 * D;
+  hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+  for (int i = 0; i < 3; ++i) fd_tfmr_tail(a, 0);
+  (void)hipEventRecord(t0, 0);
+  const int iters = 50;
+  for (int i = 0; i < iters; ++i) fd_tfmr_tail(a, 0);
+  (void)hipEventRecord(t1, 0); (void)hipEventSynchronize(t1);
+  float ms; (void)hipEventElapsedTime(&ms, t0, t1);
+  printf("tfmr_tail M=%d: %.2f us/launch\n", M, ms / iters * 1e3);
+#ifdef FD_PROF
+  {
+    const int nb = 75;
+    std::vector<unsigned long long> h((size_t)nb * 16);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fd_prof), h.size() * 8);
+    const char* names[9] = {"", "inputs + constants -> LDS", "stage 1 MFMA (out_proj)", "residual + LayerNorm1", "x_a -> LDS + fragments", "stage 2 MFMA (FFN 1)", "relu -> LDS + fragments", "stage 3 MFMA (FFN 2)", "residual + LayerNorm2"};
+    for (int k = 1; k < 9; ++k) {
+      double s = 0;
+      for (int b = 0; b < nb; ++b) s += (double)(h[(size_t)b * 16 + k] - h[(size_t)b * 16 + k - 1]);
+      printf("  %-30s %8.0f cyc\n", names[k], s / nb);
+    }
+  }
+#endif
+  return 0;
+}
