@@ -29,6 +29,14 @@ __host__ __device__ constexpr int rb_max(int a, int b) { return a > b ? a : b; }
 // FLAGS bit0 / bit1: ReLU after hidden 1 / 2, bit2: LayerNorm.  Residual and the final row mask are optional (pointers).
 // Activation rows in LDS are [32][width bf16 + 16 B]: with widths 80..320 the 16 lanes of a b128 read hit 16 distinct
 // 16 B slots, no swizzle needed.
+template <int N, class F>
+__device__ __forceinline__ void ch_rb_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+  if constexpr (N > 0) {
+    ch_rb_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 template <int K0, int N1, int N2, int NOUT, int FLAGS>
 struct RBShape {
   static constexpr int KS0 = (K0 + 15) / 16;
@@ -64,7 +72,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   char* stg = st_all + wave * 32 * RB_SROW;
   const char* wimg[3] = {(const char*)a.w0, (const char*)a.w1, (const char*)a.w2};
   // ---- first weight tile of this wave in flight before anything else
-  bf16x8 Wf[2][KSMAX];
+  // weight-fragment buffers: tile u of a wave lives in buffer u % NB; wide outputs with short K (8 tiles of 8 fragments per wave)
+  // keep three tiles in flight instead of one (each tile is a dependent L2 round trip otherwise)
+  constexpr int NB = (NTW >= 6 && KSMAX <= 16) ? 4 : 2;
+  bf16x8 Wf[NB][KSMAX];
   auto w_load = [&](auto BUF, auto KSC, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value, KS = decltype(KSC)::value;
 #pragma unroll
@@ -134,24 +145,29 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   auto layer = [&](auto KSC, auto NTC, const char* img, auto SWAPC) {
     constexpr int KS = decltype(KSC)::value, NT = decltype(NTC)::value;
     constexpr bool SWAP = decltype(SWAPC)::value;  // operands exchanged: lane = output feature, registers = rows
-#pragma unroll
-    for (int u = 0; u < NTW; ++u) {
+    auto load_tile = [&](auto V) {  // tile v of this wave -> buffer v % NB
+      constexpr int v = decltype(V)::value;
+      if (v < NTW && wave + 4 * v < NT) w_load(std::integral_constant<int, v % NB>{}, KSC, img, wave + 4 * v);
+    };
+    if constexpr (NB > 2) {  // tiles 1 .. NB-2 up front (tile 0 was requested by the caller, tile u + NB - 1 follows at tile u)
+      load_tile(std::integral_constant<int, 1>{});
+      load_tile(std::integral_constant<int, 2>{});
+    }
+    ch_rb_for<NTW>([&](auto U) {
+      constexpr int u = decltype(U)::value;
       const int T = wave + 4 * u;
-      if (u + 1 < NTW && T + 4 < NT) {
-        if (u & 1) w_load(std::integral_constant<int, 0>{}, KSC, img, T + 4);
-        else w_load(std::integral_constant<int, 1>{}, KSC, img, T + 4);
-      }
+      load_tile(std::integral_constant<int, u + NB - 1>{});
       if (T < NT) {
         f32x16 c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-          c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[s], Wf[u & 1][s], c, 0, 0, 0)
-                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
+          c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[s], Wf[u % NB][s], c, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u % NB][s], X[s], c, 0, 0, 0);
         acc[u] = c;
       }
-    }
+    });
   };
   // hidden = act(acc + bias) -> bf16 -> LDS rows (natural feature order); every wave then re-reads all of it
   auto to_hidden = [&](auto NTC, auto RELU, const float* bias, char* dst, unsigned short* hid_bf16, int hid_ld) {
