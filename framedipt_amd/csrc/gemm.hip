@@ -372,8 +372,13 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
     float t = 0.f;
     if (c < D) {
       t = x[(long)row * ldx + c];
-      if (residual)
-        for (int k = 0; k < nparts; ++k) t += residual[k * part_stride + (long)row * ldr + c];  // split-K partial products
+      if (residual) {  // split-K partial products: all requested together (a rolled loop is nparts dependent round trips)
+        float pr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pr[k] = k < nparts ? residual[k * part_stride + (long)row * ldr + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += pr[k];
+      }
     }
     v[i] = t;
     s += t;
@@ -408,7 +413,7 @@ int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, i
 // LayerNorm(x + sum_k parts[k]) for the split-K products of fd_linear_splitk
 int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
                        const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
-  if (M <= 0 || D <= 0 || D > 1024 || !x || !parts || nparts < 1 || !gamma || !beta || !out) return FDIPT_EINVAL;
+  if (M <= 0 || D <= 0 || D > 1024 || !x || !parts || nparts < 1 || nparts > 8 || !gamma || !beta || !out) return FDIPT_EINVAL;
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, parts, ldr, nparts,
                      part_stride, gamma, beta, rowmask, out, ldo);
   FD_CHECK_LAUNCH();
