@@ -158,6 +158,18 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
   // blockIdx.y = 0 / 1 / 2 takes the Q / K / V third of the 30 output tiles (3x the blocks: the kernel is latency-bound)
   constexpr int NTP = SQ_K / 32;  // 10 tiles per part
   const int T0 = blockIdx.y * NTP;
+  // bias of this wave's tiles, requested now (before the MFMAs), in the layout of the part's epilogue: a load issued after a
+  // tile's MFMAs is one exposed L2 round trip per tile
+  f32x4 bq[(NTP + 3) / 4][4];
+#pragma unroll
+  for (int u = 0; u < (NTP + 3) / 4; ++u) {
+    const int Tb = T0 + (wave + 4 * u < NTP ? wave + 4 * u : wave);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (blockIdx.y < 2) bq[u][g] = *(const f32x4*)(bias + 32 * Tb + 8 * g + 4 * hi);
+      else if (g == 0) bq[u][0][0] = bias[32 * Tb + li];
+    }
+  }
 #pragma unroll
   for (int u = 0; u < (NTP + 3) / 4; ++u) {
     const int T = T0 + wave + 4 * u;
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
           const int f = 32 * T + 8 * g + 4 * hi;  // 4 consecutive output features
           const bool isk = f >= SQ_K;
           const int c = isk ? f - SQ_K : f, h = c / SA_HD, cc = c - h * SA_HD;
-          const f32x4 bv = *(const f32x4*)(bias + f);
+          const f32x4 bv = bq[u][g];
           const float sc = isk ? 1.f : qscale;
           sa_bf16x4 o;
 #pragma unroll
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
 #pragma unroll
       for (int s = 0; s < SQ_KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[s], Wf[u & 1][s], acc, 0, 0, 0);
       const int f = 32 * T + li, c = f - 2 * SQ_K, h = c / SA_HD, d = c - h * SA_HD;
-      const float bv = bias[f];
+      const float bv = bq[u][0][0];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int m0 = row0 + 8 * g + 4 * hi;  // 4 consecutive rows = 4 consecutive keys of one sample (N % 4 == 0)
