@@ -25,6 +25,7 @@
 typedef __bf16 p2_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned p2_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned p2_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned p2_cvt_pk(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (round to nearest even)
   return __builtin_bit_cast(unsigned, __builtin_convertvector(p2_f32x2{lo, hi}, p2_bf16x2));
 }
@@ -59,17 +60,18 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
     for (int u = 0; u < P2_WBLK / (FD_THREADS * 16); ++u)
       p2_dma16(src + (size_t)(u * FD_THREADS + tid) * 16, lds0 + buf * P2_WBLK + (unsigned)(u * FD_THREADS + (tid & ~63)) * 16);
   };
+  FD_STAMP(0);
   if (kb < n_class) request(cblk_of(kb), 0);  // the first weight block is on its way while the activations are staged
   // ---- activation rows: fp32 -> bf16 -> LDS (buffer 1: 128 rows x 512 B, 16 B chunk c of row r at c ^ (r & 15)), once
   {
     char* xs = smem + P2_WBLK;
-#pragma unroll 16
-    for (int it = 0; it < 32; ++it) {  // 128 rows x 64 float4
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {  // 128 rows x 64 float4 (all 32 requests of a thread in flight: one round trip)
       const int idx = tid + it * FD_THREADS, r = idx >> 6, c4 = idx & 63;
       const int gr = m0 + r < M ? m0 + r : M - 1;
       const f32x4 x = *(const f32x4*)(a.A + (long)gr * a.lda + 4 * c4);
-      const u16x4 h = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
-      *(u16x4*)(xs + r * P2_XROW + (((c4 >> 1) ^ (r & 15)) << 4) + 8 * (c4 & 1)) = h;
+      const p2_u32x2 h = {p2_cvt_pk(x[0], x[1]), p2_cvt_pk(x[2], x[3])};
+      *(p2_u32x2*)(xs + r * P2_XROW + (((c4 >> 1) ^ (r & 15)) << 4) + 8 * (c4 & 1)) = h;
     }
   }
   __syncthreads();
@@ -82,6 +84,7 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       Af[i][s] = p2_frag(lds0 + P2_WBLK + r * P2_XROW + (((2 * s + hi) ^ (r & 15)) << 4));
     }
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers before the buffer is overwritten
+  FD_STAMP(1);
   // ---- store addressing, split into a part that depends on the row(s) of a register group (computed once) and a part that
   // depends on the column block (once per block): an epilogue unit adds the two and a compile-time constant
   //   Q / K images (lane = row): element ((((b H + h) ntl + (r >> 5)) (C >> 4) + (cc >> 4)) 64 + ((cc >> 3) & 1) 32 + (r & 31)) 8 + (cc & 7)
@@ -110,14 +113,19 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
   // cpart: column part of the block (QK: head; V: per j (head, channel of this lane); points: column of this lane, or -1)
   auto epi_unit = [&](const f32x16 (&acc)[2][2], const f32x4 (&bq)[2][4], const int (&cpart)[2], int kind, int i, int j, int g) {
     if constexpr (QK) {
-      if (qk_row[i] < 0) return;
-      const f32x4 bv = bq[j][g];
+      // the rows of the Q / K weight tiles are permuted in the image (fd_ipa_proj2_permute_image) so that register r of a lane
+      // is channel 16 (r >> 3) + 8 hi + (r & 7) of the tile: 8 consecutive channels = one whole 16 B fragment unit per lane and
+      // 16-group G = g >> 1; the odd g of a pair has nothing left to do
+      if ((g & 1) || qk_row[i] < 0) return;
+      const f32x4 b0 = bq[j][g], b1 = bq[j][g + 1];
       const float sc = kind == 0 ? a.qscale : 1.f;
-      const p2_u32x2 o = {p2_cvt_pk((acc[i][j][4 * g] + bv[0]) * sc, (acc[i][j][4 * g + 1] + bv[1]) * sc),
-                          p2_cvt_pk((acc[i][j][4 * g + 2] + bv[2]) * sc, (acc[i][j][4 * g + 3] + bv[3]) * sc)};
-      // cc = cbase + (2 wc + j) 32 + 8 g + 4 hi: cc >> 4 = (cbase >> 4) + 2 (2 wc + j) + (g >> 1), (cc >> 3) & 1 = g & 1, cc & 7 = 4 hi
-      bf16_t* dst = (kind == 0 ? a.Qb : a.Kb) + (long)qk_row[i] + cpart[0] + ((2 * j + (g >> 1)) * 64 + (g & 1) * 32) * 8;
-      *(p2_u32x2*)dst = o;
+      const p2_u32x4 o = {p2_cvt_pk((acc[i][j][4 * g] + b0[0]) * sc, (acc[i][j][4 * g + 1] + b0[1]) * sc),
+                          p2_cvt_pk((acc[i][j][4 * g + 2] + b0[2]) * sc, (acc[i][j][4 * g + 3] + b0[3]) * sc),
+                          p2_cvt_pk((acc[i][j][4 * g + 4] + b1[0]) * sc, (acc[i][j][4 * g + 5] + b1[1]) * sc),
+                          p2_cvt_pk((acc[i][j][4 * g + 6] + b1[2]) * sc, (acc[i][j][4 * g + 7] + b1[3]) * sc)};
+      // cc = cbase + (2 wc + j) 32 + 16 G + 8 hi: cc >> 4 = (cbase >> 4) + 2 (2 wc + j) + G, (cc >> 3) & 1 = hi, cc & 7 = 0
+      bf16_t* dst = (kind == 0 ? a.Qb : a.Kb) + (long)qk_row[i] + cpart[0] + ((2 * j + (g >> 1)) * 64) * 8;
+      *(p2_u32x4*)dst = o;
     } else {
       if (cpart[j] < 0) return;
       const float bv = bq[j][0][0];
@@ -142,7 +150,7 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
     if constexpr (QK) {
       const bool isq = n0 < HC;
       const int nn0 = isq ? n0 : n0 - HC, hh = isq ? nn0 / a.C : nn0 / (2 * a.C), cbase = isq ? nn0 % a.C : nn0 % (2 * a.C);
-      cpart[0] = (hh * ntl * (a.C >> 4) * 64 + ((cbase >> 4) + 4 * wc) * 64) * 8 + 4 * hi;
+      cpart[0] = (hh * ntl * (a.C >> 4) * 64 + ((cbase >> 4) + 4 * wc) * 64 + hi * 32) * 8;
       cpart[1] = 0;
       return isq ? 0 : 1;
     } else {
@@ -165,7 +173,7 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if constexpr (QK) bq[j][g] = *(const f32x4*)(a.bias + n0 + (wc * 2 + j) * 32 + 8 * g + 4 * hi);
+        if constexpr (QK) bq[j][g] = *(const f32x4*)(a.bias + n0 + (wc * 2 + j) * 32 + 16 * (g >> 1) + 8 * hi + 4 * (g & 1));  // (permuted rows)
         else if (g == 0) {
           const int n = n0 + (wc * 2 + j) * 32 + li;
           bq[j][0][0] = n < NOUT ? a.bias[n] : 0.f;
@@ -228,9 +236,12 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
   f32x4 bq0[2][4], bq1[2][4];
   int cp0[2] = {0, 0}, cp1[2] = {0, 0}, kind0 = 0, kind1 = 0;
   bool has_prev = false;
+  int n_step = 0;
+  (void)n_step;
   for (;;) {
     if (kb >= n_class) break;
     step(acc0, bq0, cp0, kind0, acc1, bq1, cp1, kind1, kb, has_prev, 0);
+    FD_STAMP(2 + n_step); ++n_step;
     has_prev = true;
     kb += n_walkers;
     if (kb >= n_class) {
@@ -239,6 +250,7 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       break;
     }
     step(acc1, bq1, cp1, kind1, acc0, bq0, cp0, kind0, kb, true, 1);
+    FD_STAMP(2 + n_step); ++n_step;
     kb += n_walkers;
     if (kb >= n_class) {
 #pragma unroll
@@ -253,6 +265,28 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_proj2_kernel(ProjArgs a, in
   else ipa_proj2_body<false>(a, n_cblk, blockIdx.y - n_walk_qk, gridDim.y - n_walk_qk, smem);
 }
 
+// Row permutation of the Q / K tiles of the weight image (see the Q / K epilogue unit): image row rho of a 32-row tile takes the
+// weight row of channel 16 (r >> 3) + 8 hi + (r & 7) with hi = (rho >> 2) & 1, r = (rho & 3) + 4 (rho >> 3).  Tiles: the q part
+// (H C / 32 tiles), then per head 2 C / 32 tiles of which the first C / 32 are K.  In place, one block per (tile, k-step).
+__global__ void p2_permute_rows_kernel(bf16_t* img, int ks, int n_q_tiles, int per_head) {
+  const int tile = blockIdx.x / ks, s = blockIdx.x % ks;
+  const bool qk = tile < n_q_tiles || ((tile - n_q_tiles) % per_head) < per_head / 2;
+  if (!qk) return;
+  __shared__ u16x8 buf[64];
+  u16x8* frag = (u16x8*)img + ((size_t)tile * ks + s) * 64;
+  const int lane = threadIdx.x, rho = lane & 31, half = lane >> 5;
+  buf[lane] = frag[lane];
+  __syncthreads();
+  const int hi = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3), c = 16 * (r >> 3) + 8 * hi + (r & 7);
+  frag[lane] = buf[c + 32 * half];
+}
+int fd_ipa_proj2_permute_image(void* img, int H, int C, int K, hipStream_t st) {
+  if ((C & 31) || (K & 15)) return FDIPT_EINVAL;
+  const int n_q = H * C / 32, n_kv = 2 * H * C / 32, ks = K / 16;
+  hipLaunchKernelGGL(p2_permute_rows_kernel, dim3((n_q + n_kv) * ks), dim3(64), 0, st, (bf16_t*)img, ks, n_q, 2 * C / 32);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 int fd_ipa_proj2_supported(const ProjArgs& a) {
   const int HC = a.H * a.C;
   return a.K == P2_K && a.W_img && (a.N & 3) == 0 && (a.C % 128) == 0 && (HC % 128) == 0 && (a.lda & 3) == 0 && (a.Np & 31) == 0 && (a.PT & 3) == 0;
@@ -271,7 +305,8 @@ int fd_ipa_proj2(const ProjArgs& a, hipStream_t st) {
   int ncg = 256 / n_rblk;
   if (ncg < 2) ncg = 2;
   const int n_qk = 2 * (a.H * a.C / 128), n_other = n_cblk - n_qk;
-  int wq = (ncg * n_qk + n_cblk / 2) / n_cblk;
+  // (a Q / K column block costs about 6 / 7 of a V / point block: 16 B stores against 8 B / 4 B ones)
+  int wq = (ncg * n_qk * 6 + (n_qk * 6 + n_other * 7) / 2) / (n_qk * 6 + n_other * 7);
   if (wq < 1) wq = 1;
   if (wq > ncg - 1) wq = ncg - 1;
   if (wq > n_qk) wq = n_qk;

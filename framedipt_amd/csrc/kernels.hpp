@@ -157,6 +157,8 @@ struct ProjArgs {
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
 int fd_ipa_proj_zero_pads(const ProjArgs& a, hipStream_t st);
 int fd_ipa_proj2_supported(const ProjArgs& a);
+// after the fragment image of the fused projection weight is built: permute the rows of its Q / K tiles (16 B epilogue stores)
+int fd_ipa_proj2_permute_image(void* img, int H, int C, int K, hipStream_t st);
 int fd_ipa_proj2(const ProjArgs& a, hipStream_t st);  // second generation (ipa_proj2.hip): same outputs
 
 struct Attn3Args {

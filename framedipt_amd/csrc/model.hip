@@ -298,6 +298,8 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
         return rc;
       row += parts[p]->out;
     }
+    // (only shapes fd_ipa_proj2_supported accepts ever read the image)
+    if (proj_img && C % 128 == 0 && (H * C) % 128 == 0 && (rc = fd_ipa_proj2_permute_image(D + db.wproj_img, H, C, cs, st))) return rc;
     hipLaunchKernelGGL(gamma_kernel, dim3(1), dim3(64), 0, st, H, d->no_qk_points, P + k.head_w, (float*)(D + db.gamma));
     FD_CHECK_LAUNCH();
     // pair bias pre-scaled by sqrt(1/3) (ipa_pytorch.py:256-257)
