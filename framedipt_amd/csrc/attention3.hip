@@ -90,6 +90,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
     for (int s = 0; s < 12; ++s) qB[s] = gam * qpr[2 * s + hi];
     qB[12] = gam * (hi ? -0.5f * qn : 1.0f);
   }
+  FD_STAMP(1);
   // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...  The global operands of tile u+1 (K rows as A
   // fragments, key points, bias row pieces, mask) are fetched while tile u runs through the matrix cores.
   struct TileIn {

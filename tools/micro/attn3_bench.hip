@@ -28,11 +28,11 @@ int main(int argc, char** argv) {
   const int nb = (Np / 32) * H * B;
   std::vector<unsigned long long> h((size_t)nb * 16);
   (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fd_prof), h.size() * 8);
-  const char* names[8] = {"", "prologue (Q, q_pts)", "phase 1 logits", "phase 2 softmax", "phase 3 probs/P", "barrier", "-", "phase 4 PV + o_pt"};
+  const char* names[8] = {"", "prologue (Q -> LDS, q_pts)", "phase 1 logits", "phase 2 softmax", "phase 3 probs/P", "barrier", "-", "phase 4 PV + o_pt"};
   double tot = 0;
   for (int k = 1; k < 8; ++k) {
     double s = 0;
-    for (int b = 0; b < nb; ++b) s += (double)(h[(size_t)b * 16 + k] - h[(size_t)b * 16 + k - 1]);
+    for (int b = 0; b < nb; ++b) s += (double)(h[(size_t)b * 16 + k] - h[(size_t)b * 16 + (k - 1)]);
     s /= nb; tot += s;
     printf("  %-30s %8.0f cyc\n", names[k], s);
   }
