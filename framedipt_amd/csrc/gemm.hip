@@ -360,10 +360,14 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ rowmask,
-                                                               float* __restrict__ out, int ldo) {
+                                                               float* __restrict__ out, int ldo,
+                                                               const float* __restrict__ extra, int ld_extra, int n_extra) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (FD_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= M) return;
+  // optional: columns D .. D + n_extra of the output row are a copy of extra[row] (the skip embedding of the sequence transformer's
+  // input, computed for all blocks in one launch at the start of the forward)
+  for (int c = lane; c < n_extra; c += 64) out[(long)row * ldo + D + c] = extra[(long)row * ld_extra + c];
   float v[16];
   float s = 0.f;
 #pragma unroll
@@ -406,16 +410,17 @@ int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, i
                  const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !gamma || !beta || !out) return FDIPT_EINVAL;
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, residual, ldr, 1,
-                     0L, gamma, beta, rowmask, out, ldo);
+                     0L, gamma, beta, rowmask, out, ldo, (const float*)nullptr, 0, 0);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
 // LayerNorm(x + sum_k parts[k]) for the split-K products of fd_linear_splitk
 int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
-                       const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
+                       const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, const float* extra,
+                       int ld_extra, int n_extra, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !parts || nparts < 1 || nparts > 8 || !gamma || !beta || !out) return FDIPT_EINVAL;
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, parts, ldr, nparts,
-                     part_stride, gamma, beta, rowmask, out, ldo);
+                     part_stride, gamma, beta, rowmask, out, ldo, extra, ld_extra, extra ? n_extra : 0);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

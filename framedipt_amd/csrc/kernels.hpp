@@ -258,7 +258,8 @@ int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const
 int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* W, const float* bias, float* out,
                 hipStream_t st);
 int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
-                       const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st);
+                       const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, const float* extra,
+                       int ld_extra, int n_extra, hipStream_t st);
 // the same with bf16 activation rows (what the bf16 GEMM would round them to anyway)
 int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const bf16_t* A, int lda, const void* W, int ldw, const float* bias,
                          const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);

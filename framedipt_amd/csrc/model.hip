@@ -104,6 +104,7 @@ struct DLayout {
   size_t ee2;         // LDS images of edge-embedder layers 2/3 (register-resident bf16 kernel)
   size_t ch_ne0, ch_ne2, ch_ne4, ch_tor1, ch_tor2;  // chain images: node embedder, torsion head
   size_t ch_ne2n, ch_ne4n, ch_tor2n;                // ... natural k order (rowblock.hip)
+  size_t skip_w, skip_b;                            // skip_embed of ALL blocks stacked: [num_blocks * c_skip, c_s] operand precision, bias f32
   DBlock blk[FD_MAX_BLOCKS];
   size_t total;
   int kn_pad, d1_pad, esz;
@@ -174,6 +175,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.ch_tor1 = img(d->c_s, d->c_s); L.ch_tor2 = img(d->c_s, d->c_s);
     L.ch_ne2n = img(d->c_s, d->c_s); L.ch_ne4n = img(d->c_s, d->c_s); L.ch_tor2n = img(d->c_s, d->c_s);
   }
+  L.skip_w = o; o = al256(o + (size_t)d->num_blocks * d->c_skip * d->c_s * L.esz);
+  L.skip_b = o; o = al256(o + (size_t)d->num_blocks * d->c_skip * 4);
   L.total = o;
 }
 
@@ -282,6 +285,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     const BlockW& k = iv.blk[b];
     const DBlock& db = L.blk[b];
     // fused projection [q | kv | q_pts | kv_pts] rows (ipa_pytorch.py:202-239)
+    if ((rc = copy_cols(L.esz, d->c_skip, cs, cs, P + k.skip.w, cs, 0, 1.f, D + L.skip_w + (size_t)b * d->c_skip * cs * L.esz, st)) ||
+        (rc = copy_cols(4, 1, d->c_skip, d->c_skip, P + k.skip.b, d->c_skip, 0, 1.f, D + L.skip_b + (size_t)b * d->c_skip * 4, st)))
+      return rc;
     const LinW* parts[4] = {&k.q, &k.kv, &k.qp, &k.kvp};
     long row = 0;
     const bool proj_img = L.esz == 2 && cs == 256;
@@ -391,7 +397,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, skip_all, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -426,6 +432,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.ipa_parts = take((size_t)8 * R * d->c_s * 4);
   w.vpt = take((size_t)B * H * 96 * (((size_t)N + 31) / 32 * 32) * 2);  // v_pts hi/lo fragment image (attention3 o_pt)
   w.e_bf = take(R * iv.cb * 2);  // bf16 copy of initial_embed(node) (edge_transition3 fetches it by LDS-DMA)  // split-K partial products of the IPA output projection
+  w.skip_all = take(R * (size_t)d->num_blocks * d->c_skip * 4);  // skip_embed(init_node) of all blocks
   w.r4 = take(R * (size_t)1024 * 4);  // edge_transition4: [A1 | Af | B1 | Bf] rows, then their fold-fragment images
   w.a1img = take(fd_et4_a_image_bytes(B, N));
   w.b1img = take(fd_et4_b_image_bytes(B, N));
@@ -559,6 +566,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   // ---- IpaScore trunk (ipa_pytorch.py:509-551)
   RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask, F(w.quat), F(w.trans), F(w.dmask), st));
   const float* node_cur = F(w.node0);
+  // skip_embed(init_node) of every block depends on the embedder output only: one GEMM launch for all blocks, copied behind the
+  // LayerNorm output by the LayerNorm kernel (FDIPT_SKIP_PER_BLOCK: one launch per block as before)
+  const bool skip_batched = bf && iv.feat_dim >= 1024 && !getenv("FDIPT_NO_SPLITK") && !getenv("FDIPT_SKIP_PER_BLOCK");
+  if (skip_batched)
+    RC(fd_linear(prec, R, d->num_blocks * d->c_skip, cs, F(w.node0), cs, D + L.skip_w, cs, (const float*)(D + L.skip_b), nullptr, 0,
+                 nullptr, 0, F(w.skip_all), d->num_blocks * d->c_skip, st));
   const size_t NN = (size_t)R * N;
   bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
   bool bias_ready = ee_bias_done;  // pair bias of this block's attention already written (tiled order) by the embedder / EdgeTransition
@@ -574,7 +587,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     OPairArgs oa;
     oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_bf16 = nullptr; oa.probs_np = 0; oa.out_bf16 = nullptr;
     oa.wdz = (const float*)(D + db.wdz_t); oa.wdz_img = (bf && cz == 128) ? D + db.wdz_img : nullptr; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
-    bool feats_bf16 = false;
+    bool feats_bf16 = false, skip_done = false;
     const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !getenv("FDIPT_ATTN_V1") &&
                         !getenv("FDIPT_ATTN_V2") && fd_attention3_supported(a3);
     PointsArgs pa;
@@ -645,12 +658,15 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         RC(fd_linear_splitk(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b, res_mask,
                             F(w.ipa_parts), (long)R * cs, cs, st));
       RC(fd_layernorm_parts(R, cs, node_cur, cs, F(w.ipa_parts), cs, NS, (long)R * cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr,
-                            F(w.tf_in), dt, st));
+                            F(w.tf_in), dt, skip_batched ? F(w.skip_all) + (size_t)b * d->c_skip : nullptr,
+                            d->num_blocks * d->c_skip, d->c_skip, st));
+      skip_done = skip_batched;
     } else {
       RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
       RC(fd_layernorm(R, cs, node_cur, cs, F(w.ipa_out), cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr, F(w.tf_in), dt, st));
     }
-    if (con(FD_CHAIN_SKIP)) RC(chain(FD_CHAIN_SKIP, F(w.node0), cs, D + db.ch.skip, P + k.skip.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+    if (skip_done) {
+    } else if (con(FD_CHAIN_SKIP)) RC(chain(FD_CHAIN_SKIP, F(w.node0), cs, D + db.ch.skip, P + k.skip.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                       nullptr, nullptr, nullptr, F(w.tf_in) + cs, dt));
     else RC(lin(R, k.skip, F(w.node0), cs, nullptr, 0, nullptr, 0, F(w.tf_in) + cs, dt));
     // nn.TransformerEncoder, post-norm (ipa:433-443,536-538)
