@@ -35,7 +35,7 @@ class ForwardArgs(C.Structure):
         (n, _P) for n in ("rigids_t", "res_mask", "fixed_mask", "sc_ca_t", "seq_idx", "idx_emb", "aatype", "gt_psi", "t",
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
                           "atom37", "atom14", "trace_node", "trace_edge")] + [
-        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p))]
+        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P)]
 
 
 _lib = None
@@ -53,6 +53,8 @@ SIGNATURES = {
     "fdipt_forward_workspace_bytes": (_sz, [_DP, _i, _i]),
     "fdipt_score_forward": (_i, [_DP, _P, _P, _P, C.POINTER(ForwardArgs), _P, _sz, _P]),
     "fdipt_se3_reverse_step": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P, _P]),
+    "fdipt_se3_reverse_step_atoms": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P,
+                                          _P, _P, _P, _P, _P]),
     "fdipt_quat_to_rot": (_i, [_i, _P, _P, _P]),
     "fdipt_rot_to_quat": (_i, [_i, _P, _P, _P]),
     "fdipt_quat_multiply": (_i, [_i, _P, _P, _P, _P]),

@@ -89,7 +89,74 @@ __device__ __forceinline__ void d_so3_log(const double* m, double* rv) {
   rv[0] = sc * q[0]; rv[1] = sc * q[1]; rv[2] = sc * q[2];
 }
 
-// ------------------------------------------------------------------ fused reverse step (one block per sample)
+struct BackboneTables {  // packed by framedipt_amd/residue_tables.py
+  float default_frames[21 * 8 * 16];
+  float ideal_pos[21 * 14 * 3];
+  float atom_mask[21 * 14];
+  int32_t group_idx[21 * 14];
+};
+
+__device__ __forceinline__ void d_compose(const float* R1, const float* t1, const float* R2, const float* t2, float* Ro,
+                                          float* to) {  // Rigid.compose, rigid_utils.py:1065-1079
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = R1[i * 3] * R2[j] + R1[i * 3 + 1] * R2[3 + j] + R1[i * 3 + 2] * R2[6 + j];
+  float tmp[3];
+  d_rot_vec(R1, t2, tmp);
+  to[0] = tmp[0] + t1[0]; to[1] = tmp[1] + t1[1]; to[2] = tmp[2] + t1[2];
+}
+
+// all_atom.compute_backbone for residue r with frame (Rb, tbv)
+__device__ __forceinline__ void d_backbone_residue(long r, const float* Rb, const float* tbv, const float* __restrict__ psi,
+                                                   const int32_t* __restrict__ aatype, const BackboneTables* __restrict__ tb,
+                                                   float* __restrict__ atom37, float* __restrict__ atom14) {
+  int aa = aatype ? aatype[r] : 0;
+  if (aa == 20) aa = 0;
+  const float s = psi[r * 2], co = psi[r * 2 + 1];
+  float FR[8][9], FT[8][3];
+  for (int g = 0; g < 8; ++g) {
+    const float* d44 = tb->default_frames + (aa * 8 + g) * 16;
+    float Rd[9], td[3], Ra[9];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Rd[i * 3 + j] = d44[i * 4 + j];
+      td[i] = d44[i * 4 + 3];
+    }
+    const float a0 = g == 0 ? 0.f : s, a1 = g == 0 ? 1.f : co;  // backbone frame: (sin,cos) = (0,1)
+    Ra[0] = 1; Ra[1] = 0; Ra[2] = 0; Ra[3] = 0; Ra[4] = a1; Ra[5] = -a0; Ra[6] = 0; Ra[7] = a0; Ra[8] = a1;
+    const float z3[3] = {0.f, 0.f, 0.f};
+    d_compose(Rd, td, Ra, z3, FR[g], FT[g]);
+  }
+  for (int g = 5; g < 8; ++g) {  // chi2..chi4 chained onto chi1 (feats.py:204-212)
+    float Rn[9], tn[3];
+    d_compose(FR[g - 1], FT[g - 1], FR[g], FT[g], Rn, tn);
+    for (int c = 0; c < 9; ++c) FR[g][c] = Rn[c];
+    for (int c = 0; c < 3; ++c) FT[g][c] = tn[c];
+  }
+  float pos[14][3];
+  for (int at = 0; at < 14; ++at) {
+    const int g = tb->group_idx[aa * 14 + at];
+    float Rg[9], tg[3], p[3];
+    d_compose(Rb, tbv, FR[g], FT[g], Rg, tg);
+    d_rot_vec(Rg, tb->ideal_pos + (aa * 14 + at) * 3, p);
+    const float mk = tb->atom_mask[aa * 14 + at];
+    for (int c = 0; c < 3; ++c) pos[at][c] = (p[c] + tg[c]) * mk;
+  }
+  if (atom14)
+    for (int at = 0; at < 14; ++at)
+      for (int c = 0; c < 3; ++c) atom14[(r * 14 + at) * 3 + c] = pos[at][c];
+  if (atom37) {
+    for (int c = 0; c < 37 * 3; ++c) atom37[r * 111 + c] = 0.f;
+    // atom14 order N,CA,C,O,CB -> atom37 order N,CA,C,CB,O (all_atom.py:168-174)
+    const int map[5] = {0, 1, 2, 4, 3};
+    for (int at = 0; at < 5; ++at)
+      for (int c = 0; c < 3; ++c) atom37[r * 111 + at * 3 + c] = pos[map[at]][c];
+  }
+}
+
+// ------------------------------------------------------------------ fused reverse step
+// grid (row blocks, samples): every block recomputes its sample's centre-of-mass sums (cheap: a few fused multiply-adds per
+// residue, the same summation order in every block), then takes rpb residues through the float64 SO(3) exp / log chain (a
+// long dependent sequence: one residue per lane, as many waves on as many CUs as the batch allows).  In-place updates
+// (rigids_out == rigids_t) need the whole sample in one block: rpb = N.
 struct ReverseArgs {
   int B, N;
   const float* rigids_t;
@@ -102,12 +169,17 @@ struct ReverseArgs {
   double so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, cs;
   float* rigids_out;
   float* out_rot;
+  int rpb;  // residues per block in the second pass
+  const float* psi;  // optional compute_backbone of x_{t-1} (atom37 != nullptr)
+  const int32_t* aatype;
+  const BackboneTables* tables;
+  float* atom37;
 };
 
 __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a) {
   __shared__ double red[4][FD_THREADS / 64];
   __shared__ double com[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.N;
   // schedules: so3_diffuser.py:299-319, r3_diffuser.py:48-85
   const double emax = exp(a.so3_max_sigma), emin = exp(a.so3_min_sigma);
@@ -144,7 +216,8 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
   // COM quirk of the reference: sum over ALL residues divided by the number of DIFFUSED residues (r3:379-383)
   const double cx = a.center ? com[0] / com[3] : 0.0, cy = a.center ? com[1] / com[3] : 0.0,
                cz = a.center ? com[2] / com[3] : 0.0;
-  for (int i = tid; i < N; i += FD_THREADS) {
+  const int i_end = (int)(blockIdx.x + 1) * a.rpb < N ? (int)(blockIdx.x + 1) * a.rpb : N;
+  for (int i = blockIdx.x * a.rpb + tid; i < i_end; i += FD_THREADS) {
     const long r = (long)b * N + i;
     const bool has_mask = a.diffuse_mask != nullptr;
     const double m = has_mask ? (double)a.diffuse_mask[r] : 1.0;
@@ -200,6 +273,10 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
     float* o = a.rigids_out + r * 7;
     o[0] = (float)q[3]; o[1] = (float)q[0]; o[2] = (float)q[1]; o[3] = (float)q[2];
     o[4] = (float)tr_out[0]; o[5] = (float)tr_out[1]; o[6] = (float)tr_out[2];
+    if (a.atom37) {
+      const float tf[3] = {o[4], o[5], o[6]};
+      d_backbone_residue(r, Rf, tf, a.psi, a.aatype, a.tables, a.atom37, nullptr);
+    }
   }
 }
 
@@ -210,30 +287,54 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
 // samples its residues belong to instead of evaluating a float64 exp per residue and term.
 #define RS_L 1000
 #define RS_LANES 16
+// Terms whose weight exp(-l(l+1) sigma^2 / 2) is exactly 0.0 in float64 (exponent below -760; exp underflows to 0 below
+// -745.2) add +-0.0 to both sums: the series is cut there, bit-identical to the 1000-term sum (sigma = 1.5: 28 terms,
+// sigma = 0.1: 392 terms).
+__device__ __forceinline__ int rs_cut(double sg) {
+  const double c = sqrt(1520.0) / sg + 2.0;
+  return c < (double)RS_L ? (int)c : RS_L;
+}
+// Optional epilogue of IpaScore/ScoreNetwork.forward done by otherwise idle lanes of the residue's 16-lane group: the R^3
+// score (r3_diffuser.py:387-440 with use_torch=True, scale=True), the tensor_7 / unscaled translations (ipa:557, sn:268), the
+// psi normalisation (ipa:355-362) with the fixed-residue merge (sn:259-260), and a contiguous copy of the predicted CA
+// positions (the next step's self-conditioning input, experiments/utils.py:361-366).
+struct ScoreTail {
+  const float* trans;  // [R,3] predicted translations, scaled (nullptr: rotation score only)
+  float cs;
+  const float* psi_un; int ld_psi;
+  const float *gt_psi, *fixed_mask, *t;
+  float min_b, max_b;
+  float *rigids, *psi, *trans_score, *ca_out;
+};
 __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t, int ld_t,
                                                                const float* __restrict__ quats_0, int ld_0,
                                                                const double* __restrict__ sigma,
                                                                const float* __restrict__ res_mask,
-                                                               double* __restrict__ score) {
+                                                               double* __restrict__ score, ScoreTail x) {
   __shared__ double wtab[2][RS_L];
   constexpr int RPB = FD_THREADS / RS_LANES;  // residues per block
   const long total = (long)B * N;
   const long r_first = (long)blockIdx.x * RPB;
   const int b_first = (int)((r_first < total ? r_first : total - 1) / N);
-  for (int v = threadIdx.x; v < 2 * RS_L; v += FD_THREADS) {
-    const int which = v / RS_L, l = v % RS_L;
-    const int bb = b_first + which < B ? b_first + which : B - 1;
-    const double sg = sigma[bb];
-    wtab[which][l] = (double)(2 * l + 1) * exp(-(double)l * (double)(l + 1) * sg * sg / 2);
+  const bool use_tab = N >= RPB;  // a block then spans at most two samples; tiny N evaluates the weights per lane
+  if (use_tab) {
+    const int b1 = b_first + 1 < B ? b_first + 1 : B - 1;
+    const double s0 = sigma[b_first], s1 = sigma[b1];
+    const int c0 = rs_cut(s0), c1 = (r_first + RPB - 1) / N > b_first ? rs_cut(s1) : 0;
+    for (int v = threadIdx.x; v < c0 + c1; v += FD_THREADS) {
+      const int which = v >= c0, l = which ? v - c0 : v;
+      const double sg = which ? s1 : s0;
+      wtab[which][l] = (double)(2 * l + 1) * exp(-(double)l * (double)(l + 1) * sg * sg / 2);
+    }
   }
   __syncthreads();
   const long gid = r_first + (threadIdx.x / RS_LANES);
   const int sub = threadIdx.x % RS_LANES;
   const long r = gid < total ? gid : total - 1;
   const int b = (int)(r / N);
-  const bool use_tab = N >= RPB;  // a block then spans at most two samples; tiny N evaluates the weights per lane
   const double* wt = wtab[b - b_first < 2 ? b - b_first : 1];
   const double sg = sigma[b];
+  const int lcut = rs_cut(sg);
   float qi[4], q0t[4], rv[3];
   d_invert_quat(quats_0 + r * ld_0, qi);
   d_quat_mul(qi, quats_t + r * ld_t, q0t);
@@ -242,7 +343,7 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
   const float lo = sinf(omega / 2.f), dlo = 0.5f * cosf(omega / 2.f);
   const float den = lo * lo;
   double f = 0, ds = 0;
-  for (int l = sub; l < RS_L; l += RS_LANES) {
+  for (int l = sub; l < lcut; l += RS_LANES) {
     const double w = use_tab ? wt[l] : (double)(2 * l + 1) * exp(-(double)l * (double)(l + 1) * sg * sg / 2);
     const float lh = (float)l + 0.5f;
     const float arg = omega * lh;
@@ -256,10 +357,33 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
     f += __shfl_xor(f, o, 64);
     ds += __shfl_xor(ds, o, 64);
   }
-  if (gid < total && sub < 3) {
+  if (gid >= total) return;
+  if (sub < 3) {
     const double sc = ds / (f + 1e-4);
     const double m = res_mask ? (double)res_mask[r] : 1.0;
     score[r * 3 + sub] = sc * (double)rv[sub] / (double)omega * m;
+  }
+  if (!x.trans) return;
+  if (sub >= 3 && sub < 6) {
+    const int c = sub - 3;
+    const float x0u = x.trans[r * 3 + c] / x.cs;
+    x.rigids[r * 7 + 4 + c] = x0u;
+    if (x.ca_out) x.ca_out[r * 3 + c] = x0u;
+    const float tt = x.t[b];
+    const float mb = tt * x.min_b + 0.5f * (tt * tt) * (x.max_b - x.min_b);
+    const float e = expf(-0.5f * mb);
+    const float cv = 1.f - expf(-mb);
+    const float m = res_mask ? res_mask[r] : 1.f;
+    const float xt = quats_t[r * ld_t + 4 + c] * x.cs, x0 = x0u * x.cs;  // rigids_t is tensor_7: translations behind the quaternion
+    x.trans_score[r * 3 + c] = -(xt - e * x0) / cv * m;
+  } else if (sub >= 6 && sub < 10) {
+    x.rigids[r * 7 + sub - 6] = quats_0[r * ld_0 + sub - 6];
+  } else if (sub == 10) {
+    const float a = x.psi_un[r * x.ld_psi], bq = x.psi_un[r * x.ld_psi + 1];
+    const float dn = sqrtf(fmaxf(a * a + bq * bq, 1e-8f));
+    const float dm = 1.f - x.fixed_mask[r];
+    x.psi[r * 2] = dm * (a / dn) + (1.f - dm) * x.gt_psi[r * 2];
+    x.psi[r * 2 + 1] = dm * (bq / dn) + (1.f - dm) * x.gt_psi[r * 2 + 1];
   }
 }
 
@@ -283,22 +407,6 @@ __global__ void trans_score_kernel(int B, int N, const float* __restrict__ trans
 
 // ------------------------------------------------------------------ backbone atoms
 // all_atom.py:147-176 -> openfold/utils/feats.py:165-228 -> all_atom.py:108-144.  One thread per residue.
-struct BackboneTables {  // packed by framedipt_amd/residue_tables.py
-  float default_frames[21 * 8 * 16];
-  float ideal_pos[21 * 14 * 3];
-  float atom_mask[21 * 14];
-  int32_t group_idx[21 * 14];
-};
-
-__device__ __forceinline__ void d_compose(const float* R1, const float* t1, const float* R2, const float* t2, float* Ro,
-                                          float* to) {  // Rigid.compose, rigid_utils.py:1065-1079
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = R1[i * 3] * R2[j] + R1[i * 3 + 1] * R2[3 + j] + R1[i * 3 + 2] * R2[6 + j];
-  float tmp[3];
-  d_rot_vec(R1, t2, tmp);
-  to[0] = tmp[0] + t1[0]; to[1] = tmp[1] + t1[1]; to[2] = tmp[2] + t1[2];
-}
-
 __global__ void backbone_kernel(int n, const float* __restrict__ t7, const float* __restrict__ rot,
                                 const float* __restrict__ trans, int ld_trans, const float* __restrict__ psi,
                                 const int32_t* __restrict__ aatype, const BackboneTables* __restrict__ tb,
@@ -313,47 +421,7 @@ __global__ void backbone_kernel(int n, const float* __restrict__ t7, const float
     d_quat_to_rot(t7 + r * 7, Rb);
     for (int c = 0; c < 3; ++c) tbv[c] = t7[r * 7 + 4 + c];
   }
-  int aa = aatype ? aatype[r] : 0;
-  if (aa == 20) aa = 0;
-  const float s = psi[r * 2], co = psi[r * 2 + 1];
-  float FR[8][9], FT[8][3];
-  for (int g = 0; g < 8; ++g) {
-    const float* d44 = tb->default_frames + (aa * 8 + g) * 16;
-    float Rd[9], td[3], Ra[9];
-    for (int i = 0; i < 3; ++i) {
-      for (int j = 0; j < 3; ++j) Rd[i * 3 + j] = d44[i * 4 + j];
-      td[i] = d44[i * 4 + 3];
-    }
-    const float a0 = g == 0 ? 0.f : s, a1 = g == 0 ? 1.f : co;  // backbone frame: (sin,cos) = (0,1)
-    Ra[0] = 1; Ra[1] = 0; Ra[2] = 0; Ra[3] = 0; Ra[4] = a1; Ra[5] = -a0; Ra[6] = 0; Ra[7] = a0; Ra[8] = a1;
-    const float z3[3] = {0.f, 0.f, 0.f};
-    d_compose(Rd, td, Ra, z3, FR[g], FT[g]);
-  }
-  for (int g = 5; g < 8; ++g) {  // chi2..chi4 chained onto chi1 (feats.py:204-212)
-    float Rn[9], tn[3];
-    d_compose(FR[g - 1], FT[g - 1], FR[g], FT[g], Rn, tn);
-    for (int c = 0; c < 9; ++c) FR[g][c] = Rn[c];
-    for (int c = 0; c < 3; ++c) FT[g][c] = tn[c];
-  }
-  float pos[14][3];
-  for (int at = 0; at < 14; ++at) {
-    const int g = tb->group_idx[aa * 14 + at];
-    float Rg[9], tg[3], p[3];
-    d_compose(Rb, tbv, FR[g], FT[g], Rg, tg);
-    d_rot_vec(Rg, tb->ideal_pos + (aa * 14 + at) * 3, p);
-    const float mk = tb->atom_mask[aa * 14 + at];
-    for (int c = 0; c < 3; ++c) pos[at][c] = (p[c] + tg[c]) * mk;
-  }
-  if (atom14)
-    for (int at = 0; at < 14; ++at)
-      for (int c = 0; c < 3; ++c) atom14[(r * 14 + at) * 3 + c] = pos[at][c];
-  if (atom37) {
-    for (int c = 0; c < 37 * 3; ++c) atom37[r * 111 + c] = 0.f;
-    // atom14 order N,CA,C,O,CB -> atom37 order N,CA,C,CB,O (all_atom.py:168-174)
-    const int map[5] = {0, 1, 2, 4, 3};
-    for (int at = 0; at < 5; ++at)
-      for (int c = 0; c < 3; ++c) atom37[r * 111 + at * 3 + c] = pos[map[at]][c];
-  }
+  d_backbone_residue(r, Rb, tbv, psi, aatype, tb, atom37, atom14);
 }
 
 // ------------------------------------------------------------------ small per-residue kernels of the trunk
@@ -461,8 +529,20 @@ int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, c
 
 int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
                  const float* res_mask, double* score, hipStream_t st) {
+  ScoreTail x = {};
   hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, st, B, N, qt, ld_t, q0,
-                     ld_0, sigma, res_mask, score);
+                     ld_0, sigma, res_mask, score, x);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+// rotation score + translation score + finish (tensor_7, psi, self-conditioning CA copy) in one launch; rigids_t is tensor_7
+int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const float* trans, float cs, const float* psi_un,
+                  int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
+                  const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
+                  float* ca_out, hipStream_t st) {
+  ScoreTail x = {trans, cs, psi_un, ld_psi, gt_psi, fixed_mask, t, min_b, max_b, rigids, psi, trans_score, ca_out};
+  hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, st, B, N, rigids_t, 7,
+                     quat, 4, sigma, res_mask, rot_score, x);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -577,20 +657,32 @@ int fdipt_so3_log(int n, const double* rot, double* rotvec, fdipt_stream_t s) {
   return FDIPT_OK;
 }
 
+int fdipt_se3_reverse_step_atoms(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
+                                 const float* diffuse_mask, const double* z_rot, const double* z_trans, double t, double dt,
+                                 double noise_scale, int center, int diffuse_rot, int diffuse_trans, double so3_min_sigma,
+                                 double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
+                                 float* rigids_out, float* out_rot, const float* psi, const int32_t* aatype,
+                                 const void* tables, float* atom37, fdipt_stream_t stream) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!rigids_t || !rot_score || !trans_score || !z_rot || !z_trans || !rigids_out || !(t >= 0 && t <= 1))
+    return FDIPT_EINVAL;
+  if (atom37 && (!psi || !tables || rigids_out == rigids_t)) return FDIPT_EINVAL;
+  const int rpb = rigids_out == rigids_t ? N : 64;
+  ReverseArgs a = {B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale, center,
+                   diffuse_rot, diffuse_trans, so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling,
+                   rigids_out, out_rot, rpb, psi, aatype, (const BackboneTables*)tables, atom37};
+  hipLaunchKernelGGL(reverse_step_kernel, dim3(cdiv(N, rpb), B), dim3(FD_THREADS), 0, (hipStream_t)stream, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 int fdipt_se3_reverse_step(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
                            const float* diffuse_mask, const double* z_rot, const double* z_trans, double t, double dt,
                            double noise_scale, int center, int diffuse_rot, int diffuse_trans, double so3_min_sigma,
                            double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
                            float* rigids_out, float* out_rot, fdipt_stream_t stream) {
-  if (B <= 0 || N <= 0) return FDIPT_OK;
-  if (!rigids_t || !rot_score || !trans_score || !z_rot || !z_trans || !rigids_out || !(t >= 0 && t <= 1))
-    return FDIPT_EINVAL;
-  ReverseArgs a = {B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale, center,
-                   diffuse_rot, diffuse_trans, so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling,
-                   rigids_out, out_rot};
-  hipLaunchKernelGGL(reverse_step_kernel, dim3(B), dim3(FD_THREADS), 0, (hipStream_t)stream, a);
-  FD_CHECK_LAUNCH();
-  return FDIPT_OK;
+  return fdipt_se3_reverse_step_atoms(B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale,
+                                      center, diffuse_rot, diffuse_trans, so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b,
+                                      coordinate_scaling, rigids_out, out_rot, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int fdipt_igso3_rot_score(int B, int N, const float* quats_t, const float* quats_0, const double* sigma,

@@ -285,6 +285,10 @@ int fd_finish(long n, const float* quat, const float* trans, float cs, const flo
 int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, const float* t_emb, const float* t_emb_eps,
                    const float* fixed_mask, const float* idx_emb, float* node_feat, int ld_node, float* pte, int ld_pte,
                    hipStream_t st);
+int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const float* trans, float cs, const float* psi_un,
+                  int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
+                  const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
+                  float* ca_out, hipStream_t st);
 int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
                  const float* res_mask, double* score, hipStream_t st);
 int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,

@@ -870,11 +870,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(lin(R, iv.tor2, F(w.h_a), cs, node_cur, cs, nullptr, 0, F(w.h_b), cs));
   }
   RC(lin32(R, iv.torf, F(w.h_b), cs, F(w.psi_un), 8));
-  RC(fd_finish(R, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask, a->rigids, a->psi,
-               st));
-  RC(fd_rot_score(B, N, a->rigids_t, 7, F(w.quat), 4, a->so3_sigma, res_mask, a->rot_score, st));
-  RC(fd_trans_score(B, N, a->rigids_t + 4, 7, a->rigids + 4, 7, a->t, d->r3_min_b, d->r3_max_b, d->coordinate_scaling,
-                    res_mask, a->trans_score, st));
+  // tensor_7 / psi epilogue, R^3 score and IGSO(3) score in one launch (frames.hip)
+  RC(fd_score_tail(B, N, a->rigids_t, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask,
+                   res_mask, a->so3_sigma, a->t, d->r3_min_b, d->r3_max_b, a->rigids, a->psi, a->rot_score, a->trans_score,
+                   a->ca_out, st));
   if (a->atom37 || a->atom14) {
     if (!a->bb_tables) return FDIPT_EINVAL;
     RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));

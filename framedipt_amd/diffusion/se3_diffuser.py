@@ -111,19 +111,22 @@ class SE3Diffuser:
 
     # ------------------------------------------------------------------ reverse step
     def reverse_device(self, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, center=True,
-                       noise_scale=1.0, rigids_out=None, rot_out=None):
-        """Device-resident reverse step on tensor_7 frames [B,N,7]; noise given (N(0,1), float64)."""
+                       noise_scale=1.0, rigids_out=None, rot_out=None, atoms=None):
+        """Device-resident reverse step on tensor_7 frames [B,N,7]; noise given (N(0,1), float64).
+        ``atoms=(psi, aatype, bb_tables, atom37)``: also compute_backbone of x_{t-1} in the same launch."""
         lib = _lib.load()
         _lib.require_cuda(rigids_t, "reverse")
         B, N = rigids_t.shape[0], rigids_t.shape[1]
         if rigids_out is None:
             rigids_out = torch.empty_like(rigids_t)
         so3, r3 = self._so3_diffuser, self._r3_diffuser
-        _lib.check(lib.fdipt_se3_reverse_step(
+        psi, aatype, tables, atom37 = atoms if atoms is not None else (None, None, None, None)
+        _lib.check(lib.fdipt_se3_reverse_step_atoms(
             B, N, _lib.ptr(rigids_t), _lib.ptr(rot_score), _lib.ptr(trans_score), _lib.ptr(diffuse_mask),
             _lib.ptr(z_rot), _lib.ptr(z_trans), float(t), float(dt), float(noise_scale), int(bool(center)),
             int(bool(self._diffuse_rot)), int(bool(self._diffuse_trans)), so3.min_sigma, so3.max_sigma, r3.min_b, r3.max_b,
-            r3._r3_conf.coordinate_scaling, _lib.ptr(rigids_out), _lib.ptr(rot_out), _lib.stream_ptr()), "se3_reverse_step")
+            r3._r3_conf.coordinate_scaling, _lib.ptr(rigids_out), _lib.ptr(rot_out), _lib.ptr(psi), _lib.ptr(aatype),
+            _lib.ptr(tables), _lib.ptr(atom37), _lib.stream_ptr()), "se3_reverse_step")
         return rigids_out
 
     def reverse(self, rigid_t: Rigid, rot_score, trans_score, t: float, dt: float, diffuse_mask=None,

@@ -76,41 +76,38 @@ class ReverseLoop:
             self.prot_traj = torch.empty(num_t, B, N, 37, 3, device=dev)
             self.bb0_traj = torch.empty(num_t, B, N, 37, 3, device=dev) if aux_traj else None
             self.trans_traj = torch.empty(num_t, B, N, 3, device=dev) if aux_traj else None
-            self.rot_out = torch.empty(B, N, 3, 3, device=dev)
-            self.trans_c = torch.empty(B, N, 3, device=dev)
         self.noisy = 0
 
-    def _fwd(self, k, want_atoms):
+    def _fwd(self, k, want_atoms, sc_update):
+        # the forward itself hands the predicted CA positions to the next step's self-conditioning input (read at its start,
+        # written at its end: no copy kernel)
         self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.aatype, self.gt_psi, self.t_all[k],
-                        self.temb_all[k], self.sig_all[k], want_atoms)
+                        self.temb_all[k], self.sig_all[k], want_atoms, ca_out=self.sc_ca if sc_update else None)
 
     def prime(self):
         """Self-conditioning priming call (utils.py:571-578)."""
         if self.embed_sc and self.self_condition:
             with torch.cuda.device(self.dev):
-                self._fwd(0, False)
-                self.sc_ca.copy_(self.st.rigids[..., 4:])
+                self._fwd(0, False, True)
 
     def step(self, k):
         """one_step_inference (utils.py:292-412) for reverse step k."""
         st, t, n = self.st, self.reverse_steps[k], self.B * self.N
         with torch.cuda.device(self.dev):
-            self._fwd(k, self.aux_traj)
+            self._fwd(k, self.aux_traj, self.embed_sc and t > self.min_t)
+            nxt = self.rigid_traj[k + 1]
             if t > self.min_t:
-                if self.embed_sc:
-                    self.sc_ca.copy_(st.rigids[..., 4:])
-                nxt = self.rigid_traj[k + 1]
+                # x_{t-1} lands in its trajectory slot, which is the next forward's input; its atom37 frame comes out of the
+                # same launch
                 self.diffuser.reverse_device(self.rigids_t, st.rot_score, st.trans_score, self.diffuse_mask,
                                              self.z_rot[self.noisy], self.z_trans[self.noisy], t, self.dt, self.center,
-                                             self.noise_scale, rigids_out=nxt, rot_out=self.rot_out)
+                                             self.noise_scale, rigids_out=nxt,
+                                             atoms=(st.psi, self.aatype, self.model.bb_tables, self.prot_traj[k]))
                 self.noisy += 1
-                self.rigids_t.copy_(nxt)
-                self.trans_c.copy_(nxt[..., 4:])
-                _backbone(self.model, n, None, self.rot_out, self.trans_c, st.psi, self.aatype, self.prot_traj[k])
             else:  # last step: take the x_0 prediction, utils.py:373-374
-                self.rigid_traj[k + 1] = st.rigids
-                self.rigids_t.copy_(st.rigids)
-                _backbone(self.model, n, self.rigids_t, None, None, st.psi, self.aatype, self.prot_traj[k])
+                nxt.copy_(st.rigids)
+                _backbone(self.model, n, nxt, None, None, st.psi, self.aatype, self.prot_traj[k])
+            self.rigids_t = nxt
             if self.aux_traj:
                 self.bb0_traj[k] = st.atom37
                 self.trans_traj[k] = (self.diffuse_mask[..., None] * st.rigids[..., 4:]

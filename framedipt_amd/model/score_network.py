@@ -75,8 +75,9 @@ class BatchState:
                                          device=dev)
 
     def forward(self, rigids_t, res_mask, fixed_mask, sc_ca_t, aatype, gt_psi, t_dev, t_emb_dev, sigma_dev,
-                want_atoms: bool = True):
-        """All arguments are device tensors (float32 unless noted); outputs land in this state's buffers."""
+                want_atoms: bool = True, ca_out=None):
+        """All arguments are device tensors (float32 unless noted); outputs land in this state's buffers.
+        ``ca_out`` ([B,N,3], may be ``sc_ca_t`` itself) receives the predicted CA positions for the next step."""
         lib = _lib.load()
         net = self.net
         a = _lib.ForwardArgs()
@@ -87,7 +88,7 @@ class BatchState:
                           ("bb_tables", net.bb_tables), ("psi", self.psi), ("rot_score", self.rot_score),
                           ("trans_score", self.trans_score), ("rigids", self.rigids),
                           ("atom37", self.atom37 if want_atoms else None), ("atom14", self.atom14 if want_atoms else None),
-                          ("trace_node", self.trace_node), ("trace_edge", self.trace_edge)):
+                          ("trace_node", self.trace_node), ("trace_edge", self.trace_edge), ("ca_out", ca_out)):
             setattr(a, name, _lib.ptr(tns))
         if self.ev_start is not None:
             a.ev_start, a.ev_stop = self.ev_start, self.ev_stop

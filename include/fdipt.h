@@ -113,6 +113,10 @@ typedef struct FdiptForwardArgs {
    * (num_blocks-1 pairs, created with fdipt_event_create); NULL to skip */
   void** ev_start;                /* host array of events */
   void** ev_stop;
+  /* optional: contiguous copy of the predicted CA positions rigids[...,4:] ([B,N,3] f32, Angstrom), written at the end of
+   * the forward.  May alias sc_ca_t (read at the start): the sampler's self-conditioning hand-over
+   * (experiments/utils.py:361-366,571-578) then costs no copy.  NULL to skip. */
+  float* ca_out;
 } FdiptForwardArgs;
 
 size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
@@ -132,6 +136,15 @@ int fdipt_se3_reverse_step(int B, int N, const float* rigids_t, const double* ro
                            double so3_min_sigma, double so3_max_sigma, double r3_min_b, double r3_max_b,
                            double coordinate_scaling, float* rigids_out /* [B,N,7] */, float* out_rot /* [B,N,3,3] or NULL */,
                            fdipt_stream_t stream);
+/* The same step followed by all_atom.compute_backbone on x_{t-1} (experiments/utils.py:376-388: the atom37 frame of the
+ * trajectory) in the same launch: psi [B,N,2], aatype [B,N] or NULL, tables as for fdipt_backbone_atoms, atom37 [B,N,37,3].
+ * rigids_out must not alias rigids_t. */
+int fdipt_se3_reverse_step_atoms(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
+                                 const float* diffuse_mask, const double* z_rot, const double* z_trans, double t, double dt,
+                                 double noise_scale, int center, int diffuse_rot, int diffuse_trans, double so3_min_sigma,
+                                 double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
+                                 float* rigids_out, float* out_rot, const float* psi, const int32_t* aatype,
+                                 const void* tables, float* atom37, fdipt_stream_t stream);
 
 /* ---------------------------------------------------------------- frame algebra (a8) ------- */
 /* openfold/utils/rigid_utils.py free functions and Rigid/Rotation methods, n independent items, f32. */
