@@ -305,6 +305,8 @@ struct ScoreTail {
   const float *gt_psi, *fixed_mask, *t;
   float min_b, max_b;
   float *rigids, *psi, *trans_score, *ca_out;
+  // optional last torsion layer (ipa:349-353, Linear(c_s, 2), fp32): psi_un is then computed here from hid [R, ld_hid]
+  const float *hid, *torf_w, *torf_b; int ld_hid, c_hid;
 };
 __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t, int ld_t,
                                                                const float* __restrict__ quats_0, int ld_0,
@@ -357,6 +359,21 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
     f += __shfl_xor(f, o, 64);
     ds += __shfl_xor(ds, o, 64);
   }
+  float pa = 0.f, pb = 0.f;
+  if (x.hid) {  // the residue's 16 lanes split the two c_hid-long dot products
+    const float* h = x.hid + r * x.ld_hid;
+    for (int k = sub * 4; k < x.c_hid; k += RS_LANES * 4) {
+      const float4 hv = *(const float4*)(h + k), w0 = *(const float4*)(x.torf_w + k), w1 = *(const float4*)(x.torf_w + x.c_hid + k);
+      pa = fmaf(hv.w, w0.w, fmaf(hv.z, w0.z, fmaf(hv.y, w0.y, fmaf(hv.x, w0.x, pa))));
+      pb = fmaf(hv.w, w1.w, fmaf(hv.z, w1.z, fmaf(hv.y, w1.y, fmaf(hv.x, w1.x, pb))));
+    }
+#pragma unroll
+    for (int o = 1; o < RS_LANES; o <<= 1) {
+      pa += __shfl_xor(pa, o, 64);
+      pb += __shfl_xor(pb, o, 64);
+    }
+    pa += x.torf_b[0]; pb += x.torf_b[1];
+  }
   if (gid >= total) return;
   if (sub < 3) {
     const double sc = ds / (f + 1e-4);
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
   } else if (sub >= 6 && sub < 10) {
     x.rigids[r * 7 + sub - 6] = quats_0[r * ld_0 + sub - 6];
   } else if (sub == 10) {
-    const float a = x.psi_un[r * x.ld_psi], bq = x.psi_un[r * x.ld_psi + 1];
+    const float a = x.hid ? pa : x.psi_un[r * x.ld_psi], bq = x.hid ? pb : x.psi_un[r * x.ld_psi + 1];
     const float dn = sqrtf(fmaxf(a * a + bq * bq, 1e-8f));
     const float dm = 1.f - x.fixed_mask[r];
     x.psi[r * 2] = dm * (a / dn) + (1.f - dm) * x.gt_psi[r * 2];
@@ -494,14 +511,26 @@ int fd_finish(long n, const float* quat, const float* trans, float cs, const flo
 
 // Node / pair first-layer input features (score_network.py:152-182): pte = [aatype one-hot?, t-embed, fixed_mask];
 // node_feat = [pte, index-embed] zero-padded to ld_node; pte zero-padded to ld_pte.
+struct FeatsExtra {  // optional work folded into the feature kernel's launch (nullptr to skip each part)
+  const float *t7, *res_mask; float cs; float *quat, *trans, *dmask;  // split of x_t into quaternion / scaled translation
+  const float *w1i, *w1j, *b1; int cz; float *pi, *pj;              // per-residue halves of the first edge-embedder layer
+};
 __global__ void build_feats_kernel(int B, int N, int use_aatype, int E, const int32_t* __restrict__ aatype,
                                    const float* __restrict__ t_emb, const float* __restrict__ t_emb_eps,
                                    const float* __restrict__ fixed_mask, const float* __restrict__ idx_emb,
-                                   float* __restrict__ node_feat, int ld_node, float* __restrict__ pte, int ld_pte) {
+                                   float* __restrict__ node_feat, int ld_node, float* __restrict__ pte, int ld_pte,
+                                   FeatsExtra x) {
+  __shared__ float pte_s[128];
   const long r = blockIdx.x;
   const int b = (int)(r / N);
   const float fm = fixed_mask[r];
   const int d1 = E + 1 + (use_aatype ? 21 : 0);
+  if (x.t7 && threadIdx.x < 8) {  // IpaScore.forward prologue (ipa_pytorch.py:516-524), as split_rigids_kernel
+    const int c = threadIdx.x;
+    if (c < 4) x.quat[r * 4 + c] = x.t7[r * 7 + c];
+    else if (c < 7) x.trans[r * 3 + c - 4] = x.t7[r * 7 + c] * x.cs;
+    else x.dmask[r] = (1.f - fm) * x.res_mask[r];
+  }
   for (int c = threadIdx.x; c < ld_node; c += blockDim.x) {
     float v = 0.f;
     int cc = c;
@@ -514,15 +543,38 @@ __global__ void build_feats_kernel(int B, int N, int use_aatype, int E, const in
       else if (cc < 2 * E + 1) v = idx_emb[r * E + (cc - E - 1)];
     }
     node_feat[r * ld_node + c] = v;
-    if (c < ld_pte) pte[r * ld_pte + c] = c < d1 ? v : 0.f;
+    if (c < ld_pte) {
+      pte[r * ld_pte + c] = c < d1 ? v : 0.f;
+      if (x.pi && c < 128) pte_s[c] = c < d1 ? v : 0.f;
+    }
+  }
+  if (!x.pi) return;
+  // first edge-embedder layer, per-residue halves (score_network.py:173-180: the cross-concatenated pair feature's i and j
+  // parts are each a [c_z, d1] product with this residue's feature row): column c of both, fp32
+  __syncthreads();
+  for (int c = threadIdx.x; c < x.cz; c += blockDim.x) {
+    const float4* wi = (const float4*)(x.w1i + (long)c * ld_pte);
+    const float4* wj = (const float4*)(x.w1j + (long)c * ld_pte);
+    float si = 0.f, sj = 0.f;
+    for (int k = 0; k < ld_pte / 4; ++k) {
+      const float4 a = wi[k], bq = wj[k];
+      const float p0 = pte_s[4 * k], p1 = pte_s[4 * k + 1], p2 = pte_s[4 * k + 2], p3 = pte_s[4 * k + 3];
+      si = fmaf(p3, a.w, fmaf(p2, a.z, fmaf(p1, a.y, fmaf(p0, a.x, si))));
+      sj = fmaf(p3, bq.w, fmaf(p2, bq.z, fmaf(p1, bq.y, fmaf(p0, bq.x, sj))));
+    }
+    x.pi[r * x.cz + c] = si + x.b1[c];
+    x.pj[r * x.cz + c] = sj;
   }
 }
 int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, const float* t_emb, const float* t_emb_eps,
                    const float* fixed_mask, const float* idx_emb, float* node_feat, int ld_node, float* pte, int ld_pte,
-                   hipStream_t st) {
+                   const float* t7, const float* res_mask, float cs, float* quat, float* trans, float* dmask, const float* w1i,
+                   const float* w1j, const float* b1, int cz, float* pi, float* pj, hipStream_t st) {
   if (use_aatype && (!aatype || !t_emb_eps)) return FDIPT_EINVAL;
+  if (pi && (ld_pte > 128 || (ld_pte & 3))) return FDIPT_EINVAL;
+  FeatsExtra x = {t7, res_mask, cs, quat, trans, dmask, w1i, w1j, b1, cz, pi, pj};
   hipLaunchKernelGGL(build_feats_kernel, dim3(B * N), dim3(128), 0, st, B, N, use_aatype, E, aatype, t_emb, t_emb_eps,
-                     fixed_mask, idx_emb, node_feat, ld_node, pte, ld_pte);
+                     fixed_mask, idx_emb, node_feat, ld_node, pte, ld_pte, x);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -539,8 +591,11 @@ int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int l
 int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const float* trans, float cs, const float* psi_un,
                   int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
                   const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
-                  float* ca_out, hipStream_t st) {
-  ScoreTail x = {trans, cs, psi_un, ld_psi, gt_psi, fixed_mask, t, min_b, max_b, rigids, psi, trans_score, ca_out};
+                  float* ca_out, const float* hid, int ld_hid, int c_hid, const float* torf_w, const float* torf_b,
+                  hipStream_t st) {
+  if (hid && ((c_hid & 3) || (ld_hid & 3))) return FDIPT_EINVAL;
+  ScoreTail x = {trans, cs, psi_un, ld_psi, gt_psi, fixed_mask, t, min_b, max_b, rigids, psi, trans_score, ca_out,
+                 hid, torf_w, torf_b, ld_hid, c_hid};
   hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, st, B, N, rigids_t, 7,
                      quat, 4, sigma, res_mask, rot_score, x);
   FD_CHECK_LAUNCH();

@@ -155,7 +155,7 @@ struct ProjArgs {
   int zero_pads;              // also zero the padded keys [N, Np) of Kb / Vt (first use of the buffers in a forward)
 };
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
-int fd_ipa_proj_zero_pads(const ProjArgs& a, hipStream_t st);
+int fd_ipa_proj_zero_pads(const ProjArgs& a, void* extra, size_t extra_bytes, hipStream_t st);
 int fd_ipa_proj2_supported(const ProjArgs& a);
 // after the fragment image of the fused projection weight is built: permute the rows of its Q / K tiles (16 B epilogue stores)
 int fd_ipa_proj2_permute_image(void* img, int H, int C, int K, hipStream_t st);
@@ -284,11 +284,13 @@ int fd_finish(long n, const float* quat, const float* trans, float cs, const flo
               const float* gt_psi, const float* fixed_mask, float* rigids, float* psi, hipStream_t st);
 int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, const float* t_emb, const float* t_emb_eps,
                    const float* fixed_mask, const float* idx_emb, float* node_feat, int ld_node, float* pte, int ld_pte,
-                   hipStream_t st);
+                   const float* t7, const float* res_mask, float cs, float* quat, float* trans, float* dmask, const float* w1i,
+                   const float* w1j, const float* b1, int cz, float* pi, float* pj, hipStream_t st);
 int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const float* trans, float cs, const float* psi_un,
                   int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
                   const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
-                  float* ca_out, hipStream_t st);
+                  float* ca_out, const float* hid, int ld_hid, int c_hid, const float* torf_w, const float* torf_b,
+                  hipStream_t st);
 int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
                  const float* res_mask, double* score, hipStream_t st);
 int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,

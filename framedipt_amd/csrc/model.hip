@@ -523,8 +523,13 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
 
   bool ee_bias_done = false;
   // ---- Embedder (score_network.py:129-197)
+  // ... with the split of x_t (ipa_pytorch.py:516-524) and the per-residue halves of the first edge-embedder layer in the same
+  // launch (FDIPT_FEATS_UNFUSED: three GEMM / element-wise launches more)
+  const bool feats_fused = L.d1_pad <= 128 && (L.d1_pad & 3) == 0 && !getenv("FDIPT_FEATS_UNFUSED");
   RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
-                    L.kn_pad, F(w.pte), L.d1_pad, st));
+                    L.kn_pad, F(w.pte), L.d1_pad, feats_fused ? a->rigids_t : nullptr, res_mask, d->coordinate_scaling, F(w.quat),
+                    F(w.trans), F(w.dmask), (const float*)(D + L.w1i), (const float*)(D + L.w1j), (const float*)(D + L.b1), cz,
+                    feats_fused ? F(w.pi) : nullptr, F(w.pj), st));
   if (rbk && (L.kn_pad == 72 || L.kn_pad == 88)) {
     RC(rblock(L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88, F(w.node_feat), L.kn_pad, D + L.ch_ne0, P + iv.ne0.b,
               D + L.ch_ne2n, P + iv.ne2.b, D + L.ch_ne4n, P + iv.ne4.b, nullptr, 0, &iv.neln, res_mask, F(w.node0), cs));
@@ -539,10 +544,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(lin(R, iv.ne4, F(w.h_b), cs, nullptr, 0, nullptr, 0, F(w.h_a), cs));
     RC(fd_layernorm(R, cs, F(w.h_a), cs, nullptr, 0, P + iv.neln.g, P + iv.neln.b, res_mask, F(w.node0), cs, st));
   }
-  RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1i, L.d1_pad, (const float*)(D + L.b1), nullptr, 0,
-               nullptr, 0, F(w.pi), cz, st));
-  RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1j, L.d1_pad, nullptr, nullptr, 0, nullptr, 0,
-               F(w.pj), cz, st));
+  if (!feats_fused) {
+    RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1i, L.d1_pad, (const float*)(D + L.b1), nullptr, 0,
+                 nullptr, 0, F(w.pi), cz, st));
+    RC(fd_linear(FDIPT_PREC_F32, R, cz, L.d1_pad, F(w.pte), L.d1_pad, D + L.w1j, L.d1_pad, nullptr, nullptr, 0, nullptr, 0,
+                 F(w.pj), cz, st));
+  }
   {
     EdgeEmbedArgs ea;
     ea.B = B; ea.N = N; ea.n_rel = a->n_rel; ea.rel_off = a->rel_off; ea.num_bins = d->num_bins;
@@ -564,7 +571,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       return FDIPT_ELAUNCH;
 
   // ---- IpaScore trunk (ipa_pytorch.py:509-551)
-  RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask, F(w.quat), F(w.trans), F(w.dmask), st));
+  if (!feats_fused)
+    RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask, F(w.quat), F(w.trans), F(w.dmask), st));
   const float* node_cur = F(w.node0);
   // skip_embed(init_node) of every block depends on the embedder output only: one GEMM launch for all blocks, copied behind the
   // LayerNorm output by the LayerNorm kernel (FDIPT_SKIP_PER_BLOCK: one launch per block as before)
@@ -594,8 +602,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.quat = F(w.quat); pa.trans = F(w.trans);
     pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
     pa.vpt = (use_a3 && Pv == 12) ? (unsigned short*)(W + w.vpt) : nullptr; pa.Np = Np;
-    if (pa.vpt && b == 0)  // padded keys and rows 72..95 of the image are never written: zero once per forward
-      if (hipMemsetAsync(W + w.vpt, 0, (size_t)B * H * 96 * Np * 2, st) != hipSuccess) return FDIPT_ELAUNCH;
+    // padded keys and rows 72..95 of the value-point image are never written: zero once per forward (on the launch that zeroes
+    // the padded keys of Kb / Vt when the second-generation projection runs)
+    const size_t vpt_bytes = (size_t)B * H * 96 * Np * 2;
+    bool vpt_zero = pa.vpt && b == 0;
     if (use_a3) {
       // fused projection written directly as attention operand images (Qb, Kb, Vt) + raw point columns
       ProjArgs pj;
@@ -606,9 +616,14 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       pj.W_img = (cs == 256 && !getenv("FDIPT_PROJ_V1")) ? D + db.wproj_img : nullptr;
       // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
       if (fd_ipa_proj2_supported(pj)) {
-        if (pj.zero_pads && Np > N) { ProjArgs pz = pj; pz.W_img = nullptr; RC(fd_ipa_proj_zero_pads(pz, st)); }
+        if (pj.zero_pads && (Np > N || vpt_zero)) {
+          ProjArgs pz = pj; pz.W_img = nullptr;
+          RC(fd_ipa_proj_zero_pads(pz, vpt_zero ? W + w.vpt : nullptr, vpt_zero ? vpt_bytes : 0, st));
+          vpt_zero = false;
+        }
         RC(fd_ipa_proj2(pj, st));
       } else RC(fd_ipa_proj(pj, st));
+      if (vpt_zero && hipMemsetAsync(W + w.vpt, 0, vpt_bytes, st) != hipSuccess) return FDIPT_ELAUNCH;
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
       RC(fd_points(pa, st));
       if (!bias_ready)  // blocks >= 1: already emitted by the previous block's EdgeTransition epilogue
@@ -869,11 +884,13 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(lin(R, iv.tor1, node_cur, cs, nullptr, 0, nullptr, 1, F(w.h_a), cs));
     RC(lin(R, iv.tor2, F(w.h_a), cs, node_cur, cs, nullptr, 0, F(w.h_b), cs));
   }
-  RC(lin32(R, iv.torf, F(w.h_b), cs, F(w.psi_un), 8));
+  // the last torsion layer (Linear(c_s, 2), fp32) rides on the score launch (FDIPT_TORF_UNFUSED: its own GEMM launch)
+  const bool torf_fused = (cs & 3) == 0 && !getenv("FDIPT_TORF_UNFUSED");
+  if (!torf_fused) RC(lin32(R, iv.torf, F(w.h_b), cs, F(w.psi_un), 8));
   // tensor_7 / psi epilogue, R^3 score and IGSO(3) score in one launch (frames.hip)
   RC(fd_score_tail(B, N, a->rigids_t, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask,
                    res_mask, a->so3_sigma, a->t, d->r3_min_b, d->r3_max_b, a->rigids, a->psi, a->rot_score, a->trans_score,
-                   a->ca_out, st));
+                   a->ca_out, torf_fused ? F(w.h_b) : nullptr, cs, cs, P + iv.torf.w, P + iv.torf.b, st));
   if (a->atom37 || a->atom14) {
     if (!a->bb_tables) return FDIPT_EINVAL;
     RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));
