@@ -84,8 +84,29 @@ __global__ void seq_images_kernel(int B, int N, int Np, int H, const float* __re
 // ------------------------------------------------------------------ fused in_proj -> images
 // seq_images_init_kernel: everything in the images that does not depend on the layer — zeros (padded rows / keys /
 // channels 81..95), Q's mask channel = 1, K's mask channel = -1e30 for masked or padded keys.  Once per forward.
+// The other once-per-forward fills of the trunk ride on this launch (SeqInitExtra): a plain zero fill (attention3's value-point
+// image) and the padded keys [N, Np) of attention3's Kb / Vt images (layouts: gemm.hip, kv_zero_pad_kernel).
 __global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float* __restrict__ res_mask, bf16_t* __restrict__ Qi,
-                                       bf16_t* __restrict__ Ki, bf16_t* __restrict__ Vi) {
+                                       bf16_t* __restrict__ Ki, bf16_t* __restrict__ Vi, SeqInitExtra x) {
+  const long gtid = blockIdx.x * (long)blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+  for (long i = gtid; i < x.fill_n16; i += gsz) ((uint4*)x.fill)[i] = make_uint4(0, 0, 0, 0);
+  if (x.Kb) {
+    const int pad = Np - N, ntl = Np >> 5, cg = x.C >> 3;
+    const long n = x.BH * pad * cg;
+    const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16_t* Kb = (bf16_t*)x.Kb;
+    bf16_t* Vt = (bf16_t*)x.Vt;
+    for (long i = gtid; i < n; i += gsz) {
+      const int g = (int)(i % cg);
+      const long r2 = i / cg;
+      const int key = N + (int)(r2 % pad);
+      const long bh = r2 / pad;
+      *(u16x8*)(Kb + ((((bh * ntl + (key >> 5)) * (x.C >> 4) + (g >> 1)) * 64 + (g & 1) * 32 + (key & 31)) << 3)) = z8;
+      const int p16 = key & 15, pp = (key & ~15) + 4 * (p16 >> 3) + (p16 & 3) + 8 * ((p16 & 7) >> 2);
+      for (int c = 8 * g; c < 8 * g + 8; ++c)
+        Vt[((((bh * (x.C >> 5) + (c >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (c & 31)) << 3) + (pp & 7)] = 0;
+    }
+  }
   const int nt = Np >> 5;
   const long nqk = (long)B * H * nt * SA_KS * 64, nv = (long)B * H * SA_DT * (2 * nt) * 64;
   for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < 2 * nqk + nv; u += (long)gridDim.x * blockDim.x) {
@@ -367,14 +388,15 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
 }
 
 // Fused path: fd_seq_images_init once per forward, then per layer fd_seq_qkv (in_proj + images) and fd_seq_attention_run.
-int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, hipStream_t st) {
+int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, const SeqInitExtra& x, hipStream_t st) {
+  if (x.Kb && (((N + 31) / 32 * 32) == N || (x.C & 31))) return FDIPT_EINVAL;
   if (!fd_seq_attention_supported(N, H, SA_HD)) return FDIPT_EINVAL;
   const int Np = (N + 31) / 32 * 32, nt = Np / 32;
   bf16_t* Qi = (bf16_t*)images;
   bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
   bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const long units = 2L * B * H * nt * SA_KS * 64 + (long)B * H * SA_DT * 2 * nt * 64;
-  hipLaunchKernelGGL(seq_images_init_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, res_mask, Qi, Ki, Vi);
+  hipLaunchKernelGGL(seq_images_init_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, res_mask, Qi, Ki, Vi, x);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -187,7 +187,11 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
                      float* out, int out_ld, hipStream_t st);
 
 // fused form: images initialised once per forward, in_proj writes them directly (seq_qkv), then the attention kernel
-int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, hipStream_t st);
+struct SeqInitExtra {  // once-per-forward fills folded into the sequence-image init launch (all optional)
+  void* fill; long fill_n16;       // zero fill, 16 B units
+  void* Kb; void* Vt; long BH; int C;  // padded keys of attention3's key / value images (N, Np as the sequence images: Np = ceil32(N))
+};
+int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, const SeqInitExtra& x, hipStream_t st);
 int fd_seq_qkv_supported(int N, int H, int d_model);
 int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const float* bias, float scale, void* images,
                hipStream_t st);

@@ -582,6 +582,9 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
                  nullptr, 0, F(w.skip_all), d->num_blocks * d->c_skip, st));
   const size_t NN = (size_t)R * N;
   bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
+  const bool seq_fused = rbk && !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_QKV_FUSE") &&
+                         fd_seq_attention_supported(N, d->tfmr_heads, iv.d_t / d->tfmr_heads) &&
+                         fd_seq_qkv_supported(N, d->tfmr_heads, iv.d_t);
   bool bias_ready = ee_bias_done;  // pair bias of this block's attention already written (tiled order) by the embedder / EdgeTransition
   for (int b = 0; b < d->num_blocks; ++b) {
     const BlockW& k = iv.blk[b];
@@ -616,7 +619,14 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       pj.W_img = (cs == 256 && !getenv("FDIPT_PROJ_V1")) ? D + db.wproj_img : nullptr;
       // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
       if (fd_ipa_proj2_supported(pj)) {
-        if (pj.zero_pads && (Np > N || vpt_zero)) {
+        if (pj.zero_pads && seq_fused && !seq_img_ready && (C & 31) == 0 && (vpt_bytes & 15) == 0 && !getenv("FDIPT_INIT_UNFUSED")) {
+          // every once-per-forward fill of the trunk in one launch: sequence-attention images, value-point image, key pads
+          SeqInitExtra sx = {vpt_zero ? W + w.vpt : nullptr, vpt_zero ? (long)(vpt_bytes >> 4) : 0L, Np > N ? (void*)pj.Kb : nullptr,
+                             (void*)pj.Vt, (long)B * H, C};
+          RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, sx, st));
+          seq_img_ready = true;
+          vpt_zero = false;
+        } else if (pj.zero_pads && (Np > N || vpt_zero)) {
           ProjArgs pz = pj; pz.W_img = nullptr;
           RC(fd_ipa_proj_zero_pads(pz, vpt_zero ? W + w.vpt : nullptr, vpt_zero ? vpt_bytes : 0, st));
           vpt_zero = false;
@@ -690,11 +700,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       const TfLayer& t = k.tf[l];
       const int hd0 = dt / d->tfmr_heads;
       // default bf16 path: in_proj writes the attention operand images directly (attention_seq.hip)
-      const bool qkv_fused = rbk && !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_QKV_FUSE") &&
-                             fd_seq_attention_supported(N, d->tfmr_heads, hd0) && fd_seq_qkv_supported(N, d->tfmr_heads, dt);
+      const bool qkv_fused = seq_fused;
       if (qkv_fused) {
         if (!seq_img_ready) {
-          RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, st));
+          RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, SeqInitExtra{}, st));
           seq_img_ready = true;
         }
         RC(fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));

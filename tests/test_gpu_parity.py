@@ -477,3 +477,88 @@ def test_fused_node_chains_vs_gemm_path():
             ref = G[f"tr_node_{b - 1}"]
             assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, b
     np.testing.assert_allclose(outs["gemm"][1], outs["chain"][1], atol=3e-2)
+
+
+def test_reverse_step_blocks_and_fused_atoms():
+    """The reverse step over N/64 row blocks per sample (out of place) vs one block per sample (in place), and its fused
+    atom37 frame vs fdipt_backbone_atoms on the same x_{t-1}: bit-identical."""
+    from framedipt_amd import _lib, residue_tables
+    lib = _lib.load()
+    d = _diffuser()
+    B, N = 3, 301
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, N, 4, generator=g)
+    t7 = torch.cat([q / q.norm(dim=-1, keepdim=True), 10 * torch.randn(B, N, 3, generator=g)], -1).float().cuda().contiguous()
+    rs = (0.3 * torch.randn(B, N, 3, generator=g, dtype=torch.float64)).cuda()
+    ts = (0.1 * torch.randn(B, N, 3, generator=g)).cuda()
+    dm = (torch.rand(B, N, generator=g) > 0.2).float().cuda()
+    zr, zt = torch.randn(B, N, 3, generator=g, dtype=torch.float64).cuda(), torch.randn(B, N, 3, generator=g, dtype=torch.float64).cuda()
+    psi = torch.nn.functional.normalize(torch.randn(B, N, 2, generator=g), dim=-1).cuda().contiguous()
+    aat = torch.randint(0, 21, (B, N), generator=g).int().cuda()
+    tb = dev(residue_tables.packed_bytes())
+    rot_a = torch.empty(B, N, 3, 3, device="cuda")
+    a37 = torch.full((B, N, 37, 3), 7.0, device="cuda")
+    out = d.reverse_device(t7, rs, ts, dm, zr, zt, 0.4, 0.01, True, 0.5, rot_out=rot_a, atoms=(psi, aat, tb, a37))
+    inpl = t7.clone()
+    rot_b = torch.empty_like(rot_a)
+    d.reverse_device(inpl, rs, ts, dm, zr, zt, 0.4, 0.01, True, 0.5, rigids_out=inpl, rot_out=rot_b)
+    assert torch.equal(out, inpl) and torch.equal(rot_a, rot_b)
+    ref37 = torch.empty_like(a37)
+    _lib.check(lib.fdipt_backbone_atoms(B * N, None, _lib.ptr(rot_a), _lib.ptr(out[..., 4:].contiguous()), _lib.ptr(psi),
+                                        _lib.ptr(aat), _lib.ptr(tb), _lib.ptr(ref37), None, _lib.stream_ptr()))
+    assert torch.equal(a37, ref37)
+    with pytest.raises(_lib.FdiptError):  # the fused atoms need the out-of-place form
+        d.reverse_device(inpl, rs, ts, dm, zr, zt, 0.4, 0.01, True, 0.5, rigids_out=inpl, atoms=(psi, aat, tb, a37))
+
+
+@pytest.mark.parametrize("N", [5, 20, 300])
+def test_rot_score_batched_vs_per_sample(N):
+    """IGSO(3) score of a batch whose samples sit at different noise levels (series cut, weight table per sample; blocks
+    spanning two samples at N=20, per-lane weights at N=5) vs one call per sample."""
+    from framedipt_amd import _lib
+    lib = _lib.load()
+    B = 4
+    g = torch.Generator().manual_seed(N)
+    nq = lambda: torch.nn.functional.normalize(torch.randn(B, N, 4, generator=g), dim=-1).cuda().contiguous()  # noqa: E731
+    qt, q0 = nq(), nq()
+    sig = torch.tensor([0.1, 1.5, 0.37, 0.9], dtype=torch.float64).cuda()
+    full = torch.empty(B, N, 3, dtype=torch.float64, device="cuda")
+    _lib.check(lib.fdipt_igso3_rot_score(B, N, _lib.ptr(qt), _lib.ptr(q0), _lib.ptr(sig), None, _lib.ptr(full), _lib.stream_ptr()))
+    for b in range(B):
+        one = torch.empty(1, N, 3, dtype=torch.float64, device="cuda")
+        _lib.check(lib.fdipt_igso3_rot_score(1, N, _lib.ptr(qt[b].contiguous()), _lib.ptr(q0[b].contiguous()),
+                                             _lib.ptr(sig[b:b + 1].contiguous()), None, _lib.ptr(one), _lib.stream_ptr()))
+        assert torch.equal(one[0], full[b]), b
+    assert torch.isfinite(full).all()
+
+
+def test_launch_folds_vs_separate_launches():
+    """Default forward (x_t split / first edge-embedder halves in the feature kernel, once-per-forward fills in one launch, last
+    torsion layer and R^3 score in the score launch, skip_embed of all blocks in one GEMM, CA hand-over) vs the same forward with
+    every fold switched off."""
+    import os
+    G = load_golden("fwd_full_denovo_n64.npz")
+    switches = ("FDIPT_FEATS_UNFUSED", "FDIPT_TORF_UNFUSED", "FDIPT_INIT_UNFUSED", "FDIPT_SKIP_PER_BLOCK")
+    outs = {}
+    for tag, on in (("fold", False), ("plain", True)):
+        for v in switches:
+            os.environ.pop(v, None)
+            if on:
+                os.environ[v] = "1"
+        try:
+            net, _, conf = _net("full_denovo_n64", G, "bf16")
+            f = _feats(G)
+            out = net(f)
+            outs[tag] = {k: out[k].cpu().numpy().copy() for k in ("rigids", "psi", "rot_score", "trans_score", "atom37")}
+            if not on:  # the forward's own hand-over of the predicted CA positions (self-conditioning input of the next step)
+                from framedipt_amd import inference as inf
+                loop = inf.ReverseLoop(net, _, f, num_t=10, min_t=0.01, noise_scale=0.1)
+                before = loop.sc_ca.clone()
+                loop.prime()
+                assert torch.equal(loop.sc_ca, loop.st.rigids[..., 4:]) and not torch.equal(loop.sc_ca, before)
+        finally:
+            for v in switches:
+                os.environ.pop(v, None)
+    for k in outs["fold"]:
+        a, c = outs["plain"][k], outs["fold"][k]
+        np.testing.assert_allclose(c, a, atol=2e-3 * max(1.0, np.abs(a).max()), err_msg=k)
