@@ -256,9 +256,10 @@ __device__ __forceinline__ bf16x8 sa_pack8(const float* v) {
 template <int SA_NTW, int LB>
 __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, int Np, int H, const bf16_t* __restrict__ Qi,
                                                                  const bf16_t* __restrict__ Ki, const bf16_t* __restrict__ Vi,
-                                                                 float* __restrict__ out, int out_ld) {
+                                                                 float* __restrict__ out, int out_ld, L2Warm warm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nt = Np >> 5, ks = 2 * nt;
+  unsigned warm_tok = 0;
   float* mxs = (float*)smem;              // [4][32]
   float* sms = mxs + 128;                 // [4][32]
   u16x8* Pfs = (u16x8*)(sms + 128);       // [2 nt][64]
@@ -311,6 +312,8 @@ __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, 
       S[u] = acc;
     }
   }
+  // wave 3 (no V operands, nothing in flight from here on) touches the weights of the kernel launched next
+  if (wave == 3) warm_tok = fd_l2_warm(warm, blockIdx.x, gridDim.x, lane, 64);
   // ---- softmax over all keys: own registers -> lane^32 -> the other waves through LDS
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   if (hi == 0) mxs[wave * 32 + li] = mx;
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, 
         }
     }
   }
+  fd_l2_warm_done(warm_tok);
 }
 
 size_t fd_seq_attention_image_bytes(int B, int N, int H) {
@@ -381,8 +385,8 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
   FD_CHECK_LAUNCH();
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
-  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
-  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, L2Warm{});
+  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, L2Warm{});
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -413,7 +417,8 @@ int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, 
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
-int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, hipStream_t st) {
+int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, const L2Warm* warm, hipStream_t st) {
+  const L2Warm wm = warm ? *warm : L2Warm{};
   if (!fd_seq_attention_supported(N, H, SA_HD) || (out_ld & 3)) return FDIPT_EINVAL;
   const int Np = (N + 31) / 32 * 32, nt = Np / 32;
   const bf16_t* Qi = (const bf16_t*)images;
@@ -421,8 +426,8 @@ int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, in
   const bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
-  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
-  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld);
+  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
+  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -107,6 +107,28 @@ __device__ __forceinline__ void stage_tile(typename P::T* dst, const SrcT* __res
 }
 
 // ------------------------------------------------------------------ reductions
+// L2 warm-up hand-over.  Every kernel of the node path starts with dependent reads of weights that no XCD's L2 holds any more
+// (each weight set is used once per forward, 2 ms and ~1 GB of pair traffic ago).  A kernel can touch the NEXT kernel's weights
+// (one dword per 128 B line, result discarded) at a point where it has nothing left to wait for, so that those first reads hit.
+// Blocks are dispatched round-robin over the 8 XCDs: block `id` runs on XCD id & 7 and takes slice id >> 3 of ceil(n_blocks / 8)
+// slices, i.e. every XCD's L2 sees every line.  The returned token keeps the destination register reserved: hand it to
+// fd_l2_warm_done() at the end of the kernel (the loads are invisible to the compiler's vmcnt bookkeeping).
+struct L2Warm { const void* p[3]; unsigned bytes[3]; };
+__device__ __forceinline__ unsigned fd_l2_warm(const L2Warm& w, int block_id, int n_blocks, int t, int nthreads) {
+  unsigned tok = 0;
+  const unsigned slice = (unsigned)block_id >> 3, ns = ((unsigned)n_blocks + 7) >> 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!w.p[k]) continue;
+    const unsigned lines = (w.bytes[k] + 127) >> 7, per = (lines + ns - 1) / ns;
+    const unsigned l0 = slice * per, l1 = l0 + per < lines ? l0 + per : lines;
+    for (unsigned l = l0 + t; l < l1; l += nthreads)
+      asm volatile("global_load_dword %0, %1, off" : "+v"(tok) : "v"((const char*)w.p[k] + ((size_t)l << 7)) : "memory");
+  }
+  return tok;
+}
+__device__ __forceinline__ void fd_l2_warm_done(unsigned tok) { asm volatile("s_waitcnt vmcnt(0)" : : "v"(tok) : "memory"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

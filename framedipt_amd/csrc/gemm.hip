@@ -368,7 +368,8 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ rowmask,
                                                                float* __restrict__ out, int ldo,
-                                                               const float* __restrict__ extra, int ld_extra, int n_extra) {
+                                                               const float* __restrict__ extra, int ld_extra, int n_extra,
+                                                               L2Warm warm) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (FD_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -394,6 +395,8 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
     v[i] = t;
     s += t;
   }
+  // the block's first wave touches the weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
+  const unsigned warm_tok = threadIdx.x < 64 ? fd_l2_warm(warm, blockIdx.x, gridDim.x, lane, 64) : 0u;
   const float mu = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
@@ -411,23 +414,24 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
     const int c = lane + i * 64;
     if (c < D) out[(long)row * ldo + c] = ((v[i] - mu) * rstd * gamma[c] + beta[c]) * rm;
   }
+  fd_l2_warm_done(warm_tok);
 }
 
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,
                  const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !gamma || !beta || !out) return FDIPT_EINVAL;
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, residual, ldr, 1,
-                     0L, gamma, beta, rowmask, out, ldo, (const float*)nullptr, 0, 0);
+                     0L, gamma, beta, rowmask, out, ldo, (const float*)nullptr, 0, 0, L2Warm{});
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
 // LayerNorm(x + sum_k parts[k]) for the split-K products of fd_linear_splitk
 int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
                        const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, const float* extra,
-                       int ld_extra, int n_extra, hipStream_t st) {
+                       int ld_extra, int n_extra, const L2Warm* warm, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !parts || nparts < 1 || nparts > 8 || !gamma || !beta || !out) return FDIPT_EINVAL;
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, parts, ldr, nparts,
-                     part_stride, gamma, beta, rowmask, out, ldo, extra, ld_extra, extra ? n_extra : 0);
+                     part_stride, gamma, beta, rowmask, out, ldo, extra, ld_extra, extra ? n_extra : 0, warm ? *warm : L2Warm{});
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

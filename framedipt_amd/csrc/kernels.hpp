@@ -195,7 +195,7 @@ int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images,
 int fd_seq_qkv_supported(int N, int H, int d_model);
 int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const float* bias, float scale, void* images,
                hipStream_t st);
-int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, hipStream_t st);
+int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, const L2Warm* warm, hipStream_t st);
 
 // row-complete fused per-residue MLPs (rowblock.hip): 32 rows x all output columns per block, up to 3 Linear layers
 // (+ReLU) + residual + LayerNorm + row mask; weights as fd_chain_build_image(.., permuted = 0) fragment images
@@ -232,6 +232,7 @@ struct TfmrTailArgs {
   const void *wo, *w1, *w2;       // fragment images, natural k order (fd_chain_build_image(.., 0))
   const float *bo, *g1, *be1, *b1, *b2, *g2, *be2;
   float* out;                     // must not alias x
+  L2Warm warm;                    // weights of the kernel launched next (touched once the block's own first loads are out)
 };
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st);
 
@@ -263,7 +264,7 @@ int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* 
                 hipStream_t st);
 int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts, int ldr, int nparts, long part_stride,
                        const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, const float* extra,
-                       int ld_extra, int n_extra, hipStream_t st);
+                       int ld_extra, int n_extra, const L2Warm* warm, hipStream_t st);
 // the same with bf16 activation rows (what the bf16 GEMM would round them to anyway)
 int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const bf16_t* A, int lda, const void* W, int ldw, const float* bias,
                          const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);

@@ -6,6 +6,7 @@
 // no synchronisation, no host round-trip (the reference syncs inside the forward, so3_diffuser.py:398).
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -582,6 +583,9 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
                  nullptr, 0, F(w.skip_all), d->num_blocks * d->c_skip, st));
   const size_t NN = (size_t)R * N;
   bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
+  const char* dbg_twice = getenv("FDIPT_DBG_TWICE");  // timing aid: repeat the named launches (second one runs on a warm L2)
+#define TWICE(name, call) do { RC(call); if (dbg_twice && strstr(dbg_twice, name)) RC(call); } while (0)
+  const bool warm_all = !getenv("FDIPT_NO_L2_WARM");  // L2 warm-up hand-over between consecutive launches (common.hpp)
   const bool seq_fused = rbk && !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_QKV_FUSE") &&
                          fd_seq_attention_supported(N, d->tfmr_heads, iv.d_t / d->tfmr_heads) &&
                          fd_seq_qkv_supported(N, d->tfmr_heads, iv.d_t);
@@ -631,7 +635,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
           RC(fd_ipa_proj_zero_pads(pz, vpt_zero ? W + w.vpt : nullptr, vpt_zero ? vpt_bytes : 0, st));
           vpt_zero = false;
         }
-        RC(fd_ipa_proj2(pj, st));
+        TWICE("proj", fd_ipa_proj2(pj, st));
       } else RC(fd_ipa_proj(pj, st));
       if (vpt_zero && hipMemsetAsync(W + w.vpt, 0, vpt_bytes, st) != hipSuccess) return FDIPT_ELAUNCH;
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
@@ -648,7 +652,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       if (fd_opair_mfma_eligible(prec, oa) && 2 * Np <= 4 * N && !getenv("FDIPT_PROBS_F32")) {
         a3.probs_bf16 = (bf16_t*)(W + w.probs); oa.probs_bf16 = a3.probs_bf16; oa.probs_np = Np;
       }
-      RC(fd_attention3(a3, st));
+      TWICE("attn3", fd_attention3(a3, st));
     } else {
       // fused q | kv | q_pts | kv_pts projection (fp32 activations), then the LDS / register attention kernels
       RC(fd_linear(prec, R, iv.proj_out, cs, node_cur, cs, D + db.wproj, cs, (const float*)(D + db.bproj), nullptr, 0,
@@ -672,19 +676,20 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         RC(fd_attention(prec, 1, aa, st));
       }
     }
-    RC(fd_opair(prec, oa, st));
+    TWICE("opair", fd_opair(prec, oa, st));
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
     if (bf && iv.feat_dim >= 1024 && !getenv("FDIPT_NO_SPLITK")) {
       const int NS = 4;  // K = 2688: slices of 704 / 576 columns -> 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower)
       if (feats_bf16)
-        RC(fd_linear_splitk_a16(R, cs, iv.feat_dim, NS, (const bf16_t*)(W + w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b,
+        TWICE("splitk", fd_linear_splitk_a16(R, cs, iv.feat_dim, NS, (const bf16_t*)(W + w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b,
                                 res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
       else
         RC(fd_linear_splitk(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b, res_mask,
                             F(w.ipa_parts), (long)R * cs, cs, st));
+      const L2Warm warm_qkv0 = {{D + db.ch.inp[0], nullptr, nullptr}, {(unsigned)fd_chain_image_bytes(3 * dt, dt), 0, 0}};
       RC(fd_layernorm_parts(R, cs, node_cur, cs, F(w.ipa_parts), cs, NS, (long)R * cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr,
                             F(w.tf_in), dt, skip_batched ? F(w.skip_all) + (size_t)b * d->c_skip : nullptr,
-                            d->num_blocks * d->c_skip, d->c_skip, st));
+                            d->num_blocks * d->c_skip, d->c_skip, warm_all && seq_fused ? &warm_qkv0 : nullptr, st));
       skip_done = skip_batched;
     } else {
       RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
@@ -706,8 +711,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
           RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, SeqInitExtra{}, st));
           seq_img_ready = true;
         }
-        RC(fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));
-        RC(fd_seq_attention_run(B, N, d->tfmr_heads, W + w.seqimg, F(w.att), dt, st));
+        TWICE("qkv", fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));
+        // ... and touches the weights of the layer's tail kernel, launched next (common.hpp: L2 warm-up hand-over)
+        const unsigned wimg = (unsigned)fd_chain_image_bytes(dt, dt);
+        L2Warm wt = {{D + db.ch.outp[l], D + db.ch.l1[l], D + db.ch.l2n[l]}, {wimg, wimg, wimg}};
+        const bool warm_on = rbk && !getenv("FDIPT_NO_TFMR_TAIL") && warm_all;
+        TWICE("sattn", fd_seq_attention_run(B, N, d->tfmr_heads, W + w.seqimg, F(w.att), dt, warm_on ? &wt : nullptr, st));
       } else {
       if (con(FD_CHAIN_INPROJ)) RC(chain(FD_CHAIN_INPROJ, x, dt, D + db.ch.inp[l], P + t.inp.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                         nullptr, nullptr, nullptr, F(w.qkv), 3 * dt));
@@ -731,7 +740,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         tt.M = R; tt.ld = dt; tt.att = F(w.att); tt.x = x; tt.wo = D + db.ch.outp[l]; tt.w1 = D + db.ch.l1[l]; tt.w2 = D + db.ch.l2n[l];
         tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
         tt.be2 = P + t.n2.b; tt.out = x == F(w.x_b) ? F(w.x_a) : F(w.x_b);
-        RC(fd_tfmr_tail(tt, st));
+        tt.warm = L2Warm{};  // next launch: the following layer's in_proj, or post_tfmr
+        if (warm_all && l + 1 < d->tfmr_layers && seq_fused) { tt.warm.p[0] = D + db.ch.inp[l + 1]; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(3 * dt, dt); }
+        else if (warm_all && l + 1 == d->tfmr_layers) { tt.warm.p[0] = D + db.ch.post; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(cs, dt); }
+        TWICE("tail", fd_tfmr_tail(tt, st));
         x = tt.out;
         continue;
       } else if (rbk) {

@@ -433,6 +433,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       const int r = 8 * it + (lane >> 3), gr = row0 + r < a.M ? row0 + r : a.M - 1;
       rv[u][it] = *(const f32x4*)(a.x + (long)gr * a.ld + 32 * T + 4 * (lane & 7));
     }
+  const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
   __syncthreads();
   FD_STAMP(1);
   bf16x8 X[TL_KS];
@@ -588,6 +589,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       }
     }
   }
+  fd_l2_warm_done(warm_tok);
 }
 
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
