@@ -242,6 +242,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
   } else {
     ch_wait_barrier<0>();
   }
+  // single-step kinds: nothing of the block is in flight any more -> touch the weights of the kernel launched next
+  unsigned warm_tok = 0;
+  if constexpr (NSTEP == 1) warm_tok = fd_l2_warm(a.warm, blockIdx.x * gridDim.y + blockIdx.y, gridDim.x * gridDim.y, tid, FD_THREADS);
   const float pre = c_pre[wave * 32 + li];
 
   bf16x8 H1[NT1 > 0 ? 2 * NT1 : 1], H2[NT2 > 0 ? 2 * NT2 : 1];
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
         }
       }
   }
+  fd_l2_warm_done(warm_tok);
 }
 
 template <int K0, int NH1, int NH2, int NOUT, int FLAGS, int YS = 1>

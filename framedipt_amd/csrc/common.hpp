@@ -127,6 +127,12 @@ __device__ __forceinline__ unsigned fd_l2_warm(const L2Warm& w, int block_id, in
   }
   return tok;
 }
+// ... by the LAST `last` blocks of a launch only (kernels that stream more than an L2's worth of data after their first
+// blocks would evict lines touched earlier): `id` is the linear block index in dispatch order
+__device__ __forceinline__ unsigned fd_l2_warm_last(const L2Warm& w, int id, int n_blocks, int last, int t, int nthreads) {
+  const int base = n_blocks > last ? (n_blocks - last + 7) & ~7 : 0;  // multiple of 8: (id - base) & 7 is still the XCD
+  return id >= base ? fd_l2_warm(w, id - base, n_blocks - base, t, nthreads) : 0u;
+}
 __device__ __forceinline__ void fd_l2_warm_done(unsigned tok) { asm volatile("s_waitcnt vmcnt(0)" : : "v"(tok) : "memory"); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -72,6 +72,7 @@ struct OPairArgs {
   bf16_t* out_bf16;      // MFMA kernel: if set, bf16 rows (same out_ld, in elements) INSTEAD of out
   long out_ld;
   int off;
+  L2Warm warm = {};  // weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
 };
 
 struct PointsArgs {
@@ -221,6 +222,7 @@ struct RowBlockArgs {
   const float *bb_w, *bb_b;     // [6, c_s], [6]
   const float* upd_mask;        // [M] or NULL
   float *quat, *trans;          // [M,4], [M,3]
+  L2Warm warm = {};             // weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
 };
 enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS, FD_RB_ET4_IMAGES };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
@@ -250,6 +252,7 @@ struct ChainArgs {
   const float* rowmask_post;     // final * mask, or NULL
   float* out;
   int ld_out;
+  L2Warm warm = {};  // weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
 };
 enum { FD_CHAIN_TRANSITION, FD_CHAIN_FFN, FD_CHAIN_OUTPROJ, FD_CHAIN_POST, FD_CHAIN_INPROJ, FD_CHAIN_SKIP, FD_CHAIN_ETINIT,
        FD_CHAIN_A1, FD_CHAIN_AF, FD_CHAIN_NODE_EMBED_72, FD_CHAIN_NODE_EMBED_88, FD_CHAIN_TORSION };

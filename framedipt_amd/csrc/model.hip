@@ -512,6 +512,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     return fd_rowblock(kind, r, st);
   };
   unsigned short* chain_bf16 = nullptr;  // one-shot: the next chain() call also writes a bf16 copy of its output rows
+  L2Warm chain_warm = {};                // one-shot: the next chain() call touches these weights (L2 warm-up hand-over)
   auto chain = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                    const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* pre,
                    const float* post, float* out, int ld_out) {
@@ -519,6 +520,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     c.M = R; c.in = in; c.ld_in = ld_in; c.w[0] = w0; c.w[1] = w1; c.w[2] = w2; c.b[0] = b0; c.b[1] = b1; c.b[2] = b2;
     c.residual = resid; c.ld_res = ld_res; c.gamma = lnw ? P + lnw->g : nullptr; c.beta = lnw ? P + lnw->b : nullptr;
     c.rowmask_pre = pre; c.rowmask_post = post; c.out = out; c.ld_out = ld_out; c.out_bf16 = chain_bf16; chain_bf16 = nullptr;
+    c.warm = chain_warm; chain_warm = L2Warm{};
     return fd_chain(kind, c, st);
   };
 
@@ -772,6 +774,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     }
     // node = node + post_tfmr(x); StructureModuleTransition; mask   (ipa:539-541, 36-58)
     if (con(FD_CHAIN_POST)) {
+      const unsigned tb = (unsigned)fd_chain_image_bytes(cs, cs);
+      if (warm_all && rbk) chain_warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.ch.t3n}, {tb, tb, tb}};
       RC(chain(FD_CHAIN_POST, x, dt, D + db.ch.post, P + k.post.b, nullptr, nullptr, nullptr, nullptr, F(w.tf_in), dt, nullptr,
                nullptr, nullptr, F(w.h_a), cs));
     } else {
@@ -786,6 +790,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       r.rowmask_post = res_mask; r.out = F(w.node); r.ld_out = cs; r.bb_w = P + k.bb.w; r.bb_b = P + k.bb.b;
       r.upd_mask = F(w.dmask); r.quat = F(w.quat); r.trans = F(w.trans); r.out2 = nullptr; r.ld_out2 = r.split = 0;
       r.hid_bf16 = nullptr;
+      if (warm_all && b < d->num_blocks - 1 && iv.cb == 128 && iv.hid == 384 && cz == 128)  // next: the EdgeTransition row launch
+        r.warm = L2Warm{{D + db.ch.et_init, D + db.ch.r4w, nullptr},
+                        {(unsigned)fd_chain_image_bytes(iv.cb, cs), (unsigned)fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb), 0}};
+      else if (warm_all && b == d->num_blocks - 1)  // ... or the torsion head
+        r.warm = L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, nullptr}, {(unsigned)fd_chain_image_bytes(cs, cs), (unsigned)fd_chain_image_bytes(cs, cs), 0}};
       RC(fd_rowblock(FD_RB_TRANSITION_BB, r, st));
       bb_done = true;
     } else if (con(FD_CHAIN_TRANSITION)) {

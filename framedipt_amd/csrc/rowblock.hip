@@ -136,6 +136,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       rv[u][it] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (has_res) rv[u][it] = *(const f32x4*)(a.residual + (long)gr * a.ld_res + 32 * T + 4 * (lane & 7));
     }
+  const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
   __syncthreads();
 
   bf16x8 X[KSMAX];
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
         }
       }
     }
+    fd_l2_warm_done(warm_tok);
     return;
   }
   // ---- + bias + residual (row segments -> fragment layout through the wave's tile)
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       a.trans[r * 3] += d0 * m; a.trans[r * 3 + 1] += d1 * m; a.trans[r * 3 + 2] += d2 * m;
     }
   }
+  fd_l2_warm_done(warm_tok);
 }
 
 // ------------------------------------------------------------------ whole post-attention half of an encoder layer
