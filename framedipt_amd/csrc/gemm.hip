@@ -417,6 +417,46 @@ __global__ __launch_bounds__(FD_THREADS) void layernorm_kernel(int M, int D, con
   fd_l2_warm_done(warm_tok);
 }
 
+// D == 256, split-K partial products: one row per wave, a lane owns 4 consecutive features -> every operand is ONE 16 B load per
+// lane (the generic kernel issues four 4 B loads per operand), all of them in flight together; same summation order.
+__global__ __launch_bounds__(FD_THREADS) void layernorm256_parts_kernel(int M, const float* __restrict__ x, int ldx,
+                                                                        const float* __restrict__ parts, int ldr, int nparts,
+                                                                        long part_stride, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta,
+                                                                        const float* __restrict__ rowmask, float* __restrict__ out,
+                                                                        int ldo, const float* __restrict__ extra, int ld_extra,
+                                                                        int n_extra, L2Warm warm) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (FD_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const f32x4 xv = *(const f32x4*)(x + (long)row * ldx + 4 * lane);
+  f32x4 pr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    pr[k] = k < nparts ? *(const f32x4*)(parts + k * part_stride + (long)row * ldr + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 gm = *(const f32x4*)(gamma + 4 * lane), bt = *(const f32x4*)(beta + 4 * lane);
+  f32x4 ex = {0.f, 0.f, 0.f, 0.f};
+  if (4 * lane < n_extra) ex = *(const f32x4*)(extra + (long)row * ld_extra + 4 * lane);
+  const float rm = rowmask ? rowmask[row] : 1.f;
+  const unsigned warm_tok = threadIdx.x < 64 ? fd_l2_warm(warm, blockIdx.x, gridDim.x, lane, 64) : 0u;
+  if (4 * lane < n_extra) *(f32x4*)(out + (long)row * ldo + 256 + 4 * lane) = ex;
+  f32x4 v = xv;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += pr[k][q];
+  const float mu = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+  float qs = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const float d = v[q] - mu; qs += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(qs) * (1.0f / 256.0f) + 1e-5f);
+  f32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = ((v[q] - mu) * rstd * gm[q] + bt[q]) * rm;
+  *(f32x4*)(out + (long)row * ldo + 4 * lane) = o;
+  fd_l2_warm_done(warm_tok);
+}
+
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,
                  const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !gamma || !beta || !out) return FDIPT_EINVAL;
@@ -430,6 +470,14 @@ int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts
                        const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, const float* extra,
                        int ld_extra, int n_extra, const L2Warm* warm, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !parts || nparts < 1 || nparts > 8 || !gamma || !beta || !out) return FDIPT_EINVAL;
+  if (D == 256 && !((ldx | ldr | ldo | ld_extra) & 3) && !(part_stride & 3) && (!extra || (n_extra & 3) == 0) && n_extra <= 256 &&
+      !getenv("FDIPT_LN_GENERIC")) {
+    hipLaunchKernelGGL(layernorm256_parts_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, x, ldx, parts, ldr,
+                       nparts, part_stride, gamma, beta, rowmask, out, ldo, extra, ld_extra, extra ? n_extra : 0,
+                       warm ? *warm : L2Warm{});
+    FD_CHECK_LAUNCH();
+    return FDIPT_OK;
+  }
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, D, x, ldx, parts, ldr, nparts,
                      part_stride, gamma, beta, rowmask, out, ldo, extra, ld_extra, extra ? n_extra : 0, warm ? *warm : L2Warm{});
   FD_CHECK_LAUNCH();
