@@ -234,6 +234,12 @@ struct TfmrTailArgs {
   const void *wo, *w1, *w2;       // fragment images, natural k order (fd_chain_build_image(.., 0))
   const float *bo, *g1, *be1, *b1, *b2, *g2, *be2;
   float* out;                     // must not alias x
+  // optional (last layer of the stack): post_tfmr (Linear 320 -> 256, fragment image wp, bias bp) + residual rows pres on the
+  // layer's output -> pout; `out` is then not written
+  const void* wp = nullptr;
+  const float *bp = nullptr, *pres = nullptr;
+  float* pout = nullptr;
+  int ld_pres = 0, ld_pout = 0;
   L2Warm warm;                    // weights of the kernel launched next (touched once the block's own first loads are out)
 };
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st);

@@ -703,6 +703,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     else RC(lin(R, k.skip, F(w.node0), cs, nullptr, 0, nullptr, 0, F(w.tf_in) + cs, dt));
     // nn.TransformerEncoder, post-norm (ipa:433-443,536-538)
     const float* x = F(w.tf_in);
+    bool post_done = false;
     for (int l = 0; l < d->tfmr_layers; ++l) {
       const TfLayer& t = k.tf[l];
       const int hd0 = dt / d->tfmr_heads;
@@ -742,8 +743,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         tt.M = R; tt.ld = dt; tt.att = F(w.att); tt.x = x; tt.wo = D + db.ch.outp[l]; tt.w1 = D + db.ch.l1[l]; tt.w2 = D + db.ch.l2n[l];
         tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
         tt.be2 = P + t.n2.b; tt.out = x == F(w.x_b) ? F(w.x_a) : F(w.x_b);
-        tt.warm = L2Warm{};  // next launch: the following layer's in_proj, or post_tfmr
+        tt.warm = L2Warm{};  // next launch: the following layer's in_proj, or post_tfmr / the transition
+        // the last layer also applies post_tfmr + the node residual (FDIPT_POST_UNFUSED: its own launch)
+        const bool post_here = l + 1 == d->tfmr_layers && cs == 256 && !getenv("FDIPT_POST_UNFUSED");
+        if (post_here) {
+          tt.wp = D + db.ch.post; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
+          post_done = true;
+        }
+        const unsigned tb = (unsigned)fd_chain_image_bytes(cs, cs);
         if (warm_all && l + 1 < d->tfmr_layers && seq_fused) { tt.warm.p[0] = D + db.ch.inp[l + 1]; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(3 * dt, dt); }
+        else if (warm_all && post_here) tt.warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.ch.t3n}, {tb, tb, tb}};
         else if (warm_all && l + 1 == d->tfmr_layers) { tt.warm.p[0] = D + db.ch.post; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(cs, dt); }
         TWICE("tail", fd_tfmr_tail(tt, st));
         x = tt.out;
@@ -773,7 +782,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       x = F(w.x_b);  // next layer: norm1 reads x_b -> x_a, norm2 reads x_a/att -> x_b (no aliasing)
     }
     // node = node + post_tfmr(x); StructureModuleTransition; mask   (ipa:539-541, 36-58)
-    if (con(FD_CHAIN_POST)) {
+    if (post_done) {
+    } else if (con(FD_CHAIN_POST)) {
       const unsigned tb = (unsigned)fd_chain_image_bytes(cs, cs);
       if (warm_all && rbk) chain_warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.ch.t3n}, {tb, tb, tb}};
       RC(chain(FD_CHAIN_POST, x, dt, D + db.ch.post, P + k.post.b, nullptr, nullptr, nullptr, nullptr, F(w.tf_in), dt, nullptr,

@@ -378,14 +378,18 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
 #define TL_KS (TL_D / 16)
 #define TL_NT (TL_D / 32)
 #define TL_XROW (TL_D * 2 + 16)
-#define TL_SMEM (2 * 32 * TL_XROW + 4 * 32 * RB_SROW + 7 * TL_D * 4 + 2 * 4 * 32 * 4 + 16)
+#define TL_NP 256  // post_tfmr output width (POST variant)
+#define TL_SMEM (2 * 32 * TL_XROW + 4 * 32 * RB_SROW + (7 * TL_D + TL_NP) * 4 + 2 * 4 * 32 * 4 + 16)
+// POST: the last layer of the stack also applies post_tfmr (Linear d_model -> c_s) + the node residual (ipa:539) to its own
+// output rows, which then never go to memory.
+template <bool POST>
 __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                                            // att rows, then hidden rows   [32][TL_XROW]
   char* hs = xs + 32 * TL_XROW;                               // x_a rows                     [32][TL_XROW]
   char* st_all = hs + 32 * TL_XROW;                           // per-wave exchange tiles      [4][32][RB_SROW]
-  float* cst = (float*)(st_all + 4 * 32 * RB_SROW);           // b_o | g1 | be1 | b1 | b2 | g2 | be2
-  float (*red)[4][32] = (float (*)[4][32])(cst + 7 * TL_D);   // [2][4][32]
+  float* cst = (float*)(st_all + 4 * 32 * RB_SROW);           // b_o | g1 | be1 | b1 | b2 | g2 | be2 | b_post
+  float (*red)[4][32] = (float (*)[4][32])(cst + 7 * TL_D + TL_NP);   // [2][4][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   const int row0 = blockIdx.x * 32;
   char* stg = st_all + wave * 32 * RB_SROW;
@@ -406,17 +410,17 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       xv[k] = *(const f32x4*)(a.att + (long)gr * a.ld + 4 * c4);
     }
     {  // the 7 x 320 constants: all 9 loads of a thread in flight together (a rolled loop is 9 dependent L2 round trips)
-      constexpr int NCV = (7 * TL_D + FD_THREADS - 1) / FD_THREADS;
+      constexpr int NC = 7 * TL_D + (POST ? TL_NP : 0), NCV = (NC + FD_THREADS - 1) / FD_THREADS;
       float cv[NCV];
 #pragma unroll
       for (int k = 0; k < NCV; ++k) {
         const int v = tid + k * FD_THREADS, which = v / TL_D, c = v % TL_D;
         const float* src = which == 0 ? a.bo : which == 1 ? a.g1 : which == 2 ? a.be1 : which == 3 ? a.b1 : which == 4 ? a.b2 : which == 5 ? a.g2 : a.be2;
-        cv[k] = v < 7 * TL_D ? src[c] : 0.f;
+        cv[k] = v < 7 * TL_D ? src[c] : (POST && v < NC ? a.bp[v - 7 * TL_D] : 0.f);
       }
 #pragma unroll
       for (int k = 0; k < NCV; ++k)
-        if (tid + k * FD_THREADS < 7 * TL_D) cst[tid + k * FD_THREADS] = cv[k];
+        if (tid + k * FD_THREADS < NC) cst[tid + k * FD_THREADS] = cv[k];
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -436,6 +440,16 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       const int r = 8 * it + (lane >> 3), gr = row0 + r < a.M ? row0 + r : a.M - 1;
       rv[u][it] = *(const f32x4*)(a.x + (long)gr * a.ld + 32 * T + 4 * (lane & 7));
     }
+  f32x4 rvp[POST ? 2 : 1][4];  // POST: node rows (residual of post_tfmr), tiles wave and wave + 4 of TL_NP / 32
+  if constexpr (POST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 8 * it + (lane >> 3), gr = row0 + r < a.M ? row0 + r : a.M - 1;
+        rvp[u][it] = *(const f32x4*)(a.pres + (long)gr * a.ld_pres + 32 * (wave + 4 * u) + 4 * (lane & 7));
+      }
+  }
   const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
   __syncthreads();
   FD_STAMP(1);
@@ -572,8 +586,62 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
         for (int q = 0; q < 4; ++q) acc[u][4 * g + q] += bv[q] + xa[u][4 * g + q];
       }
   }
+  if constexpr (POST) w_load(std::integral_constant<int, 0>{}, (const char*)a.wp, wave);  // first post_tfmr tile: in flight across the LayerNorm
   layernorm(cst + 5 * TL_D, cst + 6 * TL_D);
   FD_STAMP(8);
+  if constexpr (POST) {
+    // ---- stage 4: post_tfmr on the layer's output rows (bf16 through LDS, as every stage input) + bias + node rows
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int T = wave + 4 * u;
+      if (T < TL_NT)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f0 = 32 * T + 8 * g + 4 * hi;
+          rb_bf16x4 pk;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pk[q] = (__bf16)acc[u][4 * g + q];
+          *(rb_bf16x4*)(hs + li * TL_XROW + 2 * f0) = pk;   // the x_a rows are dead since stage 2 read them
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(hs + li * TL_XROW + 32 * s + 16 * hi);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int T = wave + 4 * u;
+      if (u == 0) w_load(std::integral_constant<int, 1>{}, (const char*)a.wp, T + 4);
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < TL_KS; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
+      acc[u] = c;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int T = wave + 4 * u;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) *(f32x4*)(stg + (8 * it + (lane >> 3)) * RB_SROW + 16 * (lane & 7)) = rvp[u][it];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const f32x4*)(cst + 7 * TL_D + 32 * T + 8 * g + 4 * hi);
+        const f32x4 rr = *(const f32x4*)(stg + li * RB_SROW + (8 * g + 4 * hi) * 4);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = acc[u][4 * g + q] + bv[q] + rr[q];
+        *(f32x4*)(stg + li * RB_SROW + (8 * g + 4 * hi) * 4) = o;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 8 * it + (lane >> 3);
+        const f32x4 o = *(const f32x4*)(stg + r * RB_SROW + 16 * (lane & 7));
+        if (row0 + r < a.M) *(f32x4*)(a.pout + (long)(row0 + r) * a.ld_pout + 32 * T + 4 * (lane & 7)) = o;
+      }
+    }
+    fd_l2_warm_done(warm_tok);
+    return;
+  }
   // ---- x_b rows out through the wave's tile (128 B row segments)
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -599,10 +667,15 @@ int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.ld & 3) || a.x == a.out) return FDIPT_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)tfmr_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)tfmr_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tfmr_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM) != hipSuccess)
+      return FDIPT_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(tfmr_tail_kernel, dim3(cdiv(a.M, 32)), dim3(FD_THREADS), TL_SMEM, st, a);
+  if (a.wp) {
+    if (!a.bp || !a.pres || !a.pout || (a.ld_pres & 3) || (a.ld_pout & 3)) return FDIPT_EINVAL;
+    hipLaunchKernelGGL(tfmr_tail_kernel<true>, dim3(cdiv(a.M, 32)), dim3(FD_THREADS), TL_SMEM, st, a);
+  } else hipLaunchKernelGGL(tfmr_tail_kernel<false>, dim3(cdiv(a.M, 32)), dim3(FD_THREADS), TL_SMEM, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
