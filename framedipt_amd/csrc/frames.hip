@@ -46,16 +46,21 @@ __device__ __forceinline__ void d_quat_to_rotvec(const float* qin, float* rv) { 
 
 // ------------------------------------------------------------------ SciPy Rotation conventions, float64
 // Rotation.from_rotvec(rv).as_matrix()  (framedipt/data/transforms.py:42 ; se3_diffuser.py:31)
-__device__ __forceinline__ void d_so3_exp(const double* rv, double* R) {
-  const double th2 = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
-  const double th = sqrt(th2);
-  const double sc = (th <= 1e-3) ? (0.5 - th2 / 48.0 + th2 * th2 / 3840.0) : (sin(th / 2) / th);
-  const double x = sc * rv[0], y = sc * rv[1], z = sc * rv[2], w = cos(th / 2);
+// Rotation(quat).as_matrix() for a unit quaternion (x, y, z, w)
+__device__ __forceinline__ void d_quat_matrix(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
   const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
   const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
   R[0] = x2 - y2 - z2 + w2; R[3] = 2 * (xy + zw); R[6] = 2 * (xz - yw);
   R[1] = 2 * (xy - zw); R[4] = -x2 + y2 - z2 + w2; R[7] = 2 * (yz + xw);
   R[2] = 2 * (xz + yw); R[5] = 2 * (yz - xw); R[8] = -x2 - y2 + z2 + w2;
+}
+__device__ __forceinline__ void d_so3_exp(const double* rv, double* R) {
+  const double th2 = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
+  const double th = sqrt(th2);
+  const double sc = (th <= 1e-3) ? (0.5 - th2 / 48.0 + th2 * th2 / 3840.0) : (sin(th / 2) / th);
+  const double q[4] = {sc * rv[0], sc * rv[1], sc * rv[2], cos(th / 2)};
+  d_quat_matrix(q, R);
 }
 // Markley quaternion of a 3x3 matrix (Rotation.from_matrix, SciPy 1.7.3 = the reference pin: no SVD projection).
 // q is scalar-LAST (x,y,z,w), normalised.
@@ -241,14 +246,37 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
     // ---- rotation: f32 quat -> f32 matrix -> f64 rotvec (se3_diffuser.py:16-23)
     float R32[9];
     d_quat_to_rot(a.rigids_t + r * 7, R32);
-    double Rt[9], rv[3];
+    double Rt[9], Ro[9];
     for (int c = 0; c < 9; ++c) Rt[c] = (double)R32[c];
+    double pert[3];
+    for (int c = 0; c < 3; ++c)
+      pert[c] = g_rot * g_rot * a.rot_score[r * 3 + c] * a.dt + g_rot * sdt * (a.noise_scale * a.z_rot[r * 3 + c]);
+    if (!has_mask || m == 1.0 || m == 0.0) {
+      // Binary masks (the only ones the samplers produce): the rotation vectors of the reference are only ever passed through
+      // exp(log(.)), which is the matrix of the Markley unit quaternion — from_rotvec(as_rotvec(q)).as_matrix() and
+      // q.as_matrix() agree to float64 rounding, far below the float32 cast that follows — so the chain
+      // log -> exp, exp -> compose -> log -> exp collapses to two quaternion extractions and ONE sin/cos pair (the float64
+      // atan2 / sin / cos calls are the whole latency of this kernel).
+      double q0[4];
+      d_markley(Rt, q0);
+      if (a.diffuse_rot && m != 0.0) {
+        double Re[9], Rp[9], Rc[9], q1[4];
+        d_quat_matrix(q0, Re);
+        d_so3_exp(pert, Rp);
+        for (int ii = 0; ii < 3; ++ii)
+          for (int jj = 0; jj < 3; ++jj)
+            Rc[ii * 3 + jj] = Re[ii * 3] * Rp[jj] + Re[ii * 3 + 1] * Rp[3 + jj] + Re[ii * 3 + 2] * Rp[6 + jj];
+        d_markley(Rc, q1);
+        d_quat_matrix(q1, Ro);
+      } else {
+        d_quat_matrix(q0, Ro);
+      }
+    } else {  // fractional mask: the reference's chain literally
+    double rv[3];
     d_so3_log(Rt, rv);
     double rv1[3] = {rv[0], rv[1], rv[2]};
     if (a.diffuse_rot) {
-      double pert[3], Rp[9], Rc[9];
-      for (int c = 0; c < 3; ++c)
-        pert[c] = g_rot * g_rot * a.rot_score[r * 3 + c] * a.dt + g_rot * sdt * (a.noise_scale * a.z_rot[r * 3 + c]);
+      double Rp[9], Rc[9];
       double Re[9];
       d_so3_exp(rv, Re);
       d_so3_exp(pert, Rp);
@@ -259,9 +287,9 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
     }
     if (has_mask)
       for (int c = 0; c < 3; ++c) rv1[c] = m * rv1[c] + (1 - m) * rv[c];
-    // ---- assemble (se3_diffuser.py:26-36): float32 rotation matrix + translation, then tensor_7
-    double Ro[9];
     d_so3_exp(rv1, Ro);
+    }
+    // ---- assemble (se3_diffuser.py:26-36): float32 rotation matrix + translation, then tensor_7
     float Rf[9];
     for (int c = 0; c < 9; ++c) Rf[c] = (float)Ro[c];
     if (a.out_rot)
