@@ -632,7 +632,88 @@ __global__ void points_kernel(PointsArgs a) {
   }
 }
 
+// The same for the attention3 path (value-point image wanted, Pv == 12, H % 2 == 0): one block = the 16 keys of one fragment
+// key group of a sample x half of the heads, 16 threads per key.  The image leaves as whole 16 B units (8 key slots of one
+// coordinate row) staged through LDS — the per-residue kernel above scatters it as single bf16 values (576 partial-sector
+// stores per residue) — and every global operand of a thread (quaternion, translation, its 7 points) is requested up front:
+// one memory round trip per block.
+__global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* vs = (unsigned short*)smem;  // [H/2][72][16] bf16: hi rows 0..35, lo rows 36..71, permuted key slot
+  const int tid = threadIdx.x, kk = tid >> 4, sub = tid & 15;
+  const int ng = (a.N + 15) >> 4, HH = a.H >> 1;
+  const int half = blockIdx.x & 1, bg = blockIdx.x >> 1, b = bg / ng, g = bg - b * ng;
+  const int key = 16 * g + kk;
+  const bool live = key < a.N;
+  const long r = (long)b * a.N + (live ? key : a.N - 1);
+  const int HPq = a.H * a.Pq, Pkv = a.Pq + a.Pv, HPkv = a.H * Pkv;
+  const int nq = HH * a.Pq, nkv = HH * Pkv;          // this block's points per key: query points, key/value points
+  constexpr int MAXI = 8;                             // (nq + nkv) / 16 <= 8 iterations per thread (H = 8: 2 + 5)
+  const float* row = a.proj + r * a.ld;
+  const f32x4 q4 = *(const f32x4*)(a.quat + r * 4);
+  const float tx = a.trans[r * 3], ty = a.trans[r * 3 + 1], tz = a.trans[r * 3 + 2];
+  float px[MAXI], py[MAXI], pz[MAXI];
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int p = sub + 16 * it;
+    px[it] = py[it] = pz[it] = 0.f;
+    if (p < nq) {
+      const int c = half * nq + p;
+      px[it] = row[a.q_off + c]; py[it] = row[a.q_off + HPq + c]; pz[it] = row[a.q_off + 2 * HPq + c];
+    } else if (p < nq + nkv) {
+      const int c = half * nkv + (p - nq);
+      px[it] = row[a.kv_off + c]; py[it] = row[a.kv_off + HPkv + c]; pz[it] = row[a.kv_off + 2 * HPkv + c];
+    }
+  }
+  if (!live)  // keys beyond the sample: their slots of the image stay zero
+    for (int v = sub; v < HH * 72; v += 16) vs[v * 16 + pt_perm16(kk)] = 0;
+  const float w = q4[0], x = q4[1], y = q4[2], z = q4[3];
+  float R[9];  // quat_to_rot (openfold/utils/rigid_utils.py:173-205), no normalisation
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+  R[3] = 2 * x * y + 2 * w * z; R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * y * z - 2 * w * x;
+  R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = w * w - x * x - y * y + z * z;
+  if (live && half == 0 && sub < 9) a.rot[r * 9 + sub] = R[sub];
+  const int slot = pt_perm16(kk);
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int p = sub + 16 * it;
+    if (!live || p >= nq + nkv) continue;
+    const float g3[3] = {R[0] * px[it] + R[1] * py[it] + R[2] * pz[it] + tx, R[3] * px[it] + R[4] * py[it] + R[5] * pz[it] + ty,
+                         R[6] * px[it] + R[7] * py[it] + R[8] * pz[it] + tz};
+    float* dst;
+    if (p < nq) {
+      dst = a.qp + (r * HPq + half * nq + p) * 3;
+    } else {
+      const int pp = p - nq, hl = pp / Pkv, e = pp - hl * Pkv, hh = half * HH + hl;
+      dst = e < a.Pq ? a.kp + ((r * a.H + hh) * a.Pq + e) * 3 : a.vp + ((r * a.H + hh) * a.Pv + (e - a.Pq)) * 3;
+      if (e >= a.Pq) {  // a value point: coordinate rows 3 (e - Pq) + {0,1,2} of head hh
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int rw = 3 * (e - a.Pq) + c;
+          const unsigned short vh = f2bf(g3[c]);
+          vs[(hl * 72 + rw) * 16 + slot] = vh;
+          vs[(hl * 72 + 36 + rw) * 16 + slot] = f2bf(g3[c] - bf2f(vh));
+        }
+      }
+    }
+    dst[0] = g3[0]; dst[1] = g3[1]; dst[2] = g3[2];
+  }
+  __syncthreads();
+  const int ks = a.Np >> 4;
+  for (int u = tid; u < HH * 144; u += 256) {
+    const int hl = u / 144, rem = u - hl * 144, rw = rem >> 1, hf = rem & 1;
+    const uint4 val = *(const uint4*)(vs + (hl * 72 + rw) * 16 + 8 * hf);
+    *(uint4*)(a.vpt + (((((long)b * a.H + half * HH + hl) * 3 + (rw >> 5)) * ks + g) * 64 + hf * 32 + (rw & 31)) * 8) = val;
+  }
+}
+
 int fd_points(const PointsArgs& a, hipStream_t st) {
+  if (a.vpt && a.Pv == 12 && (a.H & 1) == 0 && (a.H / 2) * (2 * a.Pq + a.Pv) <= 128 && (a.ld & 0) == 0 && !getenv("FDIPT_POINTS_V1")) {
+    const size_t smem = (size_t)(a.H / 2) * 72 * 16 * 2;
+    hipLaunchKernelGGL(points16_kernel, dim3(2 * a.B * ((a.N + 15) / 16)), dim3(256), smem, st, a);
+    FD_CHECK_LAUNCH();
+    return FDIPT_OK;
+  }
   hipLaunchKernelGGL(points_kernel, dim3(a.B * a.N), dim3(256), 0, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
