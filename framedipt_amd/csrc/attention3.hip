@@ -178,7 +178,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
     if (wave + 4 * u < nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = expf(S[u][r] - mx);
+        const float e = __builtin_amdgcn_exp2f((S[u][r] - mx) * 1.4426950408889634f);  // exp(x): one multiply + v_exp_f32 (expf adds range fix-ups)
         S[u][r] = e;
         sum += e;
       }
