@@ -145,14 +145,18 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
                                                                 bf16_t* __restrict__ Vi) {
   __shared__ __attribute__((aligned(16))) char xs[32 * SQ_XROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
-  const int M = B * N, row0 = blockIdx.x * 32, nt = Np >> 5, dm = H * SA_HD;
+  // 1-D grid, id = (x / 8) * 24 + y * 8 + (x % 8): the three column parts of a row block run on the row block's XCD (x % 8, the
+  // XCD whose L2 the producer of the rows — a 32-row-block kernel with the same mapping — wrote them through)
+  const int bx = (blockIdx.x / 24) * 8 + (blockIdx.x & 7), by = (blockIdx.x % 24) >> 3;
+  const int M = B * N, row0 = bx * 32, nt = Np >> 5, dm = H * SA_HD;
+  if (row0 >= M) return;
   bf16x8 Wf[2][SQ_KS];
   auto w_load = [&](auto BUF, int T) {
     constexpr int bf = decltype(BUF)::value;
 #pragma unroll
     for (int s = 0; s < SQ_KS; ++s) Wf[bf][s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(wimg + ((size_t)(T * SQ_KS + s) * 64 + lane) * 16));
   };
-  w_load(std::integral_constant<int, 0>{}, blockIdx.y * (SQ_K / 32) + wave);
+  w_load(std::integral_constant<int, 0>{}, by * (SQ_K / 32) + wave);
   {
     f32x4 xv[10];
 #pragma unroll
@@ -176,9 +180,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
   for (int s = 0; s < SQ_KS; ++s) X[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(xs + li * SQ_XROW + 32 * s + 16 * hi));
   // this lane's row (transposed tiles) -> sample / key
   const int m = row0 + li, mb = m < M ? m / N : 0, mr = m - mb * N;
-  // blockIdx.y = 0 / 1 / 2 takes the Q / K / V third of the 30 output tiles (3x the blocks: the kernel is latency-bound)
+  // by = 0 / 1 / 2 takes the Q / K / V third of the 30 output tiles (3x the blocks: the kernel is latency-bound)
   constexpr int NTP = SQ_K / 32;  // 10 tiles per part
-  const int T0 = blockIdx.y * NTP;
+  const int T0 = by * NTP;
   // bias of this wave's tiles, requested now (before the MFMAs), in the layout of the part's epilogue: a load issued after a
   // tile's MFMAs is one exposed L2 round trip per tile
   f32x4 bq[(NTP + 3) / 4][4];
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
     const int Tb = T0 + (wave + 4 * u < NTP ? wave + 4 * u : wave);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if (blockIdx.y < 2) bq[u][g] = *(const f32x4*)(bias + 32 * Tb + 8 * g + 4 * hi);
+      if (by < 2) bq[u][g] = *(const f32x4*)(bias + 32 * Tb + 8 * g + 4 * hi);
       else if (g == 0) bq[u][0][0] = bias[32 * Tb + li];
     }
   }
@@ -412,7 +416,7 @@ int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, 
   bf16_t* Qi = (bf16_t*)images;
   bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
   bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
-  hipLaunchKernelGGL(seq_qkv_kernel, dim3(cdiv(B * N, 32), 3), dim3(FD_THREADS), 0, st, B, N, Np, H, x, ld_x, (const char*)wimg, bias, scale,
+  hipLaunchKernelGGL(seq_qkv_kernel, dim3(24 * cdiv(cdiv(B * N, 32), 8)), dim3(FD_THREADS), 0, st, B, N, Np, H, x, ld_x, (const char*)wimg, bias, scale,
                      Qi, Ki, Vi);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
