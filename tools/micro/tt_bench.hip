@@ -8,7 +8,7 @@ int main() {
   (void)hipMalloc(&att, (size_t)M * D * 4); (void)hipMalloc(&x, (size_t)M * D * 4); (void)hipMalloc(&out, (size_t)M * D * 4);
   (void)hipMalloc(&vec, 7 * D * 4); (void)hipMalloc(&w, 3 * (size_t)D * D * 2);
   (void)hipMemset(att, 0, (size_t)M * D * 4); (void)hipMemset(x, 0, (size_t)M * D * 4); (void)hipMemset(vec, 0, 7 * D * 4); (void)hipMemset(w, 0, 3 * (size_t)D * D * 2);
-  TfmrTailArgs a; a.M = M; a.ld = D; a.att = att; a.x = x; a.out = out;
+  TfmrTailArgs a; a.warm = L2Warm{}; a.M = M; a.ld = D; a.att = att; a.x = x; a.out = out;
   a.wo = w; a.w1 = (char*)w + (size_t)D * D * 2; a.w2 = (char*)w + 2 * (size_t)D * D * 2;
   a.bo = vec; a.g1 = vec + D; a.be1 = vec + 2 * D; a.b1 = vec + 3 * D; a.b2 = vec + 4 * D; a.g2 = vec + 5 * D; a.be2 = vec + 6 * D;
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
