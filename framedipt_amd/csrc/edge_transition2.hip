@@ -854,7 +854,8 @@ size_t fd_ee2_image_bytes() { return 2 * EE2_IMG; }
 // 512-thread persistent blocks: 8 independent waves (two per SIMD) share the 64 KB weight images; every wave owns an
 // 8 KB LDS tile that transposes between "whole 512 B table rows per 32 lanes" (the global side) and MFMA fragments.
 #define EE2_THREADS 512
-#define EE2_LDS (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + 8192)  // ... + linear_b image of the first block
+#define EE2_MAXB 63     // distogram bins (edges in LDS)
+#define EE2_LDS (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + 8192 + 256)  // ... + linear_b image of the first block + distogram edges
 __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img,
                                                                      int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -863,6 +864,8 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
   char* stage = smem + 2 * EE2_IMG + wave * 8192;
   float* vec = (float*)(smem + 2 * EE2_IMG + 8 * 8192);  // [b2 | b3 | gamma | beta] x 128
   char* wbl = (char*)(vec + 4 * ET2_CZ);                 // 8 KB fragment image of linear_b (optional)
+  float* edg = (float*)(wbl + 8192);                     // [num_bins + 1] distogram edges, the last one 1e8
+  if (tid <= a.num_bins) edg[tid] = tid < a.num_bins ? a.edges[tid] : 1e8f;
   if (a.wb_img) et2_dma16((const char*)a.wb_img + tid * 16, wbl + (tid & ~63) * 16);
   for (int u = 0; u < 2 * EE2_IMG / 16 / EE2_THREADS; ++u)
     et2_dma16(img + (size_t)(u * EE2_THREADS + tid) * 16, smem + (size_t)(u * EE2_THREADS + (tid & ~63)) * 16);
@@ -876,7 +879,37 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
   const long n_pairs = (long)a.B * N * N;
   const float* b2row = vec + 4 * hi;
   const f32x4 bbv = a.wb_img ? f32x4{a.bb[4 * hi], a.bb[4 * hi + 1], a.bb[4 * hi + 2], a.bb[4 * hi + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+  // The per-pair inputs of the NEXT tile (sequence indices, self-conditioning CA) are requested at the top of a tile and turned
+  // into its table row ids (relative index, distogram bin) right after the current tile's gather, so that those two dependent
+  // memory round trips leave every tile's critical path at the price of two loop-carried registers; the distogram edges sit in
+  // LDS (a rolled loop over a.edges[] re-issues two dependent scalar loads per bin and tile).
+  struct PairIn { int si, sj; float ci[3], cj[3], mi, mj; };
+  auto request = [&](int tile) {
+    const long pr = (long)tile * 32 + li, pp = pr < n_pairs ? pr : n_pairs - 1;
+    const long bi = pp / N, bb = bi / N, bj = bb * N + (pp - bi * N);
+    PairIn r;
+    r.si = a.seq_idx[bi]; r.sj = a.seq_idx[bj];
+    r.mi = a.res_mask[bi]; r.mj = a.res_mask[bj];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r.ci[c] = a.sc_ca[bi * 3 + c]; r.cj[c] = a.sc_ca[bj * 3 + c]; }
+    return r;
+  };
+  auto row_ids = [&](int tile, const PairIn& r, int& rel, int& bin, float& msk) {
+    msk = r.mi * r.mj;
+    const long pr = (long)tile * 32 + li, pp = pr < n_pairs ? pr : n_pairs - 1;
+    const long bb = (pp / N) / N;
+    rel = (int)(bb * a.n_rel) + r.si - r.sj + a.rel_off;
+    const float dx = r.ci[0] - r.cj[0], dy = r.ci[1] - r.cj[1], dz = r.ci[2] - r.cj[2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    bin = a.num_bins;
+    for (int k = 0; k < a.num_bins; ++k)  // calc_distogram: strict inequalities, last upper edge 1e8 (edg[num_bins])
+      if (d > edg[k] && d < edg[k + 1]) bin = k;
+  };
+  const int tile_first = blockIdx.x * 8 + wave, tile_step = gridDim.x * 8;
+  int rel = 0, bin = 0;
+  float msk_n = 0.f;
+  if (tile_first < n_tiles) { const PairIn r0 = request(tile_first); row_ids(tile_first, r0, rel, bin, msk_n); }
+  for (int tile = tile_first; tile < n_tiles; tile += tile_step) {
     const long p0 = (long)tile * 32;
     const long p_raw = p0 + li;
     const bool valid = p_raw < n_pairs;
@@ -885,18 +918,9 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
     const int j = (int)(p - bi * N);
     const long bb = bi / N;
     const long bj = bb * N + j;
-    const int rel = (int)(bb * a.n_rel) + a.seq_idx[bi] - a.seq_idx[bj] + a.rel_off;
-    int bin = a.num_bins;
-    {
-      const float dx = a.sc_ca[bi * 3 + 0] - a.sc_ca[bj * 3 + 0];
-      const float dy = a.sc_ca[bi * 3 + 1] - a.sc_ca[bj * 3 + 1];
-      const float dz = a.sc_ca[bi * 3 + 2] - a.sc_ca[bj * 3 + 2];
-      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-      for (int k = 0; k < a.num_bins; ++k) {  // calc_distogram: strict inequalities, last upper edge 1e8
-        const float lo = a.edges[k], up = (k + 1 < a.num_bins) ? a.edges[k + 1] : 1e8f;
-        if (d > lo && d < up) bin = k;
-      }
-    }
+    const int tile_n = tile + tile_step < n_tiles ? tile + tile_step : tile;
+    const PairIn raw = request(tile_n);
+    const float msk = msk_n;
     // ---- layer 1 has no GEMM: h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]).  Two pairs per instruction: lanes 0..31 /
     // 32..63 read one whole 512 B row each (the row ids of pair 2 it + hi come from the lane that owns it)
     const int ibi = (int)bi, ibj = (int)bj;
@@ -915,6 +939,7 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
       // [32 pairs][256 B] tile, 16 B unit u of row r at u ^ (r & 15)
       *(ee_u32x2*)(stage + r * 256 + (((li >> 1) ^ (r & 15)) << 4) + 8 * (li & 1)) = pk;
     }
+    row_ids(tile_n, raw, rel, bin, msk_n);  // the next tile's row ids (this tile's were consumed by the gather above)
     bf16x8 H1[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) H1[s] = lds_frag(stage, li * 256 + (((2 * s + hi) ^ (li & 15)) << 4));
@@ -942,7 +967,7 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
       }
       mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
     }
-    ee_ln_epilogue(Y, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, a.res_mask[bi] * a.res_mask[bj], li, hi, lane,
+    ee_ln_epilogue(Y, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, msk, li, hi, lane,
                    stage, (bf16_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid,
                    a.wb_img ? wbl : nullptr, bbv, a.bias_out, a.H, bb, (int)(bi - bb * N), j, (N + 31) >> 5);
   }
@@ -951,6 +976,7 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
   const int n_tiles = cdiv(n_pairs, 32);
+  if (a.num_bins > EE2_MAXB) return FDIPT_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)edge_embed2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EE2_LDS) != hipSuccess)
