@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ET_FLOPS_PER_PAIR = 688128.0  # 2*(2*384^2 + 384*128): EdgeTransition, reference formulation
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 
 
 def pmc_traffic(precision: str, n: int, b: int):
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--n-res", type=int, default=300)
     ap.add_argument("--samples-per-gpu", type=int, default=8)
     ap.add_argument("--num-t", type=int, default=500)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
     a = ap.parse_args()
@@ -185,7 +185,7 @@ def main():
                                    f"the T={T} schedule, noise_scale 0.1, 17.4M-param synthetic weights",
                        "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(a.precision, N, B), "kernel": "edge_transition4_kernel" if a.precision == "bf16" else "edge_transition_kernel",
+                         "traffic": pmc_traffic(a.precision, N, B), "kernel": "edge_transition4_kernel" if a.precision == "fp16" else "edge_transition_kernel",
                          "avg_launch_ms": et * 1e3, "flops_per_launch": et_flops,
                          "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak},
         }

@@ -11,7 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfdipt_hip.so")
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+# FdiptDims.kernel_flags (include/fdipt.h): fallback paths of the half-precision mode, for parity tests
+KF_ET3, KF_GENERIC_PAIR, KF_GENERIC_ATTN, KF_UNFUSED_NODE, KF_UNFOLDED = 1, 2, 4, 8, 16
 _ERR = {-1: "FDIPT_EINVAL (bad argument)", -2: "FDIPT_ELAUNCH (HIP launch error)",
         -3: "FDIPT_ESIZE (workspace too small or N beyond the compiled tiling)"}
 
@@ -23,7 +25,7 @@ class FdiptError(RuntimeError):
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "c_s", "c_z", "c_hidden", "c_skip", "no_heads", "no_qk_points", "no_v_points", "tfmr_heads", "tfmr_layers",
-        "num_blocks", "index_embed", "num_bins", "use_aatype", "precision")] + [
+        "num_blocks", "index_embed", "num_bins", "use_aatype", "precision", "kernel_flags")] + [
         (n, C.c_float) for n in ("min_bin", "max_bin", "coordinate_scaling", "r3_min_b", "r3_max_b")]
 
 

@@ -261,7 +261,7 @@ static int launch_attn(AttnArgs a, hipStream_t st) {
 
 int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st) {
   if (precision == FDIPT_PREC_F32) return ipa ? launch_attn<PrecF32, true>(a, st) : launch_attn<PrecF32, false>(a, st);
-  return ipa ? launch_attn<PrecBF16, true>(a, st) : launch_attn<PrecBF16, false>(a, st);
+  return ipa ? launch_attn<PrecHalf, true>(a, st) : launch_attn<PrecHalf, false>(a, st);
 }
 
 // ------------------------------------------------------------------ o_pair
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
         if constexpr (sizeof(ZT) == 2) {
           const u16x8 raw = __builtin_bit_cast(u16x8, zr[bf][u][0]);
 #pragma unroll
-          for (int c = 0; c < 8; ++c) zv[c] = bf2f(raw[c]);
+          for (int c = 0; c < 8; ++c) zv[c] = h2f(raw[c]);
         } else {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   const int i = blockIdx.x, b = blockIdx.y;
   const long rb = (long)b * N;
-  const bf16_t* zrow = (const bf16_t*)a.z + (rb + i) * N * CZ;
+  const half_t* zrow = (const half_t*)a.z + (rb + i) * N * CZ;
   // this thread's pieces of the z rows: key PAIRS (2 jp, 2 jp + 1), jp = tid / 16 + 16 m, channels 8 (tid % 16) .. +7 — ALL
   // requested up front (one memory round trip per block); zr[2 m + w] = key 2 jp + w
   const int cg = tid & 15, jl0 = tid >> 4;
@@ -444,20 +444,20 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
     if (j < N) zr[k] = *(const u16x8*)(zrow + (long)j * CZ + 8 * cg);
   }
   // down_z as B fragments (wave 0 only): requested now, used at the very end
-  bf16x8 wdf[8];
+  hx8 wdf[8];
   if (wave == 0)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) wdf[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)((const char*)a.wdz_img + (s * 64 + lane) * 16));
+    for (int s = 0; s < 8; ++s) wdf[s] = __builtin_bit_cast(hx8, *(const u16x8*)((const char*)a.wdz_img + (s * 64 + lane) * 16));
   // attention weights -> bf16 rows (zero for padded keys) and sum_j a[h,i,j] (= 1 up to rounding and masking) in one pass:
   // 32 threads per head
-  if (a.probs_bf16) {  // already bf16 rows [b, i, h, probs_np] (attention3): 4 keys (8 B) per load, 32 threads per head
+  if (a.probs_h16) {  // already bf16 rows [b, i, h, probs_np] (attention3): 4 keys (8 B) per load, 32 threads per head
     const int hh = tid >> 5, l5 = tid & 31;
-    const bf16_t* pr = a.probs_bf16 + (((long)b * N + i) * H + hh) * a.probs_np;
+    const half_t* pr = a.probs_h16 + (((long)b * N + i) * H + hh) * a.probs_np;
     float sacc = 0.f;
     for (int j = 4 * l5; j < Np; j += 128) {
       u16x4 pv = {0, 0, 0, 0};
       if (j < a.probs_np) pv = *(const u16x4*)(pr + j);
-      sacc += (bf2f(pv[0]) + bf2f(pv[1])) + (bf2f(pv[2]) + bf2f(pv[3]));
+      sacc += (h2f(pv[0]) + h2f(pv[1])) + (h2f(pv[2]) + h2f(pv[3]));
       *(u16x4*)(pb + hh * prow + 2 * j) = pv;
     }
 #pragma unroll
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
     for (int j = l5; j < Np; j += 32) {
       const float pv = j < N ? pr[j] : 0.f;
       sacc += pv;
-      *(bf16_t*)(pb + hh * prow + 2 * j) = f2bf(pv);
+      *(half_t*)(pb + hh * prow + 2 * j) = f2h(pv);
     }
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
         u16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
         if (li < 8) af = *(const u16x8*)(arow + 2 * (ch * OM_JC + 16 * s));
         const u16x8 bfr = *(const u16x8*)(zs + 32 * s);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc, 0, 0, 0);
+        acc = fd_mfma32(__builtin_bit_cast(hx8, af), __builtin_bit_cast(hx8, bfr), acc);
       }
       if (ch + 1 < nch) scatter(std::integral_constant<int, (ch + 1 < OM_NK / 4 ? ch + 1 : 0)>{}, (ch + 1) & 1);
       __syncthreads();
@@ -533,16 +533,16 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
         const f32x4 x0 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi), x1 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi + 4);
         v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3]; v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
       }
-      bf16x8 af;
+      hx8 af;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) af[e] = (__bf16)v[e];
-      o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wdf[s], o2, 0, 0, 0);
+      for (int e = 0; e < 8; ++e) af[e] = (fd_h)v[e];
+      o2 = fd_mfma32(af, wdf[s], o2);
     }
     const float bd = a.bdz[li];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = o2[r] + bd * psum[4 * hi + r];
-      if (a.out_bf16) a.out_bf16[(rb + i) * a.out_ld + a.off + (4 * hi + r) * CD + li] = f2bf(v);
+      if (a.out_h16) a.out_h16[(rb + i) * a.out_ld + a.off + (4 * hi + r) * CD + li] = f2h(v);
       else a.out[(rb + i) * a.out_ld + a.off + (4 * hi + r) * CD + li] = v;
     }
   }
@@ -561,20 +561,20 @@ static int launch_opair(const OPairArgs& a, hipStream_t st) {
 }
 
 int fd_opair_mfma_eligible(int precision, const OPairArgs& a) {
-  return precision != FDIPT_PREC_F32 && a.CZ == 128 && a.H == 8 && a.CD == 32 && a.wdz_img && a.N <= 16 * OM_NK && !getenv("FDIPT_OPAIR_VALU");
+  return precision != FDIPT_PREC_F32 && a.CZ == 128 && a.H == 8 && a.CD == 32 && a.wdz_img && a.N <= 16 * OM_NK && !FD_DEV_ENV("FDIPT_OPAIR_VALU");
 }
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
   if (a.H > 8) return FDIPT_ESIZE;
   if (fd_opair_mfma_eligible(precision, a)) {
-    if (a.probs_bf16 && (a.probs_np & 3)) return FDIPT_EINVAL;
+    if (a.probs_h16 && (a.probs_np & 3)) return FDIPT_EINVAL;
     const int Np = (a.N + OM_JC - 1) / OM_JC * OM_JC;
     const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4;
     hipLaunchKernelGGL(opair_mfma_kernel, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
     FD_CHECK_LAUNCH();
     return FDIPT_OK;
   }
-  if (a.probs_bf16 || a.out_bf16) return FDIPT_EINVAL;  // the VALU kernels read fp32 weights and write fp32 features
-  return precision == FDIPT_PREC_F32 ? launch_opair<float>(a, st) : launch_opair<bf16_t>(a, st);
+  if (a.probs_h16 || a.out_h16) return FDIPT_EINVAL;  // the VALU kernels read fp32 weights and write fp32 features
+  return precision == FDIPT_PREC_F32 ? launch_opair<float>(a, st) : launch_opair<half_t>(a, st);
 }
 
 // ------------------------------------------------------------------ projected points -> global frame
@@ -619,8 +619,8 @@ __global__ void points_kernel(PointsArgs a) {
         const float g3[3] = {gx, gy, gz};
         for (int c = 0; c < 3; ++c) {
           const int row = 3 * (e - a.Pq) + c;
-          const unsigned short vh = f2bf(g3[c]);
-          const unsigned short vl = f2bf(g3[c] - bf2f(vh));
+          const unsigned short vh = f2h(g3[c]);
+          const unsigned short vl = f2h(g3[c] - h2f(vh));
           const long base = (bidx * a.H + hh) * 3;
           // rows < 36 (tile 0 and the first 4 rows of tile 1): high parts; rows 36..71: low parts
           const int rh = row, rl = 36 + row;
@@ -690,9 +690,9 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const int rw = 3 * (e - a.Pq) + c;
-          const unsigned short vh = f2bf(g3[c]);
+          const unsigned short vh = f2h(g3[c]);
           vs[(hl * 72 + rw) * 16 + slot] = vh;
-          vs[(hl * 72 + 36 + rw) * 16 + slot] = f2bf(g3[c] - bf2f(vh));
+          vs[(hl * 72 + 36 + rw) * 16 + slot] = f2h(g3[c] - h2f(vh));
         }
       }
     }
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
 }
 
 int fd_points(const PointsArgs& a, hipStream_t st) {
-  if (a.vpt && a.Pv == 12 && (a.H & 1) == 0 && (a.H / 2) * (2 * a.Pq + a.Pv) <= 128 && (a.ld & 0) == 0 && !getenv("FDIPT_POINTS_V1")) {
+  if (a.vpt && a.Pv == 12 && (a.H & 1) == 0 && (a.H / 2) * (2 * a.Pq + a.Pv) <= 128 && (a.ld & 0) == 0 && !FD_DEV_ENV("FDIPT_POINTS_V1")) {
     const size_t smem = (size_t)(a.H / 2) * 72 * 16 * 2;
     hipLaunchKernelGGL(points16_kernel, dim3(2 * a.B * ((a.N + 15) / 16)), dim3(256), smem, st, a);
     FD_CHECK_LAUNCH();

@@ -22,13 +22,13 @@
 #define A3_C 256
 #define A3_NTW_MAX 4  // key tiles per wave -> N <= 4 * 4 * 32 = 512
 
-__device__ __forceinline__ bf16x8 a3_pack8(const float* v) {
-  bf16x8 o;
+__device__ __forceinline__ hx8 a3_pack8(const float* v) {
+  hx8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+  for (int e = 0; e < 8; ++e) o[e] = (fd_h)v[e];
   return o;
 }
-__device__ __forceinline__ bf16x8 a3_ld(const bf16_t* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
+__device__ __forceinline__ hx8 a3_ld(const half_t* p) { return __builtin_bit_cast(hx8, *(const u16x8*)p); }
 
 // NTW: key tiles per wave (N <= 128 NTW).  NTW = 3 (N <= 384): 234 registers -> launch bound 2 -> TWO blocks per CU hide each
 // other's memory latency, so the operands of a tile are simply fetched when needed (DB = false).  NTW = 4: one block per
@@ -66,9 +66,9 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   // ---- query-side registers
   // LB == 2: Q fragments in registers.  LB == 3 (three blocks per CU: B H nt blocks then fit one round of the 256 CUs): the 64
   // registers are not affordable; the four waves need the same fragments, so they go to LDS once and are read per k-step
-  bf16x8 Qf[LB == 3 ? 1 : 16];
+  hx8 Qf[LB == 3 ? 1 : 16];
   {
-    const bf16_t* qr = a.Qb + ((bh * nt + qt) * 16 * 64 + lane) * 8;  // fragment order: 1 KB per k-step
+    const half_t* qr = a.Qb + ((bh * nt + qt) * 16 * 64 + lane) * 8;  // fragment order: 1 KB per k-step
     if constexpr (LB == 3) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) Qs[(4 * s + wave) * 64 + lane] = *(const u16x8*)(qr + (4 * s + wave) * 512);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...  The global operands of tile u+1 (K rows as A
   // fragments, key points, bias row pieces, mask) are fetched while tile u runs through the matrix cores.
   struct TileIn {
-    bf16x8 k[16];
+    hx8 k[16];
     f32x4 kp[6];
     f32x4 bv[4];
     float mA;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
     const int jA_raw = 32 * t + li;          // key owned by this lane as an A-operand ROW
     const bool vA = jA_raw < N;
     const int jA = vA ? jA_raw : N - 1;
-    const bf16_t* kr = a.Kb + ((bh * nt + t) * 16 * 64 + lane) * 8;  // fragment order (padded keys are zero rows)
+    const half_t* kr = a.Kb + ((bh * nt + t) * 16 * 64 + lane) * 8;  // fragment order (padded keys are zero rows)
 #pragma unroll
     for (int s = 0; s < 16; ++s) ti.k[s] = a3_ld(kr + s * 512);
     const float* kpr = a.kp + ((rb + jA) * H + h) * 24;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], acc, 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < 16; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ti.k[s], LB == 3 ? __builtin_bit_cast(bf16x8, Qs[s * 64 + lane]) : Qf[LB == 3 ? 0 : s], acc, 0, 0, 0);
+        acc = fd_mfma32(ti.k[s], LB == 3 ? __builtin_bit_cast(hx8, Qs[s * 64 + lane]) : Qf[LB == 3 ? 0 : s], acc);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   float* prow = a.probs + (bh * N + i) * N;
   // bf16 hand-over to the MFMA o_pair kernel: row (b, i) = the 8 heads' weights back to back, Np keys each (zero beyond N)
   const long bq = bh / a.H;
-  bf16_t* prow16 = a.probs_bf16 ? a.probs_bf16 + ((bq * N + i) * a.H + (bh - bq * a.H)) * (long)a.Np : nullptr;
+  half_t* prow16 = a.probs_h16 ? a.probs_h16 + ((bq * N + i) * a.H + (bh - bq * a.H)) * (long)a.Np : nullptr;
 #pragma unroll
   for (int u = 0; u < A3_NTW; ++u) {
     const int t = wave + 4 * u;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       if (valid && prow16) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const u16x4 o = {f2bf(v[4 * g]), f2bf(v[4 * g + 1]), f2bf(v[4 * g + 2]), f2bf(v[4 * g + 3])};
+          const u16x4 o = {f2h(v[4 * g]), f2h(v[4 * g + 1]), f2h(v[4 * g + 2]), f2h(v[4 * g + 3])};
           *(u16x4*)(prow16 + 32 * t + 8 * g + 4 * hi) = o;  // (masked / padded keys carry exact zeros)
         }
       } else if (valid) {
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   {
     constexpr int KSM = 2 * 4 * A3_NTW;  // k-steps of 16 keys at the maximum N
     const int ks = 2 * nt;
-    bf16x8 Va[DB ? 2 : 1][KSM];
-    auto v_load = [&](auto BUF, const bf16_t* base) {
+    hx8 Va[DB ? 2 : 1][KSM];
+    auto v_load = [&](auto BUF, const half_t* base) {
       constexpr int bf = decltype(BUF)::value;
 #pragma unroll
       for (int s = 0; s < KSM; ++s)
@@ -246,14 +246,14 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < KSM; ++s)
-        if (s < ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Va[bf][s], __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc, 0, 0, 0);
+        if (s < ks) acc = fd_mfma32(Va[bf][s], __builtin_bit_cast(hx8, Pfs[s * 64 + lane]), acc);
     };
     auto o_store = [&](const f32x16& acc, int dt) {
-      if (valid && a.out_bf16) {  // bf16 features: exactly what the output projection's bf16 GEMM would round them to
-        bf16_t* orow = a.out_bf16 + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
+      if (valid && a.out_h16) {  // bf16 features: exactly what the output projection's bf16 GEMM would round them to
+        half_t* orow = a.out_h16 + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const u16x4 o = {f2bf(acc[4 * g]), f2bf(acc[4 * g + 1]), f2bf(acc[4 * g + 2]), f2bf(acc[4 * g + 3])};
+          const u16x4 o = {f2h(acc[4 * g]), f2h(acc[4 * g + 1]), f2h(acc[4 * g + 2]), f2h(acc[4 * g + 3])};
           *(u16x4*)(orow + 8 * g) = o;
         }
       } else if (valid) {
@@ -307,9 +307,9 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       const float oz = R[2] * x + R[5] * y + R[8] * z;
       const int HP = H * 12;
       const float on = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
-      if (a.out_bf16) {
-        bf16_t* oo = a.out_bf16 + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
-        oo[0] = f2bf(ox); oo[HP] = f2bf(oy); oo[2 * HP] = f2bf(oz); oo[3 * HP] = f2bf(on);
+      if (a.out_h16) {
+        half_t* oo = a.out_h16 + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
+        oo[0] = f2h(ox); oo[HP] = f2h(oy); oo[2 * HP] = f2h(oz); oo[3 * HP] = f2h(on);
       } else {
         float* oo = a.out + (rb + iq) * a.out_ld + a.pt_off + h * 12 + pt;
         oo[0] = ox; oo[HP] = oy; oo[2 * HP] = oz;
@@ -330,7 +330,7 @@ int fd_attention3(const Attn3Args& a, hipStream_t st) {
   (void)Np;
   if (smem > 64 * 1024) return FDIPT_ESIZE;  // 1 KB + 12 KB + 64 B per key: 45 KB at N = 512
   const int per = (a.B * a.H + 7) / 8;  // see the block mapping in the kernel
-  if (a.N <= 3 * 4 * 32 && !getenv("FDIPT_A3_LB2")) hipLaunchKernelGGL((ipa_attn3_kernel<3, 3, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem + 16384, st, a);
+  if (a.N <= 3 * 4 * 32 && !FD_DEV_ENV("FDIPT_A3_LB2")) hipLaunchKernelGGL((ipa_attn3_kernel<3, 3, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem + 16384, st, a);
   else if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
   else hipLaunchKernelGGL((ipa_attn3_kernel<4, 1, true>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
   FD_CHECK_LAUNCH();

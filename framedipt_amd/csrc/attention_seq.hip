@@ -32,7 +32,7 @@ __host__ __device__ __forceinline__ int sa_perm16(int pos) {  // involution
 
 __global__ void seq_images_kernel(int B, int N, int Np, int H, const float* __restrict__ qkv, int ld, float qscale,
                                   const float* __restrict__ res_mask,
-                                  bf16_t* __restrict__ Qi, bf16_t* __restrict__ Ki, bf16_t* __restrict__ Vi) {
+                                  half_t* __restrict__ Qi, half_t* __restrict__ Ki, half_t* __restrict__ Vi) {
   const int nt = Np >> 5, dm = H * SA_HD;
   const long nqk = (long)B * H * nt * SA_KS * 64, nv = (long)B * H * SA_DT * (2 * nt) * 64;
   for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < 2 * nqk + nv; u += (long)gridDim.x * blockDim.x) {
@@ -52,12 +52,12 @@ __global__ void seq_images_kernel(int B, int N, int Np, int H, const float* __re
           const float* src = qkv + (b * N + row) * ld + (isk ? dm : 0) + h * SA_HD + c0;
           const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + 4);
           const float sc = isk ? 1.f : qscale;
-          o = u16x8{f2bf(x0[0] * sc), f2bf(x0[1] * sc), f2bf(x0[2] * sc), f2bf(x0[3] * sc),
-                    f2bf(x1[0] * sc), f2bf(x1[1] * sc), f2bf(x1[2] * sc), f2bf(x1[3] * sc)};
+          o = u16x8{f2h(x0[0] * sc), f2h(x0[1] * sc), f2h(x0[2] * sc), f2h(x0[3] * sc),
+                    f2h(x1[0] * sc), f2h(x1[1] * sc), f2h(x1[2] * sc), f2h(x1[3] * sc)};
         }
       } else if (c0 == SA_HD) {  // mask channel
-        if (!isk) o[0] = f2bf(1.0f);
-        else if (row >= N || res_mask[b * N + row] == 0.f) o[0] = f2bf(-1e30f);
+        if (!isk) o[0] = f2h(1.0f);
+        else if (row >= N || res_mask[b * N + row] == 0.f) o[0] = f2h(FD_H_NEG_BIG);
       }
       *(u16x8*)((isk ? Ki : Qi) + v * 8) = o;
     } else {
@@ -73,7 +73,7 @@ __global__ void seq_images_kernel(int B, int N, int Np, int H, const float* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int pos = 16 * s + 8 * (lane >> 5) + e, key = (pos & ~15) + sa_perm16(pos & 15);
-          if (key < N) o[e] = f2bf(qkv[(b * N + key) * ld + 2 * dm + h * SA_HD + d]);
+          if (key < N) o[e] = f2h(qkv[(b * N + key) * ld + 2 * dm + h * SA_HD + d]);
         }
       }
       *(u16x8*)(Vi + v * 8) = o;
@@ -86,16 +86,16 @@ __global__ void seq_images_kernel(int B, int N, int Np, int H, const float* __re
 // channels 81..95), Q's mask channel = 1, K's mask channel = -1e30 for masked or padded keys.  Once per forward.
 // The other once-per-forward fills of the trunk ride on this launch (SeqInitExtra): a plain zero fill (attention3's value-point
 // image) and the padded keys [N, Np) of attention3's Kb / Vt images (layouts: gemm.hip, kv_zero_pad_kernel).
-__global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float* __restrict__ res_mask, bf16_t* __restrict__ Qi,
-                                       bf16_t* __restrict__ Ki, bf16_t* __restrict__ Vi, SeqInitExtra x) {
+__global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float* __restrict__ res_mask, half_t* __restrict__ Qi,
+                                       half_t* __restrict__ Ki, half_t* __restrict__ Vi, SeqInitExtra x) {
   const long gtid = blockIdx.x * (long)blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
   for (long i = gtid; i < x.fill_n16; i += gsz) ((uint4*)x.fill)[i] = make_uint4(0, 0, 0, 0);
   if (x.Kb) {
     const int pad = Np - N, ntl = Np >> 5, cg = x.C >> 3;
     const long n = x.BH * pad * cg;
     const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    bf16_t* Kb = (bf16_t*)x.Kb;
-    bf16_t* Vt = (bf16_t*)x.Vt;
+    half_t* Kb = (half_t*)x.Kb;
+    half_t* Vt = (half_t*)x.Vt;
     for (long i = gtid; i < n; i += gsz) {
       const int g = (int)(i % cg);
       const long r2 = i / cg;
@@ -120,8 +120,8 @@ __global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float*
       const long b = (r2 / nt) / H;
       const int row = 32 * t + (lane & 31);
       if (s == SA_KS - 1 && (lane >> 5) == 0) {  // channels 80..87: the mask channel is the first of them
-        if (!isk) o[0] = f2bf(1.0f);
-        else if (row >= N || res_mask[b * N + row] == 0.f) o[0] = f2bf(-1e30f);
+        if (!isk) o[0] = f2h(1.0f);
+        else if (row >= N || res_mask[b * N + row] == 0.f) o[0] = f2h(FD_H_NEG_BIG);
       }
       *(u16x8*)((isk ? Ki : Qi) + v * 8) = o;
     } else {
@@ -138,11 +138,11 @@ __global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float*
 #define SQ_K 320
 #define SQ_KS (SQ_K / 16)
 #define SQ_XROW (SQ_K * 2 + 16)
-typedef __bf16 sa_bf16x4 __attribute__((ext_vector_type(4)));
+typedef fd_h sa_hx4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, int Np, int H, const float* __restrict__ x, int ld_x,
                                                                 const char* __restrict__ wimg, const float* __restrict__ bias,
-                                                                float qscale, bf16_t* __restrict__ Qi, bf16_t* __restrict__ Ki,
-                                                                bf16_t* __restrict__ Vi) {
+                                                                float qscale, half_t* __restrict__ Qi, half_t* __restrict__ Ki,
+                                                                half_t* __restrict__ Vi) {
   __shared__ __attribute__((aligned(16))) char xs[32 * SQ_XROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   // 1-D grid, id = (x / 8) * 24 + y * 8 + (x % 8): the three column parts of a row block run on the row block's XCD (x % 8, the
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
   const int bx = (blockIdx.x / 24) * 8 + (blockIdx.x & 7), by = (blockIdx.x % 24) >> 3;
   const int M = B * N, row0 = bx * 32, nt = Np >> 5, dm = H * SA_HD;
   if (row0 >= M) return;
-  bf16x8 Wf[2][SQ_KS];
+  hx8 Wf[2][SQ_KS];
   auto w_load = [&](auto BUF, int T) {
     constexpr int bf = decltype(BUF)::value;
 #pragma unroll
-    for (int s = 0; s < SQ_KS; ++s) Wf[bf][s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(wimg + ((size_t)(T * SQ_KS + s) * 64 + lane) * 16));
+    for (int s = 0; s < SQ_KS; ++s) Wf[bf][s] = __builtin_bit_cast(hx8, *(const u16x8*)(wimg + ((size_t)(T * SQ_KS + s) * 64 + lane) * 16));
   };
   w_load(std::integral_constant<int, 0>{}, by * (SQ_K / 32) + wave);
   {
@@ -168,16 +168,16 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
-      sa_bf16x4 pk;
+      sa_hx4 pk;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)xv[k][q];
-      *(sa_bf16x4*)(xs + r * SQ_XROW + 8 * c4) = pk;
+      for (int q = 0; q < 4; ++q) pk[q] = (fd_h)xv[k][q];
+      *(sa_hx4*)(xs + r * SQ_XROW + 8 * c4) = pk;
     }
   }
   __syncthreads();
-  bf16x8 X[SQ_KS];
+  hx8 X[SQ_KS];
 #pragma unroll
-  for (int s = 0; s < SQ_KS; ++s) X[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(xs + li * SQ_XROW + 32 * s + 16 * hi));
+  for (int s = 0; s < SQ_KS; ++s) X[s] = __builtin_bit_cast(hx8, *(const u16x8*)(xs + li * SQ_XROW + 32 * s + 16 * hi));
   // this lane's row (transposed tiles) -> sample / key
   const int m = row0 + li, mb = m < M ? m / N : 0, mr = m - mb * N;
   // by = 0 / 1 / 2 takes the Q / K / V third of the 30 output tiles (3x the blocks: the kernel is latency-bound)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (T < 2 * SQ_K / 32) {  // Q or K: D^T[feature, row]
 #pragma unroll
-      for (int s = 0; s < SQ_KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], acc, 0, 0, 0);
+      for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(Wf[u & 1][s], X[s], acc);
       if (m < M) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -217,17 +217,17 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
           const int c = isk ? f - SQ_K : f, h = c / SA_HD, cc = c - h * SA_HD;
           const f32x4 bv = bq[u][g];
           const float sc = isk ? 1.f : qscale;
-          sa_bf16x4 o;
+          sa_hx4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (__bf16)((acc[4 * g + q] + bv[q]) * sc);
-          bf16_t* dst = (isk ? Ki : Qi) +
+          for (int q = 0; q < 4; ++q) o[q] = (fd_h)((acc[4 * g + q] + bv[q]) * sc);
+          half_t* dst = (isk ? Ki : Qi) +
                         ((((((long)mb * H + h) * nt + (mr >> 5)) * SA_KS + (cc >> 4)) * 64 + ((cc >> 3) & 1) * 32 + (mr & 31)) << 3) + (cc & 7);
-          *(sa_bf16x4*)dst = o;
+          *(sa_hx4*)dst = o;
         }
       }
     } else {  // V: D[row, feature], lane = feature
 #pragma unroll
-      for (int s = 0; s < SQ_KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[s], Wf[u & 1][s], acc, 0, 0, 0);
+      for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(X[s], Wf[u & 1][s], acc);
       const int f = 32 * T + li, c = f - 2 * SQ_K, h = c / SA_HD, d = c - h * SA_HD;
       const float bv = bq[u][0][0];
 #pragma unroll
@@ -236,11 +236,11 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
         if (m0 < M) {
           const int b0 = m0 / N, key = m0 - b0 * N;
           const int pp = (key & ~15) + sa_perm16(key & 15);
-          sa_bf16x4 o;
+          sa_hx4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (__bf16)(acc[4 * g + q] + bv);
-          bf16_t* dst = Vi + ((((((long)b0 * H + h) * SA_DT + (d >> 5)) * (2 * nt) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (d & 31)) << 3) + (pp & 7);
-          *(sa_bf16x4*)dst = o;
+          for (int q = 0; q < 4; ++q) o[q] = (fd_h)(acc[4 * g + q] + bv);
+          half_t* dst = Vi + ((((((long)b0 * H + h) * SA_DT + (d >> 5)) * (2 * nt) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (d & 31)) << 3) + (pp & 7);
+          *(sa_hx4*)dst = o;
         }
       }
     }
@@ -248,18 +248,18 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
   (void)dm;
 }
 
-__device__ __forceinline__ bf16x8 sa_ld(const bf16_t* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
-__device__ __forceinline__ bf16x8 sa_pack8(const float* v) {
-  bf16x8 o;
+__device__ __forceinline__ hx8 sa_ld(const half_t* p) { return __builtin_bit_cast(hx8, *(const u16x8*)p); }
+__device__ __forceinline__ hx8 sa_pack8(const float* v) {
+  hx8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+  for (int e = 0; e < 8; ++e) o[e] = (fd_h)v[e];
   return o;
 }
 
 // SA_NTW: key tiles per wave (N <= 128 SA_NTW); with 3 the kernel fits 256 registers and two blocks share a CU (LB = 2)
 template <int SA_NTW, int LB>
-__global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, int Np, int H, const bf16_t* __restrict__ Qi,
-                                                                 const bf16_t* __restrict__ Ki, const bf16_t* __restrict__ Vi,
+__global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, int Np, int H, const half_t* __restrict__ Qi,
+                                                                 const half_t* __restrict__ Ki, const half_t* __restrict__ Vi,
                                                                  float* __restrict__ out, int out_ld, L2Warm warm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nt = Np >> 5, ks = 2 * nt;
@@ -282,17 +282,17 @@ __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, 
   const long bh = bhq, rb = (long)b * N;
   const int i = 32 * qt + li;
   // ---- every global operand of this wave, requested up front
-  bf16x8 Va[8 * SA_NTW];
+  hx8 Va[8 * SA_NTW];
   if (wave < SA_DT) {
-    const bf16_t* vr = Vi + (((bh * SA_DT + wave) * ks) * 64 + lane) * 8;
+    const half_t* vr = Vi + (((bh * SA_DT + wave) * ks) * 64 + lane) * 8;
 #pragma unroll
     for (int s = 0; s < 8 * SA_NTW; ++s)
       if (s < ks) Va[s] = sa_ld(vr + s * 512);
   }
-  bf16x8 Qf[SA_KS];
+  hx8 Qf[SA_KS];
 #pragma unroll
   for (int s = 0; s < SA_KS; ++s) Qf[s] = sa_ld(Qi + (((bh * nt + qt) * SA_KS + s) * 64 + lane) * 8);
-  bf16x8 Kf[SA_NTW][SA_KS];
+  hx8 Kf[SA_NTW][SA_KS];
 #pragma unroll
   for (int u = 0; u < SA_NTW; ++u) {
     const int t = wave + 4 * u;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < SA_KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kf[u][s], Qf[s], acc, 0, 0, 0);
+      for (int s = 0; s < SA_KS; ++s) acc = fd_mfma32(Kf[u][s], Qf[s], acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[r]);
       S[u] = acc;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 8 * SA_NTW; ++s)
-      if (s < ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Va[s], __builtin_bit_cast(bf16x8, Pfs[s * 64 + lane]), acc, 0, 0, 0);
+      if (s < ks) acc = fd_mfma32(Va[s], __builtin_bit_cast(hx8, Pfs[s * 64 + lane]), acc);
     if (i < N) {
       float* orow = out + (rb + i) * out_ld + (long)h * SA_HD + 32 * wave + 4 * hi;
 #pragma unroll
@@ -380,9 +380,9 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
                      float* out, int out_ld, hipStream_t st) {
   if (!fd_seq_attention_supported(N, H, SA_HD) || (ld & 3) || (out_ld & 3)) return FDIPT_EINVAL;
   const int Np = (N + 31) / 32 * 32, nt = Np / 32;
-  bf16_t* Qi = (bf16_t*)images;
-  bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
-  bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
+  half_t* Qi = (half_t*)images;
+  half_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  half_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const long units = 2L * B * H * nt * SA_KS * 64 + (long)B * H * SA_DT * 2 * nt * 64;
   hipLaunchKernelGGL(seq_images_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, qkv, ld, scale,
                      res_mask, Qi, Ki, Vi);
@@ -400,9 +400,9 @@ int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images,
   if (x.Kb && (((N + 31) / 32 * 32) == N || (x.C & 31))) return FDIPT_EINVAL;
   if (!fd_seq_attention_supported(N, H, SA_HD)) return FDIPT_EINVAL;
   const int Np = (N + 31) / 32 * 32, nt = Np / 32;
-  bf16_t* Qi = (bf16_t*)images;
-  bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
-  bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
+  half_t* Qi = (half_t*)images;
+  half_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  half_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const long units = 2L * B * H * nt * SA_KS * 64 + (long)B * H * SA_DT * 2 * nt * 64;
   hipLaunchKernelGGL(seq_images_init_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, res_mask, Qi, Ki, Vi, x);
   FD_CHECK_LAUNCH();
@@ -413,9 +413,9 @@ int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, 
                hipStream_t st) {
   if (!fd_seq_qkv_supported(N, H, SQ_K) || (ld_x & 3)) return FDIPT_EINVAL;
   const int Np = (N + 31) / 32 * 32;
-  bf16_t* Qi = (bf16_t*)images;
-  bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
-  bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
+  half_t* Qi = (half_t*)images;
+  half_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  half_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   hipLaunchKernelGGL(seq_qkv_kernel, dim3(24 * cdiv(cdiv(B * N, 32), 8)), dim3(FD_THREADS), 0, st, B, N, Np, H, x, ld_x, (const char*)wimg, bias, scale,
                      Qi, Ki, Vi);
   FD_CHECK_LAUNCH();
@@ -425,9 +425,9 @@ int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, in
   const L2Warm wm = warm ? *warm : L2Warm{};
   if (!fd_seq_attention_supported(N, H, SA_HD) || (out_ld & 3)) return FDIPT_EINVAL;
   const int Np = (N + 31) / 32 * 32, nt = Np / 32;
-  const bf16_t* Qi = (const bf16_t*)images;
-  const bf16_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
-  const bf16_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
+  const half_t* Qi = (const half_t*)images;
+  const half_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
+  const half_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
   if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);

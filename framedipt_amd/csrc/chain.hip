@@ -21,7 +21,7 @@ __host__ __device__ __forceinline__ int ch_perm16(int pos) { return 4 * (pos >> 
 // img[((T*KS + s)*64 + lane)*8 + e] = W[32T + (lane&31)][k], k = 16s + 8(lane>>5) + e  (natural)  or
 //                                                             16s + perm16(8(lane>>5) + e) (permuted: layers >= 2)
 __global__ void chain_image_kernel(const float* __restrict__ w, int N, int K, int ldw, int permuted, int NT, int KS, float scale,
-                                   bf16_t* __restrict__ img) {
+                                   half_t* __restrict__ img) {
   const long n = (long)NT * KS * 64 * 8;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -29,13 +29,13 @@ __global__ void chain_image_kernel(const float* __restrict__ w, int N, int K, in
     const int s = (int)(ts % KS), T = (int)(ts / KS);
     const int row = 32 * T + (lane & 31), pos = 8 * (lane >> 5) + e;
     const int k = 16 * s + (permuted ? ch_perm16(pos) : pos);
-    img[i] = (row < N && k < K) ? f2bf(w[(long)row * ldw + k] * scale) : (bf16_t)0;
+    img[i] = (row < N && k < K) ? f2h(w[(long)row * ldw + k] * scale) : (half_t)0;
   }
 }
 size_t fd_chain_image_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 1024; }
 int fd_chain_build_image_scaled(const float* w, int N, int K, int ldw, int permuted, float scale, void* img, hipStream_t st) {
   const int NT = (N + 31) / 32, KS = (K + 15) / 16;
-  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, permuted, NT, KS, scale, (bf16_t*)img);
+  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, permuted, NT, KS, scale, (half_t*)img);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -44,16 +44,16 @@ int fd_chain_build_image(const float* w, int N, int K, int ldw, int permuted, vo
 }
 
 // ------------------------------------------------------------------ device pieces
-__device__ __forceinline__ bf16x8 ch_pack8(const float* v) {
-  bf16x8 o;
+__device__ __forceinline__ hx8 ch_pack8(const float* v) {
+  hx8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+  for (int e = 0; e < 8; ++e) o[e] = (fd_h)v[e];
   return o;
 }
 #ifndef CH_ABL
 #define CH_ABL 0  // timing ablations for tools/micro/chain_bench.hip (results become wrong); always 0 in the library
 #endif
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef fd_h hx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void ch_lds_t;
 typedef __attribute__((address_space(1))) const void ch_gl_t;
 
@@ -87,24 +87,24 @@ template <int KS, bool HASB>
 #ifndef CH_DEPTH
 #define CH_DEPTH 4
 #endif
-__device__ __forceinline__ void ch_pair(f32x16& accA, f32x16& accB, const char* wp, const bf16x8* Bin, int lane) {
+__device__ __forceinline__ void ch_pair(f32x16& accA, f32x16& accB, const char* wp, const hx8* Bin, int lane) {
   constexpr int DEPTH = CH_DEPTH;
   const char* pa = wp + lane * 16;
   const char* pb = pa + (HASB ? KS * 1024 : 0);
-  bf16x8 ringA[DEPTH], ringB[DEPTH];
+  hx8 ringA[DEPTH], ringB[DEPTH];
 #pragma unroll
   for (int s = 0; s < DEPTH - 1; ++s) {
-    ringA[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(pa + s * 1024));
-    if (HASB) ringB[s] = __builtin_bit_cast(bf16x8, *(const u16x8*)(pb + s * 1024));
+    ringA[s] = __builtin_bit_cast(hx8, *(const u16x8*)(pa + s * 1024));
+    if (HASB) ringB[s] = __builtin_bit_cast(hx8, *(const u16x8*)(pb + s * 1024));
   }
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (s + DEPTH - 1 < KS) {
-      ringA[(s + DEPTH - 1) % DEPTH] = __builtin_bit_cast(bf16x8, *(const u16x8*)(pa + (s + DEPTH - 1) * 1024));
-      if (HASB) ringB[(s + DEPTH - 1) % DEPTH] = __builtin_bit_cast(bf16x8, *(const u16x8*)(pb + (s + DEPTH - 1) * 1024));
+      ringA[(s + DEPTH - 1) % DEPTH] = __builtin_bit_cast(hx8, *(const u16x8*)(pa + (s + DEPTH - 1) * 1024));
+      if (HASB) ringB[(s + DEPTH - 1) % DEPTH] = __builtin_bit_cast(hx8, *(const u16x8*)(pb + (s + DEPTH - 1) * 1024));
     }
-    if (!(CH_ABL & 8)) accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ringA[s % DEPTH], Bin[s], accA, 0, 0, 0);
-    if (HASB && !(CH_ABL & 8)) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ringB[s % DEPTH], Bin[s], accB, 0, 0, 0);
+    if (!(CH_ABL & 8)) accA = fd_mfma32(ringA[s % DEPTH], Bin[s], accA);
+    if (HASB && !(CH_ABL & 8)) accB = fd_mfma32(ringB[s % DEPTH], Bin[s], accB);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
     c_pre[tid] = a.rowmask_pre ? a.rowmask_pre[gr] : 1.f;
     c_post[tid] = a.rowmask_post ? a.rowmask_post[gr] : 1.f;
   }
-  bf16x8 X[KS0];
+  hx8 X[KS0];
   {
     constexpr int NCH = (K0 + 63) / 64, GRP = 3;  // 64-column chunks, loaded GRP at a time (register pressure)
     ch_static_for<0, (NCH + GRP - 1) / GRP>([&](auto G) {
@@ -222,15 +222,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
           const int r = 4 * it + sr;
-          bf16x4 pk;
+          hx4 pk;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) pk[q] = (__bf16)xin[c - c0][it][q];
-          *(bf16x4*)(stage + r * 128 + (((sc >> 1) ^ (r & 7)) << 4) + 8 * (sc & 1)) = pk;
+          for (int q = 0; q < 4; ++q) pk[q] = (fd_h)xin[c - c0][it][q];
+          *(hx4*)(stage + r * 128 + (((sc >> 1) ^ (r & 7)) << 4) + 8 * (sc & 1)) = pk;
         }
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp)
           if (4 * c + sp < KS0)
-            X[4 * c + sp] = __builtin_bit_cast(bf16x8, *(const u16x8*)(stage + li * 128 + (((2 * sp + hi) ^ (li & 7)) << 4)));
+            X[4 * c + sp] = __builtin_bit_cast(hx8, *(const u16x8*)(stage + li * 128 + (((2 * sp + hi) ^ (li & 7)) << 4)));
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
   if constexpr (NSTEP == 1) warm_tok = fd_l2_warm(a.warm, blockIdx.x * gridDim.y + blockIdx.y, gridDim.x * gridDim.y, tid, FD_THREADS);
   const float pre = c_pre[wave * 32 + li];
 
-  bf16x8 H1[NT1 > 0 ? 2 * NT1 : 1], H2[NT2 > 0 ? 2 * NT2 : 1];
+  hx8 H1[NT1 > 0 ? 2 * NT1 : 1], H2[NT2 > 0 ? 2 * NT2 : 1];
   float S1[8];  // LayerNorm: this lane's partial row sums (rows 4 it + sr)
 #pragma unroll
   for (int it = 0; it < 8; ++it) S1[it] = 0.f;
@@ -281,13 +281,13 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
-    const bf16x8* Bin = l == 0 ? X : (l == 1 ? H1 : H2);
+    const hx8* Bin = l == 0 ? X : (l == 1 ? H1 : H2);
     ch_pair<KS, tiles == 2>(accA, accB, wbuf + (i % S::NBUF) * PAIRB, Bin, lane);
     // chunk i+1 has landed everywhere and slot i % NBUF is free again after this barrier; chunk i+2 stays in flight
     if constexpr (i + 1 < NSTEP) ch_wait_barrier<(i + 2 < NSTEP ? S::ninstr(i + 2) : 0)>();
     if constexpr (!LAST) {  // hidden layer: + bias, ReLU, C/D fragment -> two B fragments of the next layer
       const float* cb = l == 0 ? c_b0 : c_b1;
-      bf16x8* Hn = l == 0 ? H1 : H2;
+      hx8* Hn = l == 0 ? H1 : H2;
       constexpr bool RELU = (FLAGS >> l) & 1;
 #pragma unroll
       for (int u = 0; u < tiles; ++u) {
@@ -335,11 +335,11 @@ __global__ __launch_bounds__(FD_THREADS, 1) void chain_kernel(ChainArgs a) {
         }
         if ((!(CH_ABL & 1) || v[0] == 1234.5f) && rok[it] && (tiles == 2 || sc < 8)) {
           *(f32x4*)(a.out + ooff[it] + 32 * T0) = v;
-          if (!LN && a.out_bf16) {  // optional bf16 copy of the rows (row stride NOUT): consumed by LDS-DMA in edge_transition3
-            bf16x4 hb;
+          if (!LN && a.out_h16) {  // optional bf16 copy of the rows (row stride NOUT): consumed by LDS-DMA in edge_transition3
+            hx4 hb;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hb[q] = (__bf16)v[q];
-            *(bf16x4*)(a.out_bf16 + (long)(wrow0 + 4 * it + sr) * NOUT + 4 * sc + 32 * T0) = hb;
+            for (int q = 0; q < 4; ++q) hb[q] = (fd_h)v[q];
+            *(hx4*)(a.out_h16 + (long)(wrow0 + 4 * it + sr) * NOUT + 4 * sc + 32 * T0) = hb;
           }
         }
       }

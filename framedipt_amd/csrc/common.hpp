@@ -2,9 +2,9 @@
 //
 // Everything matmul-shaped in the library goes through one MFMA shape, 32x32 per wave:
 //   fp32 mode : v_mfma_f32_32x32x2_f32   (exact fp32 FMA chain, 157 TF/s peak)
-//   bf16 mode : v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate, 2.5 PF/s peak)
+//   half mode : v_mfma_f32_32x32x16_f16  (fp16 operands - bf16 in a -DFDIPT_HALF_BF16 build - fp32 accumulate, 2.5 PF/s peak)
 // Fragment maps (MI355X guide, section 3):
-//   A operand, lane l : row i = l&31, k = (l>>5)*KL .. +KL   (KL = 1 for f32, 8 for bf16)
+//   A operand, lane l : row i = l&31, k = (l>>5)*KL .. +KL   (KL = 1 for f32, 8 for half)
 //   B operand, lane l : col j = l&31, same k range
 //   C/D,       lane l : col j = l&31, row i = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16)
 // A and B tiles live in LDS k-contiguous ([row][k]), so both fragments are one ds_read per step.
@@ -16,20 +16,56 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
-typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// ------------------------------------------------------------------ half-precision operand type of the throughput mode
+// One 16-bit operand type per build.  Default: IEEE fp16 (v_mfma_f32_32x32x16_f16 runs at the bf16 rate with three more
+// significant bits; every half-precision operand of this network is a post-LayerNorm / post-ReLU activation, a softmax
+// weight or a weight matrix, all far inside the fp16 range).  -DFDIPT_HALF_BF16 builds the bf16 variant for comparison.
+// `half_t` is the raw bit pattern (what buffers and LDS hold), `fd_h` the arithmetic type, `hx8` one MFMA fragment.
+typedef unsigned short half_t;
+#ifdef FDIPT_HALF_BF16
+typedef __bf16 fd_h;
+#define FDIPT_PREC_HALF FDIPT_PREC_BF16
+#define FD_H_ONE_BITS 0x3F80u   // 1.0
+#define FD_H_NEG_BIG (-1e30f)   // "minus infinity" that stays finite in the operand type (key-padding channel)
+#else
+typedef _Float16 fd_h;
+#define FDIPT_PREC_HALF FDIPT_PREC_F16
+#define FD_H_ONE_BITS 0x3C00u
+#define FD_H_NEG_BIG (-60000.f)
+#endif
+typedef __attribute__((ext_vector_type(8))) fd_h hx8;
+typedef __attribute__((ext_vector_type(4))) fd_h hx4;
+typedef __attribute__((ext_vector_type(2))) fd_h hx2;
+__device__ __forceinline__ f32x16 fd_mfma32(hx8 a, hx8 b, f32x16 c) {  // 32x32x16, 8 k-elements per lane
+#ifdef FDIPT_HALF_BF16
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 fd_mfma16(hx8 a, hx8 b, f32x4 c) {  // 16x16x32
+#ifdef FDIPT_HALF_BF16
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
 
 #define FD_WAVE 64
 #define FD_THREADS 256
 
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round to nearest even (v_cvt_f16_f32 / the bf16 conversion of gfx950)
+__device__ __forceinline__ half_t f2h(float f) { return __builtin_bit_cast(half_t, (fd_h)f); }
+__device__ __forceinline__ float h2f(half_t h) { return (float)__builtin_bit_cast(fd_h, h); }
+// two fp32 -> one word of two half values: a 2-vector conversion, which hipcc selects as ONE packed conversion
+// (element-wise conversions + bit casts become two conversions and a v_perm_b32)
+__device__ __forceinline__ unsigned fd_cvt_pk(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, hx2));
 }
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
 __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -46,18 +82,18 @@ struct PrecF32 {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_row[hi], b_row[hi], acc, 0, 0, 0);
   }
 };
-struct PrecBF16 {
-  typedef bf16_t T;
+struct PrecHalf {
+  typedef half_t T;
   static constexpr int BK = 32;
   static constexpr int PAD = 8;       // stride 40 elem = 80 B: 16-B aligned rows, conflict-free ds_read_b128
   static constexpr int KL = 8;
   static constexpr int KS = 16;
-  static __device__ __forceinline__ T from_f32(float x) { return f2bf(x); }
-  static __device__ __forceinline__ float to_f32(T x) { return bf2f(x); }
+  static __device__ __forceinline__ T from_f32(float x) { return f2h(x); }
+  static __device__ __forceinline__ float to_f32(T x) { return h2f(x); }
   static __device__ __forceinline__ void mma(f32x16& acc, const T* a_row, const T* b_row, int hi) {
-    bf16x8 a = __builtin_bit_cast(bf16x8, *(const u16x8*)(a_row + hi * 8));
-    bf16x8 b = __builtin_bit_cast(bf16x8, *(const u16x8*)(b_row + hi * 8));
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    hx8 a = __builtin_bit_cast(hx8, *(const u16x8*)(a_row + hi * 8));
+    hx8 b = __builtin_bit_cast(hx8, *(const u16x8*)(b_row + hi * 8));
+    acc = fd_mfma32(a, b, acc);
   }
 };
 
@@ -73,7 +109,7 @@ __device__ __forceinline__ void wave_mma(f32x16& acc, const typename P::T* a_row
 
 // ------------------------------------------------------------------ staging: global -> LDS tile [rows][BK+PAD]
 // src element (r, k) = src[(row0 + r) * ld + k0 + k]; rows >= nrows and k >= K are zero-filled.
-// SrcT = float (activations / fp32 weights) or bf16_t (prepared bf16 weights). ld % 4 == 0 (float) / % 8 == 0 (bf16).
+// SrcT = float (activations / fp32 weights) or half_t (prepared bf16 weights). ld % 4 == 0 (float) / % 8 == 0 (bf16).
 template <class P, class SrcT, int ROWS>
 __device__ __forceinline__ void stage_tile(typename P::T* dst, const SrcT* __restrict__ src, long ld, int row0,
                                            int nrows, int k0, int K, int tid) {
@@ -89,7 +125,7 @@ __device__ __forceinline__ void stage_tile(typename P::T* dst, const SrcT* __res
       if constexpr (sizeof(typename P::T) == 4) {
         d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = x[3];
       } else {
-        u16x4 h = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+        u16x4 h = {f2h(x[0]), f2h(x[1]), f2h(x[2]), f2h(x[3])};
         *(u16x4*)d = h;
       }
     }

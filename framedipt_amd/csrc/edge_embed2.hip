@@ -1,0 +1,308 @@
+// edge_embed2.hip — half-precision pair embedder (framedipt/model/score_network.py:98-105,184-197: the edge MLP of
+// Embedder.forward) for the reference widths, activations in REGISTERS.
+//
+//   * the first layer has no GEMM: cross-concat / relative-index / distogram features are per-residue or one-hot, so its
+//     pre-activation is four table rows summed (Pi[i] + Pj[j] + R[idx_i - idx_j] + D[bin(|ca_i - ca_j|)]), gathered as whole
+//     512 B rows through a wave-private LDS tile, the next tile's rows requested a tile ahead;
+//   * layers 2 / 3 are computed TRANSPOSED, D[out feature, pair] = W[out, k] * X^T[k, pair]: weights are the MFMA A operand
+//     from two LDS-resident 32 KB images (persistent block), activations the B operand in registers; the C/D fragment of a
+//     layer is the B fragment of the next one up to a fixed 16-wise permutation of k folded into the images;
+//   * LayerNorm + mask epilogue in registers; the same epilogue emits the first block's pair bias linear_b(z)/sqrt(3) from
+//     its output fragments (saves a pass over z).
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define ET2_CZ 128
+
+// logical (row, 16-byte chunk) -> byte offset inside a weight image (bank-conflict-free ds_read_b128)
+__host__ __device__ __forceinline__ int et2_off_wide(int row, int c, int row_bytes) {
+  return row * row_bytes + ((c ^ (row & 15)) << 4);
+}
+// position inside a 16-group of k  ->  feature offset inside the 16-group produced by the C/D fragment layout
+__host__ __device__ __forceinline__ int et2_perm16(int pos) {
+  const int hi = pos >> 3, e = pos & 7;
+  return 4 * hi + (e & 3) + 8 * (e >> 2);
+}
+// One 16 B-per-lane LDS-DMA (global_load_lds_dwordx4; LDS destination = wave-uniform `lds_dst` + lane * 16), written as
+// inline asm ON PURPOSE: hipcc's waitcnt pass treats the builtin as a FLAT access that is pending on both counters and
+// then forces EVERY later LDS wait to lgkmcnt(0) until the DMA has been waited for.  With the asm form the pass does not see
+// the DMA at all: every consumer of DMA'd data therefore sits behind an explicit et2_dma_wait() + barrier.
+__device__ __forceinline__ void et2_dma16(const void* gsrc, const char* lds_dst) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(gsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void et2_dma_wait() {  // every DMA (and ordinary vector-memory op) of this wave retired
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ hx8 lds_frag(const char* slab, int off) {
+  return __builtin_bit_cast(hx8, *(const u16x8*)(slab + off));
+}
+// acc += W_slab[32 x 16*KS] * B[16*KS x 32]: A fragments stream from LDS through a DEPTH-deep register ring so that
+// every ds_read_b128 is issued DEPTH MFMAs (= DEPTH*32 cycles) ahead of its consumer.
+template <int KS, int ROWB, int DEPTH = 8, int ABL = 0>
+__device__ __forceinline__ void mma_slab(f32x16& acc, const char* slab, int li, int hi, const hx8* Bf) {
+  hx8 ring[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) ring[s] = lds_frag(slab, et2_off_wide(li, 2 * s + hi, ROWB));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    acc = fd_mfma32(ring[s % DEPTH], Bf[s], acc);
+    if (s + DEPTH < KS) ring[s % DEPTH] = lds_frag(slab, et2_off_wide(li, 2 * (s + DEPTH) + hi, ROWB));
+    __builtin_amdgcn_sched_barrier(0);  // pin the MFMA / ds_read interleave (hipcc otherwise sinks the reads)
+  }
+}
+
+// ---- VALU-lean pieces for the embedder (its waves are issue-bound: ~1500 VALU instructions per 32-pair tile before) ----
+typedef float ee_f32x2 __attribute__((ext_vector_type(2)));
+typedef fd_h ee_hx2 __attribute__((ext_vector_type(2)));
+typedef unsigned ee_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ee_u32x4 __attribute__((ext_vector_type(4)));
+typedef short ee_s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned ee_cvt_pk(float lo, float hi) {  // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(ee_f32x2{lo, hi}, ee_hx2));
+}
+// relu + bf16 of an accumulator tile (bias already in it): conversion first, then max(x, 0) on the bf16 bit patterns as signed
+// 16-bit integers (negative values have the sign bit set): 8 + 8 instructions instead of 16 + 16 + 8
+__device__ __forceinline__ void ee_hand_off(const f32x16& acc, hx8& h0, hx8& h1) {
+  ee_u32x4 w0, w1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w0[k] = ee_cvt_pk(acc[2 * k], acc[2 * k + 1]);
+    w1[k] = ee_cvt_pk(acc[8 + 2 * k], acc[8 + 2 * k + 1]);
+  }
+  const ee_s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  h0 = __builtin_bit_cast(hx8, __builtin_elementwise_max(__builtin_bit_cast(ee_s16x8, w0), zero));
+  h1 = __builtin_bit_cast(hx8, __builtin_elementwise_max(__builtin_bit_cast(ee_s16x8, w1), zero));
+}
+// LayerNorm epilogue of the embedder in packed fp32 math (one pass: sum and sum of squares; the layer bias is already in Y):
+// same staging / stores / pair-bias emission as ln_epilogue_staged
+__device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamma_l, const float* beta_l, float em, int li, int hi,
+                                               int lane, char* stage, half_t* __restrict__ z_out, long p0, long n_pairs,
+                                               float* __restrict__ tr_row, bool valid, const char* wb_lds, const f32x4 bbv,
+                                               float* __restrict__ bias_out, int H, long bidx, int ii, int jj, int nt) {
+  ee_f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const ee_f32x2 y = {Y[t][r], Y[t][r + 1]};
+      u1 += y;
+      u2 = __builtin_elementwise_fma(y, y, u2);
+    }
+  float s1 = u1[0] + u1[1], s2 = u2[0] + u2[1];
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  const float mu = s1 * (1.0f / ET2_CZ);
+  const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / ET2_CZ) - mu * mu, 0.f) + 1e-5f);
+  const ee_f32x2 sa = {rstd, rstd}, sc = {-mu * rstd, -mu * rstd}, em2 = {em, em};
+  ee_u32x4 zB[8];  // bf16 z' as B fragments
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f0 = 32 * t + 8 * g + 4 * hi;
+      const f32x4 gm = *(const f32x4*)(gamma_l + f0), bt = *(const f32x4*)(beta_l + f0);
+      ee_f32x2 o0 = {Y[t][4 * g], Y[t][4 * g + 1]}, o1 = {Y[t][4 * g + 2], Y[t][4 * g + 3]};
+      o0 = __builtin_elementwise_fma(o0, sa, sc);
+      o1 = __builtin_elementwise_fma(o1, sa, sc);
+      o0 = __builtin_elementwise_fma(o0, ee_f32x2{gm[0], gm[1]}, ee_f32x2{bt[0], bt[1]}) * em2;
+      o1 = __builtin_elementwise_fma(o1, ee_f32x2{gm[2], gm[3]}, ee_f32x2{bt[2], bt[3]}) * em2;
+      const ee_u32x2 ow = {ee_cvt_pk(o0[0], o0[1]), ee_cvt_pk(o1[0], o1[1])};
+      // features f0..f0+3 = bytes 2 f0 .. 2 f0 + 7 of the pair's row: 16 B unit 4t + g, half hi; unit u of row r at u ^ (r & 15)
+      *(ee_u32x2*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = ow;
+      zB[2 * t + (g >> 1)][2 * (g & 1)] = ow[0];
+      zB[2 * t + (g >> 1)][2 * (g & 1) + 1] = ow[1];
+      if (tr_row && valid) *(f32x4*)(tr_row + f0) = f32x4{o0[0], o0[1], o1[0], o1[1]};
+    }
+  if (wb_lds) {
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      accb = fd_mfma32(lds_frag(wb_lds, s * 1024 + lane * 16), __builtin_bit_cast(hx8, zB[s]), accb);
+    if (valid) {
+      float* bo = bias_out + fd_bias_frag_off(bidx * H + 4 * hi, nt, ii, jj);  // 32 lanes = 32 consecutive keys: 128 B rows
+      const long hstride = (long)nt * nt * 1024;  // floats per (sample, head)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * hi + r < H) bo[r * hstride] = accb[r] + bbv[r];
+    }
+  }
+  const int sr = lane >> 4, sc16 = lane & 15;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = 4 * it + sr;
+    const u16x8 v = *(const u16x8*)(stage + r * 256 + ((sc16 ^ (r & 15)) << 4));
+    if (p0 + r < n_pairs) *(u16x8*)(z_out + (p0 + r) * ET2_CZ + 8 * sc16) = v;
+  }
+}
+
+// edge_embed2_kernel — bf16 pair branch of Embedder.forward (framedipt/model/score_network.py:98-105,173-196) in the
+// same register-resident style.  Layer 1 has no GEMM: the cross-concat / relative-index / distogram features are
+// one-hot or per-residue, so h1 = relu(Pi[i] + Pj[j] + R[idx_i - idx_j] + D[bin(|ca_i - ca_j|)]) is four table rows
+// summed directly in B-fragment layout.  Layers 2 and 3 (128x128 each, 64 KB bf16 together) stay RESIDENT in LDS for
+// the whole persistent block, so there is no per-tile barrier: waves loop over 32-pair tiles independently.
+#define EE2_IMG (128 * 128 * 2)  // 32 KB per layer
+
+__global__ void ee2_build_images_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
+                                        half_t* __restrict__ img) {
+  const int n_chunks = 2 * EE2_IMG / 16;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_chunks; g += gridDim.x * blockDim.x) {
+    const int layer = g / (EE2_IMG / 16), q = g % (EE2_IMG / 16);
+    const int row = q / 16, cp = q % 16, c = cp ^ (row & 15);  // row = out feature (slab = row/32), 256-byte rows
+    const float* src = layer == 0 ? w2 : w3;
+    for (int e = 0; e < 8; ++e) {
+      const int k = c * 8 + e;
+      const int col = layer == 0 ? k : (k & ~15) + et2_perm16(k & 15);
+      img[(long)g * 8 + e] = f2h(src[(long)row * 128 + col]);
+    }
+  }
+}
+int fd_ee2_build_images(const float* w2, const float* w3, void* img, hipStream_t st) {
+  hipLaunchKernelGGL(ee2_build_images_kernel, dim3(16), dim3(256), 0, st, w2, w3, (half_t*)img);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+size_t fd_ee2_image_bytes() { return 2 * EE2_IMG; }
+
+// 512-thread persistent blocks: 8 independent waves (two per SIMD) share the 64 KB weight images; every wave owns an
+// 8 KB LDS tile that transposes between "whole 512 B table rows per 32 lanes" (the global side) and MFMA fragments.
+#define EE2_THREADS 512
+#define EE2_MAXB 63     // distogram bins (edges in LDS)
+#define EE2_LDS (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + 8192 + 256)  // ... + linear_b image of the first block + distogram edges
+__global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img,
+                                                                     int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, li = lane & 31;
+  char* stage = smem + 2 * EE2_IMG + wave * 8192;
+  float* vec = (float*)(smem + 2 * EE2_IMG + 8 * 8192);  // [b2 | b3 | gamma | beta] x 128
+  char* wbl = (char*)(vec + 4 * ET2_CZ);                 // 8 KB fragment image of linear_b (optional)
+  float* edg = (float*)(wbl + 8192);                     // [num_bins + 1] distogram edges, the last one 1e8
+  if (tid <= a.num_bins) edg[tid] = tid < a.num_bins ? a.edges[tid] : 1e8f;
+  if (a.wb_img) et2_dma16((const char*)a.wb_img + tid * 16, wbl + (tid & ~63) * 16);
+  for (int u = 0; u < 2 * EE2_IMG / 16 / EE2_THREADS; ++u)
+    et2_dma16(img + (size_t)(u * EE2_THREADS + tid) * 16, smem + (size_t)(u * EE2_THREADS + (tid & ~63)) * 16);
+  if (tid < 4 * ET2_CZ) {
+    const int which = tid >> 7, c = tid & 127;
+    vec[tid] = which == 0 ? a.b2[c] : (which == 1 ? a.b3[c] : (which == 2 ? a.gamma[c] : a.beta[c]));
+  }
+  et2_dma_wait();
+  __syncthreads();
+  const int N = a.N;
+  const long n_pairs = (long)a.B * N * N;
+  const float* b2row = vec + 4 * hi;
+  const f32x4 bbv = a.wb_img ? f32x4{a.bb[4 * hi], a.bb[4 * hi + 1], a.bb[4 * hi + 2], a.bb[4 * hi + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+  // The per-pair inputs of the NEXT tile (sequence indices, self-conditioning CA) are requested at the top of a tile and turned
+  // into its table row ids (relative index, distogram bin) right after the current tile's gather, so that those two dependent
+  // memory round trips leave every tile's critical path at the price of two loop-carried registers; the distogram edges sit in
+  // LDS (a rolled loop over a.edges[] re-issues two dependent scalar loads per bin and tile).
+  struct PairIn { int si, sj; float ci[3], cj[3], mi, mj; };
+  auto request = [&](int tile) {
+    const long pr = (long)tile * 32 + li, pp = pr < n_pairs ? pr : n_pairs - 1;
+    const long bi = pp / N, bb = bi / N, bj = bb * N + (pp - bi * N);
+    PairIn r;
+    r.si = a.seq_idx[bi]; r.sj = a.seq_idx[bj];
+    r.mi = a.res_mask[bi]; r.mj = a.res_mask[bj];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r.ci[c] = a.sc_ca[bi * 3 + c]; r.cj[c] = a.sc_ca[bj * 3 + c]; }
+    return r;
+  };
+  auto row_ids = [&](int tile, const PairIn& r, int& rel, int& bin, float& msk) {
+    msk = r.mi * r.mj;
+    const long pr = (long)tile * 32 + li, pp = pr < n_pairs ? pr : n_pairs - 1;
+    const long bb = (pp / N) / N;
+    rel = (int)(bb * a.n_rel) + r.si - r.sj + a.rel_off;
+    const float dx = r.ci[0] - r.cj[0], dy = r.ci[1] - r.cj[1], dz = r.ci[2] - r.cj[2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    bin = a.num_bins;
+    for (int k = 0; k < a.num_bins; ++k)  // calc_distogram: strict inequalities, last upper edge 1e8 (edg[num_bins])
+      if (d > edg[k] && d < edg[k + 1]) bin = k;
+  };
+  const int tile_first = blockIdx.x * 8 + wave, tile_step = gridDim.x * 8;
+  int rel = 0, bin = 0;
+  float msk_n = 0.f;
+  if (tile_first < n_tiles) { const PairIn r0 = request(tile_first); row_ids(tile_first, r0, rel, bin, msk_n); }
+  for (int tile = tile_first; tile < n_tiles; tile += tile_step) {
+    const long p0 = (long)tile * 32;
+    const long p_raw = p0 + li;
+    const bool valid = p_raw < n_pairs;
+    const long p = valid ? p_raw : n_pairs - 1;
+    const long bi = p / N;
+    const int j = (int)(p - bi * N);
+    const long bb = bi / N;
+    const long bj = bb * N + j;
+    const int tile_n = tile + tile_step < n_tiles ? tile + tile_step : tile;
+    const PairIn raw = request(tile_n);
+    const float msk = msk_n;
+    // ---- layer 1 has no GEMM: h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]).  Two pairs per instruction: lanes 0..31 /
+    // 32..63 read one whole 512 B row each (the row ids of pair 2 it + hi come from the lane that owns it)
+    const int ibi = (int)bi, ibj = (int)bj;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int r = 2 * it + hi;
+      const int rbi = __shfl(ibi, r, 64), rbj = __shfl(ibj, r, 64), rrel = __shfl(rel, r, 64), rbin = __shfl(bin, r, 64);
+      const f32x4 x1 = *(const f32x4*)(a.pi + (long)rbi * ET2_CZ + 4 * li), x2 = *(const f32x4*)(a.pj + (long)rbj * ET2_CZ + 4 * li);
+      const f32x4 x3 = *(const f32x4*)(a.rtab + (long)rrel * ET2_CZ + 4 * li), x4 = *(const f32x4*)(a.dtab + (long)rbin * ET2_CZ + 4 * li);
+      // packed adds, conversion, then relu on the bf16 bit patterns (v_pk_max_i16)
+      const ee_f32x2 sA = (ee_f32x2{x1[0], x1[1]} + ee_f32x2{x2[0], x2[1]}) + (ee_f32x2{x3[0], x3[1]} + ee_f32x2{x4[0], x4[1]});
+      const ee_f32x2 sB = (ee_f32x2{x1[2], x1[3]} + ee_f32x2{x2[2], x2[3]}) + (ee_f32x2{x3[2], x3[3]} + ee_f32x2{x4[2], x4[3]});
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      const ee_u32x2 cw = {ee_cvt_pk(sA[0], sA[1]), ee_cvt_pk(sB[0], sB[1])};
+      const ee_u32x2 pk = __builtin_bit_cast(ee_u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, cw), s16x4{0, 0, 0, 0}));
+      // [32 pairs][256 B] tile, 16 B unit u of row r at u ^ (r & 15)
+      *(ee_u32x2*)(stage + r * 256 + (((li >> 1) ^ (r & 15)) << 4) + 8 * (li & 1)) = pk;
+    }
+    row_ids(tile_n, raw, rel, bin, msk_n);  // the next tile's row ids (this tile's were consumed by the gather above)
+    hx8 H1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) H1[s] = lds_frag(stage, li * 256 + (((2 * s + hi) ^ (li & 15)) << 4));
+    hx8 H2[8];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      f32x16 acc;  // starts as the layer bias (LDS reads straight into the accumulator: no VALU)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const f32x4*)(b2row + 32 * T + 8 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 * g + q] = bv[q];
+      }
+      mma_slab<8, 256>(acc, smem + T * 32 * 256, li, hi, H1);
+      ee_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
+    }
+    f32x16 Y[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // starts as the layer bias b3
+        const f32x4 bv = *(const f32x4*)(vec + ET2_CZ + 4 * hi + 32 * t + 8 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y[t][4 * g + q] = bv[q];
+      }
+      mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
+    }
+    ee_ln_epilogue(Y, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, msk, li, hi, lane,
+                   stage, (half_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid,
+                   a.wb_img ? wbl : nullptr, bbv, a.bias_out, a.H, bb, (int)(bi - bb * N), j, (N + 31) >> 5);
+  }
+}
+
+int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
+  const long n_pairs = (long)a.B * a.N * a.N;
+  const int n_tiles = cdiv(n_pairs, 32);
+  if (a.num_bins > EE2_MAXB) return FDIPT_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)edge_embed2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EE2_LDS) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  const int grid = n_tiles / 8 + 1 < 256 ? n_tiles / 8 + 1 : 256;
+  hipLaunchKernelGGL(edge_embed2_kernel, dim3(grid), dim3(EE2_THREADS), EE2_LDS, st, a, (const char*)img, n_tiles);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

@@ -38,7 +38,7 @@
 #define E3_LDS (2 * E3_CHUNK + 2 * E3_BROWS * E3_BROW_BYTES + 1536 + 1024 + 4096)  // ... + linear_b image of the next block
 
 typedef __attribute__((ext_vector_type(4))) float e3_f32x4;
-typedef __bf16 e3_bf16x4 __attribute__((ext_vector_type(4)));
+typedef fd_h e3_hx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e3_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e3_u32x2 __attribute__((ext_vector_type(2)));
 
@@ -51,7 +51,7 @@ __host__ __device__ __forceinline__ int e3_chain_feat(int pos) {
 // ------------------------------------------------------------------ prepare: weight stream image
 // w1 [384,384], w2 [384,384], wf [128,384] fp32 row-major (out, in); in = [z(0:128) | e_i(128:256) | e_j(256:384)]
 __global__ void et3_build_stream_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
-                                        const float* __restrict__ wf, bf16_t* __restrict__ stream) {
+                                        const float* __restrict__ wf, half_t* __restrict__ stream) {
   const int n_units = E3_STREAM_BYTES / 16;
   for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_units; g += gridDim.x * blockDim.x) {
     int frag = g >> 6;
@@ -61,7 +61,7 @@ __global__ void et3_build_stream_kernel(const float* __restrict__ w1, const floa
     if (frag < 24 * 8) { src = w1; n = 16 * (frag / 8) + m; s = frag % 8; mode = 0; }
     else if (frag < 24 * 8 + 24 * 12) { frag -= 24 * 8; src = w2; n = 16 * (frag / 12) + m; s = frag % 12; mode = 1; }
     else { frag -= 24 * 8 + 24 * 12; src = wf; n = 16 * (frag / 20) + m; s = frag % 20; mode = 2; }
-    bf16_t out[8];
+    half_t out[8];
     for (int e = 0; e < 8; ++e) {
       const int pos = 8 * q + e;
       int col;
@@ -72,13 +72,13 @@ __global__ void et3_build_stream_kernel(const float* __restrict__ w1, const floa
         const int sh = mode == 1 ? s : s - 8;
         col = 32 * sh + e3_chain_feat(pos);  // hidden feature index (w2: all 384 inputs are h1; wf: columns 0..383 are h2)
       }
-      out[e] = f2bf(src[(long)n * E3_H + col]);
+      out[e] = f2h(src[(long)n * E3_H + col]);
     }
     for (int e = 0; e < 8; ++e) stream[(long)g * 8 + e] = out[e];
   }
 }
 int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st) {
-  hipLaunchKernelGGL(et3_build_stream_kernel, dim3(160), dim3(256), 0, st, w1, w2, wf, (bf16_t*)stream);
+  hipLaunchKernelGGL(et3_build_stream_kernel, dim3(160), dim3(256), 0, st, w1, w2, wf, (half_t*)stream);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -86,16 +86,16 @@ size_t fd_et3_stream_bytes() { return E3_STREAM_BYTES; }
 
 // linear_b of the NEXT block's attention (ipa_pytorch.py:247,256-257) as 4 fragments [k-step][lane][8]: row = head (8 of 16
 // used), k in the hand-off order of the LayerNorm output tiles; `scale` = sqrt(1/3)
-__global__ void et3_bias_image_kernel(const float* __restrict__ wb, int H, float scale, bf16_t* __restrict__ img) {
+__global__ void et3_bias_image_kernel(const float* __restrict__ wb, int H, float scale, half_t* __restrict__ img) {
   for (int g = threadIdx.x; g < 4 * 64; g += blockDim.x) {
     const int s = g >> 6, lane = g & 63, m = lane & 15, q = lane >> 4;
     for (int e = 0; e < 8; ++e)
-      img[g * 8 + e] = m < H ? f2bf(wb[m * E3_CZ + 32 * s + e3_chain_feat(8 * q + e)] * scale) : (bf16_t)0;
+      img[g * 8 + e] = m < H ? f2h(wb[m * E3_CZ + 32 * s + e3_chain_feat(8 * q + e)] * scale) : (half_t)0;
   }
 }
 int fd_et3_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st) {
   if (H > 8) return FDIPT_ESIZE;
-  hipLaunchKernelGGL(et3_bias_image_kernel, dim3(1), dim3(256), 0, st, wb, H, scale, (bf16_t*)img);
+  hipLaunchKernelGGL(et3_bias_image_kernel, dim3(1), dim3(256), 0, st, wb, H, scale, (half_t*)img);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -112,11 +112,11 @@ __device__ __forceinline__ void e3_dma_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ bf16x8 e3_frag(const char* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
-__device__ __forceinline__ bf16x8 e3_pack8(const float* v) {
-  bf16x8 o;
+__device__ __forceinline__ hx8 e3_frag(const char* p) { return __builtin_bit_cast(hx8, *(const u16x8*)p); }
+__device__ __forceinline__ hx8 e3_pack8(const float* v) {
+  hx8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+  for (int e = 0; e < 8; ++e) o[e] = (fd_h)v[e];
   return o;
 }
 template <int BYTES>
@@ -129,11 +129,11 @@ __device__ __forceinline__ void e3_dma_chunk(const char* __restrict__ src, char*
 
 // two 16-feature tiles (A, B) against the same B fragments: fragments of the pair are [tile A: KS KB][tile B: KS KB] at `base`
 template <int KS>
-__device__ __forceinline__ void e3_pair(e3_f32x4& accA, e3_f32x4& accB, const char* base, int lane, const bf16x8* Bf) {
+__device__ __forceinline__ void e3_pair(e3_f32x4& accA, e3_f32x4& accB, const char* base, int lane, const hx8* Bf) {
   constexpr int DEPTH = 3;  // fragments are requested 2 k-steps (4 MFMAs of this wave) ahead of their use (4: slower, 5+: spills)
   const char* pa = base + lane * 16;
   const char* pb = pa + KS * 1024;
-  bf16x8 rA[DEPTH], rB[DEPTH];
+  hx8 rA[DEPTH], rB[DEPTH];
 #pragma unroll
   for (int s = 0; s < DEPTH - 1; ++s) {
     rA[s] = e3_frag(pa + s * 1024);
@@ -147,8 +147,8 @@ __device__ __forceinline__ void e3_pair(e3_f32x4& accA, e3_f32x4& accB, const ch
       rB[(s + DEPTH - 1) % DEPTH] = e3_frag(pb + (s + DEPTH - 1) * 1024);
     }
     if (!(E3_ABL & 2)) {
-      accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rA[s % DEPTH], Bf[s], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rB[s % DEPTH], Bf[s], accB, 0, 0, 0);
+      accA = fd_mfma16(rA[s % DEPTH], Bf[s], accA);
+      accB = fd_mfma16(rB[s % DEPTH], Bf[s], accB);
     } else {
       accA[0] += (float)rA[s % DEPTH][0];
       accB[0] += (float)rB[s % DEPTH][0];
@@ -200,7 +200,7 @@ __device__ __forceinline__ void e3_request(const ET2Args& a, int tile, int tid, 
     e3_dma16(a.z_in + (long)(pw + r) * E3_CZ + 8 * u, xst + k * 1024);
     int rbj = b0 * N + j0 + r;
     if (j0 + r >= N && !last_i) rbj -= N;   // wrap to (i + 1, j - N); past the sample's last row it is the next sample
-    e3_dma16(a.e_bf16 + (long)rbj * E3_CB + 8 * u, xst + 4096 + k * 1024);
+    e3_dma16(a.e_h16 + (long)rbj * E3_CB + 8 * u, xst + 4096 + k * 1024);
   }
   e3_dma_chunk<E3_CHUNK>(stream, smem, tid);
   {  // A1 | Af rows i_lo .. i_lo+3: 4 x 128 units of 16 B = one per thread
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
     asm volatile("" : "+v"(lane), "+v"(tid), "+v"(n), "+v"(q));
     char* xst = smem + E3_CHUNK + (tid >> 6) * 8192;
     // B fragments of x = [z | e_j]: k-step s (32 columns) = units 4 (s & 3) + q of the z / e row of pair n
-    bf16x8 X[8];
+    hx8 X[8];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       X[s] = e3_frag(xst + n * 256 + (((4 * s + q) ^ n) << 4));
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();  // every wave has its x fragments: chunk buffer 1 may receive the second chunk
 
-    bf16x8 H1[12], H2[12];
+    hx8 H1[12], H2[12];
     e3_f32x4 Y[8];
     size_t soff = 0;
     int buf = 0;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
     }
     FD_STAMP(3);
     // ================= final layer: 4 chunks x 1 tile pair, K = 640: B fragments = x (8) then h2 (12)
-    bf16x8 XF[20];
+    hx8 XF[20];
 #pragma unroll
     for (int s = 0; s < 8; ++s) XF[s] = X[s];
 #pragma unroll
@@ -372,20 +372,20 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
       s2 += __shfl_xor(s2, 32, 64);
       const float rstd = 1.0f / sqrtf(s2 * (1.0f / E3_CZ) + 1e-5f);
       e3_u32x4 zB[4];
-      bf16_t* zo = a.z_out + (long)tc.p * E3_CZ + 4 * q;
+      half_t* zo = a.z_out + (long)tc.p * E3_CZ + 4 * q;
       float* tr_row = a.trace ? a.trace + (long)tc.p * E3_CZ + 4 * q : nullptr;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const f32x4 gm = *(const f32x4*)(gml + 16 * t), bt = *(const f32x4*)(btl + 16 * t);
         float of[4];
-        e3_bf16x4 o;
+        e3_hx4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           of[r] = ((Y[t][r] - mu) * rstd * gm[r] + bt[r]) * em;
-          o[r] = (__bf16)of[r];
+          o[r] = (fd_h)of[r];
         }
         if (tc.valid) {
-          *(e3_bf16x4*)(zo + 16 * t) = o;
+          *(e3_hx4*)(zo + 16 * t) = o;
           if (tr_row) {
             f32x4 tv = {of[0], of[1], of[2], of[3]};
             *(f32x4*)(tr_row + 16 * t) = tv;
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(E3_THREADS, 1) void edge_transition3_kernel(ET2Args
         e3_f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e3_frag((const char*)vec + 2560 + s * 1024 + lane * 16),
-                                                         __builtin_bit_cast(bf16x8, zB[s]), accb, 0, 0, 0);
+          accb = fd_mfma16(e3_frag((const char*)vec + 2560 + s * 1024 + lane * 16),
+                                                         __builtin_bit_cast(hx8, zB[s]), accb);
         if (tc.valid && q < 2) {
           const int b_idx = tc.bi / N, ii = tc.bi - b_idx * N, jj = tc.bj - b_idx * N, nt = (N + 31) >> 5;
           float* bo = a.bias_out + fd_bias_frag_off((long)b_idx * a.H + 4 * q, nt, ii, jj);
@@ -428,7 +428,7 @@ int fd_edge_transition3_supported(int N) { return N >= 43 && N <= 2048; }  // 4 
 
 int fd_edge_transition3(const ET2Args& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
-  if (n_pairs >= (1L << 31) - 256 || !a.e_bf16) return FDIPT_EINVAL;  // 32-bit pair indices in the kernel
+  if (n_pairs >= (1L << 31) - 256 || !a.e_h16) return FDIPT_EINVAL;  // 32-bit pair indices in the kernel
   const int n_tiles = cdiv(n_pairs, 128);
   static bool attr_set = false;
   if (!attr_set) {

@@ -64,10 +64,9 @@ __device__ unsigned e4_prof[256 * 8];
   do {              \
   } while (0)
 #endif
-typedef __bf16 e4_bf16x4 __attribute__((ext_vector_type(4)));
+typedef fd_h e4_hx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short e4_s16x2 __attribute__((ext_vector_type(2)));
 
 // C/D register 8u + e of lane half `half` of a 32-feature tile holds feature (offset in the tile):
@@ -76,7 +75,7 @@ __host__ __device__ __forceinline__ int e4_chain_feat(int u, int half, int e) { 
 // ------------------------------------------------------------------ prepare: weight stream image
 // w1 [384,384], w2 [384,384], wf [128,384] fp32 row-major (out, in); in = [z(0:128) | e_i(128:256) | e_j(256:384)]
 __global__ void et4_build_stream_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
-                                        const float* __restrict__ wf, bf16_t* __restrict__ stream) {
+                                        const float* __restrict__ wf, half_t* __restrict__ stream) {
   const int n_units = E4_STREAM_BYTES / 16;
   for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_units; g += gridDim.x * blockDim.x) {
     int frag = g >> 6;
@@ -92,16 +91,16 @@ __global__ void et4_build_stream_kernel(const float* __restrict__ w1, const floa
       chained = s >= 8;
       if (chained) s -= 8;
     }
-    bf16_t out[8];
+    half_t out[8];
     for (int e = 0; e < 8; ++e) {
       const int col = chained ? 32 * (s >> 1) + e4_chain_feat(s & 1, half, e) : 16 * s + 8 * half + e;  // z columns are 0..127
-      out[e] = f2bf(src[(long)n * E4_H + col]);
+      out[e] = f2h(src[(long)n * E4_H + col]);
     }
     for (int e = 0; e < 8; ++e) stream[(long)g * 8 + e] = out[e];
   }
 }
 int fd_et4_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st) {
-  hipLaunchKernelGGL(et4_build_stream_kernel, dim3(128), dim3(256), 0, st, w1, w2, wf, (bf16_t*)stream);
+  hipLaunchKernelGGL(et4_build_stream_kernel, dim3(128), dim3(256), 0, st, w1, w2, wf, (half_t*)stream);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -109,16 +108,16 @@ size_t fd_et4_stream_bytes() { return E4_STREAM_BYTES; }
 
 // linear_b of the NEXT block's attention (ipa_pytorch.py:247,256-257) as 8 fragments [k-step][lane][8]: row = head (H of 32
 // used), k in the hand-off order of the LayerNorm output tiles; `scale` = sqrt(1/3)
-__global__ void et4_bias_image_kernel(const float* __restrict__ wb, int H, float scale, bf16_t* __restrict__ img) {
+__global__ void et4_bias_image_kernel(const float* __restrict__ wb, int H, float scale, half_t* __restrict__ img) {
   for (int g = threadIdx.x; g < 8 * 64; g += blockDim.x) {
     const int s = g >> 6, lane = g & 63, f = lane & 31, half = lane >> 5;
     for (int e = 0; e < 8; ++e)
-      img[g * 8 + e] = f < H ? f2bf(wb[f * E4_CZ + 32 * (s >> 1) + e4_chain_feat(s & 1, half, e)] * scale) : (bf16_t)0;
+      img[g * 8 + e] = f < H ? f2h(wb[f * E4_CZ + 32 * (s >> 1) + e4_chain_feat(s & 1, half, e)] * scale) : (half_t)0;
   }
 }
 int fd_et4_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st) {
   if (H > 8) return FDIPT_ESIZE;
-  hipLaunchKernelGGL(et4_bias_image_kernel, dim3(1), dim3(256), 0, st, wb, H, scale, (bf16_t*)img);
+  hipLaunchKernelGGL(et4_bias_image_kernel, dim3(1), dim3(256), 0, st, wb, H, scale, (half_t*)img);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -128,8 +127,8 @@ int fd_et4_build_bias_image(const float* wb, int H, float scale, void* img, hipS
 // a_img [ceil(B*N/8)][16 feature tiles][32 f][8]: element e = flattened residue row 8 rt + e (0 beyond B*N)
 // b_img [B][N/4][16][32 f][8]: element e < 4 = row j = 4 jt + e of sample b, e >= 4 = row 4 jt + e - 4 of sample b + 1
 //                             (for the rows of a patch that straddles two samples; 0 for the last sample)
-__global__ void et4_row_images_kernel(const float* __restrict__ rows, int B, int N, bf16_t* __restrict__ a_img,
-                                      bf16_t* __restrict__ b_img) {
+__global__ void et4_row_images_kernel(const float* __restrict__ rows, int B, int N, half_t* __restrict__ a_img,
+                                      half_t* __restrict__ b_img) {
   const int M = B * N, MT8 = (M + 7) >> 3, NJ4 = N >> 2;
   const long na = (long)MT8 * 512, nb = (long)B * NJ4 * 512;
   for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < na + nb; g += (long)gridDim.x * blockDim.x) {
@@ -145,7 +144,7 @@ __global__ void et4_row_images_kernel(const float* __restrict__ rows, int B, int
       bool ok;
       if (is_b) { const int bb = b + (e >> 2); ok = bb < B; r = (long)bb * N + 4 * jt + (e & 3); }
       else { r = 8 * t + e; ok = r < M; }
-      o[e] = ok ? f2bf(rows[r * 1024 + (is_b ? 512 : 0) + c]) : (bf16_t)0;
+      o[e] = ok ? f2h(rows[r * 1024 + (is_b ? 512 : 0) + c]) : (half_t)0;
     }
     *(u16x8*)((is_b ? b_img : a_img) + u * 8) = o;
   }
@@ -154,7 +153,7 @@ size_t fd_et4_a_image_bytes(int B, int N) { return (size_t)((B * N + 7) / 8) * 8
 size_t fd_et4_b_image_bytes(int B, int N) { return (size_t)B * (N / 4) * 8192; }
 int fd_et4_row_images(const float* rows, int B, int N, void* a_img, void* b_img, hipStream_t st) {
   const long units = ((long)(B * N + 7) / 8 + (long)B * (N / 4)) * 512;
-  hipLaunchKernelGGL(et4_row_images_kernel, dim3((unsigned)cdiv(units, 256)), dim3(256), 0, st, rows, B, N, (bf16_t*)a_img, (bf16_t*)b_img);
+  hipLaunchKernelGGL(et4_row_images_kernel, dim3((unsigned)cdiv(units, 256)), dim3(256), 0, st, rows, B, N, (half_t*)a_img, (half_t*)b_img);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -174,9 +173,9 @@ __device__ __forceinline__ void e4_dma_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ bf16x8 e4_frag(unsigned off) { return __builtin_bit_cast(bf16x8, *(e4_lds_u16x8)(unsigned long)off); }
+__device__ __forceinline__ hx8 e4_frag(unsigned off) { return __builtin_bit_cast(hx8, *(e4_lds_u16x8)(unsigned long)off); }
 __device__ __forceinline__ f32x4 e4_ldsf4(unsigned off) { return *(e4_lds_f32x4)(unsigned long)off; }
-__device__ __forceinline__ bf16x8 e4_gfrag(const char* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
+__device__ __forceinline__ hx8 e4_gfrag(const char* p) { return __builtin_bit_cast(hx8, *(const u16x8*)p); }
 template <int BYTES>
 __device__ __forceinline__ void e4_dma_chunk(const char* __restrict__ src, unsigned dst, int tid, int wave) {
   static_assert(BYTES % (E4_THREADS * 16) == 0, "whole DMA instructions");
@@ -184,37 +183,30 @@ __device__ __forceinline__ void e4_dma_chunk(const char* __restrict__ src, unsig
   for (int u = 0; u < BYTES / (E4_THREADS * 16); ++u)
     if (!(E4_ABL & 4)) e4_dma16(src + (size_t)(u * E4_THREADS + tid) * 16, dst + (unsigned)(u * E4_THREADS + wave * 64) * 16);  // (scalar destination)
 }
-__device__ __forceinline__ f32x16 e4_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+__device__ __forceinline__ f32x16 e4_mfma(hx8 a, hx8 b, f32x16 c) {
   if (E4_ABL & 2) { c[0] += (float)a[0]; return c; }
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-// two fp32 -> one word of two bf16 (round to nearest even): a 2-vector conversion, which hipcc selects as ONE
-// v_cvt_pk_bf16_f32 (element-wise conversions + bit casts become two conversions and a v_perm_b32).  Not inline asm: the
-// hazard recognizer does not see asm operands, and an MFMA result read too early is stale.
-typedef __bf16 e4_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned e4_cvt_pk(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, e4_bf16x2));
+  return fd_mfma32(a, b, c);
 }
 // relu + bf16: C/D of one tile -> the two B fragments it hands to the next layer.  ReLU runs after the conversion, on the
 // bf16 bit patterns as signed 16-bit integers (negative values have the sign bit set): one v_pk_max_i16 per two values.
-__device__ __forceinline__ void e4_hand_off(const f32x16& acc, bf16x8& h0, bf16x8& h1) {
+__device__ __forceinline__ void e4_hand_off(const f32x16& acc, hx8& h0, hx8& h1) {
   e4_u32x4 w0, w1;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    w0[k] = e4_cvt_pk(acc[2 * k], acc[2 * k + 1]);
-    w1[k] = e4_cvt_pk(acc[8 + 2 * k], acc[8 + 2 * k + 1]);
+    w0[k] = fd_cvt_pk(acc[2 * k], acc[2 * k + 1]);
+    w1[k] = fd_cvt_pk(acc[8 + 2 * k], acc[8 + 2 * k + 1]);
   }
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  h0 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w0), zero));
-  h1 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w1), zero));
+  h0 = __builtin_bit_cast(hx8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w0), zero));
+  h1 = __builtin_bit_cast(hx8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w1), zero));
   __builtin_amdgcn_sched_barrier(0);  // the hand-off of a tile happens here, not batched with later tiles' (register pressure)
 }
 
 // one 32-feature tile: KS weight fragments at `pa` (this lane's 16 B of fragment 0) against B fragments Bf[0..KS)
 template <int KS, int DEPTH>
-__device__ __forceinline__ void e4_tile(f32x16& acc, unsigned pa, const bf16x8* Bf) {
-  bf16x8 r[DEPTH];
+__device__ __forceinline__ void e4_tile(f32x16& acc, unsigned pa, const hx8* Bf) {
+  hx8 r[DEPTH];
 #pragma unroll
   for (int s = 0; s < DEPTH - 1; ++s) r[s] = e4_frag(pa + s * 1024);
   __builtin_amdgcn_sched_barrier(0);
@@ -229,14 +221,14 @@ __device__ __forceinline__ void e4_tile(f32x16& acc, unsigned pa, const bf16x8* 
 // selection fragment of the fold k-step (B operand): k = 8 half + e; half 0 picks row k = p >> 2 of the patch, half 1 picks
 // column j = p & 3 — of the patch's first sample (e < 4) or, for rows >= ns of a patch that straddles two samples, of the
 // next one (e >= 4).  Rebuilt where it is used (a few VALU instructions) instead of living through layer 2.
-__device__ __forceinline__ bf16x8 e4_sel(int lane, int ns) {
+__device__ __forceinline__ hx8 e4_sel(int lane, int ns) {
   asm volatile("" : "+v"(lane));
   const int p = lane & 31, want = (lane >> 5) ? (p & 3) + ((p >> 2) >= ns ? 4 : 0) : (p >> 2);
-  const unsigned one = (want & 1) ? 0x3F800000u : 0x00003F80u;  // bf16 1.0 in the odd / even half of a word
+  const unsigned one = (want & 1) ? (FD_H_ONE_BITS << 16) : FD_H_ONE_BITS;  // 1.0 in the odd / even half of a word
   e4_u32x4 w;
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = (want >> 1) == k ? one : 0u;
-  return __builtin_bit_cast(bf16x8, w);
+  return __builtin_bit_cast(hx8, w);
 }
 
 // ------------------------------------------------------------------ kernel
@@ -362,7 +354,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int g = 2 * h2 + k;
-        const e4_u32x2 ow = {e4_cvt_pk(o[2 * k][0], o[2 * k][1]), e4_cvt_pk(o[2 * k + 1][0], o[2 * k + 1][1])};
+        const e4_u32x2 ow = {fd_cvt_pk(o[2 * k][0], o[2 * k][1]), fd_cvt_pk(o[2 * k + 1][0], o[2 * k + 1][1])};
         // registers 4 g .. 4 g + 3 of tile t -> B fragment 2 t + (g >> 1) of z'
         zB[h2][2 * k] = ow[0];
         zB[h2][2 * k + 1] = ow[1];
@@ -378,7 +370,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
     if (a.wb_img) {  // D[head, pair] += Wb[:, this tile's features] z'
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2)
-        X.accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e4_frag(wbi + (2 * t + h2) * 1024 + lane * 16), __builtin_bit_cast(bf16x8, zB[h2]), X.accb, 0, 0, 0);
+        X.accb = fd_mfma32(e4_frag(wbi + (2 * t + h2) * 1024 + lane * 16), __builtin_bit_cast(hx8, zB[h2]), X.accb);
     }
     // read the staged tile back as 64 B row segments (the LDS operations of one wave execute in order: no barrier) and store
 #pragma unroll
@@ -446,7 +438,7 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
   unsigned fold_base = fold_ptr(tc, lane0);
   // all 12 layer-1 fold fragments are requested a tile ahead: a global load inside a chunk would make the compiler wait for
   // it with vmcnt, and vmcnt being in order that is a wait for the whole weight DMA of the chunk issued just before
-  bf16x8 FA[12];
+  hx8 FA[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
   auto mask_of = [&](const E4Tile& t, int lane) {
@@ -470,12 +462,12 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     const unsigned zst = lds0 + E4_ZOFF + wave * 8192;
     const unsigned zrow = zst + p * 256;
 
-    bf16x8 H1[24], H2[24];
+    hx8 H1[24], H2[24];
     size_t soff = 0;
     // ================= layer 1: 4 chunks x 3 tiles, K = 128 (+ fold)
     {
-      const bf16x8 SEL = e4_sel(lane, tc.ns);
-      bf16x8 Zf[8];
+      const hx8 SEL = e4_sel(lane, tc.ns);
+      hx8 Zf[8];
 #pragma unroll
       for (int s = 0; s < 8; ++s) Zf[s] = e4_frag(zrow + (((2 * s) ^ (half ^ (p & 15))) << 4));
 #pragma unroll
@@ -525,7 +517,7 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) E.Y[t][r] = 0.f;
-    bf16x8 FL[4];
+    hx8 FL[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       if (cc < 3) e4_dma_chunk<32768>(stream + soff + 32768, lds0 + ((cc + 1) & 1) * E4_BUF, tid, wave);
@@ -542,8 +534,8 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
       }
       const unsigned pa = lds0 + (cc & 1) * E4_BUF + lane * 16;
       constexpr int NF = 32, DEPTH = E4_DF;  // flat ring over the chunk's 32 fragments
-      bf16x8 r[DEPTH];
-      bf16x8 zb[2];
+      hx8 r[DEPTH];
+      hx8 zb[2];
       unsigned zrow2 = 0, zx = 0;  // the z row address again, from an opaque copy (otherwise the 8 layer-1 addresses stay live)
       if (cc == 0) {
         const int l2 = lane_id();
@@ -575,7 +567,7 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
       }
     }
     {
-      const bf16x8 SEL = e4_sel(lane, tc.ns);
+      const hx8 SEL = e4_sel(lane, tc.ns);
 #pragma unroll
       for (int t = 0; t < 4; ++t) E.Y[t] = e4_mfma(FL[t], SEL, E.Y[t]);
     }

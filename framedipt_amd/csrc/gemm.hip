@@ -35,7 +35,7 @@ struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading 
       if constexpr (sizeof(SrcT) == 4 && sizeof(typename P::T) == 4) {
         d[0] = r[u][0]; d[1] = r[u][1]; d[2] = r[u][2]; d[3] = r[u][3];
       } else if constexpr (sizeof(SrcT) == 4) {
-        u16x4 h = {f2bf(r[u][0]), f2bf(r[u][1]), f2bf(r[u][2]), f2bf(r[u][3])};
+        u16x4 h = {f2h(r[u][0]), f2h(r[u][1]), f2h(r[u][2]), f2h(r[u][3])};
         *(u16x4*)d = h;
       } else {
         *(u16x8*)d = r[u];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(FD_THREADS) void linear_splitk_kernel(int M, int N,
 __device__ __forceinline__ int g_perm16(int pos) { return 4 * (pos >> 3) + (pos & 3) + 8 * ((pos & 7) >> 2); }
 
 __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
-  typedef PrecBF16 P;
+  typedef PrecHalf P;
   constexpr int BM = 128, BN = 128, LDT = 64 + P::PAD, TM = 2, TN = 2;
   __shared__ __attribute__((aligned(16))) P::T smem[2 * (BM + BN) * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -191,10 +191,10 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
   // of a tile make 512 contiguous bytes per store instruction (the untransposed epilogue wrote single bf16 values)
   const bool qk_block = (HC % BN) == 0 && (a.C % BN) == 0 && (n0 < HC || (n0 < 3 * HC && ((n0 - HC) % (2 * a.C)) < a.C));
   if (qk_block) {
-    gemm_tile<P, float, bf16_t, BM, BN, true>(acc, M, NOUT, a.K, a.A, a.lda, (const bf16_t*)a.W, a.K, smem, m0, n0, tid);
+    gemm_tile<P, float, half_t, BM, BN, true>(acc, M, NOUT, a.K, a.A, a.lda, (const half_t*)a.W, a.K, smem, m0, n0, tid);
     const bool isq = n0 < HC;
     const int nn0 = isq ? n0 : n0 - HC, hh = isq ? nn0 / a.C : nn0 / (2 * a.C), cb = isq ? nn0 % a.C : nn0 % (2 * a.C);
-    bf16_t* dst0 = isq ? a.Qb : a.Kb;
+    half_t* dst0 = isq ? a.Qb : a.Kb;
     const float sc = isq ? a.qscale : 1.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
           const f32x4 bv = *(const f32x4*)(a.bias + n0 + (wc * TN + jn) * 32 + 8 * g + 4 * (lane >> 5));
           u16x4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = f2bf((acc[i][jn][4 * g + q] + bv[q]) * sc);
+          for (int q = 0; q < 4; ++q) o[q] = f2h((acc[i][jn][4 * g + q] + bv[q]) * sc);
           *(u16x4*)(dst0 + ((((((long)b * a.H + hh) * ntl_ + (r >> 5)) * (a.C >> 4) + (cc >> 4)) * 64 + ((cc >> 3) & 1) * 32 + (r & 31)) << 3) +
                     (cc & 7)) = o;
         }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
     }
     return;
   }
-  gemm_tile<P, float, bf16_t, BM, BN>(acc, M, NOUT, a.K, a.A, a.lda, (const bf16_t*)a.W, a.K, smem, m0, n0, tid);
+  gemm_tile<P, float, half_t, BM, BN>(acc, M, NOUT, a.K, a.A, a.lda, (const half_t*)a.W, a.K, smem, m0, n0, tid);
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
     const int n = n0 + (wc * TN + jn) * 32 + (lane & 31);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
         if (kind == 2 && mg + 3 < M && (a.N & 3) == 0) {
           const int b = mg / a.N, key = mg - b * a.N;  // 4 keys of one sample (N % 4 == 0), contiguous after perm16
           const int pp = (key & ~15) + g_perm16(key & 15);
-          u16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          u16x4 o = {f2h(v[0]), f2h(v[1]), f2h(v[2]), f2h(v[3])};
           *(u16x4*)(a.Vt + ((((((long)b * a.H + hh) * (a.C >> 5) + (cc >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 +
                              (cc & 31)) << 3) + (pp & 7)) = o;
           continue;
@@ -257,13 +257,13 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
           if (m >= M) continue;
           const int b = m / a.N, r = m - b * a.N;
           if (kind == 0 || kind == 1) {
-            bf16_t* dst = kind == 0 ? a.Qb : a.Kb;
+            half_t* dst = kind == 0 ? a.Qb : a.Kb;
             dst[((((((long)b * a.H + hh) * ntl + (r >> 5)) * (a.C >> 4) + (cc >> 4)) * 64 + ((cc >> 3) & 1) * 32 + (r & 31)) << 3) +
-                (cc & 7)] = f2bf(kind == 0 ? v[q] * a.qscale : v[q]);
+                (cc & 7)] = f2h(kind == 0 ? v[q] * a.qscale : v[q]);
           } else if (kind == 2) {
             const int pp = (r & ~15) + g_perm16(r & 15);
             a.Vt[((((((long)b * a.H + hh) * (a.C >> 5) + (cc >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (cc & 31)) << 3) +
-                 (pp & 7)] = f2bf(v[q]);
+                 (pp & 7)] = f2h(v[q]);
           } else a.pts[(long)m * a.PT + cc] = v[q];
         }
       }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
 
 // zero the padded keys [N, Np) of Kb and Vt (P is exactly 0 there and the logits are masked, but the operands must not
 // be NaN/Inf).  One thread per (bh, padded key, 8-channel group).
-__global__ void kv_zero_pad_kernel(long BH, int N, int Np, int C, bf16_t* __restrict__ Kb, bf16_t* __restrict__ Vt,
+__global__ void kv_zero_pad_kernel(long BH, int N, int Np, int C, half_t* __restrict__ Kb, half_t* __restrict__ Vt,
                                    uint4* __restrict__ extra, long extra_n16) {
   // another once-per-forward zero fill riding on this launch (the value-point image of attention3: 16 B units)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < extra_n16; i += (long)gridDim.x * blockDim.x)
@@ -335,7 +335,7 @@ static int launch_linear(int precision, int M, int N, int K, const float* A, int
     launch_tiles<PrecF32, float, float>(M, N, K, A, lda, (const float*)W, ldw, bias, residual, ldr, rowmask, relu, out, ldo,
                                         st);
   else
-    launch_tiles<PrecBF16, float, bf16_t>(M, N, K, A, lda, (const bf16_t*)W, ldw, bias, residual, ldr, rowmask, relu, out,
+    launch_tiles<PrecHalf, float, half_t>(M, N, K, A, lda, (const half_t*)W, ldw, bias, residual, ldr, rowmask, relu, out,
                                           ldo, st);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
@@ -349,7 +349,7 @@ int fd_linear_z(int precision, long M, int N, int K, const void* A, const void* 
     launch_tiles<PrecF32, float, float>((int)M, N, K, (const float*)A, K, (const float*)W, K, bias, nullptr, 0, nullptr, 0,
                                         out, N, st);
   else
-    launch_tiles<PrecBF16, bf16_t, bf16_t>((int)M, N, K, (const bf16_t*)A, K, (const bf16_t*)W, K, bias, nullptr, 0, nullptr,
+    launch_tiles<PrecHalf, half_t, half_t>((int)M, N, K, (const half_t*)A, K, (const half_t*)W, K, bias, nullptr, 0, nullptr,
                                            0, out, N, st);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
@@ -471,7 +471,7 @@ int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts
                        int ld_extra, int n_extra, const L2Warm* warm, hipStream_t st) {
   if (M <= 0 || D <= 0 || D > 1024 || !x || !parts || nparts < 1 || nparts > 8 || !gamma || !beta || !out) return FDIPT_EINVAL;
   if (D == 256 && !((ldx | ldr | ldo | ld_extra) & 3) && !(part_stride & 3) && (!extra || (n_extra & 3) == 0) && n_extra <= 256 &&
-      !getenv("FDIPT_LN_GENERIC")) {
+      !FD_DEV_ENV("FDIPT_LN_GENERIC")) {
     hipLaunchKernelGGL(layernorm256_parts_kernel, dim3(cdiv(M, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, M, x, ldx, parts, ldr,
                        nparts, part_stride, gamma, beta, rowmask, out, ldo, extra, ld_extra, extra ? n_extra : 0,
                        warm ? *warm : L2Warm{});
@@ -489,28 +489,28 @@ int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, c
   if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 3) || (ldw & 7)) return FDIPT_EINVAL;
   const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
   if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
-  hipLaunchKernelGGL((linear_splitk_kernel<PrecBF16, float, bf16_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
-                     st, M, N, K, kslice, A, lda, (const bf16_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecHalf, float, half_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
+                     st, M, N, K, kslice, A, lda, (const half_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
-int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const bf16_t* A, int lda, const void* W, int ldw, const float* bias,
+int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const half_t* A, int lda, const void* W, int ldw, const float* bias,
                      const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 7) || (ldw & 7)) return FDIPT_EINVAL;
   const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
   if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
-  hipLaunchKernelGGL((linear_splitk_kernel<PrecBF16, bf16_t, bf16_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
-                     st, M, N, K, kslice, A, lda, (const bf16_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecHalf, half_t, half_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
+                     st, M, N, K, kslice, A, lda, (const half_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
 
-__global__ void f32_to_bf16_kernel(long n, const float* __restrict__ in, bf16_t* __restrict__ out) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+__global__ void f32_to_half_kernel(long n, const float* __restrict__ in, half_t* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f2h(in[i]);
 }
-int fd_f32_to_bf16(long n, const float* in, bf16_t* out, hipStream_t st) {
+int fd_f32_to_half(long n, const float* in, half_t* out, hipStream_t st) {
   if (n <= 0) return FDIPT_OK;
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(f32_to_half_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
                      n, in, out);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
@@ -535,15 +535,15 @@ int fdipt_selftest_mfma(int precision, double* max_err_host) {
   for (int i = 0; i < M * K; ++i) hA[i] = (float)((i * 37 % 101) - 50) / 64.f;
   for (int i = 0; i < N * K; ++i) hW[i] = (float)((i * 53 % 89) - 44) / 32.f;
   float *dA, *dW, *dO;
-  bf16_t* dWb;
+  half_t* dWb;
   int rc = FDIPT_OK;
   if (hipMalloc(&dA, M * K * 4) != hipSuccess || hipMalloc(&dW, N * K * 4) != hipSuccess ||
       hipMalloc(&dO, M * N * 4) != hipSuccess || hipMalloc(&dWb, N * K * 2) != hipSuccess)
     return FDIPT_ELAUNCH;
   hipMemcpy(dA, hA, M * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(dW, hW, N * K * 4, hipMemcpyHostToDevice);
-  if (precision == FDIPT_PREC_BF16) {
-    fd_f32_to_bf16(N * K, dW, dWb, 0);
+  if (precision == FDIPT_PREC_HALF) {
+    fd_f32_to_half(N * K, dW, dWb, 0);
     rc = launch_linear(precision, M, N, K, dA, K, dWb, K, nullptr, nullptr, 0, nullptr, 0, dO, N, 0);
   } else {
     rc = launch_linear(precision, M, N, K, dA, K, dW, K, nullptr, nullptr, 0, nullptr, 0, dO, N, 0);

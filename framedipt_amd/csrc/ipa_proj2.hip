@@ -22,20 +22,17 @@
 #define P2_XROW (P2_K * 2)                  // bf16 activation row in LDS: 128 rows = exactly one weight buffer (buffer 1)
 #define P2_LDS (2 * P2_WBLK)
 
-typedef __bf16 p2_bf16x2 __attribute__((ext_vector_type(2)));
+typedef fd_h p2_hx2 __attribute__((ext_vector_type(2)));
 typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned p2_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned p2_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned p2_cvt_pk(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (round to nearest even)
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(p2_f32x2{lo, hi}, p2_bf16x2));
-}
 __device__ __forceinline__ int p2_perm16(int pos) { return 4 * (pos >> 3) + (pos & 3) + 8 * ((pos & 7) >> 2); }
 __device__ __forceinline__ void p2_dma16(const void* gsrc, unsigned lds_dst) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(gsrc) : "memory", "m0");
 }
 typedef const __attribute__((address_space(3))) u16x8* p2_lds_u16x8;
-__device__ __forceinline__ bf16x8 p2_frag(unsigned off) { return __builtin_bit_cast(bf16x8, *(p2_lds_u16x8)(unsigned long)off); }
+__device__ __forceinline__ hx8 p2_frag(unsigned off) { return __builtin_bit_cast(hx8, *(p2_lds_u16x8)(unsigned long)off); }
 
 // QK: this block walks the Q / K column blocks (n_walk_qk walkers, blockIdx.y < n_walk_qk) or the V / point blocks
 template <bool QK>
@@ -70,12 +67,12 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       const int idx = tid + it * FD_THREADS, r = idx >> 6, c4 = idx & 63;
       const int gr = m0 + r < M ? m0 + r : M - 1;
       const f32x4 x = *(const f32x4*)(a.A + (long)gr * a.lda + 4 * c4);
-      const p2_u32x2 h = {p2_cvt_pk(x[0], x[1]), p2_cvt_pk(x[2], x[3])};
+      const p2_u32x2 h = {fd_cvt_pk(x[0], x[1]), fd_cvt_pk(x[2], x[3])};
       *(p2_u32x2*)(xs + r * P2_XROW + (((c4 >> 1) ^ (r & 15)) << 4) + 8 * (c4 & 1)) = h;
     }
   }
   __syncthreads();
-  bf16x8 Af[2][P2_KS];
+  hx8 Af[2][P2_KS];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -119,12 +116,12 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       if ((g & 1) || qk_row[i] < 0) return;
       const f32x4 b0 = bq[j][g], b1 = bq[j][g + 1];
       const float sc = kind == 0 ? a.qscale : 1.f;
-      const p2_u32x4 o = {p2_cvt_pk((acc[i][j][4 * g] + b0[0]) * sc, (acc[i][j][4 * g + 1] + b0[1]) * sc),
-                          p2_cvt_pk((acc[i][j][4 * g + 2] + b0[2]) * sc, (acc[i][j][4 * g + 3] + b0[3]) * sc),
-                          p2_cvt_pk((acc[i][j][4 * g + 4] + b1[0]) * sc, (acc[i][j][4 * g + 5] + b1[1]) * sc),
-                          p2_cvt_pk((acc[i][j][4 * g + 6] + b1[2]) * sc, (acc[i][j][4 * g + 7] + b1[3]) * sc)};
+      const p2_u32x4 o = {fd_cvt_pk((acc[i][j][4 * g] + b0[0]) * sc, (acc[i][j][4 * g + 1] + b0[1]) * sc),
+                          fd_cvt_pk((acc[i][j][4 * g + 2] + b0[2]) * sc, (acc[i][j][4 * g + 3] + b0[3]) * sc),
+                          fd_cvt_pk((acc[i][j][4 * g + 4] + b1[0]) * sc, (acc[i][j][4 * g + 5] + b1[1]) * sc),
+                          fd_cvt_pk((acc[i][j][4 * g + 6] + b1[2]) * sc, (acc[i][j][4 * g + 7] + b1[3]) * sc)};
       // cc = cbase + (2 wc + j) 32 + 16 G + 8 hi: cc >> 4 = (cbase >> 4) + 2 (2 wc + j) + G, (cc >> 3) & 1 = hi, cc & 7 = 0
-      bf16_t* dst = (kind == 0 ? a.Qb : a.Kb) + (long)qk_row[i] + cpart[0] + ((2 * j + (g >> 1)) * 64) * 8;
+      half_t* dst = (kind == 0 ? a.Qb : a.Kb) + (long)qk_row[i] + cpart[0] + ((2 * j + (g >> 1)) * 64) * 8;
       *(p2_u32x4*)dst = o;
     } else {
       if (cpart[j] < 0) return;
@@ -134,7 +131,7 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + bv;
       if (kind == 2) {
         if (v_row[i][g] < 0) return;
-        const p2_u32x2 o = {p2_cvt_pk(v[0], v[1]), p2_cvt_pk(v[2], v[3])};
+        const p2_u32x2 o = {fd_cvt_pk(v[0], v[1]), fd_cvt_pk(v[2], v[3])};
         *(p2_u32x2*)(a.Vt + (long)v_row[i][g] + cpart[j]) = o;
       } else {
         if (p_row[i][g] < 0) return;
@@ -197,7 +194,7 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
     const unsigned wb = lds0 + bufc * P2_WBLK + (wc * 2) * (P2_KS * 1024) + lane * 16;
     // weight fragments two k-steps ahead of their MFMAs (one wave per SIMD: nothing else hides the LDS latency); pinned
     constexpr int DEPTH = 3;
-    bf16x8 w0[DEPTH], w1[DEPTH];
+    hx8 w0[DEPTH], w1[DEPTH];
 #pragma unroll
     for (int s = 0; s < DEPTH - 1; ++s) {
       w0[s] = p2_frag(wb + s * 1024);
@@ -213,14 +210,14 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       if constexpr (QK) {  // operands exchanged: lane = row
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          accN[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s % DEPTH], Af[i][s], accN[i][0], 0, 0, 0);
-          accN[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s % DEPTH], Af[i][s], accN[i][1], 0, 0, 0);
+          accN[i][0] = fd_mfma32(w0[s % DEPTH], Af[i][s], accN[i][0]);
+          accN[i][1] = fd_mfma32(w1[s % DEPTH], Af[i][s], accN[i][1]);
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          accN[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][s], w0[s % DEPTH], accN[i][0], 0, 0, 0);
-          accN[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][s], w1[s % DEPTH], accN[i][1], 0, 0, 0);
+          accN[i][0] = fd_mfma32(Af[i][s], w0[s % DEPTH], accN[i][0]);
+          accN[i][1] = fd_mfma32(Af[i][s], w1[s % DEPTH], accN[i][1]);
         }
       }
       // (two units per k-step in the first half of the block: their stores then have the second half to retire before the
@@ -268,7 +265,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void ipa_proj2_kernel(ProjArgs a, in
 // Row permutation of the Q / K tiles of the weight image (see the Q / K epilogue unit): image row rho of a 32-row tile takes the
 // weight row of channel 16 (r >> 3) + 8 hi + (r & 7) with hi = (rho >> 2) & 1, r = (rho & 3) + 4 (rho >> 3).  Tiles: the q part
 // (H C / 32 tiles), then per head 2 C / 32 tiles of which the first C / 32 are K.  In place, one block per (tile, k-step).
-__global__ void p2_permute_rows_kernel(bf16_t* img, int ks, int n_q_tiles, int per_head) {
+__global__ void p2_permute_rows_kernel(half_t* img, int ks, int n_q_tiles, int per_head) {
   const int tile = blockIdx.x / ks, s = blockIdx.x % ks;
   const bool qk = tile < n_q_tiles || ((tile - n_q_tiles) % per_head) < per_head / 2;
   if (!qk) return;
@@ -283,7 +280,7 @@ __global__ void p2_permute_rows_kernel(bf16_t* img, int ks, int n_q_tiles, int p
 int fd_ipa_proj2_permute_image(void* img, int H, int C, int K, hipStream_t st) {
   if ((C & 31) || (K & 15)) return FDIPT_EINVAL;
   const int n_q = H * C / 32, n_kv = 2 * H * C / 32, ks = K / 16;
-  hipLaunchKernelGGL(p2_permute_rows_kernel, dim3((n_q + n_kv) * ks), dim3(64), 0, st, (bf16_t*)img, ks, n_q, 2 * C / 32);
+  hipLaunchKernelGGL(p2_permute_rows_kernel, dim3((n_q + n_kv) * ks), dim3(64), 0, st, (half_t*)img, ks, n_q, 2 * C / 32);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -3,7 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef unsigned short bf16_t;
+typedef unsigned short half_t;  // raw bits of the half-precision operand type (common.hpp)
+
+// development switch: product builds compile it to `false` and never read the environment
+#ifdef FDIPT_DEV
+#include <stdlib.h>
+#define FD_DEV_ENV(name) (getenv(name) != nullptr)
+#else
+#define FD_DEV_ENV(name) false
+#endif
 
 struct EdgeTransArgs {
   int B, N;
@@ -63,13 +71,13 @@ struct OPairArgs {
   int B, N, H, CZ, CD;   // CD = CZ/4
   const void* z;         // [B,N,N,CZ] ZT
   const float* probs;    // [B,H,N,N]
-  const bf16_t* probs_bf16;  // optional (MFMA kernel): the same weights as bf16 rows [B,N,H,probs_np], zero beyond N; else NULL
+  const half_t* probs_h16;  // optional (MFMA kernel): the same weights as bf16 rows [B,N,H,probs_np], zero beyond N; else NULL
   int probs_np;
   const float* wdz;      // [CZ,CD] f32 (down_z weight, transposed)
   const void* wdz_img;   // optional: down_z weight [CD, CZ] as a bf16 fragment image (fd_chain_build_image, natural k) for the MFMA kernel
   const float* bdz;      // [CD]
   float* out;            // row (b*N+i): out + r*out_ld + off + h*CD + d
-  bf16_t* out_bf16;      // MFMA kernel: if set, bf16 rows (same out_ld, in elements) INSTEAD of out
+  half_t* out_h16;      // MFMA kernel: if set, bf16 rows (same out_ld, in elements) INSTEAD of out
   long out_ld;
   int off;
   L2Warm warm = {};  // weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
@@ -101,10 +109,10 @@ __host__ __device__ __forceinline__ long fd_bias_frag_off(long bh, int nt, int i
 
 struct ET2Args {
   int B, N;
-  const bf16_t* z_in;   // [B,N,N,128] bf16
-  bf16_t* z_out;        // may alias z_in
+  const half_t* z_in;   // [B,N,N,128] bf16
+  half_t* z_out;        // may alias z_in
   const float* e;       // [B*N,128] f32 initial_embed(node)
-  const bf16_t* e_bf16; // the same rows in bf16 (edge_transition3: fetched by LDS-DMA)
+  const half_t* e_h16; // the same rows in bf16 (edge_transition3: fetched by LDS-DMA)
   const float* a1;      // [B*N,384] f32: W1[:, e_i cols] e_i + b1
   const float* af;      // [B*N,128] f32: Wf[:, e_i cols] e_i + bf
   const void* stream;   // pre-swizzled weight stream (fd_et2_build_stream)
@@ -119,17 +127,13 @@ struct ET2Args {
   const void* a1_img;   // [ceil(B*N/8)][16][32][8] bf16: A1 | Af rows of 8 consecutive (flattened) residue rows
   const void* b1_img;   // [B][N/4][16][32][8] bf16: B1 | Bf rows (e_j columns) of 4 consecutive j (+ the next sample's)
 };
-int fd_et2_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
-size_t fd_et2_stream_bytes();
-int fd_edge_transition2(const ET2Args& a, hipStream_t st);
-int fd_edge_transition2_supported(int N);
-// second-generation kernel (edge_transition3.hip): 16-pair waves, two waves per SIMD; same arguments, its own stream image
+// edge_transition3.hip: 16-pair waves, two waves per SIMD (any N >= 43)
 int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et3_stream_bytes();
 int fd_edge_transition3(const ET2Args& a, hipStream_t st);
 int fd_et3_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st);  // 4 KB, for ET2Args.wb_img
 int fd_edge_transition3_supported(int N);
-// third generation (edge_transition4.hip): 32-pair waves (8 i x 4 j patches), e_i / e_j parts folded into one k-step
+// edge_transition4.hip (default, N % 4 == 0): 32-pair waves (8 i x 4 j patches), e_i / e_j parts folded into one k-step
 int fd_et4_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et4_stream_bytes();
 int fd_et4_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st);  // 8 KB, for ET2Args.wb_img
@@ -151,7 +155,7 @@ struct ProjArgs {
   const void* W_img;          // the same as a fragment image, zero-padded to whole 128-column blocks (ipa_proj2.hip), or NULL
   const float* bias;          // [3*H*C + PT]
   float qscale;               // sqrt(1/(3C)) folded into Q
-  bf16_t *Qb, *Kb, *Vt;
+  half_t *Qb, *Kb, *Vt;
   float* pts;                 // [B*N, PT]
   int zero_pads;              // also zero the padded keys [N, Np) of Kb / Vt (first use of the buffers in a forward)
 };
@@ -164,16 +168,16 @@ int fd_ipa_proj2(const ProjArgs& a, hipStream_t st);  // second generation (ipa_
 
 struct Attn3Args {
   int B, N, H, Np;
-  const bf16_t *Qb, *Kb, *Vt;     // operand images written by ipa_proj_kernel
+  const half_t *Qb, *Kb, *Vt;     // operand images written by ipa_proj_kernel
   const float* bias;              // pre-scaled pair bias in fd_bias_frag_off order (B*H*Np*Np floats)
   const float* res_mask;          // [B,N]
   const float *qp, *kp, *vp;      // [B,N,H,8,3], [B,N,H,8,3], [B,N,H,12,3] global-frame points (scaled units)
-  const bf16_t* vpt;              // v_pts hi/lo fragment image (PointsArgs.vpt)
+  const half_t* vpt;              // v_pts hi/lo fragment image (PointsArgs.vpt)
   const float* gamma;             // [H]
   const float *rot, *trans;       // [B,N,9], [B,N,3]
   float* probs;                   // [B,H,N,N]
-  bf16_t* out_bf16;               // if set: the output features are written as bf16 rows (same out_ld, in elements) INSTEAD of out
-  bf16_t* probs_bf16;             // if set: written INSTEAD, as bf16 rows [B,N,H,Np] (what the MFMA o_pair kernel consumes)
+  half_t* out_h16;               // if set: the output features are written as bf16 rows (same out_ld, in elements) INSTEAD of out
+  half_t* probs_h16;             // if set: written INSTEAD, as bf16 rows [B,N,H,Np] (what the MFMA o_pair kernel consumes)
   float* out;                     // feature rows: o at h*256, point features at pt_off
   long out_ld;
   int pt_off;
@@ -214,7 +218,7 @@ struct RowBlockArgs {
   int ld_out;
   float* out2;                  // optional: output columns >= split go to out2 (column - split), or NULL
   int ld_out2, split;
-  unsigned short* hid_bf16;     // optional bf16 copy of the first hidden layer's rows [M, N1], or NULL
+  unsigned short* hid_h16;     // optional bf16 copy of the first hidden layer's rows [M, N1], or NULL
   // FD_RB_ET4_IMAGES: the 1024 output columns [A1 | Af | B1 | Bf] leave as edge_transition4's fold-fragment images (bf16)
   void *img_a, *img_b;          // fd_et4_row_images layouts
   int img_B, img_N;
@@ -253,7 +257,7 @@ struct ChainArgs {
   const float* residual;    // added to the output layer (fp32) or NULL
   int ld_res;
   const float *gamma, *beta;     // LayerNorm parameters (kinds with LN)
-  unsigned short* out_bf16;      // optional bf16 copy of the output rows, [M, NOUT] (kinds without LayerNorm), or NULL
+  unsigned short* out_h16;      // optional bf16 copy of the output rows, [M, NOUT] (kinds without LayerNorm), or NULL
   const float* rowmask_pre;      // (W x + b) * mask before the residual, or NULL
   const float* rowmask_post;     // final * mask, or NULL
   float* out;
@@ -275,20 +279,18 @@ int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts
                        const float* gamma, const float* beta, const float* rowmask, float* out, int ldo, const float* extra,
                        int ld_extra, int n_extra, const L2Warm* warm, hipStream_t st);
 // the same with bf16 activation rows (what the bf16 GEMM would round them to anyway)
-int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const bf16_t* A, int lda, const void* W, int ldw, const float* bias,
+int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const half_t* A, int lda, const void* W, int ldw, const float* bias,
                          const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, const void* W, int ldw, const float* bias,
                      const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,
                  const float* beta, const float* rowmask, float* out, int ldo, hipStream_t st);
-int fd_f32_to_bf16(long n, const float* in, bf16_t* out, hipStream_t st);
+int fd_f32_to_half(long n, const float* in, half_t* out, hipStream_t st);
 int fd_edge_transition(int precision, int cz, int cb, const EdgeTransArgs& a, hipStream_t st);
 int fd_edge_embed(int precision, int cz, const EdgeEmbedArgs& a, hipStream_t st);
 int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st);
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
-int fd_opair_mfma_eligible(int precision, const OPairArgs& a);  // the MFMA kernel will run (it can take probs_bf16)
-int fd_attention2_supported(int ipa, const AttnArgs& a);
-int fd_attention2(int ipa, const AttnArgs& a, hipStream_t st);
+int fd_opair_mfma_eligible(int precision, const OPairArgs& a);  // the MFMA kernel will run (it can take probs_h16)
 int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, int frag, hipStream_t st);
 int fd_points(const PointsArgs& a, hipStream_t st);
 int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask, hipStream_t st);

@@ -13,6 +13,58 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+// ------------------------------------------------------------------ kernel-selection switches
+// The library reads no environment on the launch path.  FdiptDims.kernel_flags (include/fdipt.h: FDIPT_KF_*) selects the
+// fallback paths that other shapes use anyway, so that parity tests can run them at the golden sizes; a -DFDIPT_DEV build
+// (build.sh dev -> lib/libfdipt_hip_dev.so, used by tools/) additionally reads the FDIPT_* development switches, once per
+// process.  The weight images built by fdipt_model_prepare and the forward of the same FdiptDims see the same switches.
+struct Switches {
+  bool generic_pair = false;    // LDS-chain EdgeTransition / edge embedder (any width) instead of the register kernels
+  bool et3 = false;             // 16-pair EdgeTransition kernel (the N % 4 != 0 path) for every N
+  bool generic_attn = false;    // LDS-score attention kernels (the N > 512 path) for every N
+  bool no_rowblock = false;     // node path as GEMM + LayerNorm launches (the non-reference-width path)
+  bool no_chain = false;
+  bool no_splitk = false;
+  bool no_et_bias = false, no_ee_bias = false;  // pair bias as its own pass over z
+  bool feats_unfused = false, torf_unfused = false, init_unfused = false, skip_per_block = false, post_unfused = false,
+       no_tfmr_tail = false, et4_rows_unfused = false, no_qkv_fuse = false, proj_v1 = false, feats_f32 = false,
+       probs_f32 = false, no_l2_warm = false;
+  unsigned chain_mask = 0xFC9u;  // fused chain kinds (chain.hip) that beat the launches they replace (profiles/r01_chain_vs_gemm.md)
+  const char* twice = nullptr;   // timing aid: repeat the named launches (the second one runs on a warm L2)
+};
+static const Switches& dev_switches() {
+  static const Switches sw = [] {
+    Switches s;
+#ifdef FDIPT_DEV
+    auto on = [](const char* n) { return getenv(n) != nullptr; };
+    s.generic_pair = on("FDIPT_ET_V1"); s.et3 = on("FDIPT_ET_V3"); s.generic_attn = on("FDIPT_ATTN_V1");
+    s.no_rowblock = on("FDIPT_NO_ROWBLOCK"); s.no_chain = on("FDIPT_NO_CHAIN"); s.no_splitk = on("FDIPT_NO_SPLITK");
+    s.no_et_bias = on("FDIPT_NO_ET_BIAS"); s.no_ee_bias = on("FDIPT_NO_EE_BIAS"); s.feats_unfused = on("FDIPT_FEATS_UNFUSED");
+    s.torf_unfused = on("FDIPT_TORF_UNFUSED"); s.init_unfused = on("FDIPT_INIT_UNFUSED");
+    s.skip_per_block = on("FDIPT_SKIP_PER_BLOCK"); s.post_unfused = on("FDIPT_POST_UNFUSED");
+    s.no_tfmr_tail = on("FDIPT_NO_TFMR_TAIL"); s.et4_rows_unfused = on("FDIPT_ET4_ROWS_UNFUSED");
+    s.no_qkv_fuse = on("FDIPT_NO_QKV_FUSE"); s.proj_v1 = on("FDIPT_PROJ_V1"); s.feats_f32 = on("FDIPT_FEATS_F32");
+    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM");
+    if (const char* m = getenv("FDIPT_CHAIN_MASK")) s.chain_mask = (unsigned)strtoul(m, nullptr, 0);
+    s.twice = getenv("FDIPT_DBG_TWICE");
+#endif
+    return s;
+  }();
+  return sw;
+}
+static Switches switches_of(const FdiptDims* d) {
+  Switches s = dev_switches();
+  const unsigned f = (unsigned)d->kernel_flags;
+  if (f & FDIPT_KF_GENERIC_PAIR) s.generic_pair = true;
+  if (f & FDIPT_KF_ET3) s.et3 = true;
+  if (f & FDIPT_KF_GENERIC_ATTN) s.generic_attn = true;
+  if (f & FDIPT_KF_UNFUSED_NODE) s.no_rowblock = s.no_chain = s.no_splitk = true;
+  if (f & FDIPT_KF_UNFOLDED)
+    s.no_et_bias = s.no_ee_bias = s.feats_unfused = s.torf_unfused = s.init_unfused = s.skip_per_block = s.post_unfused =
+        s.et4_rows_unfused = true;
+  return s;
+}
+
 // ------------------------------------------------------------------ inventory (== framedipt_amd/weights.py)
 struct LinW { long w, b; int out, in; };
 struct LNW { long g, b; int d; };
@@ -44,7 +96,7 @@ static bool dims_ok(const FdiptDims* d) {
   return d && d->num_blocks >= 1 && d->num_blocks <= FD_MAX_BLOCKS && d->tfmr_layers >= 1 && d->tfmr_layers <= FD_MAX_TL &&
          d->c_s > 0 && (d->c_s % 8) == 0 && d->c_z > 0 && (d->c_z % 8) == 0 && d->no_heads > 0 && d->no_heads <= 16 &&
          d->index_embed == 32 && d->num_bins > 0 && d->num_bins < 64 && (d->c_skip % 8) == 0 &&
-         (d->precision == FDIPT_PREC_F32 || d->precision == FDIPT_PREC_BF16);
+         (d->precision == FDIPT_PREC_F32 || d->precision == FDIPT_PREC_HALF) && (d->kernel_flags & ~FDIPT_KF_ALL) == 0;
 }
 
 static void build_inventory(const FdiptDims* d, Inventory& iv) {
@@ -97,9 +149,9 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, wproj_img, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et2, et3, et4, wdz_t, wdz_img; DChain ch; };
+struct DBlock { size_t wproj, wproj_img, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img; DChain ch; };
 struct DLayout {
-  size_t bf16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
+  size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
   size_t w1i, w1j, w1r, dtab, edges, b1;  // fp32 pieces of the concat-free first edge-embedder layer
   size_t ee2;         // LDS images of edge-embedder layers 2/3 (register-resident bf16 kernel)
@@ -111,23 +163,23 @@ struct DLayout {
   int kn_pad, d1_pad, esz;
 };
 
-// register-resident bf16 EdgeTransition (edge_transition2.hip) is compiled for the reference widths only
-static bool use_et2(const FdiptDims* d) {
-  return d->precision == FDIPT_PREC_BF16 && d->c_z == 128 && d->c_s == 256 && !getenv("FDIPT_ET_V1");
+// the register-resident half-precision pair kernels (edge_transition3/4.hip, edge_embed2) are compiled for the reference widths only
+static bool use_regpair(const FdiptDims* d) {
+  return d->precision == FDIPT_PREC_HALF && d->c_z == 128 && d->c_s == 256 && !switches_of(d).generic_pair;
 }
 
 // fused node-path chains (chain.hip) are compiled for the reference widths only
 static bool use_chain(const FdiptDims* d) {
-  return d->precision == FDIPT_PREC_BF16 && d->c_s == 256 && d->c_skip == 64 && d->c_z == 128 && !getenv("FDIPT_NO_CHAIN");
+  return d->precision == FDIPT_PREC_HALF && d->c_s == 256 && d->c_skip == 64 && d->c_z == 128 && !switches_of(d).no_chain;
 }
 
 static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   size_t o = 0;
-  L.esz = d->precision == FDIPT_PREC_BF16 ? 2 : 4;
+  L.esz = d->precision == FDIPT_PREC_HALF ? 2 : 4;
   L.kn_pad = rup8(iv.node_in);
   L.d1_pad = rup8(iv.d1);
-  L.bf16_base = o;
-  if (d->precision == FDIPT_PREC_BF16) o = al256(o + (size_t)iv.offsets.back() * 2);
+  L.h16_base = o;
+  if (d->precision == FDIPT_PREC_HALF) o = al256(o + (size_t)iv.offsets.back() * 2);
   L.ne0_pad = o; o = al256(o + (size_t)d->c_s * L.kn_pad * L.esz);
   L.w1i = o; o = al256(o + (size_t)d->c_z * L.d1_pad * 4);
   L.w1j = o; o = al256(o + (size_t)d->c_z * L.d1_pad * 4);
@@ -136,7 +188,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   L.edges = o; o = al256(o + (size_t)d->num_bins * 4);
   L.b1 = o; o = al256(o + (size_t)d->c_z * 4);
   L.ee2 = o;
-  if (use_et2(d)) o = al256(o + fd_ee2_image_bytes());
+  if (use_regpair(d)) o = al256(o + fd_ee2_image_bytes());
   for (int b = 0; b < d->num_blocks; ++b) {
     L.blk[b].wproj = o; o = al256(o + (size_t)iv.proj_out * d->c_s * L.esz);
     L.blk[b].wproj_img = o;  // the same matrix as a fragment image, zero-padded to whole 128-column blocks (ipa_proj2.hip)
@@ -150,12 +202,10 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].wb_img4 = o; o = al256(o + 8192);  // ... as 32 x 128 in edge_transition4's hand-off order
     L.blk[b].wdz_img = o; o = al256(o + 8192);  // down_z [c_z/4, c_z] as a bf16 fragment image (MFMA o_pair kernel)
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
-    L.blk[b].et2 = o;
-    if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et2_stream_bytes());
     L.blk[b].et3 = o;
-    if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et3_stream_bytes());
+    if (use_regpair(d) && b < d->num_blocks - 1) o = al256(o + fd_et3_stream_bytes());
     L.blk[b].et4 = o;
-    if (use_et2(d) && b < d->num_blocks - 1) o = al256(o + fd_et4_stream_bytes());
+    if (use_regpair(d) && b < d->num_blocks - 1) o = al256(o + fd_et4_stream_bytes());
     if (use_chain(d)) {
       DChain& c = L.blk[b].ch;
       auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
@@ -190,7 +240,7 @@ __global__ void copy_cols_kernel(int rows, int ncols, int ld_dst, const float* _
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
     const float v = c < ncols ? scale * src[(long)r * ld_src + col0 + c] : 0.f;
-    if constexpr (sizeof(T) == 4) dst[i] = v; else dst[i] = f2bf(v);
+    if constexpr (sizeof(T) == 4) dst[i] = v; else dst[i] = f2h(v);
   }
 }
 static int copy_cols(int esz, int rows, int ncols, int ld_dst, const float* src, int ld_src, int col0, float scale,
@@ -201,8 +251,8 @@ static int copy_cols(int esz, int rows, int ncols, int ld_dst, const float* src,
     hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(g), dim3(256), 0, st, rows, ncols, ld_dst, src, ld_src, col0, scale,
                        (float*)dst);
   else
-    hipLaunchKernelGGL(copy_cols_kernel<bf16_t>, dim3(g), dim3(256), 0, st, rows, ncols, ld_dst, src, ld_src, col0, scale,
-                       (bf16_t*)dst);
+    hipLaunchKernelGGL(copy_cols_kernel<half_t>, dim3(g), dim3(256), 0, st, rows, ncols, ld_dst, src, ld_src, col0, scale,
+                       (half_t*)dst);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -268,8 +318,8 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
   build_layout(d, iv, L);
   char* D = (char*)derived;
   int rc;
-  if (d->precision == FDIPT_PREC_BF16)
-    if ((rc = fd_f32_to_bf16(iv.offsets.back(), P, (bf16_t*)(D + L.bf16_base), st))) return rc;
+  if (d->precision == FDIPT_PREC_HALF)
+    if ((rc = fd_f32_to_half(iv.offsets.back(), P, (half_t*)(D + L.h16_base), st))) return rc;
   const int cs = d->c_s, cz = d->c_z, E = d->index_embed, H = d->no_heads, C = d->c_hidden;
   if ((rc = copy_cols(L.esz, cs, iv.node_in, L.kn_pad, P + iv.ne0.w, iv.node_in, 0, 1.f, D + L.ne0_pad, st))) return rc;
   if ((rc = copy_cols(4, cz, iv.d1, L.d1_pad, P + iv.ee0.w, iv.edge_in, 0, 1.f, D + L.w1i, st))) return rc;
@@ -279,7 +329,7 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
                      P + iv.ee0.w, d->min_bin, d->max_bin, (float*)(D + L.dtab), (float*)(D + L.edges));
   FD_CHECK_LAUNCH();
   if ((rc = copy_cols(4, 1, cz, cz, P + iv.ee0.b, cz, 0, 1.f, D + L.b1, st))) return rc;
-  if (use_et2(d))
+  if (use_regpair(d))
     if ((rc = fd_ee2_build_images(P + iv.ee2.w, P + iv.ee4.w, D + L.ee2, st))) return rc;
   const float s3 = sqrtf(1.0f / 3.0f);
   for (int b = 0; b < d->num_blocks; ++b) {
@@ -320,9 +370,8 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
     if (cz == 128 && (rc = fd_chain_build_image(P + k.dz.w, cz / 4, cz, cz, 0, D + db.wdz_img, st))) return rc;
-    if (use_et2(d) && b < d->num_blocks - 1)
-      if ((rc = fd_et2_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et2, st)) ||
-          (rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)) ||
+    if (use_regpair(d) && b < d->num_blocks - 1)
+      if ((rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)) ||
           (rc = fd_et4_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et4, st)))
         return rc;
     if (use_chain(d)) {
@@ -479,8 +528,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   const char* D = (const char*)derived;
   const int prec = d->precision, cs = d->c_s, cz = d->c_z, H = d->no_heads, C = d->c_hidden, Pq = d->no_qk_points,
             Pv = d->no_v_points, E = d->index_embed, dt = iv.d_t;
-  const bool bf = prec == FDIPT_PREC_BF16;
-  const bf16_t* PB = (const bf16_t*)(D + L.bf16_base);
+  const bool bf = prec == FDIPT_PREC_HALF;
+  const half_t* PB = (const half_t*)(D + L.h16_base);
   // operand-precision view of a weight matrix of the fp32 blob
   auto WM = [&](const LinW& l) -> const void* { return bf ? (const void*)(PB + l.w) : (const void*)(P + l.w); };
   auto F = [&](size_t off) { return (float*)(W + off); };
@@ -496,11 +545,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   // bit k enables fused chain kind k (FD_CHAIN_*).  Default: the kinds that beat the GEMM + LayerNorm launches they replace
   // at B*N ~ 2400 rows on MI355X (profiles/r01_chain_vs_gemm.md): the 3-layer chains and the narrow heads; the 320-wide
   // transformer layers (FFN, out_proj, in_proj) and skip_embed stay on the tiled GEMM, which spreads over 10x more CUs.
-  const char* cmask_s = getenv("FDIPT_CHAIN_MASK");
-  const unsigned cmask = cmask_s ? (unsigned)strtoul(cmask_s, nullptr, 0) : 0xFC9u;
+  const Switches sw = switches_of(d);
+  const unsigned cmask = sw.chain_mask;
   auto con = [&](int kind) { return chn_all && ((cmask >> kind) & 1u); };
   // row-complete fused MLPs (rowblock.hip) take the multi-layer kinds and the 320-wide transformer layers
-  const bool rbk = chn_all && cs == 256 && iv.d_t == 320 && !getenv("FDIPT_NO_ROWBLOCK");
+  const bool rbk = chn_all && cs == 256 && iv.d_t == 320 && !sw.no_rowblock;
   auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                     const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
                     float* out, int ld_out) {
@@ -508,10 +557,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     r.M = R; r.in = in; r.ld_in = ld_in; r.w0 = w0; r.w1 = w1; r.w2 = w2; r.b0 = b0; r.b1 = b1; r.b2 = b2; r.residual = resid;
     r.ld_res = ld_res; r.gamma = lnw ? P + lnw->g : nullptr; r.beta = lnw ? P + lnw->b : nullptr; r.rowmask_post = post;
     r.out = out; r.ld_out = ld_out; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
-    r.out2 = nullptr; r.ld_out2 = r.split = 0; r.hid_bf16 = nullptr;
+    r.out2 = nullptr; r.ld_out2 = r.split = 0; r.hid_h16 = nullptr;
     return fd_rowblock(kind, r, st);
   };
-  unsigned short* chain_bf16 = nullptr;  // one-shot: the next chain() call also writes a bf16 copy of its output rows
+  unsigned short* chain_h16 = nullptr;  // one-shot: the next chain() call also writes a bf16 copy of its output rows
   L2Warm chain_warm = {};                // one-shot: the next chain() call touches these weights (L2 warm-up hand-over)
   auto chain = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                    const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* pre,
@@ -519,7 +568,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     ChainArgs c;
     c.M = R; c.in = in; c.ld_in = ld_in; c.w[0] = w0; c.w[1] = w1; c.w[2] = w2; c.b[0] = b0; c.b[1] = b1; c.b[2] = b2;
     c.residual = resid; c.ld_res = ld_res; c.gamma = lnw ? P + lnw->g : nullptr; c.beta = lnw ? P + lnw->b : nullptr;
-    c.rowmask_pre = pre; c.rowmask_post = post; c.out = out; c.ld_out = ld_out; c.out_bf16 = chain_bf16; chain_bf16 = nullptr;
+    c.rowmask_pre = pre; c.rowmask_post = post; c.out = out; c.ld_out = ld_out; c.out_h16 = chain_h16; chain_h16 = nullptr;
     c.warm = chain_warm; chain_warm = L2Warm{};
     return fd_chain(kind, c, st);
   };
@@ -528,7 +577,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   // ---- Embedder (score_network.py:129-197)
   // ... with the split of x_t (ipa_pytorch.py:516-524) and the per-residue halves of the first edge-embedder layer in the same
   // launch (FDIPT_FEATS_UNFUSED: three GEMM / element-wise launches more)
-  const bool feats_fused = L.d1_pad <= 128 && (L.d1_pad & 3) == 0 && !getenv("FDIPT_FEATS_UNFUSED");
+  const bool feats_fused = L.d1_pad <= 128 && (L.d1_pad & 3) == 0 && !sw.feats_unfused;
   RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
                     L.kn_pad, F(w.pte), L.d1_pad, feats_fused ? a->rigids_t : nullptr, res_mask, d->coordinate_scaling, F(w.quat),
                     F(w.trans), F(w.dmask), (const float*)(D + L.w1i), (const float*)(D + L.w1j), (const float*)(D + L.b1), cz,
@@ -562,11 +611,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     ea.gamma = P + iv.eeln.g; ea.beta = P + iv.eeln.b; ea.res_mask = res_mask; ea.z_out = W + w.z;
     ea.trace = a->trace_edge;
     // the first block's pair bias linear_b(z)/sqrt(3) from the embedder's LayerNorm epilogue (saves a pass over z)
-    const bool ee_bias = use_et2(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 512 &&
-                         !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && !getenv("FDIPT_NO_EE_BIAS");
+    const bool ee_bias = use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 512 &&
+                         !sw.generic_attn && !sw.no_et_bias && !sw.no_ee_bias;
     ea.wb_img = ee_bias ? D + L.blk[0].wb_img : nullptr; ea.bb = (const float*)(D + L.blk[0].bb); ea.bias_out = F(w.bias); ea.H = H;
     ee_bias_done = ee_bias;
-    if (use_et2(d)) RC(fd_edge_embed2(ea, D + L.ee2, st));
+    if (use_regpair(d)) RC(fd_edge_embed2(ea, D + L.ee2, st));
     else RC(fd_edge_embed(prec, cz, ea, st));
   }
   if (a->trace_node)
@@ -579,16 +628,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   const float* node_cur = F(w.node0);
   // skip_embed(init_node) of every block depends on the embedder output only: one GEMM launch for all blocks, copied behind the
   // LayerNorm output by the LayerNorm kernel (FDIPT_SKIP_PER_BLOCK: one launch per block as before)
-  const bool skip_batched = bf && iv.feat_dim >= 1024 && !getenv("FDIPT_NO_SPLITK") && !getenv("FDIPT_SKIP_PER_BLOCK");
+  const bool skip_batched = bf && iv.feat_dim >= 1024 && !sw.no_splitk && !sw.skip_per_block;
   if (skip_batched)
     RC(fd_linear(prec, R, d->num_blocks * d->c_skip, cs, F(w.node0), cs, D + L.skip_w, cs, (const float*)(D + L.skip_b), nullptr, 0,
                  nullptr, 0, F(w.skip_all), d->num_blocks * d->c_skip, st));
   const size_t NN = (size_t)R * N;
   bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
-  const char* dbg_twice = getenv("FDIPT_DBG_TWICE");  // timing aid: repeat the named launches (second one runs on a warm L2)
+  const char* dbg_twice = sw.twice;  // timing aid: repeat the named launches (second one runs on a warm L2)
 #define TWICE(name, call) do { RC(call); if (dbg_twice && strstr(dbg_twice, name)) RC(call); } while (0)
-  const bool warm_all = !getenv("FDIPT_NO_L2_WARM");  // L2 warm-up hand-over between consecutive launches (common.hpp)
-  const bool seq_fused = rbk && !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_QKV_FUSE") &&
+  const bool warm_all = !sw.no_l2_warm;  // L2 warm-up hand-over between consecutive launches (common.hpp)
+  const bool seq_fused = rbk && !sw.generic_attn && !sw.no_qkv_fuse &&
                          fd_seq_attention_supported(N, d->tfmr_heads, iv.d_t / d->tfmr_heads) &&
                          fd_seq_qkv_supported(N, d->tfmr_heads, iv.d_t);
   bool bias_ready = ee_bias_done;  // pair bias of this block's attention already written (tiled order) by the embedder / EdgeTransition
@@ -597,16 +646,15 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     const DBlock& db = L.blk[b];
     const int PT = iv.proj_out - 3 * H * C, Np = (N + 31) / 32 * 32;
     Attn3Args a3;
-    a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const bf16_t*)(W + w.qb); a3.Kb = (const bf16_t*)(W + w.kb);
-    a3.Vt = (const bf16_t*)(W + w.vt); a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
-    a3.vp = F(w.vp); a3.vpt = (const bf16_t*)(W + w.vpt); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
-    a3.probs = F(w.probs); a3.probs_bf16 = nullptr; a3.out_bf16 = nullptr; a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
+    a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const half_t*)(W + w.qb); a3.Kb = (const half_t*)(W + w.kb);
+    a3.Vt = (const half_t*)(W + w.vt); a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
+    a3.vp = F(w.vp); a3.vpt = (const half_t*)(W + w.vpt); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
+    a3.probs = F(w.probs); a3.probs_h16 = nullptr; a3.out_h16 = nullptr; a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
     OPairArgs oa;
-    oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_bf16 = nullptr; oa.probs_np = 0; oa.out_bf16 = nullptr;
+    oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_h16 = nullptr; oa.probs_np = 0; oa.out_h16 = nullptr;
     oa.wdz = (const float*)(D + db.wdz_t); oa.wdz_img = (bf && cz == 128) ? D + db.wdz_img : nullptr; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
-    bool feats_bf16 = false, skip_done = false;
-    const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !getenv("FDIPT_ATTN_V1") &&
-                        !getenv("FDIPT_ATTN_V2") && fd_attention3_supported(a3);
+    bool feats_h16 = false, skip_done = false;
+    const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !sw.generic_attn && fd_attention3_supported(a3);
     PointsArgs pa;
     pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.quat = F(w.quat); pa.trans = F(w.trans);
     pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
@@ -620,12 +668,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       ProjArgs pj;
       pj.B = B; pj.N = N; pj.H = H; pj.C = C; pj.K = cs; pj.PT = PT; pj.Np = Np; pj.A = node_cur; pj.lda = cs;
       pj.W = D + db.wproj; pj.bias = (const float*)(D + db.bproj); pj.qscale = sqrtf(1.0f / (3.0f * (float)C));
-      pj.Qb = (bf16_t*)(W + w.qb); pj.Kb = (bf16_t*)(W + w.kb); pj.Vt = (bf16_t*)(W + w.vt); pj.pts = F(w.pts);
+      pj.Qb = (half_t*)(W + w.qb); pj.Kb = (half_t*)(W + w.kb); pj.Vt = (half_t*)(W + w.vt); pj.pts = F(w.pts);
       pj.zero_pads = b == 0;
-      pj.W_img = (cs == 256 && !getenv("FDIPT_PROJ_V1")) ? D + db.wproj_img : nullptr;
+      pj.W_img = (cs == 256 && !sw.proj_v1) ? D + db.wproj_img : nullptr;
       // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
       if (fd_ipa_proj2_supported(pj)) {
-        if (pj.zero_pads && seq_fused && !seq_img_ready && (C & 31) == 0 && (vpt_bytes & 15) == 0 && !getenv("FDIPT_INIT_UNFUSED")) {
+        if (pj.zero_pads && seq_fused && !seq_img_ready && (C & 31) == 0 && (vpt_bytes & 15) == 0 && !sw.init_unfused) {
           // every once-per-forward fill of the trunk in one launch: sequence-attention images, value-point image, key pads
           SeqInitExtra sx = {vpt_zero ? W + w.vpt : nullptr, vpt_zero ? (long)(vpt_bytes >> 4) : 0L, Np > N ? (void*)pj.Kb : nullptr,
                              (void*)pj.Vt, (long)B * H, C};
@@ -648,11 +696,11 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       // the fp32 buffer is reused: B N H Np bf16 <= B H N N fp32); FDIPT_PROBS_F32 keeps the fp32 [B,H,N,N] hand-over
       // ... and both kernels write the attention features as bf16 rows when the output projection is the bf16 split-K GEMM
       // (the values it would round them to anyway: identical results, half the bytes, no conversion in its staging)
-      feats_bf16 = fd_opair_mfma_eligible(prec, oa) && iv.feat_dim >= 1024 && (iv.feat_dim & 7) == 0 && !getenv("FDIPT_NO_SPLITK") &&
-                   !getenv("FDIPT_FEATS_F32");
-      if (feats_bf16) { a3.out_bf16 = (bf16_t*)(W + w.feats); oa.out_bf16 = a3.out_bf16; }
-      if (fd_opair_mfma_eligible(prec, oa) && 2 * Np <= 4 * N && !getenv("FDIPT_PROBS_F32")) {
-        a3.probs_bf16 = (bf16_t*)(W + w.probs); oa.probs_bf16 = a3.probs_bf16; oa.probs_np = Np;
+      feats_h16 = fd_opair_mfma_eligible(prec, oa) && iv.feat_dim >= 1024 && (iv.feat_dim & 7) == 0 && !sw.no_splitk &&
+                   !sw.feats_f32;
+      if (feats_h16) { a3.out_h16 = (half_t*)(W + w.feats); oa.out_h16 = a3.out_h16; }
+      if (fd_opair_mfma_eligible(prec, oa) && 2 * Np <= 4 * N && !sw.probs_f32) {
+        a3.probs_h16 = (half_t*)(W + w.probs); oa.probs_h16 = a3.probs_h16; oa.probs_np = Np;
       }
       TWICE("attn3", fd_attention3(a3, st));
     } else {
@@ -670,20 +718,15 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       aa.bias = F(w.bias); aa.res_mask = res_mask; aa.qp = F(w.qp); aa.kp = F(w.kp); aa.vp = F(w.vp); aa.Pq = Pq; aa.Pv = Pv;
       aa.gamma = (const float*)(D + db.gamma); aa.rot = F(w.rot); aa.trans = F(w.trans); aa.probs = F(w.probs);
       aa.out = F(w.feats); aa.out_ld = iv.feat_dim; aa.pt_off = H * C; aa.lds_s = 0;
-      if (bf && cz == 128 && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(1, aa)) {
-        RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), 0, st));  // [B,H,N,N]
-        RC(fd_attention2(1, aa, st));
-      } else {
-        RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
-        RC(fd_attention(prec, 1, aa, st));
-      }
+      RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
+      RC(fd_attention(prec, 1, aa, st));
     }
     TWICE("opair", fd_opair(prec, oa, st));
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
-    if (bf && iv.feat_dim >= 1024 && !getenv("FDIPT_NO_SPLITK")) {
+    if (bf && iv.feat_dim >= 1024 && !sw.no_splitk) {
       const int NS = 4;  // K = 2688: slices of 704 / 576 columns -> 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower)
-      if (feats_bf16)
-        TWICE("splitk", fd_linear_splitk_a16(R, cs, iv.feat_dim, NS, (const bf16_t*)(W + w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b,
+      if (feats_h16)
+        TWICE("splitk", fd_linear_splitk_a16(R, cs, iv.feat_dim, NS, (const half_t*)(W + w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b,
                                 res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
       else
         RC(fd_linear_splitk(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b, res_mask,
@@ -718,7 +761,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         // ... and touches the weights of the layer's tail kernel, launched next (common.hpp: L2 warm-up hand-over)
         const unsigned wimg = (unsigned)fd_chain_image_bytes(dt, dt);
         L2Warm wt = {{D + db.ch.outp[l], D + db.ch.l1[l], D + db.ch.l2n[l]}, {wimg, wimg, wimg}};
-        const bool warm_on = rbk && !getenv("FDIPT_NO_TFMR_TAIL") && warm_all;
+        const bool warm_on = rbk && !sw.no_tfmr_tail && warm_all;
         TWICE("sattn", fd_seq_attention_run(B, N, d->tfmr_heads, W + w.seqimg, F(w.att), dt, warm_on ? &wt : nullptr, st));
       } else {
       if (con(FD_CHAIN_INPROJ)) RC(chain(FD_CHAIN_INPROJ, x, dt, D + db.ch.inp[l], P + t.inp.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
@@ -732,20 +775,19 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       ta.C = hd; ta.Dv = hd; ta.scale = 1.0f / sqrtf((float)hd); ta.bias = nullptr; ta.res_mask = res_mask;
       ta.qp = ta.kp = ta.vp = nullptr; ta.Pq = ta.Pv = 0; ta.gamma = nullptr; ta.rot = ta.trans = nullptr; ta.probs = nullptr;
       ta.out = F(w.att); ta.out_ld = dt; ta.pt_off = 0; ta.lds_s = 0;
-      if (bf && !getenv("FDIPT_ATTN_V1") && !getenv("FDIPT_ATTN_V2") && fd_seq_attention_supported(N, d->tfmr_heads, hd))
+      if (bf && !sw.generic_attn && fd_seq_attention_supported(N, d->tfmr_heads, hd))
         RC(fd_seq_attention(B, N, d->tfmr_heads, F(w.qkv), 3 * dt, ta.scale, res_mask, W + w.seqimg, F(w.att), dt, st));
-      else if (bf && !getenv("FDIPT_ATTN_V1") && fd_attention2_supported(0, ta)) RC(fd_attention2(0, ta, st));
       else RC(fd_attention(prec, 0, ta, st));
       }
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
-      if (rbk && !getenv("FDIPT_NO_TFMR_TAIL")) {
+      if (rbk && !sw.no_tfmr_tail) {
         TfmrTailArgs tt;
         tt.M = R; tt.ld = dt; tt.att = F(w.att); tt.x = x; tt.wo = D + db.ch.outp[l]; tt.w1 = D + db.ch.l1[l]; tt.w2 = D + db.ch.l2n[l];
         tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
         tt.be2 = P + t.n2.b; tt.out = x == F(w.x_b) ? F(w.x_a) : F(w.x_b);
         tt.warm = L2Warm{};  // next launch: the following layer's in_proj, or post_tfmr / the transition
         // the last layer also applies post_tfmr + the node residual (FDIPT_POST_UNFUSED: its own launch)
-        const bool post_here = l + 1 == d->tfmr_layers && cs == 256 && !getenv("FDIPT_POST_UNFUSED");
+        const bool post_here = l + 1 == d->tfmr_layers && cs == 256 && !sw.post_unfused;
         if (post_here) {
           tt.wp = D + db.ch.post; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
           post_done = true;
@@ -799,7 +841,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       r.b1 = P + k.t2.b; r.b2 = P + k.t3.b; r.residual = F(w.h_a); r.ld_res = cs; r.gamma = P + k.tln.g; r.beta = P + k.tln.b;
       r.rowmask_post = res_mask; r.out = F(w.node); r.ld_out = cs; r.bb_w = P + k.bb.w; r.bb_b = P + k.bb.b;
       r.upd_mask = F(w.dmask); r.quat = F(w.quat); r.trans = F(w.trans); r.out2 = nullptr; r.ld_out2 = r.split = 0;
-      r.hid_bf16 = nullptr;
+      r.hid_h16 = nullptr;
       if (warm_all && b < d->num_blocks - 1 && iv.cb == 128 && iv.hid == 384 && cz == 128)  // next: the EdgeTransition row launch
         r.warm = L2Warm{{D + db.ch.et_init, D + db.ch.r4w, nullptr},
                         {(unsigned)fd_chain_image_bytes(iv.cb, cs), (unsigned)fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb), 0}};
@@ -824,78 +866,60 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
     }
     if (b < d->num_blocks - 1) {
-      // bf16 default path: e = initial_embed(node) and the per-residue rows A1[i] | Af[i] in ONE row-block launch
-      // (edge_transition3 only needs e as bf16; the 32-pair kernel reads the fp32 rows)
-      const bool et_rows_fused = rbk && iv.cb == 128 && iv.hid == 384 && cz == 128 && use_et2(d) && !getenv("FDIPT_ET_V2") &&
-                                 fd_edge_transition3_supported(N);
-      // edge_transition4 (N % 4 == 0; FDIPT_ET_V3 keeps the 16-pair kernel): the same launch also produces the e_j rows
-      const bool use_et4 = et_rows_fused && !getenv("FDIPT_ET_V3") && fd_edge_transition4_supported(N);
+      // register-resident pair kernels (reference widths): e = initial_embed(node) and the per-residue rows of the concat-free
+      // layers come out of ONE row-block launch.  edge_transition4 (8 x 4-pair patches, N % 4 == 0) gets [A1 | Af | B1 | Bf] as
+      // its fold-fragment images; edge_transition3 (16-pair waves: any N >= 43) gets A1 | Af rows and e in half precision.
+      // Anything else (N < 43 with N % 4 != 0, other widths) runs the LDS-chain kernel of pair_mlp.hip.
+      const bool reg_ok = rbk && iv.cb == 128 && iv.hid == 384 && cz == 128 && use_regpair(d);
+      const bool use_et4 = reg_ok && !sw.et3 && fd_edge_transition4_supported(N);
+      const bool use_et3 = reg_ok && !use_et4 && fd_edge_transition3_supported(N);
       if (use_et4) {
         RowBlockArgs r;
         r.M = R; r.in = node_cur; r.ld_in = cs; r.w0 = D + db.ch.et_init; r.b0 = P + k.et_init.b; r.w1 = D + db.ch.r4w;
         r.b1 = (const float*)(D + db.ch.r4b); r.w2 = nullptr; r.b2 = nullptr; r.residual = nullptr; r.ld_res = 0; r.gamma = r.beta = nullptr;
         r.rowmask_post = nullptr; r.out = F(w.r4); r.ld_out = 1024; r.out2 = nullptr; r.ld_out2 = 0; r.split = 0;
-        r.hid_bf16 = nullptr; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
+        r.hid_h16 = nullptr; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
         r.img_a = W + w.a1img; r.img_b = W + w.b1img; r.img_B = B; r.img_N = N;
-        if (!getenv("FDIPT_ET4_ROWS_UNFUSED")) {  // the row-block epilogue writes the fold-fragment images itself
+        if (!sw.et4_rows_unfused) {  // the row-block epilogue writes the fold-fragment images itself
           RC(fd_rowblock(FD_RB_ET4_IMAGES, r, st));
         } else {
           RC(fd_rowblock(FD_RB_ET4_ROWS, r, st));
           RC(fd_et4_row_images(F(w.r4), B, N, W + w.a1img, W + w.b1img, st));
         }
-      } else if (et_rows_fused) {
+      } else if (use_et3) {
         RowBlockArgs r;
         r.M = R; r.in = node_cur; r.ld_in = cs; r.w0 = D + db.ch.et_init; r.b0 = P + k.et_init.b; r.w1 = D + db.ch.a1af;
         r.b1 = (const float*)(D + db.ch.b1f); r.w2 = nullptr; r.b2 = nullptr; r.residual = nullptr; r.ld_res = 0; r.gamma = r.beta = nullptr;
         r.rowmask_post = nullptr; r.out = F(w.a1); r.ld_out = iv.hid; r.out2 = F(w.af); r.ld_out2 = cz; r.split = iv.hid;
-        r.hid_bf16 = (unsigned short*)(W + w.e_bf); r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
+        r.hid_h16 = (unsigned short*)(W + w.e_bf); r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
         RC(fd_rowblock(FD_RB_ET_ROWS, r, st));
       } else if (con(FD_CHAIN_ETINIT)) {
-        chain_bf16 = (unsigned short*)(W + w.e_bf);
+        chain_h16 = (unsigned short*)(W + w.e_bf);
         RC(chain(FD_CHAIN_ETINIT, node_cur, cs, D + db.ch.et_init, P + k.et_init.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                  nullptr, nullptr, nullptr, F(w.e), iv.cb));
       } else {
         RC(lin(R, k.et_init, node_cur, cs, nullptr, 0, nullptr, 0, F(w.e), iv.cb));
-        if (bf) RC(fd_f32_to_bf16((long)R * iv.cb, F(w.e), (bf16_t*)(W + w.e_bf), st));
+        if (bf) RC(fd_f32_to_half((long)R * iv.cb, F(w.e), (half_t*)(W + w.e_bf), st));
       }
       float* tr_ptr = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
       bias_ready = false;
-      if (use_et2(d) && fd_edge_transition2_supported(N)) {
-        // per-residue parts of the concat-free layers: A1[i] = W1[:, e_i cols] e_i + b1, Af[i] = Wf[:, e_i cols] e_i + bf
-        if (et_rows_fused) {
-        } else if (con(FD_CHAIN_A1)) {
-          RC(chain(FD_CHAIN_A1, F(w.e), iv.cb, D + db.ch.a1, P + k.et1.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
-                   nullptr, nullptr, F(w.a1), iv.hid));
-          RC(chain(FD_CHAIN_AF, F(w.e), iv.cb, D + db.ch.af, P + k.etf.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
-                   nullptr, nullptr, F(w.af), cz));
-        } else {
-          RC(fd_linear(prec, R, iv.hid, iv.cb, F(w.e), iv.cb, PB + k.et1.w + cz, iv.hid, P + k.et1.b, nullptr, 0, nullptr, 0,
-                       F(w.a1), iv.hid, st));
-          RC(fd_linear(prec, R, cz, iv.cb, F(w.e), iv.cb, PB + k.etf.w + cz, iv.hid, P + k.etf.b, nullptr, 0, nullptr, 0,
-                       F(w.af), cz, st));
-        }
+      if (use_et4 || use_et3) {
         ET2Args t2;
-        t2.B = B; t2.N = N; t2.z_in = (const bf16_t*)(W + w.z); t2.z_out = (bf16_t*)(W + w.z); t2.e = F(w.e);
-        t2.e_bf16 = (const bf16_t*)(W + w.e_bf);
-        t2.a1 = F(w.a1); t2.af = F(w.af); t2.stream = D + db.et2; t2.b2 = P + k.et2.b; t2.gamma = P + k.et_ln.g;
+        t2.B = B; t2.N = N; t2.z_in = (const half_t*)(W + w.z); t2.z_out = (half_t*)(W + w.z); t2.e = F(w.e);
+        t2.e_h16 = (const half_t*)(W + w.e_bf);
+        t2.a1 = F(w.a1); t2.af = F(w.af); t2.stream = use_et4 ? D + db.et4 : D + db.et3; t2.b2 = P + k.et2.b; t2.gamma = P + k.et_ln.g;
         t2.beta = P + k.et_ln.b; t2.res_mask = res_mask; t2.trace = tr_ptr;
         // the next block's attention consumes linear_b(z') in fragment order when it runs attention3
         // (end to end +0.8 % at N = 300: the launch grows by about as much as the pair_bias2 launch it replaces, the gain
-        //  is the z re-read that disappears; FDIPT_NO_ET_BIAS restores the separate pass)
-        // FDIPT_ET_V2 selects the first-generation register kernel (32-pair waves, one wave per SIMD)
-        const bool use_et3 = !getenv("FDIPT_ET_V2") && fd_edge_transition3_supported(N);
-        const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !getenv("FDIPT_ATTN_V1") &&
-                               !getenv("FDIPT_ATTN_V2") && !getenv("FDIPT_NO_ET_BIAS") && N <= 512;
-        t2.wb_img = emit_bias ? D + (use_et4 ? L.blk[b + 1].wb_img4 : use_et3 ? L.blk[b + 1].wb_img3 : L.blk[b + 1].wb_img) : nullptr;
+        //  is the z re-read that disappears; FDIPT_KF_UNFOLDED restores the separate pass)
+        const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !sw.generic_attn && !sw.no_et_bias && N <= 512;
+        t2.wb_img = emit_bias ? D + (use_et4 ? L.blk[b + 1].wb_img4 : L.blk[b + 1].wb_img3) : nullptr;
         t2.a1_img = W + w.a1img; t2.b1_img = W + w.b1img;
         t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
         bias_ready = emit_bias;
-        if (use_et3) t2.stream = D + db.et3;
-        if (use_et4) t2.stream = D + db.et4;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
         if (use_et4) RC(fd_edge_transition4(t2, st));
-        else if (use_et3) RC(fd_edge_transition3(t2, st));
-        else RC(fd_edge_transition2(t2, st));
+        else RC(fd_edge_transition3(t2, st));
         if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
       } else {
       EdgeTransArgs ta;
@@ -925,7 +949,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(lin(R, iv.tor2, F(w.h_a), cs, node_cur, cs, nullptr, 0, F(w.h_b), cs));
   }
   // the last torsion layer (Linear(c_s, 2), fp32) rides on the score launch (FDIPT_TORF_UNFUSED: its own GEMM launch)
-  const bool torf_fused = (cs & 3) == 0 && !getenv("FDIPT_TORF_UNFUSED");
+  const bool torf_fused = (cs & 3) == 0 && !sw.torf_unfused;
   if (!torf_fused) RC(lin32(R, iv.torf, F(w.h_b), cs, F(w.psi_un), 8));
   // tensor_7 / psi epilogue, R^3 score and IGSO(3) score in one launch (frames.hip)
   RC(fd_score_tail(B, N, a->rigids_t, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask,

@@ -13,11 +13,11 @@
 
 template <class ZT>
 __device__ __forceinline__ float z_load(const ZT* p) {
-  if constexpr (sizeof(ZT) == 4) return *p; else return bf2f(*p);
+  if constexpr (sizeof(ZT) == 4) return *p; else return h2f(*p);
 }
 template <class ZT>
 __device__ __forceinline__ void z_store(ZT* p, float v) {
-  if constexpr (sizeof(ZT) == 4) *p = v; else *p = f2bf(v);
+  if constexpr (sizeof(ZT) == 4) *p = v; else *p = f2h(v);
 }
 
 // acc(32x32 per wave) = Act[TM x K] * W[n0 .. n0+TN, K]^T, Act resident in LDS, W streamed through Ws.
@@ -270,7 +270,7 @@ static int launch_et(int precision, const EdgeTransArgs& a, hipStream_t st) {
                        dim3(FD_THREADS), 0, st, a);
   } else {
     constexpr int TM = 64;
-    hipLaunchKernelGGL((edge_transition_kernel<PrecBF16, bf16_t, bf16_t, TM, 2, 2, CZ, CB>), dim3(cdiv(n_pairs, TM)),
+    hipLaunchKernelGGL((edge_transition_kernel<PrecHalf, half_t, half_t, TM, 2, 2, CZ, CB>), dim3(cdiv(n_pairs, TM)),
                        dim3(FD_THREADS), 0, st, a);
   }
   FD_CHECK_LAUNCH();
@@ -292,7 +292,7 @@ static int launch_ee(int precision, const EdgeEmbedArgs& a, hipStream_t st) {
                        dim3(FD_THREADS), 0, st, a);
   } else {
     constexpr int TM = 64;
-    hipLaunchKernelGGL((edge_embed_kernel<PrecBF16, bf16_t, bf16_t, TM, 2, 2, CZ>), dim3(cdiv(n_pairs, TM)),
+    hipLaunchKernelGGL((edge_embed_kernel<PrecHalf, half_t, half_t, TM, 2, 2, CZ>), dim3(cdiv(n_pairs, TM)),
                        dim3(FD_THREADS), 0, st, a);
   }
   FD_CHECK_LAUNCH();

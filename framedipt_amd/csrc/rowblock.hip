@@ -21,8 +21,8 @@
 
 #define RB_SROW 144       // bytes per row of a wave's 32 x 32 fp32 exchange tile
 
-typedef __bf16 rb_bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 rb_ld(const char* p) { return __builtin_bit_cast(bf16x8, *(const u16x8*)p); }
+typedef fd_h rb_hx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ hx8 rb_ld(const char* p) { return __builtin_bit_cast(hx8, *(const u16x8*)p); }
 __host__ __device__ constexpr int rb_max(int a, int b) { return a > b ? a : b; }
 
 // K0: input width (zero-padded to a multiple of 16); N1 / N2: hidden widths (0 = absent); NOUT: output width;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   // weight-fragment buffers: tile u of a wave lives in buffer u % NB; wide outputs with short K (8 tiles of 8 fragments per wave)
   // keep three tiles in flight instead of one (each tile is a dependent L2 round trip otherwise)
   constexpr int NB = (NTW >= 6 && KSMAX <= 16) ? 4 : 2;
-  bf16x8 Wf[NB][KSMAX];
+  hx8 Wf[NB][KSMAX];
   auto w_load = [&](auto BUF, auto KSC, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value, KS = decltype(KSC)::value;
 #pragma unroll
@@ -117,10 +117,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int idx = tid + k * FD_THREADS, r = idx / C4, c4 = idx % C4;
-      rb_bf16x4 pk;
+      rb_hx4 pk;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)xv[k][q];
-      if (idx < 32 * C4) *(rb_bf16x4*)(xs + r * XROW + 8 * c4) = pk;
+      for (int q = 0; q < 4; ++q) pk[q] = (fd_h)xv[k][q];
+      if (idx < 32 * C4) *(rb_hx4*)(xs + r * XROW + 8 * c4) = pk;
     }
   }
   // residual row segments of this wave's output tiles: requested now, consumed after the last MFMA
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
   __syncthreads();
 
-  bf16x8 X[KSMAX];
+  hx8 X[KSMAX];
   f32x16 acc[NTW];
   // one layer: tiles wave, wave+4, wave+8 (< NT) of `img` against the B fragments X[0..KS); the first tile's fragments
   // are already in Wf[0]
@@ -164,14 +164,14 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-          c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[s], Wf[u % NB][s], c, 0, 0, 0)
-                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u % NB][s], X[s], c, 0, 0, 0);
+          c = SWAP ? fd_mfma32(X[s], Wf[u % NB][s], c)
+                   : fd_mfma32(Wf[u % NB][s], X[s], c);
         acc[u] = c;
       }
     });
   };
   // hidden = act(acc + bias) -> bf16 -> LDS rows (natural feature order); every wave then re-reads all of it
-  auto to_hidden = [&](auto NTC, auto RELU, const float* bias, char* dst, unsigned short* hid_bf16, int hid_ld) {
+  auto to_hidden = [&](auto NTC, auto RELU, const float* bias, char* dst, unsigned short* hid_h16, int hid_ld) {
     constexpr int NT = decltype(NTC)::value;
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
@@ -181,15 +181,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
         for (int g = 0; g < 4; ++g) {
           const int f0 = 32 * T + 8 * g + 4 * hi;
           const f32x4 bv = *(const f32x4*)(bias + f0);
-          rb_bf16x4 pk;
+          rb_hx4 pk;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v = acc[u][4 * g + q] + bv[q];
             if (decltype(RELU)::value) v = fmaxf(v, 0.f);
-            pk[q] = (__bf16)v;
+            pk[q] = (fd_h)v;
           }
-          *(rb_bf16x4*)(dst + li * XROW + 2 * f0) = pk;
-          if (hid_bf16 && row0 + li < a.M) *(rb_bf16x4*)(hid_bf16 + (long)(row0 + li) * hid_ld + f0) = pk;  // optional bf16 copy of the rows
+          *(rb_hx4*)(dst + li * XROW + 2 * f0) = pk;
+          if (hid_h16 && row0 + li < a.M) *(rb_hx4*)(hid_h16 + (long)(row0 + li) * hid_ld + f0) = pk;  // optional bf16 copy of the rows
         }
       }
     }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   } else {
     layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0], std::false_type{});
     w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N1 / 16>{}, wimg[1], wave);  // in flight across the barrier
-    to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs, a.hid_bf16, N1);
+    to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs, a.hid_h16, N1);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < N1 / 16; ++s) X[s] = rb_ld(hs + li * XROW + 32 * s + 16 * hi);
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     static_assert(NL == 2 && NOUT == 1024, "ET4 image kind");
     const float* bo = cst + N1 + N2;
     const int NJ4 = a.img_N >> 2;
-    bf16_t* ia = (bf16_t*)a.img_a;
-    bf16_t* ib = (bf16_t*)a.img_b;
+    half_t* ia = (half_t*)a.img_a;
+    half_t* ib = (half_t*)a.img_b;
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
       const int T = wave + 4 * u;
@@ -236,12 +236,12 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       for (int g = 0; g < 4; ++g) {
         const int r0 = row0 + 8 * g + 4 * hi;  // rows r0 .. r0 + 3 (M % 4 == 0: all four valid or none)
         u16x4 o = {0, 0, 0, 0};
-        if (r0 < a.M) o = u16x4{f2bf(acc[u][4 * g] + bv), f2bf(acc[u][4 * g + 1] + bv), f2bf(acc[u][4 * g + 2] + bv), f2bf(acc[u][4 * g + 3] + bv)};
+        if (r0 < a.M) o = u16x4{f2h(acc[u][4 * g] + bv), f2h(acc[u][4 * g + 1] + bv), f2h(acc[u][4 * g + 2] + bv), f2h(acc[u][4 * g + 3] + bv)};
         if (T < 16) {
           if ((r0 >> 3) < ((a.M + 7) >> 3)) *(u16x4*)(ia + ((((long)(r0 >> 3) * 16 + T) * 32 + li) << 3) + (r0 & 4)) = o;  // (rows beyond M: zeros; the image is padded to 8 rows)
         } else if (r0 < a.M) {
           const int b = r0 / a.img_N, jt = (r0 - b * a.img_N) >> 2, ft = T - 16;
-          bf16_t* dst = ib + ((((long)b * NJ4 + jt) * 16 + ft) * 32 + li) * 8;
+          half_t* dst = ib + ((((long)b * NJ4 + jt) * 16 + ft) * 32 + li) * 8;
           *(u16x4*)dst = o;
           if (b > 0) *(u16x4*)(dst - (long)NJ4 * 16 * 32 * 8 + 4) = o;
           if (b == a.img_B - 1) *(u16x4*)(dst + 4) = u16x4{0, 0, 0, 0};
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   const int row0 = blockIdx.x * 32;
   char* stg = st_all + wave * 32 * RB_SROW;
   FD_STAMP(0);
-  bf16x8 Wf[2][TL_KS];
+  hx8 Wf[2][TL_KS];
   auto w_load = [&](auto BUF, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value;
 #pragma unroll
@@ -425,10 +425,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
-      rb_bf16x4 pk;
+      rb_hx4 pk;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = (__bf16)xv[k][q];
-      *(rb_bf16x4*)(xs + r * TL_XROW + 8 * c4) = pk;
+      for (int q = 0; q < 4; ++q) pk[q] = (fd_h)xv[k][q];
+      *(rb_hx4*)(xs + r * TL_XROW + 8 * c4) = pk;
     }
   }
   f32x4 rv[3][4];  // residual x: row segments of this wave's tiles
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
   __syncthreads();
   FD_STAMP(1);
-  bf16x8 X[TL_KS];
+  hx8 X[TL_KS];
   f32x16 acc[3], xa[3];
   auto layer = [&](const char* img) {
 #pragma unroll
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < TL_KS; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
+        for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[u & 1][s], X[s], c);
         acc[u] = c;
       }
     }
@@ -541,10 +541,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * T + 8 * g + 4 * hi;
-        rb_bf16x4 pk;
+        rb_hx4 pk;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = (__bf16)acc[u][4 * g + q];
-        *(rb_bf16x4*)(hs + li * TL_XROW + 2 * f0) = pk;
+        for (int q = 0; q < 4; ++q) pk[q] = (fd_h)acc[u][4 * g + q];
+        *(rb_hx4*)(hs + li * TL_XROW + 2 * f0) = pk;
       }
   }
   __syncthreads();
@@ -563,10 +563,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * T + 8 * g + 4 * hi;
         const f32x4 bv = *(const f32x4*)(cst + 3 * TL_D + f0);
-        rb_bf16x4 pk;
+        rb_hx4 pk;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = (__bf16)fmaxf(acc[u][4 * g + q] + bv[q], 0.f);
-        *(rb_bf16x4*)(xs + li * TL_XROW + 2 * f0) = pk;   // the att rows are dead: every wave read them before LayerNorm1's barriers
+        for (int q = 0; q < 4; ++q) pk[q] = (fd_h)fmaxf(acc[u][4 * g + q] + bv[q], 0.f);
+        *(rb_hx4*)(xs + li * TL_XROW + 2 * f0) = pk;   // the att rows are dead: every wave read them before LayerNorm1's barriers
       }
   }
   __syncthreads();
@@ -598,10 +598,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int f0 = 32 * T + 8 * g + 4 * hi;
-          rb_bf16x4 pk;
+          rb_hx4 pk;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) pk[q] = (__bf16)acc[u][4 * g + q];
-          *(rb_bf16x4*)(hs + li * TL_XROW + 2 * f0) = pk;   // the x_a rows are dead since stage 2 read them
+          for (int q = 0; q < 4; ++q) pk[q] = (fd_h)acc[u][4 * g + q];
+          *(rb_hx4*)(hs + li * TL_XROW + 2 * f0) = pk;   // the x_a rows are dead since stage 2 read them
         }
     }
     __syncthreads();
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < TL_KS; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[u & 1][s], X[s], c, 0, 0, 0);
+      for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[u & 1][s], X[s], c);
       acc[u] = c;
     }
 #pragma unroll

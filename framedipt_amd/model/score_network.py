@@ -16,11 +16,15 @@ import torch
 from .. import _lib, embedding, residue_tables, weights
 
 
-def dims_from_conf(model_conf, diffuser_conf, inpainting: bool, precision: int) -> _lib.Dims:
+PRECISIONS = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16,
+              "bf16": _lib.PREC_BF16}  # bf16: only with a library built with -DFDIPT_HALF_BF16
+
+
+def dims_from_conf(model_conf, diffuser_conf, inpainting: bool, precision: int, kernel_flags: int = 0) -> _lib.Dims:
     i, e = model_conf.ipa, model_conf.embed
     return _lib.Dims(i.c_s, i.c_z, i.c_hidden, i.c_skip, i.no_heads, i.no_qk_points, i.no_v_points,
                      i.seq_tfmr_num_heads, i.seq_tfmr_num_layers, i.num_blocks, e.index_embed_size, e.num_bins,
-                     int(bool(inpainting or model_conf.input_aatype)), precision, float(e.min_bin), float(e.max_bin),
+                     int(bool(inpainting or model_conf.input_aatype)), precision, kernel_flags, float(e.min_bin), float(e.max_bin),
                      float(i.coordinate_scaling), float(diffuser_conf.r3.min_b), float(diffuser_conf.r3.max_b))
 
 
@@ -98,12 +102,15 @@ class BatchState:
 
 
 class ScoreNetwork:
-    def __init__(self, model_conf, diffuser, inpainting: bool = False, precision: str = "fp32", device=None):
+    def __init__(self, model_conf, diffuser, inpainting: bool = False, precision: str = "fp32", device=None,
+                 kernel_flags: int = 0):
+        """``precision``: "fp32" (exact fp32 FMA chains, any width) or "fp16" (fp16 MFMA operands and pair representation,
+        fp32 accumulation / frames / statistics: the throughput mode).  ``kernel_flags``: ``_lib.KF_*`` bits."""
         self._model_conf = model_conf
         self.diffuser = diffuser
         self.inpainting = inpainting
-        self.precision = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[precision]
-        self.dims = dims_from_conf(model_conf, diffuser._se3_conf, inpainting, self.precision)
+        self.precision = PRECISIONS[precision]
+        self.dims = dims_from_conf(model_conf, diffuser._se3_conf, inpainting, self.precision, kernel_flags)
         self.shapes = weights.param_shapes(model_conf, inpainting)
         self.device = torch.device(device) if device is not None else None
         self.params = self.derived = self.bb_tables = None

@@ -31,7 +31,21 @@ extern "C" {
 
 /* GEMM operand precision of the score network (accumulation is always fp32). */
 #define FDIPT_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32, parity mode               */
-#define FDIPT_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, pair rep kept in bf16 */
+#define FDIPT_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, pair rep kept in bf16.  Only in a library built
+                             with -DFDIPT_HALF_BF16 (development comparison); the default build answers FDIPT_EINVAL */
+#define FDIPT_PREC_F16 2  /* v_mfma_f32_32x32x16_f16: fp16 operands (11 significant bits, same MFMA rate as bf16), pair
+                             rep kept in fp16; frames, points, softmax statistics, LayerNorm and scores stay fp32/fp64.
+                             Throughput mode of the default build */
+
+/* FdiptDims.kernel_flags: run a fallback path of the half-precision mode at shapes where the default selection would not
+ * (each of them is what some other shape uses anyway; parity tests run them at the golden sizes).  Same flags for
+ * fdipt_model_prepare and every forward of a model. */
+#define FDIPT_KF_ET3 1           /* EdgeTransition: the 16-pair-wave kernel (default for N % 4 != 0) for every N >= 43   */
+#define FDIPT_KF_GENERIC_PAIR 2  /* EdgeTransition / edge embedder: the any-width LDS-chain kernels                      */
+#define FDIPT_KF_GENERIC_ATTN 4  /* attention: the LDS-score kernels (default for N > 512) for every N                  */
+#define FDIPT_KF_UNFUSED_NODE 8  /* node path as plain GEMM + LayerNorm launches (default for non-reference widths)     */
+#define FDIPT_KF_UNFOLDED 16     /* launch folds off: pair bias / feature split / torsion head / fills as own launches  */
+#define FDIPT_KF_ALL 31
 
 typedef void* fdipt_stream_t; /* hipStream_t */
 
@@ -52,6 +66,7 @@ typedef struct FdiptDims {
   int32_t num_bins;    /* embed.num_bins                       (22)  */
   int32_t use_aatype;  /* 1: node features carry a 21-way aatype one-hot (inpainting / input_aatype) */
   int32_t precision;   /* FDIPT_PREC_*                                                    */
+  int32_t kernel_flags; /* FDIPT_KF_* bits; 0 = default kernel selection                  */
   float min_bin;       /* embed.min_bin (1e-5) */
   float max_bin;       /* embed.max_bin (20)   */
   float coordinate_scaling; /* ipa.coordinate_scaling = diffuser.r3.coordinate_scaling (0.1) */
@@ -181,7 +196,7 @@ int fdipt_backbone_atoms(int n, const float* t7, const float* rot, const float* 
 /* ---------------------------------------------------------------- building blocks ---------- */
 /* Exposed for parity tests and for callers that assemble their own network. */
 /* out[M,N] = epilogue(A[M,K] W[N,K]^T + bias): relu, +residual, *rowmask.  K % 8 == 0, lda/ldw in elements.
- * W is fp32 (precision F32) or bf16 (precision BF16, as produced by fdipt_model_prepare). */
+ * W is fp32 (precision F32) or the half-precision operand type (F16 / BF16, as produced by fdipt_model_prepare). */
 int fdipt_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
                  const float* residual, int ldr, const float* rowmask, int relu, float* out, int ldo, fdipt_stream_t s);
 int fdipt_layernorm(int M, int D, const float* x, const float* residual, const float* gamma, const float* beta,

@@ -23,7 +23,7 @@ def dev(x, dtype=None):
 
 
 def test_mfma_fragment_maps(lib):
-    for prec, tol in ((0, 2e-4), (1, 0.35)):
+    for prec, tol in ((0, 2e-4), (2, 0.05)):
         err = C.c_double(-1)
         assert lib.fdipt_selftest_mfma(prec, C.byref(err)) == 0
         assert 0 <= err.value < tol, (prec, err.value)
@@ -156,12 +156,12 @@ def _conf(name):
     return (config.small_config(inp) if name.startswith("small") else config.base_config(inp)), inp
 
 
-def _net(name, G, precision):
+def _net(name, G, precision, kernel_flags=0):
     from framedipt_amd.diffusion import SE3Diffuser
     from framedipt_amd.model import ScoreNetwork
     conf, inp = _conf(name)
     d = SE3Diffuser(conf.diffuser)
-    net = ScoreNetwork(conf.model, d, inpainting=inp, precision=precision)
+    net = ScoreNetwork(conf.model, d, inpainting=inp, precision=precision, kernel_flags=kernel_flags)
     net.load_synthetic(int(G["weight_seed"]), float(G["bb_gain"])).to("cuda")
     return net, d, conf
 
@@ -202,10 +202,10 @@ def test_forward_fp32_vs_reference_goldens(name):
 
 
 @pytest.mark.parametrize("name", ["small_denovo_n16", "full_denovo_n64"])
-def test_forward_bf16_vs_reference_goldens(name):
-    """bf16 GEMM operands / bf16 pair representation: separate (looser) tolerance, stated here."""
+def test_forward_fp16_vs_reference_goldens(name):
+    """fp16 GEMM operands / fp16 pair representation: separate (looser) tolerance, stated here."""
     G = load_golden(f"fwd_{name}.npz")
-    net, _, conf = _net(name, G, "bf16")
+    net, _, conf = _net(name, G, "fp16")
     out = net(_feats(G), trace=True)
     tn = out["trace_node"].cpu().numpy()
     nb = conf.model.ipa.num_blocks
@@ -267,13 +267,13 @@ def test_teacher_forced_steps_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["small_denovo_n16_T10", "full_denovo_n64_T20"])
-def test_teacher_forced_steps_bf16(name):
-    """The throughput mode (bf16 operands / bf16 pair representation) on the same per-step measure.  The frames of x_{t-1} move
-    little (the score enters scaled by dt), but the backbone oxygen is placed by the psi angle the forward predicts, whose bf16
+def test_teacher_forced_steps_fp16(name):
+    """The throughput mode (fp16 operands / fp16 pair representation) on the same per-step measure.  The frames of x_{t-1} move
+    little (the score enters scaled by dt), but the backbone oxygen is placed by the psi angle the forward predicts, whose fp16
     error (~1e-2 rad) moves it by ~3e-2 A in every step: 5e-3 .. 1.2e-2 A backbone RMSD measured (printed with -s), bound 2e-2 A
     stated here.  The 1e-3 A bar of the north star is the fp32 mode's (test above)."""
-    worst, worst_noisy = _teacher_forced_worst_rmsd(name, "bf16")
-    print(f"bf16 teacher-forced per-step backbone RMSD {name}: reverse steps {worst_noisy:.3e} A, final x_0 step {worst:.3e} A")
+    worst, worst_noisy = _teacher_forced_worst_rmsd(name, "fp16")
+    print(f"fp16 teacher-forced per-step backbone RMSD {name}: reverse steps {worst_noisy:.3e} A, final x_0 step {worst:.3e} A")
     assert worst_noisy < 2e-2 and worst < 2e-2, (worst_noisy, worst)
 
 
@@ -301,100 +301,77 @@ def test_fails_loudly_on_cpu_tensors():
 
 
 def test_edge_transition_register_kernel_vs_lds_kernel():
-    """bf16 EdgeTransition: the three register-resident kernels (edge_transition4.hip: 8x4-pair patches with the e_i / e_j
-    parts folded into one k-step, default for N % 4 == 0; edge_transition3.hip: 16-pair waves, FDIPT_ET_V3;
-    edge_transition2.hip: 32-pair waves, FDIPT_ET_V2) vs the LDS-chain kernel (pair_mlp.hip, FDIPT_ET_V1) on the
-    full-width network, and all four against the fp32 reference golden."""
-    import os
+    """Half-precision EdgeTransition: the two register-resident kernels (edge_transition4.hip: 8x4-pair patches with the
+    e_i / e_j parts folded into one k-step, default for N % 4 == 0; edge_transition3.hip: 16-pair waves, the N % 4 != 0
+    path, here forced with FDIPT_KF_ET3) vs the any-width LDS-chain kernel (pair_mlp.hip, FDIPT_KF_GENERIC_PAIR) on the
+    full-width network, and all three against the fp32 reference golden."""
+    from framedipt_amd import _lib
     G = load_golden("fwd_full_denovo_n64.npz")
     rows = list(G["trace_rows"])
     outs = {}
-    for tag, var in (("v4", None), ("v3", "FDIPT_ET_V3"), ("v2", "FDIPT_ET_V2"), ("v1", "FDIPT_ET_V1")):
-        for v in ("FDIPT_ET_V1", "FDIPT_ET_V2", "FDIPT_ET_V3"):
-            os.environ.pop(v, None)
-        if var:
-            os.environ[var] = "1"
-        try:
-            net, _, conf = _net("full_denovo_n64", G, "bf16")
-            out = net(_feats(G), trace=True)
-            outs[tag] = out["trace_edge"].cpu().numpy().copy()
-        finally:
-            for v in ("FDIPT_ET_V1", "FDIPT_ET_V2", "FDIPT_ET_V3"):
-                os.environ.pop(v, None)
-    for tag in ("v1", "v2", "v3", "v4"):  # edge embedder (trace slot 0): edge_embed2_kernel vs edge_embed_kernel
+    for tag, kf in (("v4", 0), ("v3", _lib.KF_ET3), ("v1", _lib.KF_GENERIC_PAIR)):
+        net, _, conf = _net("full_denovo_n64", G, "fp16", kf)
+        out = net(_feats(G), trace=True)
+        outs[tag] = out["trace_edge"].cpu().numpy().copy()
+    for tag in outs:  # edge embedder (trace slot 0): edge_embed2_kernel vs edge_embed_kernel
         rel = np.linalg.norm(outs[tag][0][:, rows] - G["tr_edge_init"]) / np.linalg.norm(G["tr_edge_init"])
-        assert rel < 1e-2, (tag, "embed", rel)
-    assert np.linalg.norm(outs["v1"][0] - outs["v3"][0]) / np.linalg.norm(outs["v1"][0]) < 1e-2
+        assert rel < 2e-3, (tag, "embed", rel)
+    assert np.linalg.norm(outs["v1"][0] - outs["v3"][0]) / np.linalg.norm(outs["v1"][0]) < 2e-3
     for b in range(3):
         ref = G[f"tr_edge_{b}"]
-        for tag in ("v1", "v2", "v3", "v4"):
+        for tag in outs:
             got = outs[tag][b + 1][:, rows]
             rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
-            assert rel < 2e-2, (tag, b, rel)
-        for tag in ("v2", "v3", "v4"):
+            assert rel < 3e-3, (tag, b, rel)
+        for tag in ("v3", "v4"):
             a, c = outs["v1"][b + 1], outs[tag][b + 1]
-            assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-2, (tag, b)
+            assert np.linalg.norm(a - c) / np.linalg.norm(a) < 3e-3, (tag, b)
 
 
 def test_fused_paths_vs_separate_launches():
-    """bf16 node path with every fusion of the default path switched off (row-block kernels, split-K output projection,
-    pair bias from the EdgeTransition epilogue) vs the default: same representation after every block."""
-    import os
+    """Half-precision node path with the fusions of the default path switched off (FDIPT_KF_UNFUSED_NODE: plain GEMM +
+    LayerNorm launches instead of the row-block kernels / split-K output projection; FDIPT_KF_UNFOLDED: pair bias,
+    feature split, torsion head and fills as their own launches) vs the default: same representation after every block."""
+    from framedipt_amd import _lib
     G = load_golden("fwd_full_denovo_n64.npz")
     outs = {}
-    switches = ("FDIPT_NO_ROWBLOCK", "FDIPT_NO_SPLITK", "FDIPT_NO_ET_BIAS")
-    for tag, on in (("fused", False), ("plain", True)):
-        for v in switches:
-            os.environ.pop(v, None)
-            if on:
-                os.environ[v] = "1"
-        try:
-            net, _, conf = _net("full_denovo_n64", G, "bf16")
-            out = net(_feats(G), trace=True)
-            outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["rigids"].cpu().numpy().copy(),
-                         out["psi"].cpu().numpy().copy())
-        finally:
-            for v in switches:
-                os.environ.pop(v, None)
-    for b in range(5):
-        a, c = outs["plain"][0][b], outs["fused"][0][b]
-        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, b
-    np.testing.assert_allclose(outs["plain"][1][..., 4:], outs["fused"][1][..., 4:], atol=2e-2)
-    np.testing.assert_allclose(outs["plain"][2], outs["fused"][2], atol=3e-2)
+    for tag, kf in (("fused", 0), ("plain", _lib.KF_UNFUSED_NODE | _lib.KF_UNFOLDED), ("unfolded", _lib.KF_UNFOLDED)):
+        net, _, conf = _net("full_denovo_n64", G, "fp16", kf)
+        out = net(_feats(G), trace=True)
+        outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["rigids"].cpu().numpy().copy(),
+                     out["psi"].cpu().numpy().copy())
+    for tag in ("plain", "unfolded"):
+        for b in range(5):
+            a, c = outs[tag][0][b], outs["fused"][0][b]
+            assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-3, (tag, b)
+        np.testing.assert_allclose(outs[tag][1][..., 4:], outs["fused"][1][..., 4:], atol=3e-3)
+        np.testing.assert_allclose(outs[tag][2], outs["fused"][2], atol=5e-3)
 
 
 def test_register_attention_vs_lds_attention():
-    """bf16 attention kernels of attention2.hip (scores in registers) vs attention.hip (scores in LDS): node
-    representation after every block on the full-width network."""
-    import os
+    """Half-precision attention: attention3.hip / attention_seq.hip (scores in registers, N <= 512) vs the LDS-score kernels
+    of attention.hip (the N > 512 path, here forced with FDIPT_KF_GENERIC_ATTN): node representation after every block on
+    the full-width network."""
+    from framedipt_amd import _lib
     G = load_golden("fwd_full_denovo_n64.npz")
     outs = {}
-    for tag, var in (("v3", None), ("v2", "FDIPT_ATTN_V2"), ("v1", "FDIPT_ATTN_V1")):
-        for v in ("FDIPT_ATTN_V1", "FDIPT_ATTN_V2"):
-            os.environ.pop(v, None)
-        if var:
-            os.environ[var] = "1"
-        try:
-            net, _, conf = _net("full_denovo_n64", G, "bf16")
-            out = net(_feats(G), trace=True)
-            outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["rigids"].cpu().numpy().copy())
-        finally:
-            for v in ("FDIPT_ATTN_V1", "FDIPT_ATTN_V2"):
-                os.environ.pop(v, None)
-    for tag in ("v2", "v3"):
-        for b in range(4):
-            a, c = outs["v1"][0][b + 1], outs[tag][0][b + 1]
-            assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, (tag, b)
-            ref = G[f"tr_node_{b}"]
-            assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, (tag, b)
-        np.testing.assert_allclose(outs["v1"][1][..., 4:], outs[tag][1][..., 4:], atol=2e-2)
+    for tag, kf in (("v3", 0), ("v1", _lib.KF_GENERIC_ATTN)):
+        net, _, conf = _net("full_denovo_n64", G, "fp16", kf)
+        out = net(_feats(G), trace=True)
+        outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["rigids"].cpu().numpy().copy())
+    for b in range(4):
+        a, c = outs["v1"][0][b + 1], outs["v3"][0][b + 1]
+        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 2e-3, b
+        ref = G[f"tr_node_{b}"]
+        assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 4e-3, b
+    np.testing.assert_allclose(outs["v1"][1][..., 4:], outs["v3"][1][..., 4:], atol=3e-3)
 
 
-@pytest.mark.parametrize("n,B,prec,inp", [(128, 2, "bf16", False), (450, 1, "bf16", True), (800, 1, "bf16", False),
-                                          (1000, 1, "fp32", True), (77, 3, "bf16", False), (301, 2, "bf16", False),
-                                          (45, 2, "bf16", False)])
+@pytest.mark.parametrize("n,B,prec,inp", [(128, 2, "fp16", False), (450, 1, "fp16", True), (800, 1, "fp16", False),
+                                          (1000, 1, "fp32", True), (77, 3, "fp16", False), (301, 2, "fp16", False),
+                                          (45, 2, "fp16", False)])
 def test_baseline_config_shapes_run(n, B, prec, inp):
-    """BASELINE.json configs (N=128 de novo bf16, N~450 / ~800 TCR-like, N=1000 fp32 inpainting) and ragged sizes (N not
+    """BASELINE.json configs (N=128 de novo fp16, N~450 / ~800 TCR-like, N=1000 fp32 inpainting) and ragged sizes (N not
     a multiple of 4 / 32, batches whose 32-row blocks straddle samples): two reverse steps run through every kernel
     variant these sizes select; outputs finite, frames orthonormal, motif kept fixed."""
     from framedipt_amd import config, inference
@@ -435,9 +412,9 @@ def test_baseline_config_shapes_run(n, B, prec, inp):
 
 
 @pytest.mark.parametrize("n,B", [(77, 3), (301, 2), (129, 4), (44, 3), (100, 2), (300, 2)])
-def test_forward_bf16_vs_fp32_path_ragged_sizes(n, B):
+def test_forward_fp16_vs_fp32_path_ragged_sizes(n, B):
     """Ragged shapes (N not a multiple of 4 / 32; 32-row blocks, 128-pair tiles and key tiles that straddle samples and
-    padded keys; N % 8 == 4: the 8 x 4 patches of edge_transition4 straddle two samples): the bf16 kernels against the
+    padded keys; N % 8 == 4: the 8 x 4 patches of edge_transition4 straddle two samples): the fp16 kernels against the
     fp32 path of the same network (itself pinned to the reference goldens)."""
     from framedipt_amd import config
     from framedipt_amd.diffusion import SE3Diffuser
@@ -454,49 +431,23 @@ def test_forward_bf16_vs_fp32_path_ragged_sizes(n, B):
     if "sc_ca_t" not in feats:
         feats["sc_ca_t"] = torch.zeros(B, n, 3, device="cuda")
     outs = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "fp16"):
         net = ScoreNetwork(conf.model, d, inpainting=False, precision=prec).load_synthetic(11).to("cuda")
         out = net(feats, trace=True)
         outs[prec] = {k: v.cpu().numpy().copy() for k, v in out.items()}
-    tn32, tn16 = outs["fp32"]["trace_node"], outs["bf16"]["trace_node"]
+    tn32, tn16 = outs["fp32"]["trace_node"], outs["fp16"]["trace_node"]
     for b in range(1, tn32.shape[0]):
         rel = np.linalg.norm(tn16[b] - tn32[b]) / np.linalg.norm(tn32[b])
         assert rel < 3e-2, (b, rel)
-    te32, te16 = outs["fp32"]["trace_edge"], outs["bf16"]["trace_edge"]
+    te32, te16 = outs["fp32"]["trace_edge"], outs["fp16"]["trace_edge"]
     for b in range(te32.shape[0]):  # edge embedder, then the EdgeTransition of every block but the last
         rel = np.linalg.norm(te16[b] - te32[b]) / np.linalg.norm(te32[b])
         assert rel < 3e-2, ("edge", b, rel)
-    np.testing.assert_allclose(outs["bf16"]["rigids"][..., 4:], outs["fp32"]["rigids"][..., 4:], atol=5e-2)
+    np.testing.assert_allclose(outs["fp16"]["rigids"][..., 4:], outs["fp32"]["rigids"][..., 4:], atol=5e-2)
     # psi is the unit vector of a small 2-vector (ill-conditioned where its norm is tiny): bound the outlier fraction
-    bad = np.abs(outs["bf16"]["psi"] - outs["fp32"]["psi"]).max(-1) > 0.1
+    bad = np.abs(outs["fp16"]["psi"] - outs["fp32"]["psi"]).max(-1) > 0.1
     assert bad.mean() < 0.05, bad.mean()
-    assert kabsch_free_rmsd(outs["bf16"]["atom37"], outs["fp32"]["atom37"]) < 0.1
-
-
-def test_fused_node_chains_vs_gemm_path():
-    """bf16 node path: every fused chain kind (chain.hip, FDIPT_CHAIN_MASK=0xfff: also the kinds that are off by
-    default) vs separate GEMM + LayerNorm launches (FDIPT_NO_CHAIN)."""
-    import os
-    G = load_golden("fwd_full_denovo_n64.npz")
-    outs = {}
-    for tag, env in (("chain", {"FDIPT_CHAIN_MASK": "0xfff"}), ("gemm", {"FDIPT_NO_CHAIN": "1"})):
-        for k in ("FDIPT_NO_CHAIN", "FDIPT_CHAIN_MASK"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        try:
-            net, _, conf = _net("full_denovo_n64", G, "bf16")
-            out = net(_feats(G), trace=True)
-            outs[tag] = (out["trace_node"].cpu().numpy().copy(), out["psi"].cpu().numpy().copy())
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
-    for b in range(5):
-        a, c = outs["gemm"][0][b], outs["chain"][0][b]
-        assert np.linalg.norm(a - c) / np.linalg.norm(a) < 1.5e-2, b
-        if b > 0:
-            ref = G[f"tr_node_{b - 1}"]
-            assert np.linalg.norm(c - ref) / np.linalg.norm(ref) < 3e-2, b
-    np.testing.assert_allclose(outs["gemm"][1], outs["chain"][1], atol=3e-2)
+    assert kabsch_free_rmsd(outs["fp16"]["atom37"], outs["fp32"]["atom37"]) < 0.1
 
 
 def test_reverse_step_blocks_and_fused_atoms():
@@ -552,33 +503,12 @@ def test_rot_score_batched_vs_per_sample(N):
     assert torch.isfinite(full).all()
 
 
-def test_launch_folds_vs_separate_launches():
-    """Default forward (x_t split / first edge-embedder halves in the feature kernel, once-per-forward fills in one launch, last
-    torsion layer and R^3 score in the score launch, skip_embed of all blocks in one GEMM, CA hand-over) vs the same forward with
-    every fold switched off."""
-    import os
+def test_ca_hand_over_of_the_forward():
+    """The forward's own hand-over of the predicted CA positions (self-conditioning input of the next step)."""
+    from framedipt_amd import inference as inf
     G = load_golden("fwd_full_denovo_n64.npz")
-    switches = ("FDIPT_FEATS_UNFUSED", "FDIPT_TORF_UNFUSED", "FDIPT_INIT_UNFUSED", "FDIPT_SKIP_PER_BLOCK")
-    outs = {}
-    for tag, on in (("fold", False), ("plain", True)):
-        for v in switches:
-            os.environ.pop(v, None)
-            if on:
-                os.environ[v] = "1"
-        try:
-            net, _, conf = _net("full_denovo_n64", G, "bf16")
-            f = _feats(G)
-            out = net(f)
-            outs[tag] = {k: out[k].cpu().numpy().copy() for k in ("rigids", "psi", "rot_score", "trans_score", "atom37")}
-            if not on:  # the forward's own hand-over of the predicted CA positions (self-conditioning input of the next step)
-                from framedipt_amd import inference as inf
-                loop = inf.ReverseLoop(net, _, f, num_t=10, min_t=0.01, noise_scale=0.1)
-                before = loop.sc_ca.clone()
-                loop.prime()
-                assert torch.equal(loop.sc_ca, loop.st.rigids[..., 4:]) and not torch.equal(loop.sc_ca, before)
-        finally:
-            for v in switches:
-                os.environ.pop(v, None)
-    for k in outs["fold"]:
-        a, c = outs["plain"][k], outs["fold"][k]
-        np.testing.assert_allclose(c, a, atol=2e-3 * max(1.0, np.abs(a).max()), err_msg=k)
+    net, d, conf = _net("full_denovo_n64", G, "fp16")
+    loop = inf.ReverseLoop(net, d, _feats(G), num_t=10, min_t=0.01, noise_scale=0.1)
+    before = loop.sc_ca.clone()
+    loop.prime()
+    assert torch.equal(loop.sc_ca, loop.st.rigids[..., 4:]) and not torch.equal(loop.sc_ca, before)

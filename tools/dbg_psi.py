@@ -8,7 +8,7 @@ from test_gpu_parity import _net, _feats, load_golden, kabsch_free_rmsd
 
 for gname in ("fwd_full_denovo_n64.npz",):
     G = load_golden(gname)
-    variants = {"fp32": ("fp32", {}), "bf16": ("bf16", {})}  # (an fp32 torsion head alone: psi error -25 %; the node representation dominates)
+    variants = {"fp32": ("fp32", {}), "fp16": ("fp16", {})}  # (an fp32 torsion head alone: psi error -25 %; the node representation dominates)
     for tag, (prec, env) in variants.items():
         os.environ.pop("FDIPT_TORSION_F32", None)
         os.environ.update(env)

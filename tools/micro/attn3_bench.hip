@@ -5,14 +5,14 @@
 #include <vector>
 int main(int argc, char** argv) {
   const int B = 8, H = 8, N = argc > 1 ? atoi(argv[1]) : 300, Np = (N + 31) / 32 * 32;
-  Attn3Args a; a.probs_bf16 = nullptr; a.out_bf16 = nullptr;
+  Attn3Args a; a.probs_h16 = nullptr; a.out_h16 = nullptr;
   a.B = B; a.N = N; a.H = H; a.Np = Np;
   auto dz = [](size_t bytes) { void* p; (void)hipMalloc(&p, bytes); (void)hipMemset(p, 0, bytes); return p; };
-  a.Qb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2); a.Kb = (const bf16_t*)dz((size_t)B * H * N * 256 * 2);
-  a.Vt = (const bf16_t*)dz((size_t)B * H * 256 * Np * 2); a.bias = (const float*)dz((size_t)B * H * Np * Np * 4);
+  a.Qb = (const half_t*)dz((size_t)B * H * N * 256 * 2); a.Kb = (const half_t*)dz((size_t)B * H * N * 256 * 2);
+  a.Vt = (const half_t*)dz((size_t)B * H * 256 * Np * 2); a.bias = (const float*)dz((size_t)B * H * Np * Np * 4);
   a.res_mask = (const float*)dz((size_t)B * N * 4); a.qp = (const float*)dz((size_t)B * N * H * 24 * 4);
   a.kp = (const float*)dz((size_t)B * N * H * 24 * 4); a.vp = (const float*)dz((size_t)B * N * H * 36 * 4);
-  a.vpt = (const bf16_t*)dz((size_t)B * H * 96 * Np * 2);
+  a.vpt = (const half_t*)dz((size_t)B * H * 96 * Np * 2);
   a.gamma = (const float*)dz(64); a.rot = (const float*)dz((size_t)B * N * 9 * 4); a.trans = (const float*)dz((size_t)B * N * 3 * 4);
   a.probs = (float*)dz((size_t)B * H * N * N * 4); a.out_ld = 2432; a.out = (float*)dz((size_t)B * N * a.out_ld * 4); a.pt_off = H * 256;
   if (!fd_attention3_supported(a)) { printf("unsupported\n"); return 1; }

@@ -6,7 +6,7 @@
 int main(int argc, char** argv) {
   const int B = 8, N = argc > 1 ? atoi(argv[1]) : 300;
   const long P = (long)B * N * N, R = (long)B * N;
-  bf16_t* z; float *e, *a1, *af, *b2, *g, *bt, *rm; void* stream;
+  half_t* z; float *e, *a1, *af, *b2, *g, *bt, *rm; void* stream;
   (void)hipMalloc(&z, P * 128 * 2); (void)hipMalloc(&e, R * 128 * 4); (void)hipMalloc(&a1, R * 384 * 4); (void)hipMalloc(&af, R * 128 * 4);
   (void)hipMalloc(&b2, 384 * 4); (void)hipMalloc(&g, 128 * 4); (void)hipMalloc(&bt, 128 * 4); (void)hipMalloc(&rm, R * 4);
   (void)hipMalloc(&stream, fd_et4_stream_bytes());
@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
   ET2Args a; a.B = B; a.N = N; a.z_in = z; a.z_out = z; a.e = e; a.a1 = a1; a.af = af; a.stream = stream; a.b2 = b2; a.gamma = g;
   a.beta = bt; a.res_mask = rm; a.trace = nullptr;
   { char* ai; const size_t na = fd_et4_a_image_bytes(B, N), nb = fd_et4_b_image_bytes(B, N);  // one allocation: 32-bit offsets between the images
-    (void)hipMalloc(&ai, na + nb); (void)hipMemset(ai, 0, na + nb); a.a1_img = ai; a.b1_img = ai + na; a.e_bf16 = nullptr; }
+    (void)hipMalloc(&ai, na + nb); (void)hipMemset(ai, 0, na + nb); a.a1_img = ai; a.b1_img = ai + na; a.e_h16 = nullptr; }
   {  // next block's pair bias from the epilogue (argv[2] = 0 disables)
     void* wimg; float* bo; const long Np = (N + 31) / 32 * 32;
     (void)hipMalloc(&wimg, 8192); (void)hipMemset(wimg, 0, 8192); (void)hipMalloc(&bo, (size_t)B * 8 * Np * Np * 4);

@@ -4,17 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 hx8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 __global__ void k(const float* A, const float* B, float* D) {  // A [16][32], B [32][16], D [16][16] row-major
   const int l = threadIdx.x;
-  bf16x8 a, b;
+  hx8 a, b;
   for (int e = 0; e < 8; ++e) {
-    a[e] = (__bf16)A[(l & 15) * 32 + 8 * (l >> 4) + e];
-    b[e] = (__bf16)B[(8 * (l >> 4) + e) * 16 + (l & 15)];
+    a[e] = (fd_h)A[(l & 15) * 32 + 8 * (l >> 4) + e];
+    b[e] = (fd_h)B[(8 * (l >> 4) + e) * 16 + (l & 15)];
   }
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  c = fd_mfma16(a, b, c);
   for (int r = 0; r < 4; ++r) D[(4 * (l >> 4) + r) * 16 + (l & 15)] = c[r];
 }
 int main() {

@@ -2,7 +2,7 @@
 // comes from registers vs. one ds_read_b128 per MFMA vs. one per two MFMAs.   hipcc --offload-arch=gfx950 -O3 -w
 #include <hip/hip_runtime.h>
 #include <cstdio>
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 hx8;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int ITERS = 256, KS = 16;
@@ -15,9 +15,9 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const char* gsrc) {
   __syncthreads();
   f32x16 acc[NACC];
   for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-  bf16x8 B[KS];
-  for (int s = 0; s < KS; ++s) for (int e = 0; e < 8; ++e) B[s][e] = (__bf16)(float)(tid + s + e);
-  bf16x8 A0 = B[0];
+  hx8 B[KS];
+  for (int s = 0; s < KS; ++s) for (int e = 0; e < 8; ++e) B[s][e] = (fd_h)(float)(tid + s + e);
+  hx8 A0 = B[0];
   u16x8 stg[16];
   for (int u = 0; u < 16; ++u) stg[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
   for (int it = 0; it < ITERS; ++it) {
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const char* gsrc) {
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      bf16x8 a;
+      hx8 a;
       if (MODE == 8) {  // same 64 KB per 64 MFMAs as 4 B-per-lane DMAs: 2 per MFMA pair... 64 per 64 MFMAs x 4 (256 B each)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256, 1) void k(float* out, const char* gsrc) {
       if (MODE == 0) a = A0;
       else if (MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 9) {  // ET2 layer-1 slab pattern: row li (512 B rows), 16 B unit (2s+hi) ^ (li & 15)
         const int li = lane & 31, hi = lane >> 5;
-        a = __builtin_bit_cast(bf16x8, *(const u16x8*)(smem + ((it & 1) << 15) + li * 512 + ((((2 * s + hi) & 31) ^ (li & 15)) << 4)));
+        a = __builtin_bit_cast(hx8, *(const u16x8*)(smem + ((it & 1) << 15) + li * 512 + ((((2 * s + hi) & 31) ^ (li & 15)) << 4)));
       } else if (MODE == 5) {  // two reads per MFMA (LDS headroom probe)
-        a = __builtin_bit_cast(bf16x8, *(const u16x8*)(p + s * 1024));
-        const bf16x8 a2 = __builtin_bit_cast(bf16x8, *(const u16x8*)(p + ((s + 7) & 15) * 1024 + 16384));
+        a = __builtin_bit_cast(hx8, *(const u16x8*)(p + s * 1024));
+        const hx8 a2 = __builtin_bit_cast(hx8, *(const u16x8*)(p + ((s + 7) & 15) * 1024 + 16384));
         a[0] += a2[0];
-      } else a = __builtin_bit_cast(bf16x8, *(const u16x8*)(p + (MODE == 2 ? (s >> 1) : s) * 1024));
+      } else a = __builtin_bit_cast(hx8, *(const u16x8*)(p + (MODE == 2 ? (s >> 1) : s) * 1024));
 #pragma unroll
-      for (int q = 0; q < NACC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B[(s + q) % KS], acc[q], 0, 0, 0);
+      for (int q = 0; q < NACC; ++q) acc[q] = fd_mfma32(a, B[(s + q) % KS], acc[q]);
     }
   }
   float t = 0.f;

@@ -4,7 +4,7 @@
 #include <vector>
 int main() {
   const int B = 8, N = 300, H = 8, C = 256, K = 256, PT = 672, Np = 320, M = B * N, NOUT = 3 * H * C + PT;
-  float *A, *bias, *pts; void* wimg; bf16_t *Qb, *Kb, *Vt;
+  float *A, *bias, *pts; void* wimg; half_t *Qb, *Kb, *Vt;
   const size_t img = (size_t)((NOUT + 127) / 128) * 65536, qs = (size_t)B * H * Np * C * 2;
   (void)hipMalloc(&A, (size_t)M * K * 4); (void)hipMalloc(&bias, NOUT * 4); (void)hipMalloc(&pts, (size_t)M * PT * 4); (void)hipMalloc(&wimg, img);
   (void)hipMalloc(&Qb, qs); (void)hipMalloc(&Kb, qs); (void)hipMalloc(&Vt, qs);
