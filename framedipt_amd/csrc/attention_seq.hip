@@ -139,11 +139,16 @@ __global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float*
 #define SQ_KS (SQ_K / 16)
 #define SQ_XROW (SQ_K * 2 + 16)
 typedef fd_h sa_hx4 __attribute__((ext_vector_type(4)));
+// SPLIT: the product runs on split operands (x = hi + lo, W = hi + lo: Whi.xhi + Whi.xlo + Wlo.xhi, see rowblock.hip); the
+// images still receive half-precision values (their rounding is averaged over the keys by the attention, tools/err_budget.py).
+template <bool SPLIT>
 __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, int Np, int H, const float* __restrict__ x, int ld_x,
-                                                                const char* __restrict__ wimg, const float* __restrict__ bias,
+                                                                const char* __restrict__ wimg, const char* __restrict__ wimg_lo,
+                                                                const float* __restrict__ bias,
                                                                 float qscale, half_t* __restrict__ Qi, half_t* __restrict__ Ki,
                                                                 half_t* __restrict__ Vi) {
-  __shared__ __attribute__((aligned(16))) char xs[32 * SQ_XROW];
+  __shared__ __attribute__((aligned(16))) char xs[(SPLIT ? 2 : 1) * 32 * SQ_XROW];
+  constexpr int XLO = 32 * SQ_XROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   // 1-D grid, id = (x / 8) * 24 + y * 8 + (x % 8): the three column parts of a row block run on the row block's XCD (x % 8, the
   // XCD whose L2 the producer of the rows — a 32-row-block kernel with the same mapping — wrote them through)
@@ -151,12 +156,13 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
   const int M = B * N, row0 = bx * 32, nt = Np >> 5, dm = H * SA_HD;
   if (row0 >= M) return;
   hx8 Wf[2][SQ_KS];
-  auto w_load = [&](auto BUF, int T) {
+  auto w_load = [&](auto BUF, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value;
 #pragma unroll
-    for (int s = 0; s < SQ_KS; ++s) Wf[bf][s] = __builtin_bit_cast(hx8, *(const u16x8*)(wimg + ((size_t)(T * SQ_KS + s) * 64 + lane) * 16));
+    for (int s = 0; s < SQ_KS; ++s) Wf[bf][s] = __builtin_bit_cast(hx8, *(const u16x8*)(img + ((size_t)(T * SQ_KS + s) * 64 + lane) * 16));
   };
-  w_load(std::integral_constant<int, 0>{}, by * (SQ_K / 32) + wave);
+  w_load(std::integral_constant<int, 0>{}, wimg, by * (SQ_K / 32) + wave);
+  if constexpr (SPLIT) w_load(std::integral_constant<int, 1>{}, wimg_lo, by * (SQ_K / 32) + wave);
   {
     f32x4 xv[10];
 #pragma unroll
@@ -168,16 +174,24 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
-      sa_hx4 pk;
+      sa_hx4 pk, pl;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = (fd_h)xv[k][q];
+      for (int q = 0; q < 4; ++q) {
+        pk[q] = (fd_h)xv[k][q];
+        pl[q] = (fd_h)(xv[k][q] - (float)pk[q]);
+      }
       *(sa_hx4*)(xs + r * SQ_XROW + 8 * c4) = pk;
+      if constexpr (SPLIT) *(sa_hx4*)(xs + XLO + r * SQ_XROW + 8 * c4) = pl;
     }
   }
   __syncthreads();
   hx8 X[SQ_KS];
+  hx8 Xl[SPLIT ? SQ_KS : 1];
 #pragma unroll
-  for (int s = 0; s < SQ_KS; ++s) X[s] = __builtin_bit_cast(hx8, *(const u16x8*)(xs + li * SQ_XROW + 32 * s + 16 * hi));
+  for (int s = 0; s < SQ_KS; ++s) {
+    X[s] = __builtin_bit_cast(hx8, *(const u16x8*)(xs + li * SQ_XROW + 32 * s + 16 * hi));
+    if constexpr (SPLIT) Xl[s] = __builtin_bit_cast(hx8, *(const u16x8*)(xs + XLO + li * SQ_XROW + 32 * s + 16 * hi));
+  }
   // this lane's row (transposed tiles) -> sample / key
   const int m = row0 + li, mb = m < M ? m / N : 0, mr = m - mb * N;
   // by = 0 / 1 / 2 takes the Q / K / V third of the 30 output tiles (3x the blocks: the kernel is latency-bound)
@@ -198,17 +212,43 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
 #pragma unroll
   for (int u = 0; u < (NTP + 3) / 4; ++u) {
     const int T = T0 + wave + 4 * u;
-    if (u + 1 < (NTP + 3) / 4 && wave + 4 * (u + 1) < NTP) {
-      if (u & 1) w_load(std::integral_constant<int, 0>{}, T + 4);
-      else w_load(std::integral_constant<int, 1>{}, T + 4);
+    const bool more = u + 1 < (NTP + 3) / 4 && wave + 4 * (u + 1) < NTP;
+    if (!SPLIT && more) {
+      if (u & 1) w_load(std::integral_constant<int, 0>{}, wimg, T + 4);
+      else w_load(std::integral_constant<int, 1>{}, wimg, T + 4);
     }
     if (wave + 4 * u >= NTP) continue;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (T < 2 * SQ_K / 32) {  // Q or K: D^T[feature, row]
+    const bool qk = T < 2 * SQ_K / 32;  // Q or K: D^T[feature, row]; V: D[row, feature], lane = feature
+    if constexpr (SPLIT) {  // hi fragments in buffer 0, lo fragments in buffer 1; the next tile's follow as the buffers free up
+      if (qk) {
 #pragma unroll
-      for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(Wf[u & 1][s], X[s], acc);
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(Wf[0][s], X[s], acc);
+#pragma unroll
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(Wf[0][s], Xl[s], acc);
+      } else {
+#pragma unroll
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(X[s], Wf[0][s], acc);
+#pragma unroll
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(Xl[s], Wf[0][s], acc);
+      }
+      if (more) w_load(std::integral_constant<int, 0>{}, wimg, T + 4);
+      if (qk) {
+#pragma unroll
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(Wf[1][s], X[s], acc);
+      } else {
+#pragma unroll
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(X[s], Wf[1][s], acc);
+      }
+      if (more) w_load(std::integral_constant<int, 1>{}, wimg_lo, T + 4);
+    }
+    if (qk) {
+      if constexpr (!SPLIT) {
+#pragma unroll
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(Wf[u & 1][s], X[s], acc);
+      }
       if (m < M) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -225,9 +265,11 @@ __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, in
           *(sa_hx4*)dst = o;
         }
       }
-    } else {  // V: D[row, feature], lane = feature
+    } else {
+      if constexpr (!SPLIT) {
 #pragma unroll
-      for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(X[s], Wf[u & 1][s], acc);
+        for (int s = 0; s < SQ_KS; ++s) acc = fd_mfma32(X[s], Wf[u & 1][s], acc);
+      }
       const int f = 32 * T + li, c = f - 2 * SQ_K, h = c / SA_HD, d = c - h * SA_HD;
       const float bv = bq[u][0][0];
 #pragma unroll
@@ -409,15 +451,20 @@ int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images,
   return FDIPT_OK;
 }
 int fd_seq_qkv_supported(int N, int H, int d_model) { return d_model == SQ_K && H * SA_HD == SQ_K && (N & 3) == 0; }
-int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const float* bias, float scale, void* images,
-               hipStream_t st) {
+int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const void* wimg_lo, const float* bias, float scale,
+               void* images, hipStream_t st) {
   if (!fd_seq_qkv_supported(N, H, SQ_K) || (ld_x & 3)) return FDIPT_EINVAL;
   const int Np = (N + 31) / 32 * 32;
   half_t* Qi = (half_t*)images;
   half_t* Ki = Qi + (size_t)B * H * Np * SA_KS * 16;
   half_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
-  hipLaunchKernelGGL(seq_qkv_kernel, dim3(24 * cdiv(cdiv(B * N, 32), 8)), dim3(FD_THREADS), 0, st, B, N, Np, H, x, ld_x, (const char*)wimg, bias, scale,
-                     Qi, Ki, Vi);
+  const dim3 grid(24 * cdiv(cdiv(B * N, 32), 8));
+  if (wimg_lo)  // split operands (lo image given)
+    hipLaunchKernelGGL(seq_qkv_kernel<true>, grid, dim3(FD_THREADS), 0, st, B, N, Np, H, x, ld_x, (const char*)wimg, (const char*)wimg_lo,
+                       bias, scale, Qi, Ki, Vi);
+  else
+    hipLaunchKernelGGL(seq_qkv_kernel<false>, grid, dim3(FD_THREADS), 0, st, B, N, Np, H, x, ld_x, (const char*)wimg, (const char*)nullptr,
+                       bias, scale, Qi, Ki, Vi);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

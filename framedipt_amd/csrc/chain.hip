@@ -20,8 +20,9 @@ __host__ __device__ __forceinline__ int ch_perm16(int pos) { return 4 * (pos >> 
 // ------------------------------------------------------------------ weight image
 // img[((T*KS + s)*64 + lane)*8 + e] = W[32T + (lane&31)][k], k = 16s + 8(lane>>5) + e  (natural)  or
 //                                                             16s + perm16(8(lane>>5) + e) (permuted: layers >= 2)
+// lo: the image of W - half(W) (second part of a split operand) instead of half(W)
 __global__ void chain_image_kernel(const float* __restrict__ w, int N, int K, int ldw, int permuted, int NT, int KS, float scale,
-                                   half_t* __restrict__ img) {
+                                   int lo, half_t* __restrict__ img) {
   const long n = (long)NT * KS * 64 * 8;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -29,13 +30,20 @@ __global__ void chain_image_kernel(const float* __restrict__ w, int N, int K, in
     const int s = (int)(ts % KS), T = (int)(ts / KS);
     const int row = 32 * T + (lane & 31), pos = 8 * (lane >> 5) + e;
     const int k = 16 * s + (permuted ? ch_perm16(pos) : pos);
-    img[i] = (row < N && k < K) ? f2h(w[(long)row * ldw + k] * scale) : (half_t)0;
+    const float v = (row < N && k < K) ? w[(long)row * ldw + k] * scale : 0.f;
+    img[i] = lo ? f2h(v - h2f(f2h(v))) : f2h(v);
   }
 }
 size_t fd_chain_image_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 1024; }
 int fd_chain_build_image_scaled(const float* w, int N, int K, int ldw, int permuted, float scale, void* img, hipStream_t st) {
   const int NT = (N + 31) / 32, KS = (K + 15) / 16;
-  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, permuted, NT, KS, scale, (half_t*)img);
+  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, permuted, NT, KS, scale, 0, (half_t*)img);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fd_chain_build_image_lo(const float* w, int N, int K, int ldw, void* img, hipStream_t st) {
+  const int NT = (N + 31) / 32, KS = (K + 15) / 16;
+  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, 0, NT, KS, 1.0f, 1, (half_t*)img);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -76,6 +76,7 @@ struct PrecF32 {
   static constexpr int PAD = 1;       // LDS row padding (elements): stride 33 words -> conflict-free ds_read_b32
   static constexpr int KL = 1;        // k elements per lane per MFMA
   static constexpr int KS = 2;        // k per MFMA
+  static constexpr int LDMUL = 1;
   static __device__ __forceinline__ T from_f32(float x) { return x; }
   static __device__ __forceinline__ float to_f32(T x) { return x; }
   static __device__ __forceinline__ void mma(f32x16& acc, const T* a_row, const T* b_row, int hi) {
@@ -88,12 +89,30 @@ struct PrecHalf {
   static constexpr int PAD = 8;       // stride 40 elem = 80 B: 16-B aligned rows, conflict-free ds_read_b128
   static constexpr int KL = 8;
   static constexpr int KS = 16;
+  static constexpr int LDMUL = 1;
   static __device__ __forceinline__ T from_f32(float x) { return f2h(x); }
   static __device__ __forceinline__ float to_f32(T x) { return h2f(x); }
   static __device__ __forceinline__ void mma(f32x16& acc, const T* a_row, const T* b_row, int hi) {
     hx8 a = __builtin_bit_cast(hx8, *(const u16x8*)(a_row + hi * 8));
     hx8 b = __builtin_bit_cast(hx8, *(const u16x8*)(b_row + hi * 8));
     acc = fd_mfma32(a, b, acc);
+  }
+};
+
+// split operands for the tiled GEMM of gemm.hip (64-wide k-tiles): an LDS row holds the 64 hi parts, then the 64 lo parts of
+// its k-tile (x = hi + lo, each a half-precision value; 22 significant bits together); a k-step is hi.hi + hi.lo + lo.hi
+struct PrecSplit {
+  typedef half_t T;
+  static constexpr int PAD = 8;
+  static constexpr int KL = 8;
+  static constexpr int KS = 16;
+  static constexpr int LDMUL = 2;     // row length in k-tiles
+  static __device__ __forceinline__ void mma(f32x16& acc, const T* a_row, const T* b_row, int hi) {
+    const hx8 ah = __builtin_bit_cast(hx8, *(const u16x8*)(a_row + hi * 8)), al = __builtin_bit_cast(hx8, *(const u16x8*)(a_row + 64 + hi * 8));
+    const hx8 bh = __builtin_bit_cast(hx8, *(const u16x8*)(b_row + hi * 8)), bl = __builtin_bit_cast(hx8, *(const u16x8*)(b_row + 64 + hi * 8));
+    acc = fd_mfma32(ah, bh, acc);
+    acc = fd_mfma32(ah, bl, acc);
+    acc = fd_mfma32(al, bh, acc);
   }
 };
 

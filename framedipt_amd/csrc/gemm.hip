@@ -27,7 +27,7 @@ struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading 
     }
   }
   __device__ __forceinline__ void store(typename P::T* dst, int tid) const {
-    constexpr int LDT = 64 + P::PAD;
+    constexpr int LDT = 64 * P::LDMUL + P::PAD;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int v = tid + u * FD_THREADS, rr = v / VPR, kk = (v % VPR) * EPV;
@@ -37,7 +37,14 @@ struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading 
       } else if constexpr (sizeof(SrcT) == 4) {
         u16x4 h = {f2h(r[u][0]), f2h(r[u][1]), f2h(r[u][2]), f2h(r[u][3])};
         *(u16x4*)d = h;
+        if constexpr (P::LDMUL == 2) {  // split operands: the lo parts follow the row's 64 hi parts
+          u16x4 l;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) l[q] = f2h(r[u][q] - h2f(h[q]));
+          *(u16x4*)(d + 64) = l;
+        }
       } else {
+        static_assert(P::LDMUL == 1, "split operands are built from fp32 sources");
         *(u16x8*)d = r[u];
       }
     }
@@ -50,7 +57,7 @@ template <class P, class AT, class WT, int BM, int BN, bool SWAP = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[BM / 64][BN / 64], int M, int N, int K,
                                           const AT* __restrict__ A, int lda, const WT* __restrict__ W, int ldw,
                                           typename P::T* smem, int m0, int n0, int tid) {
-  constexpr int BKL = 64, LDT = BKL + P::PAD;
+  constexpr int BKL = 64, LDT = BKL * P::LDMUL + P::PAD;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int STAGE = (BM + BN) * LDT;  // elements per pipeline stage: A tile then W tile
   const int lane = tid & 63, wave = tid >> 6;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K,
                                                             const float* __restrict__ residual, int ldr,
                                                             const float* __restrict__ rowmask, int relu,
                                                             float* __restrict__ out, int ldo) {
-  constexpr int LDT = 64 + P::PAD;
+  constexpr int LDT = 64 * P::LDMUL + P::PAD;
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in each direction
   __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(FD_THREADS) void linear_splitk_kernel(int M, int N,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ rowmask,
                                                                    float* __restrict__ parts, long part_stride, int ldo) {
-  constexpr int BM = 64, BN = 64, LDT = 64 + P::PAD;
+  constexpr int BM = 64, BN = 64, LDT = 64 * P::LDMUL + P::PAD;
   __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -178,7 +185,7 @@ __device__ __forceinline__ int g_perm16(int pos) { return 4 * (pos >> 3) + (pos 
 
 __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
   typedef PrecHalf P;
-  constexpr int BM = 128, BN = 128, LDT = 64 + P::PAD, TM = 2, TN = 2;
+  constexpr int BM = 128, BN = 128, LDT = 64 * P::LDMUL + P::PAD, TM = 2, TN = 2;
   __shared__ __attribute__((aligned(16))) P::T smem[2 * (BM + BN) * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -491,6 +498,17 @@ int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, c
   if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
   hipLaunchKernelGGL((linear_splitk_kernel<PrecHalf, float, half_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
                      st, M, N, K, kslice, A, lda, (const half_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+// the same on split operands (fp32 activations and the fp32 weight matrix, both split into hi + lo parts while they are staged)
+int fd_linear_splitk_split(int M, int N, int K, int nsplit, const float* A, int lda, const float* W, int ldw, const float* bias,
+                           const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 3) || (ldw & 3)) return FDIPT_EINVAL;
+  const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
+  if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecSplit, float, float>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
+                     st, M, N, K, kslice, A, lda, W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -198,8 +198,9 @@ struct SeqInitExtra {  // once-per-forward fills folded into the sequence-image 
 };
 int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, const SeqInitExtra& x, hipStream_t st);
 int fd_seq_qkv_supported(int N, int H, int d_model);
-int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const float* bias, float scale, void* images,
-               hipStream_t st);
+// wimg_lo != NULL: split operands (image of W - half(W), fd_chain_build_image_lo)
+int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const void* wimg_lo, const float* bias, float scale,
+               void* images, hipStream_t st);
 int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, const L2Warm* warm, hipStream_t st);
 
 // row-complete fused per-residue MLPs (rowblock.hip): 32 rows x all output columns per block, up to 3 Linear layers
@@ -209,6 +210,7 @@ struct RowBlockArgs {
   const float* in;
   int ld_in;
   const void *w0, *w1, *w2;
+  const void *w0l = nullptr, *w1l = nullptr, *w2l = nullptr;  // *_SPLIT kinds: images of W - half(W) (fd_chain_build_image_lo)
   const float *b0, *b1, *b2;
   const float* residual;        // or NULL
   int ld_res;
@@ -228,7 +230,8 @@ struct RowBlockArgs {
   float *quat, *trans;          // [M,4], [M,3]
   L2Warm warm = {};             // weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
 };
-enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS, FD_RB_ET4_IMAGES };
+enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS, FD_RB_ET4_IMAGES,
+       FD_RB_TRANSITION_BB_SPLIT, FD_RB_NODE_EMBED_72_SPLIT, FD_RB_NODE_EMBED_88_SPLIT, FD_RB_TORSION_SPLIT };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 
 // post-attention half of one encoder layer in one launch (rowblock.hip): x_a = LN1(x + Wo att + bo); out = LN2(x_a + W2 relu(W1 x_a + b1) + b2)
@@ -236,6 +239,7 @@ struct TfmrTailArgs {
   int M, ld;                      // rows; common row stride of att / x / out (d_model = 320)
   const float *att, *x;           // attention output rows, layer input rows (residual)
   const void *wo, *w1, *w2;       // fragment images, natural k order (fd_chain_build_image(.., 0))
+  const void *wol = nullptr, *w1l = nullptr, *w2l = nullptr, *wpl = nullptr;  // split operands: lo images (fd_chain_build_image_lo); wol selects the split kernel
   const float *bo, *g1, *be1, *b1, *b2, *g2, *be2;
   float* out;                     // must not alias x
   // optional (last layer of the stack): post_tfmr (Linear 320 -> 256, fragment image wp, bias bp) + residual rows pres on the
@@ -268,6 +272,8 @@ enum { FD_CHAIN_TRANSITION, FD_CHAIN_FFN, FD_CHAIN_OUTPROJ, FD_CHAIN_POST, FD_CH
        FD_CHAIN_A1, FD_CHAIN_AF, FD_CHAIN_NODE_EMBED_72, FD_CHAIN_NODE_EMBED_88, FD_CHAIN_TORSION };
 size_t fd_chain_image_bytes(int N, int K);
 int fd_chain_build_image(const float* w, int N, int K, int ldw, int permuted, void* img, hipStream_t st);
+// the same for W - half(W): the lo part of a weight matrix used as split operands (hi image + lo image = 22 significant bits)
+int fd_chain_build_image_lo(const float* w, int N, int K, int ldw, void* img, hipStream_t st);
 int fd_chain_build_image_scaled(const float* w, int N, int K, int ldw, int permuted, float scale, void* img, hipStream_t st);
 int fd_chain(int kind, const ChainArgs& a, hipStream_t st);
 
@@ -281,6 +287,8 @@ int fd_layernorm_parts(int M, int D, const float* x, int ldx, const float* parts
 // the same with bf16 activation rows (what the bf16 GEMM would round them to anyway)
 int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const half_t* A, int lda, const void* W, int ldw, const float* bias,
                          const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
+int fd_linear_splitk_split(int M, int N, int K, int nsplit, const float* A, int lda, const float* W, int ldw, const float* bias,
+                           const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, const void* W, int ldw, const float* bias,
                      const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,

@@ -29,6 +29,7 @@ struct Switches {
   bool feats_unfused = false, torf_unfused = false, init_unfused = false, skip_per_block = false, post_unfused = false,
        no_tfmr_tail = false, et4_rows_unfused = false, no_qkv_fuse = false, proj_v1 = false, feats_f32 = false,
        probs_f32 = false, no_l2_warm = false;
+  bool no_split = false;        // node-path products on plain half-precision operands instead of split (hi + lo) ones
   unsigned chain_mask = 0xFC9u;  // fused chain kinds (chain.hip) that beat the launches they replace (profiles/r01_chain_vs_gemm.md)
   const char* twice = nullptr;   // timing aid: repeat the named launches (the second one runs on a warm L2)
 };
@@ -44,7 +45,7 @@ static const Switches& dev_switches() {
     s.skip_per_block = on("FDIPT_SKIP_PER_BLOCK"); s.post_unfused = on("FDIPT_POST_UNFUSED");
     s.no_tfmr_tail = on("FDIPT_NO_TFMR_TAIL"); s.et4_rows_unfused = on("FDIPT_ET4_ROWS_UNFUSED");
     s.no_qkv_fuse = on("FDIPT_NO_QKV_FUSE"); s.proj_v1 = on("FDIPT_PROJ_V1"); s.feats_f32 = on("FDIPT_FEATS_F32");
-    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM");
+    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM"); s.no_split = on("FDIPT_NO_SPLIT");
     if (const char* m = getenv("FDIPT_CHAIN_MASK")) s.chain_mask = (unsigned)strtoul(m, nullptr, 0);
     s.twice = getenv("FDIPT_DBG_TWICE");
 #endif
@@ -59,6 +60,7 @@ static Switches switches_of(const FdiptDims* d) {
   if (f & FDIPT_KF_ET3) s.et3 = true;
   if (f & FDIPT_KF_GENERIC_ATTN) s.generic_attn = true;
   if (f & FDIPT_KF_UNFUSED_NODE) s.no_rowblock = s.no_chain = s.no_splitk = true;
+  if (f & FDIPT_KF_NO_SPLIT) s.no_split = true;
   if (f & FDIPT_KF_UNFOLDED)
     s.no_et_bias = s.no_ee_bias = s.feats_unfused = s.torf_unfused = s.init_unfused = s.skip_per_block = s.post_unfused =
         s.et4_rows_unfused = true;
@@ -145,11 +147,14 @@ static void build_inventory(const FdiptDims* d, Inventory& iv) {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
+struct DSplit {  // lo images (W - half(W)) of the node-path layers that run on split operands (rowblock.hip, attention_seq.hip)
+  size_t inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3;
+};
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, wproj_img, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img; DChain ch; };
+struct DBlock { size_t wproj, wproj_img, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img; DChain ch; DSplit lo; };
 struct DLayout {
   size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -157,6 +162,7 @@ struct DLayout {
   size_t ee2;         // LDS images of edge-embedder layers 2/3 (register-resident bf16 kernel)
   size_t ch_ne0, ch_ne2, ch_ne4, ch_tor1, ch_tor2;  // chain images: node embedder, torsion head
   size_t ch_ne2n, ch_ne4n, ch_tor2n;                // ... natural k order (rowblock.hip)
+  size_t lo_ne0, lo_ne2, lo_ne4, lo_tor1, lo_tor2;  // lo images: node embedder, torsion head
   size_t skip_w, skip_b;                            // skip_embed of ALL blocks stacked: [num_blocks * c_skip, c_s] operand precision, bias f32
   DBlock blk[FD_MAX_BLOCKS];
   size_t total;
@@ -222,6 +228,13 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   }
   if (use_chain(d)) {
     auto img = [&](int n, int k) { size_t r = o; o = al256(o + fd_chain_image_bytes(n, k)); return r; };
+    const int cs = d->c_s, dt = iv.d_t;
+    for (int b = 0; b < d->num_blocks; ++b) {
+      DSplit& c = L.blk[b].lo;
+      for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); }
+      c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs);
+    }
+    L.lo_ne0 = img(cs, L.kn_pad); L.lo_ne2 = img(cs, cs); L.lo_ne4 = img(cs, cs); L.lo_tor1 = img(cs, cs); L.lo_tor2 = img(cs, cs);
     L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
     L.ch_tor1 = img(d->c_s, d->c_s); L.ch_tor2 = img(d->c_s, d->c_s);
     L.ch_ne2n = img(d->c_s, d->c_s); L.ch_ne4n = img(d->c_s, d->c_s); L.ch_tor2n = img(d->c_s, d->c_s);
@@ -413,6 +426,18 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     }
   }
   if (use_chain(d)) {
+    auto lo = [&](const LinW& l, size_t off) { return fd_chain_build_image_lo(P + l.w, l.out, l.in, l.in, D + off, st); };
+    for (int b = 0; b < d->num_blocks; ++b) {
+      const BlockW& k = iv.blk[b];
+      const DSplit& c = L.blk[b].lo;
+      for (int l = 0; l < d->tfmr_layers; ++l)
+        if ((rc = lo(k.tf[l].inp, c.inp[l])) || (rc = lo(k.tf[l].outp, c.outp[l])) || (rc = lo(k.tf[l].l1, c.l1[l])) || (rc = lo(k.tf[l].l2, c.l2[l])))
+          return rc;
+      if ((rc = lo(k.post, c.post)) || (rc = lo(k.t1, c.t1)) || (rc = lo(k.t2, c.t2)) || (rc = lo(k.t3, c.t3))) return rc;
+    }
+    if ((rc = lo(iv.ne0, L.lo_ne0)) || (rc = lo(iv.ne2, L.lo_ne2)) || (rc = lo(iv.ne4, L.lo_ne4)) || (rc = lo(iv.tor1, L.lo_tor1)) ||
+        (rc = lo(iv.tor2, L.lo_tor2)))
+      return rc;
     if ((rc = fd_chain_build_image(P + iv.ne0.w, cs, iv.node_in, iv.node_in, 0, D + L.ch_ne0, st))) return rc;
     if ((rc = fd_chain_build_image(P + iv.ne2.w, cs, cs, cs, 1, D + L.ch_ne2, st))) return rc;
     if ((rc = fd_chain_build_image(P + iv.ne4.w, cs, cs, cs, 1, D + L.ch_ne4, st))) return rc;
@@ -550,10 +575,16 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   auto con = [&](int kind) { return chn_all && ((cmask >> kind) & 1u); };
   // row-complete fused MLPs (rowblock.hip) take the multi-layer kinds and the 320-wide transformer layers
   const bool rbk = chn_all && cs == 256 && iv.d_t == 320 && !sw.no_rowblock;
+  // split operands (hi + lo half-precision parts, 3 MFMAs per k-step) for the dense layers of the node path, whose operand
+  // rounding dominates the error of the predicted frames and psi (tools/err_budget.py): node embedder, IPA output projection,
+  // sequence transformer (in_proj, out_proj, feed-forward), post_tfmr, transition, torsion head
+  const bool split = rbk && !sw.no_split;
+  const void *rb_l0 = nullptr, *rb_l1 = nullptr, *rb_l2 = nullptr;  // one-shot: lo images for the next rblock() call
   auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                     const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
                     float* out, int ld_out) {
     RowBlockArgs r;
+    r.w0l = rb_l0; r.w1l = rb_l1; r.w2l = rb_l2; rb_l0 = rb_l1 = rb_l2 = nullptr;
     r.M = R; r.in = in; r.ld_in = ld_in; r.w0 = w0; r.w1 = w1; r.w2 = w2; r.b0 = b0; r.b1 = b1; r.b2 = b2; r.residual = resid;
     r.ld_res = ld_res; r.gamma = lnw ? P + lnw->g : nullptr; r.beta = lnw ? P + lnw->b : nullptr; r.rowmask_post = post;
     r.out = out; r.ld_out = ld_out; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
@@ -583,7 +614,9 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
                     F(w.trans), F(w.dmask), (const float*)(D + L.w1i), (const float*)(D + L.w1j), (const float*)(D + L.b1), cz,
                     feats_fused ? F(w.pi) : nullptr, F(w.pj), st));
   if (rbk && (L.kn_pad == 72 || L.kn_pad == 88)) {
-    RC(rblock(L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88, F(w.node_feat), L.kn_pad, D + L.ch_ne0, P + iv.ne0.b,
+    if (split) { rb_l0 = D + L.lo_ne0; rb_l1 = D + L.lo_ne2; rb_l2 = D + L.lo_ne4; }
+    RC(rblock(split ? (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72_SPLIT : FD_RB_NODE_EMBED_88_SPLIT)
+                    : (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88), F(w.node_feat), L.kn_pad, D + L.ch_ne0, P + iv.ne0.b,
               D + L.ch_ne2n, P + iv.ne2.b, D + L.ch_ne4n, P + iv.ne4.b, nullptr, 0, &iv.neln, res_mask, F(w.node0), cs));
   } else if (con(FD_CHAIN_NODE_EMBED_72) && (L.kn_pad == 72 || L.kn_pad == 88)) {
     RC(chain(L.kn_pad == 72 ? FD_CHAIN_NODE_EMBED_72 : FD_CHAIN_NODE_EMBED_88, F(w.node_feat), L.kn_pad, D + L.ch_ne0,
@@ -697,7 +730,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       // ... and both kernels write the attention features as bf16 rows when the output projection is the bf16 split-K GEMM
       // (the values it would round them to anyway: identical results, half the bytes, no conversion in its staging)
       feats_h16 = fd_opair_mfma_eligible(prec, oa) && iv.feat_dim >= 1024 && (iv.feat_dim & 7) == 0 && !sw.no_splitk &&
-                   !sw.feats_f32;
+                   !sw.feats_f32 && !split;  // (split operands: the projection splits the fp32 features itself)
       if (feats_h16) { a3.out_h16 = (half_t*)(W + w.feats); oa.out_h16 = a3.out_h16; }
       if (fd_opair_mfma_eligible(prec, oa) && 2 * Np <= 4 * N && !sw.probs_f32) {
         a3.probs_h16 = (half_t*)(W + w.probs); oa.probs_h16 = a3.probs_h16; oa.probs_np = Np;
@@ -725,7 +758,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
     if (bf && iv.feat_dim >= 1024 && !sw.no_splitk) {
       const int NS = 4;  // K = 2688: slices of 704 / 576 columns -> 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower)
-      if (feats_h16)
+      if (split)
+        TWICE("splitk", fd_linear_splitk_split(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, P + k.out.w, iv.feat_dim, P + k.out.b,
+                                               res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
+      else if (feats_h16)
         TWICE("splitk", fd_linear_splitk_a16(R, cs, iv.feat_dim, NS, (const half_t*)(W + w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b,
                                 res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
       else
@@ -757,7 +793,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
           RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, SeqInitExtra{}, st));
           seq_img_ready = true;
         }
-        TWICE("qkv", fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));
+        TWICE("qkv", fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], split ? D + db.lo.inp[l] : nullptr, P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));
         // ... and touches the weights of the layer's tail kernel, launched next (common.hpp: L2 warm-up hand-over)
         const unsigned wimg = (unsigned)fd_chain_image_bytes(dt, dt);
         L2Warm wt = {{D + db.ch.outp[l], D + db.ch.l1[l], D + db.ch.l2n[l]}, {wimg, wimg, wimg}};
@@ -785,11 +821,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
         tt.M = R; tt.ld = dt; tt.att = F(w.att); tt.x = x; tt.wo = D + db.ch.outp[l]; tt.w1 = D + db.ch.l1[l]; tt.w2 = D + db.ch.l2n[l];
         tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
         tt.be2 = P + t.n2.b; tt.out = x == F(w.x_b) ? F(w.x_a) : F(w.x_b);
+        if (split) { tt.wol = D + db.lo.outp[l]; tt.w1l = D + db.lo.l1[l]; tt.w2l = D + db.lo.l2[l]; }
         tt.warm = L2Warm{};  // next launch: the following layer's in_proj, or post_tfmr / the transition
         // the last layer also applies post_tfmr + the node residual (FDIPT_POST_UNFUSED: its own launch)
         const bool post_here = l + 1 == d->tfmr_layers && cs == 256 && !sw.post_unfused;
         if (post_here) {
-          tt.wp = D + db.ch.post; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
+          tt.wp = D + db.ch.post; tt.wpl = split ? D + db.lo.post : nullptr; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
           post_done = true;
         }
         const unsigned tb = (unsigned)fd_chain_image_bytes(cs, cs);
@@ -847,7 +884,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
                         {(unsigned)fd_chain_image_bytes(iv.cb, cs), (unsigned)fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb), 0}};
       else if (warm_all && b == d->num_blocks - 1)  // ... or the torsion head
         r.warm = L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, nullptr}, {(unsigned)fd_chain_image_bytes(cs, cs), (unsigned)fd_chain_image_bytes(cs, cs), 0}};
-      RC(fd_rowblock(FD_RB_TRANSITION_BB, r, st));
+      if (split) { r.w0l = D + db.lo.t1; r.w1l = D + db.lo.t2; r.w2l = D + db.lo.t3; }
+      RC(fd_rowblock(split ? FD_RB_TRANSITION_BB_SPLIT : FD_RB_TRANSITION_BB, r, st));
       bb_done = true;
     } else if (con(FD_CHAIN_TRANSITION)) {
       RC(chain(FD_CHAIN_TRANSITION, F(w.h_a), cs, D + db.ch.t1, P + k.t1.b, D + db.ch.t2, P + k.t2.b, D + db.ch.t3, P + k.t3.b,
@@ -939,7 +977,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   }
   // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
   if (rbk) {
-    RC(rblock(FD_RB_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
+    if (split) { rb_l0 = D + L.lo_tor1; rb_l1 = D + L.lo_tor2; }
+    RC(rblock(split ? FD_RB_TORSION_SPLIT : FD_RB_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
               cs, nullptr, nullptr, F(w.h_b), cs));
   } else if (con(FD_CHAIN_TORSION)) {
     RC(chain(FD_CHAIN_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2, P + iv.tor2.b, nullptr, nullptr, node_cur,

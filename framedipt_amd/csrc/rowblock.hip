@@ -27,6 +27,10 @@ __host__ __device__ constexpr int rb_max(int a, int b) { return a > b ? a : b; }
 
 // K0: input width (zero-padded to a multiple of 16); N1 / N2: hidden widths (0 = absent); NOUT: output width;
 // FLAGS bit0 / bit1: ReLU after hidden 1 / 2, bit2: LayerNorm.  Residual and the final row mask are optional (pointers).
+// FLAGS bit5 (SPLIT): every product runs on split operands — activations x = hi + lo and weights W = hi + lo, each part one
+// half-precision value (22 significant bits together), as Whi.xhi + Whi.xlo + Wlo.xhi with fp32 accumulation: the accuracy of
+// an fp32 product at a third of the half-precision MFMA rate (the fp32 MFMA runs at a sixteenth).  The layers of the node
+// path whose operand rounding dominates the error of the predicted frames / psi use it (tools/err_budget.py).
 // Activation rows in LDS are [32][width bf16 + 16 B]: with widths 80..320 the 16 lanes of a b128 read hit 16 distinct
 // 16 B slots, no swizzle needed.
 template <int N, class F>
@@ -49,8 +53,10 @@ struct RBShape {
   static constexpr int NTW = (NTMAX + 3) / 4;                              // output tiles per wave
   static constexpr bool BB = (FLAGS & 8) != 0;                            // fused BackboneUpdate + compose_q_update_vec
   static constexpr bool IMG = (FLAGS & 16) != 0;                          // output = edge_transition4 fold-fragment images
+  static constexpr bool SPLIT = (FLAGS & 32) != 0;                        // split operands: x = hi + lo, W = hi + lo, 3 MFMAs per k-step
+  static constexpr int XBUF = 32 * XROW * (SPLIT ? 2 : 1);                // one activation buffer: hi rows (then lo rows)
   static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0) + (BB ? 6 * NOUT : 0);  // b0 | b1 | b_out | gamma | beta | Wbb
-  static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * 32 * XROW + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + (BB ? 4 * 32 * 8 * 4 : 0) + 16;
+  static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * XBUF + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + (BB ? 4 * 32 * 8 * 4 : 0) + 16;
   static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 1024, "tile shapes");
 };
 
@@ -61,8 +67,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   constexpr bool LN = S::LN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                                                  // activation rows (ping)  [32][XROW]
-  char* hs = xs + 32 * XROW;                                        // activation rows (pong)  [32][XROW]  (NL > 1)
-  char* st_all = hs + (NL > 1 ? 32 * XROW : 0);                     // per-wave exchange tiles [4][32][RB_SROW]
+  char* hs = xs + S::XBUF;                                          // activation rows (pong)  [32][XROW]  (NL > 1)
+  char* st_all = hs + (NL > 1 ? S::XBUF : 0);                       // per-wave exchange tiles [4][32][RB_SROW]
+  constexpr bool SPLIT = S::SPLIT;
+  constexpr int XLO = 32 * XROW;                                    // SPLIT: the lo rows follow the hi rows of a buffer
   float* cst = (float*)(st_all + 4 * 32 * RB_SROW);                 // b0 | b1 | b_out | gamma | beta
   float (*red)[4][32] = (float (*)[4][32])(cst + S::NCONST);        // [2][4][32]
   float* pmask = (float*)(red + 2);                                 // [32] final row mask
@@ -71,10 +79,12 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   const int row0 = blockIdx.x * 32;
   char* stg = st_all + wave * 32 * RB_SROW;
   const char* wimg[3] = {(const char*)a.w0, (const char*)a.w1, (const char*)a.w2};
+  const char* wlo[3] = {(const char*)a.w0l, (const char*)a.w1l, (const char*)a.w2l};  // SPLIT: images of W - half(W)
   // ---- first weight tile of this wave in flight before anything else
   // weight-fragment buffers: tile u of a wave lives in buffer u % NB; wide outputs with short K (8 tiles of 8 fragments per wave)
   // keep three tiles in flight instead of one (each tile is a dependent L2 round trip otherwise)
   constexpr int NB = (NTW >= 6 && KSMAX <= 16) ? 4 : 2;
+  static_assert(!SPLIT || NB == 2, "split operands: buffer 0 holds the hi fragments of a tile, buffer 1 the lo fragments");
   hx8 Wf[NB][KSMAX];
   auto w_load = [&](auto BUF, auto KSC, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value, KS = decltype(KSC)::value;
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     for (int s = 0; s < KS; ++s) Wf[bf][s] = rb_ld(img + ((size_t)(T * KS + s) * 64 + lane) * 16);
   };
   w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, KS0>{}, wimg[0], wave);
+  if constexpr (SPLIT) w_load(std::integral_constant<int, 1>{}, std::integral_constant<int, KS0>{}, wlo[0], wave);
   // ---- input rows -> LDS (bf16, zero-padded to 16 KS0 columns), constants -> LDS
   {
     constexpr int C4 = KS0 * 4;                       // float4 columns per row (padded)
@@ -117,10 +128,16 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int idx = tid + k * FD_THREADS, r = idx / C4, c4 = idx % C4;
-      rb_hx4 pk;
+      rb_hx4 pk, pl;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = (fd_h)xv[k][q];
-      if (idx < 32 * C4) *(rb_hx4*)(xs + r * XROW + 8 * c4) = pk;
+      for (int q = 0; q < 4; ++q) {
+        pk[q] = (fd_h)xv[k][q];
+        pl[q] = (fd_h)(xv[k][q] - (float)pk[q]);
+      }
+      if (idx < 32 * C4) {
+        *(rb_hx4*)(xs + r * XROW + 8 * c4) = pk;
+        if constexpr (SPLIT) *(rb_hx4*)(xs + XLO + r * XROW + 8 * c4) = pl;
+      }
     }
   }
   // residual row segments of this wave's output tiles: requested now, consumed after the last MFMA
@@ -140,12 +157,36 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   __syncthreads();
 
   hx8 X[KSMAX];
+  hx8 Xl[SPLIT ? KSMAX : 1];  // SPLIT: lo parts of the B fragments
   f32x16 acc[NTW];
   // one layer: tiles wave, wave+4, wave+8 (< NT) of `img` against the B fragments X[0..KS); the first tile's fragments
-  // are already in Wf[0]
-  auto layer = [&](auto KSC, auto NTC, const char* img, auto SWAPC) {
+  // are already in Wf[0] (SPLIT: and its lo fragments in Wf[1])
+  auto layer = [&](auto KSC, auto NTC, const char* img, const char* img_lo, auto SWAPC) {
     constexpr int KS = decltype(KSC)::value, NT = decltype(NTC)::value;
     constexpr bool SWAP = decltype(SWAPC)::value;  // operands exchanged: lane = output feature, registers = rows
+    if constexpr (SPLIT) {
+      // per tile: Whi.xhi + Whi.xlo out of buffer 0, then Wlo.xhi out of buffer 1; the next tile's hi fragments are requested
+      // when buffer 0 is free (under the lo pass), its lo fragments when buffer 1 is (under the next tile's hi passes)
+      ch_rb_for<NTW>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const int T = wave + 4 * u;
+        if (T < NT) {
+          f32x16 c;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) c = fd_mfma32(Wf[0][s], X[s], c);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) c = fd_mfma32(Wf[0][s], Xl[s], c);
+          if (u + 1 < NTW && T + 4 < NT) w_load(std::integral_constant<int, 0>{}, KSC, img, T + 4);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) c = fd_mfma32(Wf[1][s], X[s], c);
+          if (u + 1 < NTW && T + 4 < NT) w_load(std::integral_constant<int, 1>{}, KSC, img_lo, T + 4);
+          acc[u] = c;
+        }
+      });
+      return;
+    }
     auto load_tile = [&](auto V) {  // tile v of this wave -> buffer v % NB
       constexpr int v = decltype(V)::value;
       if (v < NTW && wave + 4 * v < NT) w_load(std::integral_constant<int, v % NB>{}, KSC, img, wave + 4 * v);
@@ -181,40 +222,50 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
         for (int g = 0; g < 4; ++g) {
           const int f0 = 32 * T + 8 * g + 4 * hi;
           const f32x4 bv = *(const f32x4*)(bias + f0);
-          rb_hx4 pk;
+          rb_hx4 pk, pl;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v = acc[u][4 * g + q] + bv[q];
             if (decltype(RELU)::value) v = fmaxf(v, 0.f);
             pk[q] = (fd_h)v;
+            pl[q] = (fd_h)(v - (float)pk[q]);
           }
           *(rb_hx4*)(dst + li * XROW + 2 * f0) = pk;
+          if constexpr (SPLIT) *(rb_hx4*)(dst + XLO + li * XROW + 2 * f0) = pl;
           if (hid_h16 && row0 + li < a.M) *(rb_hx4*)(hid_h16 + (long)(row0 + li) * hid_ld + f0) = pk;  // optional bf16 copy of the rows
         }
       }
     }
   };
+  auto x_load = [&](auto KSC, const char* buf) {  // this lane's B fragments of the activation rows in `buf`
 #pragma unroll
-  for (int s = 0; s < KS0; ++s) X[s] = rb_ld(xs + li * XROW + 32 * s + 16 * hi);
+    for (int s = 0; s < decltype(KSC)::value; ++s) {
+      X[s] = rb_ld(buf + li * XROW + 32 * s + 16 * hi);
+      if constexpr (SPLIT) Xl[s] = rb_ld(buf + XLO + li * XROW + 32 * s + 16 * hi);
+    }
+  };
+  auto w_first = [&](auto KSC, int l) {  // first tile of layer l: in flight across the barrier
+    w_load(std::integral_constant<int, 0>{}, KSC, wimg[l], wave);
+    if constexpr (SPLIT) w_load(std::integral_constant<int, 1>{}, KSC, wlo[l], wave);
+  };
+  x_load(std::integral_constant<int, KS0>{}, xs);
   if constexpr (NL == 1) {
-    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, NTO>{}, wimg[0], std::false_type{});
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, NTO>{}, wimg[0], wlo[0], std::false_type{});
   } else {
-    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0], std::false_type{});
-    w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N1 / 16>{}, wimg[1], wave);  // in flight across the barrier
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0], wlo[0], std::false_type{});
+    w_first(std::integral_constant<int, N1 / 16>{}, 1);
     to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs, a.hid_h16, N1);
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < N1 / 16; ++s) X[s] = rb_ld(hs + li * XROW + 32 * s + 16 * hi);
+    x_load(std::integral_constant<int, N1 / 16>{}, hs);
     if constexpr (NL == 2) {
-      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, NTO>{}, wimg[1], std::integral_constant<bool, S::IMG>{});
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, NTO>{}, wimg[1], wlo[1], std::integral_constant<bool, S::IMG>{});
     } else {
-      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1], std::false_type{});
-      w_load(std::integral_constant<int, 0>{}, std::integral_constant<int, N2 / 16>{}, wimg[2], wave);
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1], wlo[1], std::false_type{});
+      w_first(std::integral_constant<int, N2 / 16>{}, 2);
       to_hidden(std::integral_constant<int, N2 / 32>{}, std::integral_constant<bool, (FLAGS & 2) != 0>{}, cst + N1, xs, nullptr, 0);  // xs is free again
       __syncthreads();
-#pragma unroll
-      for (int s = 0; s < N2 / 16; ++s) X[s] = rb_ld(xs + li * XROW + 32 * s + 16 * hi);
-      layer(std::integral_constant<int, N2 / 16>{}, std::integral_constant<int, NTO>{}, wimg[2], std::false_type{});
+      x_load(std::integral_constant<int, N2 / 16>{}, xs);
+      layer(std::integral_constant<int, N2 / 16>{}, std::integral_constant<int, NTO>{}, wimg[2], wlo[2], std::false_type{});
     }
   }
   if constexpr (S::IMG) {
@@ -223,7 +274,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     // columns 512..1023 = [B1 | Bf] of 4 consecutive residues j of sample b -> b_img[b][j / 4][..][0..3], and the same 8 bytes
     // as elements 4..7 of sample b - 1 (the rows of a patch that straddles two samples); elements 4..7 of the last sample are
     // zeros (finite: they meet zeros of the selection matrix).  Needs img_N % 4 == 0.
-    static_assert(NL == 2 && NOUT == 1024, "ET4 image kind");
+    static_assert(NL == 2 && NOUT == 1024 && !SPLIT, "ET4 image kind");
     const float* bo = cst + N1 + N2;
     const int NJ4 = a.img_N >> 2;
     half_t* ia = (half_t*)a.img_a;
@@ -379,15 +430,19 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
 #define TL_NT (TL_D / 32)
 #define TL_XROW (TL_D * 2 + 16)
 #define TL_NP 256  // post_tfmr output width (POST variant)
-#define TL_SMEM (2 * 32 * TL_XROW + 4 * 32 * RB_SROW + (7 * TL_D + TL_NP) * 4 + 2 * 4 * 32 * 4 + 16)
+#define TL_SMEM(SPLIT) (((SPLIT) ? 4 : 2) * 32 * TL_XROW + 4 * 32 * RB_SROW + (7 * TL_D + TL_NP) * 4 + 2 * 4 * 32 * 4 + 16)
 // POST: the last layer of the stack also applies post_tfmr (Linear d_model -> c_s) + the node residual (ipa:539) to its own
 // output rows, which then never go to memory.
-template <bool POST>
+// SPLIT: every product on split operands (activations and weights as hi + lo half-precision parts, 3 MFMAs per k-step; see
+// rowblock_kernel): wol / w1l / w2l / wpl are the lo images.
+template <bool POST, bool SPLIT>
 __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                                            // att rows, then hidden rows   [32][TL_XROW]
-  char* hs = xs + 32 * TL_XROW;                               // x_a rows                     [32][TL_XROW]
-  char* st_all = hs + 32 * TL_XROW;                           // per-wave exchange tiles      [4][32][RB_SROW]
+  constexpr int XLO = 32 * TL_XROW;                           // SPLIT: the lo rows follow the hi rows of a buffer
+  constexpr int XBUF = SPLIT ? 2 * XLO : XLO;
+  char* hs = xs + XBUF;                                       // x_a rows                     [32][TL_XROW]
+  char* st_all = hs + XBUF;                                   // per-wave exchange tiles      [4][32][RB_SROW]
   float* cst = (float*)(st_all + 4 * 32 * RB_SROW);           // b_o | g1 | be1 | b1 | b2 | g2 | be2 | b_post
   float (*red)[4][32] = (float (*)[4][32])(cst + 7 * TL_D + TL_NP);   // [2][4][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
@@ -400,7 +455,24 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
     for (int s = 0; s < TL_KS; ++s) Wf[bf][s] = rb_ld(img + ((size_t)(T * TL_KS + s) * 64 + lane) * 16);
   };
-  w_load(std::integral_constant<int, 0>{}, (const char*)a.wo, wave);
+  // first tile of a stage: hi fragments -> buffer 0 (SPLIT: lo fragments -> buffer 1)
+  auto w_first = [&](const void* img, const void* img_lo) {
+    w_load(std::integral_constant<int, 0>{}, (const char*)img, wave);
+    if constexpr (SPLIT) w_load(std::integral_constant<int, 1>{}, (const char*)img_lo, wave);
+  };
+  // 4 values -> half-precision row pieces at byte offset `off` of an activation buffer (SPLIT: hi and lo parts)
+  auto put4 = [&](char* buf, int off, float v0, float v1, float v2, float v3) {
+    const float v[4] = {v0, v1, v2, v3};
+    rb_hx4 pk, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pk[q] = (fd_h)v[q];
+      pl[q] = (fd_h)(v[q] - (float)pk[q]);
+    }
+    *(rb_hx4*)(buf + off) = pk;
+    if constexpr (SPLIT) *(rb_hx4*)(buf + XLO + off) = pl;
+  };
+  w_first(a.wo, a.wol);
   {
     f32x4 xv[10];
 #pragma unroll
@@ -425,10 +497,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
-      rb_hx4 pk;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = (fd_h)xv[k][q];
-      *(rb_hx4*)(xs + r * TL_XROW + 8 * c4) = pk;
+      put4(xs, r * TL_XROW + 8 * c4, xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
     }
   }
   f32x4 rv[3][4];  // residual x: row segments of this wave's tiles
@@ -441,38 +510,69 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       rv[u][it] = *(const f32x4*)(a.x + (long)gr * a.ld + 32 * T + 4 * (lane & 7));
     }
   f32x4 rvp[POST ? 2 : 1][4];  // POST: node rows (residual of post_tfmr), tiles wave and wave + 4 of TL_NP / 32
-  if constexpr (POST) {
+  auto load_rvp = [&]() {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < (POST ? 2 : 0); ++u)
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = 8 * it + (lane >> 3), gr = row0 + r < a.M ? row0 + r : a.M - 1;
         rvp[u][it] = *(const f32x4*)(a.pres + (long)gr * a.ld_pres + 32 * (wave + 4 * u) + 4 * (lane & 7));
       }
-  }
+  };
+  if constexpr (POST && !SPLIT) load_rvp();  // (SPLIT: requested after the feed-forward, the registers are needed until then)
   const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
   __syncthreads();
   FD_STAMP(1);
   hx8 X[TL_KS];
+  hx8 Xl[SPLIT ? TL_KS : 1];
   f32x16 acc[3], xa[3];
-  auto layer = [&](const char* img) {
+  auto x_load = [&](const char* buf) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int s = 0; s < TL_KS; ++s) {
+      X[s] = rb_ld(buf + li * TL_XROW + 32 * s + 16 * hi);
+      if constexpr (SPLIT) Xl[s] = rb_ld(buf + XLO + li * TL_XROW + 32 * s + 16 * hi);
+    }
+  };
+  auto layer = [&](const void* img_, const void* img_lo_, auto NTC) {
+    constexpr int NT = decltype(NTC)::value, NU = (NT + 3) / 4;
+    const char* img = (const char*)img_;
+    const char* img_lo = (const char*)img_lo_;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
       const int T = wave + 4 * u;
-      if (u + 1 < 3 && T + 4 < TL_NT) {
-        if (u & 1) w_load(std::integral_constant<int, 0>{}, img, T + 4);
-        else w_load(std::integral_constant<int, 1>{}, img, T + 4);
-      }
-      if (T < TL_NT) {
-        f32x16 c;
+      const bool more = u + 1 < NU && T + 4 < NT;
+      if constexpr (SPLIT) {  // Whi.xhi + Whi.xlo out of buffer 0, Wlo.xhi out of buffer 1 (see rowblock_kernel)
+        if (T < NT) {
+          f32x16 c;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[u & 1][s], X[s], c);
-        acc[u] = c;
+          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[0][s], X[s], c);
+#pragma unroll
+          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[0][s], Xl[s], c);
+          if (more) w_load(std::integral_constant<int, 0>{}, img, T + 4);
+#pragma unroll
+          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[1][s], X[s], c);
+          if (more) w_load(std::integral_constant<int, 1>{}, img_lo, T + 4);
+          acc[u] = c;
+        }
+      } else {
+        if (more) {
+          if (u & 1) w_load(std::integral_constant<int, 0>{}, img, T + 4);
+          else w_load(std::integral_constant<int, 1>{}, img, T + 4);
+        }
+        if (T < NT) {
+          f32x16 c;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[u & 1][s], X[s], c);
+          acc[u] = c;
+        }
       }
     }
   };
+  constexpr std::integral_constant<int, TL_NT> NT_D{};
   // LayerNorm of the rows held as acc[] (lane = row, this wave's tiles) -> normalised values back in acc[]
   auto layernorm = [&](const float* gam, const float* bet) {
     // one pass: sum and sum of squares together -> ONE exchange between the lane halves and the four waves
@@ -509,12 +609,11 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
         }
     }
   };
-#pragma unroll
-  for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(xs + li * TL_XROW + 32 * s + 16 * hi);
+  x_load(xs);
   // ---- stage 1: out_proj + x, LayerNorm1
-  layer((const char*)a.wo);
+  layer(a.wo, a.wol, NT_D);
   FD_STAMP(2);
-  w_load(std::integral_constant<int, 0>{}, (const char*)a.w1, wave);  // first feed-forward tile: in flight across the barriers
+  w_first(a.w1, a.w1l);  // first feed-forward tile: in flight across the barriers
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int T = wave + 4 * u;
@@ -541,20 +640,16 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * T + 8 * g + 4 * hi;
-        rb_hx4 pk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = (fd_h)acc[u][4 * g + q];
-        *(rb_hx4*)(hs + li * TL_XROW + 2 * f0) = pk;
+        put4(hs, li * TL_XROW + 2 * f0, acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]);
       }
   }
   __syncthreads();
-#pragma unroll
-  for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(hs + li * TL_XROW + 32 * s + 16 * hi);
+  x_load(hs);
   // ---- stage 2: feed-forward
   FD_STAMP(4);
-  layer((const char*)a.w1);
+  layer(a.w1, a.w1l, NT_D);
   FD_STAMP(5);
-  w_load(std::integral_constant<int, 0>{}, (const char*)a.w2, wave);
+  w_first(a.w2, a.w2l);
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int T = wave + 4 * u;
@@ -563,17 +658,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
       for (int g = 0; g < 4; ++g) {
         const int f0 = 32 * T + 8 * g + 4 * hi;
         const f32x4 bv = *(const f32x4*)(cst + 3 * TL_D + f0);
-        rb_hx4 pk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = (fd_h)fmaxf(acc[u][4 * g + q] + bv[q], 0.f);
-        *(rb_hx4*)(xs + li * TL_XROW + 2 * f0) = pk;   // the att rows are dead: every wave read them before LayerNorm1's barriers
+        // (the att rows are dead: every wave read them before LayerNorm1's barriers)
+        put4(xs, li * TL_XROW + 2 * f0, fmaxf(acc[u][4 * g] + bv[0], 0.f), fmaxf(acc[u][4 * g + 1] + bv[1], 0.f),
+             fmaxf(acc[u][4 * g + 2] + bv[2], 0.f), fmaxf(acc[u][4 * g + 3] + bv[3], 0.f));
       }
   }
   __syncthreads();
-#pragma unroll
-  for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(xs + li * TL_XROW + 32 * s + 16 * hi);
+  x_load(xs);
   FD_STAMP(6);
-  layer((const char*)a.w2);
+  layer(a.w2, a.w2l, NT_D);
   FD_STAMP(7);
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -586,7 +679,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
         for (int q = 0; q < 4; ++q) acc[u][4 * g + q] += bv[q] + xa[u][4 * g + q];
       }
   }
-  if constexpr (POST) w_load(std::integral_constant<int, 0>{}, (const char*)a.wp, wave);  // first post_tfmr tile: in flight across the LayerNorm
+  if constexpr (POST && SPLIT) load_rvp();
+  if constexpr (POST) w_first(a.wp, a.wpl);  // first post_tfmr tile: in flight across the LayerNorm
   layernorm(cst + 5 * TL_D, cst + 6 * TL_D);
   FD_STAMP(8);
   if constexpr (POST) {
@@ -598,26 +692,13 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int f0 = 32 * T + 8 * g + 4 * hi;
-          rb_hx4 pk;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) pk[q] = (fd_h)acc[u][4 * g + q];
-          *(rb_hx4*)(hs + li * TL_XROW + 2 * f0) = pk;   // the x_a rows are dead since stage 2 read them
+          // (the x_a rows are dead since stage 2 read them)
+          put4(hs, li * TL_XROW + 2 * f0, acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]);
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(hs + li * TL_XROW + 32 * s + 16 * hi);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int T = wave + 4 * u;
-      if (u == 0) w_load(std::integral_constant<int, 1>{}, (const char*)a.wp, T + 4);
-      f32x16 c;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[u & 1][s], X[s], c);
-      acc[u] = c;
-    }
+    x_load(hs);
+    layer(a.wp, a.wpl, std::integral_constant<int, TL_NP / 32>{});
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int T = wave + 4 * u;
@@ -667,15 +748,21 @@ int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.ld & 3) || a.x == a.out) return FDIPT_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)tfmr_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM) != hipSuccess ||
-        hipFuncSetAttribute((const void*)tfmr_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)tfmr_tail_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(0)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tfmr_tail_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(0)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tfmr_tail_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(1)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tfmr_tail_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(1)) != hipSuccess)
       return FDIPT_ELAUNCH;
     attr_set = true;
   }
-  if (a.wp) {
-    if (!a.bp || !a.pres || !a.pout || (a.ld_pres & 3) || (a.ld_pout & 3)) return FDIPT_EINVAL;
-    hipLaunchKernelGGL(tfmr_tail_kernel<true>, dim3(cdiv(a.M, 32)), dim3(FD_THREADS), TL_SMEM, st, a);
-  } else hipLaunchKernelGGL(tfmr_tail_kernel<false>, dim3(cdiv(a.M, 32)), dim3(FD_THREADS), TL_SMEM, st, a);
+  const bool split = a.wol != nullptr;  // split operands: every lo image must be there
+  if (split && (!a.w1l || !a.w2l || (a.wp && !a.wpl))) return FDIPT_EINVAL;
+  if (a.wp && (!a.bp || !a.pres || !a.pout || (a.ld_pres & 3) || (a.ld_pout & 3))) return FDIPT_EINVAL;
+  const dim3 grid(cdiv(a.M, 32)), block(FD_THREADS);
+  if (a.wp && split) hipLaunchKernelGGL((tfmr_tail_kernel<true, true>), grid, block, TL_SMEM(1), st, a);
+  else if (a.wp) hipLaunchKernelGGL((tfmr_tail_kernel<true, false>), grid, block, TL_SMEM(0), st, a);
+  else if (split) hipLaunchKernelGGL((tfmr_tail_kernel<false, true>), grid, block, TL_SMEM(1), st, a);
+  else hipLaunchKernelGGL((tfmr_tail_kernel<false, false>), grid, block, TL_SMEM(0), st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -704,6 +791,11 @@ int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
     case FD_RB_FFN: return rb_launch<320, 320, 0, 320, 1 | 4>(a, st);            // l1 relu l2 + residual, LN
     case FD_RB_TRANSITION: return rb_launch<256, 256, 256, 256, 1 | 2 | 4>(a, st);  // t1 relu t2 relu t3 + residual, LN, mask
     case FD_RB_TRANSITION_BB: return rb_launch<256, 256, 256, 256, 1 | 2 | 4 | 8>(a, st);  // ... + BackboneUpdate + compose
+    // split-operand forms (RowBlockArgs.w0l / w1l / w2l): the node embedder, the transition and the torsion head
+    case FD_RB_TRANSITION_BB_SPLIT: return a.w0l && a.w1l && a.w2l ? rb_launch<256, 256, 256, 256, 1 | 2 | 4 | 8 | 32>(a, st) : FDIPT_EINVAL;
+    case FD_RB_NODE_EMBED_72_SPLIT: return a.w0l && a.w1l && a.w2l ? rb_launch<72, 256, 256, 256, 1 | 2 | 4 | 32>(a, st) : FDIPT_EINVAL;
+    case FD_RB_NODE_EMBED_88_SPLIT: return a.w0l && a.w1l && a.w2l ? rb_launch<88, 256, 256, 256, 1 | 2 | 4 | 32>(a, st) : FDIPT_EINVAL;
+    case FD_RB_TORSION_SPLIT: return a.w0l && a.w1l ? rb_launch<256, 256, 0, 256, 1 | 32>(a, st) : FDIPT_EINVAL;
     case FD_RB_NODE_EMBED_72: return rb_launch<72, 256, 256, 256, 1 | 2 | 4>(a, st);
     case FD_RB_NODE_EMBED_88: return rb_launch<88, 256, 256, 256, 1 | 2 | 4>(a, st);
     case FD_RB_TORSION: return rb_launch<256, 256, 0, 256, 1>(a, st);            // l1 relu l2 + residual

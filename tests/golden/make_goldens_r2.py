@@ -1,0 +1,176 @@
+"""Round-2 golden fixtures: the benchmarked sizes, a 4-chain TCR-pMHC-like complex, a masked res_mask, a bb_gain = 0.3
+trajectory, and feature dicts captured from the reference samplers (this container only; imports the reference).
+
+    python tests/golden/make_goldens_r2.py [name ...]      # writes tests/golden/*.npz (all, or the named ones)
+
+Same recipe as make_goldens.py (whose fixtures stay untouched): reference *source* on torch 2.10 / numpy 2.2 / scipy 1.15,
+weights regenerated from framedipt_amd.weights.synth_state_dict.  Large fixtures keep the outputs, the node representation
+after every block and a few rows of the pair representation (a few MB each).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import make_goldens as mg  # noqa: E402  (installs the import stubs, imports the reference)
+import refharness as rh  # noqa: E402
+import torch  # noqa: E402
+from framedipt_amd import weights as W  # noqa: E402
+from openfold.utils import rigid_utils as ru  # noqa: E402
+
+np32 = mg.np32
+
+
+def complex_feats(chain_lens, windows, rng, diff, res_gap=200):
+    """Synthetic multi-chain complex (seq_idx gap `res_gap` between chains, framedipt/data/utils.py:745-890 convention) with
+    diffused windows [(start, stop), ...] in flattened residue indices."""
+    n = int(sum(chain_lens))
+    q = mg.rand_quats(rng, n)
+    tr = np.cumsum(rng.standard_normal((n, 3)) * 2.2, axis=0).astype(np.float32)
+    tr -= tr.mean(0)
+    gt = ru.Rigid.from_tensor_7(torch.tensor(np.concatenate([q, tr], -1)))
+    dm = np.zeros(n)
+    for a, b in windows:
+        dm[a:b] = 1
+    seq_idx, chain_idx, off = [], [], 0
+    for c, L in enumerate(chain_lens):
+        seq_idx.append(np.arange(L) + off + c * res_gap)
+        chain_idx.append(np.full(L, c))
+        off += L
+    seq_idx, chain_idx = np.concatenate(seq_idx), np.concatenate(chain_idx).astype(np.int64)
+    with torch.no_grad():
+        ref = diff.sample_ref(n_samples=n, impute=gt, diffuse_mask=dm, chain_index=chain_idx, as_tensor_7=True)
+    tors = rng.standard_normal((1, n, 7, 2))
+    tors /= np.linalg.norm(tors, axis=-1, keepdims=True)
+    return {
+        "res_mask": torch.ones(1, n, dtype=torch.float64),
+        "seq_idx": torch.tensor(seq_idx)[None],
+        "fixed_mask": torch.tensor(1 - dm)[None],
+        "torsion_angles_sin_cos": torch.tensor(tors),
+        "sc_ca_t": torch.zeros(1, n, 3, dtype=torch.float64),
+        "rigids_t": ref["rigids_t"][None],
+        "aatype": torch.tensor(rng.integers(0, 20, size=(1, n))),
+        "chain_idx": torch.tensor(chain_idx)[None],
+    }
+
+
+def forward_golden(name, cfg, inpainting, t, feats_fn, sc_scale=1.0, trace_rows=(0, 3), bb_gain=W.BB_GAIN, inner=False,
+                   res_mask_zero=()):
+    """feats_fn(rng, diff) -> feature dict (without t).  inner: also the per-block IPA / LayerNorm / transformer traces."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
+    diff, model, shapes = mg.build(cfg, inpainting, bb_gain)
+    f = feats_fn(rng, diff)
+    n = f["rigids_t"].shape[1]
+    if sc_scale:
+        f["sc_ca_t"] = torch.tensor(f["rigids_t"][..., 4:].numpy() + rng.standard_normal((1, n, 3)).astype(np.float32) * sc_scale)
+    if len(res_mask_zero):
+        f["res_mask"] = f["res_mask"].clone()
+        f["res_mask"][0, list(res_mask_zero)] = 0
+    f["t"] = torch.tensor([t], dtype=torch.float32)
+    g = mg.feats_np(f)
+    trace, hooks, rows = {}, [], list(trace_rows)
+    trunk = model.score_model.trunk
+
+    def hk(key, fn=lambda o: o):
+        def _h(_m, _i, o):
+            trace[key] = np32(fn(o))
+        return _h
+
+    nb = cfg.model.ipa.num_blocks
+    for b in range(nb):
+        if inner:
+            hooks.append(trunk[f"ipa_{b}"].register_forward_hook(hk(f"tr_ipa_{b}")))
+            hooks.append(trunk[f"ipa_ln_{b}"].register_forward_hook(hk(f"tr_ipa_ln_{b}")))
+            hooks.append(trunk[f"seq_tfmr_{b}"].register_forward_hook(hk(f"tr_tfmr_{b}")))
+        hooks.append(trunk[f"node_transition_{b}"].register_forward_hook(hk(f"tr_node_{b}")))
+        hooks.append(trunk[f"bb_update_{b}"].register_forward_hook(hk(f"tr_bbupd_{b}")))
+        if b < nb - 1:
+            hooks.append(trunk[f"edge_transition_{b}"].register_forward_hook(hk(f"tr_edge_{b}", lambda o: o[:, rows])))
+    hooks.append(model.embedding_layer.register_forward_hook(
+        lambda _m, _i, o: trace.update(tr_node_init=np32(o[0]), tr_edge_init=np32(o[1][:, rows]))))
+    with torch.no_grad():
+        out = model(f)
+    for h in hooks:
+        h.remove()
+    g.update({"out_" + k: np32(v) for k, v in out.items()})
+    g.update(trace)
+    g["trace_rows"] = np.array(trace_rows)
+    g["weight_seed"] = mg.WEIGHT_SEED
+    g["bb_gain"] = bb_gain
+    np.savez_compressed(os.path.join(HERE, f"fwd_{name}.npz"), **g)
+    print(name, n, {k: float(np.abs(v).max()) for k, v in out.items()}, flush=True)
+
+
+def traj_golden_gain(name, cfg, n, num_t, bb_gain, noise_scale=0.1, min_t=0.01):
+    """make_goldens.traj_golden with a bb_gain other than the default (frames move by O(1) A per block)."""
+    saved = W.BB_GAIN
+    build0 = mg.build
+    mg.build = lambda c, inp=False, g=bb_gain: build0(c, inp, g)
+    try:
+        mg.traj_golden(name, cfg, n, False, num_t, noise_scale, min_t)
+    finally:
+        mg.build = build0
+    p = os.path.join(HERE, f"traj_{name}.npz")
+    g = dict(np.load(p))
+    g["bb_gain"] = np.float64(bb_gain)
+    np.savez_compressed(p, **g)
+    assert saved == W.BB_GAIN
+
+
+def sampler_goldens():
+    """Feature dicts as the reference samplers return them (experiments/sampler.py:69-135,267-354): keys, dtypes, shapes and
+    values for a fixed seed.  The conditional sampler reads processed-structure pickles through data_utils.process_csv_row;
+    here its per-structure feature dict is handed over directly (the pickle / CSV layer is the 'next' row f2)."""
+    from experiments import sampler as rs
+    from framedipt.diffusion import se3_diffuser
+    cfg = rh.load_cfg()
+    g = {}
+    diff = se3_diffuser.SE3Diffuser(cfg.diffuser)  # np.random.seed(123)
+    ds = rs.UnconditionalSampler(rh.to_attr({"min_length": 20, "max_length": 24, "length_step": 4, "samples_per_length": 2}),
+                                 diffuser=diff, device="cpu")
+    g["uncond_len"] = np.array([len(ds)])
+    for i in (0, 3):
+        with torch.no_grad():  # (the reference's inference entry point runs the dataset under no_grad as well)
+            length, sample_id, feats = ds[i]
+        g[f"uncond_{i}_meta"] = np.array([length, sample_id])
+        for k, v in feats.items():
+            g[f"uncond_{i}_{k}"] = v.numpy()
+            g[f"uncond_{i}_{k}_dtype"] = np.array(str(v.dtype))
+    np.savez_compressed(os.path.join(HERE, "sampler_dicts.npz"), **g)
+    print("sampler_dicts", sorted(k for k in g if k.startswith("uncond_0_") and not k.endswith("_dtype")), flush=True)
+
+
+def denovo(n):
+    return lambda rng, diff: mg.make_feats(n, rng, False, diff)
+
+
+JOBS = {
+    "full_denovo_n128": lambda: forward_golden("full_denovo_n128", rh.load_cfg(), False, 0.5, denovo(128), trace_rows=(0, 3, 64, 127)),
+    "full_denovo_n300_t50": lambda: forward_golden("full_denovo_n300_t50", rh.load_cfg(), False, 0.5, denovo(300),
+                                                   trace_rows=(0, 3, 150, 299)),
+    "full_denovo_n300_t02": lambda: forward_golden("full_denovo_n300_t02", rh.load_cfg(), False, 0.02, denovo(300),
+                                                   trace_rows=(0, 3, 150, 299)),
+    "full_denovo_n64_inner": lambda: forward_golden("full_denovo_n64_inner", rh.load_cfg(), False, 0.3, denovo(64), inner=True),
+    "full_denovo_n64_masked": lambda: forward_golden("full_denovo_n64_masked", rh.load_cfg(), False, 0.5, denovo(64),
+                                                     res_mask_zero=(5, 6, 31, 61, 62, 63)),
+    "full_inpaint_n724_4chain": lambda: forward_golden(
+        "full_inpaint_n724_4chain", rh.load_cfg(inpainting=True), True, 0.4,
+        lambda rng, diff: complex_feats((200, 240, 9, 275), ((92, 106), (330, 345)), rng, diff), trace_rows=(0, 100, 444, 723)),
+    "full_inpaint_n1000": lambda: forward_golden(
+        "full_inpaint_n1000", rh.load_cfg(inpainting=True), True, 0.6,
+        lambda rng, diff: complex_feats((500, 500), ((40, 90),), rng, diff), trace_rows=(0, 60, 999)),
+    "traj_full_denovo_n300_T5": lambda: mg.traj_golden("full_denovo_n300_T5", rh.load_cfg(), 300, False, 5),
+    "traj_full_denovo_n64_T20_gain03": lambda: traj_golden_gain("full_denovo_n64_T20_gain03", rh.load_cfg(), 64, 20, 0.3),
+    "sampler_dicts": sampler_goldens,
+}
+
+
+if __name__ == "__main__":
+    for name in (sys.argv[1:] or list(JOBS)):
+        JOBS[name]()
