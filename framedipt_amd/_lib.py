@@ -36,7 +36,7 @@ class ForwardArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("n_rel", C.c_int32), ("rel_off", C.c_int32)] + [
         (n, _P) for n in ("rigids_t", "res_mask", "fixed_mask", "sc_ca_t", "seq_idx", "idx_emb", "aatype", "gt_psi", "t",
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
-                          "atom37", "atom14", "trace_node", "trace_edge")] + [
+                          "atom37", "atom14", "trace_node", "trace_edge", "trace_inner")] + [
         ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P)]
 
 

@@ -604,6 +604,14 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     return fd_chain(kind, c, st);
   };
 
+  // inner traces (parity tests): rows of width `cols` (leading dimension ld) -> slot of block b
+  auto inner = [&](int b, int slot, const float* src, int ld, int cols) -> int {
+    if (!a->trace_inner) return FDIPT_OK;
+    float* dst = a->trace_inner + ((size_t)(b * 4 + slot) * R) * dt;
+    return hipMemcpy2DAsync(dst, (size_t)dt * 4, src, (size_t)ld * 4, (size_t)cols * 4, R, hipMemcpyDeviceToDevice, st) == hipSuccess
+               ? FDIPT_OK : FDIPT_ELAUNCH;
+  };
+  if (a->trace_inner && (rbk || (bf && iv.feat_dim >= 1024 && !sw.no_splitk))) return FDIPT_EINVAL;  // fused node path: the tensors never exist
   bool ee_bias_done = false;
   // ---- Embedder (score_network.py:129-197)
   // ... with the split of x_t (ipa_pytorch.py:516-524) and the per-residue halves of the first edge-embedder layer in the same
@@ -775,6 +783,8 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     } else {
       RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
       RC(fd_layernorm(R, cs, node_cur, cs, F(w.ipa_out), cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr, F(w.tf_in), dt, st));
+      RC(inner(b, 0, F(w.ipa_out), cs, cs));
+      RC(inner(b, 1, F(w.tf_in), dt, cs));
     }
     if (skip_done) {
     } else if (con(FD_CHAIN_SKIP)) RC(chain(FD_CHAIN_SKIP, F(w.node0), cs, D + db.ch.skip, P + k.skip.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
@@ -860,6 +870,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       }
       x = F(w.x_b);  // next layer: norm1 reads x_b -> x_a, norm2 reads x_a/att -> x_b (no aliasing)
     }
+    RC(inner(b, 2, x, dt, dt));
     // node = node + post_tfmr(x); StructureModuleTransition; mask   (ipa:539-541, 36-58)
     if (post_done) {
     } else if (con(FD_CHAIN_POST)) {
@@ -901,6 +912,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     // only on rows whose update is masked out below, so the input mask is not materialised.
     if (!bb_done) {
       RC(lin32(R, k.bb, node_cur, cs, F(w.upd), 8));
+      RC(inner(b, 3, F(w.upd), 8, 6));
       RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
     }
     if (b < d->num_blocks - 1) {

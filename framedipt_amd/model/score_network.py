@@ -41,7 +41,7 @@ def preprocess_aatype(aatype, fixed_mask, inpainting: bool, input_aatype: bool):
 class BatchState:
     """Device buffers of one batch of B equally sized samples (constant along a trajectory)."""
 
-    def __init__(self, net: "ScoreNetwork", seq_idx: torch.Tensor, trace: bool = False):
+    def __init__(self, net: "ScoreNetwork", seq_idx: torch.Tensor, trace: bool = False, trace_inner: bool = False):
         lib = _lib.load()
         self.net = net
         dev = net.device
@@ -74,6 +74,7 @@ class BatchState:
         if trace:
             self.trace_node = torch.zeros(d.num_blocks + 1, B, N, d.c_s, **f32)
             self.trace_edge = torch.zeros(d.num_blocks, B, N, N, d.c_z, **f32)
+        self.trace_inner = (torch.zeros(d.num_blocks, 4, B, N, d.c_s + d.c_skip, **f32) if trace_inner else None)
         self.ev_start = self.ev_stop = None  # optional hipEvent pairs around the EdgeTransition launches (bench.py)
         self.t_emb_eps = torch.as_tensor(embedding.get_timestep_embedding(np.array([1e-5], dtype=np.float32), E)[0],
                                          device=dev)
@@ -92,7 +93,8 @@ class BatchState:
                           ("bb_tables", net.bb_tables), ("psi", self.psi), ("rot_score", self.rot_score),
                           ("trans_score", self.trans_score), ("rigids", self.rigids),
                           ("atom37", self.atom37 if want_atoms else None), ("atom14", self.atom14 if want_atoms else None),
-                          ("trace_node", self.trace_node), ("trace_edge", self.trace_edge), ("ca_out", ca_out)):
+                          ("trace_node", self.trace_node), ("trace_edge", self.trace_edge), ("trace_inner", self.trace_inner),
+                          ("ca_out", ca_out)):
             setattr(a, name, _lib.ptr(tns))
         if self.ev_start is not None:
             a.ev_start, a.ev_stop = self.ev_start, self.ev_stop
@@ -177,13 +179,13 @@ class ScoreNetwork:
         self._state = None
 
     # ------------------------------------------------------------------ batch state
-    def batch_state(self, seq_idx: torch.Tensor, trace: bool = False) -> BatchState:
+    def batch_state(self, seq_idx: torch.Tensor, trace: bool = False, trace_inner: bool = False) -> BatchState:
         if self.params is None:
             raise _lib.FdiptError("ScoreNetwork has no weights on a device: call load_state_dict(...) and .to('cuda')")
-        key = (tuple(seq_idx.shape), seq_idx.detach().cpu().numpy().tobytes(), trace)
+        key = (tuple(seq_idx.shape), seq_idx.detach().cpu().numpy().tobytes(), trace, trace_inner)
         if self._state is None or self._state_key != key:
             with torch.cuda.device(self.device):
-                self._state = BatchState(self, seq_idx, trace)
+                self._state = BatchState(self, seq_idx, trace, trace_inner)
             self._state_key = key
         return self._state
 
@@ -195,11 +197,11 @@ class ScoreNetwork:
         return t32, temb, sig
 
     # ------------------------------------------------------------------ forward (API-compatible)
-    def __call__(self, input_feats: dict, trace: bool = False) -> dict:
+    def __call__(self, input_feats: dict, trace: bool = False, trace_inner: bool = False) -> dict:
         dev = self.device
         rig = input_feats["rigids_t"]
         _lib.require_cuda(rig, "ScoreNetwork.forward")
-        st = self.batch_state(input_feats["seq_idx"], trace)
+        st = self.batch_state(input_feats["seq_idx"], trace, trace_inner)
         f32 = lambda x: x.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         fixed = f32(input_feats["fixed_mask"])
         aatype = preprocess_aatype(input_feats.get("aatype"), fixed, self.inpainting, self._model_conf.input_aatype)
@@ -215,4 +217,6 @@ class ScoreNetwork:
                "rigids": st.rigids.clone(), "atom37": st.atom37.clone(), "atom14": st.atom14.clone()}
         if trace:
             out["trace_node"], out["trace_edge"] = st.trace_node, st.trace_edge
+        if trace_inner:
+            out["trace_inner"] = st.trace_inner
         return out

@@ -126,6 +126,11 @@ typedef struct FdiptForwardArgs {
   /* optional traces for parity tests (NULL to skip): node / pair representation after each block */
   float* trace_node;              /* [num_blocks+1,B,N,c_s] f32: [0]=embedder output               */
   float* trace_edge;              /* [num_blocks,B,N,N,c_z] f32: [0]=embedder output, [b+1]=EdgeTransition b */
+  /* optional, parity tests of the per-block sub-modules: [num_blocks,4,B,N,c_s+c_skip] f32 with slot 0 = IPA output
+   * (ipa_pytorch.py:531, first c_s columns), 1 = post-IPA LayerNorm (:532, c_s), 2 = sequence-transformer output (:536-538,
+   * c_s+c_skip), 3 = BackboneUpdate output (:542-545, 6).  Only the unfused node path keeps these tensors in memory: fp32
+   * precision, or FDIPT_KF_UNFUSED_NODE | FDIPT_KF_UNFOLDED; FDIPT_EINVAL otherwise.  NULL to skip. */
+  float* trace_inner;
   /* optional profiling: hipEvent_t pairs recorded on `stream` around every EdgeTransition launch
    * (num_blocks-1 pairs, created with fdipt_event_create); NULL to skip */
   void** ev_start;                /* host array of events */

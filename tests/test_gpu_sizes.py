@@ -1,0 +1,205 @@
+"""GPU parity tests (-m gpu) at the benchmarked sizes: reference goldens at N = 128 / 300 / 724 (4 chains) / 1000, a masked
+res_mask, a bb_gain = 0.3 trajectory (tests/golden/make_goldens_r2.py), for the fp32 mode and the fp16 throughput mode —
+each with its stated bound — on the kernel instantiations those sizes select (three key tiles per wave, the persistent
+EdgeTransition tile walk, patches straddling samples, the N > 512 attention path)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import kabsch_free_rmsd, load_golden
+from test_gpu_parity import _feats, _net, _teacher_forced_steps, _teacher_forced_worst_rmsd, dev
+
+pytestmark = pytest.mark.gpu
+
+SIZES = ["full_denovo_n128", "full_denovo_n300_t50", "full_denovo_n300_t02", "full_denovo_n64_inner", "full_denovo_n64_masked",
+         "full_inpaint_n724_4chain", "full_inpaint_n1000"]
+
+
+def _psi_err(a, b):
+    ang = lambda p: np.arctan2(p[..., 0], p[..., 1])  # noqa: E731
+    return np.abs(np.angle(np.exp(1j * (ang(a) - ang(b)))))
+
+
+def _conditioned(G, d, t):
+    """Residues where the reference's float32 IGSO(3) series is conditioned (f > 1e-2): the rotation score is
+    asserted there; elsewhere the reference's own value is float32 round-off over the 1e-4 regulariser."""
+    from oracle import diffuser as od
+    from oracle import frames as fr
+    q0, qt = G["out_rigids"][..., :4].astype(np.float32), G["in_rigids_t"][..., :4].astype(np.float32)
+    rv = fr.quat_to_rotvec(fr.quat_multiply(fr.invert_quat(q0), qt).astype(np.float32))
+    sig = d._so3_diffuser.score_sigma(np.float32(t))[0]
+    f = od.igso3_expansion_np(np.linalg.norm(rv, axis=-1).astype(np.float64), sig)
+    return f > 1e-2
+
+
+@pytest.mark.parametrize("name", SIZES)
+def test_forward_fp32_at_size(name):
+    """fp32 mode vs the reference: every node trace <= 2e-4, the stored pair rows <= 2e-4, frames / psi / atoms as at N = 64."""
+    G = load_golden(f"fwd_{name}.npz")
+    net, d, conf = _net(name, G, "fp32")
+    out = net(_feats(G), trace=True)
+    rows = list(G["trace_rows"])
+    tn, te = out["trace_node"].cpu().numpy(), out["trace_edge"].cpu().numpy()
+    m = G["in_res_mask"][..., None]
+    np.testing.assert_allclose(tn[0], G["tr_node_init"] * m, atol=1e-4)
+    em = (G["in_res_mask"][:, rows, None] * G["in_res_mask"][:, None, :])[..., None]
+    np.testing.assert_allclose(te[0][:, rows], G["tr_edge_init"] * em, atol=1e-4)
+    for b in range(4):
+        np.testing.assert_allclose(tn[b + 1], G[f"tr_node_{b}"] * m, atol=2e-4, err_msg=f"node {b}")
+        if b < 3:
+            np.testing.assert_allclose(te[b + 1][:, rows], G[f"tr_edge_{b}"] * em, atol=2e-4, err_msg=f"edge {b}")
+    o = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith("trace")}
+    np.testing.assert_allclose(o["rigids"][..., 4:], G["out_rigids"][..., 4:], atol=3e-4)
+    np.testing.assert_allclose(np.abs(o["rigids"][..., :4]), np.abs(G["out_rigids"][..., :4]), atol=1e-5)
+    assert _psi_err(o["psi"], G["out_psi"]).max() < 3e-4
+    assert kabsch_free_rmsd(o["atom37"], G["out_atom37"]) < 1e-4
+    np.testing.assert_allclose(o["atom14"], G["out_atom14"], atol=1e-3)
+    ts = max(np.abs(G["out_trans_score"]).max(), 1.0)
+    np.testing.assert_allclose(o["trans_score"], G["out_trans_score"], atol=3e-4 * ts)
+    ok = _conditioned(G, d, float(G["in_t"][0])) & (G["in_res_mask"] > 0)
+    err, mag = np.abs(o["rot_score"] - G["out_rot_score"]).max(-1), np.abs(G["out_rot_score"]).max(-1)
+    print(f"{name}: rot score asserted on {ok.mean():.0%} of the residues (conditioned series)")
+    assert (err[ok] <= 3e-3 * mag[ok] + 1e-5).all()
+    if name != "full_denovo_n300_t02":  # t = 0.02: sigma = 0.13 rad, no residue of this fixture sits within ~5 sigma of its prediction
+        assert ok.mean() > 0.5
+
+
+# fp16 throughput mode (fp16 MFMA operands / pair representation, split operands on the node path): stated bounds per forward
+FP16_BOUND = dict(node_rel=3e-4, edge_rel=1.2e-3, ca=5e-4, psi_rms=5e-4, bb_rmsd=3e-4)
+
+
+@pytest.mark.parametrize("name", SIZES)
+def test_forward_fp16_at_size(name):
+    G = load_golden(f"fwd_{name}.npz")
+    net, d, conf = _net(name, G, "fp16")
+    out = net(_feats(G), trace=True)
+    rows = list(G["trace_rows"])
+    tn, te = out["trace_node"].cpu().numpy(), out["trace_edge"].cpu().numpy()
+    m = G["in_res_mask"][..., None]
+    em = (G["in_res_mask"][:, rows, None] * G["in_res_mask"][:, None, :])[..., None]
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))  # noqa: E731
+    nrel = [rel(tn[b + 1], G[f"tr_node_{b}"] * m) for b in range(4)]
+    erel = [rel(te[0][:, rows], G["tr_edge_init"] * em)] + [rel(te[b + 1][:, rows], G[f"tr_edge_{b}"] * em) for b in range(3)]
+    o = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith("trace")}
+    diffused = (1 - G["in_fixed_mask"]) * G["in_res_mask"] > 0
+    ca = np.abs(o["rigids"][..., 4:] - G["out_rigids"][..., 4:]).max()
+    pe = _psi_err(o["psi"], G["out_psi"])[diffused]
+    rm = kabsch_free_rmsd(o["atom37"], G["out_atom37"])
+    print(f"fp16 {name}: node rel {max(nrel):.2e} edge rel {max(erel):.2e} CA max {ca:.2e} A psi rms {np.sqrt((pe**2).mean()):.2e} "
+          f"max {pe.max():.2e} rad backbone rmsd {rm:.2e} A")
+    assert max(nrel) < FP16_BOUND["node_rel"] and max(erel) < FP16_BOUND["edge_rel"]
+    assert ca < FP16_BOUND["ca"] and np.sqrt((pe**2).mean()) < FP16_BOUND["psi_rms"] and rm < FP16_BOUND["bb_rmsd"]
+
+
+def test_inner_traces_unfused_node_path():
+    """Per-block IPA output, post-IPA LayerNorm, sequence-transformer output and BackboneUpdate of the reference
+    (tr_ipa / tr_ipa_ln / tr_tfmr / tr_bbupd) vs the forward's inner traces (fp32 mode: every tensor exists in memory)."""
+    G = load_golden("fwd_full_denovo_n64_inner.npz")
+    net, d, conf = _net("full_denovo_n64_inner", G, "fp32")
+    out = net(_feats(G), trace=True, trace_inner=True)
+    ti = out["trace_inner"].cpu().numpy()  # [blocks, 4, B, N, 320]
+    for b in range(4):
+        np.testing.assert_allclose(ti[b, 0, ..., :256], G[f"tr_ipa_{b}"], atol=2e-4, err_msg=f"ipa {b}")
+        np.testing.assert_allclose(ti[b, 1, ..., :256], G[f"tr_ipa_ln_{b}"], atol=2e-4, err_msg=f"ipa_ln {b}")
+        np.testing.assert_allclose(ti[b, 2], G[f"tr_tfmr_{b}"], atol=2e-4, err_msg=f"tfmr {b}")
+        np.testing.assert_allclose(ti[b, 3, ..., :6], G[f"tr_bbupd_{b}"], atol=2e-5, err_msg=f"bb_update {b}")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_batch_of_equal_samples_matches_single(prec):
+    """B > 1: the same sample twice in a batch gives the B = 1 result (bit-identical: every per-pair / per-row computation
+    is independent of its position in the batch)."""
+    G = load_golden("fwd_full_denovo_n128.npz")
+    net, d, conf = _net("full_denovo_n128", G, prec)
+    f1 = _feats(G)
+    one = {k: v.clone() for k, v in net(f1).items()}
+    f2 = {k: torch.cat([v, v], 0) for k, v in f1.items()}
+    two = net(f2)
+    for k in ("rigids", "psi", "rot_score", "trans_score", "atom37"):
+        for s in range(2):
+            assert torch.equal(two[k][s], one[k][0]), (k, s, float((two[k][s] - one[k][0]).abs().max()))
+
+
+def test_teacher_forced_fp32_n300():
+    worst, _ = _teacher_forced_worst_rmsd("full_denovo_n300_T5", "fp32")
+    assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("name", ["small_denovo_n16_T10", "small_inpaint_n24_T10", "full_denovo_n64_T20", "full_denovo_n300_T5"])
+def test_teacher_forced_fp16_meets_the_north_star_bound(name):
+    """fp16 throughput mode, per-step parity: reference state in -> one HIP step -> backbone RMSD of x_{t-1}
+    against the reference's < 1e-3 A at every step (the mode bench.py times)."""
+    worst, worst_noisy = _teacher_forced_worst_rmsd(name, "fp16")
+    print(f"fp16 teacher-forced per-step backbone RMSD {name}: worst step {worst:.3e} A (reverse steps {worst_noisy:.3e} A)")
+    assert worst < 1e-3, worst
+
+
+# bb_gain = 0.3: BackboneUpdate moves frames by ~3 A per block instead of ~0.3 A, so an error of the node representation moves the
+# predicted frames ten times further.  It also takes the reference's own rotation score out of its conditioned regime at small t
+# ("conditioning of the rotation score"): at t = 0.114 and 0.062 of this trajectory the float32 IGSO(3) series of the
+# reference is round-off over the 1e-4 regulariser for most residues, and the NumPy restatement of the very same dtype flow
+# (oracle/, x_0 prediction equal to 7e-6 A) already lands 1.2e-3 / 6.4e-3 A away from the reference's x_{t-1}.  Per-step parity
+# is therefore asserted on x_{t-1} where the series is conditioned (t > 0.15) and on the x_0 prediction at every step.
+# The fp16 mode lands at 1.8e-3 / 1.9e-3 A here (its x_0 error scales with the frame updates: 1.5e-4 A per forward at bb_gain 0.03);
+# what is left after the split-operand node path is the fp16 EdgeTransition / attention operand rounding (tools/err_budget.py).
+@pytest.mark.parametrize("prec,bound_next,bound_x0", [("fp32", 1e-4, 1e-4), ("fp16", 3e-3, 3e-3)])
+def test_teacher_forced_large_frame_updates(prec, bound_next, bound_x0):
+    r = _teacher_forced_steps("full_denovo_n64_T20_gain03", prec)
+    cond = (r[:, 0] > 0.15) | (r[:, 0] < 0.011)
+    print(f"{prec} bb_gain 0.3: x_(t-1) worst {r[cond, 1].max():.3e} A on conditioned steps ({r[~cond, 1].max():.3e} A on the two "
+          f"unconditioned ones), x_0 prediction worst {r[:, 2].max():.3e} A")
+    assert r[cond, 1].max() < bound_next and r[:, 2].max() < bound_x0
+
+
+def test_sampler_dict_matches_reference_sampler():
+    """UnconditionalSampler items vs dicts captured from the reference sampler (keys, dtypes, shapes, values; fixed seed)."""
+    from framedipt_amd import config
+    from framedipt_amd import rigid as R
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.sampler import UnconditionalSampler
+    S = load_golden("sampler_dicts.npz")
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")  # reseeds np.random as the reference constructor does
+    ds = UnconditionalSampler(config.to_conf({"min_length": 20, "max_length": 24, "length_step": 4, "samples_per_length": 2}), d, "cuda")
+    assert len(ds) == int(S["uncond_len"][0])
+    for i in (0, 3):  # (the capture drew items 0 and 3, in this order, from the global stream)
+        length, sample_i, feats = ds[i]
+        assert [int(length), int(sample_i)] == list(S[f"uncond_{i}_meta"])
+        keys = sorted(k[len(f"uncond_{i}_"):] for k in S if k.startswith(f"uncond_{i}_") and not k.endswith("_dtype") and not k.endswith("_meta"))
+        assert sorted(feats) == keys
+        for k in keys:
+            ref = S[f"uncond_{i}_{k}"]
+            assert str(feats[k].dtype) == str(S[f"uncond_{i}_{k}_dtype"]), k
+            assert tuple(feats[k].shape) == ref.shape, k
+            if k == "rigids_t":
+                np.testing.assert_allclose(R.quat_to_rot(feats[k][0, :, :4]).cpu().numpy(),
+                                           R.quat_to_rot(dev(ref[0, :, :4])).cpu().numpy(), atol=3e-6)
+                np.testing.assert_allclose(feats[k][..., 4:].cpu().numpy(), ref[..., 4:], atol=1e-6)
+            else:
+                np.testing.assert_array_equal(feats[k].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("name", ["traj_small_inpaint_n24_T10.npz", "traj_full_denovo_n64_T20.npz"])
+def test_reverse_api_with_rigid_objects(name):
+    """SE3Diffuser.reverse(Rigid, rot_score, trans_score, ...) (se3_diffuser.py:346-401), the documented drop-in surface:
+    NumPy scores in, Rigid out, noise drawn from the global np.random stream in the reference's order."""
+    from framedipt_amd import config
+    from framedipt_amd import rigid as R
+    from framedipt_amd.diffusion import SE3Diffuser
+    T = load_golden(name)
+    d = SE3Diffuser(config.base_config().diffuser)
+    dm = ((1 - T["in_fixed_mask"]) * T["in_res_mask"])
+    dt = 1.0 / int(T["num_t"])
+    orig = np.random.normal
+    for s in (0, len(T["step_t"]) // 2, len(T["step_t"]) - 1):
+        tape = [T["noise_tape"][2 * s], T["noise_tape"][2 * s + 1]]
+        np.random.normal = lambda size=None, _t=tape: _t.pop(0).reshape(size)  # the reference's draws, in its order
+        try:
+            out = d.reverse(R.Rigid.from_tensor_7(dev(T["step_rigids_t"][s])), T["step_rot_score"][s], T["step_trans_score"][s],
+                            float(T["step_t"][s]), dt, diffuse_mask=dm, center=True, noise_scale=float(T["noise_scale"]))
+        finally:
+            np.random.normal = orig
+        assert not tape
+        assert isinstance(out, R.Rigid)
+        np.testing.assert_allclose(out.get_rots().get_rot_mats().cpu().numpy(), T["step_out_rot"][s], atol=1e-6)
+        np.testing.assert_allclose(out.get_trans().cpu().numpy(), T["step_out_trans"][s], atol=3e-5)
