@@ -1,20 +1,32 @@
 #!/usr/bin/env python
-"""Headline benchmark: residue x diffusion-steps / s of the de novo sampler (BASELINE.json metric).
+"""Headline benchmark: residue x diffusion-steps / s of the sampler hot loop (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 [--steps K] [--warmup W] [--config c4|c2|c3|c5] [--precision fp16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[3], weak scaling): de novo backbone, length 300, 8 samples per GPU batched in one
-trajectory batch, 500-step schedule, synthetic weights of the full 17.4 M-parameter network, bf16 GEMM operands.
-A "step" = one reverse-diffusion step of the whole batch (score-network forward + fused SE(3) reverse step +
-backbone atoms); K consecutive steps of the 500-step schedule are timed after W warm-up steps, inputs and the
-noise tape already resident in HBM.  value = B*N*K*n_gpus / max-over-ranks(time).
+Workloads (BASELINE.json configs, per GPU; weak scaling, samples sharded round-robin, no collective on the data path):
+  c4 (default, the config the metric is quoted on): de novo, N = 300, 8 samples batched, T = 500, fp16 mode
+  c2: de novo, N = 128, 8 samples, T = 500, fp16 mode
+  c3: TCR-pMHC-like inpainting, one synthetic 4-chain complex (200 + 240 + 9 + 275 = 724 residues, seq_idx gap 200, two
+      CDR3-like windows), 5 samples, T = 100, fp16 mode
+  c5: long-chain inpainting, N = 1000 (2 chains), 4 samples, one diffused window of 50, T = 100, fp32 mode
+fp16 mode = fp16 MFMA operands / pair representation with split (hi + lo) operands on the node path: the mode whose per-step
+backbone RMSD against the reference is < 1e-3 A (tests/test_gpu_sizes.py::test_teacher_forced_fp16_meets_the_north_star_bound).
 
-Also reported on the same JSON line:
-  roofline     : the dominant kernel (EdgeTransition, 89 % of reference FLOPs) timed with HIP events on the
-                 launch stream inside the timed region; achieved = reference-formulation FLOPs per launch / duration.
-  cpu_baseline : the NumPy oracle (port of the reference loop) timed on this box's host cores on a bounded sample.
+A "step" = one reverse-diffusion step of the whole batch exactly as inference_fn runs it with aux_traj=True (the reference's
+caller always passes it, experiments/inference.py:218,331): score-network forward incl. its backbone atoms, fused SE(3)
+reverse step + atom37 frame of x_{t-1}, trajectory writes.  By default K = T: W warm-up steps on a scratch trajectory, then
+the WHOLE trajectory is timed (self-conditioning priming forward + T steps, t = 1 -> min_t, the last step takes the x_0
+branch); with K < T the K timed steps are spread evenly over the schedule (every noise level, incl. the last step), priming
+untimed.  Inputs, weights and the noise tape are resident in HBM before the timed region; value = B*N*K*n_gpus / max-over-ranks.
+Every sample draws x_T and its noise tape from its own stream (seed + global sample index, framedipt_amd/sharding.py).
+
+Also on the JSON line:
+  roofline     : the dominant kernel (EdgeTransition, 89 % of the reference FLOPs) timed with HIP events recorded by the library
+                 on the launch stream around its launches in up to 16 steps of the timed region, read back after the region;
+                 achieved = reference-formulation FLOPs per launch / duration (executed FLOPs stated beside it).
+  cpu_baseline : the NumPy oracle (port of the reference loop) on this box's host cores, bounded sample, rank 0, N = 1 only.
 """
 from __future__ import annotations
 
@@ -30,33 +42,60 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ET_FLOPS_PER_PAIR = 688128.0  # 2*(2*384^2 + 384*128): EdgeTransition, reference formulation
+ET_FLOPS_PER_PAIR = 688128.0   # 2*(2*384^2 + 384*128): EdgeTransition, reference formulation
+ET4_EXEC_FLOPS_PER_PAIR = 536 * 32 * 32 * 16 * 2 / 32.0  # edge_transition4: 536 MFMAs of 32x32x16 per 32-pair wave tile
 PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+
+CONFIGS = {
+    "c2": dict(n=128, b=8, t=500, prec="fp16", inpaint=False),
+    "c3": dict(n=724, b=5, t=100, prec="fp16", inpaint=True, chains=(200, 240, 9, 275), windows=((92, 106), (330, 345))),
+    "c4": dict(n=300, b=8, t=500, prec="fp16", inpaint=False),
+    "c5": dict(n=1000, b=4, t=100, prec="fp32", inpaint=True, chains=(500, 500), windows=((40, 90),)),
+}
 
 
 def pmc_traffic(precision: str, n: int, b: int):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), only when the
-    bench runs the profiled configuration; the counters cannot be read from inside this process."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_edge_transition.json")) as f:
-            rec = json.load(f)
-        w = rec["workload"]
-        if (w["precision"], w["n_res"], w["samples_per_gpu"]) == (precision, n, b):
-            return rec["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), only when the bench
+    runs the profiled configuration; the counters cannot be read from inside this process."""
+    for name in ("r02_pmc_edge_transition.json", "r01_pmc_edge_transition.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+            w = rec["workload"]
+            if (w["precision"], w["n_res"], w["samples_per_gpu"]) == (precision, n, b):
+                return {"total": rec["traffic_bytes"], "read": rec.get("read_bytes"), "write": rec.get("write_bytes"),
+                        "algorithmic": rec.get("algorithmic_bytes"), "source": "profiles/" + name}
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
-def flops_per_forward(n: int) -> float:
-    """SURVEY.md 8d / BASELINE.md section 3 (de novo)."""
-    return 2248960.0 * n * n + 32.4e6 * n
+def flops_per_forward(n: int, inpainting: bool = False) -> float:
+    """SURVEY.md 8d / BASELINE.md section 3: reference-formulation FLOPs of one score-network forward."""
+    c2 = 2248960.0 + (107008.0 - 96256.0 if inpainting else 0.0)
+    return c2 * n * n + 32.4e6 * n
 
 
-def make_batch(sampler, B):
-    import torch
-    items = [sampler[i][2] for i in range(B)]
-    return {k: torch.cat([it[k] for it in items], dim=0) for k in items[0]}
+def synthetic_complex(chain_lens, windows, seed=0):
+    """Per-structure feature dict of a synthetic multi-chain complex (what data_utils.process_csv_row would hand over)."""
+    rng = np.random.default_rng(seed)
+    n = int(sum(chain_lens))
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    tr = np.cumsum(rng.standard_normal((n, 3)) * 2.2, 0)
+    tr -= tr.mean(0)
+    dm = np.zeros(n)
+    for a, b in windows:
+        dm[a:b] = 1
+    seq_idx, chain_idx, off = [], [], 0
+    for c, L in enumerate(chain_lens):
+        seq_idx.append(np.arange(L) + off + c * 200)
+        chain_idx.append(np.full(L, c))
+        off += L
+    tors = rng.standard_normal((n, 7, 2))
+    tors /= np.linalg.norm(tors, axis=-1, keepdims=True)
+    return {"rigids_0": np.concatenate([q, tr], -1).astype(np.float32), "diffuse_mask": dm, "aatype": rng.integers(0, 20, n),
+            "seq_idx": np.concatenate(seq_idx), "chain_idx": np.concatenate(chain_idx), "torsion_angles_sin_cos": tors}
 
 
 def cpu_baseline(n: int, conf, seed: int, steps: int = 2):
@@ -69,7 +108,6 @@ def cpu_baseline(n: int, conf, seed: int, steps: int = 2):
     odiff = od.SE3Diffuser(conf.diffuser)
     net = OracleNet(conf.model, odiff, W.synth_state_dict(W.param_shapes(conf.model), seed), tables=tables)
     feats = oi.unconditional_feats(odiff, n)
-    # steps of a 500-step schedule: emulate with num_t=500 but run only the first `steps`
     tp = np.ones((1,), dtype=np.float32)
     sched = np.linspace(0.01, 1.0, 500)[::-1]
     t0 = time.perf_counter()
@@ -81,21 +119,35 @@ def cpu_baseline(n: int, conf, seed: int, steps: int = 2):
     fwd = steps + 1
     return {"value": n * steps / (el * steps / fwd), "unit": "residue*step/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"NumPy oracle, de novo N={n}, B=1, {fwd} forwards + {steps} reverse steps of the T=500 schedule "
-                      f"({el:.1f} s wall, priming forward amortised as (T+1)/T)"}
+                      f"({el:.1f} s wall, priming forward amortised as (T+1)/T)",
+            "note": "single-threaded NumPy element-wise passes dominate the port; the reference's own torch-CPU loop measured "
+                    "213 residue*step/s at N=300 on 8 cores of the build container (SURVEY.md section 6)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: the whole schedule of the config)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n-res", type=int, default=300)
-    ap.add_argument("--samples-per-gpu", type=int, default=8)
-    ap.add_argument("--num-t", type=int, default=500)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--n-res", type=int, default=None)
+    ap.add_argument("--samples-per-gpu", type=int, default=None)
+    ap.add_argument("--num-t", type=int, default=None)
+    ap.add_argument("--precision", default=None, choices=["fp16", "fp32"])
+    ap.add_argument("--kernel-flags", type=lambda s: int(s, 0), default=0, help="FdiptDims.kernel_flags (development)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
     a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    if a.n_res is not None:
+        if cfg["inpaint"]:
+            raise SystemExit("--n-res applies to the de novo configs")
+        cfg["n"] = a.n_res
+    N, B = cfg["n"], a.samples_per_gpu or cfg["b"]
+    T, prec = a.num_t or cfg["t"], a.precision or cfg["prec"]
+    K = a.steps if a.steps is not None else T
+    if K > T or K < 1:
+        raise SystemExit("--steps must lie in [1, num_t]")
 
     import torch
     import torch.distributed as dist
@@ -114,83 +166,118 @@ def main():
     from framedipt_amd import _lib, config, inference, sharding
     from framedipt_amd.diffusion import SE3Diffuser
     from framedipt_amd.model import ScoreNetwork
-    from framedipt_amd.sampler import UnconditionalSampler
+    from framedipt_amd.sampler import ConditionalSampler, UnconditionalSampler
 
     lib = _lib.load()
-    conf = config.base_config()
-    N, B, T = a.n_res, a.samples_per_gpu, a.num_t
-    if a.warmup + a.steps > T:
-        raise SystemExit("warmup + steps exceeds the schedule length")
-    # independent samples: global sample index -> rank (round-robin), per-sample seed = seed + index
-    my_samples = sharding.shard_indices(B * world, rank, world)
-    conf.diffuser.so3.seed = conf.diffuser.r3.seed = a.seed + rank
+    inp = cfg["inpaint"]
+    conf = config.base_config(inpainting=inp)
     diff = SE3Diffuser(conf.diffuser, device=dev)
-    net = ScoreNetwork(conf.model, diff, precision=a.precision).load_synthetic(7).to(dev)
-    sampler = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1,
-                                                   "samples_per_length": len(my_samples)}), diff, dev)
-    feats = make_batch(sampler, len(my_samples))
-    loop = inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=False, noise_scale=0.1)
-    st = loop.st
-    nb = conf.model.ipa.num_blocks
-    # HIP events around every EdgeTransition launch (recorded on the launch stream by the library)
-    n_ev = nb - 1
-    ev_s, ev_e = (C.c_void_p * nb)(), (C.c_void_p * nb)()
-    for i in range(n_ev):
-        for arr in (ev_s, ev_e):
-            h = C.c_void_p()
-            _lib.check(lib.fdipt_event_create(C.byref(h)))
-            arr[i] = h
+    net = ScoreNetwork(conf.model, diff, inpainting=inp, precision=prec, kernel_flags=a.kernel_flags).load_synthetic(7).to(dev)
+    n_total = B * world
+    if inp:
+        ds = ConditionalSampler.from_features([("synthetic", synthetic_complex(cfg["chains"], cfg["windows"]))], diff, dev,
+                                              samples=n_total)
+    else:
+        ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1,
+                                                  "samples_per_length": n_total}), diff, dev)
+    # independent samples: global sample index -> rank (round-robin), per-sample stream seed + index
+    mine = sharding.shard_indices(n_total, rank, world)
+    items = [sharding.seeded_item(ds, i, a.seed, diff, T, 0.01) for i in mine]
+    feats, tape = sharding.stack_items(items)
 
-    loop.prime()
-    for k in range(a.warmup):
-        loop.step(k)
+    def new_loop():
+        return inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp,
+                                     noise_tape=tape)
+
+    nb = conf.model.ipa.num_blocks
+    n_ev = nb - 1
+    # timed steps: the whole schedule, or K steps spread evenly over it (first and last included)
+    steps = list(range(T)) if K == T else sorted({int(round(i * (T - 1) / max(K - 1, 1))) for i in range(K)})
+    while len(steps) < K:  # (rounding collisions for K close to T)
+        steps = sorted(set(steps) | {next(s for s in range(T) if s not in steps)})
+    # HIP events around every EdgeTransition launch of up to 16 of the timed steps (recorded on the launch stream by the library)
+    sampled = sorted({steps[int(round(i * (K - 1) / 15))] for i in range(16)}) if K > 1 else steps
+    events = {}
+    for k in sampled:
+        ev_s, ev_e = (C.c_void_p * nb)(), (C.c_void_p * nb)()
+        for i in range(n_ev):
+            for arr in (ev_s, ev_e):
+                h = C.c_void_p()
+                _lib.check(lib.fdipt_event_create(C.byref(h)))
+                arr[i] = h
+        events[k] = (ev_s, ev_e)
+
+    warm = new_loop()  # scratch trajectory: touches every buffer / code object once
+    warm.prime()
+    for k in range(min(a.warmup, T)):
+        warm.step(k)
+    del warm
+    loop = new_loop()
+    st = loop.st
+    if K < T:
+        loop.prime()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    et_ms, t0 = [], time.perf_counter()
-    for k in range(a.warmup, a.warmup + a.steps):
-        # the EdgeTransition launches of every 8th step are bracketed by HIP events on the launch stream (an event record costs
-        # ~6 us of queue time on either side of a launch, and reading it back syncs the stream: sampled, not every step)
-        sample = (k - a.warmup) % 8 == 0
-        st.ev_start, st.ev_stop = (ev_s, ev_e) if sample else (None, None)
+    t0 = time.perf_counter()
+    if K == T:
+        loop.prime()
+    for k in steps:
+        st.ev_start, st.ev_stop = events.get(k, (None, None))
         loop.step(k)
-        if sample:
-            for i in range(n_ev):
-                ms = C.c_float()
-                _lib.check(lib.fdipt_event_elapsed_ms(ev_s[i], ev_e[i], C.byref(ms)))
-                et_ms.append(ms.value)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     st.ev_start = st.ev_stop = None
+    t1 = time.perf_counter()
+    res = loop.results()  # D2H of the trajectories, as inference_fn returns them (not part of `value`)
+    d2h = time.perf_counter() - t1
+    d2h_bytes = sum(v.nbytes for v in res.values() if hasattr(v, "nbytes"))
+    del res
+    et_ms = []
+    for k in sampled:
+        for i in range(n_ev):
+            ms = C.c_float()
+            _lib.check(lib.fdipt_event_elapsed_ms(events[k][0][i], events[k][1][i], C.byref(ms)))
+            et_ms.append(ms.value)
     if world > 1:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        tt = torch.tensor([el, d2h], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+        el, d2h = float(tt[0].item()), float(tt[1].item())
         dist.barrier()
 
     if rank == 0:
-        res_steps = B * N * a.steps * world
+        res_steps = B * N * K * world
         value = res_steps / el
         et = float(np.mean(et_ms)) * 1e-3
         et_flops = ET_FLOPS_PER_PAIR * B * N * N
-        peak = PEAK_TFLOPS[a.precision]
+        peak = PEAK_TFLOPS[prec]
         achieved = et_flops / et / 1e12
-        fwd_tflops = value / world * (flops_per_forward(N) / N) / 1e12  # whole-forward view, per GPU
+        fwd_per_step = (T + 1) / T if K == T else 1.0
+        fwd_tflops = value / world * (flops_per_forward(N, inp) / N) * fwd_per_step / 1e12  # whole-forward view, per GPU
+        et4 = prec == "fp16" and N % 4 == 0
         out = {
             "metric": "residue*diffusion-steps/sec", "value": value, "unit": "residue*step/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"de novo backbone sampler, N={N}, {B} samples/GPU batched, {a.steps}-step window of "
-                                   f"the T={T} schedule, noise_scale 0.1, 17.4M-param synthetic weights",
-                       "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective"},
+            "steps": K, "warmup": a.warmup, "ms_per_step": el / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": f"{a.config}: {'inpainting' if inp else 'de novo'} backbone sampler, N={N}, {B} samples/GPU "
+                                   f"batched, {'whole trajectory (priming forward + all steps)' if K == T else f'{K} steps spread over the schedule'}"
+                                   f" of T={T}, aux_traj=True, noise_scale 0.1, 17.4M-param synthetic weights, per-sample seeds",
+                       "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective",
+                       "precision_mode": ("fp16 MFMA operands / pair representation, split (hi+lo) operands on the node path, fp32 "
+                                          "accumulation / frames / statistics" if prec == "fp16" else "fp32 (v_mfma_f32_32x32x2_f32)"),
+                       "kernel_flags": a.kernel_flags},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(a.precision, N, B), "kernel": "edge_transition4_kernel" if a.precision == "fp16" else "edge_transition_kernel",
-                         "avg_launch_ms": et * 1e3, "flops_per_launch": et_flops,
+                         "traffic": pmc_traffic(prec, N, B), "kernel": "edge_transition4_kernel" if et4 else
+                         ("edge_transition3_kernel" if prec == "fp16" else "edge_transition_kernel"),
+                         "avg_launch_ms": et * 1e3, "launches_timed": len(et_ms), "flops_per_launch": et_flops,
+                         "executed_flops_per_launch": ET4_EXEC_FLOPS_PER_PAIR * B * N * N if et4 else None,
+                         "executed_frac": ET4_EXEC_FLOPS_PER_PAIR * B * N * N / et / 1e12 / peak if et4 else None,
                          "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak},
+            "results_d2h": {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": res_steps / (el + d2h)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, conf, 7)
+            out["cpu_baseline"] = cpu_baseline(300 if not inp else min(N, 300), config.base_config(), 7)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -68,6 +68,10 @@ SIGNATURES = {
     "fdipt_rigid_invert": (_i, [_i, _P, _P, _P, _P]),
     "fdipt_rigid_compose_q_update": (_i, [_i, _P, _P, _P, _P, _P]),
     "fdipt_quat_to_rotvec": (_i, [_i, _P, _P, _P]),
+    "fdipt_rigid_from_3_points": (_i, [_i, _P, _P, _P, _f, _P, _P]),
+    "fdipt_so3_exp_geomstats": (_i, [_i, _P, _P, _P]),
+    "fdipt_so3_log_geomstats": (_i, [_i, _P, _P, _P]),
+    "fdipt_so3_omega": (_i, [_i, _P, _d, _P, _P]),
     "fdipt_so3_exp": (_i, [_i, _P, _P, _P]),
     "fdipt_so3_log": (_i, [_i, _P, _P, _P]),
     "fdipt_igso3_rot_score": (_i, [_i, _i, _P, _P, _P, _P, _P, _P]),

@@ -682,6 +682,95 @@ __global__ void so3_log_k(int n, const double* __restrict__ R, double* __restric
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) d_so3_log(R + r * 9, rv + r * 3);
 }
+// Rigid.from_3_points (openfold/utils/rigid_utils.py:1233-1275): Gram-Schmidt frame, columns e0 | e1 | e2, float32 in the
+// reference's evaluation order
+__global__ void from_3_points_k(int n, const float* __restrict__ pa, const float* __restrict__ po, const float* __restrict__ pc,
+                                float eps, float* __restrict__ rot) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  float e0[3], e1[3];
+  for (int c = 0; c < 3; ++c) { e0[c] = po[r * 3 + c] - pa[r * 3 + c]; e1[c] = pc[r * 3 + c] - po[r * 3 + c]; }
+  float dn = sqrtf(((e0[0] * e0[0] + e0[1] * e0[1]) + e0[2] * e0[2]) + eps);
+  for (int c = 0; c < 3; ++c) e0[c] = e0[c] / dn;
+  const float dot = (e0[0] * e1[0] + e0[1] * e1[1]) + e0[2] * e1[2];
+  for (int c = 0; c < 3; ++c) e1[c] = e1[c] - e0[c] * dot;
+  dn = sqrtf(((e1[0] * e1[0] + e1[1] * e1[1]) + e1[2] * e1[2]) + eps);
+  for (int c = 0; c < 3; ++c) e1[c] = e1[c] / dn;
+  const float e2[3] = {e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]};
+  for (int c = 0; c < 3; ++c) { rot[r * 9 + 3 * c] = e0[c]; rot[r * 9 + 3 * c + 1] = e1[c]; rot[r * 9 + 3 * c + 2] = e2[c]; }
+}
+
+// ---- SO(3) exp / log of the geomstats fork (framedipt/diffusion/so3_utils.py), float64 here (the reference evaluates them in
+// the dtype of its inputs)
+// omega (:103-117): rotation angle from the trace shrunk by (1 - eps)
+__device__ __forceinline__ double d_gs_omega(const double* R, double eps) {
+  const double tr = (R[0] + R[4] + R[8]) * (1.0 - eps);
+  return acos((tr - 1.0) / 2.0);
+}
+// rot_mat_from_axis_angle_by_exp_map (:90-100): matrix exponential of the skew matrix of v (:4-22) = Rodrigues' formula
+__device__ __forceinline__ void d_gs_exp(const double* v, double* R) {
+  const double th2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], th = sqrt(th2);
+  // sin(th)/th and (1 - cos th)/th^2 with their series near 0
+  const double a = th < 1e-4 ? 1.0 - th2 / 6.0 : sin(th) / th;
+  const double b = th < 1e-4 ? 0.5 - th2 / 24.0 : (1.0 - cos(th)) / th2;
+  const double K[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double k2 = 0;
+      for (int k = 0; k < 3; ++k) k2 += K[i * 3 + k] * K[k * 3 + j];
+      R[i * 3 + j] = (i == j ? 1.0 : 0.0) + a * K[i * 3 + j] + b * k2;
+    }
+}
+__device__ __forceinline__ bool d_isclose(double x, double y, double atol) { return fabs(x - y) <= atol + 1e-5 * fabs(y); }
+// regularize (:193-231): angle folded into [0, pi]
+__device__ __forceinline__ void d_gs_regularize(double* p) {
+  const double PI = 3.14159265358979323846;
+  const double th = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  const double k = floor(th / 2.0 / PI), ang = th - 2.0 * k * PI;
+  const bool zero = d_isclose(th, 0.0, 1e-8);
+  const double th_eps = zero ? 1.0 : th;
+  const double na = ang <= PI ? ang : 2.0 * PI - ang;
+  double ratio = zero ? 1.0 : na / th_eps;
+  if (ang > PI) ratio = -ratio;
+  for (int c = 0; c < 3; ++c) p[c] *= ratio;
+}
+// rotation_vector_from_matrix (:120-190)
+__device__ __forceinline__ void d_gs_log(const double* R, double* rv) {
+  const double PI = 3.14159265358979323846;
+  const double ang = d_gs_omega(R, 1e-4);
+  // vee(R - R^T) (:25-40)
+  double np_[3] = {-(R[5] - R[7]), R[2] - R[6], -(R[1] - R[3])};
+  const double m0 = d_isclose(ang, 0.0, 1e-8) ? 1.0 : 0.0, mpi = d_isclose(ang, PI, 1e-2) ? 1.0 : 0.0, me = (1.0 - m0) * (1.0 - mpi);
+  const double num = 0.5 * m0 + ang * me, den = (1.0 - ang * ang / 6.0) * m0 + 2.0 * sin(ang) * me + mpi;
+  for (int c = 0; c < 3; ++c) np_[c] = np_[c] * num / den;
+  double vo[9];
+  for (int i = 0; i < 9; ++i) vo[i] = 0.5 * ((i % 4 == 0 ? 1.0 : 0.0) + R[i]);
+  for (int i = 0; i < 3; ++i) vo[4 * i] = fmax(0.0, vo[4 * i]);
+  int best = 0;
+  double bn = -1.0;
+  for (int i = 0; i < 3; ++i) {
+    const double nl = sqrt(vo[3 * i] * vo[3 * i] + vo[3 * i + 1] * vo[3 * i + 1] + vo[3 * i + 2] * vo[3 * i + 2]);
+    if (nl > bn) { bn = nl; best = i; }  // (first maximum, as torch.argmax)
+  }
+  for (int c = 0; c < 3; ++c) {
+    const double sl = vo[3 * best + c], sg = sl > 0 ? 1.0 : (sl < 0 ? -1.0 : 0.0);
+    rv[c] = np_[c] + mpi * (ang * sg * sqrt(vo[4 * c]));
+  }
+  d_gs_regularize(rv);
+}
+__global__ void gs_exp_k(int n, const double* __restrict__ rv, double* __restrict__ R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) d_gs_exp(rv + r * 3, R + r * 9);
+}
+__global__ void gs_log_k(int n, const double* __restrict__ R, double* __restrict__ rv) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) d_gs_log(R + r * 9, rv + r * 3);
+}
+__global__ void gs_omega_k(int n, const double* __restrict__ R, double eps, double* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = d_gs_omega(R + r * 9, eps);
+}
+
 __global__ void cqu_t7_k(int n, const float* __restrict__ t7, const float* __restrict__ upd,
                          const float* __restrict__ mask, float* __restrict__ out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -722,6 +811,35 @@ int fdipt_rigid_compose_q_update(int n, const float* t7, const float* upd6, cons
   if (n <= 0) return FDIPT_OK;
   if (!t7 || !upd6 || !out_t7) return FDIPT_EINVAL;
   hipLaunchKernelGGL(cqu_t7_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, t7, upd6, mask, out_t7);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_rigid_from_3_points(int n, const float* p_neg_x_axis, const float* origin, const float* p_xy_plane, float eps, float* rot,
+                              fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!p_neg_x_axis || !origin || !p_xy_plane || !rot) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(from_3_points_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, p_neg_x_axis, origin, p_xy_plane, eps, rot);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_so3_exp_geomstats(int n, const double* rotvec, double* rot, fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!rotvec || !rot) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(gs_exp_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, rotvec, rot);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_so3_log_geomstats(int n, const double* rot, double* rotvec, fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!rotvec || !rot) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(gs_log_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, rot, rotvec);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_so3_omega(int n, const double* rot, double eps, double* angle, fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!angle || !rot) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(gs_omega_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, n, rot, eps, angle);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

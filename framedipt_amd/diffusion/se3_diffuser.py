@@ -28,7 +28,8 @@ def so3_log(rot: torch.Tensor) -> torch.Tensor:
     r = rot.reshape(-1, 3, 3).double().contiguous()
     _lib.require_cuda(r, "so3_log")
     out = torch.empty(r.shape[0], 3, dtype=torch.float64, device=r.device)
-    _lib.check(lib.fdipt_so3_log(r.shape[0], _lib.ptr(r), _lib.ptr(out), _lib.stream_ptr()), "so3_log")
+    with torch.cuda.device(r.device):
+        _lib.check(lib.fdipt_so3_log(r.shape[0], _lib.ptr(r), _lib.ptr(out), _lib.stream_ptr()), "so3_log")
     return out.reshape(*rot.shape[:-2], 3)
 
 
@@ -38,7 +39,8 @@ def so3_exp(rotvec: torch.Tensor) -> torch.Tensor:
     v = rotvec.reshape(-1, 3).double().contiguous()
     _lib.require_cuda(v, "so3_exp")
     out = torch.empty(v.shape[0], 3, 3, dtype=torch.float64, device=v.device)
-    _lib.check(lib.fdipt_so3_exp(v.shape[0], _lib.ptr(v), _lib.ptr(out), _lib.stream_ptr()), "so3_exp")
+    with torch.cuda.device(v.device):
+        _lib.check(lib.fdipt_so3_exp(v.shape[0], _lib.ptr(v), _lib.ptr(out), _lib.stream_ptr()), "so3_exp")
     return out.reshape(*rotvec.shape[:-1], 3, 3)
 
 
@@ -70,9 +72,8 @@ class SE3Diffuser:
 
     # ------------------------------------------------------------------ scores
     def calc_trans_score(self, trans_t, trans_0, t, use_torch: bool = False, scale: bool = True):
-        """se3_diffuser.py:269-279 -> r3_diffuser.py:410-440 (device float32 path; scale=True only)."""
-        if not scale:
-            raise NotImplementedError("calc_trans_score(scale=False) is not on the sampler path")
+        """se3_diffuser.py:269-279 -> r3_diffuser.py:410-440 (device float32 path); ``scale`` multiplies both translations by
+        the coordinate scaling first (r3_diffuser.py:436-438)."""
         lib = _lib.load()
         tt = torch.as_tensor(trans_t).float()
         t0 = torch.as_tensor(trans_0).float().to(tt.device)
@@ -83,10 +84,11 @@ class SE3Diffuser:
         tv = torch.as_tensor(t, dtype=torch.float32, device=tt.device).reshape(-1).expand(B).contiguous()
         out = torch.empty(B, N, 3, device=tt.device)
         r3 = self._r3_diffuser
-        _lib.check(lib.fdipt_r3_trans_score(B, N, _lib.ptr(tt.reshape(B, N, 3).contiguous()),
-                                            _lib.ptr(t0.reshape(B, N, 3).contiguous()), _lib.ptr(tv), r3.min_b, r3.max_b,
-                                            r3._r3_conf.coordinate_scaling, None, _lib.ptr(out), _lib.stream_ptr()),
-                   "r3_trans_score")
+        with torch.cuda.device(tt.device):
+            _lib.check(lib.fdipt_r3_trans_score(B, N, _lib.ptr(tt.reshape(B, N, 3).contiguous()),
+                                                _lib.ptr(t0.reshape(B, N, 3).contiguous()), _lib.ptr(tv), r3.min_b, r3.max_b,
+                                                r3._r3_conf.coordinate_scaling if scale else 1.0, None, _lib.ptr(out),
+                                                _lib.stream_ptr()), "r3_trans_score")
         out = out.reshape(shp)
         return out if use_torch else out.cpu().numpy()
 
@@ -101,9 +103,10 @@ class SE3Diffuser:
         sig = self._so3_diffuser.score_sigma(torch.as_tensor(t).detach().cpu().numpy().reshape(-1))
         sig = torch.as_tensor(np.broadcast_to(sig, (B,)).copy(), device=qt.device)
         out = torch.empty(B, N, 3, dtype=torch.float64, device=qt.device)
-        _lib.check(lib.fdipt_igso3_rot_score(B, N, _lib.ptr(qt.reshape(B, N, 4).contiguous()),
-                                             _lib.ptr(q0.reshape(B, N, 4).contiguous()), _lib.ptr(sig), None,
-                                             _lib.ptr(out), _lib.stream_ptr()), "igso3_rot_score")
+        with torch.cuda.device(qt.device):
+            _lib.check(lib.fdipt_igso3_rot_score(B, N, _lib.ptr(qt.reshape(B, N, 4).contiguous()),
+                                                 _lib.ptr(q0.reshape(B, N, 4).to(qt.device).contiguous()), _lib.ptr(sig), None,
+                                                 _lib.ptr(out), _lib.stream_ptr()), "igso3_rot_score")
         return out.reshape(*shp, 3)
 
     def _apply_mask(self, x_diff, x_fixed, diff_mask):
@@ -121,6 +124,17 @@ class SE3Diffuser:
             rigids_out = torch.empty_like(rigids_t)
         so3, r3 = self._so3_diffuser, self._r3_diffuser
         psi, aatype, tables, atom37 = atoms if atoms is not None else (None, None, None, None)
+        for x in (rot_score, trans_score, diffuse_mask, z_rot, z_trans, rigids_out, rot_out, psi, aatype, tables, atom37):
+            if x is not None and x.device != rigids_t.device:
+                raise _lib.FdiptError(f"reverse: tensors on different devices ({rigids_t.device} and {x.device})")
+        with torch.cuda.device(rigids_t.device):
+            self._reverse_launch(lib, B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale,
+                                 center, rigids_out, rot_out, psi, aatype, tables, atom37)
+        return rigids_out
+
+    def _reverse_launch(self, lib, B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale, center,
+                        rigids_out, rot_out, psi, aatype, tables, atom37):
+        so3, r3 = self._so3_diffuser, self._r3_diffuser
         _lib.check(lib.fdipt_se3_reverse_step_atoms(
             B, N, _lib.ptr(rigids_t), _lib.ptr(rot_score), _lib.ptr(trans_score), _lib.ptr(diffuse_mask),
             _lib.ptr(z_rot), _lib.ptr(z_trans), float(t), float(dt), float(noise_scale), int(bool(center)),

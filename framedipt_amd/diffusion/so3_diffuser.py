@@ -47,6 +47,11 @@ class SO3Diffuser:
         self.num_sigma = so3_conf.num_sigma
         self.num_omega = so3_conf.num_omega
         self.use_cached_score = so3_conf.use_cached_score
+        if self.use_cached_score:
+            # so3_diffuser.py:373-402: the cached variant looks the score norm up in a bucketised [num_sigma, num_omega] table
+            # instead of evaluating the series; the rotation-score kernel only implements the series (the reference default)
+            raise NotImplementedError("so3.use_cached_score=True (bucketised score-norm table) is not implemented; the "
+                                      "rotation score is always the 1000-term IGSO(3) series (so3.use_cached_score=False)")
         self.discrete_omega = np.linspace(0, np.pi, so3_conf.num_omega + 1)[1:]
         self._rows: dict = {}
         np.random.seed(so3_conf.seed)  # so3_diffuser.py:286
@@ -70,9 +75,17 @@ class SO3Diffuser:
         return self.sigma_idx(self.sigma(t))
 
     def score_sigma(self, t_f32) -> np.ndarray:
-        """sigma snapped to the grid as ``torch_score`` does (so3_diffuser.py:398): t arrives as float32."""
-        t = np.asarray(t_f32, dtype=np.float32).astype(np.float64).reshape(-1)
-        return self.discrete_sigma[self.t_to_idx(t)]
+        """sigma snapped to the grid as ``torch_score`` does (so3_diffuser.py:398).  t arrives there as a float32 array
+        (``move_to_np(t)``), and under the reference's pinned numpy 1.22.4 (value-based casting) ``sigma(t)`` — the mix of the
+        two exponentials and the log — is evaluated in float32 before the digitize against the float64 grid.  (NumPy >= 2
+        promotes to float64; the two differ by one grid bin, 0.3 % in sigma, for 3 of the 1000 steps of a num_t = 1000 schedule
+        and for none at num_t <= 500: tests/test_host_cpu.py.)"""
+        t = np.asarray(t_f32, dtype=np.float32).reshape(-1)
+        if np.any(t < 0) or np.any(t > 1):
+            raise ValueError(f"Invalid t={t}")
+        sig32 = np.log(t * np.float32(np.exp(self.max_sigma)) + (np.float32(1) - t) * np.float32(np.exp(self.min_sigma)))
+        assert sig32.dtype == np.float32
+        return self.discrete_sigma[self.sigma_idx(sig32)]
 
     def _row(self, idx: int):
         idx = int(idx)
@@ -85,8 +98,13 @@ class SO3Diffuser:
         return self._rows[idx]
 
     def score_scaling(self, t):
-        pdf, _, sn = self._row(self.t_to_idx(t))
-        return np.sqrt(np.abs(np.sum(sn**2 * pdf, axis=-1) / np.sum(pdf, axis=-1))) / np.sqrt(3)
+        """so3_diffuser.py:404-414; scalar or array-valued t."""
+        def one(ti):
+            pdf, _, sn = self._row(self.t_to_idx(ti))
+            return np.sqrt(np.abs(np.sum(sn**2 * pdf, axis=-1) / np.sum(pdf, axis=-1))) / np.sqrt(3)
+        if np.ndim(t) == 0:
+            return one(t)
+        return np.array([one(ti) for ti in np.asarray(t).reshape(-1)]).reshape(np.shape(t))
 
     def sample_igso3(self, t: float, n_samples: int = 1) -> np.ndarray:
         x = np.random.rand(n_samples)

@@ -50,8 +50,13 @@ class ReverseLoop:
         self.res_mask, self.fixed = f32(data_init["res_mask"]), f32(data_init["fixed_mask"])
         self.fixed_mask = self.fixed * self.res_mask
         self.diffuse_mask = ((1 - self.fixed) * self.res_mask).contiguous()
-        aatype = preprocess_aatype(data_init.get("aatype"), self.fixed, inpainting, input_aatype)
-        self.aatype = None if aatype is None else aatype.to(device=dev, dtype=torch.int32).contiguous()
+        # two aatype views, as in the reference: the network pre-processes with ITS OWN flags (score_network.py:226-232:
+        # self.inpainting / model_conf.input_aatype), the atom37 frames of the trajectory with inference_fn's arguments
+        # (experiments/utils.py:376-388)
+        to_dev = lambda x: None if x is None else x.to(device=dev, dtype=torch.int32).contiguous()  # noqa: E731
+        self.aatype = to_dev(preprocess_aatype(data_init.get("aatype"), self.fixed, inpainting, input_aatype))
+        self.net_aatype = to_dev(preprocess_aatype(data_init.get("aatype"), self.fixed, model.inpainting,
+                                                   model._model_conf.input_aatype))
         self.gt_tors = data_init["torsion_angles_sin_cos"]
         self.gt_psi = f32(self.gt_tors[..., 2, :])
         self.st = model.batch_state(data_init["seq_idx"])
@@ -81,7 +86,7 @@ class ReverseLoop:
     def _fwd(self, k, want_atoms, sc_update):
         # the forward itself hands the predicted CA positions to the next step's self-conditioning input (read at its start,
         # written at its end: no copy kernel)
-        self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.aatype, self.gt_psi, self.t_all[k],
+        self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all[k],
                         self.temb_all[k], self.sig_all[k], want_atoms, ca_out=self.sc_ca if sc_update else None)
 
     def prime(self):

@@ -16,11 +16,17 @@ def _flat(t, last):
 
 
 def _call(fn, n, *tensors):
+    """Launch ``fn`` over ``n`` items on the device (and current stream of the device) the tensors live on."""
     lib = _lib.load()
+    dev = None
     for t in tensors:
         if t is not None:
             _lib.require_cuda(t, fn)
-    _lib.check(getattr(lib, fn)(n, *[_lib.ptr(t) for t in tensors], _lib.stream_ptr()), fn)
+            if dev is not None and t.device != dev:
+                raise _lib.FdiptError(f"{fn}: tensors on different devices ({dev} and {t.device})")
+            dev = t.device
+    with torch.cuda.device(dev):
+        _lib.check(getattr(lib, fn)(n, *[_lib.ptr(t) for t in tensors], _lib.stream_ptr()), fn)
 
 
 def quat_to_rot(quat: torch.Tensor) -> torch.Tensor:  # rigid_utils.py:185
@@ -137,6 +143,63 @@ class Rigid:
         if t.shape[-1] != 7:
             raise ValueError("Incorrectly shaped input tensor")
         return Rigid(Rotation(quats=t[..., :4], normalize_quats=normalize_quats), t[..., 4:])
+
+    @staticmethod
+    def from_tensor_4x4(t: torch.Tensor):  # rigid_utils.py:1180-1198
+        if t.shape[-2:] != (4, 4):
+            raise ValueError("Incorrectly shaped input tensor")
+        return Rigid(Rotation(rot_mats=t[..., :3, :3].contiguous()), t[..., :3, 3].contiguous())
+
+    def to_tensor_4x4(self) -> torch.Tensor:  # rigid_utils.py:1165-1178
+        out = self._trans.new_zeros((*self.shape, 4, 4))
+        out[..., :3, :3] = self._rots.get_rot_mats()
+        out[..., :3, 3] = self._trans
+        out[..., 3, 3] = 1
+        return out
+
+    @staticmethod
+    def from_3_points(p_neg_x_axis, origin, p_xy_plane, eps: float = 1e-8):  # rigid_utils.py:1233-1275 (Gram-Schmidt frame)
+        a, o, c = (_flat(x, (3,)) for x in (p_neg_x_axis, origin, p_xy_plane))
+        rot = torch.empty(o.shape[0], 3, 3, device=o.device)
+        lib = _lib.load()
+        _lib.require_cuda(o, "from_3_points")
+        with torch.cuda.device(o.device):
+            _lib.check(lib.fdipt_rigid_from_3_points(o.shape[0], _lib.ptr(a), _lib.ptr(o), _lib.ptr(c), float(eps), _lib.ptr(rot),
+                                                     _lib.stream_ptr()), "fdipt_rigid_from_3_points")
+        return Rigid(Rotation(rot_mats=rot.reshape(*origin.shape[:-1], 3, 3)), origin.float())
+
+    @staticmethod
+    def cat(rigids, dim: int):  # rigid_utils.py:1333-1352 (data movement only)
+        d = dim if dim >= 0 else dim + len(rigids[0].shape)
+        return Rigid(Rotation(rot_mats=torch.cat([r.get_rots().get_rot_mats() for r in rigids], dim=d)),
+                     torch.cat([r.get_trans() for r in rigids], dim=d))
+
+    def unsqueeze(self, dim: int):  # rigid_utils.py:1309-1331
+        if dim >= len(self.shape) + 1 or dim < -len(self.shape) - 1:
+            raise ValueError("Invalid dimension")
+        d = dim if dim >= 0 else dim + len(self.shape) + 1
+        rots = self._rots
+        rots = (Rotation(rot_mats=rots._rot_mats.unsqueeze(d)) if rots._rot_mats is not None
+                else Rotation(quats=rots._quats.unsqueeze(d), normalize_quats=False))
+        return Rigid(rots, self._trans.unsqueeze(d))
+
+    def apply_trans_fn(self, fn):  # rigid_utils.py:1371-1385
+        return Rigid(self._rots, fn(self._trans))
+
+    def scale_translation(self, trans_scale_factor: float):  # rigid_utils.py:1387-1399
+        return self.apply_trans_fn(lambda t: t * trans_scale_factor)
+
+    def map_tensor_fn(self, fn):  # rigid_utils.py:1149-1163
+        r = self._rots
+        if r._rot_mats is not None:
+            m = r._rot_mats.reshape(*r._rot_mats.shape[:-2], 9)
+            rots = Rotation(rot_mats=torch.stack(list(map(fn, torch.unbind(m, dim=-1))), dim=-1).reshape(*m.shape[:-1], 3, 3))
+        else:
+            rots = Rotation(quats=torch.stack(list(map(fn, torch.unbind(r._quats, dim=-1))), dim=-1), normalize_quats=False)
+        return Rigid(rots, torch.stack(list(map(fn, torch.unbind(self._trans, dim=-1))), dim=-1))
+
+    def stop_rot_gradient(self):  # rigid_utils.py:1401 (inference only: nothing to detach)
+        return self
 
     def to_tensor_7(self) -> torch.Tensor:  # rigid_utils.py:1200-1212
         return torch.cat([self._rots.get_quats(), self._trans], dim=-1)

@@ -1,0 +1,119 @@
+"""Sample-sharded sampling over the GPUs of one node (torchrun entry; SURVEY.md section 8e, experiments/inference.py:198-242).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        -m framedipt_amd.run_sharded --out-dir samples/ --min-length 300 --max-length 300 --samples-per-length 64 --num-t 500
+
+One process per GPU.  Dataset items (length, sample index) are dealt round-robin to the ranks; every rank runs its items -
+batched by equal length - through ``inference_fn`` and writes one ``sample_<item>.npz`` per item into the shared output
+directory; rank 0 writes ``manifest.json`` once every rank is done.  No collective touches the data path: the only
+``torch.distributed`` call is the final barrier.  Per-sample seeds (``seed + item``) make a sample's trajectory independent
+of the world size (framedipt_amd/sharding.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+
+
+def run_rank(dataset, diffuser, run_batch, rank: int, world: int, out_dir: str, seed: int, num_t: int, min_t: float,
+             max_batch: int = 8, keep=("prot_traj",), final_only: bool = True):
+    """Run this rank's share of ``dataset``.  ``run_batch(feats, tape) -> dict of arrays with a batch axis at dim 1`` (the
+    keys of ``inference_fn``).  Returns the list of records written by this rank."""
+    from . import sharding
+    os.makedirs(out_dir, exist_ok=True)
+    mine = sharding.shard_indices(len(dataset), rank, world)
+    items = [sharding.seeded_item(dataset, i, seed, diffuser, num_t, min_t) for i in mine]
+    lengths = [int(it[2]["rigids_t"].shape[1]) for it in items]
+    records = []
+    for group in sharding.batches_by_length(lengths, max_batch):
+        feats, tape = sharding.stack_items([items[p] for p in group])
+        res = run_batch(feats, tape)
+        for b, p in enumerate(group):
+            item, (name, sample_i) = mine[p], items[p][:2]
+            arrays = {k: (np.asarray(res[k])[0, b] if final_only else np.asarray(res[k])[:, b]) for k in keep}
+            path = os.path.join(out_dir, f"sample_{item:06d}.npz")
+            np.savez(path, item=item, name=str(name), sample_i=int(sample_i), **arrays)
+            records.append({"item": int(item), "name": str(name), "sample_i": int(sample_i), "n_res": lengths[p],
+                            "rank": rank, "file": os.path.basename(path)})
+    with open(os.path.join(out_dir, f"records_rank{rank}.json"), "w") as f:
+        json.dump(records, f)
+    return records
+
+
+def write_manifest(out_dir: str, world: int, n_items: int, meta: dict):
+    """Rank 0, after the barrier: merge the per-rank record files; raises if an item is missing."""
+    recs = []
+    for r in range(world):
+        with open(os.path.join(out_dir, f"records_rank{r}.json")) as f:
+            recs += json.load(f)
+    recs.sort(key=lambda x: x["item"])
+    if [x["item"] for x in recs] != list(range(n_items)):
+        raise RuntimeError("sharded run is incomplete: items " + str(sorted(set(range(n_items)) - {x["item"] for x in recs})))
+    with open(os.path.join(out_dir, "manifest.json"), "w") as f:
+        json.dump({"n_items": n_items, "world_size": world, **meta, "samples": recs}, f, indent=1)
+    return recs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out-dir", required=True)
+    ap.add_argument("--min-length", type=int, default=300)
+    ap.add_argument("--max-length", type=int, default=300)
+    ap.add_argument("--length-step", type=int, default=1)
+    ap.add_argument("--samples-per-length", type=int, default=8)
+    ap.add_argument("--num-t", type=int, default=500)
+    ap.add_argument("--min-t", type=float, default=0.01)
+    ap.add_argument("--noise-scale", type=float, default=0.1)
+    ap.add_argument("--max-batch", type=int, default=8)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--weights-seed", type=int, default=7, help="synthetic weights (no checkpoint is available offline)")
+    ap.add_argument("--full-trajectory", action="store_true", help="store every step of prot_traj instead of the final sample")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from . import config, inference
+    from .diffusion import SE3Diffuser
+    from .model import ScoreNetwork
+    from .sampler import UnconditionalSampler
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    conf = config.base_config()
+    diff = SE3Diffuser(conf.diffuser, device=dev)
+    net = ScoreNetwork(conf.model, diff, precision=a.precision).load_synthetic(a.weights_seed).to(dev)
+    ds = UnconditionalSampler(config.to_conf({"min_length": a.min_length, "max_length": a.max_length,
+                                              "length_step": a.length_step, "samples_per_length": a.samples_per_length}), diff, dev)
+
+    def run_batch(feats, tape):
+        return inference.inference_fn(net, diff, feats, num_t=a.num_t, min_t=a.min_t, aux_traj=True, noise_scale=a.noise_scale,
+                                      noise_tape=tape)
+
+    t0 = time.perf_counter()
+    recs = run_rank(ds, diff, run_batch, rank, world, a.out_dir, a.seed, a.num_t, a.min_t, a.max_batch,
+                    final_only=not a.full_trajectory)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        el = time.perf_counter() - t0
+        allrecs = write_manifest(a.out_dir, world, len(ds), {"num_t": a.num_t, "precision": a.precision, "seed": a.seed, "wall_s": el})
+        print(f"{sum(r['n_res'] for r in allrecs) * a.num_t / el:.0f} residue*steps/s (incl. model set-up and file output)")
+        print(f"{len(ds)} samples on {world} GPU(s) in {el:.1f} s -> {a.out_dir}/manifest.json", flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,3 +42,44 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Per-sample random streams ("Caveat").  The reference draws x_T and every reverse step's noise from
+# ONE global legacy np.random stream, sample after sample.  Sharded runs restart that stream per sample at `seed + item`,
+# draw x_T (through the dataset item) and then the whole noise tape of the sample's trajectory in the reference's per-step
+# order: a sample's inputs - and with batch-position-independent kernels its whole trajectory - do not depend on the world
+# size, the rank that runs it or the batch it rides in.
+def seeded_item(dataset, item: int, seed: int, diffuser, num_t: int, min_t: float):
+    """``dataset[item]`` and its noise tape drawn from ``np.random.seed(seed + item)``.
+    Returns (name_or_length, sample_i, feats [1,N,...], (z_rot, z_trans) [n_noisy,1,N,3] float64)."""
+    import numpy as np
+
+    from .inference import draw_noise_tape
+    np.random.seed(seed + item)
+    name, sample_i, feats = dataset[item]
+    n = feats["rigids_t"].shape[1]
+    n_noisy = int(np.sum(np.linspace(min_t, 1.0, num_t)[::-1] > min_t))
+    return name, sample_i, feats, draw_noise_tape(diffuser, n_noisy, 1, n)
+
+
+def stack_items(items):
+    """Batch of equally sized samples from ``seeded_item`` tuples: (feats [B,N,...], (z_rot, z_trans) [n,B,N,3])."""
+    import numpy as np
+    import torch
+    feats = {k: torch.cat([it[2][k] for it in items], dim=0) for k in items[0][2]}
+    tape = tuple(np.concatenate([it[3][j] for it in items], axis=1) for j in range(2))
+    return feats, tape
+
+
+def batches_by_length(lengths, max_batch: int):
+    """Group local item positions into batches of equal N (at most ``max_batch`` samples each), in item order."""
+    out, cur = [], []
+    for pos, n in enumerate(lengths):
+        if cur and (lengths[cur[0]] != n or len(cur) == max_batch):
+            out.append(cur)
+            cur = []
+        cur.append(pos)
+    if cur:
+        out.append(cur)
+    return out

@@ -182,6 +182,13 @@ int fdipt_rigid_invert(int n, const float* t7, float* out_rot, float* out_trans,
 int fdipt_rigid_compose_q_update(int n, const float* t7, const float* upd6, const float* mask, float* out_t7,
                                  fdipt_stream_t s);                                      /* :587,:1039 (fork: update_mask) */
 int fdipt_quat_to_rotvec(int n, const float* q, float* rotvec, fdipt_stream_t s);        /* framedipt/data/transforms.py:53-69 */
+int fdipt_rigid_from_3_points(int n, const float* p_neg_x_axis, const float* origin, const float* p_xy_plane, float eps,
+                              float* rot /* [n,3,3]; the translation is `origin` */, fdipt_stream_t s);  /* :1233-1275 */
+/* SO(3) exp / log of the geomstats fork (framedipt/diffusion/so3_utils.py): rot_mat_from_axis_angle_by_exp_map (:90-100),
+ * rotation_vector_from_matrix (:120-190, with regularize :193-231), omega (:103-117); float64 buffers */
+int fdipt_so3_exp_geomstats(int n, const double* rotvec, double* rot, fdipt_stream_t s);
+int fdipt_so3_log_geomstats(int n, const double* rot, double* rotvec, fdipt_stream_t s);
+int fdipt_so3_omega(int n, const double* rot, double eps, double* angle, fdipt_stream_t s);
 /* SciPy Rotation conventions (float64): exp = from_rotvec().as_matrix(), log = from_matrix().as_rotvec() */
 int fdipt_so3_exp(int n, const double* rotvec, double* rot, fdipt_stream_t s);
 int fdipt_so3_log(int n, const double* rot, double* rotvec, fdipt_stream_t s);

@@ -146,6 +146,63 @@ def sampler_goldens():
     print("sampler_dicts", sorted(k for k in g if k.startswith("uncond_0_") and not k.endswith("_dtype")), flush=True)
 
 
+def ops_r2_goldens():
+    """Per-op vectors of round 2: geomstats-fork SO(3) exp / log / omega (framedipt/diffusion/so3_utils.py), Rigid.from_3_points /
+    from_tensor_4x4 (openfold/utils/rigid_utils.py), the unscaled R^3 score, create_redacted_regions / pad_feats
+    (framedipt/data/utils.py)."""
+    from framedipt.data import utils as du
+    from framedipt.diffusion import se3_diffuser, so3_utils
+    rng = np.random.default_rng(21)
+    g = {}
+    n = 48
+    rv = rng.standard_normal((n, 3)) * 1.3
+    rv[0] = 0
+    rv[1] = [1e-6, 0, 0]
+    rv[2] = [0, 2e-4, 0]
+    ax = np.array([0.3, -0.5, 0.8]) / np.linalg.norm([0.3, -0.5, 0.8])
+    for i, ang in enumerate([np.pi - 1e-3, np.pi - 5e-3, np.pi - 2e-2, np.pi - 1e-5, 3.0, 0.02]):
+        rv[3 + i] = ax * ang
+    g["gs_rotvec"] = rv
+    R = so3_utils.rot_mat_from_axis_angle_by_exp_map(torch.tensor(rv, dtype=torch.float64))
+    g["gs_exp"] = np32(R)            # (float32: skew_symmetric_matrix_from_axis_angle allocates a default-dtype tensor)
+    R64 = torch.linalg.matrix_exp(torch.tensor(np.stack([np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]]) for v in rv])))
+    g["gs_R64"] = R64.numpy()
+    g["gs_omega"] = so3_utils.omega(R64).numpy()
+    g["gs_log"] = so3_utils.rotation_vector_from_matrix(R64.float()).numpy()
+    g["gs_log_in"] = R64.float().numpy()
+    big = rng.standard_normal((12, 3)) * 4.0
+    g["gs_reg_in"], g["gs_reg"] = big, so3_utils.regularize(torch.tensor(big, dtype=torch.float32)).numpy()  # (the fork only runs in float32)
+    p1, p2, p3 = (rng.standard_normal((n, 3)).astype(np.float32) * 3 for _ in range(3))
+    r = ru.Rigid.from_3_points(torch.tensor(p1), torch.tensor(p2), torch.tensor(p3))
+    g.update(p3_a=p1, p3_o=p2, p3_c=p3, p3_rot=np32(r.get_rots().get_rot_mats()), p3_trans=np32(r.get_trans()))
+    m44 = r.to_tensor_4x4()
+    g["t4x4"] = np32(m44)
+    g["t4x4_t7"] = np32(ru.Rigid.from_tensor_4x4(m44).to_tensor_7())
+    diff = se3_diffuser.SE3Diffuser(rh.load_cfg().diffuser)
+    t1, t2 = rng.standard_normal((1, n, 3)).astype(np.float32) * 5, rng.standard_normal((1, n, 3)).astype(np.float32) * 5
+    g.update(ts_t1=t1, ts_t2=t2)
+    for i, t in enumerate([0.01, 0.5, 1.0]):
+        tt = torch.tensor([t], dtype=torch.float32)
+        g[f"ts_unscaled_{i}"] = np32(diff.calc_trans_score(torch.tensor(t1), torch.tensor(t2), tt[:, None, None], use_torch=True, scale=False))
+    chain_idx = np.concatenate([np.zeros(40), np.ones(25), np.full(9, 2)]).astype(np.int64)
+    res_mask = np.ones(74)
+    res_mask[:3] = 0
+    res_mask[70:] = 0
+    g.update(red_chain_idx=chain_idx, red_res_mask=res_mask)
+    for seed in (0, 1, 7):
+        g[f"red_{seed}"] = du.create_redacted_regions(chain_idx, res_mask, np.random.default_rng(seed), redact_min_len=5, redact_max_len=12)
+    g["red_none"] = du.create_redacted_regions(chain_idx, res_mask, np.random.default_rng(0), None, None)
+    feats = {"aatype": torch.arange(6), "rigids_0": torch.tensor(rng.standard_normal((6, 7)).astype(np.float32)),
+             "atom37_pos": torch.tensor(rng.standard_normal((6, 37, 3))), "t": torch.tensor(1.0)}
+    padded = du.pad_feats(feats, 9, use_torch=True)
+    for k, v in feats.items():
+        g["pad_in_" + k] = v.numpy()
+    for k, v in padded.items():
+        g["pad_out_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "ops_r2.npz"), **g)
+    print("ops_r2", len(g), "arrays", flush=True)
+
+
 def denovo(n):
     return lambda rng, diff: mg.make_feats(n, rng, False, diff)
 
@@ -168,6 +225,7 @@ JOBS = {
     "traj_full_denovo_n300_T5": lambda: mg.traj_golden("full_denovo_n300_T5", rh.load_cfg(), 300, False, 5),
     "traj_full_denovo_n64_T20_gain03": lambda: traj_golden_gain("full_denovo_n64_T20_gain03", rh.load_cfg(), 64, 20, 0.3),
     "sampler_dicts": sampler_goldens,
+    "ops_r2": ops_r2_goldens,
 }
 
 

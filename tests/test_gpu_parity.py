@@ -386,7 +386,7 @@ def test_baseline_config_shapes_run(n, B, prec, inp):
                     "aatype": rng.integers(0, 20, n), "seq_idx": np.concatenate([np.arange(n1), np.arange(n - n1) + n1 + 200]),
                     "chain_idx": np.concatenate([np.zeros(n1), np.ones(n - n1)]),
                     "torsion_angles_sin_cos": np.tile(np.array([0.0, 1.0]), (n, 7, 1))}
-        ds = ConditionalSampler([("synthetic", feats_np)], d, "cuda", samples_per_structure=B)
+        ds = ConditionalSampler.from_features([("synthetic", feats_np)], d, "cuda", samples=B)
         items = [ds[i][2] for i in range(B)]
     else:
         ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1,

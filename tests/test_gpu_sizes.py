@@ -203,3 +203,65 @@ def test_reverse_api_with_rigid_objects(name):
         assert isinstance(out, R.Rigid)
         np.testing.assert_allclose(out.get_rots().get_rot_mats().cpu().numpy(), T["step_out_rot"][s], atol=1e-6)
         np.testing.assert_allclose(out.get_trans().cpu().numpy(), T["step_out_trans"][s], atol=3e-5)
+
+
+def test_round2_frame_ops_vs_reference_goldens():
+    """geomstats-fork SO(3) exp / log / omega (framedipt/diffusion/so3_utils.py:90-231), Rigid.from_3_points / from_tensor_4x4
+    (rigid_utils.py:1233-1275,1180-1198), calc_trans_score(scale=False) (r3_diffuser.py:410-440)."""
+    from framedipt_amd import _lib, config
+    from framedipt_amd import rigid as R
+    from framedipt_amd.diffusion import SE3Diffuser
+    lib = _lib.load()
+    G = load_golden("ops_r2.npz")
+    n = G["gs_rotvec"].shape[0]
+    rv = dev(G["gs_rotvec"])
+    rot = torch.empty(n, 3, 3, dtype=torch.float64, device="cuda")
+    _lib.check(lib.fdipt_so3_exp_geomstats(n, _lib.ptr(rv), _lib.ptr(rot), _lib.stream_ptr()))
+    np.testing.assert_allclose(rot.cpu().numpy(), G["gs_R64"], atol=1e-12)
+    np.testing.assert_allclose(rot.cpu().numpy(), G["gs_exp"], atol=2e-6)  # the reference's own (float32) evaluation
+    om = torch.empty(n, dtype=torch.float64, device="cuda")
+    _lib.check(lib.fdipt_so3_omega(n, _lib.ptr(dev(G["gs_R64"])), 1e-4, _lib.ptr(om), _lib.stream_ptr()))
+    np.testing.assert_allclose(om.cpu().numpy(), G["gs_omega"], atol=1e-12)
+    lg = torch.empty(n, 3, dtype=torch.float64, device="cuda")
+    _lib.check(lib.fdipt_so3_log_geomstats(n, _lib.ptr(dev(G["gs_log_in"].astype(np.float64))), _lib.ptr(lg), _lib.stream_ptr()))
+    # float32 reference flow; near pi the log of a float32-rounded matrix is conditioned like sqrt(eps): looser there
+    ang = np.linalg.norm(G["gs_rotvec"], axis=-1)
+    near_pi = ang > np.pi - 3e-2
+    np.testing.assert_allclose(lg.cpu().numpy()[~near_pi], G["gs_log"][~near_pi], atol=2e-5)
+    np.testing.assert_allclose(lg.cpu().numpy()[near_pi], G["gs_log"][near_pi], atol=2e-3)
+    r = R.Rigid.from_3_points(dev(G["p3_a"]), dev(G["p3_o"]), dev(G["p3_c"]))
+    np.testing.assert_allclose(r.get_rots().get_rot_mats().cpu().numpy(), G["p3_rot"], atol=1e-6)
+    np.testing.assert_array_equal(r.get_trans().cpu().numpy(), G["p3_trans"])
+    m44 = dev(G["t4x4"])
+    np.testing.assert_allclose(r.to_tensor_4x4().cpu().numpy(), G["t4x4"], atol=1e-6)
+    t7 = R.Rigid.from_tensor_4x4(m44).to_tensor_7().cpu().numpy()
+    sgn = np.sign((t7[:, :4] * G["t4x4_t7"][:, :4]).sum(-1, keepdims=True))  # quaternion sign is free (rot_to_quat, eigh)
+    np.testing.assert_allclose(t7[:, :4] * sgn, G["t4x4_t7"][:, :4], atol=2e-6)
+    np.testing.assert_array_equal(t7[:, 4:], G["t4x4_t7"][:, 4:])
+    cat = R.Rigid.cat([r[:10], r[10:]], dim=0)
+    assert cat.shape == r.shape and torch.equal(cat.get_trans(), r.get_trans())
+    assert r.unsqueeze(0).shape == (1, n) and torch.equal(r.scale_translation(0.1).get_trans(), r.get_trans() * 0.1)
+    d = SE3Diffuser(config.base_config().diffuser)
+    for i, t in enumerate([0.01, 0.5, 1.0]):
+        ts = d.calc_trans_score(dev(G["ts_t1"]), dev(G["ts_t2"]), torch.tensor([t]), use_torch=True, scale=False).cpu().numpy()
+        np.testing.assert_allclose(ts, G[f"ts_unscaled_{i}"], rtol=3e-6, atol=2e-6)
+
+
+def test_conditional_sampler_items_on_device():
+    """ConditionalSampler.from_features -> items with the reference's keys (sampler.py:267-354), motif frames kept, t = 1."""
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.sampler import ConditionalSampler
+    import bench
+    d = SE3Diffuser(config.base_config(inpainting=True).diffuser, device="cuda")
+    f = bench.synthetic_complex((30, 40, 9, 21), ((5, 12), (40, 50)))
+    ds = ConditionalSampler.from_features([("cplx", f)], d, "cuda", samples=2)
+    assert len(ds) == 2
+    name, si, it = ds[1]
+    assert (name, si) == ("cplx", 1)
+    for k in ("aatype", "seq_idx", "chain_idx", "res_mask", "fixed_mask", "rigids_0", "rigids_t", "sc_ca_t", "t", "torsion_angles_sin_cos"):
+        assert k in it and it[k].shape[0] == 1, k
+    fixed = it["fixed_mask"][0].bool().cpu().numpy()
+    assert fixed.sum() == 100 - 17
+    np.testing.assert_allclose(it["rigids_t"][0, fixed, 4:].cpu().numpy(), f["rigids_0"][fixed, 4:], atol=1e-5)
+    assert float(it["t"][0]) == 1.0 and it["rigids_t"].dtype == torch.float32

@@ -118,3 +118,71 @@ def test_unconditional_sampler_lengths():
     cfg = config.to_conf({"min_length": 100, "max_length": 200, "length_step": 50, "samples_per_length": 3})
     s = UnconditionalSampler(cfg, diffuser=None, device="cpu")
     assert list(s.all_sampling_lengths) == [100] * 3 + [150] * 3 + [200] * 3 and len(s) == 9
+
+
+def test_redaction_and_padding_ports_vs_reference_goldens():
+    """create_redacted_regions / pad_feats (framedipt/data/utils.py:613-689,311-378) restated in framedipt_amd.sampler."""
+    import torch
+    from framedipt_amd import sampler
+    G = load_golden("ops_r2.npz")
+    for seed in (0, 1, 7):
+        got = sampler.create_redacted_regions(G["red_chain_idx"], G["red_res_mask"], np.random.default_rng(seed), 5, 12)
+        np.testing.assert_array_equal(got, G[f"red_{seed}"])
+    np.testing.assert_array_equal(sampler.create_redacted_regions(G["red_chain_idx"], G["red_res_mask"], np.random.default_rng(0), None, None),
+                                  G["red_none"])
+    feats = {k[len("pad_in_"):]: torch.tensor(v) for k, v in G.items() if k.startswith("pad_in_")}
+    out = sampler.pad_feats(feats, 9)
+    for k, v in out.items():
+        np.testing.assert_array_equal(v.numpy(), G["pad_out_" + k], err_msg=k)
+        assert v.numpy().dtype == G["pad_out_" + k].dtype, k
+
+
+def test_conditional_sampler_surface_without_gpu(tmp_path):
+    """Reference constructor signatures (experiments/sampler.py:141,363); metadata.csv handling; the mask logic; loud failure
+    where the mmCIF preparation step has not been run."""
+    import inspect
+    import pandas as pd
+    from framedipt_amd import _lib, config, sampler
+    for cls in (sampler.ConditionalSampler, sampler.TCRSampler):
+        assert list(inspect.signature(cls.__init__).parameters)[1:] == ["data_conf", "diffuser", "device"]
+    assert list(inspect.signature(sampler.UnconditionalSampler.__init__).parameters)[1:] == ["cfg", "diffuser", "device"]
+    conf = config.to_conf({"download_dir": str(tmp_path), "data_path": str(tmp_path / "none.csv"), "samples": 3, "seed": 1,
+                           "redaction": {"redact_min_len": 4, "redact_max_len": 6}, "cdr_loops": ["CDR3"]})
+    with pytest.raises(_lib.FdiptError):
+        sampler.ConditionalSampler(conf, None, "cpu")
+    n = 30
+    feats = {"aatype": np.zeros(n, dtype=np.int64), "seq_idx": np.arange(n), "chain_idx": np.repeat([0, 1], 15),
+             "res_mask": np.ones(n), "rigids_0": np.tile(np.array([1, 0, 0, 0, 0, 0, 0], dtype=np.float32), (n, 1)),
+             "torsion_angles_sin_cos": np.zeros((n, 7, 2))}
+    (tmp_path / "processed").mkdir()
+    np.savez(tmp_path / "processed" / "1abc.npz", **feats)
+    pd.DataFrame([{"pdb_name": "1abc", "processed_path": str(tmp_path / "processed" / "1abc.npz"), "modeled_seq_len": n}]).to_csv(
+        tmp_path / "processed" / "metadata.csv", index=False)
+    ds = sampler.ConditionalSampler(conf, None, "cpu")
+    assert len(ds) == 3
+    m = ds.create_diffusion_mask(ds._chain_feats(0), 0)
+    assert m.shape == (n,) and 8 <= m.sum() <= 12 and m[:15].sum() >= 4 and m[15:].sum() >= 4
+    assert ds.create_diffusion_mask(None, 0) is m  # cached per example
+    tcr = sampler.TCRSampler(conf, None, "cpu")
+    with pytest.raises(_lib.FdiptError):  # no CDR mask in the features, no ANARCI here
+        tcr.create_diffusion_mask(tcr._chain_feats(0), 0)
+
+
+def test_score_sigma_float32_evaluation():
+    """sigma(t) before the grid snap is evaluated in float32 (value-based casting of the reference's pinned numpy 1.22.4); the
+    float64 evaluation of NumPy >= 2 lands in the neighbouring grid bin for a few steps of a num_t = 1000 schedule only."""
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import so3_diffuser
+    so3 = so3_diffuser.SO3Diffuser(config.base_config().diffuser.so3)
+    for num_t, max_diff in ((10, 0), (20, 0), (50, 0), (100, 0), (200, 0), (500, 0), (1000, 5)):
+        t32 = np.linspace(0.01, 1.0, num_t)[::-1].astype(np.float32)
+        got = so3.score_sigma(t32)
+        f64 = so3.discrete_sigma[so3.t_to_idx(t32.astype(np.float64))]
+        ndiff = int((got != f64).sum())
+        assert ndiff <= max_diff, (num_t, ndiff)
+        assert np.all(np.abs(got - f64) <= 0.004 * f64)
+    conf = config.base_config().diffuser.so3
+    conf.use_cached_score = True
+    with pytest.raises(NotImplementedError):
+        so3_diffuser.SO3Diffuser(conf)
+    assert np.shape(so3.score_scaling(np.array([0.1, 0.5]))) == (2,)
