@@ -54,6 +54,10 @@ SIGNATURES = {
     "fdipt_sample_setup": (_i, [_DP, _P, _P, _i, _i, _i, _P, _P, _P]),
     "fdipt_forward_workspace_bytes": (_sz, [_DP, _i, _i]),
     "fdipt_score_forward": (_i, [_DP, _P, _P, _P, C.POINTER(ForwardArgs), _P, _sz, _P]),
+    "fdipt_edge_embed_fwd": (_i, [_DP, _P, _P, _P, C.POINTER(ForwardArgs), _P, _P, _P, _sz, _P]),
+    "fdipt_ipa_project_points": (_i, [_DP, _P, _P, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "fdipt_ipa_attention_fwd": (_i, [_DP, _P, _P, _i, _i, _i, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "fdipt_edge_transition_fwd": (_i, [_DP, _P, _P, _i, _i, _i, _P, _P, _P, _P, _P, _sz, _P]),
     "fdipt_se3_reverse_step": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P, _P]),
     "fdipt_se3_reverse_step_atoms": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P,
                                           _P, _P, _P, _P, _P]),

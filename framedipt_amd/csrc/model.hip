@@ -531,14 +531,35 @@ size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N) {
     if (rc__) return rc__;      \
   } while (0)
 
-int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived, const void* setup,
-                        const FdiptForwardArgs* a, void* workspace, size_t workspace_bytes, fdipt_stream_t stream) {
-  if (!dims_ok(d) || !P || !derived || !setup || !a || !workspace) return FDIPT_EINVAL;
-  if (a->B <= 0 || a->N <= 0 || !a->rigids_t || !a->res_mask || !a->fixed_mask || !a->sc_ca_t || !a->seq_idx ||
-      !a->idx_emb || !a->gt_psi || !a->t || !a->t_emb || !a->so3_sigma || !a->psi || !a->rot_score || !a->trans_score ||
-      !a->rigids)
+}  // extern "C"
+
+// One sub-module of the forward on caller-provided inputs (the per-op entries of include/fdipt.h): the same launch schedule
+// as the full forward, cut at the sub-module's boundary.
+enum { OP_ALL, OP_EMBED, OP_POINTS, OP_IPA, OP_ET };
+#define FD_STOP 1  // (internal) the selected sub-module is done
+struct OpSel {
+  int kind = OP_ALL, block = 0;
+  const float* node_in = nullptr;   // [B,N,c_s]                      (POINTS, IPA, ET)
+  const void* z_in = nullptr;       // [B,N,N,c_z] pair type           (IPA, ET)
+  void* z_out = nullptr;            // [B,N,N,c_z] pair type           (EMBED, ET)
+  float* node_out = nullptr;        // [B,N,c_s]                       (EMBED)
+  float* out = nullptr;             // [B,N,c_s] linear_out(features)  (IPA)
+  float *qp = nullptr, *kp = nullptr, *vp = nullptr;  // global-frame points (POINTS)
+};
+
+static int forward_impl(const FdiptDims* d, const float* P, const void* derived, const void* setup,
+                        const FdiptForwardArgs* a, void* workspace, size_t workspace_bytes, fdipt_stream_t stream, const OpSel& op) {
+  if (!dims_ok(d) || !P || !derived || !a || !workspace) return FDIPT_EINVAL;
+  if (a->B <= 0 || a->N <= 0 || !a->res_mask) return FDIPT_EINVAL;
+  if (op.kind == OP_ALL || op.kind == OP_EMBED) {
+    if (!setup || !a->fixed_mask || !a->sc_ca_t || !a->seq_idx || !a->idx_emb || !a->t_emb) return FDIPT_EINVAL;
+    if (d->use_aatype && (!a->aatype || !a->t_emb_eps)) return FDIPT_EINVAL;
+  }
+  if (op.kind == OP_ALL && (!a->rigids_t || !a->gt_psi || !a->t || !a->so3_sigma || !a->psi || !a->rot_score || !a->trans_score ||
+                            !a->rigids))
     return FDIPT_EINVAL;
-  if (d->use_aatype && (!a->aatype || !a->t_emb_eps)) return FDIPT_EINVAL;
+  if ((op.kind == OP_POINTS || op.kind == OP_IPA) && !a->rigids_t) return FDIPT_EINVAL;
+  if (op.kind != OP_ALL && op.kind != OP_EMBED && (op.block < 0 || op.block >= d->num_blocks - (op.kind == OP_ET ? 1 : 0))) return FDIPT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   Inventory iv;
   DLayout L;
@@ -616,7 +637,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
   // ---- Embedder (score_network.py:129-197)
   // ... with the split of x_t (ipa_pytorch.py:516-524) and the per-residue halves of the first edge-embedder layer in the same
   // launch (FDIPT_FEATS_UNFUSED: three GEMM / element-wise launches more)
-  const bool feats_fused = L.d1_pad <= 128 && (L.d1_pad & 3) == 0 && !sw.feats_unfused;
+  const bool feats_fused = L.d1_pad <= 128 && (L.d1_pad & 3) == 0 && !sw.feats_unfused && (op.kind == OP_ALL);
+  const bool run_embed = op.kind == OP_ALL || op.kind == OP_EMBED;
+  const size_t NN = (size_t)R * N;
+  auto embed = [&]() -> int {
   RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
                     L.kn_pad, F(w.pte), L.d1_pad, feats_fused ? a->rigids_t : nullptr, res_mask, d->coordinate_scaling, F(w.quat),
                     F(w.trans), F(w.dmask), (const float*)(D + L.w1i), (const float*)(D + L.w1j), (const float*)(D + L.b1), cz,
@@ -659,21 +683,41 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     if (use_regpair(d)) RC(fd_edge_embed2(ea, D + L.ee2, st));
     else RC(fd_edge_embed(prec, cz, ea, st));
   }
-  if (a->trace_node)
+  return FDIPT_OK;
+  };
+  auto d2d = [&](void* dst, const void* src, size_t bytes) {
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? FDIPT_OK : FDIPT_ELAUNCH;
+  };
+  if (run_embed) RC(embed());
+  if (op.kind == OP_EMBED) {
+    if (op.node_out) RC(d2d(op.node_out, F(w.node0), (size_t)R * cs * 4));
+    if (op.z_out) RC(d2d(op.z_out, W + w.z, NN * cz * L.esz));
+    return FDIPT_OK;
+  }
+  if (a->trace_node && run_embed)
     if (hipMemcpyAsync(a->trace_node, F(w.node0), (size_t)R * cs * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return FDIPT_ELAUNCH;
 
   // ---- IpaScore trunk (ipa_pytorch.py:509-551)
-  if (!feats_fused)
-    RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask, F(w.quat), F(w.trans), F(w.dmask), st));
+  if (!feats_fused && a->rigids_t)
+    RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask ? a->fixed_mask : res_mask, F(w.quat),
+                       F(w.trans), F(w.dmask), st));
   const float* node_cur = F(w.node0);
+  if (op.kind != OP_ALL) {  // per-op entry: the sub-module's inputs come from the caller
+    if (!op.node_in) return FDIPT_EINVAL;
+    RC(d2d(F(w.node), op.node_in, (size_t)R * cs * 4));
+    node_cur = F(w.node);
+    if (op.kind != OP_POINTS) {
+      if (!op.z_in) return FDIPT_EINVAL;
+      RC(d2d(W + w.z, op.z_in, NN * cz * L.esz));
+    }
+  }
   // skip_embed(init_node) of every block depends on the embedder output only: one GEMM launch for all blocks, copied behind the
   // LayerNorm output by the LayerNorm kernel (FDIPT_SKIP_PER_BLOCK: one launch per block as before)
-  const bool skip_batched = bf && iv.feat_dim >= 1024 && !sw.no_splitk && !sw.skip_per_block;
+  const bool skip_batched = bf && iv.feat_dim >= 1024 && !sw.no_splitk && !sw.skip_per_block && op.kind == OP_ALL;
   if (skip_batched)
     RC(fd_linear(prec, R, d->num_blocks * d->c_skip, cs, F(w.node0), cs, D + L.skip_w, cs, (const float*)(D + L.skip_b), nullptr, 0,
                  nullptr, 0, F(w.skip_all), d->num_blocks * d->c_skip, st));
-  const size_t NN = (size_t)R * N;
   bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
   const char* dbg_twice = sw.twice;  // timing aid: repeat the named launches (second one runs on a warm L2)
 #define TWICE(name, call) do { RC(call); if (dbg_twice && strstr(dbg_twice, name)) RC(call); } while (0)
@@ -683,9 +727,12 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
                          fd_seq_qkv_supported(N, d->tfmr_heads, iv.d_t);
   bool bias_ready = ee_bias_done;  // pair bias of this block's attention already written (tiled order) by the embedder / EdgeTransition
   for (int b = 0; b < d->num_blocks; ++b) {
+    if (op.kind != OP_ALL && b != op.block) continue;
     const BlockW& k = iv.blk[b];
     const DBlock& db = L.blk[b];
     const int PT = iv.proj_out - 3 * H * C, Np = (N + 31) / 32 * 32;
+    // IPA + node path of the block (everything up to the frame update)
+    auto trunk = [&]() -> int {
     Attn3Args a3;
     a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const half_t*)(W + w.qb); a3.Kb = (const half_t*)(W + w.kb);
     a3.Vt = (const half_t*)(W + w.vt); a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
@@ -703,14 +750,14 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     // padded keys and rows 72..95 of the value-point image are never written: zero once per forward (on the launch that zeroes
     // the padded keys of Kb / Vt when the second-generation projection runs)
     const size_t vpt_bytes = (size_t)B * H * 96 * Np * 2;
-    bool vpt_zero = pa.vpt && b == 0;
+    bool vpt_zero = pa.vpt && (b == 0 || op.kind != OP_ALL);
     if (use_a3) {
       // fused projection written directly as attention operand images (Qb, Kb, Vt) + raw point columns
       ProjArgs pj;
       pj.B = B; pj.N = N; pj.H = H; pj.C = C; pj.K = cs; pj.PT = PT; pj.Np = Np; pj.A = node_cur; pj.lda = cs;
       pj.W = D + db.wproj; pj.bias = (const float*)(D + db.bproj); pj.qscale = sqrtf(1.0f / (3.0f * (float)C));
       pj.Qb = (half_t*)(W + w.qb); pj.Kb = (half_t*)(W + w.kb); pj.Vt = (half_t*)(W + w.vt); pj.pts = F(w.pts);
-      pj.zero_pads = b == 0;
+      pj.zero_pads = b == 0 || op.kind != OP_ALL;  // (per-op entry: the workspace is the caller's, pads unknown)
       pj.W_img = (cs == 256 && !sw.proj_v1) ? D + db.wproj_img : nullptr;
       // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
       if (fd_ipa_proj2_supported(pj)) {
@@ -731,6 +778,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       if (vpt_zero && hipMemsetAsync(W + w.vpt, 0, vpt_bytes, st) != hipSuccess) return FDIPT_ELAUNCH;
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
       RC(fd_points(pa, st));
+      if (op.kind == OP_POINTS) return FD_STOP;
       if (!bias_ready)  // blocks >= 1: already emitted by the previous block's EdgeTransition epilogue
         RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), 1, st));
       // the attention weights go to the MFMA o_pair kernel as bf16 rows [b, i, h, Np] (half the bytes, no conversion pass;
@@ -738,7 +786,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       // ... and both kernels write the attention features as bf16 rows when the output projection is the bf16 split-K GEMM
       // (the values it would round them to anyway: identical results, half the bytes, no conversion in its staging)
       feats_h16 = fd_opair_mfma_eligible(prec, oa) && iv.feat_dim >= 1024 && (iv.feat_dim & 7) == 0 && !sw.no_splitk &&
-                   !sw.feats_f32 && !split;  // (split operands: the projection splits the fp32 features itself)
+                   !sw.feats_f32 && !split && op.kind == OP_ALL;  // (split operands: the projection splits the fp32 features itself)
       if (feats_h16) { a3.out_h16 = (half_t*)(W + w.feats); oa.out_h16 = a3.out_h16; }
       if (fd_opair_mfma_eligible(prec, oa) && 2 * Np <= 4 * N && !sw.probs_f32) {
         a3.probs_h16 = (half_t*)(W + w.probs); oa.probs_h16 = a3.probs_h16; oa.probs_np = Np;
@@ -750,6 +798,7 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
                    nullptr, 0, F(w.proj), iv.proj_out, st));
       pa.proj = F(w.proj); pa.ld = iv.proj_out; pa.q_off = 3 * H * C; pa.kv_off = 3 * H * C + 3 * H * Pq;
       RC(fd_points(pa, st));
+      if (op.kind == OP_POINTS) return FD_STOP;
       AttnArgs aa;
       aa.B = B; aa.N = N; aa.H = H;
       aa.q = F(w.proj); aa.q_ld = iv.proj_out; aa.q_hs = C;
@@ -764,6 +813,10 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     }
     TWICE("opair", fd_opair(prec, oa, st));
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
+    if (op.kind == OP_IPA) {  // per-op entry: linear_out(features) * mask as one GEMM (the forward sums split-K slices in its LayerNorm)
+      RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
+      return FD_STOP;
+    }
     if (bf && iv.feat_dim >= 1024 && !sw.no_splitk) {
       const int NS = 4;  // K = 2688: slices of 704 / 576 columns -> 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower)
       if (split)
@@ -915,6 +968,24 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       RC(inner(b, 3, F(w.upd), 8, 6));
       RC(fd_compose_q_update(R, F(w.quat), F(w.trans), F(w.upd), 8, F(w.dmask), st));
     }
+    return FDIPT_OK;
+    };  // trunk
+    if (op.kind != OP_ET) {
+      const int rc_t = trunk();
+      if (rc_t == FD_STOP) {
+        if (op.kind == OP_POINTS) {
+          if (!op.qp || !op.kp || !op.vp) return FDIPT_EINVAL;
+          RC(d2d(op.qp, F(w.qp), (size_t)R * H * Pq * 3 * 4));
+          RC(d2d(op.kp, F(w.kp), (size_t)R * H * Pq * 3 * 4));
+          RC(d2d(op.vp, F(w.vp), (size_t)R * H * Pv * 3 * 4));
+        } else {
+          if (!op.out) return FDIPT_EINVAL;
+          RC(d2d(op.out, F(w.ipa_out), (size_t)R * cs * 4));
+        }
+        return FDIPT_OK;
+      }
+      if (rc_t) return rc_t;
+    }
     if (b < d->num_blocks - 1) {
       // register-resident pair kernels (reference widths): e = initial_embed(node) and the per-residue rows of the concat-free
       // layers come out of ONE row-block launch.  edge_transition4 (8 x 4-pair patches, N % 4 == 0) gets [A1 | Af | B1 | Bf] as
@@ -982,11 +1053,17 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
       if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
       }
     }
+    if (op.kind == OP_ET) {
+      if (!op.z_out) return FDIPT_EINVAL;
+      RC(d2d(op.z_out, W + w.z, NN * cz * L.esz));
+      return FDIPT_OK;
+    }
     if (a->trace_node)
       if (hipMemcpyAsync(a->trace_node + (size_t)(b + 1) * R * cs, node_cur, (size_t)R * cs * 4, hipMemcpyDeviceToDevice,
                          st) != hipSuccess)
         return FDIPT_ELAUNCH;
   }
+  if (op.kind != OP_ALL) return FDIPT_EINVAL;  // (unreachable: every per-op selection returns inside the loop)
   // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
   if (rbk) {
     if (split) { rb_l0 = D + L.lo_tor1; rb_l1 = D + L.lo_tor2; }
@@ -1011,6 +1088,51 @@ int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived,
     RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));
   }
   return FDIPT_OK;
+}
+
+extern "C" {
+
+int fdipt_score_forward(const FdiptDims* d, const float* P, const void* derived, const void* setup,
+                        const FdiptForwardArgs* a, void* workspace, size_t workspace_bytes, fdipt_stream_t stream) {
+  return forward_impl(d, P, derived, setup, a, workspace, workspace_bytes, stream, OpSel{});
+}
+
+int fdipt_edge_embed_fwd(const FdiptDims* d, const float* P, const void* derived, const void* setup, const FdiptForwardArgs* a,
+                         float* node_out, void* z_out, void* workspace, size_t workspace_bytes, fdipt_stream_t stream) {
+  OpSel op;
+  op.kind = OP_EMBED; op.node_out = node_out; op.z_out = z_out;
+  return forward_impl(d, P, derived, setup, a, workspace, workspace_bytes, stream, op);
+}
+
+static FdiptForwardArgs op_args(int B, int N, const float* rigids_t, const float* res_mask) {
+  FdiptForwardArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.N = N; a.rigids_t = rigids_t; a.res_mask = res_mask;
+  return a;
+}
+int fdipt_ipa_project_points(const FdiptDims* d, const float* P, const void* derived, int block, int B, int N, const float* node,
+                             const float* rigids, const float* res_mask, float* q_pts, float* k_pts, float* v_pts,
+                             void* workspace, size_t workspace_bytes, fdipt_stream_t stream) {
+  OpSel op;
+  op.kind = OP_POINTS; op.block = block; op.node_in = node; op.qp = q_pts; op.kp = k_pts; op.vp = v_pts;
+  const FdiptForwardArgs a = op_args(B, N, rigids, res_mask);
+  return forward_impl(d, P, derived, nullptr, &a, workspace, workspace_bytes, stream, op);
+}
+int fdipt_ipa_attention_fwd(const FdiptDims* d, const float* P, const void* derived, int block, int B, int N, const float* node,
+                            const void* z, const float* rigids, const float* res_mask, float* out, void* workspace,
+                            size_t workspace_bytes, fdipt_stream_t stream) {
+  OpSel op;
+  op.kind = OP_IPA; op.block = block; op.node_in = node; op.z_in = z; op.out = out;
+  const FdiptForwardArgs a = op_args(B, N, rigids, res_mask);
+  return forward_impl(d, P, derived, nullptr, &a, workspace, workspace_bytes, stream, op);
+}
+int fdipt_edge_transition_fwd(const FdiptDims* d, const float* P, const void* derived, int block, int B, int N, const float* node,
+                              const float* res_mask, const void* z_in, void* z_out, void* workspace, size_t workspace_bytes,
+                              fdipt_stream_t stream) {
+  OpSel op;
+  op.kind = OP_ET; op.block = block; op.node_in = node; op.z_in = z_in; op.z_out = z_out;
+  const FdiptForwardArgs a = op_args(B, N, nullptr, res_mask);
+  return forward_impl(d, P, derived, nullptr, &a, workspace, workspace_bytes, stream, op);
 }
 
 int fdipt_event_create(void** ev_host) {

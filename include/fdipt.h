@@ -145,6 +145,31 @@ size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
 int fdipt_score_forward(const FdiptDims* dims, const float* params_f32, const void* derived, const void* setup,
                         const FdiptForwardArgs* args, void* workspace, size_t workspace_bytes, fdipt_stream_t stream);
 
+/* ---------------------------------------------------------------- sub-modules of the forward ---- */
+/* The forward's launch schedule cut at a sub-module boundary, on caller-provided inputs (callers that assemble their own
+ * network, per-module parity tests).  Same model handles (dims / params / derived) and workspace as fdipt_score_forward;
+ * "pair type" = float in FDIPT_PREC_F32, IEEE half in FDIPT_PREC_F16.  node [B,N,c_s] f32, z [B,N,N,c_z] pair type,
+ * rigids [B,N,7] f32 tensor_7 in Angstrom (scaled by coordinate_scaling inside, ipa_pytorch.py:524), res_mask [B,N] f32. */
+/* Embedder.forward (framedipt/model/score_network.py:129-197): node and pair embeddings, masked as score_network.py:236-237.
+ * Reads B, N, n_rel, rel_off, res_mask, fixed_mask, sc_ca_t, seq_idx, idx_emb, aatype, t_emb, t_emb_eps of `args`. */
+int fdipt_edge_embed_fwd(const FdiptDims* dims, const float* params_f32, const void* derived, const void* setup,
+                         const FdiptForwardArgs* args, float* node_out, void* z_out, void* workspace, size_t workspace_bytes,
+                         fdipt_stream_t stream);
+/* Point projections of InvariantPointAttention `block` in the global frame (ipa_pytorch.py:213-239): q_pts, k_pts
+ * [B,N,H,no_qk_points,3] and v_pts [B,N,H,no_v_points,3] f32, in scaled units (nm). */
+int fdipt_ipa_project_points(const FdiptDims* dims, const float* params_f32, const void* derived, int block, int B, int N,
+                             const float* node, const float* rigids, const float* res_mask, float* q_pts, float* k_pts,
+                             float* v_pts, void* workspace, size_t workspace_bytes, fdipt_stream_t stream);
+/* InvariantPointAttention.forward of `block` (ipa_pytorch.py:170-329: projections, logits with pair bias and point distances,
+ * softmax, o / o_pt / o_pair, linear_out) times res_mask (:531): out [B,N,c_s] f32. */
+int fdipt_ipa_attention_fwd(const FdiptDims* dims, const float* params_f32, const void* derived, int block, int B, int N,
+                            const float* node, const void* z, const float* rigids, const float* res_mask, float* out,
+                            void* workspace, size_t workspace_bytes, fdipt_stream_t stream);
+/* EdgeTransition.forward of `block` < num_blocks - 1 (ipa_pytorch.py:84-102) times the pair mask (:549): z_out may alias z_in. */
+int fdipt_edge_transition_fwd(const FdiptDims* dims, const float* params_f32, const void* derived, int block, int B, int N,
+                              const float* node, const float* res_mask, const void* z_in, void* z_out, void* workspace,
+                              size_t workspace_bytes, fdipt_stream_t stream);
+
 /* ---------------------------------------------------------------- reverse step ------------- */
 /* Replaces SE3Diffuser.reverse (framedipt/diffusion/se3_diffuser.py:346-401) with
  * _extract_trans_rots (:16-23), SO3Diffuser.reverse (so3_diffuser.py:569-602), compose_rotvec

@@ -265,3 +265,72 @@ def test_conditional_sampler_items_on_device():
     assert fixed.sum() == 100 - 17
     np.testing.assert_allclose(it["rigids_t"][0, fixed, 4:].cpu().numpy(), f["rigids_0"][fixed, 4:], atol=1e-5)
     assert float(it["t"][0]) == 1.0 and it["rigids_t"].dtype == torch.float32
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("fp16", 4e-3)])
+def test_per_module_entries_vs_oracle(prec, tol):
+    """fdipt_edge_embed_fwd / fdipt_ipa_project_points / fdipt_ipa_attention_fwd / fdipt_edge_transition_fwd on the golden's
+    inputs against the NumPy oracle's sub-modules (Embedder.forward, IPA point projections, InvariantPointAttention.forward,
+    EdgeTransition.forward).  Tolerance relative to the largest magnitude of the output (fp16: operand rounding of one module)."""
+    import ctypes as C
+    from framedipt_amd import _lib, embedding
+    from oracle import frames as fr
+    from test_oracle_forward import _feats as ofeats, _model as omodel
+    lib = _lib.load()
+    name = "full_denovo_n64"
+    G = load_golden(f"fwd_{name}.npz")
+    net, d, conf = _net(name, G, prec)
+    onet, _ = omodel(name, G, None)  # (no residue tables: the backbone builder is not called here)
+    f = ofeats(G)
+    B, N = f["seq_idx"].shape
+    mask = f["res_mask"].astype(np.float32)
+    t = np.asarray(f["t"], dtype=np.float32)
+    # ---- oracle sub-modules
+    node0, edge0 = onet.embed(f["seq_idx"], t, f["fixed_mask"].astype(np.float32), f["sc_ca_t"].astype(np.float32), None)
+    rig = f["rigids_t"].astype(np.float32)
+    quat, trans = rig[..., :4], (rig[..., 4:] * np.float32(0.1)).astype(np.float32)
+    blk = 1
+    s_in = node0 * np.float32(1.0)
+    ipa_ref = onet.ipa(blk, s_in, edge0, quat, trans, mask)
+    et_ref = onet.edge_transition(blk, s_in, edge0)
+    rot = fr.quat_to_rot(quat).astype(np.float32)
+    p = f"score_model.trunk.ipa_{blk}."
+    H, Pq, Pv = 8, 8, 12
+
+    def pts(pname, n_pts):
+        x = onet._lin(p + pname, s_in)
+        x = np.stack(np.split(x, 3, axis=-1), axis=-1)
+        return fr.rigid_apply(rot[:, :, None], trans[:, :, None], x).astype(np.float32).reshape(B, N, H, n_pts, 3)
+
+    qp_ref, kvp = pts("linear_q_points", Pq), pts("linear_kv_points", Pq + Pv)
+    # ---- HIP per-module entries
+    st = net.batch_state(dev(f["seq_idx"]))
+    zt = torch.float32 if prec == "fp32" else torch.float16
+    f32 = dict(dtype=torch.float32, device="cuda")
+    a = _lib.ForwardArgs()
+    a.B, a.N, a.n_rel, a.rel_off = B, N, st.n_rel, st.rel_off
+    keep = [dev(mask), dev(f["fixed_mask"].astype(np.float32)), dev(f["sc_ca_t"].astype(np.float32)),
+            torch.as_tensor(embedding.get_timestep_embedding(t, 32), device="cuda")]
+    for nm, tn in (("res_mask", keep[0]), ("fixed_mask", keep[1]), ("sc_ca_t", keep[2]), ("seq_idx", st.seq_idx), ("idx_emb", st.idx_emb),
+                   ("t_emb", keep[3]), ("t_emb_eps", st.t_emb_eps)):
+        setattr(a, nm, _lib.ptr(tn))
+    node_out, z_out = torch.empty(B, N, 256, **f32), torch.empty(B, N, N, 128, dtype=zt, device="cuda")
+    ws, wsb, sp = _lib.ptr(st.ws), st.ws_bytes, _lib.stream_ptr()
+    dm, pr, dr = C.byref(net.dims), _lib.ptr(net.params), _lib.ptr(net.derived)
+    _lib.check(lib.fdipt_edge_embed_fwd(dm, pr, dr, _lib.ptr(st.setup), C.byref(a), _lib.ptr(node_out), _lib.ptr(z_out), ws, wsb, sp))
+    rel = lambda x, r: float(np.abs(x - r).max() / np.abs(r).max())  # noqa: E731
+    assert rel(node_out.cpu().numpy(), node0) < tol / 4, "node embedder"
+    assert rel(z_out.float().cpu().numpy(), edge0) < tol, "edge embedder"
+    node_in, z_in, rig_d = dev(s_in), dev(edge0).to(zt).contiguous(), dev(rig)
+    qp, kp, vp = torch.empty(B, N, H, Pq, 3, **f32), torch.empty(B, N, H, Pq, 3, **f32), torch.empty(B, N, H, Pv, 3, **f32)
+    _lib.check(lib.fdipt_ipa_project_points(dm, pr, dr, blk, B, N, _lib.ptr(node_in), _lib.ptr(rig_d), keep[0].data_ptr(), _lib.ptr(qp),
+                                            _lib.ptr(kp), _lib.ptr(vp), ws, wsb, sp))
+    assert rel(qp.cpu().numpy(), qp_ref) < tol and rel(kp.cpu().numpy(), kvp[..., :Pq, :]) < tol and rel(vp.cpu().numpy(), kvp[..., Pq:, :]) < tol
+    out = torch.empty(B, N, 256, **f32)
+    _lib.check(lib.fdipt_ipa_attention_fwd(dm, pr, dr, blk, B, N, _lib.ptr(node_in), _lib.ptr(z_in), _lib.ptr(rig_d), keep[0].data_ptr(),
+                                           _lib.ptr(out), ws, wsb, sp))
+    assert rel(out.cpu().numpy(), ipa_ref) < tol, ("ipa", rel(out.cpu().numpy(), ipa_ref))
+    z2 = torch.empty_like(z_in)
+    _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, blk, B, N, _lib.ptr(node_in), keep[0].data_ptr(), _lib.ptr(z_in), _lib.ptr(z2), ws, wsb, sp))
+    assert rel(z2.float().cpu().numpy(), et_ref) < tol, ("et", rel(z2.float().cpu().numpy(), et_ref))
+    assert lib.fdipt_edge_transition_fwd(dm, pr, dr, 3, B, N, _lib.ptr(node_in), keep[0].data_ptr(), _lib.ptr(z_in), _lib.ptr(z2), ws, wsb, sp) == -1
