@@ -1,0 +1,201 @@
+"""Checkpoint ingest: the reference's ``.pth`` / ``.pkl`` checkpoints -> weights + configuration.
+
+A reference checkpoint (``framedipt/data/utils.py:381-417 write_checkpoint``) is ``torch.save`` of
+``{"model": state_dict, "conf": omegaconf.DictConfig, "optim": ..., "epoch": ..., "step": ...}``; the state-dict keys may carry a
+``module.`` prefix (DataParallel), and ``Inference._load_ckpt`` (``experiments/inference.py:107-161``) merges ``conf.model`` over
+the run's model config and takes ``conf.diffuser.r3`` wholesale before it builds ``SE3Diffuser`` / ``ScoreNetwork``.
+
+Unpickling the ``DictConfig`` needs the ``omegaconf`` package, which this image does not have: ``load_checkpoint`` unpickles with
+a stand-in for every ``omegaconf.*`` class that only keeps the pickled state, and then reads the configuration out of that state
+(omegaconf 2.x layout: containers hold ``_content`` - a dict / list of nodes -, value nodes hold ``_val``).  ``${a.b}``
+interpolations that point inside the same configuration are resolved; anything else stays a string.
+
+    python -m framedipt_amd.checkpoint weights.pth out_prefix      # -> out_prefix.npz (state dict) + out_prefix.yaml (conf)
+"""
+from __future__ import annotations
+
+import pickle
+import re
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+
+
+class _Stub:
+    """Stand-in for an omegaconf class: keeps whatever state the pickle carries."""
+
+    def __init__(self, *args, **kwargs):
+        self.__dict__["_ctor_args"] = (args, kwargs)
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):  # (dict state, slots state)
+            state = {**(state[0] or {}), **state[1]}
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__["_state"] = state
+
+    def __setattr__(self, k, v):
+        self.__dict__[k] = v
+
+    def __reduce_ex__(self, protocol):  # pragma: no cover - stubs are never re-pickled
+        raise pickle.PicklingError("omegaconf stand-ins are read-only")
+
+
+_stub_classes: dict = {}
+
+
+def _stub_for(module: str, name: str):
+    key = (module, name)
+    if key not in _stub_classes:
+        _stub_classes[key] = type(name, (_Stub,), {"__module__": module, "_fd_stub": True})
+    return _stub_classes[key]
+
+
+class _ShimUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == "omegaconf" or module.startswith("omegaconf."):
+            try:
+                return super().find_class(module, name)  # the real package, if present
+            except (ImportError, AttributeError):
+                return _stub_for(module, name)
+        return super().find_class(module, name)
+
+
+# torch.load(pickle_module=...) wants a module-like object with Unpickler / load / loads
+_shim = types.ModuleType("framedipt_amd._ckpt_pickle")
+_shim.Unpickler = _ShimUnpickler
+_shim.Pickler = pickle.Pickler
+_shim.load = lambda f, **kw: _ShimUnpickler(f, **kw).load()
+_shim.loads = pickle.loads
+_shim.dump, _shim.dumps = pickle.dump, pickle.dumps
+_shim.__name__ = "pickle"
+
+
+def to_plain(node):
+    """omegaconf container / node (real or stand-in) -> dict / list / scalar."""
+    if isinstance(node, (str, int, float, bool, type(None))):
+        return node
+    if isinstance(node, dict):
+        return {k: to_plain(v) for k, v in node.items()}
+    if isinstance(node, (list, tuple)):
+        return [to_plain(v) for v in node]
+    d = getattr(node, "__dict__", {})
+    if "_content" in d:
+        return to_plain(d["_content"])
+    if "_val" in d:
+        return to_plain(d["_val"])
+    if hasattr(node, "value") and type(node).__module__.startswith("enum"):  # pragma: no cover
+        return node.value
+    try:  # a real omegaconf object
+        from omegaconf import OmegaConf  # type: ignore
+        return OmegaConf.to_container(node, resolve=False)
+    except Exception as e:  # noqa: BLE001
+        raise TypeError(f"cannot read configuration node of type {type(node)}") from e
+
+
+_INTERP = re.compile(r"^\$\{([A-Za-z0-9_.]+)\}$")
+
+
+def resolve_interpolations(conf: dict) -> dict:
+    """``${a.b.c}`` -> the value at that path of the same configuration (as OmegaConf resolves the three interpolations of
+    config/base.yaml); unresolvable ones stay as they are."""
+    def lookup(path):
+        cur = conf
+        for p in path.split("."):
+            cur = cur[p]
+        return cur
+
+    def walk(x, depth=0):
+        if isinstance(x, dict):
+            return {k: walk(v, depth) for k, v in x.items()}
+        if isinstance(x, list):
+            return [walk(v, depth) for v in x]
+        if isinstance(x, str):
+            m = _INTERP.match(x)
+            if m and depth < 8:
+                try:
+                    return walk(lookup(m.group(1)), depth + 1)
+                except (KeyError, TypeError):
+                    return x
+        return x
+    return walk(conf)
+
+
+def load_checkpoint(path, map_location="cpu"):
+    """-> (state_dict: OrderedDict name -> float32 ndarray without the ``module.`` prefix, conf: plain nested dict or None,
+    extras: {"epoch", "step"} when present)."""
+    import torch
+    try:
+        ckpt = torch.load(path, map_location=map_location, pickle_module=_shim, weights_only=False)
+    except (pickle.UnpicklingError, RuntimeError, EOFError):  # plain pickle written with use_torch=False
+        with open(path, "rb") as f:
+            ckpt = _ShimUnpickler(f).load()
+    if not isinstance(ckpt, dict) or "model" not in ckpt:
+        raise ValueError(f"{path}: not a FrameDiPT checkpoint (expected a dict with a 'model' entry)")
+    sd = OrderedDict()
+    for k, v in ckpt["model"].items():
+        arr = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        sd[k.replace("module.", "")] = arr.astype(np.float32, copy=False)  # inference.py:156-158
+    conf = ckpt.get("conf")
+    conf = resolve_interpolations(to_plain(conf)) if conf is not None else None
+    return sd, conf, {k: ckpt[k] for k in ("epoch", "step") if k in ckpt}
+
+
+def merge(base: dict, over: dict) -> dict:
+    """OmegaConf.merge for plain dicts: ``over`` wins, dictionaries merge recursively."""
+    out = dict(base)
+    for k, v in over.items():
+        out[k] = merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+    return out
+
+
+def apply_checkpoint_conf(cfg, ckpt_conf: dict, seed=None):
+    """The configuration steps of ``Inference._load_ckpt`` (inference.py:133-148) on a ``framedipt_amd.config.Conf``: model <-
+    merge(model, ckpt.model); diffuser.r3 <- ckpt.diffuser.r3; both diffuser seeds <- the inference seed."""
+    from .config import to_conf
+    cfg = to_conf(merge(dict(cfg), {"model": ckpt_conf.get("model", {})}))
+    if "diffuser" in ckpt_conf and "r3" in ckpt_conf["diffuser"]:
+        cfg.diffuser.r3 = to_conf(dict(ckpt_conf["diffuser"]["r3"]))
+    m = cfg.model
+    # fields the library reads from the ipa / embed sub-configs (config/base.yaml interpolations)
+    m.ipa.setdefault("c_s", m.node_embed_size)
+    m.ipa.setdefault("c_z", m.edge_embed_size)
+    m.ipa.setdefault("coordinate_scaling", cfg.diffuser.r3.coordinate_scaling)
+    m.embed.min_bin = float(m.embed.min_bin)
+    if seed is None:
+        seed = cfg.get("inference", {}).get("seed", 123)
+    cfg.diffuser.so3.seed = cfg.diffuser.r3.seed = seed
+    cfg.diffuser.r3.setdefault("seed", seed)
+    return cfg
+
+
+def load_model(weights_path, cfg=None, inpainting: bool = False, precision: str = "fp16", device="cuda"):
+    """``Inference._load_ckpt``: checkpoint -> (cfg, SE3Diffuser, ScoreNetwork on ``device``)."""
+    from . import config
+    from .diffusion import SE3Diffuser
+    from .model import ScoreNetwork
+    sd, ckpt_conf, _ = load_checkpoint(weights_path)
+    cfg = apply_checkpoint_conf(cfg if cfg is not None else config.base_config(inpainting), ckpt_conf or {})
+    diffuser = SE3Diffuser(cfg.diffuser, device=device)
+    model = ScoreNetwork(cfg.model, diffuser, inpainting=inpainting, precision=precision)
+    model.load_state_dict(sd)
+    return cfg, diffuser, model.to(device).eval()
+
+
+def main(argv=None):
+    import yaml
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 2:
+        raise SystemExit(__doc__)
+    sd, conf, extra = load_checkpoint(argv[0])
+    np.savez(argv[1] + ".npz", **sd)
+    with open(argv[1] + ".yaml", "w") as f:
+        yaml.safe_dump({"conf": conf, **{k: int(v) for k, v in extra.items()}}, f, sort_keys=False)
+    print(f"{len(sd)} tensors, {sum(v.size for v in sd.values())} parameters -> {argv[1]}.npz / .yaml")
+
+
+if __name__ == "__main__":
+    main()

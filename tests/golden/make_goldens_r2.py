@@ -203,6 +203,49 @@ def ops_r2_goldens():
     print("ops_r2", len(g), "arrays", flush=True)
 
 
+def writer_goldens():
+    """Files the reference's output writers produce from given arrays (framedipt/analysis/utils.py:76-157 -> protein.py:165-281,
+    experiments/utils.py:690-749): stored as bytes next to their inputs (data, not source)."""
+    import pathlib
+    import tempfile
+
+    from experiments import utils as eu
+    from framedipt.analysis import utils as au
+    rng = np.random.default_rng(3)
+    g = {}
+    n, T = 23, 3
+    pos = np.zeros((T, n, 37, 3), dtype=np.float32)
+    pos[:, :, :5] = rng.standard_normal((T, n, 5, 3)).astype(np.float32) * 30  # backbone atoms N, CA, C, CB, O
+    pos[0, 2, 3] = 0  # a missing CB (glycine-like): masked by |x| < 1e-7
+    pos[:, 5, :5, 0] = [-123.4567, 999.9994, 0.0004, -0.0005, 1234.5]
+    aatype = rng.integers(0, 21, n)
+    chain_index = np.concatenate([np.full(9, 3), np.full(8, 7), np.full(6, 12)])
+    residue_index = np.concatenate([np.arange(9) + 5, np.arange(8) + 220, np.arange(6) + 441])
+    dm = np.zeros(n)
+    dm[2:6] = 1
+    dm[11:14] = 1
+    dm[15:16] = 1
+    b_factors = np.tile((dm * 100)[:, None], (1, 37))
+    g.update(pos=pos, aatype=aatype, chain_index=chain_index, residue_index=residue_index, diffuse_mask=dm)
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        p1 = au.write_prot_to_pdb(pos[0], td / "sample_0", b_factors=b_factors, aatype=aatype, residue_index=residue_index, chain_index=chain_index)
+        p2 = au.write_prot_to_pdb(pos, td / "bb_traj_0", b_factors=b_factors, aatype=aatype, residue_index=residue_index, chain_index=chain_index)
+        p3 = au.write_prot_to_pdb(pos[1], td / "plain", no_indexing=True)
+        p4 = au.write_prot_to_pdb(pos[0], td / "sample_0", b_factors=b_factors)  # second call: index suffix _2
+        g["pdb_names"] = np.array([p.name for p in (p1, p2, p3, p4)])
+        for k, p in zip(("pdb_sample", "pdb_traj", "pdb_plain", "pdb_second"), (p1, p2, p3, p4)):
+            g[k] = np.frombuffer(p.read_bytes(), dtype=np.uint8)
+        seq = "".join("ARNDCQEGHILKMFPSTWYVX"[a] for a in aatype)
+        eu.save_diffusion_info(td, "1abc", seq, dm, chain_index)
+        g["info_seq"] = np.array(seq)
+        g["info_csv"] = np.frombuffer((td / "diffusion_info.csv").read_bytes(), dtype=np.uint8)
+        ch, st, en = eu.get_diffused_region_per_chain(dm, chain_index)
+        g.update(region_chains=np.array(ch), region_starts=np.array(st), region_ends=np.array(en))
+    np.savez_compressed(os.path.join(HERE, "writers.npz"), **g)
+    print("writers", list(g["pdb_names"]), len(g["pdb_sample"]), "bytes", flush=True)
+
+
 def denovo(n):
     return lambda rng, diff: mg.make_feats(n, rng, False, diff)
 
@@ -226,6 +269,7 @@ JOBS = {
     "traj_full_denovo_n64_T20_gain03": lambda: traj_golden_gain("full_denovo_n64_T20_gain03", rh.load_cfg(), 64, 20, 0.3),
     "sampler_dicts": sampler_goldens,
     "ops_r2": ops_r2_goldens,
+    "writers": writer_goldens,
 }
 
 

@@ -186,3 +186,103 @@ def test_score_sigma_float32_evaluation():
     with pytest.raises(NotImplementedError):
         so3_diffuser.SO3Diffuser(conf)
     assert np.shape(so3.score_scaling(np.array([0.1, 0.5]))) == (2,)
+
+
+def test_output_writers_byte_equal_reference_files(tmp_path):
+    """framedipt_amd.output vs files written by the reference from the same arrays (tests/golden/writers.npz): PDB files
+    (single model, trajectory, no_indexing, index suffix of a second call) and diffusion_info.csv, byte for byte."""
+    from framedipt_amd import output
+    G = load_golden("writers.npz")
+    pos, aatype, ci, ri, dm = G["pos"], G["aatype"], G["chain_index"], G["residue_index"], G["diffuse_mask"]
+    bfac = np.tile((dm * 100)[:, None], (1, 37))
+    p1 = output.write_prot_to_pdb(pos[0], tmp_path / "sample_0", b_factors=bfac, aatype=aatype, residue_index=ri, chain_index=ci)
+    p2 = output.write_prot_to_pdb(pos, tmp_path / "bb_traj_0", b_factors=bfac, aatype=aatype, residue_index=ri, chain_index=ci)
+    p3 = output.write_prot_to_pdb(pos[1], tmp_path / "plain", no_indexing=True)
+    p4 = output.write_prot_to_pdb(pos[0], tmp_path / "sample_0", b_factors=bfac)
+    assert [p.name for p in (p1, p2, p3, p4)] == [str(x) for x in G["pdb_names"]]
+    for p, k in zip((p1, p2, p3, p4), ("pdb_sample", "pdb_traj", "pdb_plain", "pdb_second")):
+        assert p.read_bytes() == bytes(G[k]), k
+    seq = output.aatype_to_seq(aatype)
+    assert seq == str(G["info_seq"])
+    output.save_diffusion_info(tmp_path, "1abc", seq, dm, ci)
+    assert (tmp_path / "diffusion_info.csv").read_bytes() == bytes(G["info_csv"])
+    ch, st, en = output.get_diffused_region_per_chain(dm, ci)
+    assert (list(ch), list(st), list(en)) == (list(G["region_chains"]), list(G["region_starts"]), list(G["region_ends"]))
+    paths = output.save_traj(pos, pos, dm, tmp_path, 7, aatype=aatype, residue_index=ri, chain_index=ci)
+    assert paths["sample_path"].name == "sample_7_1.pdb" and paths["traj_path"].name == "bb_traj_7_1.pdb"
+    assert paths["traj_path"].read_bytes() == bytes(G["pdb_traj"])
+    with pytest.raises(ValueError):
+        output.write_prot_to_pdb(pos[0, :, :5], tmp_path / "bad")
+
+
+_FAKE_OMEGACONF = '''
+"""Minimal package with the pickle layout of omegaconf 2.x containers / nodes (test double: the real package is not installed)."""
+class ContainerMetadata:
+    def __init__(self): self.ref_type = None; self.object_type = dict; self.optional = True; self.key = None; self.flags = {}
+class Metadata(ContainerMetadata): pass
+class Node:
+    def __getstate__(self):
+        d = dict(self.__dict__); d.pop("_flags_cache", None); return d
+    def __setstate__(self, d): self.__dict__.update(d); self.__dict__["_flags_cache"] = None
+class AnyNode(Node):
+    def __init__(self, v, parent=None): self.__dict__.update(_val=v, _metadata=Metadata(), _parent=parent, _flags_cache=None)
+class DictConfig(Node):
+    def __init__(self, content, parent=None):
+        self.__dict__.update(_metadata=ContainerMetadata(), _parent=parent, _flags_cache=None, _content={})
+        for k, v in content.items(): self._content[k] = wrap(v, self)
+class ListConfig(Node):
+    def __init__(self, content, parent=None):
+        self.__dict__.update(_metadata=ContainerMetadata(), _parent=parent, _flags_cache=None, _content=[wrap(v, self) for v in content])
+def wrap(v, parent):
+    if isinstance(v, dict): return DictConfig(v, parent)
+    if isinstance(v, list): return ListConfig(v, parent)
+    return AnyNode(v, parent)
+'''
+
+
+def test_checkpoint_ingest_without_omegaconf(tmp_path):
+    """framedipt_amd.checkpoint: a checkpoint in the reference's format (torch.save of {"model", "conf": DictConfig, ...},
+    ``module.`` prefixes, ``${...}`` interpolations) written by a subprocess that has an omegaconf-shaped package, read here
+    without one; then the configuration steps of Inference._load_ckpt."""
+    import subprocess
+    import sys
+    from framedipt_amd import checkpoint, config
+    from framedipt_amd import weights as W
+    pkg = tmp_path / "fake" / "omegaconf"
+    pkg.mkdir(parents=True)
+    (pkg / "__init__.py").write_text(_FAKE_OMEGACONF)
+    shapes = W.param_shapes(config.small_config().model)
+    names = list(shapes)[:6]
+    writer = f'''
+import sys; sys.path.insert(0, {str(tmp_path / "fake")!r}); sys.path.insert(0, {ROOT!r})
+import torch, omegaconf
+from framedipt_amd import config, weights as W
+shapes = W.param_shapes(config.small_config().model)
+sd = W.synth_state_dict(shapes, 3)
+conf = {{"model": {{"node_embed_size": 64, "edge_embed_size": 32, "input_aatype": False,
+                  "embed": {{"index_embed_size": 32, "num_bins": 22, "min_bin": "1e-5", "max_bin": 20.0, "embed_self_conditioning": True}},
+                  "ipa": {{"c_s": "${{model.node_embed_size}}", "c_z": "${{model.edge_embed_size}}", "c_hidden": 16, "c_skip": 16, "no_heads": 4,
+                          "no_qk_points": 4, "no_v_points": 6, "seq_tfmr_num_heads": 2, "seq_tfmr_num_layers": 1, "num_blocks": 2,
+                          "coordinate_scaling": "${{diffuser.r3.coordinate_scaling}}"}}}},
+        "diffuser": {{"r3": {{"min_b": 0.1, "max_b": 20.0, "coordinate_scaling": 0.1}}, "so3": {{"num_omega": 1000}}}},
+        "experiment": {{"tags": ["a", "b"], "nested": [{{"x": 1}}]}}}}
+torch.save({{"model": {{"module." + k: torch.tensor(v) for k, v in sd.items()}}, "conf": omegaconf.DictConfig(conf), "optim": {{}},
+            "epoch": 7, "step": 1234}}, {str(tmp_path / "ckpt.pth")!r})
+'''
+    subprocess.run([sys.executable, "-c", writer], check=True)
+    assert "omegaconf" not in sys.modules or getattr(sys.modules["omegaconf"], "__file__", None) is None
+    sd, conf, extra = checkpoint.load_checkpoint(tmp_path / "ckpt.pth")
+    ref = W.synth_state_dict(shapes, 3)
+    assert list(sd) == list(ref) and all(not k.startswith("module.") for k in sd)
+    for k in names:
+        np.testing.assert_array_equal(sd[k], ref[k])
+    assert extra == {"epoch": 7, "step": 1234}
+    assert conf["model"]["ipa"]["c_s"] == 64 and conf["model"]["ipa"]["coordinate_scaling"] == 0.1  # interpolations resolved
+    assert conf["experiment"] == {"tags": ["a", "b"], "nested": [{"x": 1}]}
+    cfg = checkpoint.apply_checkpoint_conf(config.base_config(), conf, seed=11)
+    assert cfg.model.ipa.c_hidden == 16 and cfg.model.ipa.c_z == 32 and cfg.model.embed.min_bin == 1e-5
+    assert cfg.diffuser.r3.seed == 11 and cfg.diffuser.so3.seed == 11 and cfg.diffuser.so3.num_sigma == 1000
+    assert W.param_shapes(cfg.model) == shapes
+    checkpoint.main([str(tmp_path / "ckpt.pth"), str(tmp_path / "out")])
+    z = np.load(tmp_path / "out.npz")
+    assert sorted(z.files) == sorted(ref) and (tmp_path / "out.yaml").exists()
