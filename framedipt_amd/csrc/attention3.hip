@@ -20,7 +20,7 @@
 #include "kernels.hpp"
 
 #define A3_C 256
-#define A3_NTW_MAX 4  // key tiles per wave -> N <= 4 * 4 * 32 = 512
+#define A3_NTW_MAX 8  // key tiles per wave -> N <= 8 * 4 * 32 = 1024
 
 __device__ __forceinline__ hx8 a3_pack8(const float* v) {
   hx8 o;
@@ -326,13 +326,24 @@ int fd_attention3_supported(const Attn3Args& a) {
 
 int fd_attention3(const Attn3Args& a, hipStream_t st) {
   const int nt = (a.N + 31) / 32, Np = nt * 32;
-  const size_t smem = 2 * 128 * 4 + (size_t)32 * 96 * 4 + (size_t)2 * nt * 64 * 16 + 16;
+  const size_t smem = 2 * 128 * 4 + (size_t)32 * 96 * 4 + (size_t)2 * nt * 64 * 16 + 16;  // 1 KB + 12 KB + 64 B per key: 77 KB at N = 1024
   (void)Np;
-  if (smem > 64 * 1024) return FDIPT_ESIZE;  // 1 KB + 12 KB + 64 B per key: 45 KB at N = 512
+  if (!fd_attention3_supported(a)) return FDIPT_ESIZE;
+  static bool attr_set = false;
+  if (!attr_set) {  // N > 800: more than the default 64 KB of dynamic LDS
+    if (hipFuncSetAttribute((const void*)ipa_attn3_kernel<6, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)ipa_attn3_kernel<8, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
   const int per = (a.B * a.H + 7) / 8;  // see the block mapping in the kernel
-  if (a.N <= 3 * 4 * 32 && !FD_DEV_ENV("FDIPT_A3_LB2")) hipLaunchKernelGGL((ipa_attn3_kernel<3, 3, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem + 16384, st, a);
-  else if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
-  else hipLaunchKernelGGL((ipa_attn3_kernel<4, 1, true>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, a);
+  const dim3 grid(8 * per * nt), block(FD_THREADS);
+  if (a.N <= 3 * 4 * 32 && !FD_DEV_ENV("FDIPT_A3_LB2")) hipLaunchKernelGGL((ipa_attn3_kernel<3, 3, false>), grid, block, smem + 16384, st, a);
+  else if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), grid, block, smem, st, a);
+  else if (a.N <= 4 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<4, 1, true>), grid, block, smem, st, a);
+  // 512 < N <= 1024 (TCR-pMHC complexes, long chains): 6 / 8 key tiles per wave, one block per CU, operands fetched per tile
+  else if (a.N <= 6 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<6, 1, false>), grid, block, smem, st, a);
+  else hipLaunchKernelGGL((ipa_attn3_kernel<8, 1, false>), grid, block, smem, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

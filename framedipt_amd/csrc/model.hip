@@ -676,7 +676,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     ea.gamma = P + iv.eeln.g; ea.beta = P + iv.eeln.b; ea.res_mask = res_mask; ea.z_out = W + w.z;
     ea.trace = a->trace_edge;
     // the first block's pair bias linear_b(z)/sqrt(3) from the embedder's LayerNorm epilogue (saves a pass over z)
-    const bool ee_bias = use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 512 &&
+    const bool ee_bias = use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 1024 &&
                          !sw.generic_attn && !sw.no_et_bias && !sw.no_ee_bias;
     ea.wb_img = ee_bias ? D + L.blk[0].wb_img : nullptr; ea.bb = (const float*)(D + L.blk[0].bb); ea.bias_out = F(w.bias); ea.H = H;
     ee_bias_done = ee_bias;
@@ -1033,7 +1033,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         // the next block's attention consumes linear_b(z') in fragment order when it runs attention3
         // (end to end +0.8 % at N = 300: the launch grows by about as much as the pair_bias2 launch it replaces, the gain
         //  is the z re-read that disappears; FDIPT_KF_UNFOLDED restores the separate pass)
-        const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !sw.generic_attn && !sw.no_et_bias && N <= 512;
+        const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !sw.generic_attn && !sw.no_et_bias && N <= 1024;
         t2.wb_img = emit_bias ? D + (use_et4 ? L.blk[b + 1].wb_img4 : L.blk[b + 1].wb_img3) : nullptr;
         t2.a1_img = W + w.a1img; t2.b1_img = W + w.b1img;
         t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
