@@ -419,8 +419,17 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
 // from LDS).  Wave w owns channels 32w..32w+31.  The tail (sum_j a, down_z projection) is the VALU code of opair_kernel.
 #define OM_JC 64                    // keys per chunk
 #define OM_ZROW (OM_JC * 2 + 16)    // bytes per Zt row (16 lanes of a b128 read hit 16 distinct slots)
-#define OM_NK 20                    // 16-key row groups per thread: N <= 320
-__global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, int Np) {
+// OM_NK: 16-key row groups per thread (all of a row's z pieces are requested up front): 20 -> N <= 320, two blocks per CU;
+// 64 -> N <= 1024, one block per CU
+template <int N_, class F>
+__device__ __forceinline__ void om_for(F&& f) {
+  if constexpr (N_ > 0) {
+    om_for<N_ - 1>(f);
+    f(std::integral_constant<int, N_ - 1>{});
+  }
+}
+template <int OM_NK, int LB>
+__global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a, int Np) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CZ = 128, H = 8, CD = 32;
   const int N = a.N, nch = Np / OM_JC;
@@ -509,11 +518,7 @@ __global__ __launch_bounds__(FD_THREADS, 2) void opair_mfma_kernel(OPairArgs a, 
       __syncthreads();
     }
   };
-  chunk(std::integral_constant<int, 0>{});
-  chunk(std::integral_constant<int, 1>{});
-  chunk(std::integral_constant<int, 2>{});
-  chunk(std::integral_constant<int, 3>{});
-  chunk(std::integral_constant<int, 4>{});
+  om_for<OM_NK / 4>(chunk);
   // D[h, Zt row]: lane (row 32 wave + li, hi) holds heads 4 hi + r in registers r < 4; row 16 e + cg = channel 8 cg + e
   {
     const int zrow_i = 32 * wave + li, ch_i = 8 * (zrow_i & 15) + (zrow_i >> 4);
@@ -561,7 +566,7 @@ static int launch_opair(const OPairArgs& a, hipStream_t st) {
 }
 
 int fd_opair_mfma_eligible(int precision, const OPairArgs& a) {
-  return precision != FDIPT_PREC_F32 && a.CZ == 128 && a.H == 8 && a.CD == 32 && a.wdz_img && a.N <= 16 * OM_NK && !FD_DEV_ENV("FDIPT_OPAIR_VALU");
+  return precision != FDIPT_PREC_F32 && a.CZ == 128 && a.H == 8 && a.CD == 32 && a.wdz_img && a.N <= 1024 && !FD_DEV_ENV("FDIPT_OPAIR_VALU");
 }
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
   if (a.H > 8) return FDIPT_ESIZE;
@@ -569,7 +574,9 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
     if (a.probs_h16 && (a.probs_np & 3)) return FDIPT_EINVAL;
     const int Np = (a.N + OM_JC - 1) / OM_JC * OM_JC;
     const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4;
-    hipLaunchKernelGGL(opair_mfma_kernel, dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+    if (a.N <= 320) hipLaunchKernelGGL((opair_mfma_kernel<20, 2>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+    else if (a.N <= 640) hipLaunchKernelGGL((opair_mfma_kernel<40, 1>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+    else hipLaunchKernelGGL((opair_mfma_kernel<64, 1>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
     FD_CHECK_LAUNCH();
     return FDIPT_OK;
   }

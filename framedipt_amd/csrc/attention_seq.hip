@@ -23,7 +23,7 @@
 #define SA_HD 80
 #define SA_KS 6         // k-steps of 16 channels: 80 + the mask channel, padded to 96
 #define SA_DT 3         // 32-channel output tiles (80 -> 96, padded rows are zero)
-#define SA_NTW_MAX 4    // key tiles per wave -> N <= 4 * 4 * 32 = 512
+#define SA_NTW_MAX 8    // key tiles per wave -> N <= 8 * 4 * 32 = 1024
 
 __host__ __device__ __forceinline__ int sa_perm16(int pos) {  // involution
   const int hi = pos >> 3, e = pos & 7;
@@ -323,14 +323,19 @@ __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, 
   const int h = bhq % H, b = bhq / H;
   const long bh = bhq, rb = (long)b * N;
   const int i = 32 * qt + li;
-  // ---- every global operand of this wave, requested up front
+  // ---- every global operand of this wave, requested up front (more than 4 key tiles per wave: the V fragments would not fit
+  // beside the K fragments and the scores; they are requested once the scores are final)
+  constexpr bool EARLY_V = SA_NTW <= 4;
   hx8 Va[8 * SA_NTW];
-  if (wave < SA_DT) {
-    const half_t* vr = Vi + (((bh * SA_DT + wave) * ks) * 64 + lane) * 8;
+  auto v_request = [&]() {
+    if (wave < SA_DT) {
+      const half_t* vr = Vi + (((bh * SA_DT + wave) * ks) * 64 + lane) * 8;
 #pragma unroll
-    for (int s = 0; s < 8 * SA_NTW; ++s)
-      if (s < ks) Va[s] = sa_ld(vr + s * 512);
-  }
+      for (int s = 0; s < 8 * SA_NTW; ++s)
+        if (s < ks) Va[s] = sa_ld(vr + s * 512);
+    }
+  };
+  if constexpr (EARLY_V) v_request();
   hx8 Qf[SA_KS];
 #pragma unroll
   for (int s = 0; s < SA_KS; ++s) Qf[s] = sa_ld(Qi + (((bh * nt + qt) * SA_KS + s) * 64 + lane) * 8);
@@ -390,6 +395,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_kernel(int B, int N, 
       Pfs[(2 * t + 1) * 64 + lane] = __builtin_bit_cast(u16x8, sa_pack8(v + 8));
     }
   }
+  if constexpr (!EARLY_V) v_request();
   __syncthreads();
   // ---- O^T[d, query] for channel tile `wave` over all keys
   if (wave < SA_DT) {
@@ -429,12 +435,7 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
   hipLaunchKernelGGL(seq_images_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, H, qkv, ld, scale,
                      res_mask, Qi, Ki, Vi);
   FD_CHECK_LAUNCH();
-  const int per = (B * H + 7) / 8;
-  const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
-  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, L2Warm{});
-  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, L2Warm{});
-  FD_CHECK_LAUNCH();
-  return FDIPT_OK;
+  return fd_seq_attention_run(B, N, H, images, out, out_ld, nullptr, st);
 }
 
 // Fused path: fd_seq_images_init once per forward, then per layer fd_seq_qkv (in_proj + images) and fd_seq_attention_run.
@@ -477,8 +478,16 @@ int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, in
   const half_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
-  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
-  else hipLaunchKernelGGL((seq_attn_kernel<4, 1>), dim3(8 * per * nt), dim3(FD_THREADS), smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
+  static bool attr_set = false;
+  if (!attr_set) {  // N > 1000: more than the default 64 KB of dynamic LDS
+    if (hipFuncSetAttribute((const void*)seq_attn_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  const dim3 grid(8 * per * nt), block(FD_THREADS);
+  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), grid, block, smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
+  else if (N <= 4 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<4, 1>), grid, block, smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
+  else if (N <= 6 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<6, 1>), grid, block, smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
+  else hipLaunchKernelGGL((seq_attn_kernel<8, 1>), grid, block, smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
