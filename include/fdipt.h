@@ -139,6 +139,10 @@ typedef struct FdiptForwardArgs {
    * the forward.  May alias sc_ca_t (read at the start): the sampler's self-conditioning hand-over
    * (experiments/utils.py:361-366,571-578) then costs no copy.  NULL to skip. */
   float* ca_out;
+  /* Concurrent sub-batches (one forward per HIP stream): the persistent pair kernels (edge embedder, EdgeTransition) start
+   * on all CUs but `reserve_cus` of them, so that the latency-bound node-path launches of another stream keep finding free
+   * CUs while they run.  0 = use every CU (single stream). */
+  int32_t reserve_cus;
 } FdiptForwardArgs;
 
 size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
