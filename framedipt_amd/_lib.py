@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfdipt_hip.so")
+# FDIPT_LIB: another build of the library (the -DFDIPT_DEV build that tools/ use: csrc/build.sh with FDIPT_DEV=1)
+LIB_PATH = os.environ.get("FDIPT_LIB") or os.path.join(_HERE, "lib", "libfdipt_hip.so")
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 # FdiptDims.kernel_flags (include/fdipt.h): fallback paths of the half-precision mode, for parity tests
@@ -37,7 +38,7 @@ class ForwardArgs(C.Structure):
         (n, _P) for n in ("rigids_t", "res_mask", "fixed_mask", "sc_ca_t", "seq_idx", "idx_emb", "aatype", "gt_psi", "t",
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
                           "atom37", "atom14", "trace_node", "trace_edge", "trace_inner")] + [
-        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P), ("reserve_cus", C.c_int32)]
+        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P)]
 
 
 _lib = None

@@ -3,17 +3,21 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../lib"
-mkdir -p "$OUT" "$HERE/build"
+# FDIPT_DEV=1: development build (-DFDIPT_DEV: the FDIPT_* environment switches of model.hip / kernels.hpp are read, once per
+# process) -> lib/libfdipt_hip_dev.so, loaded instead of the product library when FDIPT_LIB points at it (tools/)
+BUILD="$HERE/build"; LIBNAME=libfdipt_hip.so; EXTRA=""
+if [ -n "${FDIPT_DEV:-}" ]; then BUILD="$HERE/build_dev"; LIBNAME=libfdipt_hip_dev.so; EXTRA="-DFDIPT_DEV"; fi
+mkdir -p "$OUT" "$BUILD"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -Wno-inline-asm: the LDS-DMA helpers name m0 (a reserved register hipcc re-materialises before each of its own uses) as clobbered
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -Wno-inline-asm"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -Wno-inline-asm $EXTRA"
 pids=()
 for f in gemm ipa_proj2 pair_mlp edge_embed2 edge_transition3 edge_transition4 attention attention3 pair_bias attention_seq chain rowblock frames model; do
-  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.hpp" -nt "$HERE/build/$f.o" ] || [ "$HERE/kernels.hpp" -nt "$HERE/build/$f.o" ] || [ "$HERE/../../include/fdipt.h" -nt "$HERE/build/$f.o" ]; then
-    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
+  if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/common.hpp" -nt "$BUILD/$f.o" ] || [ "$HERE/kernels.hpp" -nt "$BUILD/$f.o" ] || [ "$HERE/../../include/fdipt.h" -nt "$BUILD/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfdipt_hip.so" "$HERE"/build/{gemm,ipa_proj2,pair_mlp,edge_embed2,edge_transition3,edge_transition4,attention,attention3,pair_bias,attention_seq,chain,rowblock,frames,model}.o
-echo "built $OUT/libfdipt_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "$BUILD"/{gemm,ipa_proj2,pair_mlp,edge_embed2,edge_transition3,edge_transition4,attention,attention3,pair_bias,attention_seq,chain,rowblock,frames,model}.o
+echo "built $OUT/$LIBNAME"

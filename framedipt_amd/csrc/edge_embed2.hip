@@ -301,8 +301,7 @@ int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
       return FDIPT_ELAUNCH;
     attr_set = true;
   }
-  const int cus = a.reserve_cus > 0 && a.reserve_cus < 248 ? (256 - a.reserve_cus) & ~7 : 256;
-  const int grid = n_tiles / 8 + 1 < cus ? n_tiles / 8 + 1 : cus;
+  const int grid = n_tiles / 8 + 1 < 256 ? n_tiles / 8 + 1 : 256;
   hipLaunchKernelGGL(edge_embed2_kernel, dim3(grid), dim3(EE2_THREADS), EE2_LDS, st, a, (const char*)img, n_tiles);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -149,8 +149,9 @@ __global__ __launch_bounds__(FD_THREADS) void linear_splitk_kernel(int M, int N,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ rowmask,
                                                                    float* __restrict__ parts, long part_stride, int ldo) {
-  constexpr int BM = 64, BN = 64, LDT = 64 * P::LDMUL + P::PAD;
-  __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
+  constexpr int BM = 64, BN = 64;
+  extern __shared__ __attribute__((aligned(16))) char splitk_smem[];  // 2 * (BM + BN) * LDT elements (dynamic: 68 KB with split operands)
+  typename P::T* smem = (typename P::T*)splitk_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
@@ -496,8 +497,8 @@ int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, c
   if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 3) || (ldw & 7)) return FDIPT_EINVAL;
   const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
   if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
-  hipLaunchKernelGGL((linear_splitk_kernel<PrecHalf, float, half_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
-                     st, M, N, K, kslice, A, lda, (const half_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecHalf, float, half_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS),
+                     (size_t)2 * 128 * (64 + PrecHalf::PAD) * sizeof(half_t), st, M, N, K, kslice, A, lda, (const half_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -507,7 +508,14 @@ int fd_linear_splitk_split(int M, int N, int K, int nsplit, const float* A, int 
   if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 3) || (ldw & 3)) return FDIPT_EINVAL;
   const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
   if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
-  hipLaunchKernelGGL((linear_splitk_kernel<PrecSplit, float, float>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
+  constexpr size_t smem = (size_t)2 * 128 * (64 * PrecSplit::LDMUL + PrecSplit::PAD) * sizeof(half_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)linear_splitk_kernel<PrecSplit, float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecSplit, float, float>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), smem,
                      st, M, N, K, kslice, A, lda, W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
@@ -517,8 +525,8 @@ int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const half_t* A, int l
   if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 7) || (ldw & 7)) return FDIPT_EINVAL;
   const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
   if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
-  hipLaunchKernelGGL((linear_splitk_kernel<PrecHalf, half_t, half_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), 0,
-                     st, M, N, K, kslice, A, lda, (const half_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecHalf, half_t, half_t>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS),
+                     (size_t)2 * 128 * (64 + PrecHalf::PAD) * sizeof(half_t), st, M, N, K, kslice, A, lda, (const half_t*)W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -43,7 +43,6 @@ struct EdgeEmbedArgs {
   const float* bb;
   float* bias_out;
   int H;
-  int reserve_cus = 0;  // persistent kernel: CUs left to launches of other streams
 };
 
 struct AttnArgs {
@@ -125,7 +124,6 @@ struct ET2Args {
   float* bias_out;      // fragment order (fd_bias_frag_off)
   int H;
   // edge_transition4: per-residue rows as fold fragments (fd_et4_row_images)
-  int reserve_cus = 0;  // persistent kernels: CUs left to launches of other streams (FdiptForwardArgs.reserve_cus)
   const void* a1_img;   // [ceil(B*N/8)][16][32][8] bf16: A1 | Af rows of 8 consecutive (flattened) residue rows
   const void* b1_img;   // [B][N/4][16][32][8] bf16: B1 | Bf rows (e_j columns) of 4 consecutive j (+ the next sample's)
 };

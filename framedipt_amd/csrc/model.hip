@@ -29,7 +29,10 @@ struct Switches {
   bool feats_unfused = false, torf_unfused = false, init_unfused = false, skip_per_block = false, post_unfused = false,
        no_tfmr_tail = false, et4_rows_unfused = false, no_qkv_fuse = false, proj_v1 = false, feats_f32 = false,
        probs_f32 = false, no_l2_warm = false;
+  bool no_seq_attn = false;     // (dev) sequence attention on the LDS-score kernel only (IPA attention unchanged)
   bool no_split = false;        // node-path products on plain half-precision operands instead of split (hi + lo) ones
+  int splitk_ns = 4;            // K slices of the IPA output projection (K = 2688)
+  unsigned split_mask = 63u;    // split operands per layer group: 1 node embedder, 2 output projection, 4 in_proj, 8 tails, 16 transition, 32 torsion
   unsigned chain_mask = 0xFC9u;  // fused chain kinds (chain.hip) that beat the launches they replace (profiles/r01_chain_vs_gemm.md)
   const char* twice = nullptr;   // timing aid: repeat the named launches (the second one runs on a warm L2)
 };
@@ -45,9 +48,11 @@ static const Switches& dev_switches() {
     s.skip_per_block = on("FDIPT_SKIP_PER_BLOCK"); s.post_unfused = on("FDIPT_POST_UNFUSED");
     s.no_tfmr_tail = on("FDIPT_NO_TFMR_TAIL"); s.et4_rows_unfused = on("FDIPT_ET4_ROWS_UNFUSED");
     s.no_qkv_fuse = on("FDIPT_NO_QKV_FUSE"); s.proj_v1 = on("FDIPT_PROJ_V1"); s.feats_f32 = on("FDIPT_FEATS_F32");
-    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM"); s.no_split = on("FDIPT_NO_SPLIT");
+    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM"); s.no_split = on("FDIPT_NO_SPLIT"); s.no_seq_attn = on("FDIPT_NO_SEQ_ATTN");
     if (const char* m = getenv("FDIPT_CHAIN_MASK")) s.chain_mask = (unsigned)strtoul(m, nullptr, 0);
     s.twice = getenv("FDIPT_DBG_TWICE");
+    if (const char* m = getenv("FDIPT_SPLITK_NS")) s.splitk_ns = atoi(m);
+    if (const char* m = getenv("FDIPT_SPLIT_MASK")) s.split_mask = (unsigned)strtoul(m, nullptr, 0);
 #endif
     return s;
   }();
@@ -599,7 +604,11 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // split operands (hi + lo half-precision parts, 3 MFMAs per k-step) for the dense layers of the node path, whose operand
   // rounding dominates the error of the predicted frames and psi (tools/err_budget.py): node embedder, IPA output projection,
   // sequence transformer (in_proj, out_proj, feed-forward), post_tfmr, transition, torsion head
-  const bool split = rbk && !sw.no_split;
+  const bool split_any = rbk && !sw.no_split;
+  const bool split = split_any && (sw.split_mask & 2u);                                   // IPA output projection
+  const bool split_embed = split_any && (sw.split_mask & 1u), split_qkv = split_any && (sw.split_mask & 4u),
+             split_tail = split_any && (sw.split_mask & 8u), split_trans = split_any && (sw.split_mask & 16u),
+             split_tors = split_any && (sw.split_mask & 32u);
   const void *rb_l0 = nullptr, *rb_l1 = nullptr, *rb_l2 = nullptr;  // one-shot: lo images for the next rblock() call
   auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                     const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
@@ -646,8 +655,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
                     F(w.trans), F(w.dmask), (const float*)(D + L.w1i), (const float*)(D + L.w1j), (const float*)(D + L.b1), cz,
                     feats_fused ? F(w.pi) : nullptr, F(w.pj), st));
   if (rbk && (L.kn_pad == 72 || L.kn_pad == 88)) {
-    if (split) { rb_l0 = D + L.lo_ne0; rb_l1 = D + L.lo_ne2; rb_l2 = D + L.lo_ne4; }
-    RC(rblock(split ? (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72_SPLIT : FD_RB_NODE_EMBED_88_SPLIT)
+    if (split_embed) { rb_l0 = D + L.lo_ne0; rb_l1 = D + L.lo_ne2; rb_l2 = D + L.lo_ne4; }
+    RC(rblock(split_embed ? (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72_SPLIT : FD_RB_NODE_EMBED_88_SPLIT)
                     : (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88), F(w.node_feat), L.kn_pad, D + L.ch_ne0, P + iv.ne0.b,
               D + L.ch_ne2n, P + iv.ne2.b, D + L.ch_ne4n, P + iv.ne4.b, nullptr, 0, &iv.neln, res_mask, F(w.node0), cs));
   } else if (con(FD_CHAIN_NODE_EMBED_72) && (L.kn_pad == 72 || L.kn_pad == 88)) {
@@ -674,7 +683,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     ea.edges = (const float*)(D + L.edges); ea.seq_idx = a->seq_idx; ea.sc_ca = a->sc_ca_t;
     ea.w2 = WM(iv.ee2); ea.w3 = WM(iv.ee4); ea.b2 = P + iv.ee2.b; ea.b3 = P + iv.ee4.b;
     ea.gamma = P + iv.eeln.g; ea.beta = P + iv.eeln.b; ea.res_mask = res_mask; ea.z_out = W + w.z;
-    ea.trace = a->trace_edge; ea.reserve_cus = a->reserve_cus;
+    ea.trace = a->trace_edge;
     // the first block's pair bias linear_b(z)/sqrt(3) from the embedder's LayerNorm epilogue (saves a pass over z)
     const bool ee_bias = use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 1024 &&
                          !sw.generic_attn && !sw.no_et_bias && !sw.no_ee_bias;
@@ -722,7 +731,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   const char* dbg_twice = sw.twice;  // timing aid: repeat the named launches (second one runs on a warm L2)
 #define TWICE(name, call) do { RC(call); if (dbg_twice && strstr(dbg_twice, name)) RC(call); } while (0)
   const bool warm_all = !sw.no_l2_warm;  // L2 warm-up hand-over between consecutive launches (common.hpp)
-  const bool seq_fused = rbk && !sw.generic_attn && !sw.no_qkv_fuse &&
+  const bool seq_fused = rbk && !sw.generic_attn && !sw.no_qkv_fuse && !sw.no_seq_attn &&
                          fd_seq_attention_supported(N, d->tfmr_heads, iv.d_t / d->tfmr_heads) &&
                          fd_seq_qkv_supported(N, d->tfmr_heads, iv.d_t);
   bool bias_ready = ee_bias_done;  // pair bias of this block's attention already written (tiled order) by the embedder / EdgeTransition
@@ -818,7 +827,11 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       return FD_STOP;
     }
     if (bf && iv.feat_dim >= 1024 && !sw.no_splitk) {
-      const int NS = 4;  // K = 2688: slices of 704 / 576 columns -> 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower)
+      // K = 2688 in slices: 4x the blocks, a quarter of the dependent k-iterations (7 slices: slower).  Split operands: 3 slices
+      // (70 KB of LDS per block = two blocks per CU: at B N = 2400 rows 456 blocks run in one round of the 256 CUs, 30 us;
+      // 4 slices = 608 blocks need two rounds, 41 us).  The slice count must not depend on the batch size: the order of the
+      // partial sums is part of a sample's result (sub-batches and sharded runs reproduce the whole-batch result bit for bit)
+      const int NS = sw.splitk_ns != 4 ? sw.splitk_ns : (split ? 3 : 4);
       if (split)
         TWICE("splitk", fd_linear_splitk_split(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, P + k.out.w, iv.feat_dim, P + k.out.b,
                                                res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
@@ -856,7 +869,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
           RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, SeqInitExtra{}, st));
           seq_img_ready = true;
         }
-        TWICE("qkv", fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], split ? D + db.lo.inp[l] : nullptr, P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));
+        TWICE("qkv", fd_seq_qkv(B, N, d->tfmr_heads, x, dt, D + db.ch.inp[l], split_qkv ? D + db.lo.inp[l] : nullptr, P + t.inp.b, 1.0f / sqrtf((float)hd0), W + w.seqimg, st));
         // ... and touches the weights of the layer's tail kernel, launched next (common.hpp: L2 warm-up hand-over)
         const unsigned wimg = (unsigned)fd_chain_image_bytes(dt, dt);
         L2Warm wt = {{D + db.ch.outp[l], D + db.ch.l1[l], D + db.ch.l2n[l]}, {wimg, wimg, wimg}};
@@ -874,7 +887,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       ta.C = hd; ta.Dv = hd; ta.scale = 1.0f / sqrtf((float)hd); ta.bias = nullptr; ta.res_mask = res_mask;
       ta.qp = ta.kp = ta.vp = nullptr; ta.Pq = ta.Pv = 0; ta.gamma = nullptr; ta.rot = ta.trans = nullptr; ta.probs = nullptr;
       ta.out = F(w.att); ta.out_ld = dt; ta.pt_off = 0; ta.lds_s = 0;
-      if (bf && !sw.generic_attn && fd_seq_attention_supported(N, d->tfmr_heads, hd))
+      if (bf && !sw.generic_attn && !sw.no_seq_attn && fd_seq_attention_supported(N, d->tfmr_heads, hd))
         RC(fd_seq_attention(B, N, d->tfmr_heads, F(w.qkv), 3 * dt, ta.scale, res_mask, W + w.seqimg, F(w.att), dt, st));
       else RC(fd_attention(prec, 0, ta, st));
       }
@@ -884,12 +897,12 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         tt.M = R; tt.ld = dt; tt.att = F(w.att); tt.x = x; tt.wo = D + db.ch.outp[l]; tt.w1 = D + db.ch.l1[l]; tt.w2 = D + db.ch.l2n[l];
         tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
         tt.be2 = P + t.n2.b; tt.out = x == F(w.x_b) ? F(w.x_a) : F(w.x_b);
-        if (split) { tt.wol = D + db.lo.outp[l]; tt.w1l = D + db.lo.l1[l]; tt.w2l = D + db.lo.l2[l]; }
+        if (split_tail) { tt.wol = D + db.lo.outp[l]; tt.w1l = D + db.lo.l1[l]; tt.w2l = D + db.lo.l2[l]; }
         tt.warm = L2Warm{};  // next launch: the following layer's in_proj, or post_tfmr / the transition
         // the last layer also applies post_tfmr + the node residual (FDIPT_POST_UNFUSED: its own launch)
         const bool post_here = l + 1 == d->tfmr_layers && cs == 256 && !sw.post_unfused;
         if (post_here) {
-          tt.wp = D + db.ch.post; tt.wpl = split ? D + db.lo.post : nullptr; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
+          tt.wp = D + db.ch.post; tt.wpl = split_tail ? D + db.lo.post : nullptr; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
           post_done = true;
         }
         const unsigned tb = (unsigned)fd_chain_image_bytes(cs, cs);
@@ -948,8 +961,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
                         {(unsigned)fd_chain_image_bytes(iv.cb, cs), (unsigned)fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb), 0}};
       else if (warm_all && b == d->num_blocks - 1)  // ... or the torsion head
         r.warm = L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, nullptr}, {(unsigned)fd_chain_image_bytes(cs, cs), (unsigned)fd_chain_image_bytes(cs, cs), 0}};
-      if (split) { r.w0l = D + db.lo.t1; r.w1l = D + db.lo.t2; r.w2l = D + db.lo.t3; }
-      RC(fd_rowblock(split ? FD_RB_TRANSITION_BB_SPLIT : FD_RB_TRANSITION_BB, r, st));
+      if (split_trans) { r.w0l = D + db.lo.t1; r.w1l = D + db.lo.t2; r.w2l = D + db.lo.t3; }
+      RC(fd_rowblock(split_trans ? FD_RB_TRANSITION_BB_SPLIT : FD_RB_TRANSITION_BB, r, st));
       bb_done = true;
     } else if (con(FD_CHAIN_TRANSITION)) {
       RC(chain(FD_CHAIN_TRANSITION, F(w.h_a), cs, D + db.ch.t1, P + k.t1.b, D + db.ch.t2, P + k.t2.b, D + db.ch.t3, P + k.t3.b,
@@ -1036,7 +1049,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !sw.generic_attn && !sw.no_et_bias && N <= 1024;
         t2.wb_img = emit_bias ? D + (use_et4 ? L.blk[b + 1].wb_img4 : L.blk[b + 1].wb_img3) : nullptr;
         t2.a1_img = W + w.a1img; t2.b1_img = W + w.b1img;
-        t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H; t2.reserve_cus = a->reserve_cus;
+        t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
         bias_ready = emit_bias;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
         if (use_et4) RC(fd_edge_transition4(t2, st));
@@ -1066,8 +1079,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   if (op.kind != OP_ALL) return FDIPT_EINVAL;  // (unreachable: every per-op selection returns inside the loop)
   // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
   if (rbk) {
-    if (split) { rb_l0 = D + L.lo_tor1; rb_l1 = D + L.lo_tor2; }
-    RC(rblock(split ? FD_RB_TORSION_SPLIT : FD_RB_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
+    if (split_tors) { rb_l0 = D + L.lo_tor1; rb_l1 = D + L.lo_tor2; }
+    RC(rblock(split_tors ? FD_RB_TORSION_SPLIT : FD_RB_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
               cs, nullptr, nullptr, F(w.h_b), cs));
   } else if (con(FD_CHAIN_TORSION)) {
     RC(chain(FD_CHAIN_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2, P + iv.tor2.b, nullptr, nullptr, node_cur,

@@ -75,7 +75,6 @@ class BatchState:
             self.trace_node = torch.zeros(d.num_blocks + 1, B, N, d.c_s, **f32)
             self.trace_edge = torch.zeros(d.num_blocks, B, N, N, d.c_z, **f32)
         self.trace_inner = (torch.zeros(d.num_blocks, 4, B, N, d.c_s + d.c_skip, **f32) if trace_inner else None)
-        self.reserve_cus = 0  # CUs the persistent pair kernels leave to concurrent sub-batch streams (inference.StreamedLoops)
         self.ev_start = self.ev_stop = None  # optional hipEvent pairs around the EdgeTransition launches (bench.py)
         self.t_emb_eps = torch.as_tensor(embedding.get_timestep_embedding(np.array([1e-5], dtype=np.float32), E)[0],
                                          device=dev)
@@ -97,7 +96,6 @@ class BatchState:
                           ("trace_node", self.trace_node), ("trace_edge", self.trace_edge), ("trace_inner", self.trace_inner),
                           ("ca_out", ca_out)):
             setattr(a, name, _lib.ptr(tns))
-        a.reserve_cus = self.reserve_cus
         if self.ev_start is not None:
             a.ev_start, a.ev_stop = self.ev_start, self.ev_stop
         _lib.check(lib.fdipt_score_forward(C.byref(net.dims), _lib.ptr(net.params), _lib.ptr(net.derived),

@@ -1,0 +1,76 @@
+"""GPU robustness tests (-m gpu) of the score-network forward: no write outside the caller's buffers, no dependence on bytes of
+the workspace the forward did not write itself, bit-reproducible results."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, b, prec):
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.model.score_network import BatchState
+    from framedipt_amd.sampler import UnconditionalSampler
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision=prec).load_synthetic(7).to("cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": b}), d, "cuda")
+    feats, _ = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, 6, 0.01) for i in range(b)])
+    st = BatchState(net, feats["seq_idx"])
+    t32, temb, sig = net.step_scalars(np.full(b, 0.5))
+    f32 = lambda x: x.to(device="cuda", dtype=torch.float32).contiguous()  # noqa: E731
+    args = (f32(feats["rigids_t"]), f32(feats["res_mask"]), f32(feats["fixed_mask"]), f32(feats["sc_ca_t"]) + 1.0, None,
+            f32(feats["torsion_angles_sin_cos"][..., 2, :]), torch.as_tensor(t32, device="cuda"), torch.as_tensor(temb, device="cuda"),
+            torch.as_tensor(sig, device="cuda"))
+    return net, st, args
+
+
+OUT = ("rigids", "psi", "rot_score", "trans_score", "atom37", "atom14")
+
+
+@pytest.mark.parametrize("n,b,prec", [(100, 2, "fp16"), (301, 2, "fp16"), (300, 3, "fp16"), (64, 1, "fp32")])
+def test_forward_writes_inside_its_buffers_only(n, b, prec):
+    """Workspace and every output buffer between 1 MiB guard bands: the bands are intact after two forwards."""
+    net, st, args = _setup(n, b, prec)
+    G, guards = 1 << 20, {}
+
+    def guard(name, t):
+        nb = t.numel() * t.element_size()
+        big = torch.full((G + nb + G,), 0xAB, dtype=torch.uint8, device="cuda")
+        guards[name] = (big, nb)
+        return big[G:G + nb].view(t.dtype).view(t.shape)
+
+    setup = st.setup.clone()
+    st.ws = guard("ws", st.ws)
+    for nm in OUT + ("setup",):
+        setattr(st, nm, guard(nm, getattr(st, nm)))
+    st.setup.copy_(setup)
+    ca = guard("ca_out", torch.empty(b, n, 3, device="cuda"))
+    for _ in range(2):
+        st.forward(*args, ca_out=ca)
+    torch.cuda.synchronize()
+    for name, (big, nb) in guards.items():
+        assert bool((big[:G] == 0xAB).all()) and bool((big[G + nb:] == 0xAB).all()), f"write outside {name}"
+
+
+@pytest.mark.parametrize("n,b,prec", [(100, 2, "fp16"), (301, 2, "fp16"), (64, 1, "fp32")])
+def test_forward_independent_of_workspace_contents(n, b, prec):
+    """Same forward with the workspace pre-filled with zeros, 0xFF (NaN patterns) and random bytes: bit-identical outputs - the
+    forward reads nothing it did not write (pads and never-written slots are zeroed by the forward itself)."""
+    net, st, args = _setup(n, b, prec)
+    res = {}
+    for tag in ("zeros", "ff", "random", "zeros_again"):
+        if tag.startswith("zeros"):
+            st.ws.zero_()
+        elif tag == "ff":
+            st.ws.fill_(0xFF)
+        else:
+            st.ws.copy_(torch.randint(0, 256, (st.ws.numel(),), dtype=torch.uint8, device="cuda"))
+        st.forward(*args)
+        torch.cuda.synchronize()
+        res[tag] = {k: getattr(st, k).clone() for k in OUT}
+    for tag in ("ff", "random", "zeros_again"):
+        for k in OUT:
+            assert torch.equal(res[tag][k], res["zeros"][k]), (tag, k)

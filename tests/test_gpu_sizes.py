@@ -334,33 +334,3 @@ def test_per_module_entries_vs_oracle(prec, tol):
     _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, blk, B, N, _lib.ptr(node_in), keep[0].data_ptr(), _lib.ptr(z_in), _lib.ptr(z2), ws, wsb, sp))
     assert rel(z2.float().cpu().numpy(), et_ref) < tol, ("et", rel(z2.float().cpu().numpy(), et_ref))
     assert lib.fdipt_edge_transition_fwd(dm, pr, dr, 3, B, N, _lib.ptr(node_in), keep[0].data_ptr(), _lib.ptr(z_in), _lib.ptr(z2), ws, wsb, sp) == -1
-
-
-def test_streamed_sub_batches_equal_single_batch():
-    """inference.StreamedLoops (the batch as two sub-batches on two HIP streams, persistent pair kernels leaving CUs to the other
-    stream) returns exactly what one ReverseLoop over the whole batch returns."""
-    from framedipt_amd import config, inference, sharding
-    from framedipt_amd.diffusion import SE3Diffuser
-    from framedipt_amd.model import ScoreNetwork
-    from framedipt_amd.sampler import UnconditionalSampler
-    conf = config.base_config()
-    d = SE3Diffuser(conf.diffuser, device="cuda")
-    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
-    N, B, T = 100, 4, 6
-    ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": B}), d, "cuda")
-    feats, tape = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, T, 0.01) for i in range(B)])
-    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
-    one = inference.ReverseLoop(net, d, feats, **kw)
-    one.prime()
-    two = inference.StreamedLoops(net, d, feats, 2, **kw)
-    two.prime()
-    for k in range(T):
-        one.step(k)
-        two.step(k)
-    torch.cuda.synchronize()
-    ra, rb = one.results(), two.results()
-    assert sorted(ra) == sorted(rb)
-    for k in ra:
-        a, b = (x.cpu().numpy() if torch.is_tensor(x) else x for x in (ra[k], rb[k]))
-        assert a.shape == b.shape, k
-        np.testing.assert_array_equal(a, b, err_msg=k)

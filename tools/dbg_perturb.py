@@ -1,0 +1,43 @@
+"""Is a single forward reproducible while an unrelated memory-bound / compute-bound load runs on another stream?  (developer aid)"""
+import sys, torch, numpy as np
+sys.path.insert(0, '/root/repo')
+from framedipt_amd import config, sharding
+from framedipt_amd.diffusion import SE3Diffuser
+from framedipt_amd.model import ScoreNetwork
+from framedipt_amd.model.score_network import BatchState
+from framedipt_amd.sampler import UnconditionalSampler
+N, B, load = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+conf = config.base_config()
+d = SE3Diffuser(conf.diffuser, device="cuda")
+net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
+ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": B}), d, "cuda")
+feats, _ = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, 6, 0.01) for i in range(B)])
+st = BatchState(net, feats["seq_idx"], trace=True)
+t32, temb, sig = net.step_scalars(np.full(B, 0.5))
+f32 = lambda x: x.to(device="cuda", dtype=torch.float32).contiguous()
+args = (f32(feats["rigids_t"]), f32(feats["res_mask"]), f32(feats["fixed_mask"]), f32(feats["sc_ca_t"]) + 1.0, None,
+        f32(feats["torsion_angles_sin_cos"][..., 2, :]), torch.as_tensor(t32, device="cuda"), torch.as_tensor(temb, device="cuda"),
+        torch.as_tensor(sig, device="cuda"))
+s_fwd, s_load = torch.cuda.Stream(), torch.cuda.Stream()
+a, b = torch.empty(1 << 28, dtype=torch.uint8, device="cuda"), torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+m1, m2 = torch.randn(4096, 4096, device="cuda", dtype=torch.float16), torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+torch.cuda.synchronize()
+def fwd(loaded):
+    if loaded:
+        with torch.cuda.stream(s_load):
+            for _ in range(40):
+                if load == "copy": b.copy_(a)
+                elif load == "gemm": torch.matmul(m1, m2)
+                else: torch.cuda._sleep(2_000_000)
+    with torch.cuda.stream(s_fwd):
+        for _ in range(3): st.forward(*args)
+    torch.cuda.synchronize()
+    return st.trace_node.cpu().numpy().copy(), st.rigids.cpu().numpy().copy()
+ref = fwd(False)
+bad = 0
+for rep in range(15):
+    got = fwd(True)
+    dn = [float(np.abs(got[0][i] - ref[0][i]).max()) for i in range(5)]
+    if max(dn) > 0 or np.abs(got[1] - ref[1]).max() > 0:
+        bad += 1; print("rep", rep, "node diffs", dn)
+print("load", load, "N", N, "B", B, "bad", bad, "of 15")
