@@ -1,18 +1,23 @@
 #!/bin/bash
 # Collect the round's judged profiles on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/final/{kernel_stats.md,pmc_FETCH.md,pmc_WRITE.md,pmc_MFMA.md,bench.json,bench_fp32.json,bench_n128.json}
-# PMC passes are separate --pmc runs (never combined with sys/hip tracing), as MI355X_MICROARCH.md prescribes.
+#   gpurun_out/final/{bench*.json, kernel_stats.md, pmc_FETCH.md, pmc_WRITE.md, pmc_MFMA.md}
+# PMC passes are separate --pmc runs with --kernel-trace only (never combined with sys/hip tracing), as MI355X_MICROARCH.md
+# prescribes.  The kernel-stats run is the SAME command as the bench (whole trajectory), so that its EdgeTransition average agrees
+# with the HIP-event timing on the bench's JSON line.
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/final"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
-python "$ROOT/bench.py" --precision fp32 --steps 6 --warmup 2 --no-cpu-baseline > "$OUT/bench_fp32.json" 2>> "$OUT/bench.err"
-python "$ROOT/bench.py" --n-res 128 --no-cpu-baseline > "$OUT/bench_n128.json" 2>> "$OUT/bench.err"
-rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline --steps 20 > "$OUT/bench_prof.log" 2>&1
+for c in c2 c3 c5; do python "$ROOT/bench.py" --config $c --no-cpu-baseline > "$OUT/bench_$c.json" 2>> "$OUT/bench.err"; done
+python "$ROOT/bench.py" --precision fp32 --steps 6 --warmup 2 --no-cpu-baseline > "$OUT/bench_c4_fp32.json" 2>> "$OUT/bench.err"
+python "$ROOT/bench.py" --config c5 --precision fp16 --no-cpu-baseline > "$OUT/bench_c5_fp16.json" 2>> "$OUT/bench.err"
+python "$ROOT/bench.py" --kernel-flags 32 --no-cpu-baseline > "$OUT/bench_c4_nosplit.json" 2>> "$OUT/bench.err"
+python "$ROOT/bench.py" --samples-per-gpu 24 --no-cpu-baseline > "$OUT/bench_c4_b24.json" 2>> "$OUT/bench.err"
+rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_prof.log" 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
-[ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats.md"
+[ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats.md" > /dev/null
 for spec in "FETCH:FETCH_SIZE" "WRITE:WRITE_SIZE" "MFMA:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=${spec%%:*}; ctr=${spec#*:}
   rm -rf /tmp/prof_$tag

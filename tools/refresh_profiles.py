@@ -1,52 +1,118 @@
 #!/usr/bin/env python
-"""Turn gpurun_out/final/* (tools/collect_profiles.sh) into the committed artefacts under profiles/."""
-import json, os, re
+"""Turn gpurun_out/final/* (tools/collect_profiles.sh) into the committed round-2 artefacts under profiles/."""
+import json
+import os
+import re
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, P = os.path.join(ROOT, "gpurun_out", "final") + "/", os.path.join(ROOT, "profiles") + "/"
-def ctr(fn, name, kernel="edge_transition4_kernel"):
-    sec = None
-    for l in open(d + fn):
-        if l.startswith("## "): sec = l[3:].strip()
-        m = re.match(r"\| `(.+?)` \| (\d+) \| ([\d.]+) \|", l)
-        if m and sec == name and m.group(1).startswith(kernel): return float(m.group(3))
-    raise KeyError(name)
-fetch, write = ctr("pmc_FETCH.md", "FETCH_SIZE"), ctr("pmc_WRITE.md", "WRITE_SIZE")
-gui, busy = ctr("pmc_MFMA.md", "GRBM_GUI_ACTIVE"), ctr("pmc_MFMA.md", "SQ_VALU_MFMA_BUSY_CYCLES")
-open(P + "r01_final_bench_bf16_kernel_stats.md", "w").write(
-    "# Round 1 (final) — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 20` (1 x MI355X, bf16, N=300, B=8)\n\n"
-    "26 forwards (5 warm-up + 20 timed + priming); per-kernel totals over the whole process (prepare-time kernels included).\n\n" + open(d + "kernel_stats.md").read())
-hdr = f"""# Round 1 (final) — PMC counters of the bench command (MI355X, bf16, N=300, B=8)
 
-Collected in separate passes as MI355X_MICROARCH.md prescribes (never combined with sys/hip tracing; tools/collect_profiles.sh):
+
+def table(fn):
+    out, sec = {}, None
+    for line in open(d + fn):
+        if line.startswith("## "):
+            sec = line[3:].strip()
+        m = re.match(r"\| `(.+?)` \| (\d+) \| ([\d.]+) \|", line)
+        if m and sec:
+            out.setdefault(sec, {})[m.group(1)] = float(m.group(3))
+    return out
+
+
+F, W, M = table("pmc_FETCH.md")["FETCH_SIZE"], table("pmc_WRITE.md")["WRITE_SIZE"], table("pmc_MFMA.md")
+gui, busy = M["GRBM_GUI_ACTIVE"], M["SQ_VALU_MFMA_BUSY_CYCLES"]
+kst = {}
+for line in open(d + "kernel_stats.md"):
+    m = re.match(r"\| `(.+?)` \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", line)
+    if m:
+        kst[m.group(1)] = float(m.group(4))
+
+
+def key(tab, prefix):
+    return next(k for k in tab if k.startswith(prefix))
+
+
+ET, A3, OP, EE = "edge_transition4_kernel", "ipa_attn3_kernel", "opair_mfma_kernel", "edge_embed2_kernel"
+util = {k: busy[k] / 1024 / (gui[k] / 8) for k in busy if k in gui}
+et_f, et_w = F[ET] * 1024, W[ET] * 1024
+B, N = 8, 300
+z_bytes = B * N * N * 128 * 2
+bias_bytes = B * 8 * 320 * 320 * 4 / 1.0  # fragment-order pair bias, Np = 320
+alg_read, alg_write = z_bytes, z_bytes + B * 8 * N * N * 4
+bench = json.load(open(d + "bench.json"))
+et_us = kst[ET]
+
+open(P + "r02_bench_c4_fp16_kernel_stats.md", "w").write(
+    "# Round 2 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (1 x MI355X, config c4: fp16 mode, N=300, B=8)\n\n"
+    "The SAME command as the bench line in r02_bench.json (whole T = 500 trajectory: 5 warm-up steps on a scratch trajectory, priming\n"
+    "forward + 500 steps timed).  Per-kernel totals over the whole process (prepare-time kernels and the D2H of the trajectories,\n"
+    f"`__amd_rocclr_copyBuffer`, included).  edge_transition4_kernel: {et_us:.1f} us average here vs {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us\n"
+    "from the HIP events of the bench's timed region.\n\n" + open(d + "kernel_stats.md").read())
+
+hdr = f"""# Round 2 — PMC counters of the bench command (MI355X, config c4: fp16 mode, N=300, B=8)
+
+Separate passes as MI355X_MICROARCH.md prescribes (never combined with sys/hip tracing; tools/collect_profiles.sh):
 `rocprofv3 --kernel-trace --pmc <COUNTERS> --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline`
-(three passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE).  FETCH/WRITE are in KiB.
-gfx950 correction: HBM read bytes = 2 x FETCH_SIZE x 1024 for wide coalesced reads; WRITE_SIZE x 1024 calibrates exactly
-(edge_embed2_kernel writes 720,000 pair rows x 256 B = 184.3 MB of z plus 23 MB of pair bias: 203,818 KiB).
+(three passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE).  FETCH / WRITE are in KiB per dispatch.
+gfx950 correction (guide, HBM section): read bytes = 2 x FETCH_SIZE x 1024 for wide (16 B per lane) streaming reads; WRITE_SIZE x 1024
+calibrates as is.  Both calibrations re-checked on this run:
+* `opair_mfma_kernel` reads z exactly once (8 x 300^2 x 256 B = 184.3 MB) + the fp16 attention weights (12.3 MB) = 196.6 MB;
+  2 x FETCH = {2 * F[key(F, OP)] * 1024 / 1e6:.1f} MB.  The x2 correction is exact for this access pattern.
+* `edge_embed2_kernel` writes z (184.3 MB) + the fragment-order pair bias of block 0 (8 heads x 8 x 320^2 x 4 B = 26.2 MB, of which the
+  padded-key slots are not written: 23.0 MB) = 207.3 MB; WRITE = {W[key(W, EE)] * 1024 / 1e6:.1f} MB.
+
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) (GRBM_GUI_ACTIVE is summed over the 8 XCDs).
 
 ## edge_transition4_kernel (the roofline kernel of bench.py), per launch
-* SQ_VALU_MFMA_BUSY_CYCLES {busy:,.0f} = 22,500 wave patches x 536 MFMAs x 32 cycles, exactly (edge_transition3: 463.68 M).
-* GRBM_GUI_ACTIVE {gui:,.0f} summed over the 8 XCDs -> {gui/8/1e6:.3f} M cycles per launch; MFMA utilisation =
-  {busy/1e6:.2f} M / (1024 SIMDs x {gui/8/1e6:.3f} M) = **{busy/1024/(gui/8)*100:.1f} %** of executed matrix cycles (edge_transition3: 42.8 %), and the
-  executed cycles are 17 % fewer for the same result.
-* WRITE_SIZE {write:,.1f} KiB = {write*1024/1e6:.1f} MB: the algorithmic bytes (z' 184.3 MB + pair bias of the next block 23.0 MB = 207.4 MB).
-  FETCH_SIZE {fetch:,.1f} KiB -> 2 x = {2*fetch*1024/1e6:.1f} MB with the prescribed correction (z 184.3 MB + per-residue images and the
-  weight stream, which hit L2 / MALL); `roofline.traffic` = 2 x FETCH + WRITE = **{(2*fetch+write)*1024/1e6:.0f} MB** vs 397.7 MB algorithmic.
-* History of this number: the first edge_transition4 build had 18 spilled registers, and its counters were WRITE 293,012 /
-  FETCH 208,423 KiB: a spilled dword is 256 B of scratch per wave and tile = 5.8 MB of HBM writes per launch (plus the
-  reload), and a scratch reload or any other global load next to the inline-asm LDS-DMAs is a `vmcnt` wait that drains the
-  whole DMA queue.  Removing the spills (lane index from v_mbcnt, scalar wave index, 32-bit image offsets) and the in-loop
-  global loads (pair mask / linear_b bias from LDS) took WRITE to the algorithmic 207 MB and the launch from 0.343 to 0.30 ms.
+* SQ_VALU_MFMA_BUSY_CYCLES {busy[ET]:,.0f} = 22,500 wave patches x 536 MFMAs x 32 cycles (v_mfma_f32_32x32x16_f16 at the bf16 rate).
+* MFMA utilisation {util[ET] * 100:.1f} % of the launch's cycles (executed FLOPs 548,864 per pair; on the reference count of 688,128 per pair:
+  {bench['roofline']['frac'] * 100:.1f} % of the 2.5 PFLOP/s peak at the bench's {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us per launch).
+* WRITE {et_w / 1e6:.1f} MB against 207.3 MB algorithmic (z' 184.3 MB + pair bias of the next block 23.0 MB): +{(et_w / 207.36e6 - 1) * 100:.0f} %, no spill traffic.
+* FETCH: 2 x {et_f / 1e6:.1f} = {2 * et_f / 1e6:.1f} MB against 184.3 MB of z.  The x2 correction is right (see the o_pair calibration above), so
+  {2 * et_f / 1e6 - 184.3:.0f} MB per launch are real memory-side requests beyond z: the 512 KB weight stream of a 256-pair tile is consumed by
+  every CU once per tile (2813 tiles), and the z stream that passes through each 4 MB XCD L2 between two uses (32 CUs x (128 KB in +
+  145 KB out) = 8.7 MB per tile round) evicts it, so every XCD re-fetches the stream ~{(2 * et_f / 1e6 - 184.3) / 8 / 0.524:.0f} times per launch from the
+  Infinity Cache (these requests are counted by FETCH_SIZE although they never reach HBM: guide, "Infinity-Cache hits appear to be
+  counted").  The fold-row images (2.5 MB) are the rest.  HBM-side the launch moves the algorithmic 184 MB in / 207 MB out.
+* `roofline.traffic`: read {2 * et_f / 1e6:.0f} MB (memory-side, incl. {2 * et_f / 1e6 - 184.3:.0f} MB of Infinity-Cache hits) + write {et_w / 1e6:.0f} MB = {(2 * et_f + et_w) / 1e6:.0f} MB vs
+  {(alg_read + alg_write) / 1e6:.0f} MB algorithmic.
 
-"""
-open(P + "r01_final_pmc_bench_bf16.md", "w").write(hdr + open(d + "pmc_FETCH.md").read() + open(d + "pmc_WRITE.md").read() + open(d + "pmc_MFMA.md").read())
-traffic = (2 * fetch + write) * 1024
-json.dump({"kernel": "edge_transition4_kernel", "workload": {"precision": "bf16", "n_res": 300, "samples_per_gpu": 8},
-           "fetch_size_kib": fetch, "write_size_kib": write, "hbm_read_bytes": 2 * fetch * 1024, "hbm_write_bytes": write * 1024,
-           "traffic_bytes": traffic, "sq_valu_mfma_busy_cycles": busy, "grbm_gui_active_sum_xcd": gui,
-           "source": "profiles/r01_final_pmc_bench_bf16.md (rocprofv3 --pmc, separate passes, gfx950 FETCH x2 correction)"},
-          open(P + "r01_pmc_edge_transition.json", "w"), indent=1)
-lines = {k: json.loads(open(d + f).read()) for k, f in (("bf16_n300", "bench.json"), ("fp32_n300", "bench_fp32.json"), ("bf16_n128", "bench_n128.json"))}
-for v in lines.values():  # the bench read the previous round's traffic file: store the line with the counters of THIS collection
-    if v.get("roofline", {}).get("traffic"): v["roofline"]["traffic"] = traffic
-json.dump(lines, open(P + "r01_final_bench.json", "w"), indent=1)
-print({k: (round(v["value"]), round(v["ms_per_step"], 3)) for k, v in lines.items()}, "util", round(busy / 1024 / (gui / 8), 4), "traffic MB", round(traffic / 1e6))
+## ipa_attn3_kernel (IPA attention: QK^T + pair bias + point distances, softmax, P V, o_pt) — the north star's "MFMA utilisation on the
+attention GEMMs"
+* {kst[key(kst, A3)]:.1f} us per call (x4 per step); SQ_VALU_MFMA_BUSY_CYCLES {busy[key(busy, A3)]:,.0f}; MFMA utilisation
+  **{util[key(util, A3)] * 100:.1f} %**.  The kernel is latency-bound, not matrix-bound: 640 blocks (64 (sample, head) x 10 query tiles) run in one round at
+  three blocks per CU, each wave walks three key tiles whose K fragments (16 KB per tile) come straight from L2; 5.9 GF of MFMA work.
+* memory side: 2 x FETCH {2 * F[key(F, A3)] * 1024 / 1e6:.0f} MB, WRITE {W[key(W, A3)] * 1024 / 1e6:.0f} MB per call.
+
+## HBM-bound passes
+* `opair_mfma_kernel`: 196.8 MB in {kst[key(kst, OP)]:.1f} us = {2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6:.2f} TB/s ({2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6 / 8 * 100:.0f} % of the 8 TB/s peak, {2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6 / 6.3 * 100:.0f} % of the 6.3 TB/s achievable).
+* `edge_embed2_kernel`: 207 MB written in {kst[key(kst, EE)]:.1f} us = {W[key(W, EE)] * 1024 / kst[key(kst, EE)] / 1e6:.2f} TB/s; MFMA utilisation {util[key(util, EE)] * 100:.1f} % (47 GF): bound by neither,
+  its four-row table gather per pair (2 KB through L2 -> LDS) is the next thing to restructure.
+
+## MFMA utilisation of every kernel with matrix work
+| kernel | us per launch | MFMA busy cycles | utilisation |
+|---|---|---|---|
+""" + "".join(f"| `{k[:70]}` | {kst.get(k, float('nan')):.1f} | {busy[k]:,.0f} | {util[k] * 100:.1f} % |\n" for k in sorted(util, key=lambda k: -busy[k])) + "\n"
+open(P + "r02_pmc_bench_c4_fp16.md", "w").write(hdr + open(d + "pmc_FETCH.md").read() + open(d + "pmc_WRITE.md").read() + open(d + "pmc_MFMA.md").read())
+
+rec = {"kernel": ET, "workload": {"precision": "fp16", "n_res": N, "samples_per_gpu": B},
+       "fetch_size_kib": F[ET], "write_size_kib": W[ET], "read_bytes": 2 * et_f, "write_bytes": et_w, "traffic_bytes": 2 * et_f + et_w,
+       "algorithmic_bytes": alg_read + alg_write, "algorithmic_read_bytes": alg_read, "algorithmic_write_bytes": alg_write,
+       "infinity_cache_hit_read_bytes_estimate": 2 * et_f - alg_read,
+       "sq_valu_mfma_busy_cycles": busy[ET], "grbm_gui_active_sum_xcd": gui[ET], "mfma_utilisation": util[ET],
+       "ipa_attn3_mfma_utilisation": util[key(util, A3)],
+       "source": "profiles/r02_pmc_bench_c4_fp16.md (rocprofv3 --pmc, separate passes; gfx950 FETCH x2 correction, calibrated on o_pair)"}
+json.dump(rec, open(P + "r02_pmc_edge_transition.json", "w"), indent=1)
+
+lines = {}
+for tag, fn in (("c4_fp16_n300_b8", "bench.json"), ("c2_fp16_n128_b8", "bench_c2.json"), ("c3_fp16_n724_4chain_b5", "bench_c3.json"),
+                ("c5_fp32_n1000_b4", "bench_c5.json"), ("c5_shape_in_fp16", "bench_c5_fp16.json"), ("c4_fp32", "bench_c4_fp32.json"),
+                ("c4_fp16_without_split_operands", "bench_c4_nosplit.json"), ("c4_fp16_b24", "bench_c4_b24.json")):
+    if os.path.exists(d + fn):
+        lines[tag] = json.load(open(d + fn))
+        if tag.startswith("c4_fp16_n300") and lines[tag]["roofline"].get("traffic") is None:
+            lines[tag]["roofline"]["traffic"] = {"total": rec["traffic_bytes"], "read": rec["read_bytes"], "write": rec["write_bytes"],
+                                                 "algorithmic": rec["algorithmic_bytes"], "source": "profiles/r02_pmc_edge_transition.json"}
+json.dump(lines, open(P + "r02_bench.json", "w"), indent=1)
+print({k: (round(v["value"]), round(v["ms_per_step"], 3), round(v["roofline"]["whole_forward_frac"], 3)) for k, v in lines.items()})
+print("ET util", round(util[ET], 4), "attn3 util", round(util[key(util, A3)], 4), "traffic MB", round(rec["traffic_bytes"] / 1e6))
