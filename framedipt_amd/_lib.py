@@ -62,6 +62,8 @@ SIGNATURES = {
     "fdipt_se3_reverse_step": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P, _P]),
     "fdipt_se3_reverse_step_atoms": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P,
                                           _P, _P, _P, _P, _P]),
+    "fdipt_se3_reverse_step_traj": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P,
+                                         _P, _P, _P, _P, _P, _P, _P, _P]),
     "fdipt_quat_to_rot": (_i, [_i, _P, _P, _P]),
     "fdipt_rot_to_quat": (_i, [_i, _P, _P, _P]),
     "fdipt_quat_multiply": (_i, [_i, _P, _P, _P, _P]),

@@ -179,6 +179,10 @@ struct ReverseArgs {
   const int32_t* aatype;
   const BackboneTables* tables;
   float* atom37;
+  // optional trans_traj row of the trajectory (experiments/utils.py:390-400): diffuse_mask * trans(x_0 prediction) + fixed * trans(x_{t-1})
+  const float* pred_rigids;   // [B,N,7] x_0 prediction of this step's forward
+  const float* traj_fixed;    // [B,N] fixed_mask * res_mask
+  float* trans_traj;          // [B,N,3]
 };
 
 __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a) {
@@ -304,6 +308,10 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
     if (a.atom37) {
       const float tf[3] = {o[4], o[5], o[6]};
       d_backbone_residue(r, Rf, tf, a.psi, a.aatype, a.tables, a.atom37, nullptr);
+    }
+    if (a.trans_traj) {
+      const float dm = a.diffuse_mask ? a.diffuse_mask[r] : 1.f, fm = a.traj_fixed[r];
+      for (int c = 0; c < 3; ++c) a.trans_traj[r * 3 + c] = dm * a.pred_rigids[r * 7 + 4 + c] + fm * o[4 + c];
     }
   }
 }
@@ -871,7 +879,27 @@ int fdipt_se3_reverse_step_atoms(int B, int N, const float* rigids_t, const doub
   const int rpb = rigids_out == rigids_t ? N : 64;
   ReverseArgs a = {B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale, center,
                    diffuse_rot, diffuse_trans, so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling,
-                   rigids_out, out_rot, rpb, psi, aatype, (const BackboneTables*)tables, atom37};
+                   rigids_out, out_rot, rpb, psi, aatype, (const BackboneTables*)tables, atom37, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(reverse_step_kernel, dim3(cdiv(N, rpb), B), dim3(FD_THREADS), 0, (hipStream_t)stream, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_se3_reverse_step_traj(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
+                                const float* diffuse_mask, const double* z_rot, const double* z_trans, double t, double dt,
+                                double noise_scale, int center, int diffuse_rot, int diffuse_trans, double so3_min_sigma,
+                                double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
+                                float* rigids_out, float* out_rot, const float* psi, const int32_t* aatype,
+                                const void* tables, float* atom37, const float* pred_rigids, const float* traj_fixed_mask,
+                                float* trans_traj, fdipt_stream_t stream) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!rigids_t || !rot_score || !trans_score || !z_rot || !z_trans || !rigids_out || !(t >= 0 && t <= 1))
+    return FDIPT_EINVAL;
+  if (atom37 && (!psi || !tables || rigids_out == rigids_t)) return FDIPT_EINVAL;
+  if (trans_traj && (!pred_rigids || !traj_fixed_mask)) return FDIPT_EINVAL;
+  const int rpb = rigids_out == rigids_t ? N : 64;
+  ReverseArgs a = {B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale, center,
+                   diffuse_rot, diffuse_trans, so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling,
+                   rigids_out, out_rot, rpb, psi, aatype, (const BackboneTables*)tables, atom37, pred_rigids, traj_fixed_mask, trans_traj};
   hipLaunchKernelGGL(reverse_step_kernel, dim3(cdiv(N, rpb), B), dim3(FD_THREADS), 0, (hipStream_t)stream, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -114,9 +114,10 @@ class SE3Diffuser:
 
     # ------------------------------------------------------------------ reverse step
     def reverse_device(self, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, center=True,
-                       noise_scale=1.0, rigids_out=None, rot_out=None, atoms=None):
+                       noise_scale=1.0, rigids_out=None, rot_out=None, atoms=None, traj=None):
         """Device-resident reverse step on tensor_7 frames [B,N,7]; noise given (N(0,1), float64).
-        ``atoms=(psi, aatype, bb_tables, atom37)``: also compute_backbone of x_{t-1} in the same launch."""
+        ``atoms=(psi, aatype, bb_tables, atom37)``: also compute_backbone of x_{t-1} in the same launch.
+        ``traj=(pred_rigids, fixed_mask * res_mask, trans_traj_row)``: also the step's trans_traj row (utils.py:390-400)."""
         lib = _lib.load()
         _lib.require_cuda(rigids_t, "reverse")
         B, N = rigids_t.shape[0], rigids_t.shape[1]
@@ -124,23 +125,24 @@ class SE3Diffuser:
             rigids_out = torch.empty_like(rigids_t)
         so3, r3 = self._so3_diffuser, self._r3_diffuser
         psi, aatype, tables, atom37 = atoms if atoms is not None else (None, None, None, None)
-        for x in (rot_score, trans_score, diffuse_mask, z_rot, z_trans, rigids_out, rot_out, psi, aatype, tables, atom37):
+        pred, tfix, ttraj = traj if traj is not None else (None, None, None)
+        for x in (rot_score, trans_score, diffuse_mask, z_rot, z_trans, rigids_out, rot_out, psi, aatype, tables, atom37, pred, tfix, ttraj):
             if x is not None and x.device != rigids_t.device:
                 raise _lib.FdiptError(f"reverse: tensors on different devices ({rigids_t.device} and {x.device})")
         with torch.cuda.device(rigids_t.device):
             self._reverse_launch(lib, B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale,
-                                 center, rigids_out, rot_out, psi, aatype, tables, atom37)
+                                 center, rigids_out, rot_out, psi, aatype, tables, atom37, pred, tfix, ttraj)
         return rigids_out
 
     def _reverse_launch(self, lib, B, N, rigids_t, rot_score, trans_score, diffuse_mask, z_rot, z_trans, t, dt, noise_scale, center,
-                        rigids_out, rot_out, psi, aatype, tables, atom37):
+                        rigids_out, rot_out, psi, aatype, tables, atom37, pred, tfix, ttraj):
         so3, r3 = self._so3_diffuser, self._r3_diffuser
-        _lib.check(lib.fdipt_se3_reverse_step_atoms(
+        _lib.check(lib.fdipt_se3_reverse_step_traj(
             B, N, _lib.ptr(rigids_t), _lib.ptr(rot_score), _lib.ptr(trans_score), _lib.ptr(diffuse_mask),
             _lib.ptr(z_rot), _lib.ptr(z_trans), float(t), float(dt), float(noise_scale), int(bool(center)),
             int(bool(self._diffuse_rot)), int(bool(self._diffuse_trans)), so3.min_sigma, so3.max_sigma, r3.min_b, r3.max_b,
             r3._r3_conf.coordinate_scaling, _lib.ptr(rigids_out), _lib.ptr(rot_out), _lib.ptr(psi), _lib.ptr(aatype),
-            _lib.ptr(tables), _lib.ptr(atom37), _lib.stream_ptr()), "se3_reverse_step")
+            _lib.ptr(tables), _lib.ptr(atom37), _lib.ptr(pred), _lib.ptr(tfix), _lib.ptr(ttraj), _lib.stream_ptr()), "se3_reverse_step")
         return rigids_out
 
     def reverse(self, rigid_t: Rigid, rot_score, trans_score, t: float, dt: float, diffuse_mask=None,

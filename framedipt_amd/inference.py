@@ -48,7 +48,7 @@ class ReverseLoop:
         B, N = self.B, self.N = rig0.shape[0], rig0.shape[1]
         f32 = lambda x: x.to(device=dev, dtype=torch.float32).contiguous().clone()  # noqa: E731
         self.res_mask, self.fixed = f32(data_init["res_mask"]), f32(data_init["fixed_mask"])
-        self.fixed_mask = self.fixed * self.res_mask
+        self.fixed_mask = (self.fixed * self.res_mask).contiguous()
         self.diffuse_mask = ((1 - self.fixed) * self.res_mask).contiguous()
         # two aatype views, as in the reference: the network pre-processes with ITS OWN flags (score_network.py:226-232:
         # self.inpainting / model_conf.input_aatype), the atom37 frames of the trajectory with inference_fn's arguments
@@ -87,7 +87,8 @@ class ReverseLoop:
         # the forward itself hands the predicted CA positions to the next step's self-conditioning input (read at its start,
         # written at its end: no copy kernel)
         self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all[k],
-                        self.temb_all[k], self.sig_all[k], want_atoms, ca_out=self.sc_ca if sc_update else None)
+                        self.temb_all[k], self.sig_all[k], want_atoms, ca_out=self.sc_ca if sc_update else None,
+                        atom37_out=self.bb0_traj[k] if want_atoms else None)  # rigid_0_traj row: straight into its slot
 
     def prime(self):
         """Self-conditioning priming call (utils.py:571-578)."""
@@ -107,16 +108,15 @@ class ReverseLoop:
                 self.diffuser.reverse_device(self.rigids_t, st.rot_score, st.trans_score, self.diffuse_mask,
                                              self.z_rot[self.noisy], self.z_trans[self.noisy], t, self.dt, self.center,
                                              self.noise_scale, rigids_out=nxt,
-                                             atoms=(st.psi, self.aatype, self.model.bb_tables, self.prot_traj[k]))
+                                             atoms=(st.psi, self.aatype, self.model.bb_tables, self.prot_traj[k]),
+                                             traj=(st.rigids, self.fixed_mask, self.trans_traj[k]) if self.aux_traj else None)
                 self.noisy += 1
             else:  # last step: take the x_0 prediction, utils.py:373-374
                 nxt.copy_(st.rigids)
                 _backbone(self.model, n, nxt, None, None, st.psi, self.aatype, self.prot_traj[k])
+                if self.aux_traj:  # (on the other steps the reverse-step launch writes this row)
+                    self.trans_traj[k] = self.diffuse_mask[..., None] * st.rigids[..., 4:] + self.fixed_mask[..., None] * nxt[..., 4:]
             self.rigids_t = nxt
-            if self.aux_traj:
-                self.bb0_traj[k] = st.atom37
-                self.trans_traj[k] = (self.diffuse_mask[..., None] * st.rigids[..., 4:]
-                                      + self.fixed_mask[..., None] * self.rigids_t[..., 4:])
 
     def results(self, return_device=False):
         st = self.st

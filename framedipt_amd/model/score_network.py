@@ -80,7 +80,7 @@ class BatchState:
                                          device=dev)
 
     def forward(self, rigids_t, res_mask, fixed_mask, sc_ca_t, aatype, gt_psi, t_dev, t_emb_dev, sigma_dev,
-                want_atoms: bool = True, ca_out=None):
+                want_atoms: bool = True, ca_out=None, atom37_out=None):
         """All arguments are device tensors (float32 unless noted); outputs land in this state's buffers.
         ``ca_out`` ([B,N,3], may be ``sc_ca_t`` itself) receives the predicted CA positions for the next step."""
         lib = _lib.load()
@@ -92,7 +92,7 @@ class BatchState:
                           ("t", t_dev), ("t_emb", t_emb_dev), ("t_emb_eps", self.t_emb_eps), ("so3_sigma", sigma_dev),
                           ("bb_tables", net.bb_tables), ("psi", self.psi), ("rot_score", self.rot_score),
                           ("trans_score", self.trans_score), ("rigids", self.rigids),
-                          ("atom37", self.atom37 if want_atoms else None), ("atom14", self.atom14 if want_atoms else None),
+                          ("atom37", (self.atom37 if atom37_out is None else atom37_out) if want_atoms else None), ("atom14", self.atom14 if want_atoms else None),
                           ("trace_node", self.trace_node), ("trace_edge", self.trace_edge), ("trace_inner", self.trace_inner),
                           ("ca_out", ca_out)):
             setattr(a, name, _lib.ptr(tns))

@@ -196,6 +196,17 @@ int fdipt_se3_reverse_step_atoms(int B, int N, const float* rigids_t, const doub
                                  float* rigids_out, float* out_rot, const float* psi, const int32_t* aatype,
                                  const void* tables, float* atom37, fdipt_stream_t stream);
 
+/* ... and the step's row of trans_traj (experiments/utils.py:390-400) from the same launch:
+ * trans_traj[b,i] = diffuse_mask * trans(pred_rigids) + traj_fixed_mask * trans(x_{t-1}); pred_rigids [B,N,7] = the forward's x_0
+ * prediction, traj_fixed_mask [B,N] = fixed_mask * res_mask.  trans_traj == NULL: exactly fdipt_se3_reverse_step_atoms. */
+int fdipt_se3_reverse_step_traj(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
+                                const float* diffuse_mask, const double* z_rot, const double* z_trans, double t, double dt,
+                                double noise_scale, int center, int diffuse_rot, int diffuse_trans, double so3_min_sigma,
+                                double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
+                                float* rigids_out, float* out_rot, const float* psi, const int32_t* aatype,
+                                const void* tables, float* atom37, const float* pred_rigids, const float* traj_fixed_mask,
+                                float* trans_traj, fdipt_stream_t stream);
+
 /* ---------------------------------------------------------------- frame algebra (a8) ------- */
 /* openfold/utils/rigid_utils.py free functions and Rigid/Rotation methods, n independent items, f32. */
 int fdipt_quat_to_rot(int n, const float* quat, float* rot, fdipt_stream_t s);           /* :185 */
