@@ -64,6 +64,9 @@ SIGNATURES = {
                                           _P, _P, _P, _P, _P]),
     "fdipt_se3_reverse_step_traj": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fdipt_se3_forward_step": (_i, [_i, _i, _P, _P, _P, _P, _P, _d, _d, _d, _d, _d, _d, _d, _d, _P, _P, _P, _P]),
+    "fdipt_se3_step_log_prob": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _d, _d, _d, _d, _P, _P]),
+    "fdipt_se3_prior_log_prob": (_i, [_i, _i, _P, _P, _d, _P, _P]),
     "fdipt_quat_to_rot": (_i, [_i, _P, _P, _P]),
     "fdipt_rot_to_quat": (_i, [_i, _P, _P, _P]),
     "fdipt_quat_multiply": (_i, [_i, _P, _P, _P, _P]),

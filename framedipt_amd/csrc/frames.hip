@@ -933,3 +933,208 @@ int fdipt_backbone_atoms(int n, const float* t7, const float* rot, const float* 
   return fd_backbone(n, t7, rot, trans, 3, psi, aatype, tables, atom37, atom14, (hipStream_t)s);
 }
 }  // extern "C"
+
+// ------------------------------------------------------------------ EigenFold confidence score
+// experiments/utils.py:752-869 walks x_0 -> x_T with one-step forward noising and sums log p(x_{t-1} | x_t) - log q(x_t | x_{t-1}).
+// The state between steps is what the reference carries: float32 rotation matrices + float32 translations (se3_diffuser.py:26-36),
+// all arithmetic in between is float64 (NumPy on the host there).
+struct SdeConsts { double so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, cs; };
+__device__ __forceinline__ double d_g_rot(const SdeConsts& k, double t) {  // so3_diffuser.py:299-319
+  const double emax = exp(k.so3_max_sigma), emin = exp(k.so3_min_sigma);
+  const double sig = log(t * emax + (1 - t) * emin);
+  return sqrt(2 * (emax - emin) * sig / exp(sig));
+}
+__device__ __forceinline__ double d_b_t(const SdeConsts& k, double t) { return k.r3_min_b + t * (k.r3_max_b - k.r3_min_b); }  // r3:48-62
+__device__ __forceinline__ void d_matmul3(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+// transforms.compose_rotvec (framedipt/data/transforms.py:33-46)
+__device__ __forceinline__ void d_compose_rotvec(const double* r1, const double* r2, double* out) {
+  double R1[9], R2[9], Rc[9];
+  d_so3_exp(r1, R1);
+  d_so3_exp(r2, R2);
+  d_matmul3(R1, R2, Rc);
+  d_so3_log(Rc, out);
+}
+// so3_diffuser.py:99-119 align_rotation_vectors
+__device__ __forceinline__ void d_align_rotvec(const double* in, const double* target, double* out) {
+  const double ang = sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]);
+  const double tn = sqrt(target[0] * target[0] + target[1] * target[1] + target[2] * target[2]);
+  const double ax[3] = {in[0] / ang, in[1] / ang, in[2] / ang};
+  const double dot = (target[0] / tn) * ax[0] + (target[1] / tn) * ax[1] + (target[2] / tn) * ax[2];
+  const double sign = dot > 0 ? 1.0 : (dot < 0 ? -1.0 : dot);  // np.sign (0 and NaN pass through)
+  const double new_ang = sign > 0 ? ang : 2 * M_PI - ang;
+  for (int c = 0; c < 3; ++c) out[c] = ax[c] * sign * new_ang;
+}
+// torch.distributions.Normal(mu, std).log_prob(x)
+__device__ __forceinline__ double d_normal_logp(double x, double mu, double std) {
+  const double d = x - mu;
+  return -(d * d) / (2 * std * std) - log(std) - 0.91893853320467274178;  // log(sqrt(2 pi))
+}
+__device__ __forceinline__ void d_rot32_log(const float* R32, double* rv) {  // se3_diffuser.py:16-23 on a float32 matrix
+  double R[9];
+  for (int c = 0; c < 9; ++c) R[c] = (double)R32[c];
+  d_so3_log(R, rv);
+}
+
+// SE3Diffuser.forward (se3_diffuser.py:50-95; r3_diffuser.py:122-161 with center=False; so3_diffuser.py:408-443)
+__global__ void se3_forward_step_kernel(long n, const float* __restrict__ rot_1, const float* __restrict__ trans_1,
+                                        const float* __restrict__ mask, const double* __restrict__ z_rot,
+                                        const double* __restrict__ z_trans, double t_1, double dt, double noise_scale, SdeConsts k,
+                                        float* __restrict__ rot_out, float* __restrict__ trans_out, float* __restrict__ t7_out) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const bool has_mask = mask != nullptr;
+  const double m = has_mask ? (double)mask[r] : 1.0;
+  const double sdt = sqrt(dt), bt = d_b_t(k, t_1), g_tr = sqrt(bt), g_rot = d_g_rot(k, t_1);
+  float tr[3];
+  for (int c = 0; c < 3; ++c) {
+    const double x0 = (double)trans_1[r * 3 + c];
+    const double x = x0 * k.cs;
+    double pert = (-0.5 * bt * x) * dt + g_tr * sdt * (noise_scale * z_trans[r * 3 + c]);
+    if (has_mask) pert *= m;
+    const double xt = (x + pert) / k.cs;
+    tr[c] = (float)(has_mask ? m * xt + (1 - m) * x0 : xt);
+  }
+  double rv1[3], pert[3], rvt[3], Ro[9];
+  d_rot32_log(rot_1 + r * 9, rv1);
+  for (int c = 0; c < 3; ++c) {
+    pert[c] = g_rot * sdt * (noise_scale * z_rot[r * 3 + c]);
+    if (has_mask) pert[c] *= m;
+  }
+  d_compose_rotvec(rv1, pert, rvt);
+  if (has_mask)
+    for (int c = 0; c < 3; ++c) rvt[c] = m * rvt[c] + (1 - m) * rv1[c];
+  d_so3_exp(rvt, Ro);
+  float Rf[9];
+  for (int c = 0; c < 9; ++c) Rf[c] = (float)Ro[c];
+  for (int c = 0; c < 9; ++c) rot_out[r * 9 + c] = Rf[c];
+  for (int c = 0; c < 3; ++c) trans_out[r * 3 + c] = tr[c];
+  if (t7_out) {  // Rigid.to_tensor_7 (rot_to_quat up to sign, as in the reverse step)
+    double Rd[9], q[4];
+    for (int c = 0; c < 9; ++c) Rd[c] = (double)Rf[c];
+    d_markley(Rd, q);
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    float* o = t7_out + r * 7;
+    o[0] = (float)q[3]; o[1] = (float)q[0]; o[2] = (float)q[1]; o[3] = (float)q[2];
+    o[4] = tr[0]; o[5] = tr[1]; o[6] = tr[2];
+  }
+}
+
+// One block per sample: out[b] = {log p backward (trans, rot), log q forward (trans, rot)} summed over the diffused residues
+// (se3_diffuser.py:97-196, r3_diffuser.py:163-260, so3_diffuser.py:466-567, r3_utils.py:10-42).  scores == nullptr: forward terms only.
+__global__ __launch_bounds__(FD_THREADS) void se3_step_log_prob_kernel(int N, const float* __restrict__ rot_t, const float* __restrict__ trans_t,
+                                                                        const float* __restrict__ rot_1, const float* __restrict__ trans_1,
+                                                                        const double* __restrict__ rot_score, const float* __restrict__ trans_score,
+                                                                        const float* __restrict__ mask, double t, double t_1, double dt,
+                                                                        SdeConsts k, double* __restrict__ out) {
+  __shared__ double red[4][FD_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double sdt = sqrt(dt);
+  const double bt = d_b_t(k, t), bt1 = d_b_t(k, t_1), g_rot = d_g_rot(k, t), g_rot1 = d_g_rot(k, t_1);
+  double acc[4] = {0, 0, 0, 0};
+  for (int i = tid; i < N; i += FD_THREADS) {
+    const long r = (long)b * N + i;
+    const double m = mask ? (double)mask[r] : 1.0;
+    if (mask && mask[r] == 0.f) continue;  // torch.masked_select(log_p, mask.bool())
+    // ---- translations (scaled coordinates)
+    for (int c = 0; c < 3; ++c) {
+      const double xt = (double)trans_t[r * 3 + c] * k.cs, x1 = (double)trans_1[r * 3 + c] * k.cs;
+      if (trans_score) {  // p(x_{t-1} | x_t): r3_diffuser.py:163-191, 227-260 (mask as bool)
+        const double f = -0.5 * bt * xt, g2 = bt;
+        const double mu = xt - (f - g2 * (double)trans_score[r * 3 + c]) * dt;
+        acc[0] += d_normal_logp(x1, mu, sqrt(bt) * sdt);
+      }
+      const double muf = (x1 + (-0.5 * bt1 * x1) * dt) * m;  // q(x_t | x_{t-1}): r3_diffuser.py:193-225
+      acc[2] += d_normal_logp(xt, muf, sqrt(bt1) * sdt);
+    }
+    // ---- rotations (rotation vectors of the float32 matrices)
+    double rvt[3], rv1[3], al[3];
+    d_rot32_log(rot_t + r * 9, rvt);
+    d_rot32_log(rot_1 + r * 9, rv1);
+    if (rot_score) {  // so3_diffuser.py:497-567
+      double drift[3], mu[3];
+      for (int c = 0; c < 3; ++c) drift[c] = g_rot * g_rot * rot_score[r * 3 + c] * dt * m;
+      d_compose_rotvec(rvt, drift, mu);
+      d_align_rotvec(rv1, mu, al);
+      for (int c = 0; c < 3; ++c) acc[1] += d_normal_logp(al[c], mu[c], g_rot * sdt);
+    }
+    d_align_rotvec(rvt, rv1, al);  // so3_diffuser.py:466-495
+    for (int c = 0; c < 3; ++c) acc[3] += d_normal_logp(al[c], rv1[c], g_rot1 * sdt);
+  }
+  for (int q = 0; q < 4; ++q) {
+    const double s = wave_sum_d(acc[q]);
+    if (lane == 0) red[q][wave] = s;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    double s = 0;
+    for (int w = 0; w < FD_THREADS / 64; ++w) s += red[tid][w];
+    out[b * 4 + tid] = s;
+  }
+}
+
+// Terminal term of logp_confidence_score (experiments/utils.py:846-866): standard-normal log density of the scaled x_T translations
+// (float32 there) over the diffused residues + log(1 / pi^2) per diffused residue.  out[b] = {trans, rot}
+__global__ __launch_bounds__(FD_THREADS) void se3_prior_log_prob_kernel(int N, const float* __restrict__ trans_T, const float* __restrict__ mask,
+                                                                         float cs, double* __restrict__ out) {
+  __shared__ double red[2][FD_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double a0 = 0, a1 = 0;
+  for (int i = tid; i < N; i += FD_THREADS) {
+    const long r = (long)b * N + i;
+    if (mask && mask[r] == 0.f) continue;
+    for (int c = 0; c < 3; ++c) {
+      const float x = trans_T[r * 3 + c] * cs;
+      a0 += (double)(-(x * x) / 2.f - 0.91893853320467274178f);
+    }
+    a1 += mask ? (double)mask[r] : 1.0;
+  }
+  a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
+  if (lane == 0) { red[0][wave] = a0; red[1][wave] = a1; }
+  __syncthreads();
+  if (tid == 0) {
+    double s0 = 0, s1 = 0;
+    for (int w = 0; w < FD_THREADS / 64; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
+    out[b * 2] = s0;
+    out[b * 2 + 1] = log(1.0 / (M_PI * M_PI)) * s1;
+  }
+}
+
+extern "C" {
+int fdipt_se3_forward_step(int B, int N, const float* rot_t_1, const float* trans_t_1, const float* diffuse_mask, const double* z_rot,
+                           const double* z_trans, double t_1, double dt, double noise_scale, double so3_min_sigma, double so3_max_sigma,
+                           double r3_min_b, double r3_max_b, double coordinate_scaling, float* rot_t, float* trans_t, float* rigids_t,
+                           fdipt_stream_t stream) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!rot_t_1 || !trans_t_1 || !z_rot || !z_trans || !rot_t || !trans_t || !(t_1 >= 0 && t_1 <= 1)) return FDIPT_EINVAL;
+  const long n = (long)B * N;
+  const SdeConsts k = {so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling};
+  hipLaunchKernelGGL(se3_forward_step_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, n, rot_t_1, trans_t_1, diffuse_mask,
+                     z_rot, z_trans, t_1, dt, noise_scale, k, rot_t, trans_t, rigids_t);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_se3_step_log_prob(int B, int N, const float* rot_t, const float* trans_t, const float* rot_t_1, const float* trans_t_1,
+                            const double* rot_score, const float* trans_score, const float* diffuse_mask, double t, double t_1, double dt,
+                            double so3_min_sigma, double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
+                            double* out, fdipt_stream_t stream) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!rot_t || !trans_t || !rot_t_1 || !trans_t_1 || !out || (rot_score == nullptr) != (trans_score == nullptr)) return FDIPT_EINVAL;
+  const SdeConsts k = {so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling};
+  hipLaunchKernelGGL(se3_step_log_prob_kernel, dim3(B), dim3(FD_THREADS), 0, (hipStream_t)stream, N, rot_t, trans_t, rot_t_1, trans_t_1,
+                     rot_score, trans_score, diffuse_mask, t, t_1, dt, k, out);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+int fdipt_se3_prior_log_prob(int B, int N, const float* trans_T, const float* diffuse_mask, double coordinate_scaling, double* out,
+                             fdipt_stream_t stream) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!trans_T || !out) return FDIPT_EINVAL;
+  hipLaunchKernelGGL(se3_prior_log_prob_kernel, dim3(B), dim3(FD_THREADS), 0, (hipStream_t)stream, N, trans_T, diffuse_mask,
+                     (float)coordinate_scaling, out);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+}  // extern "C"

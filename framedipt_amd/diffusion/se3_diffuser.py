@@ -172,6 +172,90 @@ class SE3Diffuser:
             torch.as_tensor(z_trans, device=dev).reshape(B, N, 3).contiguous(), t, dt, center, noise_scale, rot_out=rot_out)
         return Rigid(Rotation(rot_mats=rot_out.reshape(*lead, N, 3, 3)), out[..., 4:].reshape(*lead, N, 3))
 
+    # ------------------------------------------------------------------ forward noising + log-probabilities (EigenFold confidence)
+    def _consts(self):
+        so3, r3 = self._so3_diffuser, self._r3_diffuser
+        return so3.min_sigma, so3.max_sigma, r3.min_b, r3.max_b, r3._r3_conf.coordinate_scaling
+
+    @staticmethod
+    def _state_of(rigid: Rigid):
+        """(rot float32 [B,N,3,3], trans float32 [B,N,3], lead shape) of a Rigid shaped [N] or [B,N]."""
+        rot, trans = rigid.get_rots().get_rot_mats().float(), rigid.get_trans().float()
+        _lib.require_cuda(rot, "SE3Diffuser")
+        lead, N = rot.shape[:-3], rot.shape[-3]
+        B = int(np.prod(lead)) if len(lead) else 1
+        return rot.reshape(B, N, 3, 3).contiguous(), trans.reshape(B, N, 3).contiguous(), lead
+
+    @staticmethod
+    def _mask_of(diffuse_mask, B, N, dev):
+        if diffuse_mask is None:
+            return None
+        m = diffuse_mask.detach().cpu().numpy() if torch.is_tensor(diffuse_mask) else np.asarray(diffuse_mask)
+        return torch.as_tensor(np.broadcast_to(m.astype(np.float32).reshape(-1, N), (B, N)).copy(), device=dev)
+
+    def forward_device(self, rot_1, trans_1, diffuse_mask, z_rot, z_trans, t_1, dt, noise_scale=1.0, rot_out=None, trans_out=None,
+                       rigids_out=None):
+        """One-step forward noising on device state (rot [B,N,3,3], trans [B,N,3] float32; noise N(0,1) float64)."""
+        lib = _lib.load()
+        _lib.require_cuda(rot_1, "forward")
+        B, N = rot_1.shape[0], rot_1.shape[1]
+        rot_out = torch.empty_like(rot_1) if rot_out is None else rot_out
+        trans_out = torch.empty_like(trans_1) if trans_out is None else trans_out
+        with torch.cuda.device(rot_1.device):
+            _lib.check(lib.fdipt_se3_forward_step(B, N, _lib.ptr(rot_1), _lib.ptr(trans_1), _lib.ptr(diffuse_mask), _lib.ptr(z_rot),
+                                                  _lib.ptr(z_trans), float(t_1), float(dt), float(noise_scale), *self._consts(),
+                                                  _lib.ptr(rot_out), _lib.ptr(trans_out), _lib.ptr(rigids_out), _lib.stream_ptr()),
+                       "se3_forward_step")
+        return rot_out, trans_out
+
+    def forward(self, rigids_t_1: Rigid, t_1: float, dt: float, diffuse_mask=None, chain_indices=None) -> Rigid:
+        """se3_diffuser.py:50-95: samples q(x_t | x_{t-1}).  Noise from the global ``np.random`` stream in the reference order
+        (R^3 draw, then SO(3) draw)."""
+        rot, trans, lead = self._state_of(rigids_t_1)
+        B, N = rot.shape[:2]
+        z_trans = np.random.normal(size=(*lead, N, 3))
+        z_rot = np.random.normal(size=(*lead, N, 3))
+        dev = rot.device
+        ro, to = self.forward_device(rot, trans, self._mask_of(diffuse_mask, B, N, dev),
+                                     torch.as_tensor(z_rot, device=dev).reshape(B, N, 3), torch.as_tensor(z_trans, device=dev).reshape(B, N, 3),
+                                     t_1, dt)
+        return Rigid(Rotation(rot_mats=ro.reshape(*lead, N, 3, 3)), to.reshape(*lead, N, 3))
+
+    def step_log_prob_device(self, rot_t, trans_t, rot_1, trans_1, rot_score, trans_score, diffuse_mask, t, t_1, dt, out=None):
+        """[B,4] float64: log p_trans, log p_rot (backward, needs the scores at t), log q_trans, log q_rot (forward) of one step."""
+        lib = _lib.load()
+        B, N = rot_t.shape[0], rot_t.shape[1]
+        out = torch.zeros(B, 4, dtype=torch.float64, device=rot_t.device) if out is None else out
+        with torch.cuda.device(rot_t.device):
+            _lib.check(lib.fdipt_se3_step_log_prob(B, N, _lib.ptr(rot_t), _lib.ptr(trans_t), _lib.ptr(rot_1), _lib.ptr(trans_1),
+                                                   _lib.ptr(rot_score), _lib.ptr(trans_score), _lib.ptr(diffuse_mask), float(t), float(t_1),
+                                                   float(dt), *self._consts(), _lib.ptr(out), _lib.stream_ptr()), "se3_step_log_prob")
+        return out
+
+    def _log_prob(self, rigids_t, rigids_t_1, rot_score, trans_score, t, t_1, dt, diffuse_mask, cols):
+        rot_t, trans_t, lead = self._state_of(rigids_t)
+        rot_1, trans_1, _ = self._state_of(rigids_t_1)
+        B, N = rot_t.shape[:2]
+        dev = rot_t.device
+        if rot_score is not None:
+            rot_score = torch.as_tensor(np.asarray(rot_score.detach().cpu() if torch.is_tensor(rot_score) else rot_score),
+                                        dtype=torch.float64).reshape(B, N, 3).to(dev).contiguous()
+            trans_score = torch.as_tensor(np.asarray(trans_score.detach().cpu() if torch.is_tensor(trans_score) else trans_score),
+                                          dtype=torch.float32).reshape(B, N, 3).to(dev).contiguous()
+        out = self.step_log_prob_device(rot_t, trans_t, rot_1, trans_1, rot_score, trans_score, self._mask_of(diffuse_mask, B, N, dev),
+                                        t, t_1, dt).cpu().numpy()
+        lp = out[:, cols[0]] + out[:, cols[1]]
+        return float(lp[0]) if not len(lead) else lp.reshape(lead)
+
+    def log_prob_forward(self, rigids_t: Rigid, rigids_t_1: Rigid, t_1: float, dt: float, diffuse_mask=None, chain_indices=None):
+        """se3_diffuser.py:97-144: log q(x_t | x_{t-1}) summed over the diffused residues (per sample for batched input)."""
+        return self._log_prob(rigids_t, rigids_t_1, None, None, t_1, t_1, dt, diffuse_mask, (2, 3))
+
+    def log_prob_backward(self, rigids_t: Rigid, rigids_t_1: Rigid, trans_score_t, rot_score_t, t: float, dt: float, diffuse_mask,
+                          chain_indices=None):
+        """se3_diffuser.py:146-196: log p(x_{t-1} | x_t) under the scores at time t."""
+        return self._log_prob(rigids_t, rigids_t_1, rot_score_t, trans_score_t, t, t, dt, diffuse_mask, (0, 1))
+
     # ------------------------------------------------------------------ x_T
     def sample_ref(self, n_samples: int, chain_index=None, impute: Rigid | None = None, diffuse_mask=None,
                    as_tensor_7: bool = False):

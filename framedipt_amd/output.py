@@ -152,6 +152,18 @@ def save_diffusion_info(output_dir, pdb_name: str, seq: str, diffused_mask, chai
         f.write("\t".join(["pdb_name", "seq", "chain", "start", "end"]) + "\n" + "\t".join(row) + "\n")
 
 
+def save_confidence(diffusion_info_path, sample_dir, sample_i: int, log_p: float, log_probs, diffused_region_len) -> None:
+    """What ``run_conditional_sampling`` does with an EigenFold score (experiments/inference.py:357-372): three ``log_p_sample_<i>*``
+    columns appended to ``diffusion_info.csv`` (re-written through pandas, which adds its index column, as there) and
+    ``<sample_dir>/log_probs.csv``."""
+    import pandas as pd
+    cols = {f"log_p_sample_{sample_i}": log_p,
+            f"log_p_sample_{sample_i}_per_residue": log_p / diffused_region_len,
+            f"log_p_sample_{sample_i}_per_residue_norm": log_p / (6 * diffused_region_len - 1)}
+    pd.read_csv(diffusion_info_path, sep="\t").assign(**cols).to_csv(diffusion_info_path, sep="\t")
+    pd.DataFrame({"log_probs": list(log_probs)}).to_csv(pathlib.Path(sample_dir) / "log_probs.csv")
+
+
 def aatype_to_seq(aatype) -> str:
     """framedipt/data/utils.py:74-83."""
     return "".join((RESTYPES + "X")[int(a)] for a in aatype)

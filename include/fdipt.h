@@ -207,6 +207,27 @@ int fdipt_se3_reverse_step_traj(int B, int N, const float* rigids_t, const doubl
                                 const void* tables, float* atom37, const float* pred_rigids, const float* traj_fixed_mask,
                                 float* trans_traj, fdipt_stream_t stream);
 
+/* ---------------------------------------------------------------- EigenFold confidence score (f4) */
+/* SE3Diffuser.forward: one-step forward noising q(x_t | x_{t-1}) (framedipt/diffusion/se3_diffuser.py:50-95; r3_diffuser.py:122-161
+ * with center=False; so3_diffuser.py:408-443).  State = what the reference carries between steps: float32 rotation matrices
+ * rot [B,N,3,3] and translations trans [B,N,3] in Angstrom; z_* are N(0,1) draws (float64); diffuse_mask [B,N] or NULL.
+ * rigids_t (optional, [B,N,7]) receives Rigid.to_tensor_7 of the result (the next forward's input). */
+int fdipt_se3_forward_step(int B, int N, const float* rot_t_1, const float* trans_t_1, const float* diffuse_mask, const double* z_rot,
+                           const double* z_trans, double t_1, double dt, double noise_scale, double so3_min_sigma, double so3_max_sigma,
+                           double r3_min_b, double r3_max_b, double coordinate_scaling, float* rot_t, float* trans_t, float* rigids_t,
+                           fdipt_stream_t stream);
+/* SE3Diffuser.log_prob_backward / log_prob_forward (se3_diffuser.py:97-196; r3_diffuser.py:163-260; so3_diffuser.py:99-119,466-567;
+ * r3_utils.py:10-42) of one step, summed over the diffused residues of each sample in float64:
+ * out[b] = { log p_trans(x_{t-1}|x_t), log p_rot(x_{t-1}|x_t), log q_trans(x_t|x_{t-1}), log q_rot(x_t|x_{t-1}) }.
+ * rot_score [B,N,3] float64 / trans_score [B,N,3] float32 are the model's scores at time t; both NULL: forward terms only. */
+int fdipt_se3_step_log_prob(int B, int N, const float* rot_t, const float* trans_t, const float* rot_t_1, const float* trans_t_1,
+                            const double* rot_score, const float* trans_score, const float* diffuse_mask, double t, double t_1, double dt,
+                            double so3_min_sigma, double so3_max_sigma, double r3_min_b, double r3_max_b, double coordinate_scaling,
+                            double* out, fdipt_stream_t stream);
+/* Terminal term of logp_confidence_score (experiments/utils.py:846-866): out[b] = { sum log N(0,1)(scaled trans_T), log(1/pi^2) * n_diffused } */
+int fdipt_se3_prior_log_prob(int B, int N, const float* trans_T, const float* diffuse_mask, double coordinate_scaling, double* out,
+                             fdipt_stream_t stream);
+
 /* ---------------------------------------------------------------- frame algebra (a8) ------- */
 /* openfold/utils/rigid_utils.py free functions and Rigid/Rotation methods, n independent items, f32. */
 int fdipt_quat_to_rot(int n, const float* quat, float* rot, fdipt_stream_t s);           /* :185 */

@@ -246,6 +246,64 @@ def writer_goldens():
     print("writers", list(g["pdb_names"]), len(g["pdb_sample"]), "bytes", flush=True)
 
 
+def confidence_golden(name, cfg, n, inpainting, num_t, min_t=0.01):
+    """EigenFold confidence walk (experiments/utils.py:752-869) of the reference with every per-step quantity captured: the noise
+    tape, the frames after each forward-noising step, the model's scores and the two log-probabilities."""
+    from experiments import utils as exp_utils
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + 7)
+    diff, model, _ = mg.build(cfg, inpainting)
+    np.random.seed(321)
+    f = mg.make_feats(n, rng, inpainting, diff)
+    g = mg.feats_np(f)
+    q = mg.rand_quats(rng, n)[::-1].copy()  # generic rotations first; (an identity rotation makes the reference itself fail:
+    q[-9:] = q[:9]                          #  align_rotation_vectors divides by the angle) -> replace the edge-case rows
+    q[3] = mg.rand_quats(rng, 9)[5]         # ... but keep one angle ~ pi - 1e-7
+    tr = np.cumsum(rng.standard_normal((n, 3)) * 2.2, axis=0).astype(np.float32)
+    tr -= tr.mean(0)
+    x0 = np.concatenate([q, tr], -1).astype(np.float32)
+    dm = 1.0 - f["fixed_mask"][0].numpy()
+    tape, steps = [], []
+    orig_normal = np.random.normal
+
+    def rec_normal(*a, **k):
+        z = orig_normal(*a, **k)
+        tape.append(z.copy())
+        return z
+
+    o_fwd, o_lpb, o_lpf = diff.forward, diff.log_prob_backward, diff.log_prob_forward
+
+    def rec_fwd(**kw):
+        out = o_fwd(**kw)
+        steps.append({"t_1": kw["t_1"], "rot": np32(out.get_rots().get_rot_mats()), "trans": np32(out.get_trans())})
+        return out
+
+    def rec_lpb(**kw):
+        v = o_lpb(**kw)
+        steps[-1].update(t=kw["t"], trans_score=np.asarray(kw["trans_score_t"]), rot_score=np.asarray(kw["rot_score_t"]), lp_backward=float(v))
+        return v
+
+    def rec_lpf(**kw):
+        v = o_lpf(**kw)
+        steps[-1]["lp_forward"] = float(v)
+        return v
+
+    diff.forward, diff.log_prob_backward, diff.log_prob_forward = rec_fwd, rec_lpb, rec_lpf
+    np.random.normal = rec_normal
+    try:
+        lp, lps = exp_utils.logp_confidence_score(model=model, diffuser=diff, rigids_t=ru.Rigid.from_tensor_7(torch.tensor(x0)),
+                                                   sample_feats={k: v.clone() for k, v in f.items()}, diffuse_mask=dm, num_t=num_t,
+                                                   min_t=min_t, device="cpu", self_condition=True)
+    finally:
+        np.random.normal = orig_normal
+    g.update(weight_seed=mg.WEIGHT_SEED, bb_gain=W.BB_GAIN, x0=x0, diffuse_mask=dm, num_t=num_t, min_t=min_t, log_prob=float(lp), log_probs=np.array([float(v) for v in lps]),
+             noise_tape=np.stack(tape))  # [2 (T-1), N, 3]: R^3 draw then SO(3) draw per step
+    for k in ("t_1", "t", "rot", "trans", "trans_score", "rot_score", "lp_backward", "lp_forward"):
+        g["step_" + k] = np.stack([np.asarray(s[k]) for s in steps])
+    g["score_dtypes"] = np.array([str(steps[0]["trans_score"].dtype), str(steps[0]["rot_score"].dtype)])
+    np.savez_compressed(os.path.join(HERE, f"conf_{name}.npz"), **g)
+    print(name, "log_prob", lp, "dtypes", g["score_dtypes"], flush=True)
+
+
 def denovo(n):
     return lambda rng, diff: mg.make_feats(n, rng, False, diff)
 
@@ -267,6 +325,8 @@ JOBS = {
         lambda rng, diff: complex_feats((500, 500), ((40, 90),), rng, diff), trace_rows=(0, 60, 999)),
     "traj_full_denovo_n300_T5": lambda: mg.traj_golden("full_denovo_n300_T5", rh.load_cfg(), 300, False, 5),
     "traj_full_denovo_n64_T20_gain03": lambda: traj_golden_gain("full_denovo_n64_T20_gain03", rh.load_cfg(), 64, 20, 0.3),
+    "conf_small_denovo_n24_T6": lambda: confidence_golden("small_denovo_n24_T6", rh.small_model_cfg(rh.load_cfg()), 24, False, 6),
+    "conf_full_inpaint_n40_T5": lambda: confidence_golden("full_inpaint_n40_T5", rh.load_cfg(inpainting=True), 40, True, 5),
     "sampler_dicts": sampler_goldens,
     "ops_r2": ops_r2_goldens,
     "writers": writer_goldens,

@@ -213,6 +213,13 @@ def test_output_writers_byte_equal_reference_files(tmp_path):
     assert paths["traj_path"].read_bytes() == bytes(G["pdb_traj"])
     with pytest.raises(ValueError):
         output.write_prot_to_pdb(pos[0, :, :5], tmp_path / "bad")
+    # EigenFold columns (experiments/inference.py:357-372): same pandas round trip as the reference
+    import pandas as pd
+    output.save_confidence(tmp_path / "diffusion_info.csv", tmp_path, 2, -130.5, [-1.0, -2.5], int(dm.sum()))
+    df = pd.read_csv(tmp_path / "diffusion_info.csv", sep="\t")
+    assert df["log_p_sample_2"][0] == -130.5 and df["log_p_sample_2_per_residue"][0] == -130.5 / dm.sum()
+    assert df["log_p_sample_2_per_residue_norm"][0] == -130.5 / (6 * dm.sum() - 1) and df["pdb_name"][0] == "1abc"
+    assert list(pd.read_csv(tmp_path / "log_probs.csv")["log_probs"]) == [-1.0, -2.5]
 
 
 _FAKE_OMEGACONF = '''
