@@ -140,10 +140,24 @@ class ConditionalSampler(torch.utils.data.Dataset):
         metadata_path = download_dir / "processed" / "metadata.csv"
         data_path = getattr(self.data_conf, "data_path", None)
         self.pdb_csv = pd.read_csv(data_path) if data_path and os.path.exists(str(data_path)) else None
-        if not metadata_path.exists():
-            raise _lib.FdiptError(
-                f"{metadata_path} not found: downloading / parsing mmCIF files (process_pdb_dataset.process_serially of the "
-                "reference) is data preparation outside the sampler hot path; run it once and point download_dir here")
+        # sampler.py:189-222: the mmCIF files under <download_dir>/cifs (downloading them is the caller's job: no network access
+        # is attempted) are parsed into processed pickles + metadata.csv unless that file exists already
+        cifs = sorted((download_dir / "cifs").glob("*.cif"))
+        if self.pdb_csv is not None and "pdb_id" in self.pdb_csv:
+            ids = set(self.pdb_csv["pdb_id"].astype(str))
+            cifs = [c for c in cifs if c.stem[:4] in ids]
+        self.pdb_files = cifs
+        if not metadata_path.exists() or getattr(self.data_conf, "overwrite", False):
+            if not cifs:
+                raise _lib.FdiptError(f"neither {metadata_path} nor mmCIF files under {download_dir / 'cifs'}: fetch the structures "
+                                      "first (data_utils.download_cifs of the reference; this package makes no network access)")
+            from .data import mmcif
+            g = lambda k: getattr(self.data_conf, k, None)  # noqa: E731
+            rows = mmcif.process_serially(cifs, download_dir / "processed", self.get_chains_to_process(), max_len=g("max_len"),
+                                          min_len=g("min_len"), chain_max_len=g("chain_max_len"), chain_min_len=g("chain_min_len"),
+                                          max_num_chains=g("max_num_chains"))
+            (download_dir / "processed").mkdir(parents=True, exist_ok=True)
+            pd.DataFrame(rows).to_csv(metadata_path, index=False)
         md = pd.read_csv(metadata_path)
         if self.pdb_csv is not None and "pdb_id" in self.pdb_csv:
             keep = set(self.pdb_csv["pdb_id"].astype(str))
@@ -158,12 +172,10 @@ class ConditionalSampler(torch.utils.data.Dataset):
         path = str(self.metadata[example_idx]["processed_path"])
         if path.endswith(".npz"):
             return dict(np.load(path, allow_pickle=False))
-        import pickle
-        with open(path, "rb") as f:
-            feats = pickle.load(f)
-        if "rigidgroups_0" not in feats and "rigids_0" not in feats:
-            from .data import features
-            feats = features.process_csv_row(feats)  # raw parsed structure (atom_positions, ...) -> per-residue features
+        from .data import features
+        feats = features.read_pkl(path)
+        if "rigidgroups_0" not in feats and "rigids_0" not in feats:  # a processed-structure pickle (sampler.py:284-289)
+            feats = features.process_csv_row(feats, process_monomer=False, extract_single_chain=False, rng=self.rng)
         return feats
 
     def create_diffusion_mask(self, chain_feats, example_idx: int) -> np.ndarray:
@@ -209,7 +221,9 @@ class ConditionalSampler(torch.utils.data.Dataset):
                                                 diffuse_mask=diffused_mask, as_tensor_7=True)
         chain_feats.update(diff_feats_t)
         chain_feats["t"] = 1.0
-        final = {k: v if torch.is_tensor(v) else torch.tensor(np.asarray(v)) for k, v in chain_feats.items()}
+        # (torch.tensor of a Python float is float32, of a NumPy array the array's dtype: tree.map_structure in sampler.py:341-344)
+        final = {k: v if torch.is_tensor(v) else torch.tensor(v if isinstance(v, (float, int)) else np.asarray(v))
+                 for k, v in chain_feats.items()}
         final = pad_feats(final, int(row["modeled_seq_len"]))
         return row["pdb_name"], sample_idx, {k: v[None].to(self.device) for k, v in final.items()}
 
@@ -254,7 +268,8 @@ class TCRSampler(ConditionalSampler):
             pdb_id = pdb_file.stem if hasattr(pdb_file, "stem") else str(pdb_file)
             if getattr(self.data_conf, "first_assembly", False):
                 pdb_id = pdb_id[:4]
-            ex = self.pdb_csv[self.pdb_csv["pdb_id"] == pdb_id].iloc[0]
+            hit = self.pdb_csv[self.pdb_csv["pdb_id"] == pdb_id]
+            ex = (hit if len(hit) else self.pdb_csv[self.pdb_csv["pdb_id"] == pdb_id[:4]]).iloc[0]
             chains = [ex["tcr_alpha_chain"], ex["tcr_beta_chain"]]
             for col in ("peptide_chain", "mhc_alpha_chain", "mhc_beta_chain"):
                 if col in ex and ex[col] is not None and isinstance(ex[col], str):

@@ -142,7 +142,33 @@ def sampler_goldens():
         for k, v in feats.items():
             g[f"uncond_{i}_{k}"] = v.numpy()
             g[f"uncond_{i}_{k}_dtype"] = np.array(str(v.dtype))
+    # ConditionalSampler item (sampler.py:267-354) on a processed-structure pickle of the reference's own test complex 1fyt (its
+    # processed features are the inputs stored in features.npz); metadata handed over directly (no download / Biopython here)
+    import pathlib
+    import pickle
+    import tempfile
+    import pandas as pd
+    F = dict(np.load(os.path.join(HERE, "features.npz")))
+    cf = {k[len("1fyt_in_"):]: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in F.items() if k.startswith("1fyt_in_")}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = pathlib.Path(td) / "1fyt.pkl"
+        with open(pkl, "wb") as f:
+            pickle.dump(cf, f)
+        n_mod = int(np.sum(cf["max_modeled_idxs"] - cf["min_modeled_idxs"] + 1))
+        cs = rs.ConditionalSampler.__new__(rs.ConditionalSampler)
+        cs._data_conf = rh.to_attr({"samples": 2, "seed": 123, "redaction": {"redact_min_len": 8, "redact_max_len": 14}})
+        cs.metadata = pd.DataFrame([{"pdb_name": "1fyt-assembly1", "processed_path": str(pkl), "modeled_seq_len": n_mod}])
+        np.random.seed(77)
+        cs._diffuser, cs.device, cs.diffused_masks, cs.rng = diff, "cpu", {}, np.random.default_rng(123)
+        with torch.no_grad():
+            name, sample_id, feats = cs[1]
+    g["cond_meta"] = np.array([name, str(sample_id), str(n_mod)])
+    for k, v in feats.items():
+        v = v.numpy()
+        g[f"cond_{k}"] = v.astype(np.float32) if (v.dtype == np.float64 and v.size > 5000) else v
+        g[f"cond_{k}_dtype"] = np.array(str(v.dtype))
     np.savez_compressed(os.path.join(HERE, "sampler_dicts.npz"), **g)
+    print("sampler_dicts cond", name, sample_id, n_mod, int((1 - feats["fixed_mask"]).sum()), flush=True)
     print("sampler_dicts", sorted(k for k in g if k.startswith("uncond_0_") and not k.endswith("_dtype")), flush=True)
 
 
@@ -304,6 +330,80 @@ def confidence_golden(name, cfg, n, inpainting, num_t, min_t=0.01):
     print(name, "log_prob", lp, "dtypes", g["score_dtypes"], flush=True)
 
 
+def feature_tables():
+    """Residue-constant index tables of the feature builder (framedipt_amd/data/feature_tables.npz), from
+    openfold/np/residue_constants.py the way openfold/data/data_transforms.py:572-645,755-800,891-920 derive them."""
+    from openfold.np import residue_constants as rc
+    from openfold.data import data_transforms as dt
+    base = np.full([21, 8, 3], "", dtype=object)
+    base[:, 0, :] = ["C", "CA", "N"]
+    base[:, 3, :] = ["CA", "C", "O"]
+    gmask = np.zeros((21, 8))
+    gmask[:, 0] = gmask[:, 3] = 1
+    gmask[:20, 4:] = rc.chi_angles_mask
+    for r, letter in enumerate(rc.restypes):
+        for c in range(4):
+            if rc.chi_angles_mask[r][c]:
+                base[r, c + 4, :] = rc.chi_angles_atoms[rc.restype_1to3[letter]][c][1:]
+    lut = dict(rc.atom_order)
+    lut[""] = 0
+    a14_37, a37_14, a14_mask = [], [], []
+    for rt in rc.restypes:
+        names = rc.restype_name_to_atom14_names[rc.restype_1to3[rt]]
+        a14_37.append([(rc.atom_order[n] if n else 0) for n in names])
+        i14 = {n: i for i, n in enumerate(names)}
+        a37_14.append([i14.get(n, 0) for n in rc.atom_types])
+        a14_mask.append([1.0 if n else 0.0 for n in names])
+    a14_37.append([0] * 14); a37_14.append([0] * 37); a14_mask.append([0.0] * 14)
+    a37_mask = np.zeros((21, 37))
+    for r, letter in enumerate(rc.restypes):
+        for n in rc.residue_atoms[rc.restype_1to3[letter]]:
+            a37_mask[r, rc.atom_order[n]] = 1
+    out = {
+        "atom_types": np.array(rc.atom_types), "restype_3": np.array([rc.restype_1to3[r] for r in rc.restypes]),
+        "rigidgroup_base_atom37_idx": np.vectorize(lambda x: lut[x])(base).astype(np.int64), "rigidgroup_mask": gmask,
+        "atom14_to_atom37": np.array(a14_37, dtype=np.int64), "atom37_to_atom14": np.array(a37_14, dtype=np.int64),
+        "atom14_mask": np.array(a14_mask), "atom37_mask": a37_mask,
+        "chi_atom_indices": np.array(dt.get_chi_atom_indices(), dtype=np.int64),
+        "chi_angles_mask": np.array(list(rc.chi_angles_mask) + [[0.0] * 4]), "chi_pi_periodic": np.array(rc.chi_pi_periodic),
+    }
+    np.savez_compressed(os.path.join(mg.ROOT, "framedipt_amd", "data", "feature_tables.npz"), **out)
+    print("feature_tables", {k: v.shape for k, v in out.items()}, flush=True)
+
+
+def feature_builder_golden():
+    """process_csv_row of the reference (framedipt/data/utils.py:745-890) on the three complexes of the reference's own test data
+    (tests/data/inference_data/structures/cifs): the processed-structure dict is read from the mmCIF by framedipt_amd.data.mmcif
+    (Biopython is not installed here) and stored with the outputs.  One all-chains row per structure + one single-chain row with a cut."""
+    import pathlib
+    import pickle
+    import tempfile
+    from framedipt.data import utils as du
+    from framedipt_amd.data import mmcif
+    cif_dir = pathlib.Path("/root/reference/tests/data/inference_data/structures/cifs")
+    g = {}
+    for cif in sorted(cif_dir.glob("*.cif")):
+        name = cif.stem[:4]
+        _, _, _, cf = mmcif.extract_features_from_mmcif(cif)
+        for k, v in cf.items():
+            g[f"{name}_in_{k}"] = v.astype(np.float32) if k in ("atom_positions", "b_factors", "bb_positions") else v
+        cf = {k: (g[f"{name}_in_{k}"].astype(np.float64) if v.dtype.kind == "f" else v) for k, v in cf.items()}
+        with tempfile.TemporaryDirectory() as td:
+            p = pathlib.Path(td) / f"{name}.pkl"
+            with open(p, "wb") as f:
+                pickle.dump(cf, f)
+            out = du.process_csv_row(p, False, False, None, None)
+            rng = np.random.default_rng(11)
+            one = du.process_csv_row(p, False, True, rng, 150)
+        for tag, o in (("all", out), ("one", one)):
+            for k, v in o.items():
+                v = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+                g[f"{name}_{tag}_{k}"] = v.astype(np.float32) if (v.dtype == np.float64 and k in ("atom37_pos", "atom14_pos")) else v
+                g[f"{name}_{tag}_{k}_dtype"] = np.array(str(v.dtype))
+        print(name, "N", len(out["aatype"]), "chains", len(np.unique(out["chain_idx"])), "single-chain N", len(one["aatype"]), flush=True)
+    np.savez_compressed(os.path.join(HERE, "features.npz"), **g)
+
+
 def denovo(n):
     return lambda rng, diff: mg.make_feats(n, rng, False, diff)
 
@@ -327,6 +427,8 @@ JOBS = {
     "traj_full_denovo_n64_T20_gain03": lambda: traj_golden_gain("full_denovo_n64_T20_gain03", rh.load_cfg(), 64, 20, 0.3),
     "conf_small_denovo_n24_T6": lambda: confidence_golden("small_denovo_n24_T6", rh.small_model_cfg(rh.load_cfg()), 24, False, 6),
     "conf_full_inpaint_n40_T5": lambda: confidence_golden("full_inpaint_n40_T5", rh.load_cfg(inpainting=True), 40, True, 5),
+    "feature_tables": feature_tables,
+    "features": feature_builder_golden,
     "sampler_dicts": sampler_goldens,
     "ops_r2": ops_r2_goldens,
     "writers": writer_goldens,

@@ -113,3 +113,84 @@ def test_confidence_batch_matches_single():
     for b in range(2):
         assert lp[b] == single[b][0]
         np.testing.assert_array_equal(lps[:, b], np.array(single[b][1]))
+
+
+def test_conditional_sampler_from_processed_pickle_matches_reference(tmp_path):
+    """ConditionalSampler(data_conf, diffuser, device) on a processed-structure pickle of the TCR-pMHC complex 1fyt (the reference's
+    own test data): metadata.csv -> process_csv_row (row f2) -> redaction -> sample_ref -> padding, vs the item captured from the
+    reference sampler (tests/golden/make_goldens_r2.py sampler_goldens): keys, dtypes, shapes, values."""
+    import pickle
+
+    import pandas as pd
+
+    from framedipt_amd import config
+    from framedipt_amd import rigid as R
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.sampler import ConditionalSampler
+    S, F = load_golden("sampler_dicts.npz"), load_golden("features.npz")
+    cf = {k[len("1fyt_in_"):]: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in F.items() if k.startswith("1fyt_in_")}
+    (tmp_path / "processed").mkdir()
+    with open(tmp_path / "processed" / "1fyt.pkl", "wb") as f:
+        pickle.dump(cf, f)
+    pd.DataFrame([{"pdb_name": str(S["cond_meta"][0]), "processed_path": str(tmp_path / "processed" / "1fyt.pkl"),
+                   "modeled_seq_len": int(S["cond_meta"][2])}]).to_csv(tmp_path / "processed" / "metadata.csv", index=False)
+    d = SE3Diffuser(config.base_config(inpainting=True).diffuser, device="cuda")
+    ds = ConditionalSampler(config.to_conf({"download_dir": str(tmp_path), "samples": 2, "seed": 123,
+                                            "redaction": {"redact_min_len": 8, "redact_max_len": 14}}), d, "cuda")
+    np.random.seed(77)
+    name, sample_id, feats = ds[1]
+    assert (name, str(sample_id)) == (str(S["cond_meta"][0]), str(S["cond_meta"][1]))
+    keys = sorted(k[5:] for k in S if k.startswith("cond_") and not k.endswith("_dtype") and k != "cond_meta")
+    assert sorted(feats) == keys
+    for k in keys:
+        ref = S[f"cond_{k}"]
+        assert str(feats[k].dtype) == "torch." + str(S[f"cond_{k}_dtype"]), (k, feats[k].dtype)
+        assert tuple(feats[k].shape) == ref.shape, k
+        v = feats[k].cpu().numpy()
+        if k in ("rigids_t", "rigids_0"):
+            np.testing.assert_allclose(R.quat_to_rot(feats[k][0, :, :4].float()).cpu().numpy(),
+                                       R.quat_to_rot(dev(ref[0, :, :4])).cpu().numpy(), atol=3e-6, err_msg=k)
+            np.testing.assert_allclose(v[..., 4:], ref[..., 4:], atol=2e-5, err_msg=k)
+        elif v.dtype.kind in "iu":
+            np.testing.assert_array_equal(v, ref, err_msg=k)
+        else:
+            np.testing.assert_allclose(v, ref, rtol=1e-6, atol=2e-6, err_msg=k)
+    assert int((1 - feats["fixed_mask"]).sum()) == 50  # five chains, one redacted loop each
+
+
+def test_inpainting_on_real_complex_keeps_the_motif(tmp_path):
+    """BASELINE config 1 / 3 in miniature: redesign loops of the TCR-pMHC complex 1fyt (N = 810, 5 chains) for 4 reverse steps in the
+    fp16 mode: motif frames stay put, the redesigned residues move and stay finite, per-chain seq_idx gaps reach the network."""
+    import pickle
+
+    import pandas as pd
+
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.inference import inference_fn
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import ConditionalSampler
+    F = load_golden("features.npz")
+    cf = {k[len("1fyt_in_"):]: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in F.items() if k.startswith("1fyt_in_")}
+    (tmp_path / "processed").mkdir()
+    with open(tmp_path / "processed" / "1fyt.pkl", "wb") as f:
+        pickle.dump(cf, f)
+    pd.DataFrame([{"pdb_name": "1fyt-assembly1", "processed_path": str(tmp_path / "processed" / "1fyt.pkl"), "modeled_seq_len": 810}]
+                 ).to_csv(tmp_path / "processed" / "metadata.csv", index=False)
+    conf = config.base_config(inpainting=True)
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, inpainting=True, precision="fp16")
+    net.load_synthetic(7).to("cuda")
+    ds = ConditionalSampler(config.to_conf({"download_dir": str(tmp_path), "samples": 1, "seed": 123,
+                                            "redaction": {"redact_min_len": 8, "redact_max_len": 14}}), d, "cuda")
+    np.random.seed(5)
+    _, _, feats = ds[0]
+    assert int(feats["seq_idx"].max()) >= 810 + 4 * 200 - 1
+    out = inference_fn(net, d, feats, num_t=4, min_t=0.01, aux_traj=True, inpainting=True, embed_self_conditioning=True)
+    fixed = feats["fixed_mask"][0].bool().cpu().numpy()
+    x0, xT = out["rigid_traj"][0][0], out["rigid_traj"][-1][0]
+    assert np.isfinite(out["prot_traj"]).all()
+    np.testing.assert_allclose(x0[fixed, 4:], feats["rigids_0"][0, fixed, 4:].cpu().numpy(), atol=1e-4)
+    assert np.abs(x0[~fixed, 4:] - xT[~fixed, 4:]).max() > 0.1
+    ca = out["prot_traj"][0][0][:, 1]
+    np.testing.assert_allclose(ca[fixed], feats["atom37_pos"][0, fixed, 1].cpu().numpy(), atol=2e-3)

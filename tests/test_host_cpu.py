@@ -293,3 +293,82 @@ torch.save({{"model": {{"module." + k: torch.tensor(v) for k, v in sd.items()}},
     checkpoint.main([str(tmp_path / "ckpt.pth"), str(tmp_path / "out")])
     z = np.load(tmp_path / "out.npz")
     assert sorted(z.files) == sorted(ref) and (tmp_path / "out.yaml").exists()
+
+
+@pytest.mark.parametrize("name", ["1fyt", "5ksa", "7t2d"])
+def test_feature_builder_vs_reference_process_csv_row(name):
+    """framedipt_amd.data.features.process_csv_row (row f2) vs the reference's on the complexes of the reference's own test data
+    (tests/golden/features.npz): all chains, and one randomly extracted chain cut to 150 residues (same Generator stream)."""
+    from framedipt_amd.data import features
+    G = load_golden("features.npz")
+    pre = f"{name}_in_"
+    cf = {k[len(pre):]: (G[k].astype(np.float64) if G[k].dtype.kind == "f" else G[k]) for k in G if k.startswith(pre)}
+    for tag, kw in (("all", {}), ("one", {"extract_single_chain": True, "rng": np.random.default_rng(11), "chain_max_len": 150})):
+        out = features.process_csv_row(dict(cf), **kw)
+        ref = {k[len(f"{name}_{tag}_"):]: G[k] for k in G if k.startswith(f"{name}_{tag}_") and not k.endswith("_dtype")}
+        assert set(out) == set(ref)
+        for k, v in out.items():
+            assert str(v.dtype) == str(G[f"{name}_{tag}_{k}_dtype"]), (k, v.dtype)
+            if v.dtype.kind in "iu":
+                np.testing.assert_array_equal(v, ref[k], err_msg=k)
+            elif k == "rigidgroups_0":
+                # float32 frames from float64 Gram-Schmidt; groups whose base atoms are missing are degenerate in both
+                np.testing.assert_allclose(v, ref[k], atol=2e-6, err_msg=k)
+            elif k == "torsion_angles_sin_cos":
+                np.testing.assert_allclose(v, ref[k], atol=2e-6, err_msg=k)
+            else:
+                np.testing.assert_allclose(v, ref[k], rtol=1e-6, atol=1e-6, err_msg=k)
+
+
+def test_mmcif_reader_on_synthetic_file(tmp_path):
+    """framedipt_amd.data.mmcif on a hand-written _atom_site loop: author chain ids, insertion codes, alternate locations by
+    occupancy, second model ignored, hetero residues -> X, waters at the chain end trimmed from the modelled range, quoted names."""
+    from framedipt_amd.data import features, mmcif
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "label_seq_id",
+            "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy", "B_iso_or_equiv", "auth_seq_id", "auth_asym_id",
+            "pdbx_PDB_model_num"]
+    rows, n = [], [0]
+
+    def atom(grp, name, alt, comp, seq, ins, xyz, occ, chain, model=1):
+        n[0] += 1
+        nm = f'"{name}"' if "'" in name else name
+        rows.append(f"{grp} {n[0]} C {nm} {alt} {comp} Z {seq} {ins} {xyz[0]} {xyz[1]} {xyz[2]} {occ} 10.0 {seq} {chain} {model}")
+
+    for i, comp in enumerate(["MSE", "ALA", "GLY", "LYS"]):  # MSE: non-standard -> X at the start (trimmed)
+        for j, a in enumerate(["N", "CA", "C", "O"]):
+            atom("HETATM" if comp == "MSE" else "ATOM", a, ".", comp, 10 + i, "?", (i * 3.8 + j, j, 0.5), 1.0, "b")
+    atom("ATOM", "CB", "A", "ALA", 11, "?", (1.0, 2.0, 3.0), 0.4, "b")
+    atom("ATOM", "CB", "B", "ALA", 11, "?", (9.0, 9.0, 9.0), 0.6, "b")      # higher occupancy wins
+    atom("ATOM", "CA", ".", "SER", 12, "A", (5.0, 5.0, 5.0), 1.0, "b")      # insertion code: its own residue
+    atom("HETATM", "O", ".", "HOH", 201, "?", (0.0, 0.0, 0.0), 1.0, "b")    # water at the end
+    atom("ATOM", "O5'", ".", "DA", 1, "?", (0.0, 0.0, 0.0), 1.0, "C")       # nucleotide chain: no modelled residue -> dropped
+    atom("ATOM", "CA", ".", "ALA", 10, "?", (7.0, 7.0, 7.0), 1.0, "b", model=2)
+    p = tmp_path / "1abc-assembly1.cif"
+    p.write_text("data_1ABC\n#\n_entry.id 1ABC\n#\nloop_\n" + "".join(f"_atom_site.{c}\n" for c in cols) + "\n".join(rows) + "\n#\n")
+    num_chains, lens, mlens, cf = mmcif.extract_features_from_mmcif(p)
+    assert num_chains == 2 and lens == [6] and mlens == [4]
+    assert list(cf["aatype"]) == [20, 0, 7, 11, 15, 20] and list(cf["residue_index"]) == [10, 11, 12, 13, 12, 201]
+    assert list(cf["min_modeled_idxs"]) == [1] and list(cf["max_modeled_idxs"]) == [4]
+    assert set(cf["chain_index"]) == {features.chain_str_to_int("A")} and features.chain_str_to_int("A") == 26
+    ca, cb = features.ATOM_ORDER["CA"], features.ATOM_ORDER["CB"]
+    center = cf["atom_positions"][:, ca].sum(0) / 6  # every residue but the water has a CA; parse_chain_feats centres on them
+    np.testing.assert_allclose(cf["atom_positions"][1, cb] - cf["atom_positions"][1, ca], np.array([9, 9, 9]) - np.array([4.8, 1.0, 0.5]),
+                               atol=1e-5)
+    assert cf["atom_mask"][4].sum() == 1 and cf["bb_mask"][5] == 0 and abs(center).max() < 1e-3
+    row = mmcif.process_mmcif(p, tmp_path / "processed")
+    assert row["pdb_name"] == "1abc-assembly1" and row["modeled_seq_len"] == 4 and row["seq_len"] == 6
+    # ConditionalSampler(data_conf, ...) processes <download_dir>/cifs itself when metadata.csv is absent (sampler.py:189-222)
+    from framedipt_amd import config
+    from framedipt_amd.sampler import ConditionalSampler, TCRSampler
+    (tmp_path / "dl" / "cifs").mkdir(parents=True)
+    (tmp_path / "dl" / "cifs" / p.name).write_text(p.read_text())
+    (tmp_path / "set.csv").write_text("pdb_id,tcr_alpha_chain,tcr_beta_chain\n1abc,B,B\n")
+    dc = config.to_conf({"download_dir": str(tmp_path / "dl"), "data_path": str(tmp_path / "set.csv"), "samples": 3, "seed": 1,
+                         "first_assembly": True, "cdr_loops": ["CDR3"], "redaction": {"redact_min_len": 1, "redact_max_len": 2}})
+    ds = ConditionalSampler(dc, None, "cuda")
+    assert len(ds) == 3 and ds.metadata[0]["modeled_seq_len"] == 4 and (tmp_path / "dl" / "processed" / "metadata.csv").exists()
+    assert ds._chain_feats(0)["rigidgroups_0"].shape == (4, 8, 4, 4)
+    assert TCRSampler(dc, None, "cuda").all_chains_to_process == [["B", "B"]]
+    out = features.process_csv_row(row["processed_path"])
+    assert out["aatype"].shape == (4,) and list(out["seq_idx"]) == [0, 1, 2, 3] and out["rigidgroups_0"].shape == (4, 8, 4, 4)
+    assert features.map_to_new_str_name(26) == "AA" and features.map_to_new_str_name(676) == "ZA"
