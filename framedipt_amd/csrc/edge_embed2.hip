@@ -79,8 +79,9 @@ __device__ __forceinline__ void ee_hand_off(const f32x16& acc, hx8& h0, hx8& h1)
 }
 // LayerNorm epilogue of the embedder in packed fp32 math (one pass: sum and sum of squares; the layer bias is already in Y):
 // same staging / stores / pair-bias emission as ln_epilogue_staged
+template <bool TRACE>
 __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamma_l, const float* beta_l, float em, int li, int hi,
-                                               int lane, char* stage, half_t* __restrict__ z_out, long p0, long n_pairs,
+                                               int lane, char* stage, half_t* __restrict__ z_tile, int nvalid,
                                                float* __restrict__ tr_row, bool valid, const char* wb_lds, const f32x4 bbv,
                                                float* __restrict__ bias_out, int H, long bidx, int ii, int jj, int nt) {
   ee_f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
@@ -98,46 +99,72 @@ __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamm
   const float mu = s1 * (1.0f / ET2_CZ);
   const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / ET2_CZ) - mu * mu, 0.f) + 1e-5f);
   const ee_f32x2 sa = {rstd, rstd}, sc = {-mu * rstd, -mu * rstd}, em2 = {em, em};
-  ee_u32x4 zB[8];  // bf16 z' as B fragments
+  ee_u32x4 zB[8];  // half-precision z' as B fragments
+  // (gamma, beta) of a feature group come from LDS one group AHEAD of their use; the interleave is pinned: left alone hipcc
+  // emits read -> s_waitcnt lgkmcnt(0) -> use for each of the 16 groups (16 exposed LDS round trips per tile)
+  f32x4 gq[2], bq[2];
+  gq[0] = *(const f32x4*)(gamma_l + 4 * hi);
+  bq[0] = *(const f32x4*)(beta_l + 4 * hi);
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int f0 = 32 * t + 8 * g + 4 * hi;
-      const f32x4 gm = *(const f32x4*)(gamma_l + f0), bt = *(const f32x4*)(beta_l + f0);
-      ee_f32x2 o0 = {Y[t][4 * g], Y[t][4 * g + 1]}, o1 = {Y[t][4 * g + 2], Y[t][4 * g + 3]};
-      o0 = __builtin_elementwise_fma(o0, sa, sc);
-      o1 = __builtin_elementwise_fma(o1, sa, sc);
-      o0 = __builtin_elementwise_fma(o0, ee_f32x2{gm[0], gm[1]}, ee_f32x2{bt[0], bt[1]}) * em2;
-      o1 = __builtin_elementwise_fma(o1, ee_f32x2{gm[2], gm[3]}, ee_f32x2{bt[2], bt[3]}) * em2;
-      const ee_u32x2 ow = {ee_cvt_pk(o0[0], o0[1]), ee_cvt_pk(o1[0], o1[1])};
-      // features f0..f0+3 = bytes 2 f0 .. 2 f0 + 7 of the pair's row: 16 B unit 4t + g, half hi; unit u of row r at u ^ (r & 15)
-      *(ee_u32x2*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = ow;
-      zB[2 * t + (g >> 1)][2 * (g & 1)] = ow[0];
-      zB[2 * t + (g >> 1)][2 * (g & 1) + 1] = ow[1];
-      if (tr_row && valid) *(f32x4*)(tr_row + f0) = f32x4{o0[0], o0[1], o1[0], o1[1]};
+  for (int idx = 0; idx < 16; ++idx) {
+    const int t = idx >> 2, g = idx & 3, f0 = 32 * t + 8 * g + 4 * hi;
+    if (idx + 1 < 16) {
+      const int f1 = 32 * ((idx + 1) >> 2) + 8 * ((idx + 1) & 3) + 4 * hi;
+      gq[(idx + 1) & 1] = *(const f32x4*)(gamma_l + f1);
+      bq[(idx + 1) & 1] = *(const f32x4*)(beta_l + f1);
     }
+    const f32x4 gm = gq[idx & 1], bt = bq[idx & 1];
+    ee_f32x2 o0 = {Y[t][4 * g], Y[t][4 * g + 1]}, o1 = {Y[t][4 * g + 2], Y[t][4 * g + 3]};
+    o0 = __builtin_elementwise_fma(o0, sa, sc);
+    o1 = __builtin_elementwise_fma(o1, sa, sc);
+    o0 = __builtin_elementwise_fma(o0, ee_f32x2{gm[0], gm[1]}, ee_f32x2{bt[0], bt[1]}) * em2;
+    o1 = __builtin_elementwise_fma(o1, ee_f32x2{gm[2], gm[3]}, ee_f32x2{bt[2], bt[3]}) * em2;
+    const ee_u32x2 ow = {ee_cvt_pk(o0[0], o0[1]), ee_cvt_pk(o1[0], o1[1])};
+    // features f0..f0+3 = bytes 2 f0 .. 2 f0 + 7 of the pair's row: 16 B unit 4t + g, half hi; unit u of row r at u ^ (r & 15)
+    *(ee_u32x2*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = ow;
+    zB[2 * t + (g >> 1)][2 * (g & 1)] = ow[0];
+    zB[2 * t + (g >> 1)][2 * (g & 1) + 1] = ow[1];
+    if (TRACE && valid) *(f32x4*)(tr_row + f0) = f32x4{o0[0], o0[1], o1[0], o1[1]};
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // every LDS operand of the tail is requested before the first use: the 8 row segments of the z tile (other lanes' writes above:
+  // DS operations of a wave execute in order) and the 8 linear_b fragments
+  const int sr = lane >> 4, sc16 = lane & 15;
+  u16x8 zrow[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = 4 * it + sr;
+    zrow[it] = *(const u16x8*)(stage + r * 256 + ((sc16 ^ (r & 15)) << 4));
+  }
+  const bool full = nvalid == 32;  // wave-uniform: 9 of 10 tiles at N = 300 take the branch-free stores
   if (wb_lds) {
+    hx8 wf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wf[s] = lds_frag(wb_lds, s * 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      accb = fd_mfma32(lds_frag(wb_lds, s * 1024 + lane * 16), __builtin_bit_cast(hx8, zB[s]), accb);
-    if (valid) {
-      float* bo = bias_out + fd_bias_frag_off(bidx * H + 4 * hi, nt, ii, jj);  // 32 lanes = 32 consecutive keys: 128 B rows
-      const long hstride = (long)nt * nt * 1024;  // floats per (sample, head)
+    for (int s = 0; s < 8; ++s) accb = fd_mfma32(wf[s], __builtin_bit_cast(hx8, zB[s]), accb);
+    float* bo = bias_out + fd_bias_frag_off(bidx * H + 4 * hi, nt, ii, valid ? jj : 0);  // 32 lanes = 32 consecutive keys: 128 B rows
+    const long hstride = (long)nt * nt * 1024;  // floats per (sample, head)
+    if (full && H == 8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bo[r * hstride] = accb[r] + bbv[r];
+    } else if (valid) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (4 * hi + r < H) bo[r * hstride] = accb[r] + bbv[r];
     }
   }
-  const int sr = lane >> 4, sc16 = lane & 15;
+  if (full) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int r = 4 * it + sr;
-    const u16x8 v = *(const u16x8*)(stage + r * 256 + ((sc16 ^ (r & 15)) << 4));
-    if (p0 + r < n_pairs) *(u16x8*)(z_out + (p0 + r) * ET2_CZ + 8 * sc16) = v;
+    for (int it = 0; it < 8; ++it) *(u16x8*)(z_tile + (4 * it + sr) * ET2_CZ + 8 * sc16) = zrow[it];
+  } else {
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      if (4 * it + sr < nvalid) *(u16x8*)(z_tile + (4 * it + sr) * ET2_CZ + 8 * sc16) = zrow[it];
   }
 }
 
@@ -171,18 +198,53 @@ size_t fd_ee2_image_bytes() { return 2 * EE2_IMG; }
 
 // 512-thread persistent blocks: 8 independent waves (two per SIMD) share the 64 KB weight images; every wave owns an
 // 8 KB LDS tile that transposes between "whole 512 B table rows per 32 lanes" (the global side) and MFMA fragments.
+//
+// Work decomposition (round 2): a tile is one query row i against 32 consecutive keys j0..j0+31 of one sample, and a wave walks
+// CONSECUTIVE rows i of one (sample, key tile) group.  Of the four table rows a pair sums, only R[idx_i - idx_j] is then a per-tile
+// gather from L2 (16 KB): Pj[j] of the 32 keys stays in 64 registers for the whole walk, Pi[i] is one 512 B row per tile and the
+// distogram table D (num_bins + 1 rows) sits in LDS.  The previous generation walked flat 32-pair tiles and fetched all four rows of
+// every pair (64 KB per tile through the 64 B/clk L2 -> CU path: 1.5 GB per launch).  The next row's R rows and Pi row are
+// requested before the LayerNorm epilogue of the current one.
 #define EE2_THREADS 512
-#define EE2_MAXB 63     // distogram bins (edges in LDS)
-#define EE2_LDS (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + 8192 + 256)  // ... + linear_b image of the first block + distogram edges
-__global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img,
-                                                                     int n_tiles) {
+// phase profile (-DEE2_PROF, tools/micro/ee2_bench.hip): cycles of wave 0 of every block, accumulated over its tiles
+#ifdef EE2_PROF
+__device__ unsigned ee2_prof[256 * 8];
+#define EE2_STAMP(k)                                             \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+    ph[k] += t_ - tlast;                                         \
+    tlast = t_;                                                  \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+#else
+#define EE2_STAMP(k) \
+  do {               \
+  } while (0)
+#endif
+#ifndef EE2_RESIDENT
+#define EE2_RESIDENT 0   // Pj rows of the key tile stay in registers for the whole walk
+#endif
+#ifndef EE2_EARLY
+#define EE2_EARLY 0      // R rows of the next tile requested before the LayerNorm epilogue (the rest after it: register budget)
+#endif
+#define EE2_MAXB 63      // distogram bins (edges in LDS)
+#define EE2_MAXB_LDS 39  // ... with the table rows in LDS as well (20 KB)
+#define EE2_LDS_BASE (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + 8192 + 256)  // ... + linear_b image of the first block + distogram edges
+template <bool DLDS, bool TRACE>
+__global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img, int nt, int wpg,
+                                                                     int rpw, int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef EE2_PROF
+  unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
   char* stage = smem + 2 * EE2_IMG + wave * 8192;
   float* vec = (float*)(smem + 2 * EE2_IMG + 8 * 8192);  // [b2 | b3 | gamma | beta] x 128
   char* wbl = (char*)(vec + 4 * ET2_CZ);                 // 8 KB fragment image of linear_b (optional)
   float* edg = (float*)(wbl + 8192);                     // [num_bins + 1] distogram edges, the last one 1e8
+  float* dl = edg + 64;                                  // DLDS: [num_bins + 1][128] distogram rows of the first layer
   if (tid <= a.num_bins) edg[tid] = tid < a.num_bins ? a.edges[tid] : 1e8f;
   if (a.wb_img) et2_dma16((const char*)a.wb_img + tid * 16, wbl + (tid & ~63) * 16);
   for (int u = 0; u < 2 * EE2_IMG / 16 / EE2_THREADS; ++u)
@@ -191,118 +253,205 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
     const int which = tid >> 7, c = tid & 127;
     vec[tid] = which == 0 ? a.b2[c] : (which == 1 ? a.b3[c] : (which == 2 ? a.gamma[c] : a.beta[c]));
   }
+  if (DLDS) {
+    f32x4 t[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {  // (EE2_MAXB_LDS + 1) * 32 units of 16 B <= 3 * 512
+      const int v = u * EE2_THREADS + tid;
+      if (v < (a.num_bins + 1) * 32) t[u] = *(const f32x4*)(a.dtab + (long)v * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int v = u * EE2_THREADS + tid;
+      if (v < (a.num_bins + 1) * 32) *(f32x4*)(dl + (long)v * 4) = t[u];
+    }
+  }
   et2_dma_wait();
   __syncthreads();
-  const int N = a.N;
-  const long n_pairs = (long)a.B * N * N;
+  EE2_STAMP(0);
+  const int N = a.N, nb = a.num_bins;
   const float* b2row = vec + 4 * hi;
   const f32x4 bbv = a.wb_img ? f32x4{a.bb[4 * hi], a.bb[4 * hi + 1], a.bb[4 * hi + 2], a.bb[4 * hi + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-  // The per-pair inputs of the NEXT tile (sequence indices, self-conditioning CA) are requested at the top of a tile and turned
-  // into its table row ids (relative index, distogram bin) right after the current tile's gather, so that those two dependent
-  // memory round trips leave every tile's critical path at the price of two loop-carried registers; the distogram edges sit in
-  // LDS (a rolled loop over a.edges[] re-issues two dependent scalar loads per bin and tile).
-  struct PairIn { int si, sj; float ci[3], cj[3], mi, mj; };
-  auto request = [&](int tile) {
-    const long pr = (long)tile * 32 + li, pp = pr < n_pairs ? pr : n_pairs - 1;
-    const long bi = pp / N, bb = bi / N, bj = bb * N + (pp - bi * N);
-    PairIn r;
-    r.si = a.seq_idx[bi]; r.sj = a.seq_idx[bj];
-    r.mi = a.res_mask[bi]; r.mj = a.res_mask[bj];
+  // distogram bin of one distance: calc_distogram's strict inequalities against the stored edges (last upper edge 1e8); the
+  // candidate comes from the edge spacing, its neighbours are re-tested, so the result is the one a full scan finds
+  const float e0 = edg[0], inv_step = nb > 1 ? 1.0f / (edg[1] - edg[0]) : 0.f;
+  auto bin_of = [&](float d) {
+    int k0 = (int)((d - e0) * inv_step);
+    k0 = k0 < 1 ? 1 : (k0 > nb - 2 ? nb - 2 : k0);
+    int bin = nb;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { r.ci[c] = a.sc_ca[bi * 3 + c]; r.cj[c] = a.sc_ca[bj * 3 + c]; }
-    return r;
+    for (int k = -1; k <= 1; ++k) {
+      const int kk = k0 + k;
+      if (kk >= 0 && kk < nb && d > edg[kk] && d < edg[kk + 1]) bin = kk;
+    }
+    return bin;
   };
-  auto row_ids = [&](int tile, const PairIn& r, int& rel, int& bin, float& msk) {
-    msk = r.mi * r.mj;
-    const long pr = (long)tile * 32 + li, pp = pr < n_pairs ? pr : n_pairs - 1;
-    const long bb = (pp / N) / N;
-    rel = (int)(bb * a.n_rel) + r.si - r.sj + a.rel_off;
-    const float dx = r.ci[0] - r.cj[0], dy = r.ci[1] - r.cj[1], dz = r.ci[2] - r.cj[2];
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-    bin = a.num_bins;
-    for (int k = 0; k < a.num_bins; ++k)  // calc_distogram: strict inequalities, last upper edge 1e8 (edg[num_bins])
-      if (d > edg[k] && d < edg[k + 1]) bin = k;
-  };
-  const int tile_first = blockIdx.x * 8 + wave, tile_step = gridDim.x * 8;
-  int rel = 0, bin = 0;
-  float msk_n = 0.f;
-  if (tile_first < n_tiles) { const PairIn r0 = request(tile_first); row_ids(tile_first, r0, rel, bin, msk_n); }
-  for (int tile = tile_first; tile < n_tiles; tile += tile_step) {
-    const long p0 = (long)tile * 32;
-    const long p_raw = p0 + li;
-    const bool valid = p_raw < n_pairs;
-    const long p = valid ? p_raw : n_pairs - 1;
-    const long bi = p / N;
-    const int j = (int)(p - bi * N);
-    const long bb = bi / N;
-    const long bj = bb * N + j;
-    const int tile_n = tile + tile_step < n_tiles ? tile + tile_step : tile;
-    const PairIn raw = request(tile_n);
-    const float msk = msk_n;
-    // ---- layer 1 has no GEMM: h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]).  Two pairs per instruction: lanes 0..31 /
-    // 32..63 read one whole 512 B row each (the row ids of pair 2 it + hi come from the lane that owns it)
-    const int ibi = (int)bi, ibj = (int)bj;
-#pragma unroll 4
+  for (int item = blockIdx.x * 8 + wave; item < n_items; item += gridDim.x * 8) {
+    // ---- group (sample b, key tile jt): per-key state of the 32 keys, resident for the whole walk
+    const int grp = item / wpg, part = item - grp * wpg;
+    const int b = grp / nt, jt = grp - b * nt, j0 = jt * 32;
+    const int i_first = part * rpw, i_end = (i_first + rpw < N) ? i_first + rpw : N;
+    if (i_first >= i_end) continue;
+    const int nvalid = N - j0 < 32 ? N - j0 : 32;
+    const bool valid = li < nvalid;
+    const int j = valid ? j0 + li : N - 1;
+    const long bj = (long)b * N + j;
+    const int sj = a.seq_idx[bj];
+    const float mj = a.res_mask[bj];
+    const float cj0 = a.sc_ca[bj * 3], cj1 = a.sc_ca[bj * 3 + 1], cj2 = a.sc_ca[bj * 3 + 2];
+    const float* pj_base = a.pj + ((long)b * N + j0) * ET2_CZ + 4 * li;  // row r of the tile at + min(r, nvalid - 1) * 128
+    // per-row scalars (wave-uniform addresses: scalar loads) -> this lane's table row ids
+    // per-row scalars: requested (scalar loads) at the top of the previous row, turned into table row ids after its gather
+    struct RowIn { int si; float mi, c0, c1, c2; };
+    auto row_request = [&](int i) {
+      const long bi = (long)b * N + i;
+      return RowIn{a.seq_idx[bi], a.res_mask[bi], a.sc_ca[bi * 3], a.sc_ca[bi * 3 + 1], a.sc_ca[bi * 3 + 2]};
+    };
+    auto row_ids = [&](const RowIn& r, int& rel, int& bin, float& msk) {
+      msk = r.mi * mj;
+      rel = b * a.n_rel + r.si - sj + a.rel_off;
+      const float dx = r.c0 - cj0, dy = r.c1 - cj1, dz = r.c2 - cj2;
+      bin = bin_of(sqrtf(dx * dx + dy * dy + dz * dz));
+    };
+    f32x4 RR[16], PJ[16], PI;
+#if EE2_RESIDENT
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int r = 2 * it + hi;
-      const int rbi = __shfl(ibi, r, 64), rbj = __shfl(ibj, r, 64), rrel = __shfl(rel, r, 64), rbin = __shfl(bin, r, 64);
-      const f32x4 x1 = *(const f32x4*)(a.pi + (long)rbi * ET2_CZ + 4 * li), x2 = *(const f32x4*)(a.pj + (long)rbj * ET2_CZ + 4 * li);
-      const f32x4 x3 = *(const f32x4*)(a.rtab + (long)rrel * ET2_CZ + 4 * li), x4 = *(const f32x4*)(a.dtab + (long)rbin * ET2_CZ + 4 * li);
-      // packed adds, conversion, then relu on the bf16 bit patterns (v_pk_max_i16)
-      const ee_f32x2 sA = (ee_f32x2{x1[0], x1[1]} + ee_f32x2{x2[0], x2[1]}) + (ee_f32x2{x3[0], x3[1]} + ee_f32x2{x4[0], x4[1]});
-      const ee_f32x2 sB = (ee_f32x2{x1[2], x1[3]} + ee_f32x2{x2[2], x2[3]}) + (ee_f32x2{x3[2], x3[3]} + ee_f32x2{x4[2], x4[3]});
-      typedef short s16x4 __attribute__((ext_vector_type(4)));
-      const ee_u32x2 cw = {ee_cvt_pk(sA[0], sA[1]), ee_cvt_pk(sB[0], sB[1])};
-      const ee_u32x2 pk = __builtin_bit_cast(ee_u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, cw), s16x4{0, 0, 0, 0}));
-      // [32 pairs][256 B] tile, 16 B unit u of row r at u ^ (r & 15)
-      *(ee_u32x2*)(stage + r * 256 + (((li >> 1) ^ (r & 15)) << 4) + 8 * (li & 1)) = pk;
+      PJ[it] = *(const f32x4*)(pj_base + (r < nvalid ? r : nvalid - 1) * ET2_CZ);
     }
-    row_ids(tile_n, raw, rel, bin, msk_n);  // the next tile's row ids (this tile's were consumed by the gather above)
-    hx8 H1[8];
+#endif
+    auto request = [&](int i, int rel, const int it0, const int it1) {
+      if (it0 == 0) PI = *(const f32x4*)(a.pi + ((long)b * N + i) * ET2_CZ + 4 * li);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) H1[s] = lds_frag(stage, li * 256 + (((2 * s + hi) ^ (li & 15)) << 4));
-    hx8 H2[8];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      f32x16 acc;  // starts as the layer bias (LDS reads straight into the accumulator: no VALU)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv = *(const f32x4*)(b2row + 32 * T + 8 * g);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[4 * g + q] = bv[q];
+      for (int it = it0; it < it1; ++it) {
+        const int r = 2 * it + hi;
+        const int rrel = __shfl(rel, r, 64);
+        RR[it] = *(const f32x4*)(a.rtab + (long)rrel * ET2_CZ + 4 * li);
+#if !EE2_RESIDENT
+        PJ[it] = *(const f32x4*)(pj_base + (r < nvalid ? r : nvalid - 1) * ET2_CZ);  // (the same 16 KB for every row of the walk: L2 hits)
+#endif
       }
-      mma_slab<8, 256>(acc, smem + T * 32 * 256, li, hi, H1);
-      ee_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
-    }
-    f32x16 Y[4];
+    };
+    int rel, bin;
+    float msk;
+    row_ids(row_request(i_first), rel, bin, msk);
+    request(i_first, rel, 0, 16);
+    EE2_STAMP(1);
+    for (int i = i_first; i < i_end; ++i) {
+      // Lane-derived LDS / global offsets are recomputed per row: left to itself hipcc hoists ~100 of them out of this loop and
+      // spills them (every reload is a vmcnt wait in front of the matrix phase).
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int hi = lane_o >> 5, li = lane_o & 31;
+      const float* b2row = vec + 4 * hi;
+      const int i_next = i + 1 < i_end ? i + 1 : i;
+      const RowIn rin = row_request(i_next);
+      // ---- layer 1 has no GEMM: h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]).  Two pairs per instruction: lanes 0..31 / 32..63
+      // hold one whole 512 B row each.  The 16 bin shuffles, then the 16 distogram rows, are issued as batches (one LDS round trip
+      // each instead of one per pair of rows).
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+      for (int half = 0; half < 4; ++half) {
+      int rb[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {  // starts as the layer bias b3
-        const f32x4 bv = *(const f32x4*)(vec + ET2_CZ + 4 * hi + 32 * t + 8 * g);
+      for (int q = 0; q < 4; ++q) rb[q] = __shfl(bin, 2 * (4 * half + q) + hi, 64);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 DD[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Y[t][4 * g + q] = bv[q];
+      for (int q = 0; q < 4; ++q)
+        DD[q] = DLDS ? *(const f32x4*)(dl + rb[q] * ET2_CZ + 4 * li) : *(const f32x4*)(a.dtab + (long)rb[q] * ET2_CZ + 4 * li);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int it = 4 * half + q, r = 2 * it + hi;
+        const f32x4 x1 = PI, x2 = PJ[it], x3 = RR[it], x4 = DD[q];
+        // packed adds, conversion, then relu on the half-precision bit patterns (v_pk_max_i16)
+        const ee_f32x2 sA = (ee_f32x2{x1[0], x1[1]} + ee_f32x2{x2[0], x2[1]}) + (ee_f32x2{x3[0], x3[1]} + ee_f32x2{x4[0], x4[1]});
+        const ee_f32x2 sB = (ee_f32x2{x1[2], x1[3]} + ee_f32x2{x2[2], x2[3]}) + (ee_f32x2{x3[2], x3[3]} + ee_f32x2{x4[2], x4[3]});
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const ee_u32x2 cw = {ee_cvt_pk(sA[0], sA[1]), ee_cvt_pk(sB[0], sB[1])};
+        const ee_u32x2 pk = __builtin_bit_cast(ee_u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, cw), s16x4{0, 0, 0, 0}));
+        // [32 pairs][256 B] tile, 16 B unit u of row r at u ^ (r & 15)
+        *(ee_u32x2*)(stage + r * 256 + (((li >> 1) ^ (r & 15)) << 4) + 8 * (li & 1)) = pk;
       }
-      mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
+      }
+      EE2_STAMP(2);
+      const float msk_cur = msk;
+      row_ids(rin, rel, bin, msk);  // the next row's ids (this row's were consumed by the gather above)
+      hx8 H1[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) H1[s] = lds_frag(stage, li * 256 + (((2 * s + hi) ^ (li & 15)) << 4));
+      hx8 H2[8];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        f32x16 acc;  // starts as the layer bias (LDS reads straight into the accumulator: no VALU)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *(const f32x4*)(b2row + 32 * T + 8 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[4 * g + q] = bv[q];
+        }
+        mma_slab<8, 256>(acc, smem + T * 32 * 256, li, hi, H1);
+        ee_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
+      }
+      EE2_STAMP(3);
+      f32x16 Y[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // starts as the layer bias b3
+          const f32x4 bv = *(const f32x4*)(vec + ET2_CZ + 4 * hi + 32 * t + 8 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Y[t][4 * g + q] = bv[q];
+        }
+        mma_slab<8, 256>(Y[t], smem + EE2_IMG + t * 32 * 256, li, hi, H2);
+      }
+      EE2_STAMP(4);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      request(i_next, rel, 0, EE2_EARLY);  // in flight under the epilogue
+      __builtin_amdgcn_sched_barrier(0);
+      const int rel_next = rel;
+      const long prow = ((long)b * N + i) * N + j0;  // first pair of the tile
+      ee_ln_epilogue<TRACE>(Y, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, msk_cur, li, hi, lane, stage, (half_t*)a.z_out + prow * ET2_CZ, nvalid,
+                     TRACE ? a.trace + (prow + (valid ? li : 0)) * ET2_CZ : nullptr, valid, a.wb_img ? wbl : nullptr, bbv,
+                     a.bias_out, a.H, b, i, j0 + li, nt);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      request(i_next, rel_next, EE2_EARLY, 16);
+      EE2_STAMP(5);
     }
-    ee_ln_epilogue(Y, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, msk, li, hi, lane,
-                   stage, (half_t*)a.z_out, p0, n_pairs, a.trace ? a.trace + p * ET2_CZ : nullptr, valid,
-                   a.wb_img ? wbl : nullptr, bbv, a.bias_out, a.H, bb, (int)(bi - bb * N), j, (N + 31) >> 5);
   }
+#ifdef EE2_PROF
+  if (tid == 0 && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) ee2_prof[blockIdx.x * 8 + k] = ph[k];
+#endif
 }
 
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
-  const long n_pairs = (long)a.B * a.N * a.N;
-  const int n_tiles = cdiv(n_pairs, 32);
-  if (a.num_bins > EE2_MAXB) return FDIPT_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)edge_embed2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EE2_LDS) != hipSuccess)
+  if (a.num_bins > EE2_MAXB || a.num_bins < 3) return FDIPT_EINVAL;
+  const bool dlds = a.num_bins <= EE2_MAXB_LDS;
+  const int lds = EE2_LDS_BASE + (dlds ? (a.num_bins + 1) * ET2_CZ * 4 : 0);
+  typedef void (*kern_t)(EdgeEmbedArgs, const char*, int, int, int, int);
+  static const kern_t kerns[4] = {edge_embed2_kernel<false, false>, edge_embed2_kernel<false, true>, edge_embed2_kernel<true, false>,
+                                  edge_embed2_kernel<true, true>};
+  const int kid = 2 * dlds + (a.trace != nullptr);
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[kid]) {
+    if (hipFuncSetAttribute((const void*)kerns[kid], hipFuncAttributeMaxDynamicSharedMemorySize,
+                            EE2_LDS_BASE + (EE2_MAXB_LDS + 1) * ET2_CZ * 4) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_set[kid] = true;
   }
-  const int grid = n_tiles / 8 + 1 < 256 ? n_tiles / 8 + 1 : 256;
-  hipLaunchKernelGGL(edge_embed2_kernel, dim3(grid), dim3(EE2_THREADS), EE2_LDS, st, a, (const char*)img, n_tiles);
+  // one work item = (sample, key tile of 32, range of rpw consecutive query rows); wpg items per group so that ~2048 waves are busy
+  const int nt = cdiv(a.N, 32), n_groups = a.B * nt, n_waves = 256 * 8;
+  int wpg = n_waves / n_groups < 1 ? 1 : n_waves / n_groups;
+  if (wpg > a.N) wpg = a.N;
+  const int rpw = cdiv(a.N, wpg);
+  wpg = cdiv(a.N, rpw);
+  const int n_items = n_groups * wpg;
+  const int grid = cdiv(n_items, 8) < 256 ? cdiv(n_items, 8) : 256;
+  hipLaunchKernelGGL(kerns[kid], dim3(grid), dim3(EE2_THREADS), lds, st, a, (const char*)img, nt, wpg, rpw, n_items);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
