@@ -174,6 +174,235 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_kernel(EdgeTransAr
 }
 
 
+// ------------------------------------------------------------------ fp32 EdgeTransition for the reference widths (round 2)
+// Same scheme as edge_transition_kernel - 32 pair rows per block, activations resident in LDS, v_mfma_f32_32x32x2_f32 - with the
+// weight stream software-pipelined: the (pass, k-tile) loops of the three layers are one flat sequence of 84 [128 x 32] weight
+// tiles that travel L2 -> registers -> a ring of three LDS slots -> operand registers, each hop one tile ahead of its use: ONE
+// barrier per k-tile and no exposed latency between the matrix instructions of consecutive tiles (the first generation loaded,
+// stored, synchronised, multiplied and synchronised again for every tile: 1.0 k matrix cycles out of ~3 k per tile = the 34 % of the
+// fp32 matrix peak it measured at).  Operands come out of LDS as 16-byte runs: within a group of 8 consecutive k the lane half hi
+// reads k0 + 4 hi .. + 3 and MFMA j multiplies the pairs (k0 + j | k0 + 4 + j) - the same pairing on both operands, so no data is
+// permuted (row strides 388 / 36 words: conflict-free ds_read_b128).  Everything a block reads before its first matrix instruction
+// (X0 = [z | e_i | e_j], biases, pair masks, three weight tiles) is requested up front.
+#define ETF_H 384
+#define ETF_CZ 128
+#define ETF_LDA 388
+#define ETF_LDW 36
+#define ETF_LDY 132
+#define ETF_BUF (32 * ETF_LDA * 4)
+#define ETF_WS (128 * ETF_LDW * 4)
+#define ETF_LDS (2 * ETF_BUF + 3 * ETF_WS)
+// The weight tiles of one block in stream order: layer 1 (3 passes x 12 k-tiles), layer 2 (3 x 12), final layer (1 x 12).
+#define ETF_TILES 84
+// phase profile (-DETF_PROF, tools/micro/etf_bench.hip): cycles of wave 0 of the first 256 blocks
+#ifdef ETF_PROF
+__device__ unsigned etf_prof[256 * 8];
+#define ETF_STAMP(k)                                             \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+    ph[k] += t_ - tlast;                                         \
+    tlast = t_;                                                  \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+#else
+#define ETF_STAMP(k) \
+  do {               \
+  } while (0)
+#endif
+struct EtfTile {
+  f32x4 r[4];
+  __device__ __forceinline__ void load(const float* __restrict__ W, int n0, int k0, int tid) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = tid + u * FD_THREADS, row = v >> 3, kk = (v & 7) * 4;
+      r[u] = *(const f32x4*)(W + (long)(n0 + row) * ETF_H + k0 + kk);
+    }
+  }
+  __device__ __forceinline__ void store(float* Ws, int tid) const {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = tid + u * FD_THREADS, row = v >> 3, kk = (v & 7) * 4;
+      *(f32x4*)(Ws + row * ETF_LDW + kk) = r[u];
+    }
+  }
+};
+struct EtfStream {
+  const float *w1, *w2, *wf;
+  __device__ __forceinline__ void load(EtfTile& r, int t, int tid) const {
+    if (t >= ETF_TILES) return;
+    const float* W = t < 36 ? w1 : (t < 72 ? w2 : wf);
+    const int tl = t < 36 ? t : (t < 72 ? t - 36 : t - 72);
+    r.load(W, (tl / 12) * 128, (tl % 12) * 32, tid);
+  }
+};
+// MFMA operands of one k-tile in registers: 4 x 16-byte runs of the activation row and of the weight row of this lane
+struct EtfOps {
+  f32x4 a[4], w[4];
+  __device__ __forceinline__ void read(const float* arow, const float* wrow) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = *(const f32x4*)(arow + 8 * q);
+      w[q] = *(const f32x4*)(wrow + 8 * q);
+    }
+  }
+  __device__ __forceinline__ void mma(f32x16& acc) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], w[q][j], acc, 0, 0, 0);
+  }
+};
+// One layer = NP passes x 12 k-tiles, starting at stream position t0.  Weight tiles live in a ring of THREE LDS slots (tile t in
+// slot t % 3): during tile t the block multiplies from registers (operands of tile t, read during tile t - 1), reads the operands of
+// tile t + 1 (stored during tile t - 1, visible since the barrier that closed it), stores tile t + 2 (requested from L2 during
+// tile t - 1) into the slot tile t - 1 occupied, and requests tile t + 3.  Entry state: tiles t0, t0 + 1 in their slots (barrier
+// done), tile t0 + 2 in g0.  (The first tile of a layer reads its operands on entry: its activations were completed by the previous
+// layer's last epilogue.)  epi(pass, acc) runs once per pass.
+template <int NP, class Epi>
+__device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st, int t0, float* Ws0, EtfTile& g0, EtfTile& g1, int tid,
+                                          Epi epi) {
+  const int lane = tid & 63, wc = tid >> 6, hi = lane >> 5;
+  const float* arow = act + (lane & 31) * ETF_LDA + 4 * hi;
+  const int woff = (wc * 32 + (lane & 31)) * ETF_LDW + 4 * hi;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  EtfOps o0, o1;
+  o0.read(arow, Ws0 + (t0 % 3) * (ETF_WS / 4) + woff);
+  auto step = [&](int tl, EtfOps& cur, EtfOps& nxt, EtfTile& gs, EtfTile& gl) {
+    const int t = t0 + tl, kt = tl % 12;
+    st.load(gl, t + 3, tid);  // L2 -> registers, two tiles ahead of its store
+    if (tl + 1 < NP * 12) nxt.read(arow + ((kt + 1) % 12) * 32, Ws0 + ((t + 1) % 3) * (ETF_WS / 4) + woff);
+    cur.mma(acc);
+    if (kt == 11) {
+      epi(tl / 12, acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+    if (t + 2 < ETF_TILES) gs.store(Ws0 + ((t + 2) % 3) * (ETF_WS / 4), tid);
+    __syncthreads();
+  };
+  for (int tl = 0; tl < NP * 12; tl += 2) {
+    step(tl, o0, o1, g0, g1);
+    step(tl + 1, o1, o0, g1, g0);
+  }
+}
+
+template <class ZT>
+__global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTransArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef ETF_PROF
+  unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  float* buf0 = (float*)smem;
+  float* buf1 = (float*)(smem + ETF_BUF);
+  float* Ws = (float*)(smem + 2 * ETF_BUF);
+  float* ybuf = buf1;
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+  const int N = a.N;
+  const long n_pairs = (long)a.B * N * N;
+  const long p0 = (long)blockIdx.x * 32;
+  const ZT* z_in = (const ZT*)a.z_in;
+  const EtfStream st = {(const float*)a.w1, (const float*)a.w2, (const float*)a.wf};
+  const int ncol = wc * 32 + (lane & 31);
+  EtfTile g0, g1, g2;
+  st.load(g0, 0, tid);
+  st.load(g1, 1, tid);
+  st.load(g2, 2, tid);
+  f32x4 xr[12];
+#pragma unroll
+  for (int u = 0; u < 12; ++u) {
+    const int part = u >> 2, v = tid + (u & 3) * FD_THREADS, m = v >> 5, c = (v & 31) * 4;  // 32 pieces of 16 B per 128-float part
+    const long pr = p0 + m, p = pr < n_pairs ? pr : n_pairs - 1;
+    const long bi = p / N;
+    const int j = (int)(p - bi * N);
+    const long bb = bi / N;
+    if (part == 0) {
+      if constexpr (sizeof(ZT) == 4) xr[u] = *(const f32x4*)((const float*)z_in + p * ETF_CZ + c);
+      else
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xr[u][q] = z_load<ZT>(z_in + p * ETF_CZ + c + q);
+    } else {
+      xr[u] = *(const f32x4*)(a.e + (part == 1 ? bi : bb * N + j) * ETF_CZ + c);
+    }
+    if (pr >= n_pairs) xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float bias1[3], bias2[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { bias1[q] = a.b1[q * 128 + ncol]; bias2[q] = a.b2[q * 128 + ncol]; }
+  const float biasf = a.bf[ncol];
+  float em_row = 0.f;  // lanes 0..31 of every wave: pair mask of row `lane`
+  if (lane < 32) {
+    const long p = p0 + lane;
+    if (p < n_pairs) {
+      const long bi = p / N;
+      em_row = a.res_mask[bi] * a.res_mask[(bi / N) * N + (p - bi * N)];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 12; ++u) {
+    const int part = u >> 2, v = tid + (u & 3) * FD_THREADS, m = v >> 5, c = (v & 31) * 4;
+    *(f32x4*)(buf0 + m * ETF_LDA + part * ETF_CZ + c) = xr[u];
+  }
+  g0.store(Ws, tid);
+  g1.store(Ws + ETF_WS / 4, tid);
+  __syncthreads();
+  ETF_STAMP(0);
+  // layer 1: buf1 = relu(W1 x + b1)   (a layer has an even number of tiles and 36 / 72 are multiples of 3: the register and slot
+  // roles at the entry of every layer are the same)
+  etf_layer<3>(buf0, st, 0, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
+    const int n = pass * 128 + ncol;
+    const float bv = pass == 0 ? bias1[0] : (pass == 1 ? bias1[1] : bias1[2]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf1[c_row(r, lane) * ETF_LDA + n] = fmaxf(acc[r] + bv, 0.f);
+  });
+  ETF_STAMP(1);
+  // layer 2 (+ residual): buf0 = relu(W2 h1 + b2) + x   (in place: element-wise same-thread read-modify-write)
+  etf_layer<3>(buf1, st, 36, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
+    const int n = pass * 128 + ncol;
+    const float bv = pass == 0 ? bias2[0] : (pass == 1 ? bias2[1] : bias2[2]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* d = buf0 + c_row(r, lane) * ETF_LDA + n;
+      *d = fmaxf(acc[r] + bv, 0.f) + *d;
+    }
+  });
+  ETF_STAMP(2);
+  // final layer: y = Wf (h2 + x) + bf -> ybuf (aliases buf1, which the final layer does not read)
+  etf_layer<1>(buf0, st, 72, Ws, g2, g0, tid, [&](int, const f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
+  });
+  ETF_STAMP(3);
+  // LayerNorm of the 32 rows (8 per wave, two columns per lane), times the pair mask, -> z
+  {
+    const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], b0v = a.beta[lane], b1v = a.beta[lane + 64];
+    ZT* z_out = (ZT*)a.z_out;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int m = wc + 4 * q;
+      const long p = p0 + m;
+      const float v0 = ybuf[m * ETF_LDY + lane], v1 = ybuf[m * ETF_LDY + lane + 64];
+      const float mu = wave_sum(v0 + v1) * (1.0f / ETF_CZ);
+      const float d0 = v0 - mu, d1 = v1 - mu;
+      const float rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.0f / ETF_CZ) + 1e-5f);
+      const float em = __shfl(em_row, m, 64);
+      if (p < n_pairs) {
+        const float o0 = (d0 * rstd * g0v + b0v) * em, o1 = (d1 * rstd * g1v + b1v) * em;
+        z_store<ZT>(z_out + p * ETF_CZ + lane, o0);
+        z_store<ZT>(z_out + p * ETF_CZ + lane + 64, o1);
+        if (a.trace) { a.trace[p * ETF_CZ + lane] = o0; a.trace[p * ETF_CZ + lane + 64] = o1; }
+      }
+    }
+  }
+  ETF_STAMP(4);
+#ifdef ETF_PROF
+  if (tid == 0 && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) etf_prof[blockIdx.x * 8 + k] = ph[k];
+#endif
+}
+
 template <class P, class WT, class ZT, int TM, int WR, int WC, int CZ>
 __global__ __launch_bounds__(FD_THREADS) void edge_embed_kernel(EdgeEmbedArgs a) {
   constexpr int LDA = CZ + P::PAD;
@@ -266,8 +495,19 @@ static int launch_et(int precision, const EdgeTransArgs& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
   if (precision == FDIPT_PREC_F32) {
     constexpr int TM = 32;
-    hipLaunchKernelGGL((edge_transition_kernel<PrecF32, float, float, TM, 1, 4, CZ, CB>), dim3(cdiv(n_pairs, TM)),
-                       dim3(FD_THREADS), 0, st, a);
+    if constexpr (CZ == ETF_CZ && CB == ETF_CZ) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)edge_transition_f32_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, ETF_LDS) !=
+            hipSuccess)
+          return FDIPT_ELAUNCH;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(edge_transition_f32_kernel<float>, dim3(cdiv(n_pairs, TM)), dim3(FD_THREADS), ETF_LDS, st, a);
+    } else {
+      hipLaunchKernelGGL((edge_transition_kernel<PrecF32, float, float, TM, 1, 4, CZ, CB>), dim3(cdiv(n_pairs, TM)),
+                         dim3(FD_THREADS), 0, st, a);
+    }
   } else {
     constexpr int TM = 64;
     hipLaunchKernelGGL((edge_transition_kernel<PrecHalf, half_t, half_t, TM, 2, 2, CZ, CB>), dim3(cdiv(n_pairs, TM)),
