@@ -246,11 +246,9 @@ struct EtfOps {
       w[q] = *(const f32x4*)(wrow + 8 * q);
     }
   }
-  __device__ __forceinline__ void mma(f32x16& acc) const {
+  __device__ __forceinline__ void mma(f32x16& acc, int q) const {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], w[q][j], acc, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], w[q][j], acc, 0, 0, 0);
   }
 };
 // One layer = NP passes x 12 k-tiles, starting at stream position t0.  Weight tiles live in a ring of THREE LDS slots (tile t in
@@ -270,18 +268,32 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   EtfOps o0, o1;
   o0.read(arow, Ws0 + (t0 % 3) * (ETF_WS / 4) + woff);
+  // The order inside a step is pinned: the LDS stores, the wait for them, the barrier and the next tile's operand reads all sit
+  // BETWEEN matrix instructions (the first generation of this loop had them after the 16th one: the matrix pipe idled through
+  // store completion + barrier + LDS read latency, ~600 of 1640 cycles per tile).
   auto step = [&](int tl, EtfOps& cur, EtfOps& nxt, EtfTile& gs, EtfTile& gl) {
     const int t = t0 + tl, kt = tl % 12;
-    st.load(gl, t + 3, tid);  // L2 -> registers, two tiles ahead of its store
+#ifndef ETF_ABL
+#define ETF_ABL 0  // timing ablations of tools/micro/etf_bench.hip (results are wrong with any bit set)
+#endif
+    if (!(ETF_ABL & 4)) st.load(gl, t + 3, tid);  // L2 -> registers, two tiles ahead of its store
     if (tl + 1 < NP * 12) nxt.read(arow + ((kt + 1) % 12) * 32, Ws0 + ((t + 1) % 3) * (ETF_WS / 4) + woff);
-    cur.mma(acc);
+    __builtin_amdgcn_sched_barrier(0);
+    cur.mma(acc, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < ETF_TILES && !(ETF_ABL & 2)) gs.store(Ws0 + ((t + 2) % 3) * (ETF_WS / 4), tid);
+    __builtin_amdgcn_sched_barrier(0);
+    cur.mma(acc, 1);
+    cur.mma(acc, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ETF_ABL & 1)) __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    cur.mma(acc, 3);
     if (kt == 11) {
       epi(tl / 12, acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
-    if (t + 2 < ETF_TILES) gs.store(Ws0 + ((t + 2) % 3) * (ETF_WS / 4), tid);
-    __syncthreads();
   };
   for (int tl = 0; tl < NP * 12; tl += 2) {
     step(tl, o0, o1, g0, g1);
