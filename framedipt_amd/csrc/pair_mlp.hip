@@ -229,6 +229,12 @@ struct EtfTile {
 };
 struct EtfStream {
   const float *w1, *w2, *wf;
+  __device__ __forceinline__ const float* ptr(int t) const {  // first element of weight tile t (clamped to the stream)
+    t = t < ETF_TILES ? t : ETF_TILES - 1;
+    const float* W = t < 36 ? w1 : (t < 72 ? w2 : wf);
+    const int tl = t < 36 ? t : (t < 72 ? t - 36 : t - 72);
+    return W + (long)((tl / 12) * 128) * ETF_H + (tl % 12) * 32;
+  }
   __device__ __forceinline__ void load(EtfTile& r, int t, int tid) const {
     if (t >= ETF_TILES) return;
     const float* W = t < 36 ? w1 : (t < 72 ? w2 : wf);
@@ -267,28 +273,43 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   EtfOps o0, o1;
+  __syncthreads();  // the previous layer's last epilogue / the prologue's stores
   o0.read(arow, Ws0 + (t0 % 3) * (ETF_WS / 4) + woff);
-  // The order inside a step is pinned: the LDS stores, the wait for them, the barrier and the next tile's operand reads all sit
-  // BETWEEN matrix instructions (the first generation of this loop had them after the 16th one: the matrix pipe idled through
-  // store completion + barrier + LDS read latency, ~600 of 1640 cycles per tile).
+  // A step = the 16 matrix instructions of tile t with everything else of the pipeline placed in the gaps BETWEEN them, a few
+  // instructions per gap (one wave per SIMD issues in order: whatever stands between two MFMAs is hidden only up to the 64 cycles
+  // the first one runs; the first generations of this loop had loads, LDS reads, LDS stores and the barrier in three clumps and
+  // lost ~600 of 1640 cycles per tile to them).  Gap 0: barrier (publishes the previous step's stores = tile t + 1); gaps 1-4: L2
+  // requests of tile t + 3; gaps 5-12: operand reads of tile t + 1; gaps 13-16 (the last one after the 16th MFMA): LDS stores of
+  // tile t + 2 (requested during the previous step).
+  const int goff = ((tid >> 3) * ETF_H + (tid & 7) * 4), loff = (tid >> 3) * ETF_LDW + (tid & 7) * 4;
   auto step = [&](int tl, EtfOps& cur, EtfOps& nxt, EtfTile& gs, EtfTile& gl) {
     const int t = t0 + tl, kt = tl % 12;
-#ifndef ETF_ABL
-#define ETF_ABL 0  // timing ablations of tools/micro/etf_bench.hip (results are wrong with any bit set)
-#endif
-    if (!(ETF_ABL & 4)) st.load(gl, t + 3, tid);  // L2 -> registers, two tiles ahead of its store
-    if (tl + 1 < NP * 12) nxt.read(arow + ((kt + 1) % 12) * 32, Ws0 + ((t + 1) % 3) * (ETF_WS / 4) + woff);
-    __builtin_amdgcn_sched_barrier(0);
-    cur.mma(acc, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < ETF_TILES && !(ETF_ABL & 2)) gs.store(Ws0 + ((t + 2) % 3) * (ETF_WS / 4), tid);
-    __builtin_amdgcn_sched_barrier(0);
-    cur.mma(acc, 1);
-    cur.mma(acc, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(ETF_ABL & 1)) __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    cur.mma(acc, 3);
+    const float* src = st.ptr(t + 3) + goff;
+    const float* an = arow + ((kt + 1) % 12) * 32;
+    const float* wn = Ws0 + ((t + 1) % 3) * (ETF_WS / 4) + woff;
+    float* wd = Ws0 + ((t + 2) % 3) * (ETF_WS / 4) + loff;  // (beyond the stream: a free slot nobody reads)
+#define ETF_MMA(i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[(i) >> 2][(i) & 3], cur.w[(i) >> 2][(i) & 3], acc, 0, 0, 0); \
+                   __builtin_amdgcn_sched_barrier(0)
+#define ETF_GAP(...) __VA_ARGS__; __builtin_amdgcn_sched_barrier(0)
+    ETF_MMA(0);  ETF_GAP(__syncthreads());
+    ETF_MMA(1);  ETF_GAP(gl.r[0] = *(const f32x4*)(src));
+    ETF_MMA(2);  ETF_GAP(gl.r[1] = *(const f32x4*)(src + 32 * ETF_H));
+    ETF_MMA(3);  ETF_GAP(gl.r[2] = *(const f32x4*)(src + 64 * ETF_H));
+    ETF_MMA(4);  ETF_GAP(gl.r[3] = *(const f32x4*)(src + 96 * ETF_H));
+    ETF_MMA(5);  ETF_GAP(nxt.a[0] = *(const f32x4*)(an));
+    ETF_MMA(6);  ETF_GAP(nxt.w[0] = *(const f32x4*)(wn));
+    ETF_MMA(7);  ETF_GAP(nxt.a[1] = *(const f32x4*)(an + 8));
+    ETF_MMA(8);  ETF_GAP(nxt.w[1] = *(const f32x4*)(wn + 8));
+    ETF_MMA(9);  ETF_GAP(nxt.a[2] = *(const f32x4*)(an + 16));
+    ETF_MMA(10); ETF_GAP(nxt.w[2] = *(const f32x4*)(wn + 16));
+    ETF_MMA(11); ETF_GAP(nxt.a[3] = *(const f32x4*)(an + 24));
+    ETF_MMA(12); ETF_GAP(nxt.w[3] = *(const f32x4*)(wn + 24));
+    ETF_MMA(13); ETF_GAP(*(f32x4*)(wd) = gs.r[0]);
+    ETF_MMA(14); ETF_GAP(*(f32x4*)(wd + 32 * ETF_LDW) = gs.r[1]);
+    ETF_MMA(15); ETF_GAP(*(f32x4*)(wd + 64 * ETF_LDW) = gs.r[2]);
+    ETF_GAP(*(f32x4*)(wd + 96 * ETF_LDW) = gs.r[3]);
+#undef ETF_MMA
+#undef ETF_GAP
     if (kt == 11) {
       epi(tl / 12, acc);
 #pragma unroll
@@ -386,6 +407,7 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
 #pragma unroll
     for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
   });
+  __syncthreads();
   ETF_STAMP(3);
   // LayerNorm of the 32 rows (8 per wave, two columns per lane), times the pair mask, -> z
   {
