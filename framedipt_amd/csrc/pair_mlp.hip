@@ -229,8 +229,8 @@ struct EtfTile {
 };
 struct EtfStream {
   const float *w1, *w2, *wf;
-  __device__ __forceinline__ const float* ptr(int t) const {  // first element of weight tile t (clamped to the stream)
-    t = t < ETF_TILES ? t : ETF_TILES - 1;
+  __device__ __forceinline__ const float* ptr(int t) const {  // first element of weight tile t; the stream is cyclic (next block)
+    t = t < ETF_TILES ? t : t - ETF_TILES;
     const float* W = t < 36 ? w1 : (t < 72 ? w2 : wf);
     const int tl = t < 36 ? t : (t < 72 ? t - 36 : t - 72);
     return W + (long)((tl / 12) * 128) * ETF_H + (tl % 12) * 32;
@@ -322,8 +322,11 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
   }
 }
 
+// Persistent blocks (one per CU: 151 KB of LDS): a block walks row tiles blk, blk + gridDim.x, ...; the weight stream is cyclic
+// (84 tiles, a multiple of the ring's 3 slots and of the 2 register roles), so the pipeline never drains between tiles, and the
+// next tile's X0 / pair masks are requested before the final layer and stored once it has read buf0 for the last time.
 template <class ZT>
-__global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTransArgs a) {
+__global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTransArgs a, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef ETF_PROF
   unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_amdgcn_s_memtime();
@@ -335,102 +338,140 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
   const int N = a.N;
   const long n_pairs = (long)a.B * N * N;
-  const long p0 = (long)blockIdx.x * 32;
   const ZT* z_in = (const ZT*)a.z_in;
   const EtfStream st = {(const float*)a.w1, (const float*)a.w2, (const float*)a.wf};
   const int ncol = wc * 32 + (lane & 31);
+  // ---- everything the block reads from memory before its first matrix instruction is requested up front: the first three
+  // weight tiles, the 12 16-byte pieces per thread of X0 = [z_ij | e_i | e_j] (32 rows x 384), the seven bias values of this
+  // lane's output columns and (lanes 0..31) the pair mask of a row
   EtfTile g0, g1, g2;
   st.load(g0, 0, tid);
   st.load(g1, 1, tid);
   st.load(g2, 2, tid);
   f32x4 xr[12];
+  float em_next = 0.f;
+  auto request_x0 = [&](long p0) {
 #pragma unroll
-  for (int u = 0; u < 12; ++u) {
-    const int part = u >> 2, v = tid + (u & 3) * FD_THREADS, m = v >> 5, c = (v & 31) * 4;  // 32 pieces of 16 B per 128-float part
-    const long pr = p0 + m, p = pr < n_pairs ? pr : n_pairs - 1;
-    const long bi = p / N;
-    const int j = (int)(p - bi * N);
-    const long bb = bi / N;
-    if (part == 0) {
-      if constexpr (sizeof(ZT) == 4) xr[u] = *(const f32x4*)((const float*)z_in + p * ETF_CZ + c);
-      else
+    for (int u = 0; u < 12; ++u) {
+      const int part = u >> 2, v = tid + (u & 3) * FD_THREADS, m = v >> 5, c = (v & 31) * 4;  // 32 pieces of 16 B per 128-float part
+      const long pr = p0 + m, p = pr < n_pairs ? pr : n_pairs - 1;
+      const long bi = p / N;
+      const int j = (int)(p - bi * N);
+      const long bb = bi / N;
+      if (part == 0) {
+        if constexpr (sizeof(ZT) == 4) xr[u] = *(const f32x4*)((const float*)z_in + p * ETF_CZ + c);
+        else
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xr[u][q] = z_load<ZT>(z_in + p * ETF_CZ + c + q);
-    } else {
-      xr[u] = *(const f32x4*)(a.e + (part == 1 ? bi : bb * N + j) * ETF_CZ + c);
+          for (int q = 0; q < 4; ++q) xr[u][q] = z_load<ZT>(z_in + p * ETF_CZ + c + q);
+      } else {
+        xr[u] = *(const f32x4*)(a.e + (part == 1 ? bi : bb * N + j) * ETF_CZ + c);
+      }
+      if (pr >= n_pairs) xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (pr >= n_pairs) xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+    em_next = 0.f;  // lanes 0..31 of every wave: pair mask of row `lane`
+    if (lane < 32) {
+      const long p = p0 + lane;
+      if (p < n_pairs) {
+        const long bi = p / N;
+        em_next = a.res_mask[bi] * a.res_mask[(bi / N) * N + (p - bi * N)];
+      }
+    }
+  };
+  auto store_x0 = [&]() {
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int part = u >> 2, v = tid + (u & 3) * FD_THREADS, m = v >> 5, c = (v & 31) * 4;
+      *(f32x4*)(buf0 + m * ETF_LDA + part * ETF_CZ + c) = xr[u];
+    }
+  };
+  int blk = blockIdx.x;
+  request_x0((long)blk * 32);
   float bias1[3], bias2[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) { bias1[q] = a.b1[q * 128 + ncol]; bias2[q] = a.b2[q * 128 + ncol]; }
   const float biasf = a.bf[ncol];
-  float em_row = 0.f;  // lanes 0..31 of every wave: pair mask of row `lane`
-  if (lane < 32) {
-    const long p = p0 + lane;
-    if (p < n_pairs) {
-      const long bi = p / N;
-      em_row = a.res_mask[bi] * a.res_mask[(bi / N) * N + (p - bi * N)];
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 12; ++u) {
-    const int part = u >> 2, v = tid + (u & 3) * FD_THREADS, m = v >> 5, c = (v & 31) * 4;
-    *(f32x4*)(buf0 + m * ETF_LDA + part * ETF_CZ + c) = xr[u];
-  }
+  const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], b0v = a.beta[lane], b1v = a.beta[lane + 64];
+  store_x0();
   g0.store(Ws, tid);
   g1.store(Ws + ETF_WS / 4, tid);
-  __syncthreads();
   ETF_STAMP(0);
-  // layer 1: buf1 = relu(W1 x + b1)   (a layer has an even number of tiles and 36 / 72 are multiples of 3: the register and slot
-  // roles at the entry of every layer are the same)
-  etf_layer<3>(buf0, st, 0, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
-    const int n = pass * 128 + ncol;
-    const float bv = pass == 0 ? bias1[0] : (pass == 1 ? bias1[1] : bias1[2]);
+  for (; blk < n_blocks; blk += gridDim.x) {
+    const long p0 = (long)blk * 32;
+    const float em_row = em_next;
+    // layer 1: buf1 = relu(W1 x + b1)   (a layer has an even number of tiles and 36 / 72 / 84 are multiples of 3: the register and
+    // slot roles at the entry of every layer, and of every row tile, are the same)
+    etf_layer<3>(buf0, st, 0, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
+      const int n = pass * 128 + ncol;
+      const float bv = pass == 0 ? bias1[0] : (pass == 1 ? bias1[1] : bias1[2]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) buf1[c_row(r, lane) * ETF_LDA + n] = fmaxf(acc[r] + bv, 0.f);
-  });
-  ETF_STAMP(1);
-  // layer 2 (+ residual): buf0 = relu(W2 h1 + b2) + x   (in place: element-wise same-thread read-modify-write)
-  etf_layer<3>(buf1, st, 36, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
-    const int n = pass * 128 + ncol;
-    const float bv = pass == 0 ? bias2[0] : (pass == 1 ? bias2[1] : bias2[2]);
+      for (int r = 0; r < 16; ++r) buf1[c_row(r, lane) * ETF_LDA + n] = fmaxf(acc[r] + bv, 0.f);
+    });
+    ETF_STAMP(1);
+    // layer 2 (+ residual): buf0 = relu(W2 h1 + b2) + x   (in place: element-wise same-thread read-modify-write)
+    etf_layer<3>(buf1, st, 36, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
+      const int n = pass * 128 + ncol;
+      const float bv = pass == 0 ? bias2[0] : (pass == 1 ? bias2[1] : bias2[2]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* d = buf0 + c_row(r, lane) * ETF_LDA + n;
-      *d = fmaxf(acc[r] + bv, 0.f) + *d;
-    }
-  });
-  ETF_STAMP(2);
-  // final layer: y = Wf (h2 + x) + bf -> ybuf (aliases buf1, which the final layer does not read)
-  etf_layer<1>(buf0, st, 72, Ws, g2, g0, tid, [&](int, const f32x16& acc) {
+      for (int r = 0; r < 16; ++r) {
+        float* d = buf0 + c_row(r, lane) * ETF_LDA + n;
+        *d = fmaxf(acc[r] + bv, 0.f) + *d;
+      }
+    });
+    ETF_STAMP(2);
+    // the next row tile's inputs travel under the final layer
+    if (blk + (int)gridDim.x < n_blocks) request_x0((long)(blk + gridDim.x) * 32);
+    // final layer: y = Wf (h2 + x) + bf -> ybuf (aliases buf1, which the final layer does not read)
+    etf_layer<1>(buf0, st, 72, Ws, g2, g0, tid, [&](int, const f32x16& acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
-  });
-  __syncthreads();
-  ETF_STAMP(3);
-  // LayerNorm of the 32 rows (8 per wave, two columns per lane), times the pair mask, -> z
-  {
-    const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], b0v = a.beta[lane], b1v = a.beta[lane + 64];
-    ZT* z_out = (ZT*)a.z_out;
+      for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
+    });
+    __syncthreads();
+    ETF_STAMP(3);
+    store_x0();  // buf0 is free (the next layer 1 starts with a barrier)
+    // LayerNorm of the 32 rows (8 per wave, two columns per lane), times the pair mask, -> z.  The eight rows of a wave are reduced
+    // TOGETHER: every butterfly step is eight independent cross-lane exchanges in flight (row after row, the 2 x 6 dependent
+    // exchanges of a row were ~1.2 k exposed cycles each)
+    {
+      ZT* z_out = (ZT*)a.z_out;
+      float v0[8], v1[8], s1[8], s2[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int m = wc + 4 * q;
-      const long p = p0 + m;
-      const float v0 = ybuf[m * ETF_LDY + lane], v1 = ybuf[m * ETF_LDY + lane + 64];
-      const float mu = wave_sum(v0 + v1) * (1.0f / ETF_CZ);
-      const float d0 = v0 - mu, d1 = v1 - mu;
-      const float rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.0f / ETF_CZ) + 1e-5f);
-      const float em = __shfl(em_row, m, 64);
-      if (p < n_pairs) {
-        const float o0 = (d0 * rstd * g0v + b0v) * em, o1 = (d1 * rstd * g1v + b1v) * em;
-        z_store<ZT>(z_out + p * ETF_CZ + lane, o0);
-        z_store<ZT>(z_out + p * ETF_CZ + lane + 64, o1);
-        if (a.trace) { a.trace[p * ETF_CZ + lane] = o0; a.trace[p * ETF_CZ + lane + 64] = o1; }
+      for (int q = 0; q < 8; ++q) {
+        const int m = wc + 4 * q;
+        v0[q] = ybuf[m * ETF_LDY + lane];
+        v1[q] = ybuf[m * ETF_LDY + lane + 64];
+        s1[q] = v0[q] + v1[q];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s1[q] += __shfl_xor(s1[q], o, 64);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float mu = s1[q] * (1.0f / ETF_CZ);
+        v0[q] -= mu;
+        v1[q] -= mu;
+        s2[q] = v0[q] * v0[q] + v1[q] * v1[q];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s2[q] += __shfl_xor(s2[q], o, 64);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int m = wc + 4 * q;
+        const long p = p0 + m;
+        const float rstd = 1.0f / sqrtf(s2[q] * (1.0f / ETF_CZ) + 1e-5f);
+        const float em = __shfl(em_row, m, 64);
+        if (p < n_pairs) {
+          const float o0 = (v0[q] * rstd * g0v + b0v) * em, o1 = (v1[q] * rstd * g1v + b1v) * em;
+          z_store<ZT>(z_out + p * ETF_CZ + lane, o0);
+          z_store<ZT>(z_out + p * ETF_CZ + lane + 64, o1);
+          if (a.trace) { a.trace[p * ETF_CZ + lane] = o0; a.trace[p * ETF_CZ + lane + 64] = o1; }
+        }
       }
     }
+    ETF_STAMP(4);
   }
-  ETF_STAMP(4);
 #ifdef ETF_PROF
   if (tid == 0 && blockIdx.x < 256)
     for (int k = 0; k < 8; ++k) etf_prof[blockIdx.x * 8 + k] = ph[k];
@@ -537,7 +578,9 @@ static int launch_et(int precision, const EdgeTransArgs& a, hipStream_t st) {
           return FDIPT_ELAUNCH;
         attr_set = true;
       }
-      hipLaunchKernelGGL(edge_transition_f32_kernel<float>, dim3(cdiv(n_pairs, TM)), dim3(FD_THREADS), ETF_LDS, st, a);
+      const int n_blocks = (int)cdiv(n_pairs, TM);
+      hipLaunchKernelGGL(edge_transition_f32_kernel<float>, dim3(n_blocks < 256 ? n_blocks : 256), dim3(FD_THREADS), ETF_LDS, st, a,
+                         n_blocks);
     } else {
       hipLaunchKernelGGL((edge_transition_kernel<PrecF32, float, float, TM, 1, 4, CZ, CB>), dim3(cdiv(n_pairs, TM)),
                          dim3(FD_THREADS), 0, st, a);
