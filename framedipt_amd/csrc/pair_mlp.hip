@@ -260,12 +260,12 @@ struct EtfOps {
 // One layer = NP passes x 12 k-tiles, starting at stream position t0.  Weight tiles live in a ring of THREE LDS slots (tile t in
 // slot t % 3): during tile t the block multiplies from registers (operands of tile t, read during tile t - 1), reads the operands of
 // tile t + 1 (stored during tile t - 1, visible since the barrier that closed it), stores tile t + 2 (requested from L2 during
-// tile t - 1) into the slot tile t - 1 occupied, and requests tile t + 3.  Entry state: tiles t0, t0 + 1 in their slots (barrier
-// done), tile t0 + 2 in g0.  (The first tile of a layer reads its operands on entry: its activations were completed by the previous
+// tile t - 1) into the slot tile t - 1 occupied, and requests tile t + 4.  Entry state: tiles t0, t0 + 1 in their slots, tile t0 + 2
+// in g2, tile t0 + 3 in g0 (t0 a multiple of 6).  (The first tile of a layer reads its operands on entry: its activations were completed by the previous
 // layer's last epilogue.)  epi(pass, acc) runs once per pass.
 template <int NP, class Epi>
-__device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st, int t0, float* Ws0, EtfTile& g0, EtfTile& g1, int tid,
-                                          Epi epi) {
+__device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st, int t0, float* Ws0, EtfTile& g0, EtfTile& g1, EtfTile& g2,
+                                          int tid, Epi epi) {
   const int lane = tid & 63, wc = tid >> 6, hi = lane >> 5;
   const float* arow = act + (lane & 31) * ETF_LDA + 4 * hi;
   const int woff = (wc * 32 + (lane & 31)) * ETF_LDW + 4 * hi;
@@ -279,23 +279,28 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
   // instructions per gap (one wave per SIMD issues in order: whatever stands between two MFMAs is hidden only up to the 64 cycles
   // the first one runs; the first generations of this loop had loads, LDS reads, LDS stores and the barrier in three clumps and
   // lost ~600 of 1640 cycles per tile to them).  Gap 0: barrier (publishes the previous step's stores = tile t + 1); gaps 1-4: L2
-  // requests of tile t + 3; gaps 5-12: operand reads of tile t + 1; gaps 13-16 (the last one after the 16th MFMA): LDS stores of
-  // tile t + 2 (requested during the previous step).
+  // requests of tile t + 4; gaps 5-12: operand reads of tile t + 1; gaps 13-16 (the last one after the 16th MFMA): LDS stores of
+  // tile t + 2 (requested two steps earlier).  Timing ablations (tools/micro/etf_bench.hip -DETF_ABL=..., N = 300, B = 8): 4.74 ms
+  // as is; 3.93 without the LDS stores, 4.15 without the L2 requests, 3.86 without both and the barrier: what is left above the
+  // matrix work (3.15 ms) is the VGPR <-> LDS / L2 movement of the weight stream itself, not its latency.
   const int goff = ((tid >> 3) * ETF_H + (tid & 7) * 4), loff = (tid >> 3) * ETF_LDW + (tid & 7) * 4;
   auto step = [&](int tl, EtfOps& cur, EtfOps& nxt, EtfTile& gs, EtfTile& gl) {
     const int t = t0 + tl, kt = tl % 12;
-    const float* src = st.ptr(t + 3) + goff;
+    const float* src = st.ptr(t + 4) + goff;
     const float* an = arow + ((kt + 1) % 12) * 32;
     const float* wn = Ws0 + ((t + 1) % 3) * (ETF_WS / 4) + woff;
     float* wd = Ws0 + ((t + 2) % 3) * (ETF_WS / 4) + loff;  // (beyond the stream: a free slot nobody reads)
 #define ETF_MMA(i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[(i) >> 2][(i) & 3], cur.w[(i) >> 2][(i) & 3], acc, 0, 0, 0); \
                    __builtin_amdgcn_sched_barrier(0)
 #define ETF_GAP(...) __VA_ARGS__; __builtin_amdgcn_sched_barrier(0)
-    ETF_MMA(0);  ETF_GAP(__syncthreads());
-    ETF_MMA(1);  ETF_GAP(gl.r[0] = *(const f32x4*)(src));
-    ETF_MMA(2);  ETF_GAP(gl.r[1] = *(const f32x4*)(src + 32 * ETF_H));
-    ETF_MMA(3);  ETF_GAP(gl.r[2] = *(const f32x4*)(src + 64 * ETF_H));
-    ETF_MMA(4);  ETF_GAP(gl.r[3] = *(const f32x4*)(src + 96 * ETF_H));
+#ifndef ETF_ABL
+#define ETF_ABL 0  // timing ablations of tools/micro/etf_bench.hip (results are wrong with any bit set)
+#endif
+    ETF_MMA(0);  ETF_GAP(if (!(ETF_ABL & 1)) __syncthreads());
+    ETF_MMA(1);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[0] = *(const f32x4*)(src));
+    ETF_MMA(2);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[1] = *(const f32x4*)(src + 32 * ETF_H));
+    ETF_MMA(3);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[2] = *(const f32x4*)(src + 64 * ETF_H));
+    ETF_MMA(4);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[3] = *(const f32x4*)(src + 96 * ETF_H));
     ETF_MMA(5);  ETF_GAP(nxt.a[0] = *(const f32x4*)(an));
     ETF_MMA(6);  ETF_GAP(nxt.w[0] = *(const f32x4*)(wn));
     ETF_MMA(7);  ETF_GAP(nxt.a[1] = *(const f32x4*)(an + 8));
@@ -304,10 +309,10 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
     ETF_MMA(10); ETF_GAP(nxt.w[2] = *(const f32x4*)(wn + 16));
     ETF_MMA(11); ETF_GAP(nxt.a[3] = *(const f32x4*)(an + 24));
     ETF_MMA(12); ETF_GAP(nxt.w[3] = *(const f32x4*)(wn + 24));
-    ETF_MMA(13); ETF_GAP(*(f32x4*)(wd) = gs.r[0]);
-    ETF_MMA(14); ETF_GAP(*(f32x4*)(wd + 32 * ETF_LDW) = gs.r[1]);
-    ETF_MMA(15); ETF_GAP(*(f32x4*)(wd + 64 * ETF_LDW) = gs.r[2]);
-    ETF_GAP(*(f32x4*)(wd + 96 * ETF_LDW) = gs.r[3]);
+    ETF_MMA(13); ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd) = gs.r[0]);
+    ETF_MMA(14); ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd + 32 * ETF_LDW) = gs.r[1]);
+    ETF_MMA(15); ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd + 64 * ETF_LDW) = gs.r[2]);
+    ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd + 96 * ETF_LDW) = gs.r[3]);
 #undef ETF_MMA
 #undef ETF_GAP
     if (kt == 11) {
@@ -316,9 +321,14 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
   };
-  for (int tl = 0; tl < NP * 12; tl += 2) {
-    step(tl, o0, o1, g0, g1);
-    step(tl + 1, o1, o0, g1, g0);
+  // register roles: G[k] carries the tiles with index = k (mod 3): step t stores G[(t + 2) % 3] and re-loads G[(t + 1) % 3]
+  for (int tl = 0; tl < NP * 12; tl += 6) {
+    step(tl, o0, o1, g2, g1);
+    step(tl + 1, o1, o0, g0, g2);
+    step(tl + 2, o0, o1, g1, g0);
+    step(tl + 3, o1, o0, g2, g1);
+    step(tl + 4, o0, o1, g0, g2);
+    step(tl + 5, o1, o0, g1, g0);
   }
 }
 
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
   EtfTile g0, g1, g2;
   st.load(g0, 0, tid);
   st.load(g1, 1, tid);
-  st.load(g2, 2, tid);
+  st.load(g2, 2, tid);  // (entry state of a layer / row tile: G[2] = tile t0 + 2, G[0] = tile t0 + 3, both possibly still in flight)
   f32x4 xr[12];
   float em_next = 0.f;
   auto request_x0 = [&](long p0) {
@@ -394,13 +404,14 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
   store_x0();
   g0.store(Ws, tid);
   g1.store(Ws + ETF_WS / 4, tid);
+  st.load(g0, 3, tid);
   ETF_STAMP(0);
   for (; blk < n_blocks; blk += gridDim.x) {
     const long p0 = (long)blk * 32;
     const float em_row = em_next;
     // layer 1: buf1 = relu(W1 x + b1)   (a layer has an even number of tiles and 36 / 72 / 84 are multiples of 3: the register and
     // slot roles at the entry of every layer, and of every row tile, are the same)
-    etf_layer<3>(buf0, st, 0, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
+    etf_layer<3>(buf0, st, 0, Ws, g0, g1, g2, tid, [&](int pass, const f32x16& acc) {
       const int n = pass * 128 + ncol;
       const float bv = pass == 0 ? bias1[0] : (pass == 1 ? bias1[1] : bias1[2]);
 #pragma unroll
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
     });
     ETF_STAMP(1);
     // layer 2 (+ residual): buf0 = relu(W2 h1 + b2) + x   (in place: element-wise same-thread read-modify-write)
-    etf_layer<3>(buf1, st, 36, Ws, g2, g0, tid, [&](int pass, const f32x16& acc) {
+    etf_layer<3>(buf1, st, 36, Ws, g0, g1, g2, tid, [&](int pass, const f32x16& acc) {
       const int n = pass * 128 + ncol;
       const float bv = pass == 0 ? bias2[0] : (pass == 1 ? bias2[1] : bias2[2]);
 #pragma unroll
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
     // the next row tile's inputs travel under the final layer
     if (blk + (int)gridDim.x < n_blocks) request_x0((long)(blk + gridDim.x) * 32);
     // final layer: y = Wf (h2 + x) + bf -> ybuf (aliases buf1, which the final layer does not read)
-    etf_layer<1>(buf0, st, 72, Ws, g2, g0, tid, [&](int, const f32x16& acc) {
+    etf_layer<1>(buf0, st, 72, Ws, g0, g1, g2, tid, [&](int, const f32x16& acc) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
     });
