@@ -419,8 +419,10 @@ __global__ __launch_bounds__(FD_THREADS) void opair_kernel(OPairArgs a) {
 // from LDS).  Wave w owns channels 32w..32w+31.  The tail (sum_j a, down_z projection) is the VALU code of opair_kernel.
 #define OM_JC 64                    // keys per chunk
 #define OM_ZROW (OM_JC * 2 + 16)    // bytes per Zt row (16 lanes of a b128 read hit 16 distinct slots)
-// OM_NK: 16-key row groups per thread (all of a row's z pieces are requested up front): 20 -> N <= 320, two blocks per CU;
-// 64 -> N <= 1024, one block per CU
+// OM_NK: 16-key row groups per thread (all of a row's z pieces of one PASS are requested up front): 20 -> N <= 320, two blocks per
+// CU.  NH passes over the key range (round 2): longer rows are taken in two passes of 32 groups (N <= 1024) so that the pieces of a
+// pass fit 128 registers and TWO blocks share a CU and overlap each other's memory round trips - a single 64-group pass (256
+// registers, one block per CU) streamed z at 2.7 TB/s at N = 724.
 template <int N_, class F>
 __device__ __forceinline__ void om_for(F&& f) {
   if constexpr (N_ > 0) {
@@ -428,7 +430,7 @@ __device__ __forceinline__ void om_for(F&& f) {
     f(std::integral_constant<int, N_ - 1>{});
   }
 }
-template <int OM_NK, int LB>
+template <int OM_NK, int LB, int NH = 1>
 __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a, int Np) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CZ = 128, H = 8, CD = 32;
@@ -446,12 +448,15 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
   // requested up front (one memory round trip per block); zr[2 m + w] = key 2 jp + w
   const int cg = tid & 15, jl0 = tid >> 4;
   u16x8 zr[OM_NK];
+  auto request = [&](int pass) {
 #pragma unroll
-  for (int k = 0; k < OM_NK; ++k) {
-    const int j = 2 * (jl0 + 16 * (k >> 1)) + (k & 1);
-    zr[k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (j < N) zr[k] = *(const u16x8*)(zrow + (long)j * CZ + 8 * cg);
-  }
+    for (int k = 0; k < OM_NK; ++k) {
+      const int j = pass * (OM_NK * 16) + 2 * (jl0 + 16 * (k >> 1)) + (k & 1);
+      zr[k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (j < N) zr[k] = *(const u16x8*)(zrow + (long)j * CZ + 8 * cg);
+    }
+  };
+  request(0);
   // down_z as B fragments (wave 0 only): requested now, used at the very end
   hx8 wdf[8];
   if (wave == 0)
@@ -497,28 +502,36 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
         *(unsigned*)(dst + (16 * e + cg) * OM_ZROW + 4 * (jl0 + 16 * m)) =
             (unsigned)zr[4 * ch + 2 * m][e] | ((unsigned)zr[4 * ch + 2 * m + 1][e] << 16);
   };
-  scatter(std::integral_constant<int, 0>{}, 0);
-  __syncthreads();
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const char* arow = pb + (li < 8 ? li : 0) * prow + 16 * hi;  // A fragment source: row = head (lanes >= 8: zero)
-  auto chunk = [&](auto CH) {
-    constexpr int ch = decltype(CH)::value;
-    if (ch < nch) {
-      const char* zs = zt + (ch & 1) * CZ * OM_ZROW + (32 * wave + li) * OM_ZROW + 16 * hi;
 #pragma unroll
-      for (int s = 0; s < OM_JC / 16; ++s) {
-        u16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (li < 8) af = *(const u16x8*)(arow + 2 * (ch * OM_JC + 16 * s));
-        const u16x8 bfr = *(const u16x8*)(zs + 32 * s);
-        acc = fd_mfma32(__builtin_bit_cast(hx8, af), __builtin_bit_cast(hx8, bfr), acc);
-      }
-      if (ch + 1 < nch) scatter(std::integral_constant<int, (ch + 1 < OM_NK / 4 ? ch + 1 : 0)>{}, (ch + 1) & 1);
-      __syncthreads();
+  for (int pass = 0; pass < NH; ++pass) {
+    if (pass > 0) {
+      if (pass * (OM_NK / 4) >= nch) break;
+      request(pass);
     }
-  };
-  om_for<OM_NK / 4>(chunk);
+    const int ch0 = pass * (OM_NK / 4);  // first chunk of the pass (the slots alternate on the chunk index inside the pass)
+    scatter(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+    auto chunk = [&](auto CH) {
+      constexpr int ch = decltype(CH)::value;
+      if (ch0 + ch < nch) {
+        const char* zs = zt + (ch & 1) * CZ * OM_ZROW + (32 * wave + li) * OM_ZROW + 16 * hi;
+#pragma unroll
+        for (int s = 0; s < OM_JC / 16; ++s) {
+          u16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (li < 8) af = *(const u16x8*)(arow + 2 * ((ch0 + ch) * OM_JC + 16 * s));
+          const u16x8 bfr = *(const u16x8*)(zs + 32 * s);
+          acc = fd_mfma32(__builtin_bit_cast(hx8, af), __builtin_bit_cast(hx8, bfr), acc);
+        }
+        if (ch + 1 < OM_NK / 4 && ch0 + ch + 1 < nch) scatter(std::integral_constant<int, (ch + 1 < OM_NK / 4 ? ch + 1 : 0)>{}, (ch + 1) & 1);
+        __syncthreads();
+      }
+    };
+    om_for<OM_NK / 4>(chunk);
+  }
   // D[h, Zt row]: lane (row 32 wave + li, hi) holds heads 4 hi + r in registers r < 4; row 16 e + cg = channel 8 cg + e
   {
     const int zrow_i = 32 * wave + li, ch_i = 8 * (zrow_i & 15) + (zrow_i >> 4);
@@ -575,8 +588,12 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
     const int Np = (a.N + OM_JC - 1) / OM_JC * OM_JC;
     const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4;
     if (a.N <= 320) hipLaunchKernelGGL((opair_mfma_kernel<20, 2>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
-    else if (a.N <= 640) hipLaunchKernelGGL((opair_mfma_kernel<40, 1>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
-    else hipLaunchKernelGGL((opair_mfma_kernel<64, 1>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+#ifndef OM_MID
+#define OM_MID 0
+#endif
+    else if (a.N <= 512 && OM_MID) hipLaunchKernelGGL((opair_mfma_kernel<32, 2, 1>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+    else if (a.N <= 640 && !OM_MID) hipLaunchKernelGGL((opair_mfma_kernel<40, 1>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+    else hipLaunchKernelGGL((opair_mfma_kernel<32, 2, 2>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
     FD_CHECK_LAUNCH();
     return FDIPT_OK;
   }
