@@ -18,6 +18,10 @@ python "$ROOT/bench.py" --samples-per-gpu 24 --no-cpu-baseline > "$OUT/bench_c4_
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_prof.log" 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 [ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats.md" > /dev/null
+# config 5 (fp32 mode, N = 1000): kernel table of the parity mode's heaviest configuration
+rm -rf /tmp/prof_c5 && rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -- python "$ROOT/bench.py" --config c5 --no-cpu-baseline > "$OUT/bench_c5_prof.log" 2>&1
+DB=$(find /tmp/prof_c5 -name "*.db" | head -1)
+[ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats_c5.md" > /dev/null
 for spec in "FETCH:FETCH_SIZE" "WRITE:WRITE_SIZE" "MFMA:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=${spec%%:*}; ctr=${spec#*:}
   rm -rf /tmp/prof_$tag

@@ -6,7 +6,7 @@ import sys
 import pandas as pd
 
 
-def main(path, top=12):
+def main(path, top=24):
     df = pd.read_csv(path)
     df["k"] = df["Kernel_Name"].map(lambda s: re.sub(r"\(.*", "", s).replace("void ", "")[:70])
     g = df.groupby(["k", "Counter_Name"])["Counter_Value"].agg(["count", "mean"]).reset_index()

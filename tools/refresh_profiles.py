@@ -49,6 +49,15 @@ open(P + "r02_bench_c4_fp16_kernel_stats.md", "w").write(
     f"`__amd_rocclr_copyBuffer`, included).  edge_transition4_kernel: {et_us:.1f} us average here vs {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us\n"
     "from the HIP events of the bench's timed region.\n\n" + open(d + "kernel_stats.md").read())
 
+if os.path.exists(d + "kernel_stats_c5.md"):
+    c5 = json.load(open(d + "bench_c5.json"))
+    open(P + "r02_bench_c5_fp32_kernel_stats.md", "w").write(
+        "# Round 2 — `rocprofv3 --kernel-trace --stats -- python bench.py --config c5 --no-cpu-baseline` (1 x MI355X, config c5: fp32 mode, N = 1000, B = 4)\n\n"
+        f"Bench line of the same configuration: {c5['value']:.0f} residue*step/s, {c5['ms_per_step']:.1f} ms per step; `edge_transition_f32_kernel` "
+        f"{c5['roofline']['avg_launch_ms']:.2f} ms per launch = {c5['roofline']['frac'] * 100:.1f} % of the 157.3 TFLOP/s fp32 matrix peak (`v_mfma_f32_32x32x2_f32`; "
+        "round 1: 51 ms = 34 %).\n\n" + open(d + "kernel_stats_c5.md").read())
+
+fetch_ee = next((f"2 x {F[k] * 1024 / 1e6:.0f} MB" for k in F if k.startswith(EE)), "below the ten largest of the step")
 hdr = f"""# Round 2 — PMC counters of the bench command (MI355X, config c4: fp16 mode, N=300, B=8)
 
 Separate passes as MI355X_MICROARCH.md prescribes (never combined with sys/hip tracing; tools/collect_profiles.sh):
@@ -86,8 +95,8 @@ attention GEMMs"
 
 ## HBM-bound passes
 * `opair_mfma_kernel`: 196.8 MB in {kst[key(kst, OP)]:.1f} us = {2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6:.2f} TB/s ({2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6 / 8 * 100:.0f} % of the 8 TB/s peak, {2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6 / 6.3 * 100:.0f} % of the 6.3 TB/s achievable).
-* `edge_embed2_kernel`: 207 MB written in {kst[key(kst, EE)]:.1f} us = {W[key(W, EE)] * 1024 / kst[key(kst, EE)] / 1e6:.2f} TB/s; MFMA utilisation {util[key(util, EE)] * 100:.1f} % (47 GF): bound by neither,
-  its four-row table gather per pair (2 KB through L2 -> LDS) is the next thing to restructure.
+* `edge_embed2_kernel`: 207 MB written in {kst[key(kst, EE)]:.1f} us = {W[key(W, EE)] * 1024 / kst[key(kst, EE)] / 1e6:.2f} TB/s; MFMA utilisation {util[key(util, EE)] * 100:.1f} % (47 GF): bound by neither
+  (since the row-walk decomposition of round 2 its table rows come out of L2 / LDS: FETCH_SIZE {fetch_ee}; phase profile in DESIGN.md section 4.4).
 
 ## MFMA utilisation of every kernel with matrix work
 | kernel | us per launch | MFMA busy cycles | utilisation |
