@@ -143,32 +143,35 @@ __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K,
 // Split-K variant for the "long K, few columns" products (IPA output projection: M = B*N rows, N = c_s, K = 2688): the
 // 64 x 64 tile grid alone is ~150 blocks of 42 dependent k-iterations each; blockIdx.z takes a K slice and writes its
 // partial product to parts[z] (bias added by slice 0, row mask by every slice) - the LayerNorm that follows sums them.
-template <class P, class AT, class WT>
+template <class P, class AT, class WT, int BN = 64>
 __global__ __launch_bounds__(FD_THREADS) void linear_splitk_kernel(int M, int N, int K, int kslice, const AT* __restrict__ A,
                                                                    int lda, const WT* __restrict__ W, int ldw,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ rowmask,
                                                                    float* __restrict__ parts, long part_stride, int ldo) {
-  constexpr int BM = 64, BN = 64;
-  extern __shared__ __attribute__((aligned(16))) char splitk_smem[];  // 2 * (BM + BN) * LDT elements (dynamic: 68 KB with split operands)
+  constexpr int BM = 64, TN = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char splitk_smem[];  // 2 * (BM + BN) * LDT elements (dynamic: 68 / 102 KB with split operands)
   typename P::T* smem = (typename P::T*)splitk_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
   const int k0 = z * kslice, klen = K - k0 < kslice ? K - k0 : kslice;
-  f32x16 acc[1][1];
+  f32x16 acc[1][TN];
   gemm_tile<P, AT, WT, BM, BN>(acc, M, N, klen, A + k0, lda, W + k0, ldw, smem, m0, n0, tid);
-  const int n = n0 + wc * 32 + (lane & 31);
-  if (n >= N) return;
-  const float bv = (bias && z == 0) ? bias[n] : 0.f;
   float* out = parts + z * part_stride;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wr * 32 + c_row(r, lane);
-    if (m < M) {
-      float v = acc[0][0][r] + bv;
-      if (rowmask) v *= rowmask[m];
-      out[(long)m * ldo + n] = v;
+  for (int jn = 0; jn < TN; ++jn) {
+    const int n = n0 + (wc * TN + jn) * 32 + (lane & 31);
+    if (n >= N) continue;
+    const float bv = (bias && z == 0) ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wr * 32 + c_row(r, lane);
+      if (m < M) {
+        float v = acc[0][jn][r] + bv;
+        if (rowmask) v *= rowmask[m];
+        out[(long)m * ldo + n] = v;
+      }
     }
   }
 }
@@ -508,14 +511,19 @@ int fd_linear_splitk_split(int M, int N, int K, int nsplit, const float* A, int 
   if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 3) || (ldw & 3)) return FDIPT_EINVAL;
   const int kslice = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
   if ((long)kslice * (nsplit - 1) >= K) return FDIPT_EINVAL;  // an empty slice
-  constexpr size_t smem = (size_t)2 * 128 * (64 * PrecSplit::LDMUL + PrecSplit::PAD) * sizeof(half_t);
+  // (128-column blocks - the fp32 A tile read and split by two column blocks instead of four - measured 38 us against 30: 228 blocks)
+#ifndef FD_SPLITK_BN
+#define FD_SPLITK_BN 64
+#endif
+  constexpr int BN = (FD_SPLITK_BN);
+  constexpr size_t smem = (size_t)2 * (64 + BN) * (64 * PrecSplit::LDMUL + PrecSplit::PAD) * sizeof(half_t);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)linear_splitk_kernel<PrecSplit, float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)linear_splitk_kernel<PrecSplit, float, float, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return FDIPT_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((linear_splitk_kernel<PrecSplit, float, float>), dim3(cdiv(M, 64), cdiv(N, 64), nsplit), dim3(FD_THREADS), smem,
+  hipLaunchKernelGGL((linear_splitk_kernel<PrecSplit, float, float, BN>), dim3(cdiv(M, 64), cdiv(N, BN), nsplit), dim3(FD_THREADS), smem,
                      st, M, N, K, kslice, A, lda, W, ldw, bias, rowmask, parts, part_stride, ldo);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
