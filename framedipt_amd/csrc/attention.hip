@@ -634,7 +634,7 @@ __global__ void points_kernel(PointsArgs a) {
     const float gx = R[0] * px + R[1] * py + R[2] * pz + tx;
     const float gy = R[3] * px + R[4] * py + R[5] * pz + ty;
     const float gz = R[6] * px + R[7] * py + R[8] * pz + tz;
-    dst[0] = gx; dst[1] = gy; dst[2] = gz;
+    fd_store3(dst, gx, gy, gz);
     if (a.vpt && p >= HPq) {
       const int pp2 = p - HPq, hh = pp2 / Pkv, e = pp2 % Pkv;
       if (e >= a.Pq) {  // a value point: coordinates 3 (e - Pq) + {0,1,2} of head hh, key = residue index in its sample
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
         }
       }
     }
-    dst[0] = g3[0]; dst[1] = g3[1]; dst[2] = g3[2];
+    fd_store3(dst, g3[0], g3[1], g3[2]);  // (not one dwordx3 store: common.hpp)
   }
   __syncthreads();
   const int ks = a.Np >> 4;

@@ -147,13 +147,13 @@ __device__ __forceinline__ void d_backbone_residue(long r, const float* Rb, cons
   }
   if (atom14)
     for (int at = 0; at < 14; ++at)
-      for (int c = 0; c < 3; ++c) atom14[(r * 14 + at) * 3 + c] = pos[at][c];
+      for (int c = 0; c < 3; ++c) fd_st(atom14 + (r * 14 + at) * 3 + c, pos[at][c]);
   if (atom37) {
-    for (int c = 0; c < 37 * 3; ++c) atom37[r * 111 + c] = 0.f;
+    for (int c = 0; c < 37 * 3; ++c) fd_st(atom37 + r * 111 + c, 0.f);
     // atom14 order N,CA,C,O,CB -> atom37 order N,CA,C,CB,O (all_atom.py:168-174)
     const int map[5] = {0, 1, 2, 4, 3};
     for (int at = 0; at < 5; ++at)
-      for (int c = 0; c < 3; ++c) atom37[r * 111 + at * 3 + c] = pos[map[at]][c];
+      for (int c = 0; c < 3; ++c) fd_st(atom37 + r * 111 + at * 3 + c, pos[map[at]][c]);
   }
 }
 
@@ -297,21 +297,21 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
     float Rf[9];
     for (int c = 0; c < 9; ++c) Rf[c] = (float)Ro[c];
     if (a.out_rot)
-      for (int c = 0; c < 9; ++c) a.out_rot[r * 9 + c] = Rf[c];
+      for (int c = 0; c < 9; ++c) fd_st(a.out_rot + r * 9 + c, Rf[c]);
     double Rd[9], q[4];
     for (int c = 0; c < 9; ++c) Rd[c] = (double)Rf[c];
     d_markley(Rd, q);  // rot_to_quat (rigid_utils.py:208-227) up to sign; consumers are sign-invariant
     if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
     float* o = a.rigids_out + r * 7;
-    o[0] = (float)q[3]; o[1] = (float)q[0]; o[2] = (float)q[1]; o[3] = (float)q[2];
-    o[4] = (float)tr_out[0]; o[5] = (float)tr_out[1]; o[6] = (float)tr_out[2];
+    fd_st(o, (float)q[3]); fd_st(o + 1, (float)q[0]); fd_st(o + 2, (float)q[1]); fd_st(o + 3, (float)q[2]);
+    fd_st(o + 4, (float)tr_out[0]); fd_st(o + 5, (float)tr_out[1]); fd_st(o + 6, (float)tr_out[2]);
     if (a.atom37) {
       const float tf[3] = {o[4], o[5], o[6]};
       d_backbone_residue(r, Rf, tf, a.psi, a.aatype, a.tables, a.atom37, nullptr);
     }
     if (a.trans_traj) {
       const float dm = a.diffuse_mask ? a.diffuse_mask[r] : 1.f, fm = a.traj_fixed[r];
-      for (int c = 0; c < 3; ++c) a.trans_traj[r * 3 + c] = dm * a.pred_rigids[r * 7 + 4 + c] + fm * o[4 + c];
+      for (int c = 0; c < 3; ++c) fd_st(a.trans_traj + r * 3 + c, dm * a.pred_rigids[r * 7 + 4 + c] + fm * o[4 + c]);
     }
   }
 }
@@ -421,14 +421,14 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
     const int c = sub - 3;
     const float x0u = x.trans[r * 3 + c] / x.cs;
     x.rigids[r * 7 + 4 + c] = x0u;
-    if (x.ca_out) x.ca_out[r * 3 + c] = x0u;
+    if (x.ca_out) fd_st(x.ca_out + r * 3 + c, x0u);
     const float tt = x.t[b];
     const float mb = tt * x.min_b + 0.5f * (tt * tt) * (x.max_b - x.min_b);
     const float e = expf(-0.5f * mb);
     const float cv = 1.f - expf(-mb);
     const float m = res_mask ? res_mask[r] : 1.f;
     const float xt = quats_t[r * ld_t + 4 + c] * x.cs, x0 = x0u * x.cs;  // rigids_t is tensor_7: translations behind the quaternion
-    x.trans_score[r * 3 + c] = -(xt - e * x0) / cv * m;
+    fd_st(x.trans_score + r * 3 + c, -(xt - e * x0) / cv * m);
   } else if (sub >= 6 && sub < 10) {
     x.rigids[r * 7 + sub - 6] = quats_0[r * ld_0 + sub - 6];
   } else if (sub == 10) {
@@ -454,7 +454,7 @@ __global__ void trans_score_kernel(int B, int N, const float* __restrict__ trans
   const float m = res_mask ? res_mask[r] : 1.f;
   for (int c = 0; c < 3; ++c) {
     const float xt = trans_t[r * ld_t + c] * cs, x0 = trans_0[r * ld_0 + c] * cs;
-    score[r * 3 + c] = -(xt - e * x0) / cv * m;
+    fd_st(score + r * 3 + c, -(xt - e * x0) / cv * m);
   }
 }
 
@@ -493,7 +493,7 @@ __global__ void compose_q_update_kernel(long n, float* __restrict__ quat, float*
   for (int c = 0; c < 4; ++c) nq[c] = q[c] + dq[c] * m;
   const float nrm = sqrtf(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
   for (int c = 0; c < 4; ++c) quat[r * 4 + c] = nq[c] / nrm;
-  for (int c = 0; c < 3; ++c) trans[r * 3 + c] = trans[r * 3 + c] + dt[c] * m;
+  for (int c = 0; c < 3; ++c) fd_st(trans + r * 3 + c, trans[r * 3 + c] + dt[c] * m);
 }
 
 int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask,
@@ -510,7 +510,7 @@ __global__ void split_rigids_kernel(long n, const float* __restrict__ t7, float 
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   for (int c = 0; c < 4; ++c) quat[r * 4 + c] = t7[r * 7 + c];
-  for (int c = 0; c < 3; ++c) trans[r * 3 + c] = t7[r * 7 + 4 + c] * cs;
+  for (int c = 0; c < 3; ++c) fd_st(trans + r * 3 + c, t7[r * 7 + 4 + c] * cs);
   diffuse_mask[r] = (1.f - fixed_mask[r]) * res_mask[r];
 }
 int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,
@@ -530,7 +530,7 @@ __global__ void finish_kernel(long n, const float* __restrict__ quat, const floa
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   for (int c = 0; c < 4; ++c) rigids[r * 7 + c] = quat[r * 4 + c];
-  for (int c = 0; c < 3; ++c) rigids[r * 7 + 4 + c] = trans[r * 3 + c] / cs;
+  for (int c = 0; c < 3; ++c) fd_st(rigids + r * 7 + 4 + c, trans[r * 3 + c] / cs);
   const float a = psi_un[r * ld_psi], bq = psi_un[r * ld_psi + 1];
   const float den = sqrtf(fmaxf(a * a + bq * bq, 1e-8f));
   const float dm = 1.f - fixed_mask[r];
@@ -1009,16 +1009,16 @@ __global__ void se3_forward_step_kernel(long n, const float* __restrict__ rot_1,
   d_so3_exp(rvt, Ro);
   float Rf[9];
   for (int c = 0; c < 9; ++c) Rf[c] = (float)Ro[c];
-  for (int c = 0; c < 9; ++c) rot_out[r * 9 + c] = Rf[c];
-  for (int c = 0; c < 3; ++c) trans_out[r * 3 + c] = tr[c];
+  for (int c = 0; c < 9; ++c) fd_st(rot_out + r * 9 + c, Rf[c]);
+  for (int c = 0; c < 3; ++c) fd_st(trans_out + r * 3 + c, tr[c]);
   if (t7_out) {  // Rigid.to_tensor_7 (rot_to_quat up to sign, as in the reverse step)
     double Rd[9], q[4];
     for (int c = 0; c < 9; ++c) Rd[c] = (double)Rf[c];
     d_markley(Rd, q);
     if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
     float* o = t7_out + r * 7;
-    o[0] = (float)q[3]; o[1] = (float)q[0]; o[2] = (float)q[1]; o[3] = (float)q[2];
-    o[4] = tr[0]; o[5] = tr[1]; o[6] = tr[2];
+    fd_st(o, (float)q[3]); fd_st(o + 1, (float)q[0]); fd_st(o + 2, (float)q[1]); fd_st(o + 3, (float)q[2]);
+    fd_st(o + 4, tr[0]); fd_st(o + 5, tr[1]); fd_st(o + 6, tr[2]);
   }
 }
 

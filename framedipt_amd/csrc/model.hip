@@ -10,6 +10,7 @@
 
 #include <vector>
 
+#include <cstdio>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -35,6 +36,8 @@ struct Switches {
   unsigned split_mask = 63u;    // split operands per layer group: 1 node embedder, 2 output projection, 4 in_proj, 8 tails, 16 transition, 32 torsion
   unsigned chain_mask = 0xFC9u;  // fused chain kinds (chain.hip) that beat the launches they replace (profiles/r01_chain_vs_gemm.md)
   const char* twice = nullptr;   // timing aid: repeat the named launches (the second one runs on a warm L2)
+  unsigned rb_mask = 31u;        // (dev) row-block kernels per use: 1 node embedder, 2 transformer tails, 4 transition, 8 torsion head, 16 sequence attention images
+  int ipa_stop = 0;              // (dev) fdipt_ipa_attention_fwd returns after 1: pair bias, 2: attention, 3: o_pair (concurrency bisection)
 };
 static const Switches& dev_switches() {
   static const Switches sw = [] {
@@ -52,6 +55,8 @@ static const Switches& dev_switches() {
     if (const char* m = getenv("FDIPT_CHAIN_MASK")) s.chain_mask = (unsigned)strtoul(m, nullptr, 0);
     s.twice = getenv("FDIPT_DBG_TWICE");
     if (const char* m = getenv("FDIPT_SPLITK_NS")) s.splitk_ns = atoi(m);
+    if (const char* m = getenv("FDIPT_IPA_STOP")) s.ipa_stop = atoi(m);
+    if (const char* m = getenv("FDIPT_RB_MASK")) s.rb_mask = (unsigned)strtoul(m, nullptr, 0);
     if (const char* m = getenv("FDIPT_SPLIT_MASK")) s.split_mask = (unsigned)strtoul(m, nullptr, 0);
 #endif
     return s;
@@ -527,6 +532,15 @@ size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N) {
   build_inventory(dims, iv);
   build_layout(dims, iv, L);
   build_ws(dims, iv, L, B, N, w);
+#ifdef FDIPT_DEV
+  if (getenv("FDIPT_DUMP_LAYOUT")) {  // (dev) workspace layout for buffer-level diffs (tools/conc_victim_check.py)
+    const char* names[] = {"node_feat", "pte", "pi", "pj", "h_a", "h_b", "node0", "node", "z", "quat", "trans", "dmask", "rot", "proj", "qp", "kp", "vp",
+                           "bias", "probs", "feats", "ipa_out", "tf_in", "qkv", "att", "x_a", "x_b", "ff", "e", "upd", "psi_un", "a1", "af", "qb", "kb",
+                           "vt", "pts", "seqimg", "ipa_parts", "e_bf", "vpt", "r4", "a1img", "b1img", "skip_all", "total"};
+    const size_t* offs = &w.node_feat;
+    for (int i = 0; i < 45; ++i) fprintf(stderr, "FDIPT_LAYOUT %s %zu\n", names[i], offs[i]);
+  }
+#endif
   return w.total;
 }
 
@@ -654,7 +668,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
                     L.kn_pad, F(w.pte), L.d1_pad, feats_fused ? a->rigids_t : nullptr, res_mask, d->coordinate_scaling, F(w.quat),
                     F(w.trans), F(w.dmask), (const float*)(D + L.w1i), (const float*)(D + L.w1j), (const float*)(D + L.b1), cz,
                     feats_fused ? F(w.pi) : nullptr, F(w.pj), st));
-  if (rbk && (L.kn_pad == 72 || L.kn_pad == 88)) {
+  if (rbk && (sw.rb_mask & 1u) && (L.kn_pad == 72 || L.kn_pad == 88)) {
     if (split_embed) { rb_l0 = D + L.lo_ne0; rb_l1 = D + L.lo_ne2; rb_l2 = D + L.lo_ne4; }
     RC(rblock(split_embed ? (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72_SPLIT : FD_RB_NODE_EMBED_88_SPLIT)
                     : (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88), F(w.node_feat), L.kn_pad, D + L.ch_ne0, P + iv.ne0.b,
@@ -731,7 +745,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   const char* dbg_twice = sw.twice;  // timing aid: repeat the named launches (second one runs on a warm L2)
 #define TWICE(name, call) do { RC(call); if (dbg_twice && strstr(dbg_twice, name)) RC(call); } while (0)
   const bool warm_all = !sw.no_l2_warm;  // L2 warm-up hand-over between consecutive launches (common.hpp)
-  const bool seq_fused = rbk && !sw.generic_attn && !sw.no_qkv_fuse && !sw.no_seq_attn &&
+  const bool seq_fused = rbk && (sw.rb_mask & 16u) && !sw.generic_attn && !sw.no_qkv_fuse && !sw.no_seq_attn &&
                          fd_seq_attention_supported(N, d->tfmr_heads, iv.d_t / d->tfmr_heads) &&
                          fd_seq_qkv_supported(N, d->tfmr_heads, iv.d_t);
   bool bias_ready = ee_bias_done;  // pair bias of this block's attention already written (tiled order) by the embedder / EdgeTransition
@@ -790,6 +804,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       if (op.kind == OP_POINTS) return FD_STOP;
       if (!bias_ready)  // blocks >= 1: already emitted by the previous block's EdgeTransition epilogue
         RC(fd_pair_bias2(B, N, H, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), 1, st));
+      if (op.kind == OP_IPA && sw.ipa_stop == 1) return FD_STOP;
       // the attention weights go to the MFMA o_pair kernel as bf16 rows [b, i, h, Np] (half the bytes, no conversion pass;
       // the fp32 buffer is reused: B N H Np bf16 <= B H N N fp32); FDIPT_PROBS_F32 keeps the fp32 [B,H,N,N] hand-over
       // ... and both kernels write the attention features as bf16 rows when the output projection is the bf16 split-K GEMM
@@ -820,7 +835,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
       RC(fd_attention(prec, 1, aa, st));
     }
+    if (op.kind == OP_IPA && sw.ipa_stop == 2) return FD_STOP;
     TWICE("opair", fd_opair(prec, oa, st));
+    if (op.kind == OP_IPA && sw.ipa_stop == 3) return FD_STOP;
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
     if (op.kind == OP_IPA) {  // per-op entry: linear_out(features) * mask as one GEMM (the forward sums split-K slices in its LayerNorm)
       RC(lin(R, k.out, F(w.feats), iv.feat_dim, nullptr, 0, res_mask, 0, F(w.ipa_out), cs));
@@ -873,7 +890,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         // ... and touches the weights of the layer's tail kernel, launched next (common.hpp: L2 warm-up hand-over)
         const unsigned wimg = (unsigned)fd_chain_image_bytes(dt, dt);
         L2Warm wt = {{D + db.ch.outp[l], D + db.ch.l1[l], D + db.ch.l2n[l]}, {wimg, wimg, wimg}};
-        const bool warm_on = rbk && !sw.no_tfmr_tail && warm_all;
+        const bool warm_on = rbk && (sw.rb_mask & 2u) && !sw.no_tfmr_tail && warm_all;
         TWICE("sattn", fd_seq_attention_run(B, N, d->tfmr_heads, W + w.seqimg, F(w.att), dt, warm_on ? &wt : nullptr, st));
       } else {
       if (con(FD_CHAIN_INPROJ)) RC(chain(FD_CHAIN_INPROJ, x, dt, D + db.ch.inp[l], P + t.inp.b, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
@@ -892,7 +909,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       else RC(fd_attention(prec, 0, ta, st));
       }
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))
-      if (rbk && !sw.no_tfmr_tail) {
+      if (rbk && (sw.rb_mask & 2u) && !sw.no_tfmr_tail) {
         TfmrTailArgs tt;
         tt.M = R; tt.ld = dt; tt.att = F(w.att); tt.x = x; tt.wo = D + db.ch.outp[l]; tt.w1 = D + db.ch.l1[l]; tt.w2 = D + db.ch.l2n[l];
         tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
@@ -912,7 +929,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         TWICE("tail", fd_tfmr_tail(tt, st));
         x = tt.out;
         continue;
-      } else if (rbk) {
+      } else if (rbk && (sw.rb_mask & 2u)) {
         RC(rblock(FD_RB_OUTPROJ, F(w.att), dt, D + db.ch.outp[l], P + t.outp.b, nullptr, nullptr, nullptr, nullptr, x, dt, &t.n1,
                   nullptr, F(w.x_a), dt));
         RC(rblock(FD_RB_FFN, F(w.x_a), dt, D + db.ch.l1[l], P + t.l1.b, D + db.ch.l2n[l], P + t.l2.b, nullptr, nullptr, F(w.x_a),
@@ -948,7 +965,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       RC(lin(R, k.post, x, dt, F(w.tf_in), dt, nullptr, 0, F(w.h_a), cs));
     }
     bool bb_done = false;
-    if (rbk) {
+    if (rbk && (sw.rb_mask & 4u)) {
       // ... with BackboneUpdate + compose_q_update_vec fused in (the fp32 Linear c_s -> 6 is a per-row dot product)
       RowBlockArgs r;
       r.M = R; r.in = F(w.h_a); r.ld_in = cs; r.w0 = D + db.ch.t1; r.w1 = D + db.ch.t2n; r.w2 = D + db.ch.t3n; r.b0 = P + k.t1.b;
@@ -1078,7 +1095,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   }
   if (op.kind != OP_ALL) return FDIPT_EINVAL;  // (unreachable: every per-op selection returns inside the loop)
   // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
-  if (rbk) {
+  if (rbk && (sw.rb_mask & 8u)) {
     if (split_tors) { rb_l0 = D + L.lo_tor1; rb_l1 = D + L.lo_tor2; }
     RC(rblock(split_tors ? FD_RB_TORSION_SPLIT : FD_RB_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
               cs, nullptr, nullptr, F(w.h_b), cs));

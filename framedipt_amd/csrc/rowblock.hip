@@ -415,7 +415,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       const float n0 = q0 + dq0 * m, n1 = q1 + dq1 * m, n2 = q2 + dq2 * m, n3 = q3 + dq3 * m;
       const float nrm = sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
       a.quat[r * 4] = n0 / nrm; a.quat[r * 4 + 1] = n1 / nrm; a.quat[r * 4 + 2] = n2 / nrm; a.quat[r * 4 + 3] = n3 / nrm;
-      a.trans[r * 3] += d0 * m; a.trans[r * 3 + 1] += d1 * m; a.trans[r * 3 + 2] += d2 * m;
+      fd_store3(a.trans + r * 3, a.trans[r * 3] + d0 * m, a.trans[r * 3 + 1] + d1 * m, a.trans[r * 3 + 2] + d2 * m);
     }
   }
   fd_l2_warm_done(warm_tok);

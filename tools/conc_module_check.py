@@ -28,8 +28,10 @@ for h in range(2):
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 torch.cuda.synchronize()
 dm, pr, dr = C.byref(net.dims), _lib.ptr(net.params), _lib.ptr(net.derived)
-def call(hv, blk):
+def call(hv, blk, what=what):
     st = hv["st"]; sp = _lib.stream_ptr(); P = _lib.ptr
+    if what == "mix":  # EdgeTransition of one half next to the IPA block of the other
+        return call(hv, blk, "et" if hv is halves[0] else "ipa")
     if what == "ipa":
         _lib.check(lib.fdipt_ipa_attention_fwd(dm, pr, dr, blk, hv["b"], N, P(hv["node"]), P(hv["z"]), P(hv["rig"]), P(hv["mask"]), P(hv["out"]), P(st.ws), st.ws_bytes, sp))
     elif what == "points":
@@ -37,7 +39,8 @@ def call(hv, blk):
     else:
         _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, blk, hv["b"], N, P(hv["node"]), P(hv["mask"]), P(hv["z"]), P(hv["z2"]), P(st.ws), st.ws_bytes, sp))
 def outs(hv):
-    return [hv[k].float().cpu().numpy().copy() for k in (("out",) if what == "ipa" else ("qp", "kp", "vp") if what == "points" else ("z2",))]
+    w = what if what != "mix" else ("et" if hv is halves[0] else "ipa")
+    return [hv[k].float().cpu().numpy().copy() for k in (("out",) if w == "ipa" else ("qp", "kp", "vp") if w == "points" else ("z2",))]
 def run(conc):
     for rep in range(4):
         for hv, s in zip(halves, streams):
