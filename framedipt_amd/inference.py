@@ -131,14 +131,81 @@ class ReverseLoop:
         return ret
 
 
+_SUB_BATCH_STREAMS: dict = {}  # device -> HIP streams of the sub-batches, created once (HIP multiplexes streams onto a few hardware
+                               # queues: fresh streams per trajectory would end up sharing one)
+
+
+def _sub_batch_streams(dev, n):
+    pool = _SUB_BATCH_STREAMS.setdefault(str(dev), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
+class StreamedLoops:
+    """The batch cut into ``n_streams`` sub-batches, each a ``ReverseLoop`` with its own workspace on its own HIP stream.
+
+    The node path of the score network (M = B*N rows: a few dozen workgroups per launch) is latency-bound and leaves most of the
+    256 CUs idle, while the pair path (EdgeTransition, IPA attention, o_pair) is throughput-bound: with two sub-batches in
+    flight the GPU runs one sub-batch's pair kernels under the other's node-path launches.  Results do not change: a sample's
+    trajectory is bit-identical whatever batch it rides in (tests: test_batch_of_equal_samples_matches_single,
+    test_concurrent_forwards_are_bit_identical).  Same interface as ``ReverseLoop`` (prime / step / results)."""
+
+    def __init__(self, model, diffuser, data_init, n_streams, num_t, min_t, noise_tape=None, **kw):
+        B = data_init["rigids_t"].shape[0]
+        n_streams = max(1, min(n_streams, B))
+        cuts = [round(i * B / n_streams) for i in range(n_streams + 1)]
+        self.dev = model.device
+        if noise_tape is None:
+            n_noisy = int(np.sum(np.linspace(min_t, 1.0, num_t)[::-1] > min_t))
+            noise_tape = draw_noise_tape(diffuser, n_noisy, B, data_init["rigids_t"].shape[1])
+        self.loops, self.streams = [], _sub_batch_streams(self.dev, n_streams)
+        with torch.cuda.device(self.dev):
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                sub = {k: v[lo:hi] for k, v in data_init.items() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B}
+                self.loops.append(ReverseLoop(model, diffuser, sub, num_t, min_t, noise_tape=tuple(z[:, lo:hi] for z in noise_tape),
+                                              state=model.new_batch_state(sub["seq_idx"]), **kw))
+        torch.cuda.synchronize(self.dev)  # set-up ran on the current stream
+        self.st = self.loops[0].st
+
+    def _each(self, fn):
+        # (no per-step ordering against the caller's stream: an event on the default stream orders every sub-batch stream behind
+        #  all work enqueued before it, i.e. the sub-batches would run one after the other; set-up was synchronised once)
+        for loop, s in zip(self.loops, self.streams):
+            with torch.cuda.stream(s):
+                fn(loop)
+
+    def prime(self):
+        self._each(lambda lp: lp.prime())
+
+    def step(self, k):
+        self._each(lambda lp: lp.step(k))
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def results(self, return_device=False):
+        self.synchronize()
+        parts = [lp.results(return_device) for lp in self.loops]
+        cat = lambda xs: torch.cat(xs, 1) if torch.is_tensor(xs[0]) else np.concatenate(xs, 1)  # noqa: E731
+        return {k: cat([p[k] for p in parts]) for k in parts[0]}  # (every returned array carries the batch on axis 1)
+
+
 def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None,
-                 return_device=False):
+                 return_device=False, streams=1):
     """Same arguments / returned keys as the reference.  ``noise_tape=(z_rot, z_trans)`` ([num_t-1,B,N,3] float64
     N(0,1) draws) overrides the global ``np.random`` stream (sample-sharded runs).  ``data_init`` tensors carry a
-    leading batch dimension B >= 1 (the reference always passes B = 1)."""
-    loop = ReverseLoop(model, diffuser, data_init, num_t, min_t, center, aux_traj, self_condition, noise_scale,
-                       embed_self_conditioning, inpainting, input_aatype, noise_tape)
+    leading batch dimension B >= 1 (the reference always passes B = 1).  ``streams=n``: the batch runs as n sub-batches on n HIP
+    streams (same results; the latency-bound node path of one sub-batch overlaps the pair kernels of the other)."""
+    if streams > 1 and data_init["rigids_t"].shape[0] > 1:  # sub-batches on their own HIP streams (same results)
+        loop = StreamedLoops(model, diffuser, data_init, streams, num_t, min_t, noise_tape=noise_tape, center=center, aux_traj=aux_traj,
+                             self_condition=self_condition, noise_scale=noise_scale, embed_self_conditioning=embed_self_conditioning,
+                             inpainting=inpainting, input_aatype=input_aatype)
+    else:
+        loop = ReverseLoop(model, diffuser, data_init, num_t, min_t, center, aux_traj, self_condition, noise_scale,
+                           embed_self_conditioning, inpainting, input_aatype, noise_tape)
     loop.prime()
     for k in range(num_t):
         loop.step(k)

@@ -74,3 +74,72 @@ def test_forward_independent_of_workspace_contents(n, b, prec):
     for tag in ("ff", "random", "zeros_again"):
         for k in OUT:
             assert torch.equal(res[tag][k], res["zeros"][k]), (tag, k)
+
+
+def test_concurrent_forwards_are_bit_identical():
+    """Two forwards of this library in flight on two HIP streams == the same forwards one after the other, bit for bit.  Regression
+    test of the round-2 finding: a merged `global_store_dwordx3` in points16_kernel (three floats of a point) read its data registers
+    after the next point's arithmetic had overwritten the first of them whenever another kernel contended the CU's memory pipeline -
+    ~28 % of the forwards that ran next to another forward differed (one residue's point x coordinates, then the sample's whole
+    node representation through the attention).  DESIGN.md section 5; tools/check_store_hazard.py, tools/conc_*.py."""
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.model.score_network import BatchState
+    from framedipt_amd.sampler import UnconditionalSampler
+    N, B = 128, 8
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": B}), d, "cuda")
+    feats, _ = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, 6, 0.01) for i in range(B)])
+    t32, temb, sig = net.step_scalars(np.full(B // 2, 0.5))
+    f32 = lambda x: x.to(device="cuda", dtype=torch.float32).contiguous()  # noqa: E731
+    halves = []
+    for lo, hi in ((0, B // 2), (B // 2, B)):
+        st = BatchState(net, feats["seq_idx"][lo:hi])
+        args = (f32(feats["rigids_t"][lo:hi]), f32(feats["res_mask"][lo:hi]), f32(feats["fixed_mask"][lo:hi]), f32(feats["sc_ca_t"][lo:hi]) + 1.0,
+                None, f32(feats["torsion_angles_sin_cos"][lo:hi][..., 2, :]), torch.as_tensor(t32, device="cuda"),
+                torch.as_tensor(temb, device="cuda"), torch.as_tensor(sig, device="cuda"))
+        halves.append((st, args))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+
+    def run(conc):
+        for _ in range(3):
+            for (st, args), s in zip(halves, streams):
+                with torch.cuda.stream(s if conc else streams[0]):
+                    st.forward(*args)
+        torch.cuda.synchronize()
+        return [(st.rigids.cpu().numpy().copy(), st.psi.cpu().numpy().copy(), st.rot_score.cpu().numpy().copy()) for st, _ in halves]
+
+    ref = run(False)
+    for rep in range(40):
+        got = run(True)
+        for h in range(2):
+            for a, b in zip(got[h], ref[h]):
+                np.testing.assert_array_equal(a, b, err_msg=f"repetition {rep}, sub-batch {h}")
+
+
+def test_streamed_sub_batches_match_the_single_stream_trajectory():
+    """inference_fn(streams=2): sub-batches on two HIP streams give the trajectory of the single-stream batch, bit for bit."""
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.inference import draw_noise_tape, inference_fn
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    N, B, T = 64, 6, 8
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": B}), d, "cuda")
+    feats, _ = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, T, 0.01) for i in range(B)])
+    np.random.seed(11)
+    tape = draw_noise_tape(d, T - 1, B, N)
+    one = inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
+    two = inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape, streams=2)
+    assert sorted(one) == sorted(two)
+    for k in one:
+        host = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)  # noqa: E731
+        assert host(one[k]).shape == host(two[k]).shape, k
+        np.testing.assert_array_equal(host(one[k]), host(two[k]), err_msg=k)
