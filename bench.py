@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--kernel-flags", type=lambda s: int(s, 0), default=0, help="FdiptDims.kernel_flags (development)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--reserve-cus", type=int, default=48, help="with --streams > 1: CUs the persistent pair kernels leave to the other streams")
+    ap.add_argument("--streams", type=int, default=1, help="sub-batches on this many HIP streams (same results; not the default: the "
+                    "roofline kernel's launches are then sub-batch sized and rocprofv3 serialises the streams)")
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
     if a.n_res is not None:
@@ -186,6 +189,9 @@ def main():
     feats, tape = sharding.stack_items(items)
 
     def new_loop():
+        if a.streams > 1:
+            return inference.StreamedLoops(net, diff, feats, a.streams, T, 0.01, noise_tape=tape, reserve_cus=a.reserve_cus, aux_traj=True,
+                                           noise_scale=0.1, inpainting=inp)
         return inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp,
                                      noise_tape=tape)
 
@@ -251,7 +257,8 @@ def main():
         res_steps = B * N * K * world
         value = res_steps / el
         et = float(np.mean(et_ms)) * 1e-3
-        et_flops = ET_FLOPS_PER_PAIR * B * N * N
+        B_ev = loop.loops[0].B if a.streams > 1 else B  # samples in the launches the events bracket (first sub-batch)
+        et_flops = ET_FLOPS_PER_PAIR * B_ev * N * N
         peak = PEAK_TFLOPS[prec]
         achieved = et_flops / et / 1e12
         fwd_per_step = (T + 1) / T if K == T else 1.0
@@ -264,7 +271,7 @@ def main():
             "config": {"workload": f"{a.config}: {'inpainting' if inp else 'de novo'} backbone sampler, N={N}, {B} samples/GPU "
                                    f"batched, {'whole trajectory (priming forward + all steps)' if K == T else f'{K} steps spread over the schedule'}"
                                    f" of T={T}, aux_traj=True, noise_scale 0.1, 17.4M-param synthetic weights, per-sample seeds",
-                       "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective",
+                       "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective" + (f", {a.streams} sub-batch streams per GPU" if a.streams > 1 else ""),
                        "precision_mode": ("fp16 MFMA operands / pair representation, split (hi+lo) operands on the node path, fp32 "
                                           "accumulation / frames / statistics" if prec == "fp16" else "fp32 (v_mfma_f32_32x32x2_f32)"),
                        "kernel_flags": a.kernel_flags},
@@ -272,8 +279,8 @@ def main():
                          "traffic": pmc_traffic(prec, N, B), "kernel": "edge_transition4_kernel" if et4 else
                          ("edge_transition3_kernel" if prec == "fp16" else "edge_transition_f32_kernel"),
                          "avg_launch_ms": et * 1e3, "launches_timed": len(et_ms), "flops_per_launch": et_flops,
-                         "executed_flops_per_launch": ET4_EXEC_FLOPS_PER_PAIR * B * N * N if et4 else None,
-                         "executed_frac": ET4_EXEC_FLOPS_PER_PAIR * B * N * N / et / 1e12 / peak if et4 else None,
+                         "executed_flops_per_launch": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N if et4 else None,
+                         "executed_frac": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N / et / 1e12 / peak if et4 else None,
                          "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak},
             "results_d2h": {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": res_steps / (el + d2h)},
         }

@@ -38,7 +38,7 @@ class ForwardArgs(C.Structure):
         (n, _P) for n in ("rigids_t", "res_mask", "fixed_mask", "sc_ca_t", "seq_idx", "idx_emb", "aatype", "gt_psi", "t",
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
                           "atom37", "atom14", "trace_node", "trace_edge", "trace_inner")] + [
-        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P)]
+        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P), ("reserve_cus", C.c_int32)]
 
 
 _lib = None

@@ -450,7 +450,8 @@ int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
   const int rpw = cdiv(a.N, wpg);
   wpg = cdiv(a.N, rpw);
   const int n_items = n_groups * wpg;
-  const int grid = cdiv(n_items, 8) < 256 ? cdiv(n_items, 8) : 256;
+  const int cus = a.reserve_cus > 0 && a.reserve_cus < 248 ? (256 - a.reserve_cus) & ~7 : 256;  // (whole XCD rounds of 8)
+  const int grid = cdiv(n_items, 8) < cus ? cdiv(n_items, 8) : cus;
   hipLaunchKernelGGL(kerns[kid], dim3(grid), dim3(EE2_THREADS), lds, st, a, (const char*)img, nt, wpg, rpw, n_items);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -443,7 +443,9 @@ int fd_edge_transition3(const ET2Args& a, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDIPT_ELAUNCH;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int grid = n_tiles < n_cu ? n_tiles : n_cu;  // persistent: one block per CU
+  // persistent: one block per CU (minus the CUs left to concurrent streams, in whole XCD rounds of 8)
+  const int cus = a.reserve_cus > 0 && a.reserve_cus < n_cu - 8 ? (n_cu - a.reserve_cus) & ~7 : n_cu;
+  const int grid = n_tiles < cus ? n_tiles : cus;
   hipLaunchKernelGGL(edge_transition3_kernel, dim3(grid), dim3(E3_THREADS), E3_LDS, st, a, n_tiles);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -43,6 +43,7 @@ struct EdgeEmbedArgs {
   const float* bb;
   float* bias_out;
   int H;
+  int reserve_cus = 0;  // persistent kernel: CUs left to launches of other streams (FdiptForwardArgs.reserve_cus)
 };
 
 struct AttnArgs {
@@ -126,6 +127,7 @@ struct ET2Args {
   // edge_transition4: per-residue rows as fold fragments (fd_et4_row_images)
   const void* a1_img;   // [ceil(B*N/8)][16][32][8] bf16: A1 | Af rows of 8 consecutive (flattened) residue rows
   const void* b1_img;   // [B][N/4][16][32][8] bf16: B1 | Bf rows (e_j columns) of 4 consecutive j (+ the next sample's)
+  int reserve_cus = 0;  // persistent kernels: CUs left to launches of other streams (FdiptForwardArgs.reserve_cus)
 };
 // edge_transition3.hip: 16-pair waves, two waves per SIMD (any N >= 43)
 int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);

@@ -697,7 +697,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     ea.edges = (const float*)(D + L.edges); ea.seq_idx = a->seq_idx; ea.sc_ca = a->sc_ca_t;
     ea.w2 = WM(iv.ee2); ea.w3 = WM(iv.ee4); ea.b2 = P + iv.ee2.b; ea.b3 = P + iv.ee4.b;
     ea.gamma = P + iv.eeln.g; ea.beta = P + iv.eeln.b; ea.res_mask = res_mask; ea.z_out = W + w.z;
-    ea.trace = a->trace_edge;
+    ea.trace = a->trace_edge; ea.reserve_cus = a->reserve_cus;
     // the first block's pair bias linear_b(z)/sqrt(3) from the embedder's LayerNorm epilogue (saves a pass over z)
     const bool ee_bias = use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 1024 &&
                          !sw.generic_attn && !sw.no_et_bias && !sw.no_ee_bias;
@@ -1066,7 +1066,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         const bool emit_bias = cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && !sw.generic_attn && !sw.no_et_bias && N <= 1024;
         t2.wb_img = emit_bias ? D + (use_et4 ? L.blk[b + 1].wb_img4 : L.blk[b + 1].wb_img3) : nullptr;
         t2.a1_img = W + w.a1img; t2.b1_img = W + w.b1img;
-        t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H;
+        t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H; t2.reserve_cus = a->reserve_cus;
         bias_ready = emit_bias;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
         if (use_et4) RC(fd_edge_transition4(t2, st));

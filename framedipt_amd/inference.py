@@ -151,7 +151,7 @@ class StreamedLoops:
     trajectory is bit-identical whatever batch it rides in (tests: test_batch_of_equal_samples_matches_single,
     test_concurrent_forwards_are_bit_identical).  Same interface as ``ReverseLoop`` (prime / step / results)."""
 
-    def __init__(self, model, diffuser, data_init, n_streams, num_t, min_t, noise_tape=None, **kw):
+    def __init__(self, model, diffuser, data_init, n_streams, num_t, min_t, noise_tape=None, reserve_cus=48, **kw):
         B = data_init["rigids_t"].shape[0]
         n_streams = max(1, min(n_streams, B))
         cuts = [round(i * B / n_streams) for i in range(n_streams + 1)]
@@ -163,8 +163,10 @@ class StreamedLoops:
         with torch.cuda.device(self.dev):
             for lo, hi in zip(cuts[:-1], cuts[1:]):
                 sub = {k: v[lo:hi] for k, v in data_init.items() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B}
+                st = model.new_batch_state(sub["seq_idx"])
+                st.reserve_cus = reserve_cus if n_streams > 1 else 0  # the persistent pair kernels leave CUs to the other streams
                 self.loops.append(ReverseLoop(model, diffuser, sub, num_t, min_t, noise_tape=tuple(z[:, lo:hi] for z in noise_tape),
-                                              state=model.new_batch_state(sub["seq_idx"]), **kw))
+                                              state=st, **kw))
         torch.cuda.synchronize(self.dev)  # set-up ran on the current stream
         self.st = self.loops[0].st
 

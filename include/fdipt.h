@@ -8,9 +8,9 @@
  * Conventions
  *   - every function returns 0 on success, a negative FDIPT_E* code otherwise; no exceptions,
  *     no allocation, no global mutable state; one hipStream_t per call (passed as void*).  Calls for different devices
- *     are independent.  Run ONE score-network forward at a time per device: two forwards of this library in flight on
- *     two streams of the same GPU gave intermittently different results in testing ("concurrent forwards"),
- *     although no memory is shared between them; the cause was not found.
+ *     are independent, and so are calls on different streams of one device as long as they share no output / workspace buffer
+ *     (forwards of two sub-batches may be in flight together: FdiptForwardArgs.reserve_cus; the round-2 mismatch between
+ *     concurrent forwards was a wide-store hazard in one kernel, fixed and regression-tested: DESIGN.md section 5).
  *   - all pointers are DEVICE pointers unless the name ends in _host; the caller (PyTorch) owns
  *     every buffer, including the workspace (query sizes with the *_bytes functions).
  *   - layouts are row-major contiguous, residue-major.  Quaternions are scalar-first (w,x,y,z);
@@ -142,6 +142,10 @@ typedef struct FdiptForwardArgs {
    * the forward.  May alias sc_ca_t (read at the start): the sampler's self-conditioning hand-over
    * (experiments/utils.py:361-366,571-578) then costs no copy.  NULL to skip. */
   float* ca_out;
+  /* Concurrent sub-batches (one forward per HIP stream): the persistent pair kernels (edge embedder, EdgeTransition) start
+   * on all CUs but `reserve_cus` of them, so that the latency-bound node-path launches of another stream keep finding free
+   * CUs while they run.  0 = use every CU (single stream). */
+  int32_t reserve_cus;
 } FdiptForwardArgs;
 
 size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
