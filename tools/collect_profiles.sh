@@ -15,6 +15,8 @@ python "$ROOT/bench.py" --precision fp32 --steps 6 --warmup 2 --no-cpu-baseline 
 python "$ROOT/bench.py" --config c5 --precision fp16 --no-cpu-baseline > "$OUT/bench_c5_fp16.json" 2>> "$OUT/bench.err"
 python "$ROOT/bench.py" --kernel-flags 32 --no-cpu-baseline > "$OUT/bench_c4_nosplit.json" 2>> "$OUT/bench.err"
 python "$ROOT/bench.py" --samples-per-gpu 24 --no-cpu-baseline > "$OUT/bench_c4_b24.json" 2>> "$OUT/bench.err"
+python "$ROOT/bench.py" --streams 2 --reserve-cus 64 --no-cpu-baseline > "$OUT/bench_c4_streams2.json" 2>> "$OUT/bench.err"
+python "$ROOT/bench.py" --config c3 --streams 2 --reserve-cus 64 --no-cpu-baseline > "$OUT/bench_c3_streams2.json" 2>> "$OUT/bench.err"
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_prof.log" 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 [ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats.md" > /dev/null

@@ -116,7 +116,8 @@ json.dump(rec, open(P + "r02_pmc_edge_transition.json", "w"), indent=1)
 lines = {}
 for tag, fn in (("c4_fp16_n300_b8", "bench.json"), ("c2_fp16_n128_b8", "bench_c2.json"), ("c3_fp16_n724_4chain_b5", "bench_c3.json"),
                 ("c5_fp32_n1000_b4", "bench_c5.json"), ("c5_shape_in_fp16", "bench_c5_fp16.json"), ("c4_fp32", "bench_c4_fp32.json"),
-                ("c4_fp16_without_split_operands", "bench_c4_nosplit.json"), ("c4_fp16_b24", "bench_c4_b24.json")):
+                ("c4_fp16_without_split_operands", "bench_c4_nosplit.json"), ("c4_fp16_b24", "bench_c4_b24.json"),
+                ("c4_fp16_two_sub_batch_streams", "bench_c4_streams2.json"), ("c3_fp16_two_sub_batch_streams", "bench_c3_streams2.json")):
     if os.path.exists(d + fn):
         lines[tag] = json.load(open(d + fn))
         if tag.startswith("c4_fp16_n300") and lines[tag]["roofline"].get("traffic") is None:
