@@ -372,3 +372,29 @@ def test_mmcif_reader_on_synthetic_file(tmp_path):
     out = features.process_csv_row(row["processed_path"])
     assert out["aatype"].shape == (4,) and list(out["seq_idx"]) == [0, 1, 2, 3] and out["rigidgroups_0"].shape == (4, 8, 4, 4)
     assert features.map_to_new_str_name(26) == "AA" and features.map_to_new_str_name(676) == "ZA"
+
+
+def test_hot_kernels_have_no_three_dword_stores(tmp_path):
+    """ISA audit (cross-compiled, no GPU): the kernels of the sampler loop contain no `global_store_dwordx3`.  A merged three-float
+    store in points16_kernel read its data registers late under memory-pipeline contention and stored the next point's x coordinate
+    (the concurrent-forward mismatch); three-float runs are written dword by dword (common.hpp: fd_store3)."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "framedipt_amd", "csrc")
+    hot = {"attention": ("points16_kernel", "points_kernel", "opair_mfma_kernel"), "rowblock": ("rowblock_kernel", "tfmr_tail_kernel"),
+           "frames": ("reverse_step_kernel", "backbone_kernel", "rot_score_kernel", "build_feats_kernel", "finish_kernel", "split_rigids_kernel",
+                      "se3_forward_step_kernel", "se3_step_log_prob_kernel", "compose_q_update_kernel", "trans_score_kernel")}
+    for unit, kernels in hot.items():
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-c", os.path.join(csrc, unit + ".hip"), "-o",
+                        str(tmp_path / (unit + ".o")), "-save-temps=obj"], check=True, cwd=csrc)
+        asm = open(tmp_path / f"{unit}-hip-amdgcn-amd-amdhsa-gfx950.s").read().split("\n")
+        cur, bad = None, []
+        for line in asm:
+            if line.startswith("_Z") and line.rstrip().endswith(":"):
+                cur = line
+            if "_store_dwordx3" in line and cur and any(k in cur for k in kernels):
+                bad.append((cur.strip(), line.strip()))
+        assert not bad, bad[:4]
