@@ -206,8 +206,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // for is kept) then reaches memory instead of the stored value, 16 lanes at a time: points16_kernel produced wrong x coordinates for
 // 16 points of a residue in ~10 % of the forwards that ran next to another forward's attention kernels (DESIGN.md section 5;
 // tools/check_store_hazard.py lists the remaining wide stores with early overwrites).
-__device__ __forceinline__ void fd_st(float* p, float v) { *(volatile float*)p = v; }
-__device__ __forceinline__ void fd_st(double* p, double v) { *(volatile double*)p = v; }
+// (inline asm rather than a volatile store: hipcc follows every volatile access with s_waitcnt vmcnt(0) - reverse_step_kernel went from
+// 20 to 71 us - while it cannot merge asm statements; a store the compiler's counter model does not see only makes its later vmcnt
+// waits conservative, the counter being in order)
+__device__ __forceinline__ void fd_st(float* p, float v) { asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void fd_st(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void fd_store3(float* p, float x, float y, float z) { fd_st(p, x); fd_st(p + 1, y); fd_st(p + 2, z); }
 
 __device__ __forceinline__ double wave_sum_d(double v) {

@@ -149,7 +149,7 @@ __device__ __forceinline__ void d_backbone_residue(long r, const float* Rb, cons
     for (int at = 0; at < 14; ++at)
       for (int c = 0; c < 3; ++c) fd_st(atom14 + (r * 14 + at) * 3 + c, pos[at][c]);
   if (atom37) {
-    for (int c = 0; c < 37 * 3; ++c) fd_st(atom37 + r * 111 + c, 0.f);
+    for (int c = 0; c < 37 * 3; ++c) atom37[r * 111 + c] = 0.f;  // (merged wide stores of a constant register: nothing overwrites it)
     // atom14 order N,CA,C,O,CB -> atom37 order N,CA,C,CB,O (all_atom.py:168-174)
     const int map[5] = {0, 1, 2, 4, 3};
     for (int at = 0; at < 5; ++at)
