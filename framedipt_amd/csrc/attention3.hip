@@ -66,10 +66,11 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   // ---- query-side registers
   // LB == 2: Q fragments in registers.  LB == 3 (three blocks per CU: B H nt blocks then fit one round of the 256 CUs): the 64
   // registers are not affordable; the four waves need the same fragments, so they go to LDS once and are read per k-step
-  hx8 Qf[LB == 3 ? 1 : 16];
+  constexpr bool QLDS = LB == 3 || (LB == 2 && A3_NTW >= 6);  // Q fragments through LDS (frees 64 registers)
+  hx8 Qf[QLDS ? 1 : 16];
   {
     const half_t* qr = a.Qb + ((bh * nt + qt) * 16 * 64 + lane) * 8;  // fragment order: 1 KB per k-step
-    if constexpr (LB == 3) {
+    if constexpr (QLDS) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) Qs[(4 * s + wave) * 64 + lane] = *(const u16x8*)(qr + (4 * s + wave) * 512);
       __syncthreads();
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], acc, 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < 16; ++s)
-        acc = fd_mfma32(ti.k[s], LB == 3 ? __builtin_bit_cast(hx8, Qs[s * 64 + lane]) : Qf[LB == 3 ? 0 : s], acc);
+        acc = fd_mfma32(ti.k[s], QLDS ? __builtin_bit_cast(hx8, Qs[s * 64 + lane]) : Qf[QLDS ? 0 : s], acc);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -332,6 +333,7 @@ int fd_attention3(const Attn3Args& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {  // N > 800: more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute((const void*)ipa_attn3_kernel<6, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)ipa_attn3_kernel<6, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)ipa_attn3_kernel<8, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
       return FDIPT_ELAUNCH;
     attr_set = true;
@@ -342,6 +344,10 @@ int fd_attention3(const Attn3Args& a, hipStream_t st) {
   else if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), grid, block, smem, st, a);
   else if (a.N <= 4 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<4, 1, true>), grid, block, smem, st, a);
   // 512 < N <= 1024 (TCR-pMHC complexes, long chains): 6 / 8 key tiles per wave, one block per CU, operands fetched per tile
+#ifndef A3_MID2
+#define A3_MID2 1
+#endif
+  else if (a.N <= 6 * 4 * 32 && A3_MID2) hipLaunchKernelGGL((ipa_attn3_kernel<6, 2, false>), grid, block, smem + 16384, st, a);
   else if (a.N <= 6 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<6, 1, false>), grid, block, smem, st, a);
   else hipLaunchKernelGGL((ipa_attn3_kernel<8, 1, false>), grid, block, smem, st, a);
   FD_CHECK_LAUNCH();
