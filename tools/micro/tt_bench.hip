@@ -2,14 +2,18 @@
 #include "../../framedipt_amd/csrc/rowblock.hip"
 #include <cstdio>
 #include <vector>
-int main() {
-  const int M = 2400, D = 320;
+int main(int argc, char** argv) {
+  const int M = argc > 2 ? atoi(argv[2]) : 2400, D = 320;
+  const bool split = argc > 1 && atoi(argv[1]) != 0;  // argv[1] = 1: split operands (hi + lo weight images)
   float *att, *x, *out, *vec; void* w;
   (void)hipMalloc(&att, (size_t)M * D * 4); (void)hipMalloc(&x, (size_t)M * D * 4); (void)hipMalloc(&out, (size_t)M * D * 4);
   (void)hipMalloc(&vec, 7 * D * 4); (void)hipMalloc(&w, 3 * (size_t)D * D * 2);
   (void)hipMemset(att, 0, (size_t)M * D * 4); (void)hipMemset(x, 0, (size_t)M * D * 4); (void)hipMemset(vec, 0, 7 * D * 4); (void)hipMemset(w, 0, 3 * (size_t)D * D * 2);
   TfmrTailArgs a; a.warm = L2Warm{}; a.M = M; a.ld = D; a.att = att; a.x = x; a.out = out;
   a.wo = w; a.w1 = (char*)w + (size_t)D * D * 2; a.w2 = (char*)w + 2 * (size_t)D * D * 2;
+  a.wol = a.w1l = a.w2l = a.wpl = nullptr;
+  if (split) { void* wl; (void)hipMalloc(&wl, 3 * (size_t)D * D * 2); (void)hipMemset(wl, 0, 3 * (size_t)D * D * 2);
+               a.wol = wl; a.w1l = (char*)wl + (size_t)D * D * 2; a.w2l = (char*)wl + 2 * (size_t)D * D * 2; }
   a.bo = vec; a.g1 = vec + D; a.be1 = vec + 2 * D; a.b1 = vec + 3 * D; a.b2 = vec + 4 * D; a.g2 = vec + 5 * D; a.be2 = vec + 6 * D;
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
   for (int i = 0; i < 3; ++i) fd_tfmr_tail(a, 0);
@@ -18,10 +22,10 @@ int main() {
   for (int i = 0; i < iters; ++i) fd_tfmr_tail(a, 0);
   (void)hipEventRecord(t1, 0); (void)hipEventSynchronize(t1);
   float ms; (void)hipEventElapsedTime(&ms, t0, t1);
-  printf("tfmr_tail M=%d: %.2f us/launch\n", M, ms / iters * 1e3);
+  printf("tfmr_tail M=%d split=%d: %.2f us/launch\n", M, (int)split, ms / iters * 1e3);
 #ifdef FD_PROF
   {
-    const int nb = 75;
+    const int nb = (M + 31) / 32;
     std::vector<unsigned long long> h((size_t)nb * 16);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fd_prof), h.size() * 8);
     const char* names[9] = {"", "inputs + constants -> LDS", "stage 1 MFMA (out_proj)", "residual + LayerNorm1", "x_a -> LDS + fragments", "stage 2 MFMA (FFN 1)", "relu -> LDS + fragments", "stage 3 MFMA (FFN 2)", "residual + LayerNorm2"};
