@@ -5,7 +5,7 @@ from framedipt_amd.diffusion import SE3Diffuser
 from framedipt_amd.inference import inference_fn
 from framedipt_amd.model import ScoreNetwork
 from framedipt_amd.sampler import UnconditionalSampler
-N, B, T = 300, 8, 100
+N, B, T = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (300, 8, 100)
 conf = config.base_config()
 d = SE3Diffuser(conf.diffuser, device="cuda")
 net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
@@ -21,4 +21,4 @@ for k in outs[0]:
     h = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
     for i in (1, 2, 3):
         assert np.array_equal(h(outs[0][k]), h(outs[i][k])), (k, i)
-print("T=100 N=300 B=8 trajectories bit-identical for 1 / 2 / 3 streams and on repetition")
+print(f"T={T} N={N} B={B} trajectories bit-identical for 1 / 2 / 3 streams and on repetition")
