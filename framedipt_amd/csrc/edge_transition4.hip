@@ -36,23 +36,33 @@
 #endif
 #define E4_CZ 128
 #define E4_H 384
-#define E4_THREADS 512
+#ifndef E4_WAVES
+#define E4_WAVES 8  // waves per block (4: experiment builds of tools/micro/et4_bench.hip)
+#endif
+#define E4_THREADS (64 * E4_WAVES)
+#ifdef E4_FAKE2  // TIMING ONLY (wrong results): the LDS footprint of a two-blocks-per-CU design with the present chunk sizes —
+#define E4_BUF 16384   // the chunks overlap each other and the z rows
+#define E4_WBI 2048
+#else
 #define E4_BUF 32768
+#define E4_WBI 8192
+#endif
 #define E4_L1_FR (12 * 8)    // fragments (1 KB): layer 1, 12 tiles x 8 k-steps (K = 128: z)
 #define E4_L2_FR (12 * 24)   // layer 2, 12 tiles x 24 k-steps
 #define E4_LF_FR (32 * 4)    // final layer, k-major: 32 k-steps (8 z + 24 h2) x 4 tiles
 #define E4_STREAM_BYTES ((E4_L1_FR + E4_L2_FR + E4_LF_FR) * 1024)
 #define E4_ZOFF (2 * E4_BUF)                 // per-wave z rows [8][32 rows x 256 B]
-#define E4_VOFF (E4_ZOFF + 8 * 8192)         // b2[384] | gamma[128] | beta[128] f32, then linear_b image (8 KB)
-#define E4_SOFF (E4_VOFF + 1536 + 1024 + 8192)  // per-wave output staging [8][32 rows x 64 B]
-#define E4_MOFF (E4_SOFF + 8 * 2048)          // per-lane pair masks of the current tile [512] f32
-#define E4_BOFF (E4_MOFF + 2048)              // bias of linear_b [8] f32
+#define E4_VOFF (E4_ZOFF + E4_WAVES * 8192)         // b2[384] | gamma[128] | beta[128] f32, then linear_b image (8 KB)
+#define E4_SOFF (E4_VOFF + 1536 + 1024 + E4_WBI)  // per-wave output staging [8][32 rows x 64 B]
+#define E4_MOFF (E4_SOFF + E4_WAVES * 2048)          // per-lane pair masks of the current tile [512] f32
+#define E4_BOFF (E4_MOFF + E4_THREADS * 4)              // bias of linear_b [8] f32
 #define E4_LDS (E4_BOFF + 32)
 
 // phase profile (-DE4_PROF, tools/micro/et4_bench.hip): cycle differences accumulate in scalar registers over all tiles of a
 // block and are written once at the end (FD_STAMP's per-stamp vector store costs registers this kernel does not have)
 #ifdef E4_PROF
 __device__ unsigned e4_prof[256 * 8];
+__device__ unsigned long long e4_span[1024 * 3];  // per block: start, end (s_memrealtime), HW_ID
 #define E4_STAMP(k)                                              \
   do {                                                           \
     const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); \
@@ -397,7 +407,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
   }
 }
 
-__global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args a, int n_tiles, int n_wt) {
+__global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_kernel(ET2Args a, int n_tiles, int n_wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
   const unsigned vec = lds0 + E4_VOFF;          // b2[384] | gamma[128] | beta[128] (f32)
@@ -417,8 +427,9 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
   if (tile >= n_tiles) return;
 #ifdef E4_PROF
   unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_amdgcn_s_memtime();
+  const unsigned long long span0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  E4Tile tc = e4_tile_of(tile * 8 + wave, n_wt, N, NJ4);
+  E4Tile tc = e4_tile_of(tile * E4_WAVES + wave, n_wt, N, NJ4);
   // ---- first tile: z rows, first weight chunk, small vectors
   e4_request_z(a, tc, lane0, lds0 + E4_ZOFF + wave * 8192, M);
   e4_dma_chunk<24576>(stream, lds0, tid0, wave);
@@ -426,7 +437,10 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
     e4_dma16(src, vec + (tid0 & ~63) * 16);
   }
-  if (a.wb_img) e4_dma16((const char*)a.wb_img + tid0 * 16, wbi + (tid0 & ~63) * 16);
+  if (a.wb_img)
+#pragma unroll
+    for (int u = 0; u < 512 / E4_THREADS; ++u)
+      e4_dma16((const char*)a.wb_img + (u * E4_THREADS + tid0) * 16, wbi + (u * E4_THREADS + (tid0 & ~63)) * 16);
   // fold fragments of the first layer-1 chunk (tiles 0..2): lanes < 32 read the row image, lanes >= 32 the column image
   // 32-bit byte offset from the row image (the column image follows it in the same workspace): one register, scalar base
   auto fold_ptr = [&](const E4Tile& t, int lane) {
@@ -512,7 +526,7 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
     // rows), 24 of h2, then the fold step (Af[i] + Bf[j]); 4 chunks x 8 k-steps
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < n_tiles;
-    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * 8 + wave, n_wt, N, NJ4);
+    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * E4_WAVES + wave, n_wt, N, NJ4);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -604,6 +618,14 @@ __global__ __launch_bounds__(E4_THREADS, 1) void edge_transition4_kernel(ET2Args
 #ifdef E4_PROF
   if (tid0 == 0 && blockIdx.x < 256)
     for (int k = 0; k < 8; ++k) e4_prof[blockIdx.x * 8 + k] = ph[k];
+  if (tid0 == 0 && blockIdx.x < 1024) {
+    e4_span[blockIdx.x * 3] = span0;
+    e4_span[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    e4_span[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hw;
+  }
 #endif
 }
 
@@ -617,7 +639,7 @@ int fd_edge_transition4(const ET2Args& a, hipStream_t st) {
     if (d < 0 || d + (long)fd_et4_b_image_bytes(a.B, a.N) >= (1L << 32)) return FDIPT_EINVAL;
   }
   const int n_wt = ((a.B * a.N + 7) / 8) * (a.N / 4);
-  const int n_tiles = cdiv(n_wt, 8);
+  const int n_tiles = cdiv(n_wt, E4_WAVES);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)edge_transition4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
@@ -633,7 +655,8 @@ int fd_edge_transition4(const ET2Args& a, hipStream_t st) {
   }
   // persistent: one block per CU (minus the CUs left to concurrent streams, in whole XCD rounds of 8)
   const int cus = a.reserve_cus > 0 && a.reserve_cus < n_cu - 8 ? (n_cu - a.reserve_cus) & ~7 : n_cu;
-  const int grid = n_tiles < cus ? n_tiles : cus;
+  const int slots = cus * (E4_LDS <= 81920 ? 2 : 1);
+  const int grid = n_tiles < slots ? n_tiles : slots;
   hipLaunchKernelGGL(edge_transition4_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

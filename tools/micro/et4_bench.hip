@@ -45,6 +45,25 @@ int main(int argc, char** argv) {
       printf("  %-36s %9.0f cyc per block-launch, %7.0f per tile\n", names[k], s, s / (n_tiles / 256.0));
     }
     printf("  %-36s %9.0f cyc (wave 0)\n", "total", tot);
+    std::vector<unsigned long long> sp(1024 * 3);
+    (void)hipMemcpyFromSymbol(sp.data(), HIP_SYMBOL(e4_span), sp.size() * 8);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    int nb = 0;
+    for (int b = 0; b < 1024 && sp[b * 3 + 1]; ++b) { ++nb; if (sp[b * 3] < t0) t0 = sp[b * 3]; if (sp[b * 3 + 1] > t1) t1 = sp[b * 3 + 1]; }
+    printf("  blocks %d, launch span %.1f us (100 MHz ticks)\n", nb, (t1 - t0) / 100.0);
+    for (int b = 0; b < nb; b += nb / 16) {
+      const unsigned hw = (unsigned)sp[b * 3 + 2], xcc = (unsigned)(sp[b * 3 + 2] >> 32) & 15;
+      printf("    block %4d: start %7.1f end %7.1f us  xcc %u se %u cu %u simd %u\n", b, (sp[b * 3] - t0) / 100.0, (sp[b * 3 + 1] - t0) / 100.0, xcc,
+             (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3);
+    }
+    // blocks sharing a CU
+    int shared = 0;
+    for (int b = 0; b < nb; ++b)
+      for (int c = b + 1; c < nb; ++c) {
+        const unsigned long long m = 0xF0000FF00ull | (0x7ull << 13);
+        if ((sp[b * 3 + 2] & m) == (sp[c * 3 + 2] & m) && sp[b * 3] < sp[c * 3 + 1] && sp[c * 3] < sp[b * 3 + 1]) ++shared;
+      }
+    printf("  overlapping block pairs on one CU: %d\n", shared);
   }
 #endif
   return 0;
