@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ET_FLOPS_PER_PAIR = 688128.0   # 2*(2*384^2 + 384*128): EdgeTransition, reference formulation
+NOMINAL_GHZ = 2.4  # engine clock of PEAK_TFLOPS (MI355X_MICROARCH.md)
 ET4_EXEC_FLOPS_PER_PAIR = 536 * 32 * 32 * 16 * 2 / 32.0  # edge_transition4: 536 MFMAs of 32x32x16 per 32-pair wave tile
 PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 
@@ -227,6 +228,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    clk = (C.c_ulonglong * 3)()
+    _lib.check(lib.fdipt_et4_clock(clk, 1))  # reset: the sums below cover the timed region only
     t0 = time.perf_counter()
     if K == T:
         loop.prime()
@@ -236,6 +239,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     st.ev_start = st.ev_stop = None
+    _lib.check(lib.fdipt_et4_clock(clk, 0))
     t1 = time.perf_counter()
     res = loop.results()  # D2H of the trajectories, as inference_fn returns them (not part of `value`)
     d2h = time.perf_counter() - t1
@@ -276,11 +280,16 @@ def main():
                                           "accumulation / frames / statistics" if prec == "fp16" else "fp32 (v_mfma_f32_32x32x2_f32)"),
                        "kernel_flags": a.kernel_flags},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(prec, N, B), "kernel": "edge_transition4_kernel" if et4 else
+                         "traffic": pmc_traffic(prec, N, B), "kernel": "edge_transition4_flat_kernel" if et4 else
                          ("edge_transition3_kernel" if prec == "fp16" else "edge_transition_f32_kernel"),
                          "avg_launch_ms": et * 1e3, "launches_timed": len(et_ms), "flops_per_launch": et_flops,
                          "executed_flops_per_launch": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N if et4 else None,
                          "executed_frac": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N / et / 1e12 / peak if et4 else None,
+                         # shader clock the kernel's blocks actually ran at (s_memtime / s_memrealtime inside the kernel): power
+                         # management holds it below the 2.4 GHz of `peak`; frac_at_clock prices the same FLOPs against the matrix
+                         # peak at that clock
+                         "clock_ghz": clk[0] / clk[1] / 10 if et4 and clk[1] else None,
+                         "frac_at_clock": achieved / (peak * (clk[0] / clk[1] / 10) / NOMINAL_GHZ) if et4 and clk[1] else None,
                          "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak},
             "results_d2h": {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": res_steps / (el + d2h)},
         }

@@ -17,6 +17,7 @@
 //     folded into the weight stream;
 //   * weight stream 512 KB per 256 pairs (edge_transition3: 640 KB per 128), 20 chunks through a 2 x 32 KB LDS ring.
 // Needs N % 4 == 0; other sizes run edge_transition3.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -74,6 +75,18 @@ __device__ unsigned long long e4_span[1024 * 3];  // per block: start, end (s_me
   do {              \
   } while (0)
 #endif
+// Shader clock actually sustained inside the kernel (the matrix peak scales with it: under dense MFMA load the chip runs well below
+// its 2.4 GHz nominal clock, and how far below depends on the operand bits — tools/micro/et4_bench.hip): per block, thread 0 adds
+// its core-clock cycles (s_memtime) and 100 MHz ticks (s_memrealtime) from start to end; fdipt_et4_clock reads the sums.  Three
+// atomics per block and launch.
+__device__ unsigned long long e4_clk[3];
+#define E4_CLK_BEGIN const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime()
+#define E4_CLK_END                                                                            \
+  if (threadIdx.x == 0) {                                                                     \
+    atomicAdd(&e4_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);           \
+    atomicAdd(&e4_clk[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0);        \
+    atomicAdd(&e4_clk[2], 1ull);                                                              \
+  }
 typedef fd_h e4_hx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x2 __attribute__((ext_vector_type(2)));
@@ -407,6 +420,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
   }
 }
 
+#if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)  // the chunk-synchronous predecessor: development / micro-benchmark builds only
 __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_kernel(ET2Args a, int n_tiles, int n_wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
@@ -628,10 +642,281 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_ker
   }
 #endif
 }
+#endif
+
+// ------------------------------------------------------------------ flat-stream kernel (round 2, end)
+// Same arithmetic, same MFMA order per accumulator (bit-identical results) as edge_transition4_kernel above; what changes is how
+// the 512 weight fragments of a tile reach the matrix cores.  Above: 20 chunks through a 2 x 32 KB ring, a DMA wait + barrier at
+// the END of every chunk and a fresh LDS prefetch prologue for each of the 28 (tile | chunk) units — 28 exposed LDS round trips and
+// 20 drained pipelines per 256 pairs.  Here the fragments are one cyclic stream f = 0 .. 511 (the next tile's continue it):
+//   * ring of FOUR 16 KB chunks (same 64 KB); chunk c + 3 is requested, and chunk c + 1 declared valid, at a barrier in the
+//     MIDDLE of chunk c (after fragment 16 c + 8): the wait there is for a DMA issued two chunks ago and nobody stands at a
+//     chunk boundary — the barrier orders (all waves are past chunk c - 1, whose slot the new DMA overwrites) without draining;
+//   * one operand ring of E4_DR fragments per wave runs through the whole tile, across feature tiles, chunks and layers;
+//   * no barrier and no vmcnt(0) at the tile end: z rows, fold fragments and pair masks are wave-private and are waited for by
+//     count (in-order vmcnt; every count below is a LOWER bound of the younger instructions, so it can only over-wait).
+#ifndef E4_DR
+#define E4_DR 4
+#endif
+#define E4_CHUNK 16384
+#define E4_DPC (E4_CHUNK / (E4_THREADS * 16))  // DMA instructions per chunk and wave
+__device__ __forceinline__ void e4_vm_wait(int n) {  // s_waitcnt vmcnt(n) (expcnt / lgkmcnt untouched); n folds after unrolling
+  __builtin_amdgcn_sched_barrier(0);
+  switch (n) {
+    case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+    case 14: __builtin_amdgcn_s_waitcnt(0x0F7E); break;
+    case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
+    case 18: __builtin_amdgcn_s_waitcnt(0x4F72); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+// younger VM instructions (guaranteed ones) than the DMA of chunk c + 1 at the barrier point of chunk c: always the DMA of chunk
+// c + 2; plus the 8 z requests issued at point 26, the 4 final-layer fold loads issued at point 28, the 12 + 2 fold / mask loads of
+// the tile boundary
+__device__ __forceinline__ constexpr int e4_vm_younger(int c) {
+  return E4_DPC + (c == 27 || c == 28 ? 8 : (c == 29 || c == 30 ? 4 : (c == 0 || c == 1 ? 14 : 0)));
+}
+__device__ __forceinline__ constexpr unsigned e4_ring_off(int f) { return (unsigned)(((f >> 4) & 3) * E4_CHUNK + (f & 15) * 1024); }
+struct E4Flat {
+  const char* stream;
+  unsigned lds0, pa;
+  int tid, wave;
+};
+__device__ __forceinline__ void e4_point(const E4Flat& F, int c) {
+  e4_vm_wait(e4_vm_younger(c));
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  const int cn = (c + 3) & 31;
+  e4_dma_chunk<E4_CHUNK>(F.stream + (size_t)cn * E4_CHUNK, F.lds0 + (unsigned)(cn & 3) * E4_CHUNK, F.tid, F.wave);
+}
+// one k-step of the stream: the operand ring is refilled E4_DR - 1 fragments ahead (not past the tile's last fragment)
+#define E4_STEP(f_, B_, acc_)                                                                                   \
+  do {                                                                                                          \
+    if ((f_) + E4_DR - 1 < 512) r[((f_) + E4_DR - 1) % E4_DR] = e4_frag(F.pa + e4_ring_off((f_) + E4_DR - 1)); \
+    acc_ = e4_mfma(r[(f_) % E4_DR], B_, acc_);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  } while (0)
+
+__global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_flat_kernel(ET2Args a, int n_tiles, int n_wt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+  const unsigned vec = lds0 + E4_VOFF;
+  const unsigned wbi = lds0 + E4_VOFF + 2560;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto lane_id = [] {
+    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  const int lane0 = lane_id(), tid0 = wave * 64 + lane0;
+  const int N = a.N, NJ4 = N >> 2, M = a.B * N;
+  const char* stream = (const char*)a.stream;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  E4_CLK_BEGIN;
+#ifdef E4_PROF
+  unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_amdgcn_s_memtime();
+  const unsigned long long span0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  E4Tile tc = e4_tile_of(tile * E4_WAVES + wave, n_wt, N, NJ4);
+  e4_request_z(a, tc, lane0, lds0 + E4_ZOFF + wave * 8192, M);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) e4_dma_chunk<E4_CHUNK>(stream + c * E4_CHUNK, lds0 + c * E4_CHUNK, tid0, wave);
+  if (tid0 < 160) {
+    const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
+    e4_dma16(src, vec + (tid0 & ~63) * 16);
+  }
+  if (a.wb_img)
+#pragma unroll
+    for (int u = 0; u < 512 / E4_THREADS; ++u)
+      e4_dma16((const char*)a.wb_img + (u * E4_THREADS + tid0) * 16, wbi + (u * E4_THREADS + (tid0 & ~63)) * 16);
+  auto fold_ptr = [&](const E4Tile& t, int lane) {
+    const unsigned fold_b1 = (unsigned)((const char*)a.b1_img - (const char*)a.a1_img);
+    const unsigned ob = fold_b1 + (unsigned)((t.b0 * NJ4 + t.jt) * 16) * 512u, oa = (unsigned)(t.rt * 16) * 512u;  // scalar
+    return oa + (unsigned)(lane >> 5) * (ob - oa) + (lane & 31) * 16;
+  };
+  auto fold_ld = [&](unsigned off) { return e4_gfrag((const char*)a.a1_img + off); };
+  unsigned fold_base = fold_ptr(tc, lane0);
+  hx8 FA[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
+  auto mask_of = [&](const E4Tile& t, int lane) {
+    int row = 8 * t.rt + ((lane & 31) >> 2);
+    if (row > M - 1) row = M - 1;
+    return a.res_mask[row] * a.res_mask[(row / N) * N + 4 * t.jt + (lane & 3)];
+  };
+  if (tid0 < 8) *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_BOFF + tid0 * 4) = (a.wb_img && tid0 < a.H) ? a.bb[tid0] : 0.f;
+  float em_req = mask_of(tc, lane0);
+  E4Epi E;
+  e4_dma_wait();
+  *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid0 * 4) = em_req;
+  __syncthreads();
+  E4_STAMP(0);
+#pragma unroll 1
+  for (;;) {
+    const int lane = lane_id(), tid = wave * 64 + lane;
+    const int p = lane & 31, half = lane >> 5;
+    const unsigned zst = lds0 + E4_ZOFF + wave * 8192;
+    const unsigned zrow = zst + p * 256;
+    E4Flat F;
+    F.stream = stream; F.lds0 = lds0; F.pa = lds0 + lane * 16; F.tid = tid; F.wave = wave;
+    hx8 r[E4_DR];
+#pragma unroll
+    for (int m = 0; m < E4_DR - 1; ++m) r[m] = e4_frag(F.pa + e4_ring_off(m));
+    hx8 H1[24], H2[24];
+    // ================= layer 1: fragments 0 .. 95 (12 tiles x 8 k-steps of z, + the fold step)
+    {
+      const hx8 SEL = e4_sel(lane, tc.ns);
+      hx8 Zf[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) Zf[s] = e4_frag(zrow + (((2 * s) ^ (half ^ (p & 15))) << 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int T = 0; T < 12; ++T) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        acc = e4_mfma(FA[T], SEL, acc);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int f = 8 * T + s;
+          if ((f & 15) == 8) e4_point(F, f >> 4);
+          E4_STEP(f, Zf[s], acc);
+        }
+        e4_hand_off(acc, H1[2 * T], H1[2 * T + 1]);
+      }
+    }
+    E4_STAMP(1);
+    // ================= layer 2: fragments 96 .. 383 (12 tiles x 24 k-steps); the accumulator starts as b2
+#pragma unroll
+    for (int T = 0; T < 12; ++T) {
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = e4_ldsf4(vec + 4 * (32 * T + 8 * g + 4 * half));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 * g + q] = bv[q];
+      }
+#pragma unroll
+      for (int s = 0; s < 24; ++s) {
+        const int f = E4_L1_FR + 24 * T + s;
+        if ((f & 15) == 8) e4_point(F, f >> 4);
+        E4_STEP(f, H1[s], acc);
+      }
+      e4_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
+    }
+    E4_STAMP(2);
+    // ================= final layer: fragments 384 .. 511, k-major over the 4 output tiles (8 k-steps of z re-read from the wave's
+    // LDS rows, 24 of h2), then the fold step
+    const int ntile = tile + gridDim.x;
+    const bool has_next = ntile < n_tiles;
+    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * E4_WAVES + wave, n_wt, N, NJ4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) E.Y[t][q] = 0.f;
+    hx8 FL[4];
+    {
+      hx8 zb[2];
+      const int l2 = lane_id();  // the z row address again, from an opaque copy (otherwise the 8 layer-1 addresses stay live)
+      const unsigned zrow2 = lds0 + E4_ZOFF + wave * 8192 + (l2 & 31) * 256, zx = (l2 >> 5) ^ (l2 & 15);
+      zb[0] = e4_frag(zrow2 + (zx << 4));
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int f = E4_L1_FR + E4_L2_FR + 4 * s + t;
+          if ((f & 15) == 8) e4_point(F, f >> 4);
+          if (t == 0 && s + 1 < 8) zb[(s + 1) & 1] = e4_frag(zrow2 + (((2 * (s + 1)) ^ zx) << 4));
+          E4_STEP(f, zb[s & 1], E.Y[t]);
+        }
+#pragma unroll
+      for (int s = 8; s < 32; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int f = E4_L1_FR + E4_L2_FR + 4 * s + t;
+          if ((f & 15) == 8) {
+            e4_point(F, f >> 4);
+            // point 26: the wave's z rows are free since fragment 415 — the next tile's are requested here, 5 chunks before the
+            // tile ends (always issued, the last tile re-requests its own: the counts of e4_vm_younger stay static)
+            if ((f >> 4) == 26) e4_request_z(a, tn, lane_id(), lds0 + E4_ZOFF + wave * 8192, M);
+            if ((f >> 4) == 28) {
+              const unsigned fb = fold_ptr(tc, lane_id());
+#pragma unroll
+              for (int k = 0; k < 4; ++k) FL[k] = fold_ld(fb + (12 + k) * 512);
+            }
+          }
+          E4_STEP(f, H2[s - 8], E.Y[t]);
+        }
+    }
+    {
+      const hx8 SEL = e4_sel(lane, tc.ns);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) E.Y[t] = e4_mfma(FL[t], SEL, E.Y[t]);
+    }
+    E4_STAMP(3);
+    // ================= tile boundary: the next tile's fold fragments and pair mask are requested, then the LayerNorm epilogue runs
+    fold_base = fold_ptr(tn, lane);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
+    E.t = tc;
+    em_req = mask_of(tn, lane);
+    if (!(E4_ABL & 1)) {
+      E4EpiTmp X;
+      X.moff = lds0 + E4_MOFF + tid * 4;
+      X.boff = lds0 + E4_BOFF;
+      const unsigned stg = lds0 + E4_SOFF + wave * 2048;
+      e4_epi<0>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<1>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<2>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<3>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<4>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<5>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<6>(E, X, a, lane, vec, wbi, stg, M);
+    } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
+    E4_STAMP(4);
+    if (!has_next) break;
+    tile = ntile;
+    tc = tn;
+    // the z rows (requested at point 26) are older than the 12 + 2 boundary loads and the epilogue's stores: in-order vmcnt
+    e4_vm_wait(14);
+    *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid * 4) = em_req;  // (this lane's own slot)
+    E4_STAMP(5);
+  }
+  e4_dma_wait();  // the last tile's stream DMAs (chunks 0..2 again, never read) must not outlive the block's LDS
+  E4_CLK_END;
+#ifdef E4_PROF
+  if (tid0 == 0 && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) e4_prof[blockIdx.x * 8 + k] = ph[k];
+  if (tid0 == 0 && blockIdx.x < 1024) {
+    e4_span[blockIdx.x * 3] = span0;
+    e4_span[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+    e4_span[blockIdx.x * 3 + 2] = 0;
+  }
+#endif
+}
 
 int fd_edge_transition4_supported(int N) { return N >= 8 && N <= 2048 && N % 4 == 0; }
 
+#ifndef E4_FLAT
+#define E4_FLAT 1  // 1: edge_transition4_flat_kernel, 0: the chunk-synchronous kernel
+#endif
+int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat);
 int fd_edge_transition4(const ET2Args& a, hipStream_t st) {
+#ifdef FDIPT_DEV  // development build: FDIPT_ET4_FLAT=0/1 selects the kernel (same-box A/B runs)
+  static const int flat = [] { const char* e = getenv("FDIPT_ET4_FLAT"); return e ? atoi(e) : E4_FLAT; }();
+  return fd_edge_transition4_variant(a, st, flat);
+#else
+  return fd_edge_transition4_variant(a, st, E4_FLAT);
+#endif
+}
+int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   const long n_pairs = (long)a.B * a.N * a.N;
   if (n_pairs >= (1L << 31) - 256 || !a.a1_img || !a.b1_img || a.N % 4) return FDIPT_EINVAL;  // 32-bit pair indices in the kernel
   {  // the kernel addresses both fold images with 32-bit offsets from a1_img
@@ -642,8 +927,12 @@ int fd_edge_transition4(const ET2Args& a, hipStream_t st) {
   const int n_tiles = cdiv(n_wt, E4_WAVES);
   static bool attr_set = false;
   if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)edge_transition4_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
+      return FDIPT_ELAUNCH;
+#if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)
     if (hipFuncSetAttribute((const void*)edge_transition4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
       return FDIPT_ELAUNCH;
+#endif
     attr_set = true;
   }
   static int n_cu = 0;
@@ -657,7 +946,21 @@ int fd_edge_transition4(const ET2Args& a, hipStream_t st) {
   const int cus = a.reserve_cus > 0 && a.reserve_cus < n_cu - 8 ? (n_cu - a.reserve_cus) & ~7 : n_cu;
   const int slots = cus * (E4_LDS <= 81920 ? 2 : 1);
   const int grid = n_tiles < slots ? n_tiles : slots;
-  hipLaunchKernelGGL(edge_transition4_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
+#if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)
+  if (!flat) hipLaunchKernelGGL(edge_transition4_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
+  else
+#endif
+    hipLaunchKernelGGL(edge_transition4_flat_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
   FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+extern "C" int fdipt_et4_clock(unsigned long long* out3_host, int reset) {
+  if (!out3_host) return FDIPT_EINVAL;
+  if (hipMemcpyFromSymbol(out3_host, HIP_SYMBOL(e4_clk), 24) != hipSuccess) return FDIPT_ELAUNCH;
+  if (reset) {
+    const unsigned long long z[3] = {0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(e4_clk), z, 24) != hipSuccess) return FDIPT_ELAUNCH;
+  }
   return FDIPT_OK;
 }

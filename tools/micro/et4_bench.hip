@@ -1,36 +1,79 @@
 // Stand-alone timing + in-kernel phase profile of edge_transition4_kernel (build with -DFD_PROF for the profile).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w [-DFD_PROF] [-DE4_ABL=k] tools/micro/et4_bench.hip -o et4_bench
+#define E4_KEEP_CHUNK
 #include "../../framedipt_amd/csrc/edge_transition4.hip"
 #include <cstdio>
 #include <vector>
+int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat);
+__global__ void fill_f32(float* p, long n, unsigned seed, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = ((h & 0xFFFF) / 65536.f - 0.5f) * 2.f * scale;
+  }
+}
+__global__ void fill_h16(half_t* p, long n, unsigned seed, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = f2h(((h & 0xFFFF) / 65536.f - 0.5f) * 2.f * scale);
+  }
+}
+__global__ void diff_count(const unsigned* x, const unsigned* y, long n, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) c += x[i] != y[i];
+  if (c) atomicAdd(out, c);
+}
 int main(int argc, char** argv) {
   const int B = 8, N = argc > 1 ? atoi(argv[1]) : 300;
+  const int only = argc > 3 ? atoi(argv[3]) : -1;  // time only this variant (0 chunk-synchronous, 1 flat)
+  const float ds = argc > 4 ? atof(argv[4]) : 1.f;  // data scale (0: all-zero operands, the low-power case)
   const long P = (long)B * N * N, R = (long)B * N;
-  half_t* z; float *e, *a1, *af, *b2, *g, *bt, *rm; void* stream;
-  (void)hipMalloc(&z, P * 128 * 2); (void)hipMalloc(&e, R * 128 * 4); (void)hipMalloc(&a1, R * 384 * 4); (void)hipMalloc(&af, R * 128 * 4);
+  half_t *z, *zo[2]; float *b2, *g, *bt, *rm, *w1, *w2, *wf, *wb, *rows, *bo[2]; void* stream;
+  (void)hipMalloc(&z, P * 128 * 2); (void)hipMalloc(&zo[0], P * 128 * 2); (void)hipMalloc(&zo[1], P * 128 * 2);
   (void)hipMalloc(&b2, 384 * 4); (void)hipMalloc(&g, 128 * 4); (void)hipMalloc(&bt, 128 * 4); (void)hipMalloc(&rm, R * 4);
+  (void)hipMalloc(&w1, 384 * 384 * 4); (void)hipMalloc(&w2, 384 * 384 * 4); (void)hipMalloc(&wf, 128 * 384 * 4); (void)hipMalloc(&wb, 8 * 128 * 4);
+  (void)hipMalloc(&rows, R * 1024 * 4);
   (void)hipMalloc(&stream, fd_et4_stream_bytes());
-  (void)hipMemset(z, 0, P * 128 * 2); (void)hipMemset(e, 0, R * 128 * 4); (void)hipMemset(a1, 0, R * 384 * 4); (void)hipMemset(af, 0, R * 128 * 4);
-  (void)hipMemset(b2, 0, 384 * 4); (void)hipMemset(g, 0, 128 * 4); (void)hipMemset(bt, 0, 128 * 4); (void)hipMemset(rm, 0, R * 4);
-  (void)hipMemset(stream, 0, fd_et4_stream_bytes());
-  ET2Args a; a.B = B; a.N = N; a.z_in = z; a.z_out = z; a.e = e; a.a1 = a1; a.af = af; a.stream = stream; a.b2 = b2; a.gamma = g;
-  a.beta = bt; a.res_mask = rm; a.trace = nullptr;
+  fill_h16<<<1024, 256>>>(z, P * 128, 1u, 1.0f * ds);
+  fill_f32<<<64, 256>>>(b2, 384, 2u, 0.1f); fill_f32<<<64, 256>>>(g, 128, 3u, 1.0f); fill_f32<<<64, 256>>>(bt, 128, 4u, 0.2f);
+  fill_f32<<<64, 256>>>(w1, 384 * 384, 5u, 0.08f * ds); fill_f32<<<64, 256>>>(w2, 384 * 384, 6u, 0.08f * ds); fill_f32<<<64, 256>>>(wf, 128 * 384, 7u, 0.08f * ds);
+  fill_f32<<<64, 256>>>(wb, 8 * 128, 8u, 0.1f); fill_f32<<<256, 256>>>(rows, R * 1024, 9u, 0.5f * ds);
+  { std::vector<float> m(R, 1.f); for (long i = 0; i < R; i += 37) m[i] = 0.f; (void)hipMemcpy(rm, m.data(), R * 4, hipMemcpyHostToDevice); }
+  fd_et4_build_stream(w1, w2, wf, stream, 0);
+  ET2Args a; a.B = B; a.N = N; a.z_in = z; a.e = nullptr; a.a1 = nullptr; a.af = nullptr; a.stream = stream; a.b2 = b2; a.gamma = g;
+  a.beta = bt; a.res_mask = rm; a.trace = nullptr; a.reserve_cus = 0;
   { char* ai; const size_t na = fd_et4_a_image_bytes(B, N), nb = fd_et4_b_image_bytes(B, N);  // one allocation: 32-bit offsets between the images
-    (void)hipMalloc(&ai, na + nb); (void)hipMemset(ai, 0, na + nb); a.a1_img = ai; a.b1_img = ai + na; a.e_h16 = nullptr; }
+    (void)hipMalloc(&ai, na + nb); a.a1_img = ai; a.b1_img = ai + na; a.e_h16 = nullptr;
+    fd_et4_row_images(rows, B, N, ai, ai + na, 0); }
+  const long Np = (N + 31) / 32 * 32;
   {  // next block's pair bias from the epilogue (argv[2] = 0 disables)
-    void* wimg; float* bo; const long Np = (N + 31) / 32 * 32;
-    (void)hipMalloc(&wimg, 8192); (void)hipMemset(wimg, 0, 8192); (void)hipMalloc(&bo, (size_t)B * 8 * Np * Np * 4);
-    a.wb_img = (argc > 2 && atoi(argv[2]) == 0) ? nullptr : wimg; a.bb = b2; a.bias_out = bo; a.H = 8;
+    void* wimg;
+    (void)hipMalloc(&wimg, 8192); fd_et4_build_bias_image(wb, 8, 0.57735f, wimg, 0);
+    (void)hipMalloc(&bo[0], (size_t)B * 8 * Np * Np * 4); (void)hipMalloc(&bo[1], (size_t)B * 8 * Np * Np * 4);
+    (void)hipMemset(bo[0], 0, (size_t)B * 8 * Np * Np * 4); (void)hipMemset(bo[1], 0, (size_t)B * 8 * Np * Np * 4);
+    a.wb_img = (argc > 2 && atoi(argv[2]) == 0) ? nullptr : wimg; a.bb = b2; a.H = 8;
   }
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
-  for (int i = 0; i < 3; ++i) fd_edge_transition4(a, 0);
-  (void)hipEventRecord(t0, 0);
-  const int iters = 20;
-  for (int i = 0; i < iters; ++i) fd_edge_transition4(a, 0);
-  (void)hipEventRecord(t1, 0); (void)hipEventSynchronize(t1);
-  float ms; (void)hipEventElapsedTime(&ms, t0, t1);
   const double flops = 655360.0 * P;
-  printf("ET4 N=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 2500)\n", N, ms / iters, flops / (ms / iters) / 1e9, flops / (ms / iters) / 1e9 / 25.0);
+  for (int v = 0; v < 2; ++v) {
+    if (only >= 0 && v != only) continue;
+    a.z_out = zo[v]; a.bias_out = bo[v];
+    for (int i = 0; i < 3; ++i) fd_edge_transition4_variant(a, 0, v);
+    (void)hipEventRecord(t0, 0);
+    const int iters = 20;
+    for (int i = 0; i < iters; ++i) fd_edge_transition4_variant(a, 0, v);
+    (void)hipEventRecord(t1, 0); (void)hipEventSynchronize(t1);
+    float ms; (void)hipEventElapsedTime(&ms, t0, t1);
+    printf("ET4 %s N=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 2500)\n", v ? "flat " : "chunk", N, ms / iters, flops / (ms / iters) / 1e9, flops / (ms / iters) / 1e9 / 25.0);
+  }
+  if (only < 0) {
+    unsigned long long* d; (void)hipMalloc(&d, 16); (void)hipMemset(d, 0, 16);
+    diff_count<<<1024, 256>>>((const unsigned*)zo[0], (const unsigned*)zo[1], P * 64, d);
+    diff_count<<<1024, 256>>>((const unsigned*)bo[0], (const unsigned*)bo[1], (long)B * 8 * Np * Np, d + 1);
+    unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    std::vector<half_t> hz(4096); (void)hipMemcpy(hz.data(), zo[0] + (P / 2) * 128, 8192, hipMemcpyDeviceToHost);
+    double sa = 0; for (auto x : hz) sa += fabs((double)(float)__builtin_bit_cast(_Float16, x));
+    printf("flat vs chunk: %llu differing z words of %ld, %llu differing bias words; mean |z'| %.4f\n", h[0], P * 64, h[1], sa / 4096);
+  }
 #ifdef E4_PROF
   {
     std::vector<unsigned> h(256 * 8);

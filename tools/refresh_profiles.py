@@ -32,7 +32,7 @@ def key(tab, prefix):
     return next(k for k in tab if k.startswith(prefix))
 
 
-ET, A3, OP, EE = "edge_transition4_kernel", "ipa_attn3_kernel", "opair_mfma_kernel", "edge_embed2_kernel"
+ET, A3, OP, EE = "edge_transition4_flat_kernel", "ipa_attn3_kernel", "opair_mfma_kernel", "edge_embed2_kernel"
 util = {k: busy[k] / 1024 / (gui[k] / 8) for k in busy if k in gui}
 et_f, et_w = F[ET] * 1024, W[ET] * 1024
 B, N = 8, 300
@@ -46,7 +46,7 @@ open(P + "r02_bench_c4_fp16_kernel_stats.md", "w").write(
     "# Round 2 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (1 x MI355X, config c4: fp16 mode, N=300, B=8)\n\n"
     "The SAME command as the bench line in r02_bench.json (whole T = 500 trajectory: 5 warm-up steps on a scratch trajectory, priming\n"
     "forward + 500 steps timed).  Per-kernel totals over the whole process (prepare-time kernels and the D2H of the trajectories,\n"
-    f"`__amd_rocclr_copyBuffer`, included).  edge_transition4_kernel: {et_us:.1f} us average here vs {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us\n"
+    f"`__amd_rocclr_copyBuffer`, included).  edge_transition4_flat_kernel: {et_us:.1f} us average here vs {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us\n"
     "from the HIP events of the bench's timed region.\n\n" + open(d + "kernel_stats.md").read())
 
 if os.path.exists(d + "kernel_stats_c5.md"):
@@ -72,7 +72,7 @@ calibrates as is.  Both calibrations re-checked on this run:
 
 MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) (GRBM_GUI_ACTIVE is summed over the 8 XCDs).
 
-## edge_transition4_kernel (the roofline kernel of bench.py), per launch
+## edge_transition4_flat_kernel (the roofline kernel of bench.py), per launch
 * SQ_VALU_MFMA_BUSY_CYCLES {busy[ET]:,.0f} = 22,500 wave patches x 536 MFMAs x 32 cycles (v_mfma_f32_32x32x16_f16 at the bf16 rate).
 * MFMA utilisation {util[ET] * 100:.1f} % of the launch's cycles (executed FLOPs 548,864 per pair; on the reference count of 688,128 per pair:
   {bench['roofline']['frac'] * 100:.1f} % of the 2.5 PFLOP/s peak at the bench's {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us per launch).
