@@ -24,7 +24,7 @@
 #include "kernels.hpp"
 
 #ifndef E4_ABL
-#define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA
+#define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 16 (flat) no LDS fragment reads
 #endif
 #ifndef E4_D1
 #define E4_D1 3   // weight-fragment ring depths: layer 1, layer 2, final layer
@@ -698,7 +698,7 @@ __device__ __forceinline__ void e4_point(const E4Flat& F, int c) {
 // one k-step of the stream: the operand ring is refilled E4_DR - 1 fragments ahead (not past the tile's last fragment)
 #define E4_STEP(f_, B_, acc_)                                                                                   \
   do {                                                                                                          \
-    if ((f_) + E4_DR - 1 < 512) r[((f_) + E4_DR - 1) % E4_DR] = e4_frag(F.pa + e4_ring_off((f_) + E4_DR - 1)); \
+    if ((f_) + E4_DR - 1 < 512 && (!(E4_ABL & 16) || (f_) < 8)) r[((f_) + E4_DR - 1) % E4_DR] = e4_frag(F.pa + e4_ring_off((f_) + E4_DR - 1)); \
     acc_ = e4_mfma(r[(f_) % E4_DR], B_, acc_);                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   } while (0)
