@@ -57,6 +57,24 @@ if os.path.exists(d + "kernel_stats_c5.md"):
         f"{c5['roofline']['avg_launch_ms']:.2f} ms per launch = {c5['roofline']['frac'] * 100:.1f} % of the 157.3 TFLOP/s fp32 matrix peak (`v_mfma_f32_32x32x2_f32`; "
         "round 1: 51 ms = 34 %).\n\n" + open(d + "kernel_stats_c5.md").read())
 
+def frame_row(prefix, what, alg_bytes_per_res):
+    k = next((k for k in kst if k.startswith(prefix)), None)
+    if k is None:
+        return ""
+    fk, wk = next((x for x in F if x.startswith(prefix)), None), next((x for x in W if x.startswith(prefix)), None)
+    if fk and wk:
+        nbytes, src = 2 * F[fk] * 1024 + W[wk] * 1024, "PMC"
+    else:
+        nbytes, src = alg_bytes_per_res * B * N, "algorithmic"
+    gbs = nbytes / kst[k] / 1e3
+    return f"| `{k[:40]}` | {what} | {nbytes / 1e6:.2f} MB ({src}) | {kst[k]:.1f} | {gbs:.0f} | {gbs / 8000 * 100:.1f} % |\n"
+
+
+frame_rows = (frame_row("reverse_step_kernel", "SE(3) reverse step + atom37 of x_{t-1} + trajectory rows", 28 + 24 + 12 + 48 + 8 + 28 + 444 + 12)
+              + frame_row("backbone_kernel", "atom37 / atom14 from frames + psi", 28 + 8 + 4 + 444 + 168)
+              + frame_row("rot_score_kernel", "IGSO(3) score, R^3 score, tensor_7 / psi epilogue, last torsion layer", 1024 + 28 + 28 + 24 + 12 + 8)
+              + frame_row("points16_kernel", "Rigid.apply of the q / k / v points -> MFMA fragment images (x4 per step)", 8 * 28 * 3 * 4 * 2)
+              + frame_row("build_feats_kernel", "x_t split, node / pair feature rows", 1024))
 fetch_ee = next((f"2 x {F[k] * 1024 / 1e6:.0f} MB" for k in F if k.startswith(EE)), "below the ten largest of the step")
 hdr = f"""# Round 2 — PMC counters of the bench command (MI355X, config c4: fp16 mode, N=300, B=8)
 
@@ -98,6 +116,13 @@ attention GEMMs"
 * `edge_embed2_kernel`: 207 MB written in {kst[key(kst, EE)]:.1f} us = {W[key(W, EE)] * 1024 / kst[key(kst, EE)] / 1e6:.2f} TB/s; MFMA utilisation {util[key(util, EE)] * 100:.1f} % (47 GF): bound by neither
   (since the row-walk decomposition of round 2 its table rows come out of L2 / LDS: FETCH_SIZE {fetch_ee}; phase profile in DESIGN.md section 4.4).
 
+## Frame ops (the north star's "achieved HBM GB/s on the frame ops against CDNA4 peak")
+B N = 2400 residues per launch: a few hundred bytes per residue, so these launches are latency-bound (one residue per lane, float64 chains),
+nowhere near the 8 TB/s HBM peak — which is why they are folded into as few launches as possible (DESIGN.md section 4.3).  Bytes =
+memory-side traffic of the PMC passes where the kernel is in their tables (2 x FETCH + WRITE), else the algorithmic bytes per residue.
+| kernel | what | bytes per launch | us per launch | achieved GB/s | of 8 TB/s |
+|---|---|---|---|---|---|
+{frame_rows}
 ## MFMA utilisation of every kernel with matrix work
 | kernel | us per launch | MFMA busy cycles | utilisation |
 |---|---|---|---|
