@@ -163,3 +163,26 @@ def test_edge_transition_clock_probe():
     assert 0.3 < cycles / ticks / 10 < 2.6  # GHz (ticks are 10 ns)
     _lib.check(lib.fdipt_et4_clock(out, 0))
     assert out[0] == out[1] == out[2] == 0
+
+
+@pytest.mark.parametrize("n,b", [(12, 3), (44, 2), (132, 3), (260, 2)])
+def test_half_precision_forward_tracks_the_fp32_mode_at_odd_sizes(n, b):
+    """Sizes between the golden fixtures (N % 8 == 4: EdgeTransition patches straddle samples; N = 12 / 44: the small-N kernel
+    selections): the half-precision forward (default pair kernels, and the edge_transition3 fallback via FDIPT_KF_ET3) stays within
+    5e-4 A backbone RMSD of the fp32 mode on the same inputs (measured 1.0e-4 ... 1.8e-4: tools/size_sweep.py)."""
+    from framedipt_amd import _lib
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.model.score_network import BatchState
+    net32, st32, args = _setup(n, b, "fp32")
+    st32.forward(*args)
+    torch.cuda.synchronize()
+    ref = st32.atom37.double().cpu().numpy()[:, :, [0, 1, 2, 4]]
+    for kf in (0, _lib.KF_ET3):
+        net = ScoreNetwork(net32._model_conf, net32.diffuser, precision="fp16", kernel_flags=kf).load_synthetic(7).to("cuda")
+        st = BatchState(net, st32.seq_idx)
+        st.forward(*args)
+        torch.cuda.synchronize()
+        got = st.atom37.double().cpu().numpy()[:, :, [0, 1, 2, 4]]
+        assert np.isfinite(got).all()
+        rmsd = np.sqrt(((got - ref) ** 2).sum(-1).mean(axis=(1, 2))).max()
+        assert rmsd < 5e-4, (n, b, kf, rmsd)
