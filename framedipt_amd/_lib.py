@@ -94,7 +94,7 @@ SIGNATURES = {
     "fdipt_event_destroy": (_i, [_P]),
     "fdipt_event_record": (_i, [_P, _P]),
     "fdipt_event_elapsed_ms": (_i, [_P, _P, C.POINTER(_f)]),
-    "fdipt_et4_clock": (_i, [C.POINTER(C.c_ulonglong), _i]),
+    "fdipt_edge_transition_clock": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "fdipt_version": (C.c_char_p, []),
 }
 

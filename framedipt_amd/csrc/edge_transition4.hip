@@ -76,17 +76,11 @@ __device__ unsigned long long e4_span[1024 * 3];  // per block: start, end (s_me
   } while (0)
 #endif
 // Shader clock actually sustained inside the kernel (the matrix peak scales with it: under dense MFMA load the chip runs well below
-// its 2.4 GHz nominal clock, and how far below depends on the operand bits — tools/micro/et4_bench.hip): per block, thread 0 adds
-// its core-clock cycles (s_memtime) and 100 MHz ticks (s_memrealtime) from start to end; fdipt_et4_clock reads the sums.  Three
-// atomics per block and launch.
+// its 2.4 GHz nominal clock, and how far below depends on the operand bits — tools/micro/et4_bench.hip): common.hpp FD_CLK_*,
+// read by fdipt_edge_transition_clock.  Three atomics per block and launch.
 __device__ unsigned long long e4_clk[3];
-#define E4_CLK_BEGIN const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime()
-#define E4_CLK_END                                                                            \
-  if (threadIdx.x == 0) {                                                                     \
-    atomicAdd(&e4_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);           \
-    atomicAdd(&e4_clk[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0);        \
-    atomicAdd(&e4_clk[2], 1ull);                                                              \
-  }
+#define E4_CLK_BEGIN FD_CLK_BEGIN
+#define E4_CLK_END FD_CLK_END(e4_clk)
 typedef fd_h e4_hx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x2 __attribute__((ext_vector_type(2)));
@@ -955,9 +949,8 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   return FDIPT_OK;
 }
 
-extern "C" int fdipt_et4_clock(unsigned long long* out3_host, int reset) {
-  if (!out3_host) return FDIPT_EINVAL;
-  if (hipMemcpyFromSymbol(out3_host, HIP_SYMBOL(e4_clk), 24) != hipSuccess) return FDIPT_ELAUNCH;
+int fd_et4_clock(unsigned long long* out3, int reset) {
+  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(e4_clk), 24) != hipSuccess) return FDIPT_ELAUNCH;
   if (reset) {
     const unsigned long long z[3] = {0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(e4_clk), z, 24) != hipSuccess) return FDIPT_ELAUNCH;

@@ -321,5 +321,7 @@ int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int l
                  const float* res_mask, double* score, hipStream_t st);
 int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,
                    float max_b, float cs, const float* res_mask, float* score, hipStream_t st);
+int fd_et4_clock(unsigned long long* out3, int reset);   // edge_transition4.hip / pair_mlp.hip: in-kernel shader-clock probes
+int fd_etf_clock(unsigned long long* out3, int reset);
 int fd_backbone(int n, const float* t7, const float* rot, const float* trans, int ld_trans, const float* psi,
                 const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st);

@@ -1165,6 +1165,14 @@ int fdipt_edge_transition_fwd(const FdiptDims* d, const float* P, const void* de
   return forward_impl(d, P, derived, nullptr, &a, workspace, workspace_bytes, stream, op);
 }
 
+int fdipt_edge_transition_clock(unsigned long long* out3_host, int reset) {
+  if (!out3_host) return FDIPT_EINVAL;
+  unsigned long long h[3], f[3];
+  RC(fd_et4_clock(h, reset));
+  RC(fd_etf_clock(f, reset));
+  for (int k = 0; k < 3; ++k) out3_host[k] = h[k] + f[k];
+  return FDIPT_OK;
+}
 int fdipt_event_create(void** ev_host) {
   if (!ev_host) return FDIPT_EINVAL;
   hipEvent_t e;

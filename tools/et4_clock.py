@@ -16,7 +16,7 @@ ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "len
 items = [sharding.seeded_item(ds, i, 3, d, T, 0.01) for i in range(B)]
 feats, tape = sharding.stack_items(items)
 lib = _lib.load()
-fn = lib.fdipt_et4_clock
+fn = lib.fdipt_edge_transition_clock
 out = (C.c_ulonglong * 3)()
 inference_fn(net, d, feats, num_t=10, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tuple(z[:10] for z in tape))
 torch.cuda.synchronize(); fn(out, 1)
