@@ -286,7 +286,7 @@ def main():
                        "kernel_flags": a.kernel_flags},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(prec, N, B), "kernel": "edge_transition4_flat_kernel" if et4 else
-                         ("edge_transition3_kernel" if prec == "fp16" else "edge_transition_f32_kernel"),
+                         ("edge_transition3_kernel" if prec == "fp16" else "edge_transition_f32ws_kernel"),
                          "avg_launch_ms": et * 1e3, "launches_timed": len(et_ms), "flops_per_launch": et_flops,
                          "executed_flops_per_launch": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N if et4 else None,
                          "executed_frac": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N / et / 1e12 / peak if et4 else None,

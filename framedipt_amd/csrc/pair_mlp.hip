@@ -235,6 +235,14 @@ struct EtfStream {
     const int tl = t < 36 ? t : (t < 72 ? t - 36 : t - 72);
     return W + (long)((tl / 12) * 128) * ETF_H + (tl % 12) * 32;
   }
+  // the same as an integer, without a run-time choice among pointers (hipcc turns that into a table in scratch memory)
+  __device__ __forceinline__ unsigned long addr(int t) const {
+    t = t < ETF_TILES ? t : t - ETF_TILES;
+    const unsigned long a1 = (unsigned long)w1, a2 = (unsigned long)w2, af = (unsigned long)wf;
+    const unsigned long base = a1 + (t >= 36 ? a2 - a1 : 0ul) + (t >= 72 ? af - a2 : 0ul);
+    const int tl = t < 36 ? t : (t < 72 ? t - 36 : t - 72);
+    return base + ((unsigned long)((tl / 12) * 128) * ETF_H + (tl % 12) * 32) * 4;
+  }
   __device__ __forceinline__ void load(EtfTile& r, int t, int tid) const {
     if (t >= ETF_TILES) return;
     const float* W = t < 36 ? w1 : (t < 72 ? w2 : wf);
@@ -296,11 +304,23 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
 #ifndef ETF_ABL
 #define ETF_ABL 0  // timing ablations of tools/micro/etf_bench.hip (results are wrong with any bit set)
 #endif
+#ifndef ETF_ORDER
+#define ETF_ORDER 1  // 1: LDS stores right behind the barrier, L2 requests at the end of the step; 0: the other way round
+#endif
+#define ETF_ST(k) if (!(ETF_ABL & 2)) *(f32x4*)(wd + (k) * 32 * ETF_LDW) = gs.r[k]
+#define ETF_LD(k) if (!(ETF_ABL & 4)) gl.r[k] = *(const f32x4*)(src + (k) * 32 * ETF_H)
     ETF_MMA(0);  ETF_GAP(if (!(ETF_ABL & 1)) __syncthreads());
-    ETF_MMA(1);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[0] = *(const f32x4*)(src));
-    ETF_MMA(2);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[1] = *(const f32x4*)(src + 32 * ETF_H));
-    ETF_MMA(3);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[2] = *(const f32x4*)(src + 64 * ETF_H));
-    ETF_MMA(4);  ETF_GAP(if (!(ETF_ABL & 4)) gl.r[3] = *(const f32x4*)(src + 96 * ETF_H));
+    if (ETF_ORDER) {
+      ETF_MMA(1);  ETF_GAP(ETF_ST(0));
+      ETF_MMA(2);  ETF_GAP(ETF_ST(1));
+      ETF_MMA(3);  ETF_GAP(ETF_ST(2));
+      ETF_MMA(4);  ETF_GAP(ETF_ST(3));
+    } else {
+      ETF_MMA(1);  ETF_GAP(ETF_LD(0));
+      ETF_MMA(2);  ETF_GAP(ETF_LD(1));
+      ETF_MMA(3);  ETF_GAP(ETF_LD(2));
+      ETF_MMA(4);  ETF_GAP(ETF_LD(3));
+    }
     ETF_MMA(5);  ETF_GAP(nxt.a[0] = *(const f32x4*)(an));
     ETF_MMA(6);  ETF_GAP(nxt.w[0] = *(const f32x4*)(wn));
     ETF_MMA(7);  ETF_GAP(nxt.a[1] = *(const f32x4*)(an + 8));
@@ -309,10 +329,19 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
     ETF_MMA(10); ETF_GAP(nxt.w[2] = *(const f32x4*)(wn + 16));
     ETF_MMA(11); ETF_GAP(nxt.a[3] = *(const f32x4*)(an + 24));
     ETF_MMA(12); ETF_GAP(nxt.w[3] = *(const f32x4*)(wn + 24));
-    ETF_MMA(13); ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd) = gs.r[0]);
-    ETF_MMA(14); ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd + 32 * ETF_LDW) = gs.r[1]);
-    ETF_MMA(15); ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd + 64 * ETF_LDW) = gs.r[2]);
-    ETF_GAP(if (!(ETF_ABL & 2)) *(f32x4*)(wd + 96 * ETF_LDW) = gs.r[3]);
+    if (ETF_ORDER) {
+      ETF_MMA(13); ETF_GAP(ETF_LD(0));
+      ETF_MMA(14); ETF_GAP(ETF_LD(1));
+      ETF_MMA(15); ETF_GAP(ETF_LD(2));
+      ETF_GAP(ETF_LD(3));
+    } else {
+      ETF_MMA(13); ETF_GAP(ETF_ST(0));
+      ETF_MMA(14); ETF_GAP(ETF_ST(1));
+      ETF_MMA(15); ETF_GAP(ETF_ST(2));
+      ETF_GAP(ETF_ST(3));
+    }
+#undef ETF_ST
+#undef ETF_LD
 #undef ETF_MMA
 #undef ETF_GAP
     if (kt == 11) {
@@ -491,6 +520,264 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
     for (int k = 0; k < 8; ++k) etf_prof[blockIdx.x * 8 + k] = ph[k];
 #endif
 }
+
+// ------------------------------------------------------------------ wave-specialised form (round 2, end)
+// Same arithmetic and accumulation order as edge_transition_f32_kernel above (bit-identical outputs), but the weight stream no longer
+// shares an instruction stream with the matrix cores: a block has EIGHT waves, 0..3 multiply (16 MFMAs + the 8 operand reads of the
+// next tile per step, epilogues, LayerNorm), 4..7 move (per step: the 4 LDS stores of tile t + 2 and the 4 L2 requests of tile t + 4;
+// per row tile: the next tile's X0 rows).  One wave per SIMD issues in order: every ds_write_b128 / global_load between two MFMAs of
+// the fused kernel that took longer than the 64 cycles the matrix instruction runs was a bubble (ablations above: 0.8 ms of 4.74 for
+// the stores, 0.6 ms for the requests).  Both roles execute the same sequence of barriers (one per layer entry, one per step, one after the final layer).
+#ifndef ETF_TOUCH
+#define ETF_TOUCH 0  // n > 0: the multiplier waves touch the L2 lines of tile t + n during step t (measured: no gain, the requests are L2 hits already)
+#endif
+template <int NP, class Epi>
+__device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfStream& st, int t0, float* Ws0, int tid, unsigned& tok, Epi epi) {
+  const int lane = tid & 63, wc = tid >> 6, hi = lane >> 5;
+  const float* arow = act + (lane & 31) * ETF_LDA + 4 * hi;
+  const int woff = (wc * 32 + (lane & 31)) * ETF_LDW + 4 * hi;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  EtfOps o0, o1;
+  __syncthreads();
+  o0.read(arow, Ws0 + (t0 % 3) * (ETF_WS / 4) + woff);
+  auto step = [&](int tl, EtfOps& cur, EtfOps& nxt) {
+    const int t = t0 + tl, kt = tl % 12;
+    const float* an = arow + ((kt + 1) % 12) * 32;
+    const float* wn = Ws0 + ((t + 1) % 3) * (ETF_WS / 4) + woff;
+#define ETF_MMA(i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[(i) >> 2][(i) & 3], cur.w[(i) >> 2][(i) & 3], acc, 0, 0, 0); \
+                   __builtin_amdgcn_sched_barrier(0)
+#define ETF_GAP(...) __VA_ARGS__; __builtin_amdgcn_sched_barrier(0)
+    ETF_MMA(0);  ETF_GAP(__syncthreads());
+    // one dword of each of the tile's 128 lines (row = wave * 32 + lane, 128 B per row) into ONE register that stays allocated for the
+    // whole kernel (`tok`: a dead destination would be re-used by the compiler while the load is still in flight), never waited for: the
+    // tile is in L2 when the movers ask for it four steps later (the z stream evicts the weights from the XCD's L2 between two uses)
+    ETF_MMA(1);  ETF_GAP(if (ETF_TOUCH) asm volatile("global_load_dword %0, %1, off" : "+v"(tok) : "v"(st.addr(t + ETF_TOUCH) + (unsigned long)(wc * 32 + (lane & 31)) * (ETF_H * 4)) : "memory"));
+    ETF_MMA(2);  ETF_GAP(nxt.a[0] = *(const f32x4*)(an));
+    ETF_MMA(3);  ETF_GAP(nxt.w[0] = *(const f32x4*)(wn));
+    ETF_MMA(4);
+    ETF_MMA(5);  ETF_GAP(nxt.a[1] = *(const f32x4*)(an + 8));
+    ETF_MMA(6);  ETF_GAP(nxt.w[1] = *(const f32x4*)(wn + 8));
+    ETF_MMA(7);
+    ETF_MMA(8);  ETF_GAP(nxt.a[2] = *(const f32x4*)(an + 16));
+    ETF_MMA(9);  ETF_GAP(nxt.w[2] = *(const f32x4*)(wn + 16));
+    ETF_MMA(10);
+    ETF_MMA(11); ETF_GAP(nxt.a[3] = *(const f32x4*)(an + 24));
+    ETF_MMA(12); ETF_GAP(nxt.w[3] = *(const f32x4*)(wn + 24));
+    ETF_MMA(13);
+    ETF_MMA(14);
+    ETF_MMA(15);
+#undef ETF_MMA
+#undef ETF_GAP
+    if (kt == 11) {
+      epi(tl / 12, acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+  };
+#pragma unroll 1
+  for (int tl = 0; tl < NP * 12; tl += 6) {
+    step(tl, o0, o1);
+    step(tl + 1, o1, o0);
+    step(tl + 2, o0, o1);
+    step(tl + 3, o1, o0);
+    step(tl + 4, o0, o1);
+    step(tl + 5, o1, o0);
+  }
+}
+// The mover's side of a layer: tile t + 2 (in registers since two steps) -> its LDS slot, tile t + 4 requested (the register roles of
+// etf_layer), all four mover waves every step; `mt` = 0..255.  With the requests ablated the launch takes 3.89 ms, with them 4.45:
+// the movers still arrive late at some barriers.  What was tried against that and measured SLOWER (N = 300, B = 8; fused kernel 4.62 ms):
+//  * six register sets per wave, requests eight tiles ahead, compiler-visible loads: across the back-edge of a rolled loop hipcc's vmcnt
+//    bookkeeping falls back to vmcnt(0) - it waits for the requests it has just issued (5.07 ms); fully unrolled it spills 558 registers;
+//  * the same with inline-asm requests and an explicit vmcnt(20) before a set is stored (exact waits in the ISA): 4.93 ms;
+//  * two groups of half-tile movers with two sets each (four-step distance): vmcnt(0) again behind the wave-uniform branches, 5.29 ms;
+//  * one mover wave per whole tile (four-step distance, exact wait): 16 ds_write_b128 + 16 requests do not fit one step, 6.7 ms
+//    (7.1 ms while the run-time choice among the three weight pointers made the requests FLAT loads, which count in lgkmcnt: every
+//    barrier then waited for them);
+//  * L2 touches of tile t + 8 from the multiplier waves (ETF_TOUCH): 4.63 ms - the requests are L2 hits already.
+template <int NP>
+__device__ __forceinline__ void etfs_layer_move(const EtfStream& st, int t0, float* Ws0, EtfTile& g0, EtfTile& g1, EtfTile& g2, int mt) {
+  const int goff = ((mt >> 3) * ETF_H + (mt & 7) * 4), loff = (mt >> 3) * ETF_LDW + (mt & 7) * 4;
+  __syncthreads();
+  auto step = [&](int tl, EtfTile& gs, EtfTile& gl) {
+    const int t = t0 + tl;
+    const float* src = st.ptr(t + 4) + goff;
+    float* wd = Ws0 + ((t + 2) % 3) * (ETF_WS / 4) + loff;
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);  // stores BEFORE the requests: hipcc hoists the loads otherwise and then has to wait for them
+#pragma unroll                          // (vmcnt is in order) before it can store the tile requested two steps ago
+    for (int k = 0; k < 4; ++k) if (!(ETF_ABL & 2)) *(f32x4*)(wd + k * 32 * ETF_LDW) = gs.r[k];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (!(ETF_ABL & 4)) gl.r[k] = *(const f32x4*)(src + k * 32 * ETF_H);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll 1
+  for (int tl = 0; tl < NP * 12; tl += 6) {
+    step(tl, g2, g1);
+    step(tl + 1, g0, g2);
+    step(tl + 2, g1, g0);
+    step(tl + 3, g2, g1);
+    step(tl + 4, g0, g2);
+    step(tl + 5, g1, g0);
+  }
+}
+
+template <class ZT>
+__global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(EdgeTransArgs a, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FD_CLK_BEGIN;
+  float* buf0 = (float*)smem;
+  float* buf1 = (float*)(smem + ETF_BUF);
+  float* Ws = (float*)(smem + 2 * ETF_BUF);
+  float* ybuf = buf1;
+  const int N = a.N;
+  const long n_pairs = (long)a.B * N * N;
+  const bool mover = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) >= 4;
+  if (mover) {
+    // ================= movers: weight stream and the X0 rows of the next row tile
+    const int mt = threadIdx.x - FD_THREADS;
+    const ZT* z_in = (const ZT*)a.z_in;
+    const EtfStream st = {(const float*)a.w1, (const float*)a.w2, (const float*)a.wf};
+    EtfTile g0, g1, g2;
+    st.load(g0, 0, mt);
+    st.load(g1, 1, mt);
+    st.load(g2, 2, mt);
+    f32x4 xr[12];
+    auto request_x0 = [&](long p0) {
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int part = u >> 2, v = mt + (u & 3) * FD_THREADS, mm = v >> 5, c = (v & 31) * 4;
+        const long pr = p0 + mm, p = pr < n_pairs ? pr : n_pairs - 1;
+        const long bi = p / N;
+        const int jj = (int)(p - bi * N);
+        const long bb = bi / N;
+        if (part == 0) {
+          if constexpr (sizeof(ZT) == 4) xr[u] = *(const f32x4*)((const float*)z_in + p * ETF_CZ + c);
+          else
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[u][q] = z_load<ZT>(z_in + p * ETF_CZ + c + q);
+        } else {
+          xr[u] = *(const f32x4*)(a.e + (part == 1 ? bi : bb * N + jj) * ETF_CZ + c);
+        }
+        if (pr >= n_pairs) xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto store_x0 = [&]() {
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int part = u >> 2, v = mt + (u & 3) * FD_THREADS, mm = v >> 5, c = (v & 31) * 4;
+        *(f32x4*)(buf0 + mm * ETF_LDA + part * ETF_CZ + c) = xr[u];
+      }
+    };
+    int blk = blockIdx.x;
+    request_x0((long)blk * 32);
+    store_x0();
+    g0.store(Ws, mt);
+    g1.store(Ws + ETF_WS / 4, mt);
+    st.load(g0, 3, mt);
+    for (; blk < n_blocks; blk += gridDim.x) {
+      etfs_layer_move<3>(st, 0, Ws, g0, g1, g2, mt);
+      etfs_layer_move<3>(st, 36, Ws, g0, g1, g2, mt);
+      if (blk + (int)gridDim.x < n_blocks) request_x0((long)(blk + gridDim.x) * 32);
+      etfs_layer_move<1>(st, 72, Ws, g0, g1, g2, mt);
+      __syncthreads();
+      store_x0();  // buf0 is free (the next layer 1 starts with a barrier)
+    }
+  } else {
+    // ================= multipliers
+    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+    const int ncol = wc * 32 + (lane & 31);
+    const EtfStream st = {(const float*)a.w1, (const float*)a.w2, (const float*)a.wf};
+    unsigned tok = 0;  // destination of the L2 touches (etfs_layer_compute)
+    float em_next = 0.f;
+    auto request_em = [&](long p0) {  // lanes 0..31 of every wave: pair mask of row `lane`
+      em_next = 0.f;
+      if (lane < 32) {
+        const long p = p0 + lane;
+        if (p < n_pairs) {
+          const long bi = p / N;
+          em_next = a.res_mask[bi] * a.res_mask[(bi / N) * N + (p - bi * N)];
+        }
+      }
+    };
+    int blk = blockIdx.x;
+    request_em((long)blk * 32);
+    float bias1[3], bias2[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { bias1[q] = a.b1[q * 128 + ncol]; bias2[q] = a.b2[q * 128 + ncol]; }
+    const float biasf = a.bf[ncol];
+    const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], b0v = a.beta[lane], b1v = a.beta[lane + 64];
+    for (; blk < n_blocks; blk += gridDim.x) {
+      const long p0 = (long)blk * 32;
+      const float em_row = em_next;
+      etfs_layer_compute<3>(buf0, st, 0, Ws, tid, tok, [&](int pass, const f32x16& acc) {
+        const int n = pass * 128 + ncol;
+        const float bv = pass == 0 ? bias1[0] : (pass == 1 ? bias1[1] : bias1[2]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf1[c_row(r, lane) * ETF_LDA + n] = fmaxf(acc[r] + bv, 0.f);
+      });
+      etfs_layer_compute<3>(buf1, st, 36, Ws, tid, tok, [&](int pass, const f32x16& acc) {
+        const int n = pass * 128 + ncol;
+        const float bv = pass == 0 ? bias2[0] : (pass == 1 ? bias2[1] : bias2[2]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* d = buf0 + c_row(r, lane) * ETF_LDA + n;
+          *d = fmaxf(acc[r] + bv, 0.f) + *d;
+        }
+      });
+      if (blk + (int)gridDim.x < n_blocks) request_em((long)(blk + gridDim.x) * 32);
+      etfs_layer_compute<1>(buf0, st, 72, Ws, tid, tok, [&](int, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
+      });
+      __syncthreads();
+      {
+        ZT* z_out = (ZT*)a.z_out;
+        float v0[8], v1[8], s1[8], s2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int m = wc + 4 * q;
+          v0[q] = ybuf[m * ETF_LDY + lane];
+          v1[q] = ybuf[m * ETF_LDY + lane + 64];
+          s1[q] = v0[q] + v1[q];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) s1[q] += __shfl_xor(s1[q], o, 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float mu = s1[q] * (1.0f / ETF_CZ);
+          v0[q] -= mu;
+          v1[q] -= mu;
+          s2[q] = v0[q] * v0[q] + v1[q] * v1[q];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) s2[q] += __shfl_xor(s2[q], o, 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int m = wc + 4 * q;
+          const long p = p0 + m;
+          const float rstd = 1.0f / sqrtf(s2[q] * (1.0f / ETF_CZ) + 1e-5f);
+          const float em = __shfl(em_row, m, 64);
+          if (p < n_pairs) {
+            const float o0 = (v0[q] * rstd * g0v + b0v) * em, o1 = (v1[q] * rstd * g1v + b1v) * em;
+            z_store<ZT>(z_out + p * ETF_CZ + lane, o0);
+            z_store<ZT>(z_out + p * ETF_CZ + lane + 64, o1);
+            if (a.trace) { a.trace[p * ETF_CZ + lane] = o0; a.trace[p * ETF_CZ + lane + 64] = o1; }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : : "v"(tok) : "memory");  // the last touches land before the register is released
+  }
+  FD_CLK_END(etf_clk);
+}
 int fd_etf_clock(unsigned long long* out3, int reset) {
   if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(etf_clk), 24) != hipSuccess) return FDIPT_ELAUNCH;
   if (reset) {
@@ -593,16 +880,25 @@ static int launch_et(int precision, const EdgeTransArgs& a, hipStream_t st) {
   if (precision == FDIPT_PREC_F32) {
     constexpr int TM = 32;
     if constexpr (CZ == ETF_CZ && CB == ETF_CZ) {
+#ifndef ETF_SPEC
+#define ETF_SPEC 1  // 1: edge_transition_f32ws_kernel (8 waves: 4 multiply, 4 move), 0: the fused 4-wave kernel
+#endif
       static bool attr_set = false;
       if (!attr_set) {
         if (hipFuncSetAttribute((const void*)edge_transition_f32_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, ETF_LDS) !=
-            hipSuccess)
+                hipSuccess ||
+            hipFuncSetAttribute((const void*)edge_transition_f32ws_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, ETF_LDS) !=
+                hipSuccess)
           return FDIPT_ELAUNCH;
         attr_set = true;
       }
       const int n_blocks = (int)cdiv(n_pairs, TM);
-      hipLaunchKernelGGL(edge_transition_f32_kernel<float>, dim3(n_blocks < 256 ? n_blocks : 256), dim3(FD_THREADS), ETF_LDS, st, a,
-                         n_blocks);
+      if (ETF_SPEC)
+        hipLaunchKernelGGL(edge_transition_f32ws_kernel<float>, dim3(n_blocks < 256 ? n_blocks : 256), dim3(2 * FD_THREADS), ETF_LDS, st, a,
+                           n_blocks);
+      else
+        hipLaunchKernelGGL(edge_transition_f32_kernel<float>, dim3(n_blocks < 256 ? n_blocks : 256), dim3(FD_THREADS), ETF_LDS, st, a,
+                           n_blocks);
     } else {
       hipLaunchKernelGGL((edge_transition_kernel<PrecF32, float, float, TM, 1, 4, CZ, CB>), dim3(cdiv(n_pairs, TM)),
                          dim3(FD_THREADS), 0, st, a);

@@ -53,7 +53,7 @@ if os.path.exists(d + "kernel_stats_c5.md"):
     c5 = json.load(open(d + "bench_c5.json"))
     open(P + "r02_bench_c5_fp32_kernel_stats.md", "w").write(
         "# Round 2 — `rocprofv3 --kernel-trace --stats -- python bench.py --config c5 --no-cpu-baseline` (1 x MI355X, config c5: fp32 mode, N = 1000, B = 4)\n\n"
-        f"Bench line of the same configuration: {c5['value']:.0f} residue*step/s, {c5['ms_per_step']:.1f} ms per step; `edge_transition_f32_kernel` "
+        f"Bench line of the same configuration: {c5['value']:.0f} residue*step/s, {c5['ms_per_step']:.1f} ms per step; `edge_transition_f32ws_kernel` "
         f"{c5['roofline']['avg_launch_ms']:.2f} ms per launch = {c5['roofline']['frac'] * 100:.1f} % of the 157.3 TFLOP/s fp32 matrix peak (`v_mfma_f32_32x32x2_f32`; "
         "round 1: 51 ms = 34 %).\n\n" + open(d + "kernel_stats_c5.md").read())
 
