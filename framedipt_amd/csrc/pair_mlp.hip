@@ -407,7 +407,8 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
       } else {
         xr[u] = *(const f32x4*)(a.e + (part == 1 ? bi : bb * N + j) * ETF_CZ + c);
       }
-      if (pr >= n_pairs) xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // (rows beyond the last pair carry the last pair's values: they are never stored, and a select on the loaded value here would
+      //  make the compiler wait for the requests on the spot)
     }
     em_next = 0.f;  // lanes 0..31 of every wave: pair mask of row `lane`
     if (lane < 32) {
@@ -662,7 +663,8 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
         } else {
           xr[u] = *(const f32x4*)(a.e + (part == 1 ? bi : bb * N + jj) * ETF_CZ + c);
         }
-        if (pr >= n_pairs) xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (rows beyond the last pair carry the last pair's values: they are never stored, and a select on the loaded value here would
+        //  make the compiler wait for the requests on the spot)
       }
     };
     auto store_x0 = [&]() {
