@@ -166,11 +166,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # FDIPT_BENCH_ONE_GPU=1 (tests only): all ranks share GPU 0 and rendezvous over gloo - the multi-rank code path (sharding of the
+    # samples, barriers, max-over-ranks timing, rank-0 line) on a one-GPU box, where RCCL refuses two ranks on one device
+    one_gpu = os.environ.get("FDIPT_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
 
     from framedipt_amd import _lib, config, inference, sharding
     from framedipt_amd.diffusion import SE3Diffuser
@@ -257,7 +262,7 @@ def main():
             _lib.check(lib.fdipt_event_elapsed_ms(events[k][0][i], events[k][1][i], C.byref(ms)))
             et_ms.append(ms.value)
     if world > 1:
-        tt = torch.tensor([el, d2h], device=dev, dtype=torch.float64)
+        tt = torch.tensor([el, d2h], device="cpu" if one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el, d2h = float(tt[0].item()), float(tt[1].item())
         dist.barrier()

@@ -186,3 +186,24 @@ def test_half_precision_forward_tracks_the_fp32_mode_at_odd_sizes(n, b):
         assert np.isfinite(got).all()
         rmsd = np.sqrt(((got - ref) ** 2).sum(-1).mean(axis=(1, 2))).max()
         assert rmsd < 5e-4, (n, b, kf, rmsd)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path (the driver launches it with torch.distributed.run on an 8-GPU node): two ranks on this box's one GPU
+    (FDIPT_BENCH_ONE_GPU=1: gloo rendezvous, both on cuda:0).  Rank 0 prints ONE JSON line with n_gpus = 2 and the whole-job value."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FDIPT_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert "x2" in d["config"]["parallelism"]
