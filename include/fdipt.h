@@ -290,7 +290,7 @@ int fdipt_event_record(void* ev, fdipt_stream_t s);
 int fdipt_event_elapsed_ms(void* start, void* stop, float* ms_host); /* synchronises on `stop` */
 
 /* Diagnostic for bench.py's roofline: the shader clock the EdgeTransition kernels (edge_transition4_flat_kernel in the half-precision
- * mode, edge_transition_f32_kernel in the fp32 mode) actually ran at.
+ * mode, edge_transition_f32ws_kernel in the fp32 mode) actually ran at.
  * out3_host = {core-clock cycles, 100 MHz ticks, blocks}, summed over the blocks of all launches since the last reset; cycles /
  * ticks / 10 = GHz.  The matrix peak the kernel can reach scales with this clock (power management lowers it under dense MFMA
  * load).  Synchronises the device. */
