@@ -302,7 +302,8 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
                    __builtin_amdgcn_sched_barrier(0)
 #define ETF_GAP(...) __VA_ARGS__; __builtin_amdgcn_sched_barrier(0)
 #ifndef ETF_ABL
-#define ETF_ABL 0  // timing ablations of tools/micro/etf_bench.hip (results are wrong with any bit set)
+#define ETF_ABL 0  // timing ablations of tools/micro/etf_bench.hip (results are wrong with any bit set): 1 no step barrier, 2 no LDS weight
+                   // stores, 4 no L2 requests, 8 (wave-specialised kernel) the requests go to registers nobody waits for
 #endif
 #ifndef ETF_ORDER
 #define ETF_ORDER 1  // 1: LDS stores right behind the barrier, L2 requests at the end of the step; 0: the other way round
@@ -598,8 +599,11 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
 //    (7.1 ms while the run-time choice among the three weight pointers made the requests FLAT loads, which count in lgkmcnt: every
 //    barrier then waited for them);
 //  * L2 touches of tile t + 8 from the multiplier waves (ETF_TOUCH): 4.63 ms - the requests are L2 hits already.
+// The decisive ablation (ETF_ABL = 8): the SAME requests into registers nobody ever waits for: 4.44 ms, i.e. nothing gained - it is the
+// request traffic itself (4 KB per wave and step written back into the VGPR file of the SIMD a multiplier wave shares), not its latency.
 template <int NP>
-__device__ __forceinline__ void etfs_layer_move(const EtfStream& st, int t0, float* Ws0, EtfTile& g0, EtfTile& g1, EtfTile& g2, int mt) {
+__device__ __forceinline__ void etfs_layer_move(const EtfStream& st, int t0, float* Ws0, EtfTile& g0, EtfTile& g1, EtfTile& g2, int mt,
+                                                f32x4 (&g_dummy)[4]) {
   const int goff = ((mt >> 3) * ETF_H + (mt & 7) * 4), loff = (mt >> 3) * ETF_LDW + (mt & 7) * 4;
   __syncthreads();
   auto step = [&](int tl, EtfTile& gs, EtfTile& gl) {
@@ -612,7 +616,13 @@ __device__ __forceinline__ void etfs_layer_move(const EtfStream& st, int t0, flo
     for (int k = 0; k < 4; ++k) if (!(ETF_ABL & 2)) *(f32x4*)(wd + k * 32 * ETF_LDW) = gs.r[k];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (!(ETF_ABL & 4)) gl.r[k] = *(const f32x4*)(src + k * 32 * ETF_H);
+    for (int k = 0; k < 4; ++k) {
+      if (ETF_ABL & 8) {  // timing experiment (wrong results): the same requests, into registers nobody waits for
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(g_dummy[k]) : "v"(src + k * 32 * ETF_H) : "memory");
+      } else if (!(ETF_ABL & 4)) {
+        gl.r[k] = *(const f32x4*)(src + k * 32 * ETF_H);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 #pragma unroll 1
@@ -680,14 +690,16 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
     g0.store(Ws, mt);
     g1.store(Ws + ETF_WS / 4, mt);
     st.load(g0, 3, mt);
+    f32x4 g_dummy[4] = {};  // (ETF_ABL & 8 only)
     for (; blk < n_blocks; blk += gridDim.x) {
-      etfs_layer_move<3>(st, 0, Ws, g0, g1, g2, mt);
-      etfs_layer_move<3>(st, 36, Ws, g0, g1, g2, mt);
+      etfs_layer_move<3>(st, 0, Ws, g0, g1, g2, mt, g_dummy);
+      etfs_layer_move<3>(st, 36, Ws, g0, g1, g2, mt, g_dummy);
       if (blk + (int)gridDim.x < n_blocks) request_x0((long)(blk + gridDim.x) * 32);
-      etfs_layer_move<1>(st, 72, Ws, g0, g1, g2, mt);
+      etfs_layer_move<1>(st, 72, Ws, g0, g1, g2, mt, g_dummy);
       __syncthreads();
       store_x0();  // buf0 is free (the next layer 1 starts with a barrier)
     }
+    if (ETF_ABL & 8) asm volatile("s_waitcnt vmcnt(0)" : : "v"(g_dummy[0]), "v"(g_dummy[1]), "v"(g_dummy[2]), "v"(g_dummy[3]) : "memory");
   } else {
     // ================= multipliers
     const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
