@@ -140,7 +140,7 @@ __global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float*
 #define SQ_XROW (SQ_K * 2 + 16)
 typedef fd_h sa_hx4 __attribute__((ext_vector_type(4)));
 // SPLIT: the product runs on split operands (x = hi + lo, W = hi + lo: Whi.xhi + Whi.xlo + Wlo.xhi, see rowblock.hip); the
-// images still receive half-precision values (their rounding is averaged over the keys by the attention, tools/err_budget.py).
+// images still receive half-precision values (their rounding is averaged over the keys by the attention, tests/err_budget.py).
 template <bool SPLIT>
 __global__ __launch_bounds__(FD_THREADS, 1) void seq_qkv_kernel(int B, int N, int Np, int H, const float* __restrict__ x, int ld_x,
                                                                 const char* __restrict__ wimg, const char* __restrict__ wimg_lo,

@@ -616,7 +616,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // row-complete fused MLPs (rowblock.hip) take the multi-layer kinds and the 320-wide transformer layers
   const bool rbk = chn_all && cs == 256 && iv.d_t == 320 && !sw.no_rowblock;
   // split operands (hi + lo half-precision parts, 3 MFMAs per k-step) for the dense layers of the node path, whose operand
-  // rounding dominates the error of the predicted frames and psi (tools/err_budget.py): node embedder, IPA output projection,
+  // rounding dominates the error of the predicted frames and psi (tests/err_budget.py): node embedder, IPA output projection,
   // sequence transformer (in_proj, out_proj, feed-forward), post_tfmr, transition, torsion head
   const bool split_any = rbk && !sw.no_split;
   const bool split = split_any && (sw.split_mask & 2u);                                   // IPA output projection

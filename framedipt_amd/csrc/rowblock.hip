@@ -30,7 +30,7 @@ __host__ __device__ constexpr int rb_max(int a, int b) { return a > b ? a : b; }
 // FLAGS bit5 (SPLIT): every product runs on split operands — activations x = hi + lo and weights W = hi + lo, each part one
 // half-precision value (22 significant bits together), as Whi.xhi + Whi.xlo + Wlo.xhi with fp32 accumulation: the accuracy of
 // an fp32 product at a third of the half-precision MFMA rate (the fp32 MFMA runs at a sixteenth).  The layers of the node
-// path whose operand rounding dominates the error of the predicted frames / psi use it (tools/err_budget.py).
+// path whose operand rounding dominates the error of the predicted frames / psi use it (tests/err_budget.py).
 // Activation rows in LDS are [32][width bf16 + 16 B]: with widths 80..320 the 16 lanes of a b128 read hit 16 distinct
 // 16 B slots, no swizzle needed.
 template <int N, class F>

@@ -5,7 +5,7 @@ a time (activations AND weights rounded before the product, fp32 accumulation: w
 error of psi / CA / last node representation against the unrounded oracle.  Errors of independent groups add in
 quadrature, so the table says where split (hi + lo) operands pay.
 
-    python tools/err_budget.py [golden] [fp16|bf16]
+    python tests/err_budget.py [golden] [fp16|bf16]
 """
 import os
 import sys
@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (lives under tests/: only tests, smoke() and the bench baseline may use the oracle)
 import oracle.score_network as osn  # noqa: E402
 from conftest import kabsch_free_rmsd, load_golden  # noqa: E402
 from test_oracle_forward import _feats, _model  # noqa: E402

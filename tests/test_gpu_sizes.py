@@ -141,7 +141,7 @@ def test_teacher_forced_fp16_meets_the_north_star_bound(name):
 # (oracle/, x_0 prediction equal to 7e-6 A) already lands 1.2e-3 / 6.4e-3 A away from the reference's x_{t-1}.  Per-step parity
 # is therefore asserted on x_{t-1} where the series is conditioned (t > 0.15) and on the x_0 prediction at every step.
 # The fp16 mode lands at 1.8e-3 / 1.9e-3 A here (its x_0 error scales with the frame updates: 1.5e-4 A per forward at bb_gain 0.03);
-# what is left after the split-operand node path is the fp16 EdgeTransition / attention operand rounding (tools/err_budget.py).
+# what is left after the split-operand node path is the fp16 EdgeTransition / attention operand rounding (tests/err_budget.py).
 @pytest.mark.parametrize("prec,bound_next,bound_x0", [("fp32", 1e-4, 1e-4), ("fp16", 3e-3, 3e-3)])
 def test_teacher_forced_large_frame_updates(prec, bound_next, bound_x0):
     r = _teacher_forced_steps("full_denovo_n64_T20_gain03", prec)
