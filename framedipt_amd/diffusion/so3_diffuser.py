@@ -26,15 +26,17 @@ def density(expansion, omega, marginal: bool = True):
 
 
 def score(exp, omega, eps, truncation_level: int = 1000):
-    """so3_diffuser.py:122-191 (NumPy float64 branch used for the tables)."""
-    l = np.arange(truncation_level)[None]
-    omega = np.asarray(omega)[..., None]
-    hi = np.sin(omega * (l + 1 / 2))
-    dhi = (l + 1 / 2) * np.cos(omega * (l + 1 / 2))
-    lo = np.sin(omega / 2)
-    dlo = 1 / 2 * np.cos(omega / 2)
-    dsigma = ((2 * l + 1) * np.exp(-l * (l + 1) * eps**2 / 2) * (lo * dhi - hi * dlo) / lo**2).sum(axis=-1)
-    return dsigma / (exp + 1e-4)
+    """d/d omega of log f(omega) with f the IGSO(3) series, regularised as the reference does (so3_diffuser.py:122-191,
+    NumPy float64 branch used for the tables): every term's ratio sin((l + 1/2) w) / sin(w / 2) is differentiated by the
+    quotient rule and the weighted sum is divided by ``f + 1e-4``."""
+    order = np.arange(truncation_level)[None]
+    w = np.asarray(omega)[..., None]
+    half_odd = order + 1 / 2
+    weight = (2 * order + 1) * np.exp(-order * (order + 1) * eps**2 / 2)
+    num, den = np.sin(w * half_odd), np.sin(w / 2)
+    d_num, d_den = half_odd * np.cos(w * half_odd), 1 / 2 * np.cos(w / 2)
+    d_series = (weight * (den * d_num - num * d_den) / den**2).sum(axis=-1)
+    return d_series / (exp + 1e-4)
 
 
 class SO3Diffuser:
@@ -107,13 +109,17 @@ class SO3Diffuser:
         return np.array([one(ti) for ti in np.asarray(t).reshape(-1)]).reshape(np.shape(t))
 
     def sample_igso3(self, t: float, n_samples: int = 1) -> np.ndarray:
-        x = np.random.rand(n_samples)
-        return np.interp(x, self._row(self.t_to_idx(t))[1], self.discrete_omega)
+        """Rotation angles by inverse-CDF lookup on the table row of t (so3_diffuser.py:325-340): one ``rand`` draw."""
+        cdf_row = self._row(self.t_to_idx(t))[1]
+        return np.interp(np.random.rand(n_samples), cdf_row, self.discrete_omega)
 
     def sample(self, t: float, n_samples: int = 1) -> np.ndarray:
-        x = np.random.randn(n_samples, 3)
-        x /= np.linalg.norm(x, axis=-1, keepdims=True)
-        return x * self.sample_igso3(t, n_samples=n_samples)[:, None]
+        """Rotation vectors: a uniform axis (normalised ``randn`` draw, made BEFORE the angle draw as in
+        so3_diffuser.py:342-354 — the order fixes the position in the global stream) times an IGSO(3) angle."""
+        axis = np.random.randn(n_samples, 3)
+        axis = axis / np.linalg.norm(axis, axis=-1, keepdims=True)
+        angle = self.sample_igso3(t, n_samples=n_samples)
+        return axis * angle[:, None]
 
     def sample_ref(self, n_samples: int = 1) -> np.ndarray:
         return self.sample(1.0, n_samples=n_samples)
