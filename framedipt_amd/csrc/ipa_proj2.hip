@@ -35,7 +35,12 @@ typedef const __attribute__((address_space(3))) u16x8* p2_lds_u16x8;
 __device__ __forceinline__ hx8 p2_frag(unsigned off) { return __builtin_bit_cast(hx8, *(p2_lds_u16x8)(unsigned long)off); }
 
 // QK: this block walks the Q / K column blocks (n_walk_qk walkers, blockIdx.y < n_walk_qk) or the V / point blocks
-template <bool QK>
+// SPLIT: split operands (x = hi + lo, W = hi + lo, each part one half-precision value; W_hi x_hi + W_hi x_lo + W_lo x_hi with fp32
+// accumulation: the accuracy of an fp32 product).  The q / k / v / point projections are per-residue quantities whose rounding
+// errors are coherent over all keys of the attention (tests/err_budget.py at bb_gain 0.3: the largest single group of the half mode).
+// Buffer 0 holds the hi block of the weight image, buffer 1 the lo block (no double buffering: the next block is requested once
+// every wave is done with the current one, and the epilogue's stores run under that DMA); both activation parts stay in registers.
+template <bool QK, bool SPLIT>
 __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, int walker, int n_walkers, char* smem) {
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hi = lane >> 5;
@@ -51,8 +56,9 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
     return k < nv ? nq + (k / (per_head / 2)) * per_head + per_head / 2 + k % (per_head / 2) : 3 * nq + (k - nv);
   };
   int kb = walker;
+  const char* wimg_lo = (const char*)a.W_img_lo;
   auto request = [&](int c, int buf) {
-    const char* src = wimg + (size_t)c * P2_WBLK;
+    const char* src = (SPLIT && buf ? wimg_lo : wimg) + (size_t)c * P2_WBLK;
 #pragma unroll
     for (int u = 0; u < P2_WBLK / (FD_THREADS * 16); ++u)
       p2_dma16(src + (size_t)(u * FD_THREADS + tid) * 16, lds0 + buf * P2_WBLK + (unsigned)(u * FD_THREADS + (tid & ~63)) * 16);
@@ -60,27 +66,39 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
   FD_STAMP(0);
   if (kb < n_class) request(cblk_of(kb), 0);  // the first weight block is on its way while the activations are staged
   // ---- activation rows: fp32 -> bf16 -> LDS (buffer 1: 128 rows x 512 B, 16 B chunk c of row r at c ^ (r & 15)), once
-  {
-    char* xs = smem + P2_WBLK;
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {  // 128 rows x 64 float4 (all 32 requests of a thread in flight: one round trip)
-      const int idx = tid + it * FD_THREADS, r = idx >> 6, c4 = idx & 63;
-      const int gr = m0 + r < M ? m0 + r : M - 1;
-      const f32x4 x = *(const f32x4*)(a.A + (long)gr * a.lda + 4 * c4);
-      const p2_u32x2 h = {fd_cvt_pk(x[0], x[1]), fd_cvt_pk(x[2], x[3])};
-      *(p2_u32x2*)(xs + r * P2_XROW + (((c4 >> 1) ^ (r & 15)) << 4) + 8 * (c4 & 1)) = h;
-    }
-  }
-  __syncthreads();
   hx8 Af[2][P2_KS];
+  hx8 Al[SPLIT ? 2 : 1][SPLIT ? P2_KS : 1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
+    {
+      char* xs = smem + P2_WBLK;
 #pragma unroll
-    for (int s = 0; s < P2_KS; ++s) {
-      const int r = (wr * 2 + i) * 32 + li;
-      Af[i][s] = p2_frag(lds0 + P2_WBLK + r * P2_XROW + (((2 * s + hi) ^ (r & 15)) << 4));
+      for (int it = 0; it < 32; ++it) {  // 128 rows x 64 float4 (all 32 requests of a thread in flight: one round trip)
+        const int idx = tid + it * FD_THREADS, r = idx >> 6, c4 = idx & 63;
+        const int gr = m0 + r < M ? m0 + r : M - 1;
+        f32x4 x = *(const f32x4*)(a.A + (long)gr * a.lda + 4 * c4);
+        if (pass) {  // lo part: x - half(x), exact in fp32
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] -= h2f(f2h(x[q]));
+        }
+        const p2_u32x2 h = {fd_cvt_pk(x[0], x[1]), fd_cvt_pk(x[2], x[3])};
+        *(p2_u32x2*)(xs + r * P2_XROW + (((c4 >> 1) ^ (r & 15)) << 4) + 8 * (c4 & 1)) = h;
+      }
     }
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers before the buffer is overwritten
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < P2_KS; ++s) {
+        const int r = (wr * 2 + i) * 32 + li;
+        const hx8 f = p2_frag(lds0 + P2_WBLK + r * P2_XROW + (((2 * s + hi) ^ (r & 15)) << 4));
+        if (pass == 0) Af[i][s] = f;
+        else if constexpr (SPLIT) Al[i][s] = f;
+      }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers before the buffer is overwritten
+    if (SPLIT) __syncthreads();
+  }
+  if (SPLIT && kb < n_class) request(cblk_of(kb), 1);
   FD_STAMP(1);
   // ---- store addressing, split into a part that depends on the row(s) of a register group (computed once) and a part that
   // depends on the column block (once per block): an epilogue unit adds the two and a compile-time constant
@@ -229,6 +247,60 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  if constexpr (SPLIT) {
+    f32x16 acc[2][2];
+    f32x4 bq[2][4];
+    int cp[2] = {0, 0};
+    for (; kb < n_class; kb += n_walkers) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this thread's share of both parts of the block has landed
+      __syncthreads();
+      load_bias(bq, cblk_of(kb) * 128);
+      const int kind = col_part(cblk_of(kb), cp);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      const unsigned wbh = lds0 + (wc * 2) * (P2_KS * 1024) + lane * 16, wbl = wbh + P2_WBLK;
+      constexpr int DEPTH = 2;
+      hx8 h0[DEPTH], h1[DEPTH], l0[DEPTH], l1[DEPTH];
+      h0[0] = p2_frag(wbh); h1[0] = p2_frag(wbh + P2_KS * 1024); l0[0] = p2_frag(wbl); l1[0] = p2_frag(wbl + P2_KS * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < P2_KS; ++s) {
+        if (s + 1 < P2_KS) {
+          h0[(s + 1) % DEPTH] = p2_frag(wbh + (s + 1) * 1024); h1[(s + 1) % DEPTH] = p2_frag(wbh + (P2_KS + s + 1) * 1024);
+          l0[(s + 1) % DEPTH] = p2_frag(wbl + (s + 1) * 1024); l1[(s + 1) % DEPTH] = p2_frag(wbl + (P2_KS + s + 1) * 1024);
+        }
+        const int c = s % DEPTH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (QK) {  // operands exchanged: lane = row.  Small terms first, then the hi x hi product
+            acc[i][0] = fd_mfma32(l0[c], Af[i][s], acc[i][0]); acc[i][1] = fd_mfma32(l1[c], Af[i][s], acc[i][1]);
+            acc[i][0] = fd_mfma32(h0[c], Al[i][s], acc[i][0]); acc[i][1] = fd_mfma32(h1[c], Al[i][s], acc[i][1]);
+            acc[i][0] = fd_mfma32(h0[c], Af[i][s], acc[i][0]); acc[i][1] = fd_mfma32(h1[c], Af[i][s], acc[i][1]);
+          } else {
+            acc[i][0] = fd_mfma32(Af[i][s], l0[c], acc[i][0]); acc[i][1] = fd_mfma32(Af[i][s], l1[c], acc[i][1]);
+            acc[i][0] = fd_mfma32(Al[i][s], h0[c], acc[i][0]); acc[i][1] = fd_mfma32(Al[i][s], h1[c], acc[i][1]);
+            acc[i][0] = fd_mfma32(Af[i][s], h0[c], acc[i][0]); acc[i][1] = fd_mfma32(Af[i][s], h1[c], acc[i][1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the bias must have landed BEFORE the next block is requested: a compiler-placed vmcnt wait behind those (invisible)
+      // DMAs would wait for all of them, vmcnt being in order
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[j][g]));
+      __syncthreads();  // every wave is done with both buffers
+      if (kb + n_walkers < n_class) { request(cblk_of(kb + n_walkers), 0); request(cblk_of(kb + n_walkers), 1); }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) epi_unit(acc, bq, cp, kind, u >> 3, (u >> 2) & 1, u & 3);
+    }
+    return;
+  }
   f32x16 acc0[2][2], acc1[2][2];
   f32x4 bq0[2][4], bq1[2][4];
   int cp0[2] = {0, 0}, cp1[2] = {0, 0}, kind0 = 0, kind1 = 0;
@@ -256,10 +328,11 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
     }
   }
 }
+template <bool SPLIT>
 __global__ __launch_bounds__(FD_THREADS, 1) void ipa_proj2_kernel(ProjArgs a, int n_cblk, int n_walk_qk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.y < n_walk_qk) ipa_proj2_body<true>(a, n_cblk, blockIdx.y, n_walk_qk, smem);
-  else ipa_proj2_body<false>(a, n_cblk, blockIdx.y - n_walk_qk, gridDim.y - n_walk_qk, smem);
+  if ((int)blockIdx.y < n_walk_qk) ipa_proj2_body<true, SPLIT>(a, n_cblk, blockIdx.y, n_walk_qk, smem);
+  else ipa_proj2_body<false, SPLIT>(a, n_cblk, blockIdx.y - n_walk_qk, gridDim.y - n_walk_qk, smem);
 }
 
 // Row permutation of the Q / K tiles of the weight image (see the Q / K epilogue unit): image row rho of a 32-row tile takes the
@@ -292,11 +365,10 @@ int fd_ipa_proj2(const ProjArgs& a, hipStream_t st) {
   if (!fd_ipa_proj2_supported(a)) return FDIPT_EINVAL;
   const int M = a.B * a.N, NOUT = 3 * a.H * a.C + a.PT;
   const int n_cblk = cdiv(NOUT, 128), n_rblk = cdiv(M, 128);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)ipa_proj2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS) != hipSuccess) return FDIPT_ELAUNCH;
-    attr_set = true;
-  }
+  // (the attribute is per device: set on every launch — a host-side table lookup — rather than cached per process)
+  if (hipFuncSetAttribute(a.W_img_lo ? (const void*)ipa_proj2_kernel<true> : (const void*)ipa_proj2_kernel<false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS) != hipSuccess)
+    return FDIPT_ELAUNCH;
   // one block per CU: about 256 / row-blocks column walkers per row block, split between the two column classes in
   // proportion to their column blocks
   int ncg = 256 / n_rblk;
@@ -309,7 +381,8 @@ int fd_ipa_proj2(const ProjArgs& a, hipStream_t st) {
   if (wq > n_qk) wq = n_qk;
   int wo = ncg - wq;
   if (wo > n_other) wo = n_other;
-  hipLaunchKernelGGL(ipa_proj2_kernel, dim3(n_rblk, wq + wo), dim3(FD_THREADS), P2_LDS, st, a, n_cblk, wq);
+  if (a.W_img_lo) hipLaunchKernelGGL(ipa_proj2_kernel<true>, dim3(n_rblk, wq + wo), dim3(FD_THREADS), P2_LDS, st, a, n_cblk, wq);
+  else hipLaunchKernelGGL(ipa_proj2_kernel<false>, dim3(n_rblk, wq + wo), dim3(FD_THREADS), P2_LDS, st, a, n_cblk, wq);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -155,6 +155,7 @@ struct ProjArgs {
   int lda;
   const void* W;              // [3*H*C + PT, K] bf16 fused projection weight
   const void* W_img;          // the same as a fragment image, zero-padded to whole 128-column blocks (ipa_proj2.hip), or NULL
+  const void* W_img_lo = nullptr;  // split operands (ipa_proj2.hip): the image of W - half(W), same layout; NULL = plain half operands
   const float* bias;          // [3*H*C + PT]
   float qscale;               // sqrt(1/(3C)) folded into Q
   half_t *Qb, *Kb, *Vt;

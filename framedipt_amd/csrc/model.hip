@@ -33,7 +33,8 @@ struct Switches {
   bool no_seq_attn = false;     // (dev) sequence attention on the LDS-score kernel only (IPA attention unchanged)
   bool no_split = false;        // node-path products on plain half-precision operands instead of split (hi + lo) ones
   int splitk_ns = 4;            // K slices of the IPA output projection (K = 2688)
-  unsigned split_mask = 63u;    // split operands per layer group: 1 node embedder, 2 output projection, 4 in_proj, 8 tails, 16 transition, 32 torsion
+  unsigned split_mask = 0x7FFu;  // split operands per layer group: 1 node embedder, 2 output projection, 4 in_proj, 8 tails, 16 transition, 32 torsion,
+                                 // 64 IPA input projection, 128 EdgeTransition per-residue rows, 256 o_pair down-projection, 512 skip_embed, 1024 attention P V
   unsigned chain_mask = 0xFC9u;  // fused chain kinds (chain.hip) that beat the launches they replace (profiles/r01_chain_vs_gemm.md)
   const char* twice = nullptr;   // timing aid: repeat the named launches (the second one runs on a warm L2)
   unsigned rb_mask = 31u;        // (dev) row-block kernels per use: 1 node embedder, 2 transformer tails, 4 transition, 8 torsion head, 16 sequence attention images
@@ -164,7 +165,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, wproj_img, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img; DChain ch; DSplit lo; };
+struct DBlock { size_t wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img; DChain ch; DSplit lo; };
 struct DLayout {
   size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -208,6 +209,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   for (int b = 0; b < d->num_blocks; ++b) {
     L.blk[b].wproj = o; o = al256(o + (size_t)iv.proj_out * d->c_s * L.esz);
     L.blk[b].wproj_img = o;  // the same matrix as a fragment image, zero-padded to whole 128-column blocks (ipa_proj2.hip)
+    if (L.esz == 2 && d->c_s == 256) o = al256(o + (size_t)((iv.proj_out + 127) / 128) * 65536);
+    L.blk[b].wproj_img_lo = o;  // ... and of W - half(W) (split operands)
     if (L.esz == 2 && d->c_s == 256) o = al256(o + (size_t)((iv.proj_out + 127) / 128) * 65536);
     L.blk[b].bproj = o; o = al256(o + (size_t)iv.proj_out * 4);
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
@@ -365,11 +368,15 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     const LinW* parts[4] = {&k.q, &k.kv, &k.qp, &k.kvp};
     long row = 0;
     const bool proj_img = L.esz == 2 && cs == 256;
-    if (proj_img && hipMemsetAsync(D + db.wproj_img, 0, (size_t)((iv.proj_out + 127) / 128) * 65536, st) != hipSuccess) return FDIPT_ELAUNCH;
+    if (proj_img && (hipMemsetAsync(D + db.wproj_img, 0, (size_t)((iv.proj_out + 127) / 128) * 65536, st) != hipSuccess ||
+                     hipMemsetAsync(D + db.wproj_img_lo, 0, (size_t)((iv.proj_out + 127) / 128) * 65536, st) != hipSuccess))
+      return FDIPT_ELAUNCH;
     for (int p = 0; p < 4; ++p) {
       // (tile-major images: stacking row blocks of 32 = concatenation)
       if (proj_img && (parts[p]->out % 32 || (rc = fd_chain_build_image(P + parts[p]->w, parts[p]->out, cs, cs, 0,
-                                                                         D + db.wproj_img + (size_t)(row / 32) * (cs / 16) * 1024, st))))
+                                                                         D + db.wproj_img + (size_t)(row / 32) * (cs / 16) * 1024, st)) ||
+                       (rc = fd_chain_build_image_lo(P + parts[p]->w, parts[p]->out, cs, cs,
+                                                     D + db.wproj_img_lo + (size_t)(row / 32) * (cs / 16) * 1024, st))))
         return rc ? rc : FDIPT_ESIZE;
       if ((rc = copy_cols(L.esz, parts[p]->out, cs, cs, P + parts[p]->w, cs, 0, 1.f, D + db.wproj + row * cs * L.esz, st)))
         return rc;
@@ -379,7 +386,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
       row += parts[p]->out;
     }
     // (only shapes fd_ipa_proj2_supported accepts ever read the image)
-    if (proj_img && C % 128 == 0 && (H * C) % 128 == 0 && (rc = fd_ipa_proj2_permute_image(D + db.wproj_img, H, C, cs, st))) return rc;
+    if (proj_img && C % 128 == 0 && (H * C) % 128 == 0 &&
+        ((rc = fd_ipa_proj2_permute_image(D + db.wproj_img, H, C, cs, st)) || (rc = fd_ipa_proj2_permute_image(D + db.wproj_img_lo, H, C, cs, st))))
+      return rc;
     hipLaunchKernelGGL(gamma_kernel, dim3(1), dim3(64), 0, st, H, d->no_qk_points, P + k.head_w, (float*)(D + db.gamma));
     FD_CHECK_LAUNCH();
     // pair bias pre-scaled by sqrt(1/3) (ipa_pytorch.py:256-257)
@@ -622,7 +631,10 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   const bool split = split_any && (sw.split_mask & 2u);                                   // IPA output projection
   const bool split_embed = split_any && (sw.split_mask & 1u), split_qkv = split_any && (sw.split_mask & 4u),
              split_tail = split_any && (sw.split_mask & 8u), split_trans = split_any && (sw.split_mask & 16u),
-             split_tors = split_any && (sw.split_mask & 32u);
+             split_tors = split_any && (sw.split_mask & 32u), split_proj = split_any && (sw.split_mask & 64u),
+             split_etrows = split_any && (sw.split_mask & 128u), split_dz = split_any && (sw.split_mask & 256u),
+             split_skip = split_any && (sw.split_mask & 512u), split_pv = split_any && (sw.split_mask & 1024u);
+  (void)split_etrows; (void)split_dz; (void)split_skip; (void)split_pv;
   const void *rb_l0 = nullptr, *rb_l1 = nullptr, *rb_l2 = nullptr;  // one-shot: lo images for the next rblock() call
   auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                     const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
@@ -782,6 +794,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       pj.Qb = (half_t*)(W + w.qb); pj.Kb = (half_t*)(W + w.kb); pj.Vt = (half_t*)(W + w.vt); pj.pts = F(w.pts);
       pj.zero_pads = b == 0 || op.kind != OP_ALL;  // (per-op entry: the workspace is the caller's, pads unknown)
       pj.W_img = (cs == 256 && !sw.proj_v1) ? D + db.wproj_img : nullptr;
+      pj.W_img_lo = (pj.W_img && split_proj) ? D + db.wproj_img_lo : nullptr;
       // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
       if (fd_ipa_proj2_supported(pj)) {
         if (pj.zero_pads && seq_fused && !seq_img_ready && (C & 31) == 0 && (vpt_bytes & 15) == 0 && !sw.init_unfused) {

@@ -5,7 +5,11 @@ a time (activations AND weights rounded before the product, fp32 accumulation: w
 error of psi / CA / last node representation against the unrounded oracle.  Errors of independent groups add in
 quadrature, so the table says where split (hi + lo) operands pay.
 
-    python tests/err_budget.py [golden] [fp16|bf16]
+    python tests/err_budget.py [golden] [fp16|bf16] [bb_gain] [product|all] [rows]
+
+``bb_gain`` overrides the BackboneUpdate weight scale of the fixture (0.3: frames move ~3 A per block, as trained weights
+would); ``product`` restricts the table and the ALL row to the groups the fp16 product mode runs on plain (unsplit) fp16
+operands — the node path runs on split operands there and does not round.
 """
 import os
 import sys
@@ -20,6 +24,8 @@ from conftest import kabsch_free_rmsd, load_golden  # noqa: E402
 from test_oracle_forward import _feats, _model  # noqa: E402
 
 KIND = sys.argv[2] if len(sys.argv) > 2 else "fp16"
+BB_GAIN = float(sys.argv[3]) if len(sys.argv) > 3 else None
+PRODUCT = len(sys.argv) > 4 and sys.argv[4] == "product"
 
 
 def rnd(x):
@@ -42,9 +48,30 @@ GROUPS = ["embed_node", "embed_edge", "ipa_pts", "ipa_qkv", "ipa_attn", "pair_bi
           "tfmr_attn", "post", "transition", "et", "z_store", "torsion"]
 
 
+# groups whose products run on plain fp16 operands in the fp16 product mode (everything else is on split operands / fp32)
+PRODUCT_GROUPS = ["embed_edge", "ipa_pts", "ipa_qkv", "ipa_attn", "pair_bias", "opair", "skip", "tfmr_attn", "et", "z_store"]
+
+
+def want(group, block=None, idx=None):
+    """(round activations?, round weights?) for a product of ``group`` in trunk block ``block`` (``idx``: which matmul of an
+    attention).  Entries of Net.on: ``group[.x|.w][@block][#idx]`` — e.g. ``et.w@1`` rounds only the weights of the
+    EdgeTransition after block 1, ``ipa_attn#0`` only the first matmul (Q K^T) of the IPA attention."""
+    rx = rw = False
+    for e in Net.on:
+        g, i = (e.split("#") + [None])[:2]
+        g, b = (g.split("@") + [None])[:2]
+        g, part = (g.split(".") + ["xw"])[:2]
+        if g != group or (b is not None and block is not None and int(b) != block) or (i is not None and idx is not None and int(i) != idx):
+            continue
+        rx, rw = rx or "x" in part, rw or "w" in part
+    return rx, rw
+
+
 class Net(osn.ScoreNetwork):
     on = frozenset()
     where = None  # "ipa" / "tfmr": which attention the np.matmul proxy is inside
+    block = None
+    mm_idx = 0
 
     def _group(self, name):
         for sub, g in GROUP_OF:
@@ -54,19 +81,23 @@ class Net(osn.ScoreNetwork):
 
     def _lin(self, name, x):
         w, b = self.sd[name + ".weight"], self.sd[name + ".bias"]
-        if self._group(name) in self.on:
-            x, w = rnd(x), rnd(w)
+        g = self._group(name)
+        if g is not None:
+            digits = [int(t) for t in name.replace(".", "_").split("_") if t.isdigit()]
+            blk = digits[0] if ("trunk" in name and digits) else None
+            rx, rw = want(g, blk)
+            x, w = (rnd(x) if rx else x), (rnd(w) if rw else w)
         return osn.linear(x, w, b)
 
-    def ipa(self, *a, **k):
-        Net.where = "ipa_attn"
+    def ipa(self, b, *a, **k):
+        Net.where, Net.block, Net.mm_idx = "ipa_attn", b, 0
         try:
-            return super().ipa(*a, **k)
+            return super().ipa(b, *a, **k)
         finally:
             Net.where = None
 
     def seq_tfmr(self, b, x, mask):
-        Net.where = "tfmr_attn"
+        Net.where, Net.block, Net.mm_idx = "tfmr_attn", b, 0
         # in_proj goes through osn.linear directly: round here
         try:
             return super().seq_tfmr(b, x, mask)
@@ -75,11 +106,11 @@ class Net(osn.ScoreNetwork):
 
     def embed(self, *a, **k):
         node, edge = super().embed(*a, **k)
-        return node, (rnd(edge) if "z_store" in self.on else edge)
+        return node, (rnd(edge) if want("z_store", 0)[0] else edge)
 
     def edge_transition(self, b, node, edge):
         z = super().edge_transition(b, node, edge)
-        return rnd(z) if "z_store" in self.on else z
+        return rnd(z) if want("z_store", b + 1)[0] else z
 
 
 class NPProxy:
@@ -88,8 +119,12 @@ class NPProxy:
 
     @staticmethod
     def matmul(a, b):
-        if Net.where in Net.on:
-            a, b = rnd(a), rnd(b)
+        if Net.where is not None:
+            # IPA: 0 = Q K^T, 1 = P V, 2 = P v_pts, 3 = P pair_z; sequence attention: per layer 0 = Q K^T, 1 = P V
+            idx = Net.mm_idx if Net.where == "ipa_attn" else Net.mm_idx % 2
+            Net.mm_idx += 1
+            ra, rb = want(Net.where, Net.block, idx)
+            a, b = (rnd(a) if ra else a), (rnd(b) if rb else b)
         return np.matmul(a, b)
 
 
@@ -98,8 +133,9 @@ _lin0 = osn.linear
 
 
 def _linear_hook(x, w, b):  # seq_tfmr's in_proj calls the module-level linear()
-    if Net.where == "tfmr_attn" and "tfmr" in Net.on:
-        x, w = rnd(x), rnd(w)
+    if Net.where == "tfmr_attn":
+        rx, rw = want("tfmr", Net.block)
+        x, w = (rnd(x) if rx else x), (rnd(w) if rw else w)
     return _lin0(x, w, b)
 
 
@@ -110,6 +146,9 @@ def main():
     gname = sys.argv[1] if len(sys.argv) > 1 else "fwd_full_denovo_n64"
     G = load_golden(gname + ".npz")
     tables = dict(np.load(os.path.join(ROOT, "framedipt_amd", "data", "residue_tables.npz")))
+    if BB_GAIN is not None:
+        G = dict(G)
+        G["bb_gain"] = BB_GAIN
     model, _ = _model(gname[4:], G, tables)
     model.__class__ = Net
 
@@ -122,11 +161,14 @@ def main():
 
     ref, nref = run(())
     ang = lambda p: np.arctan2(p[..., 0], p[..., 1])  # noqa: E731
-    print(f"{gname}  operand rounding: {KIND}")
+    groups = [g for g in GROUPS if not PRODUCT or g in PRODUCT_GROUPS]
+    if len(sys.argv) > 5:  # explicit rows: comma-separated selections, '+' joins selections into one row
+        groups = sys.argv[5].split(",")
+    print(f"{gname}  operand rounding: {KIND}  bb_gain: {float(G['bb_gain'])}" + ("  (groups the fp16 product mode rounds)" if PRODUCT else ""))
     print(f"{'group':12s} {'psi max':>9s} {'psi rms':>9s} {'CA max':>9s} {'CA rms':>9s} {'node rel':>9s} {'bb rmsd':>9s}")
     tot = np.zeros(3)
-    for g in GROUPS + ["ALL"]:
-        out, nd = run(GROUPS if g == "ALL" else (g,))
+    for g in groups + ["ALL"]:
+        out, nd = run(groups if g == "ALL" else g.split("+"))
         dpsi = np.abs(np.angle(np.exp(1j * (ang(out["psi"]) - ang(ref["psi"])))))
         dca = np.linalg.norm(out["rigids"][..., 4:] - ref["rigids"][..., 4:], axis=-1)
         rel = np.linalg.norm(nd - nref) / np.linalg.norm(nref)
