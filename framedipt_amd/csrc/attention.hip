@@ -458,10 +458,15 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
   };
   request(0);
   // down_z as B fragments (wave 0 only): requested now, used at the very end
-  hx8 wdf[8];
-  if (wave == 0)
+  hx8 wdf[8], wdl[8];
+  const bool dz_split = a.wdz_img_lo != nullptr;  // split operands for the down-projection (per-residue product: see OPairArgs)
+  if (wave == 0) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) wdf[s] = __builtin_bit_cast(hx8, *(const u16x8*)((const char*)a.wdz_img + (s * 64 + lane) * 16));
+    if (dz_split)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wdl[s] = __builtin_bit_cast(hx8, *(const u16x8*)((const char*)a.wdz_img_lo + (s * 64 + lane) * 16));
+  }
   // attention weights -> bf16 rows (zero for padded keys) and sum_j a[h,i,j] (= 1 up to rounding and masking) in one pass:
   // 32 threads per head
   if (a.probs_h16) {  // already bf16 rows [b, i, h, probs_np] (attention3): 4 keys (8 B) per load, 32 threads per head
@@ -551,9 +556,16 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
         const f32x4 x0 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi), x1 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi + 4);
         v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3]; v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
       }
-      hx8 af;
+      hx8 af, al;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) af[e] = (fd_h)v[e];
+      for (int e = 0; e < 8; ++e) {
+        af[e] = (fd_h)v[e];
+        al[e] = (fd_h)(v[e] - (float)af[e]);
+      }
+      if (dz_split) {
+        o2 = fd_mfma32(af, wdl[s], o2);
+        o2 = fd_mfma32(al, wdf[s], o2);
+      }
       o2 = fd_mfma32(af, wdf[s], o2);
     }
     const float bd = a.bdz[li];

@@ -76,6 +76,9 @@ struct OPairArgs {
   int probs_np;
   const float* wdz;      // [CZ,CD] f32 (down_z weight, transposed)
   const void* wdz_img;   // optional: down_z weight [CD, CZ] as a bf16 fragment image (fd_chain_build_image, natural k) for the MFMA kernel
+  // optional (MFMA kernel): image of Wdz - half(Wdz): the down-projection runs on split operands (az = hi + lo, Wdz = hi + lo).
+  // It is a per-residue product [8 x 128] x [128 x 32]: its operand rounding is shared by all keys of the row (tests/err_budget.py)
+  const void* wdz_img_lo = nullptr;
   const float* bdz;      // [CD]
   float* out;            // row (b*N+i): out + r*out_ld + off + h*CD + d
   half_t* out_h16;      // MFMA kernel: if set, bf16 rows (same out_ld, in elements) INSTEAD of out

@@ -159,13 +159,13 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int rup8(int x) { return (x + 7) & ~7; }
 
 struct DSplit {  // lo images (W - half(W)) of the node-path layers that run on split operands (rowblock.hip, attention_seq.hip)
-  size_t inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3;
+  size_t inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3, et_init, r4w;
 };
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img; DChain ch; DSplit lo; };
+struct DBlock { size_t wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo; DChain ch; DSplit lo; };
 struct DLayout {
   size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -174,6 +174,7 @@ struct DLayout {
   size_t ch_ne0, ch_ne2, ch_ne4, ch_tor1, ch_tor2;  // chain images: node embedder, torsion head
   size_t ch_ne2n, ch_ne4n, ch_tor2n;                // ... natural k order (rowblock.hip)
   size_t lo_ne0, lo_ne2, lo_ne4, lo_tor1, lo_tor2;  // lo images: node embedder, torsion head
+  size_t skip_w32;                                  // ... in fp32 (split operands: the GEMM splits both operands while it stages them)
   size_t skip_w, skip_b;                            // skip_embed of ALL blocks stacked: [num_blocks * c_skip, c_s] operand precision, bias f32
   DBlock blk[FD_MAX_BLOCKS];
   size_t total;
@@ -220,6 +221,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].wb_img3 = o; o = al256(o + 4096);  // ... as 16 x 128 (edge_transition3 epilogue)
     L.blk[b].wb_img4 = o; o = al256(o + 8192);  // ... as 32 x 128 in edge_transition4's hand-off order
     L.blk[b].wdz_img = o; o = al256(o + 8192);  // down_z [c_z/4, c_z] as a bf16 fragment image (MFMA o_pair kernel)
+    L.blk[b].wdz_img_lo = o; o = al256(o + 8192);  // ... and of Wdz - half(Wdz)
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et3 = o;
     if (use_regpair(d) && b < d->num_blocks - 1) o = al256(o + fd_et3_stream_bytes());
@@ -246,6 +248,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       DSplit& c = L.blk[b].lo;
       for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); }
       c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs);
+      c.et_init = img(iv.cb, cs); c.r4w = img(2 * (iv.hid + d->c_z), iv.cb);
     }
     L.lo_ne0 = img(cs, L.kn_pad); L.lo_ne2 = img(cs, cs); L.lo_ne4 = img(cs, cs); L.lo_tor1 = img(cs, cs); L.lo_tor2 = img(cs, cs);
     L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
@@ -254,6 +257,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
   }
   L.skip_w = o; o = al256(o + (size_t)d->num_blocks * d->c_skip * d->c_s * L.esz);
   L.skip_b = o; o = al256(o + (size_t)d->num_blocks * d->c_skip * 4);
+  L.skip_w32 = o; o = al256(o + (size_t)d->num_blocks * d->c_skip * d->c_s * 4);
   L.total = o;
 }
 
@@ -363,6 +367,7 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     const DBlock& db = L.blk[b];
     // fused projection [q | kv | q_pts | kv_pts] rows (ipa_pytorch.py:202-239)
     if ((rc = copy_cols(L.esz, d->c_skip, cs, cs, P + k.skip.w, cs, 0, 1.f, D + L.skip_w + (size_t)b * d->c_skip * cs * L.esz, st)) ||
+        (rc = copy_cols(4, d->c_skip, cs, cs, P + k.skip.w, cs, 0, 1.f, D + L.skip_w32 + (size_t)b * d->c_skip * cs * 4, st)) ||
         (rc = copy_cols(4, 1, d->c_skip, d->c_skip, P + k.skip.b, d->c_skip, 0, 1.f, D + L.skip_b + (size_t)b * d->c_skip * 4, st)))
       return rc;
     const LinW* parts[4] = {&k.q, &k.kv, &k.qp, &k.kvp};
@@ -401,7 +406,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
         return rc;
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
-    if (cz == 128 && (rc = fd_chain_build_image(P + k.dz.w, cz / 4, cz, cz, 0, D + db.wdz_img, st))) return rc;
+    if (cz == 128 && ((rc = fd_chain_build_image(P + k.dz.w, cz / 4, cz, cz, 0, D + db.wdz_img, st)) ||
+                      (rc = fd_chain_build_image_lo(P + k.dz.w, cz / 4, cz, cz, D + db.wdz_img_lo, st))))
+      return rc;
     if (use_regpair(d) && b < d->num_blocks - 1)
       if ((rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)) ||
           (rc = fd_et4_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et4, st)))
@@ -453,6 +460,15 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
         if ((rc = lo(k.tf[l].inp, c.inp[l])) || (rc = lo(k.tf[l].outp, c.outp[l])) || (rc = lo(k.tf[l].l1, c.l1[l])) || (rc = lo(k.tf[l].l2, c.l2[l])))
           return rc;
       if ((rc = lo(k.post, c.post)) || (rc = lo(k.t1, c.t1)) || (rc = lo(k.t2, c.t2)) || (rc = lo(k.t3, c.t3))) return rc;
+      if (b < d->num_blocks - 1) {  // EdgeTransition per-residue rows: initial_embed and the e_i / e_j columns of the first / final layers
+        const size_t i1 = fd_chain_image_bytes(iv.hid, iv.cb), i2 = fd_chain_image_bytes(cz, iv.cb);
+        if ((rc = lo(k.et_init, c.et_init)) ||
+            (rc = fd_chain_build_image_lo(P + k.et1.w + cz, iv.hid, iv.cb, iv.hid, D + c.r4w, st)) ||
+            (rc = fd_chain_build_image_lo(P + k.etf.w + cz, cz, iv.cb, iv.hid, D + c.r4w + i1, st)) ||
+            (rc = fd_chain_build_image_lo(P + k.et1.w + cz + iv.cb, iv.hid, iv.cb, iv.hid, D + c.r4w + i1 + i2, st)) ||
+            (rc = fd_chain_build_image_lo(P + k.etf.w + cz + iv.cb, cz, iv.cb, iv.hid, D + c.r4w + 2 * i1 + i2, st)))
+          return rc;
+      }
     }
     if ((rc = lo(iv.ne0, L.lo_ne0)) || (rc = lo(iv.ne2, L.lo_ne2)) || (rc = lo(iv.ne4, L.lo_ne4)) || (rc = lo(iv.tor1, L.lo_tor1)) ||
         (rc = lo(iv.tor2, L.lo_tor2)))
@@ -634,7 +650,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
              split_tors = split_any && (sw.split_mask & 32u), split_proj = split_any && (sw.split_mask & 64u),
              split_etrows = split_any && (sw.split_mask & 128u), split_dz = split_any && (sw.split_mask & 256u),
              split_skip = split_any && (sw.split_mask & 512u), split_pv = split_any && (sw.split_mask & 1024u);
-  (void)split_etrows; (void)split_dz; (void)split_skip; (void)split_pv;
+  (void)split_pv;
   const void *rb_l0 = nullptr, *rb_l1 = nullptr, *rb_l2 = nullptr;  // one-shot: lo images for the next rblock() call
   auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                     const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
@@ -750,7 +766,10 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // skip_embed(init_node) of every block depends on the embedder output only: one GEMM launch for all blocks, copied behind the
   // LayerNorm output by the LayerNorm kernel (FDIPT_SKIP_PER_BLOCK: one launch per block as before)
   const bool skip_batched = bf && iv.feat_dim >= 1024 && !sw.no_splitk && !sw.skip_per_block && op.kind == OP_ALL;
-  if (skip_batched)
+  if (skip_batched && split_skip && (cs & 7) == 0)
+    RC(fd_linear_splitk_split(R, d->num_blocks * d->c_skip, cs, 1, F(w.node0), cs, (const float*)(D + L.skip_w32), cs, (const float*)(D + L.skip_b),
+                              nullptr, F(w.skip_all), 0, d->num_blocks * d->c_skip, st));
+  else if (skip_batched)
     RC(fd_linear(prec, R, d->num_blocks * d->c_skip, cs, F(w.node0), cs, D + L.skip_w, cs, (const float*)(D + L.skip_b), nullptr, 0,
                  nullptr, 0, F(w.skip_all), d->num_blocks * d->c_skip, st));
   bool seq_img_ready = false;  // layer-independent part of the sequence-attention images written (once per forward)
@@ -775,7 +794,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     a3.probs = F(w.probs); a3.probs_h16 = nullptr; a3.out_h16 = nullptr; a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
     OPairArgs oa;
     oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_h16 = nullptr; oa.probs_np = 0; oa.out_h16 = nullptr;
-    oa.wdz = (const float*)(D + db.wdz_t); oa.wdz_img = (bf && cz == 128) ? D + db.wdz_img : nullptr; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
+    oa.wdz = (const float*)(D + db.wdz_t); oa.wdz_img = (bf && cz == 128) ? D + db.wdz_img : nullptr; oa.wdz_img_lo = (oa.wdz_img && split_dz) ? D + db.wdz_img_lo : nullptr; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
     bool feats_h16 = false, skip_done = false;
     const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !sw.generic_attn && fd_attention3_supported(a3);
     PointsArgs pa;
@@ -1044,6 +1063,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         r.rowmask_post = nullptr; r.out = F(w.r4); r.ld_out = 1024; r.out2 = nullptr; r.ld_out2 = 0; r.split = 0;
         r.hid_h16 = nullptr; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
         r.img_a = W + w.a1img; r.img_b = W + w.b1img; r.img_B = B; r.img_N = N;
+        if (split_etrows && !sw.et4_rows_unfused) { r.w0l = D + db.lo.et_init; r.w1l = D + db.lo.r4w; }
         if (!sw.et4_rows_unfused) {  // the row-block epilogue writes the fold-fragment images itself
           RC(fd_rowblock(FD_RB_ET4_IMAGES, r, st));
         } else {

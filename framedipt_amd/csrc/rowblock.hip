@@ -84,7 +84,9 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   // weight-fragment buffers: tile u of a wave lives in buffer u % NB; wide outputs with short K (8 tiles of 8 fragments per wave)
   // keep three tiles in flight instead of one (each tile is a dependent L2 round trip otherwise)
   constexpr int NB = (NTW >= 6 && KSMAX <= 16) ? 4 : 2;
-  static_assert(!SPLIT || NB == 2, "split operands: buffer 0 holds the hi fragments of a tile, buffer 1 the lo fragments");
+  // split operands: a tile's hi fragments live in an even buffer, its lo fragments in the odd one behind it; NB == 4 = two
+  // tiles in flight (wide outputs with short K), NB == 2 = one
+  constexpr int PAIRS = NB / 2;
   hx8 Wf[NB][KSMAX];
   auto w_load = [&](auto BUF, auto KSC, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value, KS = decltype(KSC)::value;
@@ -164,9 +166,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   auto layer = [&](auto KSC, auto NTC, const char* img, const char* img_lo, auto SWAPC) {
     constexpr int KS = decltype(KSC)::value, NT = decltype(NTC)::value;
     constexpr bool SWAP = decltype(SWAPC)::value;  // operands exchanged: lane = output feature, registers = rows
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && PAIRS == 1) {
       // per tile: Whi.xhi + Whi.xlo out of buffer 0, then Wlo.xhi out of buffer 1; the next tile's hi fragments are requested
       // when buffer 0 is free (under the lo pass), its lo fragments when buffer 1 is (under the next tile's hi passes)
+      static_assert(!SWAP, "one tile in flight: untransposed products only");
       ch_rb_for<NTW>([&](auto U) {
         constexpr int u = decltype(U)::value;
         const int T = wave + 4 * u;
@@ -182,6 +185,31 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
 #pragma unroll
           for (int s = 0; s < KS; ++s) c = fd_mfma32(Wf[1][s], X[s], c);
           if (u + 1 < NTW && T + 4 < NT) w_load(std::integral_constant<int, 1>{}, KSC, img_lo, T + 4);
+          acc[u] = c;
+        }
+      });
+      return;
+    }
+    if constexpr (SPLIT && PAIRS == 2) {
+      // two tiles in flight: tile u lives in buffers 2 (u & 1) (hi) and 2 (u & 1) + 1 (lo); tile u + 1 is requested before the
+      // products of tile u start (tile 0 was requested by the caller)
+      ch_rb_for<NTW>([&](auto U) {
+        constexpr int u = decltype(U)::value, bh = 2 * (u & 1), bn = 2 * ((u + 1) & 1);
+        const int T = wave + 4 * u;
+        if (u + 1 < NTW && T + 4 < NT) {
+          w_load(std::integral_constant<int, bn>{}, KSC, img, T + 4);
+          w_load(std::integral_constant<int, bn + 1>{}, KSC, img_lo, T + 4);
+        }
+        if (T < NT) {
+          f32x16 c;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) c = SWAP ? fd_mfma32(X[s], Wf[bh + 1][s], c) : fd_mfma32(Wf[bh + 1][s], X[s], c);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) c = SWAP ? fd_mfma32(Xl[s], Wf[bh][s], c) : fd_mfma32(Wf[bh][s], Xl[s], c);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) c = SWAP ? fd_mfma32(X[s], Wf[bh][s], c) : fd_mfma32(Wf[bh][s], X[s], c);
           acc[u] = c;
         }
       });
@@ -274,7 +302,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     // columns 512..1023 = [B1 | Bf] of 4 consecutive residues j of sample b -> b_img[b][j / 4][..][0..3], and the same 8 bytes
     // as elements 4..7 of sample b - 1 (the rows of a patch that straddles two samples); elements 4..7 of the last sample are
     // zeros (finite: they meet zeros of the selection matrix).  Needs img_N % 4 == 0.
-    static_assert(NL == 2 && NOUT == 1024 && !SPLIT, "ET4 image kind");
+    static_assert(NL == 2 && NOUT == 1024, "ET4 image kind");
     const float* bo = cst + N1 + N2;
     const int NJ4 = a.img_N >> 2;
     half_t* ia = (half_t*)a.img_a;
@@ -803,6 +831,9 @@ int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
     case FD_RB_ET4_ROWS: return rb_launch<256, 128, 0, 1024, 0>(a, st);          // ... [A1 | Af | B1 | Bf]: e_i and e_j columns
     case FD_RB_ET4_IMAGES:                                                        // ... written as edge_transition4's fold fragments
       if (!a.img_a || !a.img_b || (a.img_N & 3) || a.M != a.img_B * a.img_N) return FDIPT_EINVAL;
+      // split operands (w0l / w1l): e = initial_embed(node) and the four per-residue products to fp32 accuracy before the rows are
+      // rounded to the fold fragments — these rows are shared by all pairs of a residue, their errors do not average out over keys
+      if (a.w0l && a.w1l) return rb_launch<256, 128, 0, 1024, 16 | 32>(a, st);
       return rb_launch<256, 128, 0, 1024, 16>(a, st);
     default: return FDIPT_EINVAL;
   }
