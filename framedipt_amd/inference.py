@@ -57,6 +57,14 @@ class ReverseLoop:
         self.aatype = to_dev(preprocess_aatype(data_init.get("aatype"), self.fixed, inpainting, input_aatype))
         self.net_aatype = to_dev(preprocess_aatype(data_init.get("aatype"), self.fixed, model.inpainting,
                                                    model._model_conf.input_aatype))
+        # rigid_0_traj (bb_0_pred, experiments/utils.py:397-402) is built with inference_fn's aatype.  Where that equals the
+        # network's own view the forward writes the row itself; where it does not (the reference's default inpainting
+        # configuration: inference.input_aatype=True with model.input_aatype=False, so the network sees 20 = unknown on the
+        # diffused residues and would build ALA there) the row comes from a backbone launch on the forward's frames / psi
+        same = (self.aatype is None and self.net_aatype is None) or (
+            self.aatype is not None and self.net_aatype is not None and bool(torch.equal(self.aatype, self.net_aatype)))
+        # (net_aatype None = the backbone builder's default residue 0, as is aatype None)
+        self.bb0_from_forward = same
         self.gt_tors = data_init["torsion_angles_sin_cos"]
         self.gt_psi = f32(self.gt_tors[..., 2, :])
         self.st = state if state is not None else model.batch_state(data_init["seq_idx"])
@@ -86,9 +94,12 @@ class ReverseLoop:
     def _fwd(self, k, want_atoms, sc_update):
         # the forward itself hands the predicted CA positions to the next step's self-conditioning input (read at its start,
         # written at its end: no copy kernel)
+        direct = want_atoms and self.bb0_from_forward
         self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all[k],
-                        self.temb_all[k], self.sig_all[k], want_atoms, ca_out=self.sc_ca if sc_update else None,
-                        atom37_out=self.bb0_traj[k] if want_atoms else None)  # rigid_0_traj row: straight into its slot
+                        self.temb_all[k], self.sig_all[k], direct, ca_out=self.sc_ca if sc_update else None,
+                        atom37_out=self.bb0_traj[k] if direct else None)  # rigid_0_traj row: straight into its slot
+        if want_atoms and not direct:
+            _backbone(self.model, self.B * self.N, self.st.rigids, None, None, self.st.psi, self.aatype, self.bb0_traj[k])
 
     def prime(self):
         """Self-conditioning priming call (utils.py:571-578)."""

@@ -203,20 +203,22 @@ def test_forward_fp32_vs_reference_goldens(name):
 
 @pytest.mark.parametrize("name", ["small_denovo_n16", "full_denovo_n64"])
 def test_forward_fp16_vs_reference_goldens(name):
-    """fp16 GEMM operands / fp16 pair representation: separate (looser) tolerance, stated here."""
+    """fp16 mode against the reference at the two oldest fixtures, at the bounds of tests/test_gpu_sizes.py::test_forward_fp16_at_size
+    (FP16_BOUND there: measured values x 2-3): node representation 3e-4 relative, CA 5e-4 A, backbone RMSD 5e-4 A.  The small-config
+    network (widths the split-operand kernels are not compiled for: plain fp16 operands on the node path) gets 1e-3 / 1e-3 A."""
     G = load_golden(f"fwd_{name}.npz")
     net, _, conf = _net(name, G, "fp16")
+    small = name.startswith("small")
     out = net(_feats(G), trace=True)
     tn = out["trace_node"].cpu().numpy()
     nb = conf.model.ipa.num_blocks
     for b in range(nb):
         ref = G[f"tr_node_{b}"]
         rel = np.linalg.norm(tn[b + 1] - ref) / np.linalg.norm(ref)
-        assert rel < 3e-2, (b, rel)
+        assert rel < (1e-3 if small else 3e-4), (b, rel)
     o = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith("trace")}
-    # frames move by bb_gain-scaled updates: CA within 0.05 A, backbone atoms within 0.1 A of the fp32 reference
-    np.testing.assert_allclose(o["rigids"][..., 4:], G["out_rigids"][..., 4:], atol=5e-2)
-    assert kabsch_free_rmsd(o["atom37"], G["out_atom37"]) < 0.1
+    np.testing.assert_allclose(o["rigids"][..., 4:], G["out_rigids"][..., 4:], atol=1e-3 if small else 5e-4)
+    assert kabsch_free_rmsd(o["atom37"], G["out_atom37"]) < (1e-3 if small else 5e-4)
 
 
 def _teacher_forced_steps(name, precision):
@@ -409,7 +411,8 @@ def test_baseline_config_shapes_run(n, B, prec, inp):
 def test_forward_fp16_vs_fp32_path_ragged_sizes(n, B):
     """Ragged shapes (N not a multiple of 4 / 32; 32-row blocks, 128-pair tiles and key tiles that straddle samples and
     padded keys; N % 8 == 4: the 8 x 4 patches of edge_transition4 straddle two samples): the fp16 kernels against the
-    fp32 path of the same network (itself pinned to the reference goldens)."""
+    fp32 path of the same network (itself pinned to the reference goldens), at the bounds of the fp16 mode against the reference
+    (test_gpu_sizes.py: node representation 3e-4, pair rows 2.5e-3 relative, CA 5e-4 A, backbone RMSD 5e-4 A)."""
     from framedipt_amd import config
     from framedipt_amd.diffusion import SE3Diffuser
     from framedipt_amd.model import ScoreNetwork
@@ -432,16 +435,16 @@ def test_forward_fp16_vs_fp32_path_ragged_sizes(n, B):
     tn32, tn16 = outs["fp32"]["trace_node"], outs["fp16"]["trace_node"]
     for b in range(1, tn32.shape[0]):
         rel = np.linalg.norm(tn16[b] - tn32[b]) / np.linalg.norm(tn32[b])
-        assert rel < 3e-2, (b, rel)
+        assert rel < 3e-4, (b, rel)
     te32, te16 = outs["fp32"]["trace_edge"], outs["fp16"]["trace_edge"]
     for b in range(te32.shape[0]):  # edge embedder, then the EdgeTransition of every block but the last
         rel = np.linalg.norm(te16[b] - te32[b]) / np.linalg.norm(te32[b])
-        assert rel < 3e-2, ("edge", b, rel)
-    np.testing.assert_allclose(outs["fp16"]["rigids"][..., 4:], outs["fp32"]["rigids"][..., 4:], atol=5e-2)
+        assert rel < 2.5e-3, ("edge", b, rel)
+    np.testing.assert_allclose(outs["fp16"]["rigids"][..., 4:], outs["fp32"]["rigids"][..., 4:], atol=5e-4)
     # psi is the unit vector of a small 2-vector (ill-conditioned where its norm is tiny): bound the outlier fraction
-    bad = np.abs(outs["fp16"]["psi"] - outs["fp32"]["psi"]).max(-1) > 0.1
-    assert bad.mean() < 0.05, bad.mean()
-    assert kabsch_free_rmsd(outs["fp16"]["atom37"], outs["fp32"]["atom37"]) < 0.1
+    bad = np.abs(outs["fp16"]["psi"] - outs["fp32"]["psi"]).max(-1) > 5e-3
+    assert bad.mean() < 0.01, bad.mean()
+    assert kabsch_free_rmsd(outs["fp16"]["atom37"], outs["fp32"]["atom37"]) < 5e-4
 
 
 def test_reverse_step_blocks_and_fused_atoms():
