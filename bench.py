@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--precision", default=None, choices=["fp16", "fp32"])
     ap.add_argument("--kernel-flags", type=lambda s: int(s, 0), default=0, help="FdiptDims.kernel_flags (development)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-precision", action="store_true", help="skip the fp32 (reference precision) sub-record")
+    ap.add_argument("--reference-steps", type=int, default=6, help="timed steps of the fp32 sub-record")
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--reserve-cus", type=int, default=48, help="with --streams > 1: CUs the persistent pair kernels leave to the other streams")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches on this many HIP streams (same results; not the default: the "
@@ -199,85 +201,134 @@ def main():
     items = [sharding.seeded_item(ds, i, a.seed, diff, T, 0.01) for i in mine]
     feats, tape = sharding.stack_items(items)
 
-    def new_loop():
-        if a.streams > 1:
-            return inference.StreamedLoops(net, diff, feats, a.streams, T, 0.01, noise_tape=tape, reserve_cus=a.reserve_cus, aux_traj=True,
-                                           noise_scale=0.1, inpainting=inp)
-        return inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp,
-                                     noise_tape=tape)
-
     nb = conf.model.ipa.num_blocks
     n_ev = nb - 1
-    # timed steps: the whole schedule, or K steps spread evenly over it (first and last included)
-    steps = list(range(T)) if K == T else sorted({int(round(i * (T - 1) / max(K - 1, 1))) for i in range(K)})
-    while len(steps) < K:  # (rounding collisions for K close to T)
-        steps = sorted(set(steps) | {next(s for s in range(T) if s not in steps)})
-    # HIP events around every EdgeTransition launch of up to 16 of the timed steps (recorded on the launch stream by the library)
-    sampled = sorted({steps[int(round(i * (K - 1) / 15))] for i in range(16)}) if K > 1 else steps
-    events = {}
-    for k in sampled:
-        ev_s, ev_e = (C.c_void_p * nb)(), (C.c_void_p * nb)()
-        for i in range(n_ev):
-            for arr in (ev_s, ev_e):
-                h = C.c_void_p()
-                _lib.check(lib.fdipt_event_create(C.byref(h)))
-                arr[i] = h
-        events[k] = (ev_s, ev_e)
 
-    warm = new_loop()  # scratch trajectory: touches every buffer / code object once
-    warm.prime()
-    for k in range(min(a.warmup, T)):
-        warm.step(k)
-    torch.cuda.synchronize()
-    del warm
-    loop = new_loop()
-    st = loop.st
-    if K < T:
-        loop.prime()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    clk = (C.c_ulonglong * 3)()
-    _lib.check(lib.fdipt_edge_transition_clock(clk, 1))  # reset: the sums below cover the timed region only
-    t0 = time.perf_counter()
-    if K == T:
-        loop.prime()
-    for k in steps:
-        st.ev_start, st.ev_stop = events.get(k, (None, None))
-        loop.step(k)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    st.ev_start = st.ev_stop = None
-    _lib.check(lib.fdipt_edge_transition_clock(clk, 0))
-    t1 = time.perf_counter()
-    res = loop.results()  # D2H of the trajectories, as inference_fn returns them (not part of `value`)
-    d2h = time.perf_counter() - t1
-    d2h_bytes = sum(v.nbytes for v in res.values() if hasattr(v, "nbytes"))
-    del res
-    et_ms = []
-    for k in sampled:
-        for i in range(n_ev):
-            ms = C.c_float()
-            _lib.check(lib.fdipt_event_elapsed_ms(events[k][0][i], events[k][1][i], C.byref(ms)))
-            et_ms.append(ms.value)
-    if world > 1:
-        tt = torch.tensor([el, d2h], device="cpu" if one_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el, d2h = float(tt[0].item()), float(tt[1].item())
-        dist.barrier()
+    def timed_region(net, prec, K, warmup, streams):
+        """W warm-up steps on a scratch trajectory, then K timed steps (the whole trajectory incl. the priming forward when K == T)
+        of the batch with `net`; returns (seconds, D2H seconds, D2H bytes, EdgeTransition launch ms list, clock counters, B_ev)."""
+        def new_loop():
+            if streams > 1:
+                return inference.StreamedLoops(net, diff, feats, streams, T, 0.01, noise_tape=tape, reserve_cus=a.reserve_cus, aux_traj=True,
+                                               noise_scale=0.1, inpainting=inp)
+            return inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp,
+                                         noise_tape=tape)
+        # timed steps: the whole schedule, or K steps spread evenly over it (first and last included)
+        steps = list(range(T)) if K == T else sorted({int(round(i * (T - 1) / max(K - 1, 1))) for i in range(K)})
+        while len(steps) < K:  # (rounding collisions for K close to T)
+            steps = sorted(set(steps) | {next(s for s in range(T) if s not in steps)})
+        # HIP events around every EdgeTransition launch of up to 16 of the timed steps (recorded on the launch stream by the library)
+        sampled = sorted({steps[int(round(i * (K - 1) / 15))] for i in range(16)}) if K > 1 else steps
+        events = {}
+        for k in sampled:
+            ev_s, ev_e = (C.c_void_p * nb)(), (C.c_void_p * nb)()
+            for i in range(n_ev):
+                for arr in (ev_s, ev_e):
+                    h = C.c_void_p()
+                    _lib.check(lib.fdipt_event_create(C.byref(h)))
+                    arr[i] = h
+            events[k] = (ev_s, ev_e)
+        warm = new_loop()  # scratch trajectory: touches every buffer / code object once
+        warm.prime()
+        for k in range(min(warmup, T)):
+            warm.step(k)
+        torch.cuda.synchronize()
+        del warm
+        loop = new_loop()
+        st = loop.st
+        if K < T:
+            loop.prime()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # in-kernel shader-clock probe of the EdgeTransition launches: opt-in, into a caller-owned buffer (FdiptForwardArgs.clock_out),
+        # only on the sampled steps the HIP events bracket
+        clk_dev = torch.zeros(3, dtype=torch.int64, device=dev)
+        t0 = time.perf_counter()
+        if K == T:
+            loop.prime()
+        for k in steps:
+            st.ev_start, st.ev_stop = events.get(k, (None, None))
+            st.clock_out = clk_dev if k in events else None
+            loop.step(k)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st.ev_start = st.ev_stop = st.clock_out = None
+        clk = [int(v) for v in clk_dev.cpu()]
+        d2h = d2h_bytes = None
+        if K == T:  # D2H of the whole trajectories, as inference_fn returns them (never part of `value`; only meaningful for a whole run)
+            t1 = time.perf_counter()
+            res = loop.results()
+            d2h = time.perf_counter() - t1
+            d2h_bytes = sum(v.nbytes for v in res.values() if hasattr(v, "nbytes"))
+            del res
+        et_ms = []
+        for k in sampled:
+            for i in range(n_ev):
+                ms = C.c_float()
+                _lib.check(lib.fdipt_event_elapsed_ms(events[k][0][i], events[k][1][i], C.byref(ms)))
+                et_ms.append(ms.value)
+            for arr in events[k]:
+                for i in range(n_ev):
+                    lib.fdipt_event_destroy(arr[i])
+        if world > 1:
+            tt = torch.tensor([el, d2h or 0.0], device="cpu" if one_gpu else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el, d2h = float(tt[0].item()), (float(tt[1].item()) if d2h is not None else None)
+            dist.barrier()
+        B_ev = loop.loops[0].B if streams > 1 else B  # samples in the launches the events bracket (first sub-batch)
+        del loop
+        return el, d2h, d2h_bytes, et_ms, (clk[0], clk[1]), B_ev
 
-    if rank == 0:
+    def record(prec, K, el, et_ms, clk, B_ev, kernel_flags):
+        """value / ms_per_step / roofline of one timed region."""
         res_steps = B * N * K * world
         value = res_steps / el
         et = float(np.mean(et_ms)) * 1e-3
-        B_ev = loop.loops[0].B if a.streams > 1 else B  # samples in the launches the events bracket (first sub-batch)
         et_flops = ET_FLOPS_PER_PAIR * B_ev * N * N
         peak = PEAK_TFLOPS[prec]
         achieved = et_flops / et / 1e12
         fwd_per_step = (T + 1) / T if K == T else 1.0
         fwd_tflops = value / world * (flops_per_forward(N, inp) / N) * fwd_per_step / 1e12  # whole-forward view, per GPU
-        et4 = prec == "fp16" and N % 4 == 0 and not (a.kernel_flags & 1)  # (FDIPT_KF_ET3 forces the fallback kernel)
+        et4 = prec == "fp16" and N % 4 == 0 and not (kernel_flags & 1)  # (FDIPT_KF_ET3 forces the fallback kernel)
+        ghz = clk[0] / clk[1] / 10 if clk[1] else None
+        return value, {
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": pmc_traffic(prec, N, B), "kernel": "edge_transition4_flat_kernel" if et4 else
+            ("edge_transition3_kernel" if prec == "fp16" else "edge_transition_f32ws_kernel"),
+            "avg_launch_ms": et * 1e3, "launches_timed": len(et_ms), "flops_per_launch": et_flops,
+            "executed_flops_per_launch": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N if et4 else None,
+            "executed_frac": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N / et / 1e12 / peak if et4 else None,
+            # shader clock the kernel's blocks actually ran at (s_memtime / s_memrealtime inside the kernel): power
+            # management holds it below the 2.4 GHz of `peak`; frac_at_clock prices the same FLOPs against the matrix
+            # peak at that clock
+            "clock_ghz": ghz, "frac_at_clock": achieved / (peak * ghz / NOMINAL_GHZ) if ghz else None,
+            "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak}
+
+    PREC_MODE = {"fp16": "fp16 MFMA operands / pair representation (fp16 stands in for the bf16 BASELINE configs[1] names: same MFMA rate, "
+                         "three more significand bits), split (hi+lo) operands on every per-residue product and the attention's P V, fp32 "
+                         "accumulation / frames / statistics; per-step backbone RMSD vs the reference < 1e-3 A also at bb_gain 0.3",
+                 "fp32": "fp32 (v_mfma_f32_32x32x2_f32): the reference's arithmetic"}
+    el, d2h, d2h_bytes, et_ms, clk, B_ev = timed_region(net, prec, K, a.warmup, a.streams)
+    ref_rec = None
+    if prec != "fp32" and not a.no_reference_precision:
+        # the same workload in the reference's precision (fp32 end to end), a short window of the same schedule: its own value and
+        # roofline, so that one command yields both modes (BASELINE.json: the reference never leaves fp32)
+        del net
+        torch.cuda.empty_cache()
+        net32 = ScoreNetwork(conf.model, diff, inpainting=inp, precision="fp32", kernel_flags=a.kernel_flags).load_synthetic(7).to(dev)
+        K32 = min(a.reference_steps, T)
+        el32, _, _, et32, clk32, Bev32 = timed_region(net32, "fp32", K32, 2, 1)
+        if rank == 0:
+            v32, roof32 = record("fp32", K32, el32, et32, clk32, Bev32, a.kernel_flags)
+            ref_rec = {"dtype": "fp32", "value": v32, "unit": "residue*step/s", "steps": K32, "warmup": 2, "ms_per_step": el32 / K32 * 1e3,
+                       "precision_mode": PREC_MODE["fp32"], "roofline": roof32,
+                       "note": f"same workload and schedule, {K32} steps spread over T={T}; per-step backbone RMSD vs the reference ~1e-5 A"}
+        del net32
+
+    if rank == 0:
+        value, roof = record(prec, K, el, et_ms, clk, B_ev, a.kernel_flags)
         out = {
             "metric": "residue*diffusion-steps/sec", "value": value, "unit": "residue*step/s", "n_gpus": world,
             "steps": K, "warmup": a.warmup, "ms_per_step": el / K * 1e3, "higher_is_better": True,
@@ -286,23 +337,15 @@ def main():
                                    f"batched, {'whole trajectory (priming forward + all steps)' if K == T else f'{K} steps spread over the schedule'}"
                                    f" of T={T}, aux_traj=True, noise_scale 0.1, 17.4M-param synthetic weights, per-sample seeds",
                        "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective" + (f", {a.streams} sub-batch streams per GPU" if a.streams > 1 else ""),
-                       "precision_mode": ("fp16 MFMA operands / pair representation, split (hi+lo) operands on the node path, fp32 "
-                                          "accumulation / frames / statistics" if prec == "fp16" else "fp32 (v_mfma_f32_32x32x2_f32)"),
-                       "kernel_flags": a.kernel_flags},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(prec, N, B), "kernel": "edge_transition4_flat_kernel" if et4 else
-                         ("edge_transition3_kernel" if prec == "fp16" else "edge_transition_f32ws_kernel"),
-                         "avg_launch_ms": et * 1e3, "launches_timed": len(et_ms), "flops_per_launch": et_flops,
-                         "executed_flops_per_launch": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N if et4 else None,
-                         "executed_frac": ET4_EXEC_FLOPS_PER_PAIR * B_ev * N * N / et / 1e12 / peak if et4 else None,
-                         # shader clock the kernel's blocks actually ran at (s_memtime / s_memrealtime inside the kernel): power
-                         # management holds it below the 2.4 GHz of `peak`; frac_at_clock prices the same FLOPs against the matrix
-                         # peak at that clock
-                         "clock_ghz": clk[0] / clk[1] / 10 if clk[1] else None,
-                         "frac_at_clock": achieved / (peak * (clk[0] / clk[1] / 10) / NOMINAL_GHZ) if clk[1] else None,
-                         "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak},
-            "results_d2h": {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": res_steps / (el + d2h)},
+                       "precision_mode": PREC_MODE[prec], "kernel_flags": a.kernel_flags},
+            "roofline": roof,
         }
+        if one_gpu:
+            out["one_gpu_test_hook"] = True  # all ranks shared GPU 0 (tests): NOT a multi-GPU measurement
+        if d2h is not None:
+            out["results_d2h"] = {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": B * N * K * world / (el + d2h)}
+        if ref_rec is not None:
+            out["reference_precision"] = ref_rec
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(300 if not inp else min(N, 300), config.base_config(), 7)
         print(json.dumps(out), flush=True)

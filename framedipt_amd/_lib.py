@@ -38,7 +38,7 @@ class ForwardArgs(C.Structure):
         (n, _P) for n in ("rigids_t", "res_mask", "fixed_mask", "sc_ca_t", "seq_idx", "idx_emb", "aatype", "gt_psi", "t",
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
                           "atom37", "atom14", "trace_node", "trace_edge", "trace_inner")] + [
-        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P), ("reserve_cus", C.c_int32)]
+        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P), ("reserve_cus", C.c_int32), ("clock_out", _P)]
 
 
 _lib = None
@@ -94,7 +94,6 @@ SIGNATURES = {
     "fdipt_event_destroy": (_i, [_P]),
     "fdipt_event_record": (_i, [_P, _P]),
     "fdipt_event_elapsed_ms": (_i, [_P, _P, C.POINTER(_f)]),
-    "fdipt_edge_transition_clock": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "fdipt_version": (C.c_char_p, []),
 }
 

@@ -7,6 +7,8 @@ OUT="$HERE/../lib"
 # process) -> lib/libfdipt_hip_dev.so, loaded instead of the product library when FDIPT_LIB points at it (tools/)
 BUILD="$HERE/build"; LIBNAME=libfdipt_hip.so; EXTRA=""
 if [ -n "${FDIPT_DEV:-}" ]; then BUILD="$HERE/build_dev"; LIBNAME=libfdipt_hip_dev.so; EXTRA="-DFDIPT_DEV"; fi
+# FDIPT_VARIANT=name FDIPT_EXTRA="-D..." : an A/B build with extra compile flags -> lib/libfdipt_hip_<name>.so (loaded through FDIPT_LIB)
+if [ -n "${FDIPT_VARIANT:-}" ]; then BUILD="$HERE/build_$FDIPT_VARIANT"; LIBNAME=libfdipt_hip_$FDIPT_VARIANT.so; EXTRA="$EXTRA ${FDIPT_EXTRA:-}"; fi
 mkdir -p "$OUT" "$BUILD"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -Wno-inline-asm: the LDS-DMA helpers name m0 (a reserved register hipcc re-materialises before each of its own uses) as clobbered

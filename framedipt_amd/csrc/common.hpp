@@ -190,11 +190,12 @@ __device__ __forceinline__ unsigned fd_l2_warm_last(const L2Warm& w, int id, int
 }
 __device__ __forceinline__ void fd_l2_warm_done(unsigned tok) { asm volatile("s_waitcnt vmcnt(0)" : : "v"(tok) : "memory"); }
 
-// In-kernel shader-clock probe of the EdgeTransition kernels (fdipt_edge_transition_clock): thread 0 of a block adds its core-clock
-// cycles (s_memtime) and 100 MHz ticks (s_memrealtime) from start to end to `ctr[0..1]` and counts the block in ctr[2].
+// Opt-in in-kernel shader-clock probe of the EdgeTransition kernels (FdiptForwardArgs.clock_out): thread 0 of a block adds its
+// core-clock cycles (s_memtime) and 100 MHz ticks (s_memrealtime) from start to end to `ctr[0..1]` and counts the block in ctr[2];
+// ctr == NULL (every product launch): no atomics.
 #define FD_CLK_BEGIN const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime()
 #define FD_CLK_END(ctr)                                                                       \
-  if (threadIdx.x == 0) {                                                                     \
+  if ((ctr) != nullptr && threadIdx.x == 0) {                                                                     \
     atomicAdd(&(ctr)[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0_);           \
     atomicAdd(&(ctr)[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0_);        \
     atomicAdd(&(ctr)[2], 1ull);                                                               \

@@ -77,10 +77,9 @@ __device__ unsigned long long e4_span[1024 * 3];  // per block: start, end (s_me
 #endif
 // Shader clock actually sustained inside the kernel (the matrix peak scales with it: under dense MFMA load the chip runs well below
 // its 2.4 GHz nominal clock, and how far below depends on the operand bits — tools/micro/et4_bench.hip): common.hpp FD_CLK_*,
-// read by fdipt_edge_transition_clock.  Three atomics per block and launch.
-__device__ unsigned long long e4_clk[3];
+// into the caller's FdiptForwardArgs.clock_out (ET2Args.clock) when that is set; no atomics and no state otherwise.
 #define E4_CLK_BEGIN FD_CLK_BEGIN
-#define E4_CLK_END FD_CLK_END(e4_clk)
+#define E4_CLK_END FD_CLK_END(a.clock)
 typedef fd_h e4_hx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int e4_u32x2 __attribute__((ext_vector_type(2)));
@@ -185,6 +184,23 @@ __device__ __forceinline__ void e4_dma16(const void* gsrc, unsigned lds_dst) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(gsrc) : "memory", "m0");
 }
+// Cache policy of the pair stream (z rows in, z' rows out: 2 x 184 MB per launch at N = 300, B = 8, read / written exactly once),
+// E4_ZPOL bit 0: z loads `nt`, bit 1: z' stores `sc1` (write-through: the line does not stay in the XCD's L2), bit 2: z' stores `nt`.
+// The 512 KB weight stream every block re-reads 11 times per launch should stay L2-resident next to it (round 2: re-fetched ~38
+// times per launch from the Infinity Cache: profiles/r02_pmc_bench_c4_fp16.md).
+#ifndef E4_ZPOL
+#define E4_ZPOL 0
+#endif
+__device__ __forceinline__ void e4_dma16_z(const void* gsrc, unsigned lds_dst) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
+  if (E4_ZPOL & 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" : : "s"(m0v), "v"(gsrc) : "memory", "m0");
+  else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(gsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void e4_store_z(half_t* dst, u16x8 v) {
+  if (E4_ZPOL & 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+  else if (E4_ZPOL & 4) __builtin_nontemporal_store(v, (u16x8*)dst);
+  else *(u16x8*)dst = v;
+}
 __device__ __forceinline__ void e4_dma_wait() {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -279,7 +295,7 @@ __device__ __forceinline__ void e4_request_z(const ET2Args& a, const E4Tile& t, 
     const int lrow = 4 * r + (lane >> 4);
     const int u = (lane & 15) ^ (lrow & 15);
     const long pair = ((long)row * N + 4 * t.jt) + (lane >> 4);
-    e4_dma16(a.z_in + pair * E4_CZ + 8 * u, zst + r * 1024);
+    e4_dma16_z(a.z_in + pair * E4_CZ + 8 * u, zst + r * 1024);
   }
 }
 
@@ -394,7 +410,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
     for (int k = 0; k < 2; ++k) {
       const int pr = 16 * k + (lane >> 2);
       const u16x8 v = *(e4_lds_u16x8)(unsigned long)(stg + pr * 64 + (((lane & 3) ^ ((pr >> 2) & 3)) << 4));
-      if (X.svalid[k] && (!(E4_ABL & 8) || X.prow == -12345)) *(u16x8*)(a.z_out + X.srow[k] * E4_CZ + 32 * t + 8 * (lane & 3)) = v;
+      if (X.svalid[k] && (!(E4_ABL & 8) || X.prow == -12345)) e4_store_z(a.z_out + X.srow[k] * E4_CZ + 32 * t + 8 * (lane & 3), v);
     }
   } else if constexpr (SLOT == 6) {
     if (a.wb_img) {
@@ -949,11 +965,3 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   return FDIPT_OK;
 }
 
-int fd_et4_clock(unsigned long long* out3, int reset) {
-  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(e4_clk), 24) != hipSuccess) return FDIPT_ELAUNCH;
-  if (reset) {
-    const unsigned long long z[3] = {0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(e4_clk), z, 24) != hipSuccess) return FDIPT_ELAUNCH;
-  }
-  return FDIPT_OK;
-}

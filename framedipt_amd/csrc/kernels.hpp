@@ -22,6 +22,7 @@ struct EdgeTransArgs {
   const float *b1, *b2, *bf, *gamma, *beta;
   const float* res_mask;  // [B,N]
   float* trace;           // optional [B,N,N,CZ] f32
+  unsigned long long* clock = nullptr;  // optional shader-clock probe (FdiptForwardArgs.clock_out)
 };
 
 struct EdgeEmbedArgs {
@@ -131,6 +132,7 @@ struct ET2Args {
   const void* a1_img;   // [ceil(B*N/8)][16][32][8] bf16: A1 | Af rows of 8 consecutive (flattened) residue rows
   const void* b1_img;   // [B][N/4][16][32][8] bf16: B1 | Bf rows (e_j columns) of 4 consecutive j (+ the next sample's)
   int reserve_cus = 0;  // persistent kernels: CUs left to launches of other streams (FdiptForwardArgs.reserve_cus)
+  unsigned long long* clock = nullptr;  // optional shader-clock probe (FdiptForwardArgs.clock_out)
 };
 // edge_transition3.hip: 16-pair waves, two waves per SIMD (any N >= 43)
 int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
@@ -325,7 +327,5 @@ int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int l
                  const float* res_mask, double* score, hipStream_t st);
 int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,
                    float max_b, float cs, const float* res_mask, float* score, hipStream_t st);
-int fd_et4_clock(unsigned long long* out3, int reset);   // edge_transition4.hip / pair_mlp.hip: in-kernel shader-clock probes
-int fd_etf_clock(unsigned long long* out3, int reset);
 int fd_backbone(int n, const float* t7, const float* rot, const float* trans, int ld_trans, const float* psi,
                 const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st);

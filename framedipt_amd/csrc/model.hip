@@ -1101,6 +1101,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         t2.a1_img = W + w.a1img; t2.b1_img = W + w.b1img;
         t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H; t2.reserve_cus = a->reserve_cus;
         bias_ready = emit_bias;
+        t2.clock = a->clock_out;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
         if (use_et4) RC(fd_edge_transition4(t2, st));
         else RC(fd_edge_transition3(t2, st));
@@ -1111,6 +1112,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       ta.w1 = WM(k.et1); ta.w2 = WM(k.et2); ta.wf = WM(k.etf); ta.b1 = P + k.et1.b; ta.b2 = P + k.et2.b; ta.bf = P + k.etf.b;
       ta.gamma = P + k.et_ln.g; ta.beta = P + k.et_ln.b; ta.res_mask = res_mask;
       ta.trace = tr_ptr;
+      ta.clock = a->clock_out;
       if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
       RC(fd_edge_transition(prec, cz, iv.cb, ta, st));
       if (a->ev_stop && a->ev_stop[b]) hipEventRecord((hipEvent_t)a->ev_stop[b], st);
@@ -1198,14 +1200,6 @@ int fdipt_edge_transition_fwd(const FdiptDims* d, const float* P, const void* de
   return forward_impl(d, P, derived, nullptr, &a, workspace, workspace_bytes, stream, op);
 }
 
-int fdipt_edge_transition_clock(unsigned long long* out3_host, int reset) {
-  if (!out3_host) return FDIPT_EINVAL;
-  unsigned long long h[3], f[3];
-  RC(fd_et4_clock(h, reset));
-  RC(fd_etf_clock(f, reset));
-  for (int k = 0; k < 3; ++k) out3_host[k] = h[k] + f[k];
-  return FDIPT_OK;
-}
 int fdipt_event_create(void** ev_host) {
   if (!ev_host) return FDIPT_EINVAL;
   hipEvent_t e;

@@ -365,7 +365,6 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
 // Persistent blocks (one per CU: 151 KB of LDS): a block walks row tiles blk, blk + gridDim.x, ...; the weight stream is cyclic
 // (84 tiles, a multiple of the ring's 3 slots and of the 2 register roles), so the pipeline never drains between tiles, and the
 // next tile's X0 / pair masks are requested before the final layer and stored once it has read buf0 for the last time.
-__device__ unsigned long long etf_clk[3];  // shader-clock probe (common.hpp FD_CLK_*, fdipt_edge_transition_clock)
 template <class ZT>
 __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTransArgs a, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -516,7 +515,7 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
     }
     ETF_STAMP(4);
   }
-  FD_CLK_END(etf_clk);
+  FD_CLK_END(a.clock);
 #ifdef ETF_PROF
   if (tid == 0 && blockIdx.x < 256)
     for (int k = 0; k < 8; ++k) etf_prof[blockIdx.x * 8 + k] = ph[k];
@@ -790,15 +789,7 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
     }
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(tok) : "memory");  // the last touches land before the register is released
   }
-  FD_CLK_END(etf_clk);
-}
-int fd_etf_clock(unsigned long long* out3, int reset) {
-  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(etf_clk), 24) != hipSuccess) return FDIPT_ELAUNCH;
-  if (reset) {
-    const unsigned long long z[3] = {0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(etf_clk), z, 24) != hipSuccess) return FDIPT_ELAUNCH;
-  }
-  return FDIPT_OK;
+  FD_CLK_END(a.clock);
 }
 
 template <class P, class WT, class ZT, int TM, int WR, int WC, int CZ>

@@ -76,6 +76,7 @@ class BatchState:
             self.trace_edge = torch.zeros(d.num_blocks, B, N, N, d.c_z, **f32)
         self.trace_inner = (torch.zeros(d.num_blocks, 4, B, N, d.c_s + d.c_skip, **f32) if trace_inner else None)
         self.ev_start = self.ev_stop = None  # optional hipEvent pairs around the EdgeTransition launches (bench.py)
+        self.clock_out = None  # optional int64[3] device tensor: shader-clock probe of the EdgeTransition kernels (FdiptForwardArgs.clock_out)
         self.reserve_cus = 0  # CUs the persistent pair kernels leave to concurrent sub-batch streams (inference.StreamedLoops)
         self.t_emb_eps = torch.as_tensor(embedding.get_timestep_embedding(np.array([1e-5], dtype=np.float32), E)[0],
                                          device=dev)
@@ -100,6 +101,7 @@ class BatchState:
         if self.ev_start is not None:
             a.ev_start, a.ev_stop = self.ev_start, self.ev_stop
         a.reserve_cus = self.reserve_cus
+        a.clock_out = _lib.ptr(self.clock_out)
         _lib.check(lib.fdipt_score_forward(C.byref(net.dims), _lib.ptr(net.params), _lib.ptr(net.derived),
                                            _lib.ptr(self.setup), C.byref(a), _lib.ptr(self.ws), self.ws_bytes,
                                            _lib.stream_ptr()), "score_forward")

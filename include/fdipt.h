@@ -146,6 +146,11 @@ typedef struct FdiptForwardArgs {
    * on all CUs but `reserve_cus` of them, so that the latency-bound node-path launches of another stream keep finding free
    * CUs while they run.  0 = use every CU (single stream). */
   int32_t reserve_cus;
+  /* optional profiling: device buffer of 3 x uint64 (caller-owned, zeroed by the caller).  Thread 0 of every EdgeTransition
+   * block adds its shader-clock cycles (s_memtime), its 100 MHz ticks (s_memrealtime) and 1 to [0], [1], [2]: the clock the
+   * kernel's blocks actually ran at = [0] / [1] / 10 GHz (bench.py: roofline.clock_ghz).  NULL (the default): the kernels
+   * execute no atomics and keep no state outside the caller's buffers. */
+  unsigned long long* clock_out;
 } FdiptForwardArgs;
 
 size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
@@ -288,13 +293,6 @@ int fdipt_event_create(void** ev_host);
 int fdipt_event_destroy(void* ev);
 int fdipt_event_record(void* ev, fdipt_stream_t s);
 int fdipt_event_elapsed_ms(void* start, void* stop, float* ms_host); /* synchronises on `stop` */
-
-/* Diagnostic for bench.py's roofline: the shader clock the EdgeTransition kernels (edge_transition4_flat_kernel in the half-precision
- * mode, edge_transition_f32ws_kernel in the fp32 mode) actually ran at.
- * out3_host = {core-clock cycles, 100 MHz ticks, blocks}, summed over the blocks of all launches since the last reset; cycles /
- * ticks / 10 = GHz.  The matrix peak the kernel can reach scales with this clock (power management lowers it under dense MFMA
- * load).  Synchronises the device. */
-int fdipt_edge_transition_clock(unsigned long long* out3_host, int reset);
 
 const char* fdipt_version(void);
 

@@ -146,23 +146,24 @@ def test_streamed_sub_batches_match_the_single_stream_trajectory():
 
 
 def test_edge_transition_clock_probe():
-    """fdipt_edge_transition_clock (bench.py's ``roofline.clock_ghz``): after a half-precision forward at N % 4 == 0 the probe has counted the
-    blocks of the num_blocks - 1 EdgeTransition launches and the cycle / tick ratio is a plausible shader clock; reset zeroes it."""
-    import ctypes as C
-    from framedipt_amd import _lib
-    lib = _lib.load()
-    net, st, args = _setup(100, 2, "fp16")
-    out = (C.c_ulonglong * 3)()
-    _lib.check(lib.fdipt_edge_transition_clock(out, 1))
-    st.forward(*args)
-    torch.cuda.synchronize()
-    _lib.check(lib.fdipt_edge_transition_clock(out, 1))
-    cycles, ticks, blocks = out[0], out[1], out[2]
-    n_launch = net.dims.num_blocks - 1
-    assert blocks > 0 and blocks % n_launch == 0 and blocks // n_launch <= 256
-    assert 0.3 < cycles / ticks / 10 < 2.6  # GHz (ticks are 10 ns)
-    _lib.check(lib.fdipt_edge_transition_clock(out, 0))
-    assert out[0] == out[1] == out[2] == 0
+    """FdiptForwardArgs.clock_out (bench.py's ``roofline.clock_ghz``): opt-in and caller-owned.  With the buffer set, a forward at
+    N % 4 == 0 counts the blocks of the num_blocks - 1 EdgeTransition launches and the cycle / tick ratio is a plausible shader
+    clock, in both precision modes; the outputs are bit-identical with and without the probe (no state outside the caller's buffers)."""
+    for prec in ("fp16", "fp32"):
+        net, st, args = _setup(100, 2, prec)
+        st.forward(*args)
+        torch.cuda.synchronize()
+        ref = {k: getattr(st, k).clone() for k in ("rigids", "psi", "rot_score", "trans_score")}
+        st.clock_out = torch.zeros(3, dtype=torch.int64, device="cuda")
+        st.forward(*args)
+        torch.cuda.synchronize()
+        cycles, ticks, blocks = (int(v) for v in st.clock_out.cpu())
+        st.clock_out = None
+        n_launch = net.dims.num_blocks - 1
+        assert blocks > 0 and blocks % n_launch == 0 and blocks // n_launch <= 256, (prec, blocks)
+        assert 0.3 < cycles / ticks / 10 < 2.6  # GHz (ticks are 10 ns)
+        for k, v in ref.items():
+            assert torch.equal(getattr(st, k), v), (prec, k)
 
 
 @pytest.mark.parametrize("n,b", [(12, 3), (44, 2), (132, 3), (260, 2)])

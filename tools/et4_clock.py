@@ -15,12 +15,11 @@ net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
 ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": B}), d, "cuda")
 items = [sharding.seeded_item(ds, i, 3, d, T, 0.01) for i in range(B)]
 feats, tape = sharding.stack_items(items)
-lib = _lib.load()
-fn = lib.fdipt_edge_transition_clock
-out = (C.c_ulonglong * 3)()
 inference_fn(net, d, feats, num_t=10, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tuple(z[:10] for z in tape))
-torch.cuda.synchronize(); fn(out, 1)
+torch.cuda.synchronize()
+st = net.batch_state(feats["seq_idx"])
+st.clock_out = torch.zeros(3, dtype=torch.int64, device="cuda")  # FdiptForwardArgs.clock_out: opt-in, caller-owned
 inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
-torch.cuda.synchronize(); fn(out, 1)
-cyc, ticks, blocks = out[0], out[1], out[2]
+torch.cuda.synchronize()
+cyc, ticks, blocks = (int(v) for v in st.clock_out.cpu())
 print(f"N={N} B={B}: {blocks} blocks, {cyc / blocks:.0f} cycles and {ticks / blocks / 100:.1f} us per block -> {cyc / ticks / 10:.3f} GHz sustained in the kernel")
