@@ -33,7 +33,13 @@ __device__ __forceinline__ hx8 a3_ld(const half_t* p) { return __builtin_bit_cas
 // NTW: key tiles per wave (N <= 128 NTW).  NTW = 3 (N <= 384): 234 registers -> launch bound 2 -> TWO blocks per CU hide each
 // other's memory latency, so the operands of a tile are simply fetched when needed (DB = false).  NTW = 4: one block per
 // CU with all 512 registers, next tile's operands / second V tile in flight under the current one (DB = true).
-template <int A3_NTW, int LB, bool DB>
+// SPLIT (Attn3Args.Vt_lo): P V on split operands — the attention weights P = hi + lo and V = hi + lo, each part one half-precision
+// value, V_hi P_hi + V_hi P_lo + V_lo P_hi with fp32 accumulation (the accuracy of an fp32 product; the rounding of P and V to half
+// precision is the largest error source of the half mode once the per-residue products are split: tests/err_budget.py at bb_gain
+// 0.3).  The P_lo fragments take the LDS of the Q fragments (dead after the logits) where those live in LDS, their own region
+// otherwise; the V_lo fragments of a d tile are fetched into the registers of its V_hi fragments once those are consumed.  The
+// value-point image already is hi / lo: it gets the P_lo term.
+template <int A3_NTW, int LB, bool DB, bool SPLIT>
 __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a.N, H = a.H, nt = (N + 31) / 32, Np = nt * 32;
@@ -42,6 +48,9 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   float* opr = sms + 128;                                    // [32 queries][96]: o_pt sums, high parts then low parts
   u16x8* Pfs = (u16x8*)(opr + 32 * 96);                      // [2*nt][64]
   u16x8* Qs = Pfs + 2 * nt * 64;                             // LB == 3: the Q fragments of the query tile [16][64] (16 KB)
+  // SPLIT: P_lo fragments [2*nt][64].  They overlay the Q fragments (and extend behind them: the launcher sizes the region as the
+  // larger of the two), which nobody reads after phase 1 — two block-wide barriers (softmax) lie between
+  u16x8* Pls = Qs;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   // XCD-aware block -> (sample, head, query tile): consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each),
@@ -220,8 +229,19 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
           }
         }
       }
-      Pfs[(2 * t) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(v));
-      Pfs[(2 * t + 1) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(v + 8));
+      const hx8 p0 = a3_pack8(v), p1 = a3_pack8(v + 8);
+      Pfs[(2 * t) * 64 + lane] = __builtin_bit_cast(u16x8, p0);
+      Pfs[(2 * t + 1) * 64 + lane] = __builtin_bit_cast(u16x8, p1);
+      if constexpr (SPLIT) {
+        float w[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          w[r] = v[r] - (float)p0[r];
+          w[8 + r] = v[8 + r] - (float)p1[r];
+        }
+        Pls[(2 * t) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(w));
+        Pls[(2 * t + 1) * 64 + lane] = __builtin_bit_cast(u16x8, a3_pack8(w + 8));
+      }
     }
   }
   FD_STAMP(4);
@@ -249,6 +269,12 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       for (int s = 0; s < KSM; ++s)
         if (s < ks) acc = fd_mfma32(Va[bf][s], __builtin_bit_cast(hx8, Pfs[s * 64 + lane]), acc);
     };
+    auto v_mma_add = [&](auto BUF, f32x16& acc, const u16x8* P) {  // acc += (fragments in buffer BUF) x (weight fragments P)
+      constexpr int bf = decltype(BUF)::value;
+#pragma unroll
+      for (int s = 0; s < KSM; ++s)
+        if (s < ks) acc = fd_mfma32(Va[bf][s], __builtin_bit_cast(hx8, P[s * 64 + lane]), acc);
+    };
     auto o_store = [&](const f32x16& acc, int dt) {
       if (valid && a.out_h16) {  // bf16 features: exactly what the output projection's bf16 GEMM would round them to
         half_t* orow = a.out_h16 + (rb + i) * a.out_ld + (long)h * A3_C + 32 * dt + 4 * hi;
@@ -267,7 +293,22 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       }
     };
     f32x16 acc;
-    if constexpr (DB) {
+    if constexpr (SPLIT) {
+      constexpr std::integral_constant<int, 0> B0{};
+      const half_t* vlo = a.Vt_lo;
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+        const long off = ((bh * (A3_C / 32) + 2 * wave + dd) * ks) * 512;
+        if (dd == 0) v_load(B0, a.Vt + off);   // (d tile 1's V_hi was requested under d tile 0's last products)
+        v_mma(B0, acc);                        // V_hi P_hi
+        v_mma_add(B0, acc, Pls);               // V_hi P_lo
+        v_load(B0, vlo + off);
+        v_mma_add(B0, acc, Pfs);               // V_lo P_hi
+        if (dd == 0) v_load(B0, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
+        else if (wave < 3) v_load(B0, a.vpt + ((bh * 3 + wave) * ks) * 512);
+        o_store(acc, 2 * wave + dd);
+      }
+    } else if constexpr (DB) {
       v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave) * ks) * 512);
       v_load(std::integral_constant<int, 1>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
       v_mma(std::integral_constant<int, 0>{}, acc);
@@ -286,6 +327,8 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
     }
     if (wave < 3) {
       v_mma(std::integral_constant<int, 0>{}, acc);
+      if constexpr (SPLIT)
+        if (wave < 2) v_mma_add(std::integral_constant<int, 0>{}, acc, Pls);  // (tile 2 holds low parts only: P_lo v_lo is below fp32 resolution)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // D rows 32 wave + 8g + 4hi + q of query li
         f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
@@ -325,31 +368,40 @@ int fd_attention3_supported(const Attn3Args& a) {
   return a.N >= 1 && a.N <= A3_NTW_MAX * 4 * 32 && a.H <= 8 && a.Np == ((a.N + 31) / 32) * 32 && a.vpt != nullptr;
 }
 
-int fd_attention3(const Attn3Args& a, hipStream_t st) {
-  const int nt = (a.N + 31) / 32, Np = nt * 32;
-  const size_t smem = 2 * 128 * 4 + (size_t)32 * 96 * 4 + (size_t)2 * nt * 64 * 16 + 16;  // 1 KB + 12 KB + 64 B per key: 77 KB at N = 1024
-  (void)Np;
-  if (!fd_attention3_supported(a)) return FDIPT_ESIZE;
-  static bool attr_set = false;
-  if (!attr_set) {  // N > 800: more than the default 64 KB of dynamic LDS
-    if (hipFuncSetAttribute((const void*)ipa_attn3_kernel<6, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)ipa_attn3_kernel<6, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)ipa_attn3_kernel<8, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+template <int NTW, int LB, bool DB>
+static int a3_launch(const Attn3Args& a, dim3 grid, size_t smem, hipStream_t st) {
+  // (the attribute is per device: set on every launch rather than cached per process)
+  if (a.Vt_lo) {
+    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)ipa_attn3_kernel<NTW, LB, DB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    hipLaunchKernelGGL((ipa_attn3_kernel<NTW, LB, DB, true>), grid, dim3(FD_THREADS), smem, st, a);
+  } else {
+    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)ipa_attn3_kernel<NTW, LB, DB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    hipLaunchKernelGGL((ipa_attn3_kernel<NTW, LB, DB, false>), grid, dim3(FD_THREADS), smem, st, a);
   }
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+int fd_attention3(const Attn3Args& a, hipStream_t st) {
+  const int nt = (a.N + 31) / 32;
+  if (!fd_attention3_supported(a)) return FDIPT_ESIZE;
+  // reduction buffers 1 KB + o_pt tile 12 KB + P fragments 64 B per key, then ONE region for the Q fragments (16 KB, the variants
+  // that keep them in LDS) and / or the P_lo fragments (64 B per key, split P V): they are never live together
+  const size_t pf = (size_t)2 * nt * 64 * 16, base = 2 * 128 * 4 + (size_t)32 * 96 * 4 + pf + 16;
+  const size_t plo = a.Vt_lo ? pf : 0;
+  auto with = [&](bool qlds) { const size_t q = qlds ? 16384 : 0; return base + (q > plo ? q : plo); };
   const int per = (a.B * a.H + 7) / 8;  // see the block mapping in the kernel
-  const dim3 grid(8 * per * nt), block(FD_THREADS);
-  if (a.N <= 3 * 4 * 32 && !FD_DEV_ENV("FDIPT_A3_LB2")) hipLaunchKernelGGL((ipa_attn3_kernel<3, 3, false>), grid, block, smem + 16384, st, a);
-  else if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<3, 2, false>), grid, block, smem, st, a);
-  else if (a.N <= 4 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<4, 1, true>), grid, block, smem, st, a);
-  // 512 < N <= 1024 (TCR-pMHC complexes, long chains): 6 / 8 key tiles per wave, one block per CU, operands fetched per tile
+  const dim3 grid(8 * per * nt);
+  if (a.N <= 3 * 4 * 32 && !FD_DEV_ENV("FDIPT_A3_LB2")) return a3_launch<3, 3, false>(a, grid, with(true), st);
+  if (a.N <= 3 * 4 * 32) return a3_launch<3, 2, false>(a, grid, with(false), st);
+  if (a.N <= 4 * 4 * 32) return a3_launch<4, 1, true>(a, grid, with(false), st);
+  // 512 < N <= 1024 (TCR-pMHC complexes, long chains): 6 / 8 key tiles per wave, operands fetched per tile
 #ifndef A3_MID2
 #define A3_MID2 1
 #endif
-  else if (a.N <= 6 * 4 * 32 && A3_MID2) hipLaunchKernelGGL((ipa_attn3_kernel<6, 2, false>), grid, block, smem + 16384, st, a);
-  else if (a.N <= 6 * 4 * 32) hipLaunchKernelGGL((ipa_attn3_kernel<6, 1, false>), grid, block, smem, st, a);
-  else hipLaunchKernelGGL((ipa_attn3_kernel<8, 1, false>), grid, block, smem, st, a);
-  FD_CHECK_LAUNCH();
-  return FDIPT_OK;
+  if (a.N <= 6 * 4 * 32 && A3_MID2) return a3_launch<6, 2, false>(a, grid, with(true), st);
+  if (a.N <= 6 * 4 * 32) return a3_launch<6, 1, false>(a, grid, with(false), st);
+  return a3_launch<8, 1, false>(a, grid, with(false), st);
 }

@@ -96,6 +96,7 @@ __global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float*
     const u16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     half_t* Kb = (half_t*)x.Kb;
     half_t* Vt = (half_t*)x.Vt;
+    half_t* Vt2 = (half_t*)x.Vt2;
     for (long i = gtid; i < n; i += gsz) {
       const int g = (int)(i % cg);
       const long r2 = i / cg;
@@ -103,8 +104,11 @@ __global__ void seq_images_init_kernel(int B, int N, int Np, int H, const float*
       const long bh = r2 / pad;
       *(u16x8*)(Kb + ((((bh * ntl + (key >> 5)) * (x.C >> 4) + (g >> 1)) * 64 + (g & 1) * 32 + (key & 31)) << 3)) = z8;
       const int p16 = key & 15, pp = (key & ~15) + 4 * (p16 >> 3) + (p16 & 3) + 8 * ((p16 & 7) >> 2);
-      for (int c = 8 * g; c < 8 * g + 8; ++c)
-        Vt[((((bh * (x.C >> 5) + (c >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (c & 31)) << 3) + (pp & 7)] = 0;
+      for (int c = 8 * g; c < 8 * g + 8; ++c) {
+        const long o = ((((bh * (x.C >> 5) + (c >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (c & 31)) << 3) + (pp & 7);
+        Vt[o] = 0;
+        if (Vt2) Vt2[o] = 0;
+      }
     }
   }
   const int nt = Np >> 5;

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(FD_THREADS) void ipa_proj_kernel(ProjArgs a) {
 // zero the padded keys [N, Np) of Kb and Vt (P is exactly 0 there and the logits are masked, but the operands must not
 // be NaN/Inf).  One thread per (bh, padded key, 8-channel group).
 __global__ void kv_zero_pad_kernel(long BH, int N, int Np, int C, half_t* __restrict__ Kb, half_t* __restrict__ Vt,
-                                   uint4* __restrict__ extra, long extra_n16) {
+                                   half_t* __restrict__ Vt2, uint4* __restrict__ extra, long extra_n16) {
   // another once-per-forward zero fill riding on this launch (the value-point image of attention3: 16 B units)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < extra_n16; i += (long)gridDim.x * blockDim.x)
     extra[i] = make_uint4(0, 0, 0, 0);
@@ -300,8 +300,11 @@ __global__ void kv_zero_pad_kernel(long BH, int N, int Np, int C, half_t* __rest
     *(u16x8*)(Kb + ((((bh * ntl + (key >> 5)) * (C >> 4) + (g >> 1)) * 64 + (g & 1) * 32 + (key & 31)) << 3)) = z8;
     // Vt: this key in channels 8g .. 8g+7
     const int pp = (key & ~15) + g_perm16(key & 15);
-    for (int c = 8 * g; c < 8 * g + 8; ++c)
-      Vt[((((bh * (C >> 5) + (c >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (c & 31)) << 3) + (pp & 7)] = 0;
+    for (int c = 8 * g; c < 8 * g + 8; ++c) {
+      const long o = ((((bh * (C >> 5) + (c >> 5)) * (2 * ntl) + (pp >> 4)) * 64 + ((pp >> 3) & 1) * 32 + (c & 31)) << 3) + (pp & 7);
+      Vt[o] = 0;
+      if (Vt2) Vt2[o] = 0;
+    }
   }
 }
 
@@ -309,7 +312,7 @@ __global__ void kv_zero_pad_kernel(long BH, int N, int Np, int C, half_t* __rest
 int fd_ipa_proj_zero_pads(const ProjArgs& a, void* extra, size_t extra_bytes, hipStream_t st) {
   if (extra_bytes & 15) return FDIPT_EINVAL;
   if (a.Np > a.N || extra_bytes)
-    hipLaunchKernelGGL(kv_zero_pad_kernel, dim3(512), dim3(256), 0, st, (long)a.B * a.H, a.N, a.Np, a.C, a.Kb, a.Vt, (uint4*)extra,
+    hipLaunchKernelGGL(kv_zero_pad_kernel, dim3(512), dim3(256), 0, st, (long)a.B * a.H, a.N, a.Np, a.C, a.Kb, a.Vt, a.Vt_lo, (uint4*)extra,
                        (long)(extra_bytes >> 4));
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
@@ -319,7 +322,7 @@ int fd_ipa_proj(const ProjArgs& a, hipStream_t st) {
   if ((a.K & 7) || (a.lda & 3)) return FDIPT_EINVAL;
   if ((a.Np & 31) || (a.C & 31)) return FDIPT_EINVAL;
   if (a.Np > a.N && a.zero_pads)  // the pads are never written by the epilogue: once per forward is enough
-    hipLaunchKernelGGL(kv_zero_pad_kernel, dim3(256), dim3(256), 0, st, (long)a.B * a.H, a.N, a.Np, a.C, a.Kb, a.Vt, (uint4*)nullptr, 0L);
+    hipLaunchKernelGGL(kv_zero_pad_kernel, dim3(256), dim3(256), 0, st, (long)a.B * a.H, a.N, a.Np, a.C, a.Kb, a.Vt, (half_t*)nullptr, (uint4*)nullptr, 0L);
   hipLaunchKernelGGL(ipa_proj_kernel, dim3(cdiv(M, 128), cdiv(NOUT, 128)), dim3(FD_THREADS), 0, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -151,6 +151,13 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
         if (v_row[i][g] < 0) return;
         const p2_u32x2 o = {fd_cvt_pk(v[0], v[1]), fd_cvt_pk(v[2], v[3])};
         *(p2_u32x2*)(a.Vt + (long)v_row[i][g] + cpart[j]) = o;
+        if (SPLIT && a.Vt_lo) {  // V - half(V): the attention multiplies P with V_hi + V_lo (attention4.hip)
+          float w[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] = v[q] - h2f(f2h(v[q]));
+          const p2_u32x2 ol = {fd_cvt_pk(w[0], w[1]), fd_cvt_pk(w[2], w[3])};
+          *(p2_u32x2*)(a.Vt_lo + (long)v_row[i][g] + cpart[j]) = ol;
+        }
       } else {
         if (p_row[i][g] < 0) return;
         float* dst = a.pts + (long)p_row[i][g] + cpart[j];

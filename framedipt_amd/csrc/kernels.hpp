@@ -164,11 +164,12 @@ struct ProjArgs {
   const float* bias;          // [3*H*C + PT]
   float qscale;               // sqrt(1/(3C)) folded into Q
   half_t *Qb, *Kb, *Vt;
+  half_t* Vt_lo = nullptr;    // optional (split operands): V - half(V) in the layout of Vt (the attention's P V on split operands)
   float* pts;                 // [B*N, PT]
   int zero_pads;              // also zero the padded keys [N, Np) of Kb / Vt (first use of the buffers in a forward)
 };
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
-int fd_ipa_proj_zero_pads(const ProjArgs& a, void* extra, size_t extra_bytes, hipStream_t st);
+int fd_ipa_proj_zero_pads(const ProjArgs& a, void* extra, size_t extra_bytes, hipStream_t st);  // (Kb, Vt and Vt_lo when set)
 int fd_ipa_proj2_supported(const ProjArgs& a);
 // after the fragment image of the fused projection weight is built: permute the rows of its Q / K tiles (16 B epilogue stores)
 int fd_ipa_proj2_permute_image(void* img, int H, int C, int K, hipStream_t st);
@@ -177,6 +178,7 @@ int fd_ipa_proj2(const ProjArgs& a, hipStream_t st);  // second generation (ipa_
 struct Attn3Args {
   int B, N, H, Np;
   const half_t *Qb, *Kb, *Vt;     // operand images written by ipa_proj_kernel
+  const half_t* Vt_lo = nullptr;  // optional: V - half(V), same layout: P V (and the value-point sums) on split operands, P = hi + lo too
   const float* bias;              // pre-scaled pair bias in fd_bias_frag_off order (B*H*Np*Np floats)
   const float* res_mask;          // [B,N]
   const float *qp, *kp, *vp;      // [B,N,H,8,3], [B,N,H,8,3], [B,N,H,12,3] global-frame points (scaled units)
@@ -193,6 +195,7 @@ struct Attn3Args {
 int fd_attention3_supported(const Attn3Args& a);
 int fd_attention3(const Attn3Args& a, hipStream_t st);
 
+
 // sequence-transformer self-attention (attention_seq.hip): bf16, head_dim 80, N <= 512
 size_t fd_seq_attention_image_bytes(int B, int N, int H);
 int fd_seq_attention_supported(int N, int H, int hd);
@@ -203,6 +206,7 @@ int fd_seq_attention(int B, int N, int H, const float* qkv, int ld, float scale,
 struct SeqInitExtra {  // once-per-forward fills folded into the sequence-image init launch (all optional)
   void* fill; long fill_n16;       // zero fill, 16 B units
   void* Kb; void* Vt; long BH; int C;  // padded keys of attention3's key / value images (N, Np as the sequence images: Np = ceil32(N))
+  void* Vt2 = nullptr;                 // optional second value image (V_lo) with the same pads
 };
 int fd_seq_images_init(int B, int N, int H, const float* res_mask, void* images, const SeqInitExtra& x, hipStream_t st);
 int fd_seq_qkv_supported(int N, int H, int d_model);

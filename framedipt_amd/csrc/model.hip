@@ -507,7 +507,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, skip_all, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, skip_all, vt_lo, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -536,6 +536,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   {
     const size_t Np = ((size_t)N + 31) / 32 * 32, HC = (size_t)H * d->c_hidden;
     w.qb = take((size_t)B * HC * Np * 2); w.kb = take((size_t)B * HC * Np * 2); w.vt = take((size_t)B * HC * Np * 2);  // fragment-order images
+    w.vt_lo = take((size_t)B * HC * Np * 2);  // V - half(V) (split P V)
     w.pts = take(R * (size_t)(iv.proj_out - 3 * HC) * 4);
   }
   w.seqimg = take(fd_seq_attention_image_bytes(B, N, d->tfmr_heads));
@@ -561,9 +562,9 @@ size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N) {
   if (getenv("FDIPT_DUMP_LAYOUT")) {  // (dev) workspace layout for buffer-level diffs (tools/conc_victim_check.py)
     const char* names[] = {"node_feat", "pte", "pi", "pj", "h_a", "h_b", "node0", "node", "z", "quat", "trans", "dmask", "rot", "proj", "qp", "kp", "vp",
                            "bias", "probs", "feats", "ipa_out", "tf_in", "qkv", "att", "x_a", "x_b", "ff", "e", "upd", "psi_un", "a1", "af", "qb", "kb",
-                           "vt", "pts", "seqimg", "ipa_parts", "e_bf", "vpt", "r4", "a1img", "b1img", "skip_all", "total"};
+                           "vt", "pts", "seqimg", "ipa_parts", "e_bf", "vpt", "r4", "a1img", "b1img", "skip_all", "vt_lo", "total"};
     const size_t* offs = &w.node_feat;
-    for (int i = 0; i < 45; ++i) fprintf(stderr, "FDIPT_LAYOUT %s %zu\n", names[i], offs[i]);
+    for (int i = 0; i < 46; ++i) fprintf(stderr, "FDIPT_LAYOUT %s %zu\n", names[i], offs[i]);
   }
 #endif
   return w.total;
@@ -789,7 +790,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     auto trunk = [&]() -> int {
     Attn3Args a3;
     a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const half_t*)(W + w.qb); a3.Kb = (const half_t*)(W + w.kb);
-    a3.Vt = (const half_t*)(W + w.vt); a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
+    a3.Vt = (const half_t*)(W + w.vt); a3.Vt_lo = nullptr; a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
     a3.vp = F(w.vp); a3.vpt = (const half_t*)(W + w.vpt); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
     a3.probs = F(w.probs); a3.probs_h16 = nullptr; a3.out_h16 = nullptr; a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
     OPairArgs oa;
@@ -814,12 +815,14 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       pj.zero_pads = b == 0 || op.kind != OP_ALL;  // (per-op entry: the workspace is the caller's, pads unknown)
       pj.W_img = (cs == 256 && !sw.proj_v1) ? D + db.wproj_img : nullptr;
       pj.W_img_lo = (pj.W_img && split_proj) ? D + db.wproj_img_lo : nullptr;
+      // P V on split operands needs V_lo, which only the split second-generation projection writes
+      if (pj.W_img_lo && split_pv && fd_ipa_proj2_supported(pj)) { pj.Vt_lo = (half_t*)(W + w.vt_lo); a3.Vt_lo = pj.Vt_lo; }
       // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
       if (fd_ipa_proj2_supported(pj)) {
         if (pj.zero_pads && seq_fused && !seq_img_ready && (C & 31) == 0 && (vpt_bytes & 15) == 0 && !sw.init_unfused) {
           // every once-per-forward fill of the trunk in one launch: sequence-attention images, value-point image, key pads
           SeqInitExtra sx = {vpt_zero ? W + w.vpt : nullptr, vpt_zero ? (long)(vpt_bytes >> 4) : 0L, Np > N ? (void*)pj.Kb : nullptr,
-                             (void*)pj.Vt, (long)B * H, C};
+                             (void*)pj.Vt, (long)B * H, C, (void*)pj.Vt_lo};
           RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, sx, st));
           seq_img_ready = true;
           vpt_zero = false;
