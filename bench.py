@@ -8,8 +8,8 @@
 Workloads (BASELINE.json configs, per GPU; weak scaling, samples sharded round-robin, no collective on the data path):
   c4 (default, the config the metric is quoted on): de novo, N = 300, 8 samples batched, T = 500, fp16 mode
   c2: de novo, N = 128, 8 samples, T = 500, fp16 mode
-  c3: TCR-pMHC-like inpainting, one synthetic 4-chain complex (200 + 240 + 9 + 275 = 724 residues, seq_idx gap 200, two
-      CDR3-like windows), 5 samples, T = 100, fp16 mode
+  c3: TCR-pMHC-like inpainting, 8 different synthetic 4-chain complexes of 700 - 850 residues (seq_idx gap 200, two CDR3-like
+      windows) in ONE padded batch, T = 100, fp16 mode; value counts the real residues only (c3e: 8 samples of one 776-residue complex)
   c5: long-chain inpainting, N = 1000 (2 chains), 4 samples, one diffused window of 50, T = 100, fp32 mode
 fp16 mode = fp16 MFMA operands / pair representation with split (hi + lo) operands on the node path: the mode whose per-step
 backbone RMSD against the reference is < 1e-3 A (tests/test_gpu_sizes.py::test_teacher_forced_fp16_meets_the_north_star_bound).
@@ -49,7 +49,14 @@ PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROA
 
 CONFIGS = {
     "c2": dict(n=128, b=8, t=500, prec="fp16", inpaint=False),
-    "c3": dict(n=724, b=5, t=100, prec="fp16", inpaint=True, chains=(200, 240, 9, 275), windows=((92, 106), (330, 345))),
+    # c3: a mixed-length batch as BASELINE configs[2] would feed it — 62 synthetic 4-chain complexes, N ~ U[700, 850], grouped by
+    # length into batches of 8 (framedipt_amd/sharding.py: batches_mixed); the bench times the MIDDLE batch (rank r: the r-th after
+    # it): 8 DIFFERENT complexes, one sample each, padded to the longest with res_mask = 0 rows (stack_items_padded);
+    # c3w: the worst case, 8 complexes spanning the whole length range in one batch;
+    # c3e: the same number of samples of ONE complex of the mean length (the equal-N reference for the padding overhead)
+    "c3": dict(n=None, b=8, t=100, prec="fp16", inpaint=True, mixed=(700, 850, 62), windows=((92, 106), (330, 345))),
+    "c3w": dict(n=None, b=8, t=100, prec="fp16", inpaint=True, mixed=(700, 850, 0), windows=((92, 106), (330, 345))),
+    "c3e": dict(n=776, b=8, t=100, prec="fp16", inpaint=True, chains=(214, 258, 9, 295), windows=((92, 106), (330, 345))),
     "c4": dict(n=300, b=8, t=500, prec="fp16", inpaint=False),
     "c5": dict(n=1000, b=4, t=100, prec="fp32", inpaint=True, chains=(500, 500), windows=((40, 90),)),
 }
@@ -154,7 +161,8 @@ def main():
         if cfg["inpaint"]:
             raise SystemExit("--n-res applies to the de novo configs")
         cfg["n"] = a.n_res
-    N, B = cfg["n"], a.samples_per_gpu or cfg["b"]
+    B = a.samples_per_gpu or cfg["b"]
+    N = cfg["n"]  # (mixed-length workload: set to the padded length below)
     T, prec = a.num_t or cfg["t"], a.precision or cfg["prec"]
     K = a.steps if a.steps is not None else T
     if K > T or K < 1:
@@ -190,16 +198,47 @@ def main():
     diff = SE3Diffuser(conf.diffuser, device=dev)
     net = ScoreNetwork(conf.model, diff, inpainting=inp, precision=prec, kernel_flags=a.kernel_flags).load_synthetic(7).to(dev)
     n_total = B * world
-    if inp:
+    mixed = cfg.get("mixed")
+    if mixed:
+        # n_total different complexes: total length ~ U[lo, hi] (fixed seed), chains in the proportions 200 : 240 : 9 : 275
+        rng = np.random.default_rng(2024)
+        if mixed[2]:  # the lengths of the whole set, bucketed as run_sharded would; this job's ranks take consecutive middle buckets
+            pool = [int(v) for v in rng.integers(mixed[0], mixed[1] + 1, size=mixed[2])]
+            buckets = [g for g in sharding.batches_mixed(pool, B) if len(g) == B]
+            picks = [pool[p] for r in range(world) for p in buckets[(len(buckets) // 2 + r) % len(buckets)]]
+        else:
+            picks = [int(v) for v in rng.integers(mixed[0], mixed[1] + 1, size=n_total)]
+        structs = []
+        for k in range(n_total):
+            n_k = picks[k]
+            c = [int(round(n_k * f)) for f in (200 / 724, 240 / 724)] + [9]
+            c.append(n_k - sum(c))
+            structs.append((f"synthetic{k}", synthetic_complex(tuple(c), cfg["windows"], seed=k)))
+        ds = ConditionalSampler.from_features(structs, diff, dev, samples=1)
+    elif inp:
         ds = ConditionalSampler.from_features([("synthetic", synthetic_complex(cfg["chains"], cfg["windows"]))], diff, dev,
                                               samples=n_total)
     else:
         ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1,
                                                   "samples_per_length": n_total}), diff, dev)
     # independent samples: global sample index -> rank (round-robin), per-sample stream seed + index
-    mine = sharding.shard_indices(n_total, rank, world)
+    mine = list(range(rank * B, (rank + 1) * B)) if mixed else sharding.shard_indices(n_total, rank, world)  # (mixed: a bucket per rank)
     items = [sharding.seeded_item(ds, i, a.seed, diff, T, 0.01) for i in mine]
-    feats, tape = sharding.stack_items(items)
+    if mixed:
+        feats, tape, lengths = sharding.stack_items_padded(items)
+        N = int(feats["rigids_t"].shape[1])
+    else:
+        feats, tape = sharding.stack_items(items)
+        lengths = [N] * B
+    # real residues of all ranks' batches (the padded rows are not counted) and their reference-formulation FLOPs per forward
+    if world > 1:
+        all_len = [None] * world
+        dist.all_gather_object(all_len, lengths)
+        all_len = [n for part in all_len for n in part]
+    else:
+        all_len = lengths
+    res_per_step = int(sum(all_len))
+    fwd_flops_per_step = float(sum(flops_per_forward(n, inp) for n in all_len))
 
     nb = conf.model.ipa.num_blocks
     n_ev = nb - 1
@@ -283,14 +322,14 @@ def main():
 
     def record(prec, K, el, et_ms, clk, B_ev, kernel_flags):
         """value / ms_per_step / roofline of one timed region."""
-        res_steps = B * N * K * world
+        res_steps = res_per_step * K
         value = res_steps / el
         et = float(np.mean(et_ms)) * 1e-3
         et_flops = ET_FLOPS_PER_PAIR * B_ev * N * N
         peak = PEAK_TFLOPS[prec]
         achieved = et_flops / et / 1e12
         fwd_per_step = (T + 1) / T if K == T else 1.0
-        fwd_tflops = value / world * (flops_per_forward(N, inp) / N) * fwd_per_step / 1e12  # whole-forward view, per GPU
+        fwd_tflops = fwd_flops_per_step * K / el / world * fwd_per_step / 1e12  # whole-forward view, per GPU (real residues only)
         et4 = prec == "fp16" and N % 4 == 0 and not (kernel_flags & 1)  # (FDIPT_KF_ET3 forces the fallback kernel)
         ghz = clk[0] / clk[1] / 10 if clk[1] else None
         return value, {
@@ -333,7 +372,9 @@ def main():
             "metric": "residue*diffusion-steps/sec", "value": value, "unit": "residue*step/s", "n_gpus": world,
             "steps": K, "warmup": a.warmup, "ms_per_step": el / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
-            "config": {"workload": f"{a.config}: {'inpainting' if inp else 'de novo'} backbone sampler, N={N}, {B} samples/GPU "
+            "config": {"workload": f"{a.config}: {'inpainting' if inp else 'de novo'} backbone sampler, "
+                                   + (f"{B} different complexes/GPU of N={min(all_len)}..{max(all_len)} (mean {np.mean(all_len):.0f}) padded to {N}, "
+                                      if mixed else f"N={N}, {B} samples/GPU ") +
                                    f"batched, {'whole trajectory (priming forward + all steps)' if K == T else f'{K} steps spread over the schedule'}"
                                    f" of T={T}, aux_traj=True, noise_scale 0.1, 17.4M-param synthetic weights, per-sample seeds",
                        "n_res": N, "samples_per_gpu": B, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective" + (f", {a.streams} sub-batch streams per GPU" if a.streams > 1 else ""),
@@ -343,7 +384,7 @@ def main():
         if one_gpu:
             out["one_gpu_test_hook"] = True  # all ranks shared GPU 0 (tests): NOT a multi-GPU measurement
         if d2h is not None:
-            out["results_d2h"] = {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": B * N * K * world / (el + d2h)}
+            out["results_d2h"] = {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": res_per_step * K / (el + d2h)}
         if ref_rec is not None:
             out["reference_precision"] = ref_rec
         if world == 1 and not a.no_cpu_baseline:

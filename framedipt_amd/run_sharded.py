@@ -20,21 +20,28 @@ import numpy as np
 
 
 def run_rank(dataset, diffuser, run_batch, rank: int, world: int, out_dir: str, seed: int, num_t: int, min_t: float,
-             max_batch: int = 8, keep=("prot_traj",), final_only: bool = True):
+             max_batch: int = 8, keep=("prot_traj",), final_only: bool = True, mixed: bool = True):
     """Run this rank's share of ``dataset``.  ``run_batch(feats, tape) -> dict of arrays with a batch axis at dim 1`` (the
-    keys of ``inference_fn``).  Returns the list of records written by this rank."""
+    keys of ``inference_fn``).  ``mixed``: samples of similar (not only equal) length share a batch, padded with res_mask = 0
+    rows (sharding.batches_mixed / stack_items_padded); results are cut back to each sample's own length.
+    Returns the list of records written by this rank."""
     from . import sharding
     os.makedirs(out_dir, exist_ok=True)
     mine = sharding.shard_indices(len(dataset), rank, world)
     items = [sharding.seeded_item(dataset, i, seed, diffuser, num_t, min_t) for i in mine]
     lengths = [int(it[2]["rigids_t"].shape[1]) for it in items]
     records = []
-    for group in sharding.batches_by_length(lengths, max_batch):
-        feats, tape = sharding.stack_items([items[p] for p in group])
+    groups = sharding.batches_mixed(lengths, max_batch) if mixed else sharding.batches_by_length(lengths, max_batch)
+    for group in groups:
+        if mixed:
+            feats, tape, _ = sharding.stack_items_padded([items[p] for p in group])
+        else:
+            feats, tape = sharding.stack_items([items[p] for p in group])
         res = run_batch(feats, tape)
         for b, p in enumerate(group):
             item, (name, sample_i) = mine[p], items[p][:2]
-            arrays = {k: (np.asarray(res[k])[0, b] if final_only else np.asarray(res[k])[:, b]) for k in keep}
+            n = lengths[p]  # (every per-residue output carries the residues on the axis behind the batch)
+            arrays = {k: (np.asarray(res[k])[0, b, :n] if final_only else np.asarray(res[k])[:, b, :n]) for k in keep}
             path = os.path.join(out_dir, f"sample_{item:06d}.npz")
             np.savez(path, item=item, name=str(name), sample_i=int(sample_i), **arrays)
             records.append({"item": int(item), "name": str(name), "sample_i": int(sample_i), "n_res": lengths[p],

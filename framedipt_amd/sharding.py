@@ -72,6 +72,67 @@ def stack_items(items):
     return feats, tape
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Mixed-length batches.  The reference pads feature dicts to a common length with zeros — res_mask = 0 on the padded rows —
+# and identity frames (framedipt/data/utils.py:311-339 pad_feats / pad_rigid); its inference entry point only ever sees
+# B = 1, so padding there is a no-op.  Here it is what lets DIFFERENT complexes (config 3: 62 TCR-pMHC complexes of 700 - 850
+# residues, all different) share a batch: every kernel treats res_mask = 0 rows as absent (masked keys get exactly zero attention
+# weight, masked pair rows are zero, the reverse step leaves them where they are and they add exactly 0 to the centre of mass),
+# so a sample's trajectory on its real residues does not depend on how far it was padded
+# (tests/test_gpu_round3.py::test_padded_sample_matches_its_unpadded_run).
+_PAD_ONE = ("rigids_t",)  # padded with identity frames (quaternion 1, 0, 0, 0; translation 0)
+
+
+def pad_item(feats: dict, tape, n_pad: int):
+    """One ``[1, N, ...]`` feature dict and its noise tape ``[n, 1, N, 3]`` padded to ``n_pad`` residues."""
+    import numpy as np
+    import torch
+    n = int(feats["rigids_t"].shape[1])
+    if n_pad < n:
+        raise ValueError(f"cannot pad {n} residues to {n_pad}")
+    if n_pad == n:
+        return feats, tape
+    out = {}
+    for k, v in feats.items():
+        if not torch.is_tensor(v) or v.dim() < 2 or v.shape[1] != n:
+            out[k] = v
+            continue
+        pad = torch.zeros((v.shape[0], n_pad - n) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+        if k in _PAD_ONE:
+            pad[..., 0] = 1
+        elif k == "seq_idx":  # any value works (the rows are masked); the last real index keeps the relative-position table small
+            pad += v[:, -1:]
+        out[k] = torch.cat([v, pad], dim=1)
+    tape = tuple(np.concatenate([z, np.zeros(z.shape[:2] + (n_pad - n, 3), dtype=z.dtype)], axis=2) for z in tape)
+    return out, tape
+
+
+def stack_items_padded(items, multiple: int = 4):
+    """Batch of samples of different lengths from ``seeded_item`` tuples, padded to the longest one rounded up to ``multiple``
+    (4: the fast EdgeTransition / projection kernels want N % 4 == 0).  Returns (feats, tape, lengths)."""
+    lengths = [int(it[2]["rigids_t"].shape[1]) for it in items]
+    n_pad = -(-max(lengths) // multiple) * multiple
+    padded = [pad_item(it[2], it[3], n_pad) for it in items]
+    feats, tape = stack_items([(None, None, f, t) for f, t in padded])
+    return feats, tape, lengths
+
+
+def batches_mixed(lengths, max_batch: int, max_waste: float = 0.15):
+    """Group local item positions into batches of at most ``max_batch`` samples of SIMILAR length: positions sorted by length,
+    a batch is closed when it is full or when padding its shortest member to its longest would waste more than ``max_waste`` of
+    the pair work (1 - (n_min / n_max)^2).  Equal lengths always share a batch."""
+    order = sorted(range(len(lengths)), key=lambda p: (lengths[p], p))
+    out, cur = [], []
+    for p in order:
+        if cur and (len(cur) == max_batch or 1.0 - (lengths[cur[0]] / lengths[p]) ** 2 > max_waste):
+            out.append(cur)
+            cur = []
+        cur.append(p)
+    if cur:
+        out.append(cur)
+    return out
+
+
 def batches_by_length(lengths, max_batch: int):
     """Group local item positions into batches of equal N (at most ``max_batch`` samples each), in item order."""
     out, cur = [], []

@@ -11,11 +11,12 @@ import torch
 from conftest import kabsch_free_rmsd, load_golden
 from test_gpu_parity import _feats, _net, dev
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+@gpu
 @pytest.mark.parametrize("prec,bound", [("fp32", 1e-4), ("fp16", 1e-3)])
 def test_inpainting_trajectory_with_inference_side_aatype(prec, bound):
     """inference.input_aatype=True with model.input_aatype=False (the reference's default inpainting configuration): the network
@@ -48,6 +49,7 @@ def test_inpainting_trajectory_with_inference_side_aatype(prec, bound):
     assert np.abs(res2["rigid_0_traj"][:, :, diffused] - res["rigid_0_traj"][:, :, diffused]).max() > 1e-2
 
 
+@gpu
 def test_batch_of_two_n300_against_the_reference_golden():
     """B = 2 at N = 300 (N % 8 = 4: the 8 x 4 patches of the EdgeTransition kernel straddle the two samples) against the
     reference golden directly: sample 0 is the golden's input, sample 1 a different x_t; outputs and stored pair rows of
@@ -83,6 +85,7 @@ def test_batch_of_two_n300_against_the_reference_golden():
     assert not torch.equal(two["rigids"][1], two["rigids"][0])
 
 
+@gpu
 def test_free_running_fp16_n128_tracks_the_oracle():
     """Free-running (every step feeds on its own output) fp16 sampling at N = 128, T = 20, full network, against the NumPy oracle
     on the same x_T / weights / noise tape: the per-step errors of the throughput mode do not compound at a benchmarked size."""
@@ -116,6 +119,7 @@ def test_free_running_fp16_n128_tracks_the_oracle():
     assert per_step[0] < 2e-3 and per_step.max() < 2e-3
 
 
+@gpu
 @pytest.mark.parametrize("name", ["full_denovo_n300_t02", "full_denovo_n300_t50"])
 def test_rot_score_fence_where_the_reference_series_is_unconditioned(name):
     """Where the float32 IGSO(3) series of the reference is unconditioned (f <= 1e-2: its own score is float32 round-off over the
@@ -156,3 +160,49 @@ def test_rot_score_fence_where_the_reference_series_is_unconditioned(name):
     bound = (np.abs(df64) + eps_df) / np.maximum(f64 + 1e-4 - eps_f, 1e-5)
     print(f"{name}: {uncond.mean():.0%} unconditioned residues; |score| max {norm.max():.3g}, fence max {bound.max():.3g}")
     assert (norm <= bound * 1.001 + 1e-12).all(), float((norm / bound).max())
+
+
+@gpu
+def test_padded_sample_matches_its_unpadded_run():
+    """Mixed-length batches (BASELINE configs[2]: 62 complexes of different length): a sample padded with res_mask = 0 rows and
+    identity frames (framedipt/data/utils.py:311-339 pad_feats / pad_rigid) next to a longer sample gives, on its real residues,
+    the trajectory of its own unpadded B = 1 run — masked keys get exactly zero attention weight, masked pair rows are zero, the
+    reverse step leaves the padded rows where they are and they add exactly 0 to the centre of mass.  fp32 and fp16 modes, N = 44
+    and N = 61 padded to 64 (N % 4 != 0 unpadded: another kernel selection than the padded batch — hence a tolerance, not bits)."""
+    from framedipt_amd import config, inference, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    conf = config.base_config()
+    T = 4
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": 44, "max_length": 64, "length_step": 1, "samples_per_length": 1}), d, "cuda")
+    pick = [0, 17, 20]  # lengths 44, 61, 64
+    items = [sharding.seeded_item(ds, i, 5, d, T, 0.01) for i in pick]
+    assert [int(it[2]["rigids_t"].shape[1]) for it in items] == [44, 61, 64]
+    feats, tape, lengths = sharding.stack_items_padded(items)
+    assert feats["rigids_t"].shape[:2] == (3, 64) and float(feats["res_mask"][0, 44:].abs().sum()) == 0
+    for prec, bound in (("fp32", 2e-5), ("fp16", 1e-3)):
+        net = ScoreNetwork(conf.model, d, precision=prec).load_synthetic(3).to("cuda")
+        both = inference.inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
+        for b, it in enumerate(items):
+            n = lengths[b]
+            one = inference.inference_fn(net, d, it[2], num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=it[3])
+            for k in ("prot_traj", "rigid_0_traj"):
+                worst = max(kabsch_free_rmsd(both[k][s, b:b + 1, :n], one[k][s]) for s in range(T))
+                assert worst < bound, (prec, n, k, worst)
+            print(f"{prec} N={n} padded to 64: worst step backbone RMSD vs its unpadded run {worst:.2e} A")
+        # same kernel selection (N = 64 both ways): the unpadded sample of the batch is bit-identical to its B = 1 run
+        one = inference.inference_fn(net, d, items[2][2], num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=items[2][3])
+        np.testing.assert_array_equal(both["prot_traj"][:, 2], one["prot_traj"][:, 0])
+
+
+def test_mixed_batches_group_similar_lengths():
+    from framedipt_amd import sharding
+    lengths = [700, 850, 702, 849, 775, 775, 775, 701, 848, 776]
+    groups = sharding.batches_mixed(lengths, max_batch=4, max_waste=0.05)
+    assert sorted(p for g in groups for p in g) == list(range(len(lengths)))
+    for g in groups:
+        ns = [lengths[p] for p in g]
+        assert len(g) <= 4 and 1 - (min(ns) / max(ns)) ** 2 <= 0.05
+    assert any(len(g) > 1 for g in groups)
