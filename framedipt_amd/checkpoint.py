@@ -54,6 +54,25 @@ def _stub_for(module: str, name: str):
     return _stub_classes[key]
 
 
+# Globals a FrameDiPT checkpoint may name besides the omegaconf classes: the tensor-rebuild helpers of torch.save, the containers
+# of a state dict / optimizer state, the enums / typing objects an omegaconf 2.x container pickles.  Everything else is refused:
+# unpickling executes the callables a pickle names, so an untrusted ``.pth`` must not get to choose them.
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "set"),
+    ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "str"), ("builtins", "bool"), ("builtins", "complex"),
+    ("builtins", "slice"), ("builtins", "object"), ("builtins", "getattr"), ("typing", "Any"), ("typing", "Union"), ("typing", "Optional"),
+    ("typing", "Dict"), ("typing", "List"), ("typing", "Tuple"), ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"), ("pathlib", "Path"),
+    ("enum", "Enum"), ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"), ("_codecs", "encode"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Size"), ("torch", "device"),
+    ("torch.serialization", "_get_layout"), ("torch.nn.parameter", "Parameter"),
+}
+_ALLOWED_PREFIX = (("torch", "Storage"), ("torch", "Tensor"))  # torch.FloatStorage ..., torch.FloatTensor ... (legacy type names)
+_TORCH_DTYPES = {"float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool", "float", "double",
+                 "half", "long", "int", "short"}
+
+
 class _ShimUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == "omegaconf" or module.startswith("omegaconf."):
@@ -61,7 +80,12 @@ class _ShimUnpickler(pickle.Unpickler):
                 return super().find_class(module, name)  # the real package, if present
             except (ImportError, AttributeError):
                 return _stub_for(module, name)
-        return super().find_class(module, name)
+        if module == "__builtin__":  # protocol-2 spelling of builtins
+            module = "builtins"
+        if (module, name) in _ALLOWED_GLOBALS or (module == "torch" and (name in _TORCH_DTYPES or name.endswith(("Storage", "Tensor")))):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint names the global {module}.{name}, which a FrameDiPT checkpoint has no use for: refused "
+                                     "(unpickling runs the callables a file names; see framedipt_amd/checkpoint.py:_ALLOWED_GLOBALS)")
 
 
 # torch.load(pickle_module=...) wants a module-like object with Unpickler / load / loads
@@ -129,8 +153,14 @@ def load_checkpoint(path, map_location="cpu"):
     extras: {"epoch", "step"} when present)."""
     import torch
     try:
+        # (weights_only=False: the omegaconf container is not a tensor; what may be constructed is restricted by _ShimUnpickler instead)
         ckpt = torch.load(path, map_location=map_location, pickle_module=_shim, weights_only=False)
-    except (pickle.UnpicklingError, RuntimeError, EOFError):  # plain pickle written with use_torch=False
+    except pickle.UnpicklingError as e:
+        if "refused" in str(e):
+            raise
+        with open(path, "rb") as f:  # plain pickle written with use_torch=False
+            ckpt = _ShimUnpickler(f).load()
+    except (RuntimeError, EOFError):  # plain pickle written with use_torch=False
         with open(path, "rb") as f:
             ckpt = _ShimUnpickler(f).load()
     if not isinstance(ckpt, dict) or "model" not in ckpt:
@@ -152,11 +182,14 @@ def merge(base: dict, over: dict) -> dict:
     return out
 
 
-def apply_checkpoint_conf(cfg, ckpt_conf: dict, seed=None):
+def apply_checkpoint_conf(cfg, ckpt_conf: dict, seed=None, conf_overrides: dict | None = None):
     """The configuration steps of ``Inference._load_ckpt`` (inference.py:133-148) on a ``framedipt_amd.config.Conf``: model <-
-    merge(model, ckpt.model); diffuser.r3 <- ckpt.diffuser.r3; both diffuser seeds <- the inference seed."""
+    merge(model, ckpt.model); diffuser.r3 <- ckpt.diffuser.r3; both diffuser seeds <- the inference seed.  ``conf_overrides``
+    (the caller's overrides, inference.py:117,146-147) is merged last and wins over the checkpoint's values."""
     from .config import to_conf
     cfg = to_conf(merge(dict(cfg), {"model": ckpt_conf.get("model", {})}))
+    if conf_overrides:
+        cfg = to_conf(merge(dict(cfg), conf_overrides))
     if "diffuser" in ckpt_conf and "r3" in ckpt_conf["diffuser"]:
         cfg.diffuser.r3 = to_conf(dict(ckpt_conf["diffuser"]["r3"]))
     m = cfg.model
@@ -172,13 +205,13 @@ def apply_checkpoint_conf(cfg, ckpt_conf: dict, seed=None):
     return cfg
 
 
-def load_model(weights_path, cfg=None, inpainting: bool = False, precision: str = "fp16", device="cuda"):
+def load_model(weights_path, cfg=None, inpainting: bool = False, precision: str = "fp16", device="cuda", conf_overrides=None):
     """``Inference._load_ckpt``: checkpoint -> (cfg, SE3Diffuser, ScoreNetwork on ``device``)."""
     from . import config
     from .diffusion import SE3Diffuser
     from .model import ScoreNetwork
     sd, ckpt_conf, _ = load_checkpoint(weights_path)
-    cfg = apply_checkpoint_conf(cfg if cfg is not None else config.base_config(inpainting), ckpt_conf or {})
+    cfg = apply_checkpoint_conf(cfg if cfg is not None else config.base_config(inpainting), ckpt_conf or {}, conf_overrides=conf_overrides)
     diffuser = SE3Diffuser(cfg.diffuser, device=device)
     model = ScoreNetwork(cfg.model, diffuser, inpainting=inpainting, precision=precision)
     model.load_state_dict(sd)

@@ -247,12 +247,13 @@ static int launch_attn(AttnArgs a, hipStream_t st) {
   if (a.N > 1024 || a.Pq * 3 > 24 || a.Pv > 16 || (a.C & 3) || (a.Dv & 3)) return FDIPT_ESIZE;
   const size_t smem = attn_smem<P>(a.N, IPA ? a.Pq : 0, &a.lds_s);
   if (smem > 160 * 1024) return FDIPT_ESIZE;
-  static bool attr_set = false;  // idempotent: raises the dynamic-LDS cap of this kernel instance once
-  if (!attr_set) {
+  static FdPerDevice attr_dev;  // idempotent: raises the dynamic-LDS cap of this kernel instance once
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)attn_kernel<P, IPA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
   hipLaunchKernelGGL((attn_kernel<P, IPA>), dim3(cdiv(a.N, 32), a.H, a.B), dim3(FD_THREADS), smem, st, a);
   FD_CHECK_LAUNCH();

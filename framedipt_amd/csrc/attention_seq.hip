@@ -482,10 +482,11 @@ int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, in
   const half_t* Vi = Ki + (size_t)B * H * Np * SA_KS * 16;
   const int per = (B * H + 7) / 8;
   const size_t smem = 2 * 128 * 4 + (size_t)2 * nt * 64 * 16;
-  static bool attr_set = false;
-  if (!attr_set) {  // N > 1000: more than the default 64 KB of dynamic LDS
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {  // N > 1000: more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute((const void*)seq_attn_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
   const dim3 grid(8 * per * nt), block(FD_THREADS);
   if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_kernel<3, 2>), grid, block, smem, st, B, N, Np, H, Qi, Ki, Vi, out, out_ld, wm);

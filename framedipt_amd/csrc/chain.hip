@@ -407,12 +407,13 @@ static int ch_launch(const ChainArgs& a, hipStream_t st) {
   using S = ChainShape<K0, NH1, NH2, NOUT, FLAGS, YS>;
   if (a.M <= 0 || (a.ld_in & 3) || (a.ld_out & 3) || (a.residual && (a.ld_res & 3)) || (NOUT & 3)) return FDIPT_EINVAL;
   if (S::LN && a.residual == a.out) return FDIPT_EINVAL;  // pre-norm rows are parked in `out`
-  static bool attr_set = false;
-  if (!attr_set) {
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)chain_kernel<K0, NH1, NH2, NOUT, FLAGS, YS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)S::SMEM) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
   hipLaunchKernelGGL((chain_kernel<K0, NH1, NH2, NOUT, FLAGS, YS>), dim3(cdiv(a.M, 128), YS), dim3(FD_THREADS), S::SMEM, st, a);
   FD_CHECK_LAUNCH();

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/fdipt.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -236,6 +238,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Launch-site state that belongs to a DEVICE, not to the process (the dynamic-LDS cap of a kernel, the CU count): one slot per
+// device id, filled on the first launch from that device — a process may drive several GPUs, and callers on different host threads
+// / streams may race here (relaxed atomics: setting an attribute twice is harmless).
+#define FD_MAX_DEVICES 64
+struct FdPerDevice {
+  std::atomic<int> v[FD_MAX_DEVICES];
+  int get(int dev) const { return dev >= 0 ? v[dev].load(std::memory_order_relaxed) : 0; }
+  void set(int dev, int x) { if (dev >= 0) v[dev].store(x, std::memory_order_relaxed); }
+};
+static inline int fd_device() {
+  int d = 0;
+  return hipGetDevice(&d) == hipSuccess && d >= 0 && d < FD_MAX_DEVICES ? d : -1;
+}
+// CU count of the current device (256 on MI355X), cached per device
+static inline int fd_cu_count() {
+  static FdPerDevice cache;
+  const int dev = fd_device();
+  int n = cache.get(dev);
+  if (!n) {
+    hipDeviceProp_t prop;
+    n = (dev >= 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache.set(dev, n);
+  }
+  return n;
+}
 
 // Optional in-kernel phase timestamps for the stand-alone harnesses under tools/micro (-DFD_PROF): thread 0 of every
 // block records s_memtime (shader cycles) at phase boundaries into fd_prof[block][16].  Never enabled in the library.

@@ -436,12 +436,13 @@ int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
   static const kern_t kerns[4] = {edge_embed2_kernel<false, false>, edge_embed2_kernel<false, true>, edge_embed2_kernel<true, false>,
                                   edge_embed2_kernel<true, true>};
   const int kid = 2 * dlds + (a.trace != nullptr);
-  static bool attr_set[4] = {false, false, false, false};
-  if (!attr_set[kid]) {
+  static FdPerDevice attr_dev[4];
+  const int dev_ = fd_device();
+  if (!attr_dev[kid].get(dev_)) {
     if (hipFuncSetAttribute((const void*)kerns[kid], hipFuncAttributeMaxDynamicSharedMemorySize,
                             EE2_LDS_BASE + (EE2_MAXB_LDS + 1) * ET2_CZ * 4) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set[kid] = true;
+    attr_dev[kid].set(dev_, 1);
   }
   // one work item = (sample, key tile of 32, range of rpw consecutive query rows); wpg items per group so that ~2048 waves are busy
   const int nt = cdiv(a.N, 32), n_groups = a.B * nt, n_waves = 256 * 8;

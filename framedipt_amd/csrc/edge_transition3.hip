@@ -430,19 +430,14 @@ int fd_edge_transition3(const ET2Args& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
   if (n_pairs >= (1L << 31) - 256 || !a.e_h16) return FDIPT_EINVAL;  // 32-bit pair indices in the kernel
   const int n_tiles = cdiv(n_pairs, 128);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)edge_transition3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E3_LDS) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDIPT_ELAUNCH;
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int n_cu = fd_cu_count();
   // persistent: one block per CU (minus the CUs left to concurrent streams, in whole XCD rounds of 8)
   const int cus = a.reserve_cus > 0 && a.reserve_cus < n_cu - 8 ? (n_cu - a.reserve_cus) & ~7 : n_cu;
   const int grid = n_tiles < cus ? n_tiles : cus;

@@ -935,23 +935,18 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   }
   const int n_wt = ((a.B * a.N + 7) / 8) * (a.N / 4);
   const int n_tiles = cdiv(n_wt, E4_WAVES);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)edge_transition4_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
       return FDIPT_ELAUNCH;
 #if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)
     if (hipFuncSetAttribute((const void*)edge_transition4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
       return FDIPT_ELAUNCH;
 #endif
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDIPT_ELAUNCH;
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int n_cu = fd_cu_count();
   // persistent: one block per CU (minus the CUs left to concurrent streams, in whole XCD rounds of 8)
   const int cus = a.reserve_cus > 0 && a.reserve_cus < n_cu - 8 ? (n_cu - a.reserve_cus) & ~7 : n_cu;
   const int slots = cus * (E4_LDS <= 81920 ? 2 : 1);

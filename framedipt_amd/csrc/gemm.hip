@@ -520,11 +520,12 @@ int fd_linear_splitk_split(int M, int N, int K, int nsplit, const float* A, int 
 #endif
   constexpr int BN = (FD_SPLITK_BN);
   constexpr size_t smem = (size_t)2 * (64 + BN) * (64 * PrecSplit::LDMUL + PrecSplit::PAD) * sizeof(half_t);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)linear_splitk_kernel<PrecSplit, float, float, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
   hipLaunchKernelGGL((linear_splitk_kernel<PrecSplit, float, float, BN>), dim3(cdiv(M, 64), cdiv(N, BN), nsplit), dim3(FD_THREADS), smem,
                      st, M, N, K, kslice, A, lda, W, ldw, bias, rowmask, parts, part_stride, ldo);

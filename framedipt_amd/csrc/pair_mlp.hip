@@ -888,14 +888,15 @@ static int launch_et(int precision, const EdgeTransArgs& a, hipStream_t st) {
 #ifndef ETF_SPEC
 #define ETF_SPEC 1  // 1: edge_transition_f32ws_kernel (8 waves: 4 multiply, 4 move), 0: the fused 4-wave kernel
 #endif
-      static bool attr_set = false;
-      if (!attr_set) {
+      static FdPerDevice attr_dev;
+      const int dev_ = fd_device();
+      if (!attr_dev.get(dev_)) {
         if (hipFuncSetAttribute((const void*)edge_transition_f32_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, ETF_LDS) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void*)edge_transition_f32ws_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, ETF_LDS) !=
                 hipSuccess)
           return FDIPT_ELAUNCH;
-        attr_set = true;
+        attr_dev.set(dev_, 1);
       }
       const int n_blocks = (int)cdiv(n_pairs, TM);
       if (ETF_SPEC)

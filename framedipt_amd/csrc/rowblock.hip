@@ -774,14 +774,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.ld & 3) || a.x == a.out) return FDIPT_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)tfmr_tail_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(0)) != hipSuccess ||
         hipFuncSetAttribute((const void*)tfmr_tail_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(0)) != hipSuccess ||
         hipFuncSetAttribute((const void*)tfmr_tail_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(1)) != hipSuccess ||
         hipFuncSetAttribute((const void*)tfmr_tail_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TL_SMEM(1)) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
   const bool split = a.wol != nullptr;  // split operands: every lo image must be there
   if (split && (!a.w1l || !a.w2l || (a.wp && !a.wpl))) return FDIPT_EINVAL;
@@ -800,12 +801,13 @@ static int rb_launch(const RowBlockArgs& a, hipStream_t st) {
   using S = RBShape<K0, N1, N2, NOUT, FLAGS>;
   if (a.M <= 0 || (a.ld_in & 3) || (a.residual && (a.ld_res & 3)) || (a.ld_out & 3) || (a.residual && a.residual == a.out && false))
     return FDIPT_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)rowblock_kernel<K0, N1, N2, NOUT, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)S::SMEM) != hipSuccess)
       return FDIPT_ELAUNCH;
-    attr_set = true;
+    attr_dev.set(dev_, 1);
   }
   hipLaunchKernelGGL((rowblock_kernel<K0, N1, N2, NOUT, FLAGS>), dim3(cdiv(a.M, 32)), dim3(FD_THREADS), S::SMEM, st, a);
   FD_CHECK_LAUNCH();

@@ -145,9 +145,23 @@ def atom37_to_torsion_angles(aatype, pos, mask):
     return sc, sc * mirror[..., None], tmask
 
 
+class _ArrayUnpickler(pickle.Unpickler):
+    """Processed-structure pickles hold NumPy arrays, scalars and plain containers: nothing else may be constructed (unpickling
+    runs the callables a file names)."""
+    _OK = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+           ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode"),
+           ("collections", "OrderedDict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"),
+           ("numpy._core.numeric", "_frombuffer"), ("numpy.core.numeric", "_frombuffer")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._OK:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"processed-structure pickle names the global {module}.{name}: refused")
+
+
 def read_pkl(path):
     with open(path, "rb") as f:
-        return pickle.load(f)
+        return _ArrayUnpickler(f).load()
 
 
 def process_csv_row(processed, process_monomer: bool = False, extract_single_chain: bool = False, rng=None, chain_max_len=None) -> dict:

@@ -181,6 +181,14 @@ class StreamedLoops:
         torch.cuda.synchronize(self.dev)  # set-up ran on the current stream
         self.st = self.loops[0].st
 
+    def __del__(self):
+        # the loops' buffers were allocated on the caller's stream and are used on the side streams: if the object is dropped
+        # early (an exception mid-trajectory) the caching allocator must not hand them out while side-stream kernels still run
+        try:
+            self.synchronize()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def _each(self, fn):
         # (no per-step ordering against the caller's stream: an event on the default stream orders every sub-batch stream behind
         #  all work enqueued before it, i.e. the sub-batches would run one after the other; set-up was synchronised once)

@@ -206,3 +206,33 @@ def test_mixed_batches_group_similar_lengths():
         ns = [lengths[p] for p in g]
         assert len(g) <= 4 and 1 - (min(ns) / max(ns)) ** 2 <= 0.05
     assert any(len(g) > 1 for g in groups)
+
+
+@gpu
+def test_run_sharded_torchrun_entry_two_ranks(tmp_path):
+    """framedipt_amd.run_sharded as the driver of a multi-GPU node would launch it (torch.distributed.run, one process per rank),
+    here with two ranks on this box's one GPU (FDIPT_ONE_GPU=1: gloo rendezvous, both on cuda:0): mixed lengths (24 .. 28, padded
+    batches), per-sample files + manifest, and every sample bit-identical to a single-rank run of the same command (the D2H copy of
+    a batch overlaps the next batch: the files are written from pinned buffers)."""
+    import json
+    import subprocess
+    root = ROOT
+    outs = {}
+    for world, port in ((2, "29641"), (1, "29642")):
+        out_dir = str(tmp_path / f"w{world}")
+        env = dict(os.environ, FDIPT_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", port, "-m", "framedipt_amd.run_sharded", "--out-dir", out_dir, "--min-length", "24", "--max-length", "28",
+               "--length-step", "2", "--samples-per-length", "2", "--num-t", "4", "--max-batch", "3", "--precision", "fp32"]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        with open(os.path.join(out_dir, "manifest.json")) as f:
+            man = json.load(f)
+        assert man["n_items"] == 6 and man["world_size"] == world and [s["item"] for s in man["samples"]] == list(range(6))
+        assert sorted({s["n_res"] for s in man["samples"]}) == [24, 26, 28]
+        if world == 2:
+            assert {s["rank"] for s in man["samples"]} == {0, 1}
+        outs[world] = {s["item"]: np.load(os.path.join(out_dir, s["file"]))["prot_traj"] for s in man["samples"]}
+    for item in range(6):
+        assert outs[1][item].shape == outs[2][item].shape and outs[1][item].shape[0] in (24, 26, 28)
+        np.testing.assert_array_equal(outs[1][item], outs[2][item], err_msg=f"item {item}")

@@ -398,3 +398,32 @@ def test_hot_kernels_have_no_three_dword_stores(tmp_path):
             if "_store_dwordx3" in line and cur and any(k in cur for k in kernels):
                 bad.append((cur.strip(), line.strip()))
         assert not bad, bad[:4]
+
+
+def test_checkpoint_loader_refuses_foreign_globals(tmp_path):
+    """A ``.pth`` is a pickle: the loader constructs omegaconf stand-ins, torch's tensor-rebuild helpers and plain containers,
+    and refuses every other global a file names (os.system and friends)."""
+    import pickle
+
+    import torch
+
+    from framedipt_amd import checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+
+    bad = tmp_path / "bad.pth"
+    torch.save({"model": {"w": torch.zeros(2)}, "conf": Evil()}, bad)
+    with pytest.raises(pickle.UnpicklingError, match="refused"):
+        checkpoint.load_checkpoint(bad)
+    good = tmp_path / "good.pth"
+    torch.save({"model": {"module.w": torch.arange(4.0).reshape(2, 2)}, "epoch": 3}, good)
+    sd, conf, extra = checkpoint.load_checkpoint(good)
+    assert list(sd) == ["w"] and sd["w"].dtype == np.float32 and conf is None and extra == {"epoch": 3}
+    # conf_overrides merge last (Inference._load_ckpt)
+    from framedipt_amd import config
+    cfg = checkpoint.apply_checkpoint_conf(config.base_config(), {"model": {"ipa": {"num_blocks": 2}}},
+                                           conf_overrides={"model": {"ipa": {"num_blocks": 3}}})
+    assert cfg.model.ipa.num_blocks == 3
