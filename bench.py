@@ -106,35 +106,49 @@ def synthetic_complex(chain_lens, windows, seed=0):
             "seq_idx": np.concatenate(seq_idx), "chain_idx": np.concatenate(chain_idx), "torsion_angles_sin_cos": tors}
 
 
-def cpu_baseline(n: int, conf, seed: int, steps: int = 2):
-    """NumPy oracle, same loop (x_T + priming + `steps` reverse steps), all host cores via BLAS threads."""
+def cpu_baseline(n: int, conf, seed: int, steps: int = 20):
+    """The oracle's loop (x_T + priming forward + `steps` reverse steps of the T = 500 schedule) with the score-network forward on
+    torch-CPU ops (oracle/torch_port.py: the NumPy restatement's formulas on the multithreaded kernels the reference's own
+    torch-CPU path uses), torch.set_num_threads(k) for k = the cores this process may run on, and one forward at k = 1."""
+    import torch
     from framedipt_amd import weights as W
     from oracle import diffuser as od
     from oracle import inference as oi
-    from oracle.score_network import ScoreNetwork as OracleNet
+    from oracle.torch_port import TorchScoreNetwork
     tables = dict(np.load(os.path.join(ROOT, "framedipt_amd", "data", "residue_tables.npz")))
     odiff = od.SE3Diffuser(conf.diffuser)
-    net = OracleNet(conf.model, odiff, W.synth_state_dict(W.param_shapes(conf.model), seed), tables=tables)
+    net = TorchScoreNetwork(conf.model, odiff, W.synth_state_dict(W.param_shapes(conf.model), seed), tables=tables)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    # SMT siblings do not add matrix throughput: half of the logical CPUs when the box reports more than 16
+    threads = max(1, cores // 2) if cores > 16 else cores
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
     feats = oi.unconditional_feats(odiff, n)
     tp = np.ones((1,), dtype=np.float32)
     sched = np.linspace(0.01, 1.0, 500)[::-1]
-    t0 = time.perf_counter()
     feats = oi.set_t_feats(feats, sched[0], tp, odiff)
+    net(feats)  # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
     feats["sc_ca_t"] = net(feats)["rigids"][..., 4:]
     for k in range(steps):
         feats, *_ = oi.one_step(net, odiff, feats, sched[k], 0.01, 1 / 500, tp, noise_scale=0.1)
     el = time.perf_counter() - t0
     fwd = steps + 1
-    try:  # threads the port can actually use: NumPy's BLAS pool (everything else in the port is single-threaded)
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count()
-    return {"value": n * steps / (el * steps / fwd), "unit": "residue*step/s", "cores": cores, "kind": "port",
-            "sample": f"NumPy oracle, de novo N={n}, B=1, {fwd} forwards + {steps} reverse steps of the T=500 schedule "
-                      f"({el:.1f} s wall, priming forward amortised as (T+1)/T)",
-            "note": "single-threaded NumPy element-wise passes dominate the port; the reference's own torch-CPU loop measured "
-                    "213 residue*step/s at N=300 on 8 cores of the build container (SURVEY.md section 6)"}
+    torch.set_num_threads(1)
+    t1 = time.perf_counter()
+    net(feats)
+    el1 = time.perf_counter() - t1
+    torch.set_num_threads(prev)
+    per_step = el * (steps + 1 / 500) / fwd / steps  # priming forward amortised over the T = 500 steps of a trajectory
+    return {"value": n / per_step, "unit": "residue*step/s", "cores": threads, "kind": "port",
+            "sample": f"oracle loop with the torch-CPU forward (oracle/torch_port.py), de novo N={n}, B=1, {fwd} forwards + {steps} reverse "
+                      f"steps of the T=500 schedule ({el:.1f} s wall at {threads} threads of {cores} logical CPUs)",
+            "single_thread": {"value": n / (el1 * 501 / 500), "cores": 1, "sample": f"one forward at torch.set_num_threads(1): {el1:.2f} s"},
+            "note": "a baseline, not the target; the reference's own torch-CPU loop measured 213 residue*step/s at N=300 on 8 cores of "
+                    "the build container (SURVEY.md section 6)"}
 
 
 def main():

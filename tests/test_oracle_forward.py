@@ -106,3 +106,17 @@ def test_embedding_constants_pinned():
     np.testing.assert_array_equal(np.power(2056.0, 2 * np.arange(16) / 32).astype(np.float32), O["index_denoms"])
     np.testing.assert_allclose(osn.timestep_embedding(O["temb_t"], 32), O["temb"], atol=2e-6)
     np.testing.assert_allclose(osn.index_embedding(O["iemb_i"], 32), O["iemb"], atol=2e-6)
+
+
+def test_torch_cpu_port_matches_the_numpy_oracle(tables):
+    """oracle/torch_port.py (bench.py's cpu_baseline: the same forward on multithreaded torch-CPU ops) against the NumPy oracle
+    and, through it, the reference golden: N = 64, full network."""
+    from oracle.torch_port import TorchScoreNetwork
+    G = load_golden("fwd_full_denovo_n64.npz")
+    conf, inp = _conf("full_denovo_n64")
+    ref, diff = _model("full_denovo_n64", G, tables)
+    net = TorchScoreNetwork(conf.model, diff, ref.sd, inpainting=inp, tables=tables)
+    a, b = ref(_feats(G)), net(_feats(G))
+    for k in ("rigids", "psi", "trans_score", "atom37"):
+        np.testing.assert_allclose(b[k], a[k], atol=2e-4, err_msg=k)
+    np.testing.assert_allclose(b["atom37"], G["out_atom37"], atol=5e-4)
