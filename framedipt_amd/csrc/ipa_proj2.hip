@@ -207,6 +207,12 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
                           fd_cvt_pk((acc[i][j][4 * g + 6] + b1[2]) * sc, (acc[i][j][4 * g + 7] + b1[3]) * sc)};
       // cc = cbase + (2 wc + j) 32 + 16 G + 8 hi: cc >> 4 = (cbase >> 4) + 2 (2 wc + j) + G, (cc >> 3) & 1 = hi, cc & 7 = 0
       half_t* dst = (kind == 0 ? a.Qb : a.Kb) + (long)qk_row[i] + cpart[0] + ((2 * j + (g >> 1)) * 64) * 8;
+#ifdef P2_NARROW_STORES
+      if constexpr (SPLIT) {
+        asm volatile("global_store_dword %0, %1, off\n\tglobal_store_dword %0, %2, off offset:4\n\tglobal_store_dword %0, %3, off offset:8\n\tglobal_store_dword %0, %4, off offset:12"
+                     : : "v"(dst), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]) : "memory");
+      } else
+#endif
       *(p2_u32x4*)dst = o;
     } else {
       if (cpart[j] < 0) return;

@@ -55,7 +55,8 @@ def test_forward_writes_inside_its_buffers_only(n, b, prec):
         assert bool((big[:G] == 0xAB).all()) and bool((big[G + nb:] == 0xAB).all()), f"write outside {name}"
 
 
-@pytest.mark.parametrize("n,b,prec", [(100, 2, "fp16"), (301, 2, "fp16"), (64, 1, "fp32")])
+@pytest.mark.parametrize("n,b,prec", [(100, 2, "fp16"), (301, 2, "fp16"), (300, 3, "fp16"), (300, 2, "fp16"), (300, 8, "fp16"), (128, 3, "fp16"),
+                                      (724, 2, "fp16"), (64, 1, "fp32")])
 def test_forward_independent_of_workspace_contents(n, b, prec):
     """Same forward with the workspace pre-filled with zeros, 0xFF (NaN patterns) and random bytes: bit-identical outputs - the
     forward reads nothing it did not write (pads and never-written slots are zeroed by the forward itself)."""

@@ -13,7 +13,7 @@ ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "len
 items = [sharding.seeded_item(ds, i, 3, d, T, 0.01) for i in range(B)]
 feats, tape = sharding.stack_items(items)
 outs = []
-for streams in (1, 2, 3, 1):
+for streams in (1, 2, 2, 1):
     o = inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape, streams=streams)
     outs.append(o)
     print("streams", streams, "final CA span", float(np.abs(o["prot_traj"][0]).max()))
@@ -21,4 +21,4 @@ for k in outs[0]:
     h = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
     for i in (1, 2, 3):
         assert np.array_equal(h(outs[0][k]), h(outs[i][k])), (k, i)
-print(f"T={T} N={N} B={B} trajectories bit-identical for 1 / 2 / 3 streams and on repetition")
+print(f"T={T} N={N} B={B} trajectories bit-identical for 1 / 2 streams and on repetition")
