@@ -65,7 +65,7 @@ CONFIGS = {
 def pmc_traffic(precision: str, n: int, b: int):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), only when the bench
     runs the profiled configuration; the counters cannot be read from inside this process."""
-    for name in ("r02_pmc_edge_transition.json", "r01_pmc_edge_transition.json"):
+    for name in ("r03_pmc_edge_transition.json", "r02_pmc_edge_transition.json", "r01_pmc_edge_transition.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -106,7 +106,7 @@ def synthetic_complex(chain_lens, windows, seed=0):
             "seq_idx": np.concatenate(seq_idx), "chain_idx": np.concatenate(chain_idx), "torsion_angles_sin_cos": tors}
 
 
-def cpu_baseline(n: int, conf, seed: int, steps: int = 20):
+def cpu_baseline(n: int, conf, seed: int, steps: int = 10):
     """The oracle's loop (x_T + priming forward + `steps` reverse steps of the T = 500 schedule) with the score-network forward on
     torch-CPU ops (oracle/torch_port.py: the NumPy restatement's formulas on the multithreaded kernels the reference's own
     torch-CPU path uses), torch.set_num_threads(k) for k = the cores this process may run on, and one forward at k = 1."""
@@ -122,31 +122,40 @@ def cpu_baseline(n: int, conf, seed: int, steps: int = 20):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    # SMT siblings do not add matrix throughput: half of the logical CPUs when the box reports more than 16
-    threads = max(1, cores // 2) if cores > 16 else cores
+    phys = max(1, cores // 2) if cores > 16 else cores  # SMT siblings do not add matrix throughput
     prev = torch.get_num_threads()
-    torch.set_num_threads(threads)
     feats = oi.unconditional_feats(odiff, n)
     tp = np.ones((1,), dtype=np.float32)
     sched = np.linspace(0.01, 1.0, 500)[::-1]
     feats = oi.set_t_feats(feats, sched[0], tp, odiff)
-    net(feats)  # warm-up (thread pool, allocator)
+
+    def one_forward(k):
+        torch.set_num_threads(k)
+        net(feats)  # warm-up (thread pool, allocator)
+        t = time.perf_counter()
+        net(feats)
+        return time.perf_counter() - t
+
+    # torch-CPU does not scale to a whole 128-core host on this forward (measured on the GPU box: 2.9 s at 1 thread, 1.07 s at 16,
+    # 1.8 s at 64, 3.7 s at 128): the baseline is quoted at the best of a short scan, the all-cores and single-thread figures beside it
+    scan = {k: one_forward(k) for k in sorted({min(8, phys), min(16, phys), min(32, phys)})}
+    threads = min(scan, key=scan.get)
+    t_all = one_forward(phys) if phys not in scan else scan[phys]
+    t_one = one_forward(1)
+    torch.set_num_threads(threads)
     t0 = time.perf_counter()
     feats["sc_ca_t"] = net(feats)["rigids"][..., 4:]
     for k in range(steps):
         feats, *_ = oi.one_step(net, odiff, feats, sched[k], 0.01, 1 / 500, tp, noise_scale=0.1)
     el = time.perf_counter() - t0
     fwd = steps + 1
-    torch.set_num_threads(1)
-    t1 = time.perf_counter()
-    net(feats)
-    el1 = time.perf_counter() - t1
     torch.set_num_threads(prev)
     per_step = el * (steps + 1 / 500) / fwd / steps  # priming forward amortised over the T = 500 steps of a trajectory
     return {"value": n / per_step, "unit": "residue*step/s", "cores": threads, "kind": "port",
             "sample": f"oracle loop with the torch-CPU forward (oracle/torch_port.py), de novo N={n}, B=1, {fwd} forwards + {steps} reverse "
-                      f"steps of the T=500 schedule ({el:.1f} s wall at {threads} threads of {cores} logical CPUs)",
-            "single_thread": {"value": n / (el1 * 501 / 500), "cores": 1, "sample": f"one forward at torch.set_num_threads(1): {el1:.2f} s"},
+                      f"steps of the T=500 schedule ({el:.1f} s wall at torch.set_num_threads({threads}), the best of {sorted(scan)} on {cores} logical CPUs)",
+            "all_physical_cores": {"value": n / (t_all * 501 / 500), "cores": phys, "sample": f"one forward at {phys} threads: {t_all:.2f} s"},
+            "single_thread": {"value": n / (t_one * 501 / 500), "cores": 1, "sample": f"one forward at 1 thread: {t_one:.2f} s"},
             "note": "a baseline, not the target; the reference's own torch-CPU loop measured 213 residue*step/s at N=300 on 8 cores of "
                     "the build container (SURVEY.md section 6)"}
 
