@@ -26,7 +26,9 @@ Also on the JSON line:
   roofline     : the dominant kernel (EdgeTransition, 89 % of the reference FLOPs) timed with HIP events recorded by the library
                  on the launch stream around its launches in up to 16 steps of the timed region, read back after the region;
                  achieved = reference-formulation FLOPs per launch / duration (executed FLOPs stated beside it).
-  cpu_baseline : the NumPy oracle (port of the reference loop) on this box's host cores, bounded sample, rank 0, N = 1 only.
+  cpu_baseline : the oracle loop with a torch-CPU forward (oracle/torch_port.py) on this box's host cores: best thread count of a short scan,
+                 all physical cores and one thread; bounded sample, rank 0, N = 1 only.
+  reference_precision : the same workload in fp32 (the reference's arithmetic) for a few steps: value + roofline of that mode.
 """
 from __future__ import annotations
 
