@@ -38,7 +38,8 @@ class ForwardArgs(C.Structure):
         (n, _P) for n in ("rigids_t", "res_mask", "fixed_mask", "sc_ca_t", "seq_idx", "idx_emb", "aatype", "gt_psi", "t",
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
                           "atom37", "atom14", "trace_node", "trace_edge", "trace_inner")] + [
-        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P), ("reserve_cus", C.c_int32), ("clock_out", _P)]
+        ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P), ("reserve_cus", C.c_int32), ("clock_out", _P),
+                ("so3_score_table", _P), ("so3_omega_edges", _P), ("so3_num_omega", C.c_int32)]
 
 
 _lib = None
@@ -85,6 +86,7 @@ SIGNATURES = {
     "fdipt_so3_exp": (_i, [_i, _P, _P, _P]),
     "fdipt_so3_log": (_i, [_i, _P, _P, _P]),
     "fdipt_igso3_rot_score": (_i, [_i, _i, _P, _P, _P, _P, _P, _P]),
+    "fdipt_igso3_rot_score_cached": (_i, [_i, _i, _P, _P, _P, _P, _i, _P, _P, _P]),
     "fdipt_r3_trans_score": (_i, [_i, _i, _P, _P, _P, _f, _f, _f, _P, _P, _P]),
     "fdipt_backbone_atoms": (_i, [_i, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fdipt_linear": (_i, [_i, _i, _i, _i, _P, _i, _P, _i, _P, _P, _i, _P, _i, _P, _i, _P]),

@@ -343,6 +343,9 @@ struct ScoreTail {
   float *rigids, *psi, *trans_score, *ca_out;
   // optional last torsion layer (ipa:349-353, Linear(c_s, 2), fp32): psi_un is then computed here from hid [R, ld_hid]
   const float *hid, *torf_w, *torf_b; int ld_hid, c_hid;
+  // so3.use_cached_score (so3_diffuser.py:389-396): the score norm is looked up instead of evaluated — table [B][n_omega] = the row
+  // of _score_norms at each sample's t, edges [n_omega - 1] = discrete_omega[:-1]; index = torch.bucketize(omega, edges)
+  const double *score_table = nullptr, *omega_edges = nullptr; int n_omega = 0;
 };
 __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t, int ld_t,
                                                                const float* __restrict__ quats_0, int ld_0,
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
   const int b = (int)(r / N);
   const double* wt = wtab[b - b_first < 2 ? b - b_first : 1];
   const double sg = sigma[b];
-  const int lcut = rs_cut(sg);
+  const int lcut = x.score_table ? 0 : rs_cut(sg);  // (cached score: no series)
   float qi[4], q0t[4], rv[3];
   d_invert_quat(quats_0 + r * ld_0, qi);
   d_quat_mul(qi, quats_t + r * ld_t, q0t);
@@ -412,7 +415,17 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
   }
   if (gid >= total) return;
   if (sub < 3) {
-    const double sc = ds / (f + 1e-4);
+    double sc = ds / (f + 1e-4);
+    if (x.score_table) {
+      // bucketize (right = False): the number of edges strictly below omega (float32 promoted to float64, as torch does)
+      const double om = (double)omega;
+      int lo_i = 0, hi_i = x.n_omega - 1;
+      while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (x.omega_edges[mid] < om) lo_i = mid + 1; else hi_i = mid;
+      }
+      sc = x.score_table[(long)b * x.n_omega + lo_i];
+    }
     const double m = res_mask ? (double)res_mask[r] : 1.0;
     score[r * 3 + sub] = sc * (double)rv[sub] / (double)omega * m;
   }
@@ -628,10 +641,11 @@ int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const 
                   int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
                   const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
                   float* ca_out, const float* hid, int ld_hid, int c_hid, const float* torf_w, const float* torf_b,
-                  hipStream_t st) {
+                  const double* score_table, const double* omega_edges, int n_omega, hipStream_t st) {
   if (hid && ((c_hid & 3) || (ld_hid & 3))) return FDIPT_EINVAL;
+  if (score_table && (!omega_edges || n_omega < 2)) return FDIPT_EINVAL;
   ScoreTail x = {trans, cs, psi_un, ld_psi, gt_psi, fixed_mask, t, min_b, max_b, rigids, psi, trans_score, ca_out,
-                 hid, torf_w, torf_b, ld_hid, c_hid};
+                 hid, torf_w, torf_b, ld_hid, c_hid, score_table, omega_edges, n_omega};
   hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, st, B, N, rigids_t, 7,
                      quat, 4, sigma, res_mask, rot_score, x);
   FD_CHECK_LAUNCH();
@@ -919,6 +933,18 @@ int fdipt_igso3_rot_score(int B, int N, const float* quats_t, const float* quats
   if (B <= 0 || N <= 0) return FDIPT_OK;
   if (!quats_t || !quats_0 || !sigma || !score) return FDIPT_EINVAL;
   return fd_rot_score(B, N, quats_t, 4, quats_0, 4, sigma, res_mask, score, (hipStream_t)s);
+}
+int fdipt_igso3_rot_score_cached(int B, int N, const float* quats_t, const float* quats_0, const double* score_table,
+                                 const double* omega_edges, int n_omega, const float* res_mask, double* score, fdipt_stream_t s) {
+  if (B <= 0 || N <= 0) return FDIPT_OK;
+  if (!quats_t || !quats_0 || !score_table || !omega_edges || n_omega < 2 || !score) return FDIPT_EINVAL;
+  ScoreTail x = {};
+  x.score_table = score_table; x.omega_edges = omega_edges; x.n_omega = n_omega;
+  // (sigma is not read with a table; the table itself stands in for the pointer so that the kernel's per-sample read stays in bounds)
+  hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, (hipStream_t)s, B, N, quats_t, 4,
+                     quats_0, 4, score_table, res_mask, score, x);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
 }
 int fdipt_r3_trans_score(int B, int N, const float* trans_t, const float* trans_0, const float* t, float min_b,
                          float max_b, float coordinate_scaling, const float* res_mask, float* score, fdipt_stream_t s) {

@@ -1150,7 +1150,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // tensor_7 / psi epilogue, R^3 score and IGSO(3) score in one launch (frames.hip)
   RC(fd_score_tail(B, N, a->rigids_t, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask,
                    res_mask, a->so3_sigma, a->t, d->r3_min_b, d->r3_max_b, a->rigids, a->psi, a->rot_score, a->trans_score,
-                   a->ca_out, torf_fused ? F(w.h_b) : nullptr, cs, cs, P + iv.torf.w, P + iv.torf.b, st));
+                   a->ca_out, torf_fused ? F(w.h_b) : nullptr, cs, cs, P + iv.torf.w, P + iv.torf.b, a->so3_score_table,
+                   a->so3_omega_edges, a->so3_num_omega, st));
   if (a->atom37 || a->atom14) {
     if (!a->bb_tables) return FDIPT_EINVAL;
     RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));

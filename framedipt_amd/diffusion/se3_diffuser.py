@@ -100,9 +100,20 @@ class SE3Diffuser:
         shp = qt.shape[:-1]
         B = shp[0] if len(shp) == 2 else 1
         N = shp[-1]
-        sig = self._so3_diffuser.score_sigma(torch.as_tensor(t).detach().cpu().numpy().reshape(-1))
-        sig = torch.as_tensor(np.broadcast_to(sig, (B,)).copy(), device=qt.device)
+        t_np = torch.as_tensor(t).detach().cpu().numpy().reshape(-1)
         out = torch.empty(B, N, 3, dtype=torch.float64, device=qt.device)
+        so3 = self._so3_diffuser
+        if so3.use_cached_score:  # so3_diffuser.py:389-396: table lookup instead of the series
+            rows = np.broadcast_to(so3.score_table_rows(t_np), (B, so3.num_omega)).copy()
+            tab, edges = torch.as_tensor(rows, device=qt.device), torch.as_tensor(so3.omega_edges, device=qt.device)
+            with torch.cuda.device(qt.device):
+                _lib.check(lib.fdipt_igso3_rot_score_cached(B, N, _lib.ptr(qt.reshape(B, N, 4).contiguous()),
+                                                            _lib.ptr(q0.reshape(B, N, 4).to(qt.device).contiguous()), _lib.ptr(tab),
+                                                            _lib.ptr(edges), so3.num_omega, None, _lib.ptr(out), _lib.stream_ptr()),
+                           "igso3_rot_score_cached")
+            return out.reshape(*shp, 3)
+        sig = so3.score_sigma(t_np)
+        sig = torch.as_tensor(np.broadcast_to(sig, (B,)).copy(), device=qt.device)
         with torch.cuda.device(qt.device):
             _lib.check(lib.fdipt_igso3_rot_score(B, N, _lib.ptr(qt.reshape(B, N, 4).contiguous()),
                                                  _lib.ptr(q0.reshape(B, N, 4).to(qt.device).contiguous()), _lib.ptr(sig), None,

@@ -48,12 +48,10 @@ class SO3Diffuser:
         self.max_sigma = so3_conf.max_sigma
         self.num_sigma = so3_conf.num_sigma
         self.num_omega = so3_conf.num_omega
-        self.use_cached_score = so3_conf.use_cached_score
-        if self.use_cached_score:
-            # so3_diffuser.py:373-402: the cached variant looks the score norm up in a bucketised [num_sigma, num_omega] table
-            # instead of evaluating the series; the rotation-score kernel only implements the series (the reference default)
-            raise NotImplementedError("so3.use_cached_score=True (bucketised score-norm table) is not implemented; the "
-                                      "rotation score is always the 1000-term IGSO(3) series (so3.use_cached_score=False)")
+        # so3_diffuser.py:389-396: with use_cached_score the score norm is looked up in the [num_sigma, num_omega] table at
+        # (t_to_idx(t), bucketize(omega, discrete_omega[:-1])) instead of evaluated; the rows of that table are built on demand
+        # here (`score_table_rows`), the lookup runs in the rotation-score kernel
+        self.use_cached_score = bool(so3_conf.use_cached_score)
         self.discrete_omega = np.linspace(0, np.pi, so3_conf.num_omega + 1)[1:]
         self._rows: dict = {}
         np.random.seed(so3_conf.seed)  # so3_diffuser.py:286
@@ -98,6 +96,17 @@ class SO3Diffuser:
             cdf = pdf.cumsum() / self.num_omega * np.pi
             self._rows[idx] = (pdf, cdf, score(ev, self.discrete_omega, sig))
         return self._rows[idx]
+
+    def score_table_rows(self, t_f32) -> np.ndarray:
+        """Rows ``_score_norms[t_to_idx(t)]`` ([len(t), num_omega] float64) for ``use_cached_score`` — the index is taken as
+        ``torch_score`` takes it (``t`` arrives as float32, see ``score_sigma``)."""
+        t = np.asarray(t_f32, dtype=np.float32).reshape(-1)
+        sig32 = np.log(t * np.float32(np.exp(self.max_sigma)) + (np.float32(1) - t) * np.float32(np.exp(self.min_sigma)))
+        return np.stack([self._row(i)[2] for i in self.sigma_idx(sig32)])
+
+    @property
+    def omega_edges(self) -> np.ndarray:
+        return np.ascontiguousarray(self.discrete_omega[:-1], dtype=np.float64)
 
     def score_scaling(self, t):
         """so3_diffuser.py:404-414; scalar or array-valued t."""

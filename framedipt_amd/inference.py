@@ -78,6 +78,12 @@ class ReverseLoop:
             self.t_all = torch.as_tensor(np.repeat(t32[:, None], B, 1), device=dev)
             self.temb_all = torch.as_tensor(np.repeat(temb[:, None, :], B, 1), device=dev)
             self.sig_all = torch.as_tensor(np.repeat(sig[:, None], B, 1), device=dev)
+            so3 = diffuser._so3_diffuser
+            self.tab_all = self.omega_edges = None
+            if so3.use_cached_score:  # one row of the score-norm table per step (all samples of a batch share t)
+                rows = so3.score_table_rows(t32)
+                self.tab_all = torch.as_tensor(np.repeat(rows[:, None, :], B, 1), device=dev)
+                self.omega_edges = torch.as_tensor(so3.omega_edges, device=dev)
             if noise_tape is None:
                 noise_tape = draw_noise_tape(diffuser, n_noisy, B, N)
             self.z_rot = torch.as_tensor(np.ascontiguousarray(noise_tape[0], dtype=np.float64), device=dev)
@@ -95,6 +101,8 @@ class ReverseLoop:
         # the forward itself hands the predicted CA positions to the next step's self-conditioning input (read at its start,
         # written at its end: no copy kernel)
         direct = want_atoms and self.bb0_from_forward
+        self.st.score_table = None if self.tab_all is None else self.tab_all[k]
+        self.st.omega_edges = self.omega_edges
         self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all[k],
                         self.temb_all[k], self.sig_all[k], direct, ca_out=self.sc_ca if sc_update else None,
                         atom37_out=self.bb0_traj[k] if direct else None)  # rigid_0_traj row: straight into its slot

@@ -76,6 +76,8 @@ class BatchState:
             self.trace_edge = torch.zeros(d.num_blocks, B, N, N, d.c_z, **f32)
         self.trace_inner = (torch.zeros(d.num_blocks, 4, B, N, d.c_s + d.c_skip, **f32) if trace_inner else None)
         self.ev_start = self.ev_stop = None  # optional hipEvent pairs around the EdgeTransition launches (bench.py)
+        self.score_table = None  # so3.use_cached_score: [B, num_omega] float64 rows of the score-norm table for this call's t
+        self.omega_edges = None
         self.clock_out = None  # optional int64[3] device tensor: shader-clock probe of the EdgeTransition kernels (FdiptForwardArgs.clock_out)
         self.reserve_cus = 0  # CUs the persistent pair kernels leave to concurrent sub-batch streams (inference.StreamedLoops)
         self.t_emb_eps = torch.as_tensor(embedding.get_timestep_embedding(np.array([1e-5], dtype=np.float32), E)[0],
@@ -102,6 +104,9 @@ class BatchState:
             a.ev_start, a.ev_stop = self.ev_start, self.ev_stop
         a.reserve_cus = self.reserve_cus
         a.clock_out = _lib.ptr(self.clock_out)
+        if self.score_table is not None:
+            a.so3_score_table, a.so3_omega_edges = _lib.ptr(self.score_table), _lib.ptr(self.omega_edges)
+            a.so3_num_omega = int(self.score_table.shape[-1])
         _lib.check(lib.fdipt_score_forward(C.byref(net.dims), _lib.ptr(net.params), _lib.ptr(net.derived),
                                            _lib.ptr(self.setup), C.byref(a), _lib.ptr(self.ws), self.ws_bytes,
                                            _lib.stream_ptr()), "score_forward")
@@ -219,6 +224,12 @@ class ScoreNetwork:
         aatype_dev = None if aatype is None else aatype.to(device=dev, dtype=torch.int32).contiguous()
         t32, temb, sig = self.step_scalars(input_feats["t"].detach().cpu().numpy())
         gt = input_feats["torsion_angles_sin_cos"]
+        so3 = self.diffuser._so3_diffuser
+        if so3.use_cached_score:
+            st.score_table = torch.as_tensor(so3.score_table_rows(t32), device=dev)
+            st.omega_edges = torch.as_tensor(so3.omega_edges, device=dev)
+        else:
+            st.score_table = st.omega_edges = None
         with torch.cuda.device(dev):
             st.forward(f32(rig), f32(input_feats["res_mask"]), fixed, f32(input_feats["sc_ca_t"]), aatype_dev,
                        f32(gt[..., 2, :]), torch.as_tensor(t32, device=dev), torch.as_tensor(temb, device=dev),

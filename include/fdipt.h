@@ -151,6 +151,12 @@ typedef struct FdiptForwardArgs {
    * kernel's blocks actually ran at = [0] / [1] / 10 GHz (bench.py: roofline.clock_ghz).  NULL (the default): the kernels
    * execute no atomics and keep no state outside the caller's buffers. */
   unsigned long long* clock_out;
+  /* optional: so3.use_cached_score = True (so3_diffuser.py:389-396) — the rotation-score norm is looked up instead of evaluated:
+   * so3_score_table [B, so3_num_omega] f64 = the row of the reference's _score_norms table at each sample's t,
+   * so3_omega_edges [so3_num_omega - 1] f64 = discrete_omega[:-1]; index = torch.bucketize(omega, edges).  NULL: the series. */
+  const double* so3_score_table;
+  const double* so3_omega_edges;
+  int32_t so3_num_omega;
 } FdiptForwardArgs;
 
 size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
@@ -267,6 +273,9 @@ int fdipt_so3_log(int n, const double* rot, double* rotvec, fdipt_stream_t s);
  * series; quats_t = noisy x_t, quats_0 = prediction, sigma[B] as in FdiptForwardArgs. */
 int fdipt_igso3_rot_score(int B, int N, const float* quats_t, const float* quats_0, const double* sigma,
                           const float* res_mask, double* score, fdipt_stream_t s);
+/* ... with so3.use_cached_score = True: score_table [B, n_omega], omega_edges [n_omega - 1] as in FdiptForwardArgs. */
+int fdipt_igso3_rot_score_cached(int B, int N, const float* quats_t, const float* quats_0, const double* score_table,
+                                 const double* omega_edges, int n_omega, const float* res_mask, double* score, fdipt_stream_t s);
 /* SE3Diffuser.calc_trans_score(use_torch=True, scale=True) (se3_diffuser.py:269-279 -> r3_diffuser.py:410-440). */
 int fdipt_r3_trans_score(int B, int N, const float* trans_t, const float* trans_0, const float* t, float min_b,
                          float max_b, float coordinate_scaling, const float* res_mask, float* score, fdipt_stream_t s);

@@ -236,3 +236,39 @@ def test_run_sharded_torchrun_entry_two_ranks(tmp_path):
     for item in range(6):
         assert outs[1][item].shape == outs[2][item].shape and outs[1][item].shape[0] in (24, 26, 28)
         np.testing.assert_array_equal(outs[1][item], outs[2][item], err_msg=f"item {item}")
+
+
+@gpu
+def test_cached_rot_score_matches_the_reference_table_lookup():
+    """so3.use_cached_score = True (so3_diffuser.py:389-396): the score norm is looked up in the bucketised [sigma, omega] table
+    instead of evaluated.  calc_rot_score against values captured from the reference with the flag set, at t = 0.02 / 0.5 / 1
+    (float64 output; a residue whose omega sits within one float32 ulp of a bucket edge may land in the neighbouring bucket: at most
+    one such residue per case is tolerated, everything else to 2e-6 relative: the rotation vector is float32 arithmetic), and a forward with the flag runs the lookup."""
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.rigid import Rotation
+    G = load_golden("cached_score.npz")
+    conf = config.base_config()
+    conf.diffuser.so3.use_cached_score = True
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    for i in range(3):
+        out = d.calc_rot_score(Rotation(quats=dev(G[f"qt_{i}"])[None]), Rotation(quats=dev(G[f"q0_{i}"])[None]), torch.tensor([float(G[f"t_{i}"])]))
+        assert out.dtype == torch.float64 and str(G[f"dtype_{i}"]) == "torch.float64"
+        got, ref = out.cpu().numpy(), G[f"score_{i}"]
+        rel = np.abs(got - ref).max(-1) / np.maximum(np.abs(ref).max(-1), 1e-12)
+        assert (rel > 2e-6).sum() <= 1, (i, np.sort(rel.ravel())[-4:])
+        assert rel.max() < 5e-2, (i, rel.max())
+    # the series and the table agree where the series is conditioned (the table IS the series on the omega grid): same network,
+    # both flags, rot_score of a forward within the grid resolution
+    from framedipt_amd.model import ScoreNetwork
+    Gf = load_golden("fwd_full_denovo_n64.npz")
+    outs = {}
+    for flag in (False, True):
+        c = config.base_config()
+        c.diffuser.so3.use_cached_score = flag
+        dd = SE3Diffuser(c.diffuser, device="cuda")
+        net = ScoreNetwork(c.model, dd, precision="fp32").load_synthetic(int(Gf["weight_seed"]), float(Gf["bb_gain"])).to("cuda")
+        outs[flag] = net(_feats(Gf))["rot_score"].cpu().numpy()
+    assert np.isfinite(outs[True]).all()
+    scale = np.abs(outs[False]).max()
+    assert np.abs(outs[True] - outs[False]).max() < 0.05 * scale

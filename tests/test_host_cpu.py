@@ -183,8 +183,10 @@ def test_score_sigma_float32_evaluation():
         assert np.all(np.abs(got - f64) <= 0.004 * f64)
     conf = config.base_config().diffuser.so3
     conf.use_cached_score = True
-    with pytest.raises(NotImplementedError):
-        so3_diffuser.SO3Diffuser(conf)
+    cached = so3_diffuser.SO3Diffuser(conf)  # so3_diffuser.py:389-396: rows of the score-norm table, built on demand
+    rows = cached.score_table_rows(np.array([1.0, 0.5], dtype=np.float32))
+    assert rows.shape == (2, 1000) and rows.dtype == np.float64 and cached.omega_edges.shape == (999,)
+    np.testing.assert_array_equal(rows[0], cached._row(cached.t_to_idx(1.0))[2])
     assert np.shape(so3.score_scaling(np.array([0.1, 0.5]))) == (2,)
 
 
