@@ -272,3 +272,33 @@ def test_cached_rot_score_matches_the_reference_table_lookup():
     assert np.isfinite(outs[True]).all()
     scale = np.abs(outs[False]).max()
     assert np.abs(outs[True] - outs[False]).max() < 0.05 * scale
+
+
+@gpu
+def test_bf16_build_of_the_half_mode_runs_config2_shape():
+    """BASELINE configs[1] names bf16.  The default build's half type is fp16 (same MFMA rate, three more significand bits: the mode
+    that holds the parity bar); the -DFDIPT_HALF_BF16 build (lib/libfdipt_hip_bf16.so, built by __graft_entry__.build()) is the
+    literal bf16 variant.  It runs the N = 128 de novo golden of config 2 within bf16's own, looser bounds (stated here: node
+    representation 1e-3 relative, CA 1.5e-3 A, backbone RMSD 1e-3 A per forward — measured 3.4e-4 / 4.0e-4 / 3.4e-4, 4 - 5x the fp16 build's) — a subprocess, because a process binds one library."""
+    import subprocess
+    lib = os.path.join(ROOT, "framedipt_amd", "lib", "libfdipt_hip_bf16.so")
+    assert os.path.exists(lib), "run __graft_entry__.build() first"
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import kabsch_free_rmsd, load_golden
+from test_gpu_parity import _feats, _net
+G = load_golden("fwd_full_denovo_n128.npz")
+net, d, conf = _net("full_denovo_n128", G, "bf16")
+out = net(_feats(G), trace=True)
+tn = out["trace_node"].cpu().numpy()
+rel = max(float(np.linalg.norm(tn[b + 1] - G[f"tr_node_{b}"]) / np.linalg.norm(G[f"tr_node_{b}"])) for b in range(4))
+ca = float(np.abs(out["rigids"].cpu().numpy()[..., 4:] - G["out_rigids"][..., 4:]).max())
+rm = float(kabsch_free_rmsd(out["atom37"].cpu().numpy(), G["out_atom37"]))
+print("BF16", rel, ca, rm)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDIPT_LIB=lib), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rel, ca, rm = (float(v) for v in next(l for l in r.stdout.splitlines() if l.startswith("BF16")).split()[1:])
+    print(f"bf16 build, N = 128: node rel {rel:.2e}, CA max {ca:.2e} A, backbone rmsd {rm:.2e} A")
+    assert rel < 1e-3 and ca < 1.5e-3 and rm < 1e-3
