@@ -9,8 +9,10 @@
  *   - every function returns 0 on success, a negative FDIPT_E* code otherwise; no exceptions,
  *     no allocation, no global mutable state; one hipStream_t per call (passed as void*).  Calls for different devices
  *     are independent, and so are calls on different streams of one device as long as they share no output / workspace buffer
- *     (forwards of two sub-batches may be in flight together: FdiptForwardArgs.reserve_cus; the round-2 mismatch between
- *     concurrent forwards was a wide-store hazard in one kernel, fixed and regression-tested: DESIGN.md section 5).
+ *     (forwards of TWO sub-batches may be in flight together: FdiptForwardArgs.reserve_cus; verified bit-identical to the
+ *     sequential result in long soaks for two streams, NOT for three or more — DESIGN.md section 5 — so the Python host
+ *     refuses more than two).  No device-side state survives a call; the only atomics (the optional clock probe) target a
+ *     caller-owned buffer.
  *   - all pointers are DEVICE pointers unless the name ends in _host; the caller (PyTorch) owns
  *     every buffer, including the workspace (query sizes with the *_bytes functions).
  *   - layouts are row-major contiguous, residue-major.  Quaternions are scalar-first (w,x,y,z);
