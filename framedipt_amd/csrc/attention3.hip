@@ -67,6 +67,8 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   }
   const int h = bhq % H, b = bhq / H;
   const long rb = (long)b * N, bh = bhq;
+  const long kvh = a.kv_per_sample ? b : bh;  // index of the K / V images: per (sample, head), or per sample (merged projection: the
+                                              // node rows are keys and values of every head)
   const int i_raw = qt * 32 + li;
   const bool valid = i_raw < N;
   const int i = valid ? i_raw : N - 1;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
     const int jA_raw = 32 * t + li;          // key owned by this lane as an A-operand ROW
     const bool vA = jA_raw < N;
     const int jA = vA ? jA_raw : N - 1;
-    const half_t* kr = a.Kb + ((bh * nt + t) * 16 * 64 + lane) * 8;  // fragment order (padded keys are zero rows)
+    const half_t* kr = a.Kb + ((kvh * nt + t) * 16 * 64 + lane) * 8;  // fragment order (padded keys are zero rows)
 #pragma unroll
     for (int s = 0; s < 16; ++s) ti.k[s] = a3_ld(kr + s * 512);
     const float* kpr = a.kp + ((rb + jA) * H + h) * 24;
@@ -298,28 +300,28 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       const half_t* vlo = a.Vt_lo;
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) {
-        const long off = ((bh * (A3_C / 32) + 2 * wave + dd) * ks) * 512;
+        const long off = ((kvh * (A3_C / 32) + 2 * wave + dd) * ks) * 512;
         if (dd == 0) v_load(B0, a.Vt + off);   // (d tile 1's V_hi was requested under d tile 0's last products)
         v_mma(B0, acc);                        // V_hi P_hi
         v_mma_add(B0, acc, Pls);               // V_hi P_lo
         v_load(B0, vlo + off);
         v_mma_add(B0, acc, Pfs);               // V_lo P_hi
-        if (dd == 0) v_load(B0, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
+        if (dd == 0) v_load(B0, a.Vt + ((kvh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
         else if (wave < 3) v_load(B0, a.vpt + ((bh * 3 + wave) * ks) * 512);
         o_store(acc, 2 * wave + dd);
       }
     } else if constexpr (DB) {
-      v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave) * ks) * 512);
-      v_load(std::integral_constant<int, 1>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
+      v_load(std::integral_constant<int, 0>{}, a.Vt + ((kvh * (A3_C / 32) + 2 * wave) * ks) * 512);
+      v_load(std::integral_constant<int, 1>{}, a.Vt + ((kvh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
       v_mma(std::integral_constant<int, 0>{}, acc);
       if (wave < 3) v_load(std::integral_constant<int, 0>{}, a.vpt + ((bh * 3 + wave) * ks) * 512);  // points tile, under tile 1
       o_store(acc, 2 * wave);
       v_mma(std::integral_constant<int, 1>{}, acc);
       o_store(acc, 2 * wave + 1);
     } else {
-      v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave) * ks) * 512);
+      v_load(std::integral_constant<int, 0>{}, a.Vt + ((kvh * (A3_C / 32) + 2 * wave) * ks) * 512);
       v_mma(std::integral_constant<int, 0>{}, acc);
-      v_load(std::integral_constant<int, 0>{}, a.Vt + ((bh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
+      v_load(std::integral_constant<int, 0>{}, a.Vt + ((kvh * (A3_C / 32) + 2 * wave + 1) * ks) * 512);
       o_store(acc, 2 * wave);
       v_mma(std::integral_constant<int, 0>{}, acc);
       if (wave < 3) v_load(std::integral_constant<int, 0>{}, a.vpt + ((bh * 3 + wave) * ks) * 512);

@@ -64,13 +64,15 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
   constexpr int NTH = SPLIT ? 512 : FD_THREADS;
   const int wr = SPLIT ? wave : wave >> 1;  // row part of this wave: rows 32 TM wr .. of the block
   int wc = SPLIT ? 0 : (wave & 1);          // column half of a 128-column block: per wave (plain), per step (SPLIT)
-  const int M = a.B * a.N, HC = a.H * a.C, NOUT = 3 * HC + a.PT, ntl = a.Np >> 5;
+  const bool mrg = a.merged != 0;  // columns [q' | points] instead of [q | k, v per head | points]
+  const int M = a.B * a.N, HC = a.H * a.C, NOUT = (mrg ? HC : 3 * HC) + a.PT, ntl = a.Np >> 5;
   const int m0 = blockIdx.x * RB;
   const char* wimg = (const char*)a.W_img;
   const char* wimg_lo = (const char*)a.W_img_lo;
   // ---- column blocks of this block's class, in class order: k-th Q/K block / k-th V-or-point block -> column block index
-  const int nq = HC / 128, per_head = (2 * a.C) / 128, n_class = QK ? 2 * nq : n_cblk - 2 * nq;
+  const int nq = HC / 128, per_head = (2 * a.C) / 128, n_class = mrg ? (QK ? nq : n_cblk - nq) : (QK ? 2 * nq : n_cblk - 2 * nq);
   auto cblk_of = [&](int k) {
+    if (mrg) return QK ? k : nq + k;
     if (QK) return k < nq ? k : nq + ((k - nq) / (per_head / 2)) * per_head + (k - nq) % (per_head / 2);
     const int nv = nq;  // V blocks, then the point blocks
     return k < nv ? nq + (k / (per_head / 2)) * per_head + per_head / 2 + k % (per_head / 2) : 3 * nq + (k - nv);
@@ -249,14 +251,14 @@ __device__ __forceinline__ void ipa_proj2_body(const ProjArgs& a, int n_cblk, in
       cpart[1] = 0;
       return isq ? 0 : 1;
     } else {
-      const bool isv = n0 < 3 * HC;
+      const bool isv = !mrg && n0 < 3 * HC;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int n = n0 + (wc * 2 + j) * 32 + li;
         if (isv) {
           const int nn = n - HC, hh = nn / (2 * a.C), cc = nn % (2 * a.C) - a.C;
           cpart[j] = (hh * (a.C >> 5) + (cc >> 5)) * (2 * ntl) * 512 + (cc & 31) * 8;
-        } else cpart[j] = n < NOUT ? n - 3 * HC : -1;
+        } else cpart[j] = n < NOUT ? n - (mrg ? HC : 3 * HC) : -1;
       }
       return isv ? 2 : 3;
     }
@@ -465,6 +467,69 @@ int fd_ipa_proj2_permute_image(void* img, int H, int C, int K, hipStream_t st) {
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+int fd_ipa_proj2_permute_image_q(void* img, int H, int C, int K, hipStream_t st) {
+  if ((C & 31) || (K & 15)) return FDIPT_EINVAL;
+  const int n_q = H * C / 32, ks = K / 16;
+  hipLaunchKernelGGL(p2_permute_rows_kernel, dim3(n_q * ks), dim3(64), 0, st, (half_t*)img, ks, n_q, 2 * C / 32);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
+// ------------------------------------------------------------------ node rows -> attention operand images (merged projection)
+// One thread = one 16 B unit of an image.  Units [0, nk): Kb (key r, channels 8 cg .. 8 cg + 7: contiguous in the row);
+// units [nk, nk + nv): Vt and Vt_lo (channel cc, the 8 key slots of a half 16-group: eight coalesced row reads, lanes = channels).
+__global__ void node_images_kernel(int B, int N, int Np, const float* __restrict__ node, int ld, half_t* __restrict__ Kb,
+                                   half_t* __restrict__ Vt, half_t* __restrict__ Vt_lo) {
+  constexpr int C = 256;
+  const int ntl = Np >> 5;
+  const long nk = (long)B * Np * (C / 8), nv = (long)B * (C / 32) * (2 * ntl) * 64;
+  for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < nk + nv; u += (long)gridDim.x * blockDim.x) {
+    if (u < nk) {
+      const int cg = (int)(u % (C / 8));
+      const long br = u / (C / 8);
+      const int r = (int)(br % Np), b = (int)(br / Np);
+      p2_u32x4 o = {0u, 0u, 0u, 0u};
+      if (r < N) {
+        const float* x = node + ((long)b * N + r) * ld + 8 * cg;
+        const f32x4 x0 = *(const f32x4*)x, x1 = *(const f32x4*)(x + 4);
+        o = p2_u32x4{fd_cvt_pk(x0[0], x0[1]), fd_cvt_pk(x0[2], x0[3]), fd_cvt_pk(x1[0], x1[1]), fd_cvt_pk(x1[2], x1[3])};
+      }
+      // element ((((b ntl + (r >> 5)) (C >> 4) + (cc >> 4)) 64 + ((cc >> 3) & 1) 32 + (r & 31)) 8 + (cc & 7), cc = 8 cg
+      *(p2_u32x4*)(Kb + ((((long)b * ntl + (r >> 5)) * (C >> 4) + (cg >> 1)) * 64 + (cg & 1) * 32 + (r & 31)) * 8) = o;
+    } else {
+      const long v = u - nk;
+      const int lane = (int)(v & 63), half = lane >> 5, c5 = lane & 31;
+      const long f = v >> 6;
+      const int s16 = (int)(f % (2 * ntl));
+      const long bd = f / (2 * ntl);
+      const int dt = (int)(bd % (C / 32)), b = (int)(bd / (C / 32));
+      const int cc = 32 * dt + c5;
+      float xv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {  // slot 8 half + e of the 16-group -> key 16 s16 + pos, slot = 4 (pos >> 3) + (pos & 3) + 8 ((pos & 7) >> 2)
+        const int slot = 8 * half + e, pos = 8 * ((slot >> 2) & 1) + 4 * (slot >> 3) + (slot & 3);
+        const int key = 16 * s16 + pos;
+        xv[e] = key < N ? node[((long)b * N + key) * ld + cc] : 0.f;
+      }
+      p2_u32x4 oh, ol;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        oh[q] = fd_cvt_pk(xv[2 * q], xv[2 * q + 1]);
+        ol[q] = fd_cvt_pk(xv[2 * q] - h2f(f2h(xv[2 * q])), xv[2 * q + 1] - h2f(f2h(xv[2 * q + 1])));
+      }
+      *(p2_u32x4*)(Vt + v * 8) = oh;
+      if (Vt_lo) *(p2_u32x4*)(Vt_lo + v * 8) = ol;
+    }
+  }
+}
+int fd_node_images(int B, int N, int Np, const float* node, int ld, half_t* Kb, half_t* Vt, half_t* Vt_lo, hipStream_t st) {
+  if ((Np & 31) || Np < N || (ld & 3) || !Kb || !Vt) return FDIPT_EINVAL;
+  const long units = (long)B * Np * 32 + (long)B * 8 * (Np / 16) * 64;
+  hipLaunchKernelGGL(node_images_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, B, N, Np, node, ld, Kb, Vt, Vt_lo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
 int fd_ipa_proj2_supported(const ProjArgs& a) {
   const int HC = a.H * a.C;
   return a.K == P2_K && a.W_img && (a.N & 3) == 0 && (a.C % 128) == 0 && (HC % 128) == 0 && (a.lda & 3) == 0 && (a.Np & 31) == 0 && (a.PT & 3) == 0;
@@ -472,7 +537,7 @@ int fd_ipa_proj2_supported(const ProjArgs& a) {
 int fd_ipa_proj2(const ProjArgs& a, hipStream_t st) {
   if (!fd_ipa_proj2_supported(a)) return FDIPT_EINVAL;
   const bool split = a.W_img_lo != nullptr;
-  const int M = a.B * a.N, NOUT = 3 * a.H * a.C + a.PT;
+  const int M = a.B * a.N, NOUT = (a.merged ? 1 : 3) * a.H * a.C + a.PT;
   const int n_cblk = cdiv(NOUT, 128), n_rblk = cdiv(M, split ? 256 : 128);
   const int lds = split ? P2S_BIAS_OFF + n_cblk * 128 * 4 : P2_LDS;
   if (lds > 160 * 1024 || (split && n_cblk * 128 > 8192)) return FDIPT_ESIZE;
@@ -484,7 +549,7 @@ int fd_ipa_proj2(const ProjArgs& a, hipStream_t st) {
   // proportion to their column blocks
   int ncg = 256 / n_rblk;
   if (ncg < 2) ncg = 2;
-  const int n_qk = 2 * (a.H * a.C / 128), n_other = n_cblk - n_qk;
+  const int n_qk = (a.merged ? 1 : 2) * (a.H * a.C / 128), n_other = n_cblk - n_qk;
   // (a Q / K column block costs about 6 / 7 of a V / point block: 16 B stores against 8 B / 4 B ones)
   int wq = (ncg * n_qk * 6 + (n_qk * 6 + n_other * 7) / 2) / (n_qk * 6 + n_other * 7);
   if (wq < 1) wq = 1;

@@ -167,7 +167,15 @@ struct ProjArgs {
   half_t* Vt_lo = nullptr;    // optional (split operands): V - half(V) in the layout of Vt (the attention's P V on split operands)
   float* pts;                 // [B*N, PT]
   int zero_pads;              // also zero the padded keys [N, Np) of Kb / Vt (first use of the buffers in a forward)
+  // merged layout (ipa_proj2.hip only): the columns are [q' (H*C) | points] — no k, no v: the logits are q'.s with
+  // q' = W_k^T (W_q s + b_q) (a per-(query, head) constant drops out of the softmax), the values are the node rows themselves with
+  // W_v folded into the output projection (model.hip: merged weights).  Kb / Vt are then not written (fd_node_images writes them)
+  int merged = 0;
 };
+// the node rows as attention operand images shared by all heads of a sample (merged projection): Kb [B][Np/32][16][64][8] (key rows,
+// 256 channels), Vt / Vt_lo [B][8][Np/16][64][8] (channel rows, keys permuted inside every 16-group), padded keys zero
+int fd_node_images(int B, int N, int Np, const float* node, int ld, half_t* Kb, half_t* Vt, half_t* Vt_lo, hipStream_t st);
+int fd_ipa_proj2_permute_image_q(void* img, int H, int C, int K, hipStream_t st);  // ... of the q' tiles only (merged layout)
 int fd_ipa_proj(const ProjArgs& a, hipStream_t st);
 int fd_ipa_proj_zero_pads(const ProjArgs& a, void* extra, size_t extra_bytes, hipStream_t st);  // (Kb, Vt and Vt_lo when set)
 int fd_ipa_proj2_supported(const ProjArgs& a);
@@ -179,6 +187,7 @@ struct Attn3Args {
   int B, N, H, Np;
   const half_t *Qb, *Kb, *Vt;     // operand images written by ipa_proj_kernel
   const half_t* Vt_lo = nullptr;  // optional: V - half(V), same layout: P V (and the value-point sums) on split operands, P = hi + lo too
+  int kv_per_sample = 0;          // Kb / Vt / Vt_lo are indexed by sample, not by (sample, head): the node-row images of the merged projection
   const float* bias;              // pre-scaled pair bias in fd_bias_frag_off order (B*H*Np*Np floats)
   const float* res_mask;          // [B,N]
   const float *qp, *kp, *vp;      // [B,N,H,8,3], [B,N,H,8,3], [B,N,H,12,3] global-frame points (scaled units)

@@ -32,6 +32,7 @@ struct Switches {
        probs_f32 = false, no_l2_warm = false;
   bool no_seq_attn = false;     // (dev) sequence attention on the LDS-score kernel only (IPA attention unchanged)
   bool no_split = false;        // node-path products on plain half-precision operands instead of split (hi + lo) ones
+  bool no_merge = false;        // IPA projections in the reference's formulation (k, v explicit) instead of the merged one
   int splitk_ns = 4;            // K slices of the IPA output projection (K = 2688)
   unsigned split_mask = 0x7FFu;  // split operands per layer group: 1 node embedder, 2 output projection, 4 in_proj, 8 tails, 16 transition, 32 torsion,
                                  // 64 IPA input projection, 128 EdgeTransition per-residue rows, 256 o_pair down-projection, 512 skip_embed, 1024 attention P V
@@ -72,6 +73,7 @@ static Switches switches_of(const FdiptDims* d) {
   if (f & FDIPT_KF_GENERIC_ATTN) s.generic_attn = true;
   if (f & FDIPT_KF_UNFUSED_NODE) s.no_rowblock = s.no_chain = s.no_splitk = true;
   if (f & FDIPT_KF_NO_SPLIT) s.no_split = true;
+  if (f & FDIPT_KF_NO_MERGE) s.no_merge = true;
   if (f & FDIPT_KF_UNFOLDED)
     s.no_et_bias = s.no_ee_bias = s.feats_unfused = s.torf_unfused = s.init_unfused = s.skip_per_block = s.post_unfused =
         s.et4_rows_unfused = true;
@@ -165,7 +167,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo; DChain ch; DSplit lo; };
+struct DBlock { size_t wq_m, wproj2_img, wproj2_img_lo, bproj2, wout_m, bout_m, wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo; DChain ch; DSplit lo; };
 struct DLayout {
   size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -214,6 +216,17 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].wproj_img_lo = o;  // ... and of W - half(W) (split operands)
     if (L.esz == 2 && d->c_s == 256) o = al256(o + (size_t)((iv.proj_out + 127) / 128) * 65536);
     L.blk[b].bproj = o; o = al256(o + (size_t)iv.proj_out * 4);
+    // merged IPA projections (forward_impl: `merged`): q' = W_k^T (W_q s + b_q) per head as [H C, c_s] fp32 (+ its bias), the fragment
+    // images of [q' | q_pts | kv_pts] (hi, lo), their biases, and linear_out with W_v folded into its o columns
+    {
+      const int HCm = d->no_heads * d->c_hidden, n2 = iv.proj_out - 2 * HCm;
+      L.blk[b].wq_m = o; o = al256(o + (size_t)HCm * d->c_s * 4);
+      L.blk[b].wproj2_img = o; if (L.esz == 2 && d->c_s == 256) o = al256(o + (size_t)((n2 + 127) / 128) * 65536);
+      L.blk[b].wproj2_img_lo = o; if (L.esz == 2 && d->c_s == 256) o = al256(o + (size_t)((n2 + 127) / 128) * 65536);
+      L.blk[b].bproj2 = o; o = al256(o + (size_t)n2 * 4);
+      L.blk[b].wout_m = o; o = al256(o + (size_t)d->c_s * iv.feat_dim * 4);
+      L.blk[b].bout_m = o; o = al256(o + (size_t)d->c_s * 4);
+    }
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
@@ -313,6 +326,44 @@ __global__ void gamma_kernel(int H, int Pq, const float* __restrict__ head_w, fl
   }
 }
 
+// ------------------------------------------------------------------ merged IPA projections (prepare time, float64 accumulation)
+// q . k over the keys j of a softmax row: (W_q s_i + b_q) . (W_k s_j + b_k) = s_j . W_k^T (W_q s_i + b_q) + (a constant in j, which the
+// softmax drops) -> the keys are the node rows themselves and the query becomes q' = A s_i + c with A = W_k^T W_q, c = W_k^T b_q per head.
+// Aq [H cs, cs], cq [H cs];  qw [H C, cs], qb [H C];  kvw [H 2C, cs] (per head: C rows of k, then C rows of v)
+__global__ void merge_qk_kernel(int H, int C, int cs, const float* __restrict__ qw, const float* __restrict__ qb,
+                                const float* __restrict__ kvw, float* __restrict__ Aq, float* __restrict__ cq) {
+  const long n = (long)H * cs * (cs + 1);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (cs + 1));
+    const long hc = i / (cs + 1);
+    const int c = (int)(hc % cs), h = (int)(hc / cs);
+    double acc = 0;
+    for (int dd = 0; dd < C; ++dd)
+      acc += (double)kvw[((long)h * 2 * C + dd) * cs + c] * (double)(col < cs ? qw[((long)h * C + dd) * cs + col] : qb[h * C + dd]);
+    if (col < cs) Aq[hc * cs + col] = (float)acc; else cq[hc] = (float)acc;
+  }
+}
+// sum_j p_j v_j = W_v (sum_j p_j s_j) + b_v (sum_j p_j = 1): the values are the node rows, W_v moves into the output projection:
+// Wm[o][h cs + c] = sum_d Wout[o][h C + d] W_v^h[d][c] for the o columns, the other columns are copied; bm = b_out + Wout[:, o cols] b_v
+__global__ void merge_vo_kernel(int H, int C, int cs, int feat, const float* __restrict__ ow, const float* __restrict__ ob,
+                                const float* __restrict__ kvw, const float* __restrict__ kvb, float* __restrict__ Wm,
+                                float* __restrict__ bm) {
+  const long n = (long)cs * (feat + 1);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (feat + 1)), o = (int)(i / (feat + 1));
+    if (col == feat) {
+      double acc = ob[o];
+      for (int k = 0; k < H * C; ++k) acc += (double)ow[(long)o * feat + k] * (double)kvb[(k / C) * 2 * C + C + k % C];
+      bm[o] = (float)acc;
+    } else if (col < H * cs) {
+      const int h = col / cs, c = col % cs;
+      double acc = 0;
+      for (int dd = 0; dd < C; ++dd) acc += (double)ow[(long)o * feat + h * C + dd] * (double)kvw[((long)h * 2 * C + C + dd) * cs + c];
+      Wm[(long)o * feat + col] = (float)acc;
+    } else Wm[(long)o * feat + col] = ow[(long)o * feat + col];
+  }
+}
+
 extern "C" {
 
 int fdipt_param_count(const FdiptDims* dims) {
@@ -394,6 +445,32 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     if (proj_img && C % 128 == 0 && (H * C) % 128 == 0 &&
         ((rc = fd_ipa_proj2_permute_image(D + db.wproj_img, H, C, cs, st)) || (rc = fd_ipa_proj2_permute_image(D + db.wproj_img_lo, H, C, cs, st))))
       return rc;
+    if (cs == C) {  // merged projections (the o columns of linear_out keep their width: H cs = H C)
+      hipLaunchKernelGGL(merge_qk_kernel, dim3(512), dim3(256), 0, st, H, C, cs, P + k.q.w, P + k.q.b, P + k.kv.w, (float*)(D + db.wq_m),
+                         (float*)(D + db.bproj2));
+      hipLaunchKernelGGL(merge_vo_kernel, dim3(512), dim3(256), 0, st, H, C, cs, iv.feat_dim, P + k.out.w, P + k.out.b, P + k.kv.w, P + k.kv.b,
+                         (float*)(D + db.wout_m), (float*)(D + db.bout_m));
+      FD_CHECK_LAUNCH();
+      const int HCm = H * C, n2 = iv.proj_out - 2 * HCm;
+      if ((rc = copy_cols(4, 1, k.qp.out, k.qp.out, P + k.qp.b, k.qp.out, 0, 1.f, D + db.bproj2 + (size_t)HCm * 4, st)) ||
+          (rc = copy_cols(4, 1, k.kvp.out, k.kvp.out, P + k.kvp.b, k.kvp.out, 0, 1.f, D + db.bproj2 + (size_t)(HCm + k.qp.out) * 4, st)))
+        return rc;
+      if (proj_img && C % 128 == 0 && HCm % 128 == 0 && k.qp.out % 32 == 0 && k.kvp.out % 32 == 0) {
+        const size_t ib = (size_t)((n2 + 127) / 128) * 65536, tile = (size_t)(cs / 16) * 1024;
+        if (hipMemsetAsync(D + db.wproj2_img, 0, ib, st) != hipSuccess || hipMemsetAsync(D + db.wproj2_img_lo, 0, ib, st) != hipSuccess) return FDIPT_ELAUNCH;
+        const float* srcs[3] = {(const float*)(D + db.wq_m), P + k.qp.w, P + k.kvp.w};
+        const int rows[3] = {HCm, k.qp.out, k.kvp.out};
+        long r0 = 0;
+        for (int p3 = 0; p3 < 3; ++p3) {  // (tile-major images: stacking row blocks of 32 = concatenation)
+          if ((rc = fd_chain_build_image(srcs[p3], rows[p3], cs, cs, 0, D + db.wproj2_img + (size_t)(r0 / 32) * tile, st)) ||
+              (rc = fd_chain_build_image_lo(srcs[p3], rows[p3], cs, cs, D + db.wproj2_img_lo + (size_t)(r0 / 32) * tile, st)))
+            return rc;
+          r0 += rows[p3];
+        }
+        if ((rc = fd_ipa_proj2_permute_image_q(D + db.wproj2_img, H, C, cs, st)) || (rc = fd_ipa_proj2_permute_image_q(D + db.wproj2_img_lo, H, C, cs, st)))
+          return rc;
+      }
+    }
     hipLaunchKernelGGL(gamma_kernel, dim3(1), dim3(64), 0, st, H, d->no_qk_points, P + k.head_w, (float*)(D + db.gamma));
     FD_CHECK_LAUNCH();
     // pair bias pre-scaled by sqrt(1/3) (ipa_pytorch.py:256-257)
@@ -796,7 +873,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     OPairArgs oa;
     oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_h16 = nullptr; oa.probs_np = 0; oa.out_h16 = nullptr;
     oa.wdz = (const float*)(D + db.wdz_t); oa.wdz_img = (bf && cz == 128) ? D + db.wdz_img : nullptr; oa.wdz_img_lo = (oa.wdz_img && split_dz) ? D + db.wdz_img_lo : nullptr; oa.bdz = P + k.dz.b; oa.out = F(w.feats); oa.out_ld = iv.feat_dim; oa.off = H * C + 4 * H * Pv;
-    bool feats_h16 = false, skip_done = false;
+    bool feats_h16 = false, skip_done = false, merged = false;
     const bool use_a3 = bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && !sw.generic_attn && fd_attention3_supported(a3);
     PointsArgs pa;
     pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.quat = F(w.quat); pa.trans = F(w.trans);
@@ -815,23 +892,36 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       pj.zero_pads = b == 0 || op.kind != OP_ALL;  // (per-op entry: the workspace is the caller's, pads unknown)
       pj.W_img = (cs == 256 && !sw.proj_v1) ? D + db.wproj_img : nullptr;
       pj.W_img_lo = (pj.W_img && split_proj) ? D + db.wproj_img_lo : nullptr;
-      // P V on split operands needs V_lo, which only the split second-generation projection writes
-      if (pj.W_img_lo && split_pv && fd_ipa_proj2_supported(pj)) { pj.Vt_lo = (half_t*)(W + w.vt_lo); a3.Vt_lo = pj.Vt_lo; }
+      // Merged projections (the default of the split mode at the reference widths): no k, no v — the node rows are keys and values of
+      // every head (fd_node_images), q' = W_k^T (W_q s + b_q), W_v sits in the output projection (prepare: merge_qk / merge_vo).  40 % of
+      // the projection's columns, and K / V images an eighth of the size.  Exact algebra (softmax shift invariance, linearity); the
+      // per-op entries and FDIPT_KF_NO_MERGE keep the reference's formulation.
+      merged = pj.W_img_lo && split && cs == C && !sw.no_merge && op.kind == OP_ALL && fd_ipa_proj2_supported(pj);
+      if (merged) {
+        pj.merged = 1; pj.W_img = D + db.wproj2_img; pj.W_img_lo = D + db.wproj2_img_lo; pj.bias = (const float*)(D + db.bproj2);
+        a3.kv_per_sample = 1;
+        if (split_pv) a3.Vt_lo = (const half_t*)(W + w.vt_lo);
+      } else if (pj.W_img_lo && split_pv && fd_ipa_proj2_supported(pj)) {  // P V on split operands needs V_lo, which only the split second-generation projection writes
+        pj.Vt_lo = (half_t*)(W + w.vt_lo); a3.Vt_lo = pj.Vt_lo;
+      }
       // second generation (activation fragments in registers, weights by LDS-DMA): FDIPT_PROJ_V1 keeps the tiled GEMM
       if (fd_ipa_proj2_supported(pj)) {
         if (pj.zero_pads && seq_fused && !seq_img_ready && (C & 31) == 0 && (vpt_bytes & 15) == 0 && !sw.init_unfused) {
           // every once-per-forward fill of the trunk in one launch: sequence-attention images, value-point image, key pads
-          SeqInitExtra sx = {vpt_zero ? W + w.vpt : nullptr, vpt_zero ? (long)(vpt_bytes >> 4) : 0L, Np > N ? (void*)pj.Kb : nullptr,
+          // (merged: fd_node_images writes the padded keys of its images itself)
+          SeqInitExtra sx = {vpt_zero ? W + w.vpt : nullptr, vpt_zero ? (long)(vpt_bytes >> 4) : 0L, (Np > N && !merged) ? (void*)pj.Kb : nullptr,
                              (void*)pj.Vt, (long)B * H, C, (void*)pj.Vt_lo};
           RC(fd_seq_images_init(B, N, d->tfmr_heads, res_mask, W + w.seqimg, sx, st));
           seq_img_ready = true;
           vpt_zero = false;
-        } else if (pj.zero_pads && (Np > N || vpt_zero)) {
+        } else if (pj.zero_pads && ((Np > N && !merged) || vpt_zero)) {
           ProjArgs pz = pj; pz.W_img = nullptr;
+          if (merged) pz.Np = pz.N;  // (no key pads to zero)
           RC(fd_ipa_proj_zero_pads(pz, vpt_zero ? W + w.vpt : nullptr, vpt_zero ? vpt_bytes : 0, st));
           vpt_zero = false;
         }
         TWICE("proj", fd_ipa_proj2(pj, st));
+        if (merged) RC(fd_node_images(B, N, Np, node_cur, cs, pj.Kb, pj.Vt, split_pv ? (half_t*)(W + w.vt_lo) : nullptr, st));
       } else RC(fd_ipa_proj(pj, st));
       if (vpt_zero && hipMemsetAsync(W + w.vpt, 0, vpt_bytes, st) != hipSuccess) return FDIPT_ELAUNCH;
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
@@ -885,8 +975,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       // partial sums is part of a sample's result (sub-batches and sharded runs reproduce the whole-batch result bit for bit)
       const int NS = sw.splitk_ns != 4 ? sw.splitk_ns : (split ? 3 : 4);
       if (split)
-        TWICE("splitk", fd_linear_splitk_split(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, P + k.out.w, iv.feat_dim, P + k.out.b,
-                                               res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
+        TWICE("splitk", fd_linear_splitk_split(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, merged ? (const float*)(D + db.wout_m) : P + k.out.w,
+                                               iv.feat_dim, merged ? (const float*)(D + db.bout_m) : P + k.out.b, res_mask, F(w.ipa_parts),
+                                               (long)R * cs, cs, st));
       else if (feats_h16)
         TWICE("splitk", fd_linear_splitk_a16(R, cs, iv.feat_dim, NS, (const half_t*)(W + w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b,
                                 res_mask, F(w.ipa_parts), (long)R * cs, cs, st));

@@ -52,7 +52,9 @@ extern "C" {
 #define FDIPT_KF_UNFOLDED 16     /* launch folds off: pair bias / feature split / torsion head / fills as own launches  */
 #define FDIPT_KF_NO_SPLIT 32     /* node-path layers on plain half-precision operands instead of split (hi + lo) operands:
                                     ~8 % faster, 5x the error of the predicted frames / psi (precision modes)      */
-#define FDIPT_KF_ALL 63
+#define FDIPT_KF_NO_MERGE 64     /* IPA projections in the reference's formulation (k and v explicit) instead of the merged one
+                                    (keys = values = the node rows, W_k folded into the query, W_v into the output projection)  */
+#define FDIPT_KF_ALL 127
 
 typedef void* fdipt_stream_t; /* hipStream_t */
 
