@@ -302,3 +302,30 @@ print("BF16", rel, ca, rm)
     rel, ca, rm = (float(v) for v in next(l for l in r.stdout.splitlines() if l.startswith("BF16")).split()[1:])
     print(f"bf16 build, N = 128: node rel {rel:.2e}, CA max {ca:.2e} A, backbone rmsd {rm:.2e} A")
     assert rel < 1e-3 and ca < 1.5e-3 and rm < 1e-3
+
+
+@gpu
+def test_merged_projections_equal_the_reference_formulation():
+    """The merged IPA projections (keys = values = node rows, q' = W_k^T (W_q s + b_q), W_v folded into linear_out: DESIGN.md section 4.25)
+    against the reference's formulation with explicit k and v (FDIPT_KF_NO_MERGE) in the same library: exact algebra, so the two
+    forwards differ by operand rounding only — node representation after every block within 1e-4 relative, frames within 1e-4 A."""
+    from framedipt_amd import _lib
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    G = load_golden("fwd_full_denovo_n128.npz")
+    outs = {}
+    for kf in (0, _lib.KF_NO_MERGE):
+        conf = config.base_config()
+        d = SE3Diffuser(conf.diffuser, device="cuda")
+        net = ScoreNetwork(conf.model, d, precision="fp16", kernel_flags=kf).load_synthetic(int(G["weight_seed"]), float(G["bb_gain"])).to("cuda")
+        out = net(_feats(G), trace=True)
+        outs[kf] = {k: v.cpu().numpy().copy() for k, v in out.items()}
+    a, b = outs[0], outs[_lib.KF_NO_MERGE]
+    assert not np.array_equal(a["trace_node"][1], b["trace_node"][1])  # (two different kernels / formulations did run)
+    for blk in range(1, 5):
+        rel = np.linalg.norm(a["trace_node"][blk] - b["trace_node"][blk]) / np.linalg.norm(b["trace_node"][blk])
+        assert rel < 1e-4, (blk, rel)
+    assert np.abs(a["rigids"][..., 4:] - b["rigids"][..., 4:]).max() < 1e-4
+    for o in (a, b):  # and each within the fp16 bounds of the reference golden
+        assert kabsch_free_rmsd(o["atom37"], G["out_atom37"]) < 5e-4
