@@ -742,6 +742,49 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
     const uint4 val = *(const uint4*)(vs + (hl * 72 + rw) * 16 + 8 * hf);
     *(uint4*)(a.vpt + (((((long)b * a.H + half * HH + hl) * 3 + (rw >> 5)) * ks + g) * 64 + hf * 32 + (rw & 31)) * 8) = val;
   }
+  if (a.node) {
+    // merged projection: this 16-group of keys of the node-row images (c_s = 256): block half 0 writes the K image rows, half 1 the
+    // V_hi / V_lo units; the last group of a sample also covers the padded groups up to Np (zeros)
+    constexpr int C = 256;
+    const int ntl = a.Np >> 5;
+    const int g_end = g == ng - 1 ? (a.Np >> 4) : g + 1;
+    for (int gg = g; gg < g_end; ++gg) {
+      if (half == 0) {
+        for (int u = tid; u < 16 * (C / 8); u += 256) {
+          const int cg = u & 31, r = 16 * gg + (u >> 5);
+          uint4 o = make_uint4(0, 0, 0, 0);
+          if (r < a.N) {
+            const float* x = a.node + ((long)b * a.N + r) * a.ld_node + 8 * cg;
+            const float4 x0 = *(const float4*)x, x1 = *(const float4*)(x + 4);
+            o = make_uint4(fd_cvt_pk(x0.x, x0.y), fd_cvt_pk(x0.z, x0.w), fd_cvt_pk(x1.x, x1.y), fd_cvt_pk(x1.z, x1.w));
+          }
+          *(uint4*)(a.nKb + ((((long)b * ntl + (r >> 5)) * (C >> 4) + (cg >> 1)) * 64 + (cg & 1) * 32 + (r & 31)) * 8) = o;
+        }
+      } else {
+        for (int u = tid; u < (C / 32) * 64; u += 256) {
+          const int lane = u & 63, hf = lane >> 5, c5 = lane & 31, dt = u >> 6, cc = 32 * dt + c5;
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {  // slot 8 hf + e of the 16-group -> key (inverse of pt_perm16)
+            const int slot = 8 * hf + e, pos = 8 * ((slot >> 2) & 1) + 4 * (slot >> 3) + (slot & 3);
+            const int key = 16 * gg + pos;
+            xv[e] = key < a.N ? a.node[((long)b * a.N + key) * a.ld_node + cc] : 0.f;
+          }
+          uint4 oh, ol;
+          unsigned* ph = (unsigned*)&oh;
+          unsigned* pl = (unsigned*)&ol;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ph[q] = fd_cvt_pk(xv[2 * q], xv[2 * q + 1]);
+            pl[q] = fd_cvt_pk(xv[2 * q] - h2f(f2h(xv[2 * q])), xv[2 * q + 1] - h2f(f2h(xv[2 * q + 1])));
+          }
+          const long v = (((long)b * (C / 32) + dt) * (2 * ntl) + gg) * 64 + lane;
+          *(uint4*)(a.nVt + v * 8) = oh;
+          if (a.nVt_lo) *(uint4*)(a.nVt_lo + v * 8) = ol;
+        }
+      }
+    }
+  }
 }
 
 int fd_points(const PointsArgs& a, hipStream_t st) {
@@ -751,6 +794,7 @@ int fd_points(const PointsArgs& a, hipStream_t st) {
     FD_CHECK_LAUNCH();
     return FDIPT_OK;
   }
+  if (a.node) return FDIPT_EINVAL;  // (the node-row images ride on the 16-keys-per-block kernel only)
   hipLaunchKernelGGL(points_kernel, dim3(a.B * a.N), dim3(256), 0, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -101,6 +101,11 @@ struct PointsArgs {
   // 16 s + 8 (lane >> 5) + e with the keys permuted inside every 16-group; pads must be zeroed by the caller once
   unsigned short* vpt;
   int Np;
+  // optional (points16_kernel only; merged projection): the node rows as the attention's K / V_hi / V_lo images shared by all heads
+  // (layouts: fd_node_images), written by the same launch — a block's 16 keys are one 16-group of those images
+  const float* node = nullptr;
+  int ld_node = 0;
+  unsigned short *nKb = nullptr, *nVt = nullptr, *nVt_lo = nullptr;
 };
 
 // Pair bias of the IPA attention, tiled for BOTH sides: [sample*head][query tile][key tile][query in tile][32 keys].

@@ -921,7 +921,12 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
           vpt_zero = false;
         }
         TWICE("proj", fd_ipa_proj2(pj, st));
-        if (merged) RC(fd_node_images(B, N, Np, node_cur, cs, pj.Kb, pj.Vt, split_pv ? (half_t*)(W + w.vt_lo) : nullptr, st));
+        // (the node-row images ride on the point launch when that is the 16-keys-per-block kernel; else their own launch)
+        if (merged) {
+          if (pa.vpt && Pv == 12 && (H & 1) == 0 && cs == 256) {
+            pa.node = node_cur; pa.ld_node = cs; pa.nKb = pj.Kb; pa.nVt = pj.Vt; pa.nVt_lo = split_pv ? (half_t*)(W + w.vt_lo) : nullptr;
+          } else RC(fd_node_images(B, N, Np, node_cur, cs, pj.Kb, pj.Vt, split_pv ? (half_t*)(W + w.vt_lo) : nullptr, st));
+        }
       } else RC(fd_ipa_proj(pj, st));
       if (vpt_zero && hipMemsetAsync(W + w.vpt, 0, vpt_bytes, st) != hipSuccess) return FDIPT_ELAUNCH;
       pa.proj = F(w.pts); pa.ld = PT; pa.q_off = 0; pa.kv_off = 3 * H * Pq;
