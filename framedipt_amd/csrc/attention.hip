@@ -599,7 +599,10 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
   if (fd_opair_mfma_eligible(precision, a)) {
     if (a.probs_h16 && (a.probs_np & 3)) return FDIPT_EINVAL;
     const int Np = (a.N + OM_JC - 1) / OM_JC * OM_JC;
-    const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4;
+#ifndef OM_PAD
+#define OM_PAD 0  // (tools/micro/opair_bench.hip: extra dynamic LDS = fewer blocks per CU)
+#endif
+    const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4 + OM_PAD;
     if (a.N <= 320) hipLaunchKernelGGL((opair_mfma_kernel<20, 2>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
 #ifndef OM_MID
 #define OM_MID 0

@@ -120,6 +120,46 @@ def test_free_running_fp16_n128_tracks_the_oracle():
 
 
 @gpu
+def test_free_running_fp16_n300_tracks_the_oracle():
+    """The same at the benchmarked size: N = 300, T = 10, free-running, fp16 mode against the oracle loop on the same x_T / weights /
+    noise tape.  The oracle forward runs on torch-CPU ops (oracle/torch_port.py: the NumPy restatement's formulas, pinned against it in
+    tests/test_oracle_forward.py) so that eleven N = 300 forwards take seconds, not minutes."""
+    from framedipt_amd import config, inference
+    from framedipt_amd import weights as W
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    from oracle import diffuser as od
+    from oracle import inference as oi
+    from oracle.torch_port import TorchScoreNetwork
+    conf = config.base_config()
+    n, num_t = 300, 10
+    diff = SE3Diffuser(conf.diffuser, device="cuda:0")
+    net = ScoreNetwork(conf.model, diff, precision="fp16").load_synthetic(5).to("cuda:0")
+    sampler = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": 1}), diff,
+                                   "cuda:0")
+    np.random.seed(23)
+    _, _, feats = sampler[0]
+    tape = inference.draw_noise_tape(diff, num_t - 1, 1, n)
+    res = inference.inference_fn(net, diff, feats, num_t=num_t, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
+    torch.cuda.synchronize()
+    tables = dict(np.load(os.path.join(ROOT, "framedipt_amd", "data", "residue_tables.npz")))
+    odiff = od.SE3Diffuser(conf.diffuser)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        onet = TorchScoreNetwork(conf.model, odiff, W.synth_state_dict(W.param_shapes(conf.model), 5), tables=tables)
+        ref = oi.inference_fn(onet, odiff, {k: v.cpu().numpy() for k, v in feats.items()}, num_t, 0.01, noise_scale=0.1,
+                              noise_tape=[(tape[0][i], tape[1][i]) for i in range(num_t - 1)])
+    finally:
+        torch.set_num_threads(threads)
+    d = res["prot_traj"][..., :5, :] - ref["prot_traj"][..., :5, :]
+    per_step = np.sqrt((d ** 2).sum(-1).mean(axis=(1, 2, 3)))
+    print(f"fp16 N=300 T={num_t} free-running: backbone RMSD vs oracle: final structure {per_step[0]:.2e} A, worst step {per_step.max():.2e} A")
+    assert per_step[0] < 1e-3 and per_step.max() < 1e-3  # measured 2.0e-4
+
+
+@gpu
 @pytest.mark.parametrize("name", ["full_denovo_n300_t02", "full_denovo_n300_t50"])
 def test_rot_score_fence_where_the_reference_series_is_unconditioned(name):
     """Where the float32 IGSO(3) series of the reference is unconditioned (f <= 1e-2: its own score is float32 round-off over the
