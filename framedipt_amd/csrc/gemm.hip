@@ -532,6 +532,144 @@ int fd_linear_splitk_split(int M, int N, int K, int nsplit, const float* A, int 
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+// ------------------------------------------------------------------ IPA output projection on split operands: the dedicated kernel
+// linear_out (ipa_pytorch.py:324-329) at the reference widths: M = B N rows, K = 2688 features, 256 columns, every product on split
+// operands (x = hi + lo, W = hi + lo, x_hi W_lo + x_lo W_hi + x_hi W_hi).  The generic split-K tile loop above re-splits the fp32 weight
+// matrix in each of its 38 row blocks and runs 14 dependent load -> split -> LDS -> barrier -> MFMA rounds per block (29 us, MFMA 11 %).
+// Here: a block = 64 rows x ALL 256 columns x one K slice of KSL k-steps (2688 = 6 x 28 x 16: 38 x 6 = 228 blocks, one round of the 256
+// CUs); the block's activation slice is read once (coalesced fp32 rows), split, and parked in LDS as hi rows | lo rows (row stride
+// 2 KW + 16 B: the 16 lanes of a b128 read hit 16 distinct slots); the weights are fragment images prepared once (fd_chain_build_image /
+// _lo of the [256, K] matrix) and go STRAIGHT from L2 into registers — wave w owns column tile w, one linear 1 KB load per fragment,
+// OP_DEPTH k-steps ahead, no LDS, no barrier after the staging one.  Per k-step and wave: 2 KB of weights, 4 LDS reads, 6 MFMAs on two
+// independent accumulators (the two 32-row tiles).  The slice count is a constant of the kernel (the order of the partial sums is part
+// of a row's result: any batch composition gives the same bits); the LayerNorm that follows sums the slices.
+#define OP_DEPTH 6
+template <int KSL>
+__global__ __launch_bounds__(512, 1) void outproj_split_kernel(int M, const float* __restrict__ A, int lda, const char* __restrict__ w_hi,
+                                                                const char* __restrict__ w_lo, int ks_total,
+                                                                const float* __restrict__ bias, const float* __restrict__ rowmask,
+                                                                float* __restrict__ parts, long part_stride, int ldo) {
+  constexpr int KW = KSL * 16, XROW = KW * 2 + 16, XLO = 64 * XROW, C4 = KW / 4, NV = 64 * C4 / 512;
+  static_assert((64 * C4) % 512 == 0, "whole float4 columns per thread");
+  extern __shared__ __attribute__((aligned(16))) char op_smem[];
+  float* rm = (float*)(op_smem + 2 * XLO);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hi = lane >> 5;
+  const int m0 = blockIdx.x * 64, z = blockIdx.y;
+  typedef fd_h op_hx4 __attribute__((ext_vector_type(4)));
+  FD_STAMP(0);
+  // weight fragments of the first k-steps: in flight before anything else
+  const size_t woff = ((size_t)(wave * ks_total + z * KSL) * 64 + lane) * 16;
+  const char* wh = w_hi + woff;
+  const char* wl = w_lo + woff;
+  hx8 Wh[OP_DEPTH], Wl[OP_DEPTH];
+#pragma unroll
+  for (int s = 0; s < OP_DEPTH - 1; ++s) {
+    Wh[s] = __builtin_bit_cast(hx8, *(const u16x8*)(wh + (size_t)s * 1024));
+    Wl[s] = __builtin_bit_cast(hx8, *(const u16x8*)(wl + (size_t)s * 1024));
+  }
+  FD_STAMP(1);
+  {  // activation slice -> LDS (all loads of a thread in flight together)
+    f32x4 xv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + k * 512, r = idx / C4, c4 = idx - r * C4;
+      const int gr = m0 + r < M ? m0 + r : M - 1;
+      xv[k] = *(const f32x4*)(A + (long)gr * lda + z * KW + 4 * c4);
+    }
+    FD_STAMP(2);
+    if (tid < 64) rm[tid] = rowmask ? rowmask[m0 + tid < M ? m0 + tid : M - 1] : 1.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + k * 512, r = idx / C4, c4 = idx - r * C4;
+      op_hx4 pk, pl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pk[q] = (fd_h)xv[k][q];
+        pl[q] = (fd_h)(xv[k][q] - (float)pk[q]);
+      }
+      *(op_hx4*)(op_smem + r * XROW + 8 * c4) = pk;
+      *(op_hx4*)(op_smem + XLO + r * XROW + 8 * c4) = pl;
+    }
+  }
+  FD_STAMP(3);
+  __syncthreads();
+  FD_STAMP(4);
+  f32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+  const char* xa = op_smem + li * XROW + 16 * hi;
+  auto a_frag = [&](int s, int rt, int lo) { return __builtin_bit_cast(hx8, *(const u16x8*)(xa + lo * XLO + rt * 32 * XROW + 32 * s)); };
+  // activation fragments one k-step ahead (a read issued at the top of its own step is waited for by the step's first product)
+  hx8 ah[2][2], al[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) { ah[0][rt] = a_frag(0, rt, 0); al[0][rt] = a_frag(0, rt, 1); }
+#pragma unroll
+  for (int s = 0; s < KSL; ++s) {
+    if (s + OP_DEPTH - 1 < KSL) {
+      Wh[(s + OP_DEPTH - 1) % OP_DEPTH] = __builtin_bit_cast(hx8, *(const u16x8*)(wh + (size_t)(s + OP_DEPTH - 1) * 1024));
+      Wl[(s + OP_DEPTH - 1) % OP_DEPTH] = __builtin_bit_cast(hx8, *(const u16x8*)(wl + (size_t)(s + OP_DEPTH - 1) * 1024));
+    }
+    if (s + 1 < KSL)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) { ah[(s + 1) & 1][rt] = a_frag(s + 1, rt, 0); al[(s + 1) & 1][rt] = a_frag(s + 1, rt, 1); }
+    const hx8 bh = Wh[s % OP_DEPTH], bl = Wl[s % OP_DEPTH];
+    acc[0] = fd_mfma32(ah[s & 1][0], bl, acc[0]);
+    acc[1] = fd_mfma32(ah[s & 1][1], bl, acc[1]);
+    acc[0] = fd_mfma32(al[s & 1][0], bh, acc[0]);
+    acc[1] = fd_mfma32(al[s & 1][1], bh, acc[1]);
+    acc[0] = fd_mfma32(ah[s & 1][0], bh, acc[0]);
+    acc[1] = fd_mfma32(ah[s & 1][1], bh, acc[1]);
+    __builtin_amdgcn_sched_barrier(0);  // pin the step: hipcc otherwise sinks the reads of step s + 1 to their uses
+  }
+  FD_STAMP(5);
+  // D[row, column]: lane = column 32 wave + li, registers = rows c_row(r, lane) of a row tile.  Stored from here a store instruction
+  // would move 2 x 128 B (measured: 9.7 k cycles for the 64 KB of a block); the tile crosses LDS instead (the activation rows are dead)
+  // and leaves as whole 1 KB rows, 16 B per lane.  Row stride 264 floats: the two lane halves (rows 4 apart) land 32 banks apart.
+  constexpr int OROW = 264;
+  static_assert(64 * OROW * 4 <= 2 * XLO, "output tile fits the activation buffers");
+  __syncthreads();
+  float* ot = (float*)op_smem;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[(32 * rt + c_row(r, lane)) * OROW + 32 * wave + li] = acc[rt][r];
+  __syncthreads();
+  FD_STAMP(6);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && z == 0) bv = *(const f32x4*)(bias + 4 * lane);
+  float* out = parts + z * part_stride;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int lr = 8 * wave + k, m = m0 + lr;
+    f32x4 v = *(const f32x4*)(ot + lr * OROW + 4 * lane);
+    const float mk = rm[lr];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (v[q] + bv[q]) * mk;
+    if (m < M) *(f32x4*)(out + (long)m * ldo + 4 * lane) = v;
+  }
+  FD_STAMP(7);
+}
+#define OP_KSL 28
+#define OP_NS 6
+int fd_outproj_split_supported(int N, int K) { return N == 256 && K == OP_KSL * OP_NS * 16; }
+int fd_outproj_split_slices() { return OP_NS; }
+// parts[z][M, ldo], z < fd_outproj_split_slices(): w_hi / w_lo = fd_chain_build_image / _lo of the [256, K] weight matrix
+int fd_outproj_split(int M, int N, int K, const float* A, int lda, const void* w_hi, const void* w_lo, const float* bias, const float* rowmask,
+                     float* parts, long part_stride, int ldo, hipStream_t st) {
+  if (M <= 0 || !fd_outproj_split_supported(N, K) || (lda & 3) || (ldo & 3) || (part_stride & 3) || !w_hi || !w_lo) return FDIPT_EINVAL;
+  constexpr size_t smem = (size_t)2 * 64 * (OP_KSL * 32 + 16) + 256;
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
+    if (hipFuncSetAttribute((const void*)outproj_split_kernel<OP_KSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_dev.set(dev_, 1);
+  }
+  hipLaunchKernelGGL((outproj_split_kernel<OP_KSL>), dim3(cdiv(M, 64), OP_NS), dim3(512), smem, st, M, A, lda, (const char*)w_hi, (const char*)w_lo,
+                     K / 16, bias, rowmask, parts, part_stride, ldo);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const half_t* A, int lda, const void* W, int ldw, const float* bias,
                      const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || nsplit < 1 || (K & 7) || (lda & 7) || (ldw & 7)) return FDIPT_EINVAL;

@@ -315,6 +315,11 @@ int fd_linear_splitk_a16(int M, int N, int K, int nsplit, const half_t* A, int l
                          const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_linear_splitk_split(int M, int N, int K, int nsplit, const float* A, int lda, const float* W, int ldw, const float* bias,
                            const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
+// dedicated split-operand kernel for the IPA output projection at the reference widths (gemm.hip: outproj_split_kernel)
+int fd_outproj_split_supported(int N, int K);
+int fd_outproj_split_slices();
+int fd_outproj_split(int M, int N, int K, const float* A, int lda, const void* w_hi, const void* w_lo, const float* bias, const float* rowmask,
+                     float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_linear_splitk(int M, int N, int K, int nsplit, const float* A, int lda, const void* W, int ldw, const float* bias,
                      const float* rowmask, float* parts, long part_stride, int ldo, hipStream_t st);
 int fd_layernorm(int M, int D, const float* x, int ldx, const float* residual, int ldr, const float* gamma,

@@ -26,6 +26,7 @@ struct Switches {
   bool no_rowblock = false;     // node path as GEMM + LayerNorm launches (the non-reference-width path)
   bool no_chain = false;
   bool no_splitk = false;
+  bool no_outproj = false;      // the generic split-K kernel instead of outproj_split_kernel (A/B, FDIPT_NO_OUTPROJ)
   bool no_et_bias = false, no_ee_bias = false;  // pair bias as its own pass over z
   bool feats_unfused = false, torf_unfused = false, init_unfused = false, skip_per_block = false, post_unfused = false,
        no_tfmr_tail = false, et4_rows_unfused = false, no_qkv_fuse = false, proj_v1 = false, feats_f32 = false,
@@ -47,7 +48,7 @@ static const Switches& dev_switches() {
 #ifdef FDIPT_DEV
     auto on = [](const char* n) { return getenv(n) != nullptr; };
     s.generic_pair = on("FDIPT_ET_V1"); s.et3 = on("FDIPT_ET_V3"); s.generic_attn = on("FDIPT_ATTN_V1");
-    s.no_rowblock = on("FDIPT_NO_ROWBLOCK"); s.no_chain = on("FDIPT_NO_CHAIN"); s.no_splitk = on("FDIPT_NO_SPLITK");
+    s.no_rowblock = on("FDIPT_NO_ROWBLOCK"); s.no_chain = on("FDIPT_NO_CHAIN"); s.no_splitk = on("FDIPT_NO_SPLITK"); s.no_outproj = on("FDIPT_NO_OUTPROJ");
     s.no_et_bias = on("FDIPT_NO_ET_BIAS"); s.no_ee_bias = on("FDIPT_NO_EE_BIAS"); s.feats_unfused = on("FDIPT_FEATS_UNFUSED");
     s.torf_unfused = on("FDIPT_TORF_UNFUSED"); s.init_unfused = on("FDIPT_INIT_UNFUSED");
     s.skip_per_block = on("FDIPT_SKIP_PER_BLOCK"); s.post_unfused = on("FDIPT_POST_UNFUSED");
@@ -167,7 +168,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wq_m, wproj2_img, wproj2_img_lo, bproj2, wout_m, bout_m, wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo; DChain ch; DSplit lo; };
+struct DBlock { size_t wq_m, wproj2_img, wproj2_img_lo, bproj2, wout_m, bout_m, wout_img, wout_img_lo, wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo; DChain ch; DSplit lo; };
 struct DLayout {
   size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -226,6 +227,9 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       L.blk[b].bproj2 = o; o = al256(o + (size_t)n2 * 4);
       L.blk[b].wout_m = o; o = al256(o + (size_t)d->c_s * iv.feat_dim * 4);
       L.blk[b].bout_m = o; o = al256(o + (size_t)d->c_s * 4);
+      // ... and the merged linear_out as hi / lo fragment images (gemm.hip: outproj_split_kernel)
+      L.blk[b].wout_img = o; if (fd_outproj_split_supported(d->c_s, iv.feat_dim)) o = al256(o + fd_chain_image_bytes(d->c_s, iv.feat_dim));
+      L.blk[b].wout_img_lo = o; if (fd_outproj_split_supported(d->c_s, iv.feat_dim)) o = al256(o + fd_chain_image_bytes(d->c_s, iv.feat_dim));
     }
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
@@ -451,6 +455,10 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
       hipLaunchKernelGGL(merge_vo_kernel, dim3(512), dim3(256), 0, st, H, C, cs, iv.feat_dim, P + k.out.w, P + k.out.b, P + k.kv.w, P + k.kv.b,
                          (float*)(D + db.wout_m), (float*)(D + db.bout_m));
       FD_CHECK_LAUNCH();
+      if (fd_outproj_split_supported(cs, iv.feat_dim) &&
+          ((rc = fd_chain_build_image((const float*)(D + db.wout_m), cs, iv.feat_dim, iv.feat_dim, 0, D + db.wout_img, st)) ||
+           (rc = fd_chain_build_image_lo((const float*)(D + db.wout_m), cs, iv.feat_dim, iv.feat_dim, D + db.wout_img_lo, st))))
+        return rc;
       const int HCm = H * C, n2 = iv.proj_out - 2 * HCm;
       if ((rc = copy_cols(4, 1, k.qp.out, k.qp.out, P + k.qp.b, k.qp.out, 0, 1.f, D + db.bproj2 + (size_t)HCm * 4, st)) ||
           (rc = copy_cols(4, 1, k.kvp.out, k.kvp.out, P + k.kvp.b, k.kvp.out, 0, 1.f, D + db.bproj2 + (size_t)(HCm + k.qp.out) * 4, st)))
@@ -978,8 +986,12 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       // (70 KB of LDS per block = two blocks per CU: at B N = 2400 rows 456 blocks run in one round of the 256 CUs, 30 us;
       // 4 slices = 608 blocks need two rounds, 41 us).  The slice count must not depend on the batch size: the order of the
       // partial sums is part of a sample's result (sub-batches and sharded runs reproduce the whole-batch result bit for bit)
-      const int NS = sw.splitk_ns != 4 ? sw.splitk_ns : (split ? 3 : 4);
-      if (split)
+      const bool op_ded = split && merged && fd_outproj_split_supported(cs, iv.feat_dim) && !sw.no_outproj;
+      const int NS = op_ded ? fd_outproj_split_slices() : sw.splitk_ns != 4 ? sw.splitk_ns : (split ? 3 : 4);
+      if (op_ded)
+        TWICE("splitk", fd_outproj_split(R, cs, iv.feat_dim, F(w.feats), iv.feat_dim, D + db.wout_img, D + db.wout_img_lo, (const float*)(D + db.bout_m),
+                                         res_mask, F(w.ipa_parts), (long)R * cs, cs, st));
+      else if (split)
         TWICE("splitk", fd_linear_splitk_split(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, merged ? (const float*)(D + db.wout_m) : P + k.out.w,
                                                iv.feat_dim, merged ? (const float*)(D + db.bout_m) : P + k.out.b, res_mask, F(w.ipa_parts),
                                                (long)R * cs, cs, st));
