@@ -49,7 +49,10 @@ struct RBShape {
   static constexpr int WMAX = rb_max(KS0 * 16, rb_max(N1, N2));          // widest activation tile
   static constexpr int XROW = WMAX * 2 + 16;                              // bytes per LDS activation row
   static constexpr bool LN = (FLAGS & 4) != 0;
-  static constexpr int NTMAX = rb_max(NOUT / 32, rb_max(N1 / 32, N2 / 32));
+  static constexpr int CP = (FLAGS & 64) ? 2 : 1;                          // column parts of the LAST layer: blockIdx.y takes NOUT / CP of its
+                                                                           // columns (the hidden layers are recomputed by every part)
+  static constexpr int NTO_BLK = NOUT / 32 / CP;                           // output tiles of a block
+  static constexpr int NTMAX = rb_max(NTO_BLK, rb_max(N1 / 32, N2 / 32));
   static constexpr int NTW = (NTMAX + 3) / 4;                              // output tiles per wave
   static constexpr bool BB = (FLAGS & 8) != 0;                            // fused BackboneUpdate + compose_q_update_vec
   static constexpr bool IMG = (FLAGS & 16) != 0;                          // output = edge_transition4 fold-fragment images
@@ -58,6 +61,7 @@ struct RBShape {
   static constexpr int NCONST = N1 + N2 + NOUT + (LN ? 2 * NOUT : 0) + (BB ? 6 * NOUT : 0);  // b0 | b1 | b_out | gamma | beta | Wbb
   static constexpr size_t SMEM = (size_t)(NL > 1 ? 2 : 1) * XBUF + 4 * 32 * RB_SROW + (size_t)NCONST * 4 + 2 * 4 * 32 * 4 + 128 + (BB ? 4 * 32 * 8 * 4 : 0) + 16;
   static_assert(N1 % 32 == 0 && N2 % 32 == 0 && NOUT % 32 == 0 && NOUT <= 1024, "tile shapes");
+  static_assert(CP == 1 || ((FLAGS & 16) && N1 > 0), "column parts: image outputs (no row-wide epilogue) behind a hidden layer");
 };
 
 template <int K0, int N1, int N2, int NOUT, int FLAGS>
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   // ---- first weight tile of this wave in flight before anything else
   // weight-fragment buffers: tile u of a wave lives in buffer u % NB; wide outputs with short K (8 tiles of 8 fragments per wave)
   // keep three tiles in flight instead of one (each tile is a dependent L2 round trip otherwise)
-  constexpr int NB = (NTW >= 6 && KSMAX <= 16) ? 4 : 2;
+  constexpr int NB = ((NTW >= 6 || S::IMG) && KSMAX <= 16) ? 4 : 2;  // (image outputs: the transposed products need the two-tile form)
+  const int t0 = S::CP > 1 ? (int)blockIdx.y * S::NTO_BLK : 0;        // first output tile of this block's column part
   // split operands: a tile's hi fragments live in an even buffer, its lo fragments in the odd one behind it; NB == 4 = two
   // tiles in flight (wide outputs with short K), NB == 2 = one
   constexpr int PAIRS = NB / 2;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
   f32x16 acc[NTW];
   // one layer: tiles wave, wave+4, wave+8 (< NT) of `img` against the B fragments X[0..KS); the first tile's fragments
   // are already in Wf[0] (SPLIT: and its lo fragments in Wf[1])
-  auto layer = [&](auto KSC, auto NTC, const char* img, const char* img_lo, auto SWAPC) {
+  auto layer = [&](auto KSC, auto NTC, const char* img, const char* img_lo, auto SWAPC, int toff) {
     constexpr int KS = decltype(KSC)::value, NT = decltype(NTC)::value;
     constexpr bool SWAP = decltype(SWAPC)::value;  // operands exchanged: lane = output feature, registers = rows
     if constexpr (SPLIT && PAIRS == 1) {
@@ -181,10 +186,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
           for (int s = 0; s < KS; ++s) c = fd_mfma32(Wf[0][s], X[s], c);
 #pragma unroll
           for (int s = 0; s < KS; ++s) c = fd_mfma32(Wf[0][s], Xl[s], c);
-          if (u + 1 < NTW && T + 4 < NT) w_load(std::integral_constant<int, 0>{}, KSC, img, T + 4);
+          if (u + 1 < NTW && T + 4 < NT) w_load(std::integral_constant<int, 0>{}, KSC, img, toff + T + 4);
 #pragma unroll
           for (int s = 0; s < KS; ++s) c = fd_mfma32(Wf[1][s], X[s], c);
-          if (u + 1 < NTW && T + 4 < NT) w_load(std::integral_constant<int, 1>{}, KSC, img_lo, T + 4);
+          if (u + 1 < NTW && T + 4 < NT) w_load(std::integral_constant<int, 1>{}, KSC, img_lo, toff + T + 4);
           acc[u] = c;
         }
       });
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
         constexpr int u = decltype(U)::value, bh = 2 * (u & 1), bn = 2 * ((u + 1) & 1);
         const int T = wave + 4 * u;
         if (u + 1 < NTW && T + 4 < NT) {
-          w_load(std::integral_constant<int, bn>{}, KSC, img, T + 4);
-          w_load(std::integral_constant<int, bn + 1>{}, KSC, img_lo, T + 4);
+          w_load(std::integral_constant<int, bn>{}, KSC, img, toff + T + 4);
+          w_load(std::integral_constant<int, bn + 1>{}, KSC, img_lo, toff + T + 4);
         }
         if (T < NT) {
           f32x16 c;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     }
     auto load_tile = [&](auto V) {  // tile v of this wave -> buffer v % NB
       constexpr int v = decltype(V)::value;
-      if (v < NTW && wave + 4 * v < NT) w_load(std::integral_constant<int, v % NB>{}, KSC, img, wave + 4 * v);
+      if (v < NTW && wave + 4 * v < NT) w_load(std::integral_constant<int, v % NB>{}, KSC, img, toff + wave + 4 * v);
     };
     if constexpr (NB > 2) {  // tiles 1 .. NB-2 up front (tile 0 was requested by the caller, tile u + NB - 1 follows at tile u)
       load_tile(std::integral_constant<int, 1>{});
@@ -272,28 +277,29 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
       if constexpr (SPLIT) Xl[s] = rb_ld(buf + XLO + li * XROW + 32 * s + 16 * hi);
     }
   };
-  auto w_first = [&](auto KSC, int l) {  // first tile of layer l: in flight across the barrier
-    w_load(std::integral_constant<int, 0>{}, KSC, wimg[l], wave);
-    if constexpr (SPLIT) w_load(std::integral_constant<int, 1>{}, KSC, wlo[l], wave);
+  auto w_first = [&](auto KSC, int l, int toff) {  // first tile of layer l: in flight across the barrier
+    w_load(std::integral_constant<int, 0>{}, KSC, wimg[l], toff + wave);
+    if constexpr (SPLIT) w_load(std::integral_constant<int, 1>{}, KSC, wlo[l], toff + wave);
   };
   x_load(std::integral_constant<int, KS0>{}, xs);
+  constexpr int NTO_B = S::NTO_BLK;
   if constexpr (NL == 1) {
-    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, NTO>{}, wimg[0], wlo[0], std::false_type{});
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, NTO_B>{}, wimg[0], wlo[0], std::false_type{}, 0);
   } else {
-    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0], wlo[0], std::false_type{});
-    w_first(std::integral_constant<int, N1 / 16>{}, 1);
+    layer(std::integral_constant<int, KS0>{}, std::integral_constant<int, N1 / 32>{}, wimg[0], wlo[0], std::false_type{}, 0);
+    w_first(std::integral_constant<int, N1 / 16>{}, 1, NL == 2 ? t0 : 0);
     to_hidden(std::integral_constant<int, N1 / 32>{}, std::integral_constant<bool, (FLAGS & 1) != 0>{}, cst, hs, a.hid_h16, N1);
     __syncthreads();
     x_load(std::integral_constant<int, N1 / 16>{}, hs);
     if constexpr (NL == 2) {
-      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, NTO>{}, wimg[1], wlo[1], std::integral_constant<bool, S::IMG>{});
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, NTO_B>{}, wimg[1], wlo[1], std::integral_constant<bool, S::IMG>{}, t0);
     } else {
-      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1], wlo[1], std::false_type{});
-      w_first(std::integral_constant<int, N2 / 16>{}, 2);
+      layer(std::integral_constant<int, N1 / 16>{}, std::integral_constant<int, N2 / 32>{}, wimg[1], wlo[1], std::false_type{}, 0);
+      w_first(std::integral_constant<int, N2 / 16>{}, 2, 0);
       to_hidden(std::integral_constant<int, N2 / 32>{}, std::integral_constant<bool, (FLAGS & 2) != 0>{}, cst + N1, xs, nullptr, 0);  // xs is free again
       __syncthreads();
       x_load(std::integral_constant<int, N2 / 16>{}, xs);
-      layer(std::integral_constant<int, N2 / 16>{}, std::integral_constant<int, NTO>{}, wimg[2], wlo[2], std::false_type{});
+      layer(std::integral_constant<int, N2 / 16>{}, std::integral_constant<int, NTO_B>{}, wimg[2], wlo[2], std::false_type{}, 0);
     }
   }
   if constexpr (S::IMG) {
@@ -309,7 +315,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void rowblock_kernel(RowBlockArgs a)
     half_t* ib = (half_t*)a.img_b;
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
-      const int T = wave + 4 * u;
+      if (wave + 4 * u >= NTO_B) continue;
+      const int T = t0 + wave + 4 * u;
       const float bv = bo[32 * T + li];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -809,7 +816,7 @@ static int rb_launch(const RowBlockArgs& a, hipStream_t st) {
       return FDIPT_ELAUNCH;
     attr_dev.set(dev_, 1);
   }
-  hipLaunchKernelGGL((rowblock_kernel<K0, N1, N2, NOUT, FLAGS>), dim3(cdiv(a.M, 32)), dim3(FD_THREADS), S::SMEM, st, a);
+  hipLaunchKernelGGL((rowblock_kernel<K0, N1, N2, NOUT, FLAGS>), dim3(cdiv(a.M, 32), S::CP), dim3(FD_THREADS), S::SMEM, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -835,7 +842,8 @@ int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st) {
       if (!a.img_a || !a.img_b || (a.img_N & 3) || a.M != a.img_B * a.img_N) return FDIPT_EINVAL;
       // split operands (w0l / w1l): e = initial_embed(node) and the four per-residue products to fp32 accuracy before the rows are
       // rounded to the fold fragments — these rows are shared by all pairs of a residue, their errors do not average out over keys
-      if (a.w0l && a.w1l) return rb_launch<256, 128, 0, 1024, 16 | 32>(a, st);
+      // ... in two column parts ([A1 | Af] and [B1 | Bf]: 150 blocks, four instead of eight output tiles per wave)
+      if (a.w0l && a.w1l) return rb_launch<256, 128, 0, 1024, 16 | 32 | 64>(a, st);
       return rb_launch<256, 128, 0, 1024, 16>(a, st);
     default: return FDIPT_EINVAL;
   }
