@@ -31,6 +31,61 @@ __device__ __forceinline__ void stage_tile_T(typename P::T* dst, const float* __
   }
 }
 
+// Register-staged halves of stage_tile / stage_tile_T for fp32 sources: the global loads of k-tile t + 1 are issued before the matrix
+// instructions of k-tile t and stored to LDS after them (round 3: the unpipelined load -> LDS -> barrier -> MFMA -> barrier loop exposed
+// a full memory round trip per k-tile, 128 of them per block at N = 1000: 9x the matrix time).
+template <int ROWS, int BK>
+struct StageRegs { f32x4 v[(ROWS * (BK / 4) + FD_THREADS - 1) / FD_THREADS]; };
+template <class P, int ROWS>
+__device__ __forceinline__ void stage_load(StageRegs<ROWS, P::BK>& R, const float* __restrict__ src, long ld, int row0, int nrows, int k0, int K, int tid) {
+  constexpr int VPR = P::BK / 4, NV = (ROWS * VPR + FD_THREADS - 1) / FD_THREADS;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int v = tid + u * FD_THREADS, r = v / VPR, kk = (v % VPR) * 4;
+    R.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (v < ROWS * VPR && row0 + r < nrows && k0 + kk < K) R.v[u] = *(const f32x4*)(src + (long)(row0 + r) * ld + k0 + kk);
+  }
+}
+template <class P, int ROWS>
+__device__ __forceinline__ void stage_store(typename P::T* dst, const StageRegs<ROWS, P::BK>& R, int tid) {
+  constexpr int LDT = P::BK + P::PAD, VPR = P::BK / 4, NV = (ROWS * VPR + FD_THREADS - 1) / FD_THREADS;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int v = tid + u * FD_THREADS, r = v / VPR, kk = (v % VPR) * 4;
+    if (v < ROWS * VPR) {
+      typename P::T* d = dst + r * LDT + kk;
+      if constexpr (sizeof(typename P::T) == 4) {
+        d[0] = R.v[u][0]; d[1] = R.v[u][1]; d[2] = R.v[u][2]; d[3] = R.v[u][3];
+      } else {
+        const u16x4 h = {f2h(R.v[u][0]), f2h(R.v[u][1]), f2h(R.v[u][2]), f2h(R.v[u][3])};
+        *(u16x4*)d = h;
+      }
+    }
+  }
+}
+// transposing: Ws[n][kk] = src[(k0 + kk) * ld + n0 + n], kk < BK, n < TN
+template <class P, int TN>
+__device__ __forceinline__ void stage_load_T(StageRegs<P::BK, TN>& R, const float* __restrict__ src, long ld, int k0, int Kmax, int n0, int Nmax, int tid) {
+  constexpr int VPR = TN / 4, NV = (P::BK * VPR + FD_THREADS - 1) / FD_THREADS;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int v = tid + u * FD_THREADS, r = v / VPR, c4 = (v % VPR) * 4;
+    R.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (v < P::BK * VPR && k0 + r < Kmax && n0 + c4 < Nmax) R.v[u] = *(const f32x4*)(src + (long)(k0 + r) * ld + n0 + c4);
+  }
+}
+template <class P, int TN>
+__device__ __forceinline__ void stage_store_T(typename P::T* dst, const StageRegs<P::BK, TN>& R, int tid) {
+  constexpr int LDT = P::BK + P::PAD, VPR = TN / 4, NV = (P::BK * VPR + FD_THREADS - 1) / FD_THREADS;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int v = tid + u * FD_THREADS, r = v / VPR, c4 = (v % VPR) * 4;
+    if (v < P::BK * VPR)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) dst[(c4 + qd) * LDT + r] = P::from_f32(R.v[u][qd]);
+  }
+}
+
 template <class P, bool IPA>
 __global__ __launch_bounds__(FD_THREADS) void attn_kernel(AttnArgs a) {
   constexpr int LDT = P::BK + P::PAD;
@@ -63,10 +118,18 @@ __global__ __launch_bounds__(FD_THREADS) void attn_kernel(AttnArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    StageRegs<32, P::BK> ra;
+    StageRegs<TN, P::BK> rw;
+    stage_load<P, 32>(ra, qbase, a.q_ld, i0, N, 0, a.C, tid);
+    stage_load<P, TN>(rw, kbase, a.k_ld, j0, N, 0, a.C, tid);
     for (int k0 = 0; k0 < a.C; k0 += P::BK) {
-      stage_tile<P, float, 32>(As, qbase, a.q_ld, i0, N, k0, a.C, tid);
-      stage_tile<P, float, TN>(Ws, kbase, a.k_ld, j0, N, k0, a.C, tid);
+      stage_store<P, 32>(As, ra, tid);
+      stage_store<P, TN>(Ws, rw, tid);
       __syncthreads();
+      if (k0 + P::BK < a.C) {  // the next k-tile's rows travel under this tile's products
+        stage_load<P, 32>(ra, qbase, a.q_ld, i0, N, k0 + P::BK, a.C, tid);
+        stage_load<P, TN>(rw, kbase, a.k_ld, j0, N, k0 + P::BK, a.C, tid);
+      }
       wave_mma<P>(acc, As + (lane & 31) * LDT, Ws + (wave * 32 + (lane & 31)) * LDT, lane);
       __syncthreads();
     }
@@ -217,9 +280,12 @@ __global__ __launch_bounds__(FD_THREADS) void attn_kernel(AttnArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    StageRegs<P::BK, TN> rv;
+    stage_load_T<P, TN>(rv, vbase, a.v_ld, 0, N, d0, a.Dv, tid);
     for (int k0 = 0; k0 < N; k0 += P::BK) {
-      stage_tile_T<P, TN>(Ws, vbase, a.v_ld, k0, N, d0, a.Dv, tid);
+      stage_store_T<P, TN>(Ws, rv, tid);
       __syncthreads();
+      if (k0 + P::BK < N) stage_load_T<P, TN>(rv, vbase, a.v_ld, k0 + P::BK, N, d0, a.Dv, tid);
       wave_mma<P>(acc, Pm + (lane & 31) * ldp + k0, Ws + (wave * 32 + (lane & 31)) * LDT, lane);
       __syncthreads();
     }
