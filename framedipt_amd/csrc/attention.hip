@@ -31,38 +31,7 @@ __device__ __forceinline__ void stage_tile_T(typename P::T* dst, const float* __
   }
 }
 
-// Register-staged halves of stage_tile / stage_tile_T for fp32 sources: the global loads of k-tile t + 1 are issued before the matrix
-// instructions of k-tile t and stored to LDS after them (round 3: the unpipelined load -> LDS -> barrier -> MFMA -> barrier loop exposed
-// a full memory round trip per k-tile, 128 of them per block at N = 1000: 9x the matrix time).
-template <int ROWS, int BK>
-struct StageRegs { f32x4 v[(ROWS * (BK / 4) + FD_THREADS - 1) / FD_THREADS]; };
-template <class P, int ROWS>
-__device__ __forceinline__ void stage_load(StageRegs<ROWS, P::BK>& R, const float* __restrict__ src, long ld, int row0, int nrows, int k0, int K, int tid) {
-  constexpr int VPR = P::BK / 4, NV = (ROWS * VPR + FD_THREADS - 1) / FD_THREADS;
-#pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const int v = tid + u * FD_THREADS, r = v / VPR, kk = (v % VPR) * 4;
-    R.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (v < ROWS * VPR && row0 + r < nrows && k0 + kk < K) R.v[u] = *(const f32x4*)(src + (long)(row0 + r) * ld + k0 + kk);
-  }
-}
-template <class P, int ROWS>
-__device__ __forceinline__ void stage_store(typename P::T* dst, const StageRegs<ROWS, P::BK>& R, int tid) {
-  constexpr int LDT = P::BK + P::PAD, VPR = P::BK / 4, NV = (ROWS * VPR + FD_THREADS - 1) / FD_THREADS;
-#pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const int v = tid + u * FD_THREADS, r = v / VPR, kk = (v % VPR) * 4;
-    if (v < ROWS * VPR) {
-      typename P::T* d = dst + r * LDT + kk;
-      if constexpr (sizeof(typename P::T) == 4) {
-        d[0] = R.v[u][0]; d[1] = R.v[u][1]; d[2] = R.v[u][2]; d[3] = R.v[u][3];
-      } else {
-        const u16x4 h = {f2h(R.v[u][0]), f2h(R.v[u][1]), f2h(R.v[u][2]), f2h(R.v[u][3])};
-        *(u16x4*)d = h;
-      }
-    }
-  }
-}
+// (StageRegs / stage_load / stage_store: common.hpp)
 // transposing: Ws[n][kk] = src[(k0 + kk) * ld + n0 + n], kk < BK, n < TN
 template <class P, int TN>
 __device__ __forceinline__ void stage_load_T(StageRegs<P::BK, TN>& R, const float* __restrict__ src, long ld, int k0, int Kmax, int n0, int Nmax, int tid) {

@@ -331,6 +331,8 @@ int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st);
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
 int fd_opair_mfma_eligible(int precision, const OPairArgs& a);  // the MFMA kernel will run (it can take probs_h16)
 int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, int frag, hipStream_t st);
+// fp32 mode: out[p, h] = z[p, :] . Wb[h, :] + bb[h] over the fp32 pair representation (H = 8, c_z = 128), one streaming pass
+int fd_pair_bias_f32(long n_pairs, int H, int CZ, const float* z, const float* wb, const float* bb, float* out, hipStream_t st);
 int fd_points(const PointsArgs& a, hipStream_t st);
 int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask, hipStream_t st);
 int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,

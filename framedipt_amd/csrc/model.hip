@@ -970,7 +970,10 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       aa.bias = F(w.bias); aa.res_mask = res_mask; aa.qp = F(w.qp); aa.kp = F(w.kp); aa.vp = F(w.vp); aa.Pq = Pq; aa.Pv = Pv;
       aa.gamma = (const float*)(D + db.gamma); aa.rot = F(w.rot); aa.trans = F(w.trans); aa.probs = F(w.probs);
       aa.out = F(w.feats); aa.out_ld = iv.feat_dim; aa.pt_off = H * C; aa.lds_s = 0;
-      RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
+      if (prec == FDIPT_PREC_F32 && H == 8 && cz == 128)
+        RC(fd_pair_bias_f32((long)NN, H, cz, F(w.z), (const float*)(D + db.wb), (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
+      else
+        RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
       RC(fd_attention(prec, 1, aa, st));
     }
     if (op.kind == OP_IPA && sw.ipa_stop == 2) return FD_STOP;

@@ -58,3 +58,74 @@ int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const floa
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+
+// ------------------------------------------------------------------ fp32 mode: linear_b over the fp32 pair representation
+// out[p, h] = sum_c z[p, c] Wb[h, c] + bb[h]   ([B, N, N, H] = the layout attn_kernel<PrecF32> reads), H = 8, c_z = 128.
+// The tiled GEMM spent 1.04 ms per call at N = 1000, B = 4 on it (8 of 64 tile columns used, 2 GB of z at 2 TB/s); this is the
+// one pass over z it has to be: 16 lanes share a pair row (32 B per lane: a wave reads 2 KB of consecutive pairs per step),
+// 8 heads x 8 channels of Wb live in registers, the 16 partial sums of a head meet in a 4-step exchange in which every lane
+// gives away half of its heads per step (8 cross-lane moves instead of 32), lanes 0, 2, .. of a group store the row's 8 values.
+__device__ __forceinline__ float pb_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+__global__ __launch_bounds__(FD_THREADS) void pair_bias_f32_kernel(long n_pairs, const float* __restrict__ z, const float* __restrict__ wb,
+                                                                   const float* __restrict__ bb, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4;
+  float w[8][8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const f32x4 a = *(const f32x4*)(wb + h * 128 + 8 * l), b = *(const f32x4*)(wb + h * 128 + 8 * l + 4);
+    w[h][0] = a[0]; w[h][1] = a[1]; w[h][2] = a[2]; w[h][3] = a[3]; w[h][4] = b[0]; w[h][5] = b[1]; w[h][6] = b[2]; w[h][7] = b[3];
+  }
+  // after the exchange lane l holds head hsel: bit 2 from l & 8, bit 1 from l & 4, bit 0 from l & 2
+  const int hsel = ((l >> 3) & 1) * 4 + ((l >> 2) & 1) * 2 + ((l >> 1) & 1);
+  const float bias = bb[hsel];
+  const long n_quads = (n_pairs + 3) >> 2;
+  const long wave_id = (long)blockIdx.x * (FD_THREADS / 64) + (threadIdx.x >> 6), n_waves = (long)gridDim.x * (FD_THREADS / 64);
+  constexpr int U = 4;  // quads in flight per wave
+  for (long q0 = wave_id * U; q0 < n_quads; q0 += n_waves * U) {
+    f32x4 x[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long p = (q0 + u) * 4 + g;
+      if (p > n_pairs - 1) p = n_pairs - 1;
+      x[u][0] = *(const f32x4*)(z + p * 128 + 8 * l);
+      x[u][1] = *(const f32x4*)(z + p * 128 + 8 * l + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        float a = x[u][0][0] * w[h][0];
+        a = fmaf(x[u][0][1], w[h][1], a); a = fmaf(x[u][0][2], w[h][2], a); a = fmaf(x[u][0][3], w[h][3], a);
+        a = fmaf(x[u][1][0], w[h][4], a); a = fmaf(x[u][1][1], w[h][5], a); a = fmaf(x[u][1][2], w[h][6], a); a = fmaf(x[u][1][3], w[h][7], a);
+        s[h] = a;
+      }
+      // step 1 (lanes 8 apart): keep heads 4..7 if l & 8 else 0..3
+      float t4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float keep = (l & 8) ? s[4 + k] : s[k], give = (l & 8) ? s[k] : s[4 + k];
+        t4[k] = keep + pb_xor(give, 8);
+      }
+      float t2[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float keep = (l & 4) ? t4[2 + k] : t4[k], give = (l & 4) ? t4[k] : t4[2 + k];
+        t2[k] = keep + pb_xor(give, 4);
+      }
+      const float keep1 = (l & 2) ? t2[1] : t2[0], give1 = (l & 2) ? t2[0] : t2[1];
+      float t1 = keep1 + pb_xor(give1, 2);
+      t1 += pb_xor(t1, 1);
+      const long p = (q0 + u) * 4 + g;
+      if (!(l & 1) && p < n_pairs) out[p * 8 + hsel] = t1 + bias;
+    }
+  }
+}
+int fd_pair_bias_f32(long n_pairs, int H, int CZ, const float* z, const float* wb, const float* bb, float* out, hipStream_t st) {
+  if (H != 8 || CZ != 128 || n_pairs <= 0) return FDIPT_EINVAL;
+  const long n_quads = (n_pairs + 3) / 4, want = (n_quads + 15) / 16;
+  const int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(pair_bias_f32_kernel, dim3(grid), dim3(FD_THREADS), 0, st, n_pairs, z, wb, bb, out);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

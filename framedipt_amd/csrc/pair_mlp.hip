@@ -30,6 +30,18 @@ __device__ __forceinline__ void act_gemm(f32x16& acc, const typename P::T* act, 
   const int wr = wave / WC, wc = wave % WC;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if constexpr (sizeof(WT) == 4) {  // fp32 weights: the next k-tile's rows travel under this tile's products (common.hpp: StageRegs)
+    StageRegs<32 * WC, P::BK> rw;
+    stage_load<P, 32 * WC>(rw, W, ldw, n0, n_rows_w, 0, K, tid);
+    for (int k0 = 0; k0 < K; k0 += P::BK) {
+      stage_store<P, 32 * WC>(Ws, rw, tid);
+      __syncthreads();
+      if (k0 + P::BK < K) stage_load<P, 32 * WC>(rw, W, ldw, n0, n_rows_w, k0 + P::BK, K, tid);
+      wave_mma<P>(acc, act + (wr * 32 + (lane & 31)) * lda + k0, Ws + (wc * 32 + (lane & 31)) * LDT, lane);
+      __syncthreads();
+    }
+    return;
+  }
   for (int k0 = 0; k0 < K; k0 += P::BK) {
     stage_tile<P, WT, 32 * WC>(Ws, W, ldw, n0, n_rows_w, k0, K, tid);
     __syncthreads();
