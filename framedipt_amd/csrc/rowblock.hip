@@ -484,7 +484,14 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   const int row0 = blockIdx.x * 32;
   char* stg = st_all + wave * 32 * RB_SROW;
   FD_STAMP(0);
-  hx8 Wf[2][TL_KS];
+  // SPLIT: THREE fragment buffers.  Tile u of a wave has its hi fragments in buffer (2 u) % 3 and its lo fragments in (2 u + 1) % 3; the
+  // third buffer is free while tile u runs and takes tile u + 1's hi fragments at the START of tile u, the lo fragments follow into the hi
+  // buffer once tile u's hi products are done: every fragment load has a whole tile (60 matrix instructions) of lead instead of the 20 lo
+  // products.  The 80 registers come from the lo parts of the activation fragments, which the hi x lo pass now reads from LDS (a 3-deep
+  // ring, one read per product).  Measured (tools/micro/tt_bench.hip 1): the three stages 9.9 / 9.5 / 8.7 k -> 9.0 / 9.0 / 8.5 k cycles,
+  // 24.3 -> 23.0 us stand-alone — the lead was not what bounds a stage: 400 KB of hi + lo fragments per block and stage through the
+  // CU's 64 B/clk L2 path are 6.4 k cycles next to 5.8 k of matrix work.
+  hx8 Wf[SPLIT ? 3 : 2][TL_KS];
   auto w_load = [&](auto BUF, const char* img, int T) {
     constexpr int bf = decltype(BUF)::value;
 #pragma unroll
@@ -559,36 +566,45 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   __syncthreads();
   FD_STAMP(1);
   hx8 X[TL_KS];
-  hx8 Xl[SPLIT ? TL_KS : 1];
   f32x16 acc[3], xa[3];
+  const char* xl_base = nullptr;  // SPLIT: this lane's lo fragments of the current stage input (LDS)
   auto x_load = [&](const char* buf) {
 #pragma unroll
-    for (int s = 0; s < TL_KS; ++s) {
-      X[s] = rb_ld(buf + li * TL_XROW + 32 * s + 16 * hi);
-      if constexpr (SPLIT) Xl[s] = rb_ld(buf + XLO + li * TL_XROW + 32 * s + 16 * hi);
-    }
+    for (int s = 0; s < TL_KS; ++s) X[s] = rb_ld(buf + li * TL_XROW + 32 * s + 16 * hi);
+    xl_base = buf + XLO + li * TL_XROW + 16 * hi;
   };
   auto layer = [&](const void* img_, const void* img_lo_, auto NTC) {
     constexpr int NT = decltype(NTC)::value, NU = (NT + 3) / 4;
     const char* img = (const char*)img_;
     const char* img_lo = (const char*)img_lo_;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    ch_rb_for<NU>([&](auto U) {
+      constexpr int u = decltype(U)::value;
       const int T = wave + 4 * u;
       const bool more = u + 1 < NU && T + 4 < NT;
-      if constexpr (SPLIT) {  // Whi.xhi + Whi.xlo out of buffer 0, Wlo.xhi out of buffer 1 (see rowblock_kernel)
+      if constexpr (SPLIT) {  // Whi.xhi + Whi.xlo out of buffer HB, Wlo.xhi out of buffer LB; the free buffer takes the next hi fragments
+        constexpr int HB = (2 * u) % 3, LB = (2 * u + 1) % 3, FB = (2 * u + 2) % 3;
+        if (more) w_load(std::integral_constant<int, FB>{}, img, T + 4);
         if (T < NT) {
           f32x16 c;
 #pragma unroll
           for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[0][s], X[s], c);
+          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[HB][s], X[s], c);
+          {  // hi x lo: the lo fragments of the activations from LDS, three reads in flight
+            hx8 xr[3];
+            xr[0] = rb_ld(xl_base);
+            xr[1] = rb_ld(xl_base + 32);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[0][s], Xl[s], c);
-          if (more) w_load(std::integral_constant<int, 0>{}, img, T + 4);
+            for (int s = 0; s < TL_KS; ++s) {
+              if (s + 2 < TL_KS) xr[(s + 2) % 3] = rb_ld(xl_base + 32 * (s + 2));
+              c = fd_mfma32(Wf[HB][s], xr[s % 3], c);
+              __builtin_amdgcn_sched_barrier(0);  // pin: one read, one product per k-step (hipcc otherwise sinks the reads to their uses)
+            }
+          }
+          if (more) w_load(std::integral_constant<int, HB>{}, img_lo, T + 4);
 #pragma unroll
-          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[1][s], X[s], c);
-          if (more) w_load(std::integral_constant<int, 1>{}, img_lo, T + 4);
+          for (int s = 0; s < TL_KS; ++s) c = fd_mfma32(Wf[LB][s], X[s], c);
           acc[u] = c;
         }
       } else {
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
           acc[u] = c;
         }
       }
-    }
+    });
   };
   constexpr std::integral_constant<int, TL_NT> NT_D{};
   // LayerNorm of the rows held as acc[] (lane = row, this wave's tiles) -> normalised values back in acc[]
