@@ -170,17 +170,24 @@ class StreamedLoops:
     trajectory is bit-identical whatever batch it rides in (tests: test_batch_of_equal_samples_matches_single,
     test_concurrent_forwards_are_bit_identical).  Same interface as ``ReverseLoop`` (prime / step / results)."""
 
-    MAX_STREAMS = 2  # experimental feature, verified for two streams only (see below)
+    MAX_STREAMS = 2   # experimental feature, verified for two streams only (see below)
+    MAX_LENGTH = 384  # ... and for N <= 384 only
 
     def __init__(self, model, diffuser, data_init, n_streams, num_t, min_t, noise_tape=None, reserve_cus=48, **kw):
-        # Round-3 soak (tools/soak_streams.sh, tools/streams_stat.py: 120-step trajectories at N = 300 against the single-stream run):
-        # two streams 0 mismatching runs of ~150; THREE or FOUR streams 15 - 40 % of the runs differ in one sample by <= 6e-3 A from
-        # some step on (never with FDIPT_KF_NO_SPLIT; bisected to runs in which the eight-wave split projection kernel is present,
-        # not to a store width, not to workspace contents: tests/test_gpu_robustness.py) — unresolved, so more than two streams are
-        # refused rather than offered.  Two streams gave the measured gain anyway (three / four were slower, DESIGN.md section 5).
+        # Soak results (tools/soak_streams.sh, tools/streams_stat.py; trajectories against the single-stream run, DESIGN.md section 5):
+        #   * N = 128 / 300, two streams, any number of reserved CUs: 0 mismatching runs of ~400;
+        #   * N = 300, three or four streams: 15 - 40 % of the runs differ in one sample from some step on;
+        #   * N = 512 / 724 / 1000, two streams: 1 / 12, 3 / 12, up to 11 / 12 mismatching runs depending on `reserve_cus` (end of round 3).
+        # What goes wrong there is ONE residue's rotation score in ONE step (its inputs in memory are intact, the forward's other outputs of
+        # that step are bit-identical), while the other stream's EdgeTransition runs on the rest of the chip; a library built with
+        # `-mllvm -amdgpu-waitcnt-forcezero` does not show it; not localised further.  The single-stream path is bit-reproducible at every
+        # size.  So: refused beyond what the soaks cover rather than offered.
         if n_streams > self.MAX_STREAMS:
             raise ValueError(f"streams={n_streams}: sub-batch streams are verified bit-identical to the single-stream run for at most "
                              f"{self.MAX_STREAMS} streams")
+        if n_streams > 1 and data_init["rigids_t"].shape[1] > self.MAX_LENGTH:
+            raise ValueError(f"streams={n_streams} at N = {data_init['rigids_t'].shape[1]}: sub-batch streams are verified bit-identical to "
+                             f"the single-stream run for N <= {self.MAX_LENGTH} only")
         B = data_init["rigids_t"].shape[0]
         n_streams = max(1, min(n_streams, B))
         cuts = [round(i * B / n_streams) for i in range(n_streams + 1)]

@@ -146,6 +146,23 @@ def test_streamed_sub_batches_match_the_single_stream_trajectory():
         np.testing.assert_array_equal(host(one[k]), host(two[k]), err_msg=k)
 
 
+def test_sub_batch_streams_are_refused_beyond_the_verified_range():
+    """More than two streams, or two streams at N > 384, are refused (soak results in inference.StreamedLoops / DESIGN.md section 5)."""
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.inference import inference_fn
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
+    for n, streams in ((64, 3), (388, 2)):
+        ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": 4}), d, "cuda")
+        feats, tape = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, 3, 0.01) for i in range(4)])
+        with pytest.raises(ValueError, match="verified bit-identical"):
+            inference_fn(net, d, feats, num_t=3, min_t=0.01, noise_tape=tape, streams=streams)
+
+
 def test_edge_transition_clock_probe():
     """FdiptForwardArgs.clock_out (bench.py's ``roofline.clock_ghz``): opt-in and caller-owned.  With the buffer set, a forward at
     N % 4 == 0 counts the blocks of the num_blocks - 1 EdgeTransition launches and the cycle / tick ratio is a plausible shader
