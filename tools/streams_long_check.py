@@ -3,6 +3,8 @@ sys.path.insert(0, '/root/repo')
 from framedipt_amd import config, sharding
 from framedipt_amd.diffusion import SE3Diffuser
 from framedipt_amd.inference import inference_fn
+from framedipt_amd import inference as _inf
+_inf.StreamedLoops.MAX_LENGTH = 1 << 30  # (investigation tool: the product refuses N > 384 on sub-batch streams)
 from framedipt_amd.model import ScoreNetwork
 from framedipt_amd.sampler import UnconditionalSampler
 N, B, T = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (300, 8, 100)
