@@ -275,8 +275,11 @@ struct TfmrTailArgs {
   float* pout = nullptr;
   int ld_pres = 0, ld_pout = 0;
   L2Warm warm;                    // weights of the kernel launched next (touched once the block's own first loads are out)
+  int rows16 = 0;                 // 1: 16-row blocks (tfmr_tail16_kernel, split operands only): wo / w1 / w2 / wp and their lo images are
+                                  // fd_chain_build_image16 images
 };
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st);
+int fd_chain_build_image16(const float* w, int N, int K, int ldw, int lo, void* img, hipStream_t st);
 
 struct ChainArgs {
   int M;

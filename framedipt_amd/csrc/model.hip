@@ -26,6 +26,7 @@ struct Switches {
   bool no_rowblock = false;     // node path as GEMM + LayerNorm launches (the non-reference-width path)
   bool no_chain = false;
   bool no_splitk = false;
+  bool no_tail16 = false;       // the 32-row tail kernel instead of tfmr_tail16_kernel (A/B, FDIPT_NO_TAIL16)
   bool no_outproj = false;      // the generic split-K kernel instead of outproj_split_kernel (A/B, FDIPT_NO_OUTPROJ)
   bool no_et_bias = false, no_ee_bias = false;  // pair bias as its own pass over z
   bool feats_unfused = false, torf_unfused = false, init_unfused = false, skip_per_block = false, post_unfused = false,
@@ -48,7 +49,7 @@ static const Switches& dev_switches() {
 #ifdef FDIPT_DEV
     auto on = [](const char* n) { return getenv(n) != nullptr; };
     s.generic_pair = on("FDIPT_ET_V1"); s.et3 = on("FDIPT_ET_V3"); s.generic_attn = on("FDIPT_ATTN_V1");
-    s.no_rowblock = on("FDIPT_NO_ROWBLOCK"); s.no_chain = on("FDIPT_NO_CHAIN"); s.no_splitk = on("FDIPT_NO_SPLITK"); s.no_outproj = on("FDIPT_NO_OUTPROJ");
+    s.no_rowblock = on("FDIPT_NO_ROWBLOCK"); s.no_chain = on("FDIPT_NO_CHAIN"); s.no_splitk = on("FDIPT_NO_SPLITK"); s.no_outproj = on("FDIPT_NO_OUTPROJ"); s.no_tail16 = on("FDIPT_NO_TAIL16");
     s.no_et_bias = on("FDIPT_NO_ET_BIAS"); s.no_ee_bias = on("FDIPT_NO_EE_BIAS"); s.feats_unfused = on("FDIPT_FEATS_UNFUSED");
     s.torf_unfused = on("FDIPT_TORF_UNFUSED"); s.init_unfused = on("FDIPT_INIT_UNFUSED");
     s.skip_per_block = on("FDIPT_SKIP_PER_BLOCK"); s.post_unfused = on("FDIPT_POST_UNFUSED");
@@ -66,6 +67,8 @@ static const Switches& dev_switches() {
   }();
   return sw;
 }
+// shapes of tfmr_tail16_kernel: d_model 320, c_s 256 (the reference widths)
+template <class IV> static bool tail16_shapes(const FdiptDims* d, const IV& iv) { return iv.d_t == 320 && d->c_s == 256; }
 static Switches switches_of(const FdiptDims* d) {
   Switches s = dev_switches();
   const unsigned f = (unsigned)d->kernel_flags;
@@ -163,6 +166,8 @@ static inline int rup8(int x) { return (x + 7) & ~7; }
 
 struct DSplit {  // lo images (W - half(W)) of the node-path layers that run on split operands (rowblock.hip, attention_seq.hip)
   size_t inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3, et_init, r4w;
+  // 16-row images (fd_chain_build_image16) of the tail's matrices, hi then lo: out_proj, FFN 1, FFN 2 per layer, post_tfmr
+  size_t o16[FD_MAX_TL][2], f16[FD_MAX_TL][2], g16[FD_MAX_TL][2], p16[2];
 };
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
@@ -266,6 +271,10 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       for (int l = 0; l < d->tfmr_layers; ++l) { c.inp[l] = img(3 * dt, dt); c.outp[l] = img(dt, dt); c.l1[l] = img(dt, dt); c.l2[l] = img(dt, dt); }
       c.post = img(cs, dt); c.t1 = img(cs, cs); c.t2 = img(cs, cs); c.t3 = img(cs, cs);
       c.et_init = img(iv.cb, cs); c.r4w = img(2 * (iv.hid + d->c_z), iv.cb);
+      for (int h = 0; h < 2; ++h) {
+        for (int l = 0; l < d->tfmr_layers; ++l) { c.o16[l][h] = img(dt, dt); c.f16[l][h] = img(dt, dt); c.g16[l][h] = img(dt, dt); }
+        c.p16[h] = img(cs, dt);
+      }
     }
     L.lo_ne0 = img(cs, L.kn_pad); L.lo_ne2 = img(cs, cs); L.lo_ne4 = img(cs, cs); L.lo_tor1 = img(cs, cs); L.lo_tor2 = img(cs, cs);
     L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
@@ -545,6 +554,14 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
         if ((rc = lo(k.tf[l].inp, c.inp[l])) || (rc = lo(k.tf[l].outp, c.outp[l])) || (rc = lo(k.tf[l].l1, c.l1[l])) || (rc = lo(k.tf[l].l2, c.l2[l])))
           return rc;
       if ((rc = lo(k.post, c.post)) || (rc = lo(k.t1, c.t1)) || (rc = lo(k.t2, c.t2)) || (rc = lo(k.t3, c.t3))) return rc;
+      if (tail16_shapes(d, iv)) {  // 16-row images of the tail (tfmr_tail16_kernel)
+        auto i16 = [&](const LinW& l, int h, size_t off) { return fd_chain_build_image16(P + l.w, l.out, l.in, l.in, h, D + off, st); };
+        for (int h = 0; h < 2; ++h) {
+          for (int l = 0; l < d->tfmr_layers; ++l)
+            if ((rc = i16(k.tf[l].outp, h, c.o16[l][h])) || (rc = i16(k.tf[l].l1, h, c.f16[l][h])) || (rc = i16(k.tf[l].l2, h, c.g16[l][h]))) return rc;
+          if ((rc = i16(k.post, h, c.p16[h]))) return rc;
+        }
+      }
       if (b < d->num_blocks - 1) {  // EdgeTransition per-residue rows: initial_embed and the e_i / e_j columns of the first / final layers
         const size_t i1 = fd_chain_image_bytes(iv.hid, iv.cb), i2 = fd_chain_image_bytes(cz, iv.cb);
         if ((rc = lo(k.et_init, c.et_init)) ||
@@ -1004,7 +1021,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       else
         RC(fd_linear_splitk(R, cs, iv.feat_dim, NS, F(w.feats), iv.feat_dim, WM(k.out), iv.feat_dim, P + k.out.b, res_mask,
                             F(w.ipa_parts), (long)R * cs, cs, st));
-      const L2Warm warm_qkv0 = {{D + db.ch.inp[0], nullptr, nullptr}, {(unsigned)fd_chain_image_bytes(3 * dt, dt), 0, 0}};
+      // (round 3: the lo images are touched as well — a cold image is one exposed memory round trip per weight tile of the consumer)
+      const L2Warm warm_qkv0 = {{D + db.ch.inp[0], split_qkv ? D + db.lo.inp[0] : nullptr, nullptr},
+                                {(unsigned)fd_chain_image_bytes(3 * dt, dt), split_qkv ? (unsigned)fd_chain_image_bytes(3 * dt, dt) : 0u, 0}};
       RC(fd_layernorm_parts(R, cs, node_cur, cs, F(w.ipa_parts), cs, NS, (long)R * cs, P + k.ipa_ln.g, P + k.ipa_ln.b, nullptr,
                             F(w.tf_in), dt, skip_batched ? F(w.skip_all) + (size_t)b * d->c_skip : nullptr,
                             d->num_blocks * d->c_skip, d->c_skip, warm_all && seq_fused ? &warm_qkv0 : nullptr, st));
@@ -1036,6 +1055,11 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         // ... and touches the weights of the layer's tail kernel, launched next (common.hpp: L2 warm-up hand-over)
         const unsigned wimg = (unsigned)fd_chain_image_bytes(dt, dt);
         L2Warm wt = {{D + db.ch.outp[l], D + db.ch.l1[l], D + db.ch.l2n[l]}, {wimg, wimg, wimg}};
+        if (split && tail16_shapes(d, iv) && !sw.no_tail16 && (sw.split_mask & 8u))  // 16-row tail: its three hi images and its three lo images (each run contiguous)
+        {
+          const unsigned run = 3 * wimg + (l + 1 == d->tfmr_layers ? (unsigned)fd_chain_image_bytes(cs, dt) : 0u);  // (the last layer's run ends with post_tfmr)
+          wt = L2Warm{{D + db.lo.o16[l][0], D + db.lo.o16[l][1], nullptr}, {run, run, 0}};
+        }
         const bool warm_on = rbk && (sw.rb_mask & 2u) && !sw.no_tfmr_tail && warm_all;
         TWICE("sattn", fd_seq_attention_run(B, N, d->tfmr_heads, W + w.seqimg, F(w.att), dt, warm_on ? &wt : nullptr, st));
       } else {
@@ -1061,15 +1085,20 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         tt.bo = P + t.outp.b; tt.g1 = P + t.n1.g; tt.be1 = P + t.n1.b; tt.b1 = P + t.l1.b; tt.b2 = P + t.l2.b; tt.g2 = P + t.n2.g;
         tt.be2 = P + t.n2.b; tt.out = x == F(w.x_b) ? F(w.x_a) : F(w.x_b);
         if (split_tail) { tt.wol = D + db.lo.outp[l]; tt.w1l = D + db.lo.l1[l]; tt.w2l = D + db.lo.l2[l]; }
+        const bool t16 = split_tail && tail16_shapes(d, iv) && !sw.no_tail16;  // 16-row blocks (150 blocks at 2400 rows)
+        if (t16) { tt.rows16 = 1; tt.wo = D + db.lo.o16[l][0]; tt.wol = D + db.lo.o16[l][1]; tt.w1 = D + db.lo.f16[l][0]; tt.w1l = D + db.lo.f16[l][1]; tt.w2 = D + db.lo.g16[l][0]; tt.w2l = D + db.lo.g16[l][1]; }
         tt.warm = L2Warm{};  // next launch: the following layer's in_proj, or post_tfmr / the transition
         // the last layer also applies post_tfmr + the node residual (FDIPT_POST_UNFUSED: its own launch)
         const bool post_here = l + 1 == d->tfmr_layers && cs == 256 && !sw.post_unfused;
         if (post_here) {
-          tt.wp = D + db.ch.post; tt.wpl = split_tail ? D + db.lo.post : nullptr; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
+          tt.wp = t16 ? D + db.lo.p16[0] : D + db.ch.post; tt.wpl = t16 ? D + db.lo.p16[1] : split_tail ? D + db.lo.post : nullptr; tt.bp = P + k.post.b; tt.pres = F(w.tf_in); tt.ld_pres = dt; tt.pout = F(w.h_a); tt.ld_pout = cs;
           post_done = true;
         }
         const unsigned tb = (unsigned)fd_chain_image_bytes(cs, cs);
-        if (warm_all && l + 1 < d->tfmr_layers && seq_fused) { tt.warm.p[0] = D + db.ch.inp[l + 1]; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(3 * dt, dt); }
+        if (warm_all && l + 1 < d->tfmr_layers && seq_fused) {
+          tt.warm.p[0] = D + db.ch.inp[l + 1]; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(3 * dt, dt);
+          if (split_qkv) { tt.warm.p[1] = D + db.lo.inp[l + 1]; tt.warm.bytes[1] = tt.warm.bytes[0]; }
+        } else if (warm_all && post_here && split_trans) tt.warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.lo.t1}, {tb, 2 * tb, 3 * tb}};  // (t2n | t3n and lo t1 | t2 | t3 are contiguous)
         else if (warm_all && post_here) tt.warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.ch.t3n}, {tb, tb, tb}};
         else if (warm_all && l + 1 == d->tfmr_layers) { tt.warm.p[0] = D + db.ch.post; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(cs, dt); }
         TWICE("tail", fd_tfmr_tail(tt, st));
@@ -1120,10 +1149,12 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       r.upd_mask = F(w.dmask); r.quat = F(w.quat); r.trans = F(w.trans); r.out2 = nullptr; r.ld_out2 = r.split = 0;
       r.hid_h16 = nullptr;
       if (warm_all && b < d->num_blocks - 1 && iv.cb == 128 && iv.hid == 384 && cz == 128)  // next: the EdgeTransition row launch
-        r.warm = L2Warm{{D + db.ch.et_init, D + db.ch.r4w, nullptr},
-                        {(unsigned)fd_chain_image_bytes(iv.cb, cs), (unsigned)fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb), 0}};
+        r.warm = L2Warm{{D + db.ch.et_init, D + db.ch.r4w, split_etrows ? D + db.lo.et_init : nullptr},  // (lo et_init | r4w are contiguous)
+                        {(unsigned)fd_chain_image_bytes(iv.cb, cs), (unsigned)fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb),
+                         split_etrows ? (unsigned)(fd_chain_image_bytes(iv.cb, cs) + fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb)) : 0u}};
       else if (warm_all && b == d->num_blocks - 1)  // ... or the torsion head
-        r.warm = L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, nullptr}, {(unsigned)fd_chain_image_bytes(cs, cs), (unsigned)fd_chain_image_bytes(cs, cs), 0}};
+        r.warm = L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, split_tors ? D + L.lo_tor1 : nullptr},  // (lo tor1 | tor2 are contiguous)
+                        {(unsigned)fd_chain_image_bytes(cs, cs), (unsigned)fd_chain_image_bytes(cs, cs), split_tors ? 2 * (unsigned)fd_chain_image_bytes(cs, cs) : 0u}};
       if (split_trans) { r.w0l = D + db.lo.t1; r.w1l = D + db.lo.t2; r.w2l = D + db.lo.t3; }
       RC(fd_rowblock(split_trans ? FD_RB_TRANSITION_BB_SPLIT : FD_RB_TRANSITION_BB, r, st));
       bb_done = true;

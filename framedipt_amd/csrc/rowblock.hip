@@ -795,6 +795,233 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
   fd_l2_warm_done(warm_tok);
 }
 
+// ------------------------------------------------------------------ the same on 16-row blocks (round 3, split operands only)
+// A stage of the 32-row kernel is bound by the CU's L2 path (400 KB of hi + lo fragments at 64 B/clk = 6.4 k cycles) next to 5.8 k cycles of
+// matrix work, 75 blocks on 256 CUs.  With 16 rows per block the same bytes feed half the matrix work on twice the CUs
+// (v_mfma_f32_16x16x32_f16: tiles of 16 features, k-steps of 32; prototype tools/micro/stage16_bench.hip: a stage 12.3 k -> 7.6 k cycles,
+// the input staging 7.3 k -> 4.2 k).  Lane = (row lane % 16, feature group lane / 16): D[feature 16 T + 4 fg + i, row]; a lane's four
+// consecutive features make its residual / output accesses 16 B pieces (64 B per row and instruction), so no exchange tile is needed;
+// LayerNorm statistics are lane-local sums + the three other feature groups (lane ^ 16, ^ 32) + the four waves through LDS.
+#define T16_KS (TL_D / 32)
+#define T16_NT (TL_D / 16)
+#define T16_XROW (TL_D * 2 + 16)
+#define T16_XLO (16 * T16_XROW)
+#define T16_SMEM (4 * T16_XLO + (7 * TL_D + TL_NP) * 4 + 2 * 4 * 16 * 4 + 16)
+template <bool POST>
+__global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                       // att rows, then hidden rows: hi rows | lo rows   [2][16][T16_XROW]
+  char* hs = xs + 2 * T16_XLO;           // x_a rows
+  float* cst = (float*)(hs + 2 * T16_XLO);  // b_o | g1 | be1 | b1 | b2 | g2 | be2 | b_post
+  float (*red)[4][16] = (float (*)[4][16])(cst + 7 * TL_D + TL_NP);  // [2][4][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, fg = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  const long grow = row0 + lr < a.M ? row0 + lr : a.M - 1;
+  typedef __attribute__((ext_vector_type(8))) _Float16 t16_h8;
+  FD_STAMP(0);
+  hx8 Wh[2][T16_KS], Wl[2][T16_KS];
+  auto w_load = [&](auto BUF, const void* img, const void* img_lo, int T) {
+    constexpr int b = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < T16_KS; ++s) {
+      Wh[b][s] = rb_ld((const char*)img + ((size_t)(T * T16_KS + s) * 64 + lane) * 16);
+      Wl[b][s] = rb_ld((const char*)img_lo + ((size_t)(T * T16_KS + s) * 64 + lane) * 16);
+    }
+  };
+  auto put4 = [&](char* buf, int off, float v0, float v1, float v2, float v3) {
+    const float v[4] = {v0, v1, v2, v3};
+    rb_hx4 pk, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pk[q] = (fd_h)v[q];
+      pl[q] = (fd_h)(v[q] - (float)pk[q]);
+    }
+    *(rb_hx4*)(buf + off) = pk;
+    *(rb_hx4*)(buf + T16_XLO + off) = pl;
+  };
+  constexpr std::integral_constant<int, 0> B0{};
+  constexpr std::integral_constant<int, 1> B1{};
+  w_load(B0, a.wo, a.wol, wave);
+  {
+    f32x4 xv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+      const int gr = row0 + r < a.M ? row0 + r : a.M - 1;
+      xv[k] = *(const f32x4*)(a.att + (long)gr * a.ld + 4 * c4);
+    }
+    {
+      constexpr int NC = 7 * TL_D + (POST ? TL_NP : 0), NCV = (NC + FD_THREADS - 1) / FD_THREADS;
+      float cv[NCV];
+#pragma unroll
+      for (int k = 0; k < NCV; ++k) {
+        const int v = tid + k * FD_THREADS, which = v / TL_D, c = v % TL_D;
+        const float* src = which == 0 ? a.bo : which == 1 ? a.g1 : which == 2 ? a.be1 : which == 3 ? a.b1 : which == 4 ? a.b2 : which == 5 ? a.g2 : a.be2;
+        cv[k] = v < 7 * TL_D ? src[c] : (POST && v < NC ? a.bp[v - 7 * TL_D] : 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < NCV; ++k)
+        if (tid + k * FD_THREADS < NC) cst[tid + k * FD_THREADS] = cv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 80, c4 = idx % 80;
+      put4(xs, r * T16_XROW + 8 * c4, xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
+    }
+  }
+  // residual x: this lane's four features of its five tiles (tile T = wave + 4 u)
+  f32x4 rv[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) rv[u] = *(const f32x4*)(a.x + grow * a.ld + 16 * (wave + 4 * u) + 4 * fg);
+  const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
+  __syncthreads();
+  FD_STAMP(1);
+  hx8 X[T16_KS];
+  const char* xl_base = nullptr;  // this lane's lo fragments of the current stage input (read from LDS by the hi x lo pass: 40 registers less)
+  auto x_load = [&](const char* buf) {
+#pragma unroll
+    for (int s = 0; s < T16_KS; ++s) X[s] = rb_ld(buf + lr * T16_XROW + (32 * s + 8 * fg) * 2);
+    xl_base = buf + T16_XLO + lr * T16_XROW + 16 * fg;
+  };
+  f32x4 acc[5], xa[5];
+  auto mma = [](hx8 w, hx8 x, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t16_h8, w), __builtin_bit_cast(t16_h8, x), c, 0, 0, 0);
+  };
+  // one stage: tiles wave, wave + 4, ... (< NT); the first tile's fragments are in buffer 0, tile u + 1 is requested when tile u starts
+  auto layer = [&](const void* img, const void* img_lo, auto NTC) {
+    constexpr int NT = decltype(NTC)::value, NU = NT / 4;
+    ch_rb_for<NU>([&](auto U) {
+      constexpr int u = decltype(U)::value, b = u & 1;
+      const int T = wave + 4 * u;
+      if constexpr (u + 1 < NU) {
+        if constexpr (b == 0) w_load(B1, img, img_lo, T + 4);
+        else w_load(B0, img, img_lo, T + 4);
+      }
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < T16_KS; ++s) c = mma(Wh[b][s], X[s], c);
+      {
+        hx8 xr[3];
+        xr[0] = rb_ld(xl_base);
+        xr[1] = rb_ld(xl_base + 64);
+#pragma unroll
+        for (int s = 0; s < T16_KS; ++s) {
+          if (s + 2 < T16_KS) xr[(s + 2) % 3] = rb_ld(xl_base + 64 * (s + 2));
+          c = mma(Wh[b][s], xr[s % 3], c);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < T16_KS; ++s) c = mma(Wl[b][s], X[s], c);
+      acc[u] = c;
+    });
+  };
+  constexpr std::integral_constant<int, T16_NT> NT_D{};
+  auto layernorm = [&](const float* gam, const float* bet) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s1 += acc[u][i];
+        s2 += acc[u][i] * acc[u][i];
+      }
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    __syncthreads();  // red[] may still be read by a slower wave from the previous LayerNorm
+    if (fg == 0) {
+      red[0][wave][lr] = s1;
+      red[1][wave][lr] = s2;
+    }
+    __syncthreads();
+    const float mu = (red[0][0][lr] + red[0][1][lr] + red[0][2][lr] + red[0][3][lr]) * (1.0f / TL_D);
+    const float ex2 = (red[1][0][lr] + red[1][1][lr] + red[1][2][lr] + red[1][3][lr]) * (1.0f / TL_D);
+    const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mu * mu, 0.f) + 1e-5f);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+      const f32x4 gm = *(const f32x4*)(gam + f0), bt = *(const f32x4*)(bet + f0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[u][i] = (acc[u][i] - mu) * rstd * gm[i] + bt[i];
+    }
+  };
+  x_load(xs);
+  // ---- stage 1: out_proj + x, LayerNorm1
+  layer(a.wo, a.wol, NT_D);
+  FD_STAMP(2);
+  w_load(B0, a.w1, a.w1l, wave);  // first feed-forward tile: in flight across the barriers
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const f32x4 bv = *(const f32x4*)(cst + 16 * (wave + 4 * u) + 4 * fg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[u][i] += bv[i] + rv[u][i];
+  }
+  layernorm(cst + TL_D, cst + 2 * TL_D);
+  FD_STAMP(3);
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    xa[u] = acc[u];
+    put4(hs, lr * T16_XROW + 2 * (16 * (wave + 4 * u) + 4 * fg), acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+  }
+  __syncthreads();
+  x_load(hs);
+  FD_STAMP(4);
+  // ---- stage 2: feed-forward
+  layer(a.w1, a.w1l, NT_D);
+  FD_STAMP(5);
+  w_load(B0, a.w2, a.w2l, wave);
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+    const f32x4 bv = *(const f32x4*)(cst + 3 * TL_D + f0);
+    // (the att rows are dead: every wave read them before LayerNorm1's barriers)
+    put4(xs, lr * T16_XROW + 2 * f0, fmaxf(acc[u][0] + bv[0], 0.f), fmaxf(acc[u][1] + bv[1], 0.f), fmaxf(acc[u][2] + bv[2], 0.f),
+         fmaxf(acc[u][3] + bv[3], 0.f));
+  }
+  __syncthreads();
+  x_load(xs);
+  FD_STAMP(6);
+  layer(a.w2, a.w2l, NT_D);
+  FD_STAMP(7);
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const f32x4 bv = *(const f32x4*)(cst + 4 * TL_D + 16 * (wave + 4 * u) + 4 * fg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[u][i] += bv[i] + xa[u][i];
+  }
+  f32x4 rvp[4];
+  if constexpr (POST) {
+    w_load(B0, a.wp, a.wpl, wave);  // first post_tfmr tile: in flight across the LayerNorm
+  }
+  layernorm(cst + 5 * TL_D, cst + 6 * TL_D);
+  FD_STAMP(8);
+  if constexpr (POST) {
+    // ---- stage 4: post_tfmr on the layer's output rows + bias + node rows
+#pragma unroll
+    for (int u = 0; u < 5; ++u)  // (the x_a rows are dead since stage 2 read them)
+      put4(hs, lr * T16_XROW + 2 * (16 * (wave + 4 * u) + 4 * fg), acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+    __syncthreads();
+    x_load(hs);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rvp[u] = *(const f32x4*)(a.pres + grow * a.ld_pres + 16 * (wave + 4 * u) + 4 * fg);  // (under the stage's products)
+    layer(a.wp, a.wpl, std::integral_constant<int, TL_NP / 16>{});
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+      const f32x4 bv = *(const f32x4*)(cst + 7 * TL_D + f0);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = acc[u][i] + bv[i] + rvp[u][i];
+      if (row0 + lr < a.M) *(f32x4*)(a.pout + (long)(row0 + lr) * a.ld_pout + f0) = o;
+    }
+    fd_l2_warm_done(warm_tok);
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < 5; ++u)
+    if (row0 + lr < a.M) *(f32x4*)(a.out + (long)(row0 + lr) * a.ld + 16 * (wave + 4 * u) + 4 * fg) = acc[u];
+  fd_l2_warm_done(warm_tok);
+}
+
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.ld & 3) || a.x == a.out) return FDIPT_EINVAL;
   static FdPerDevice attr_dev;
@@ -809,6 +1036,21 @@ int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
   }
   const bool split = a.wol != nullptr;  // split operands: every lo image must be there
   if (split && (!a.w1l || !a.w2l || (a.wp && !a.wpl))) return FDIPT_EINVAL;
+  if (a.rows16) {  // 16-row blocks (split operands, fd_chain_build_image16 images)
+    if (!split) return FDIPT_EINVAL;
+    if (a.wp && (!a.bp || !a.pres || !a.pout || (a.ld_pres & 3) || (a.ld_pout & 3))) return FDIPT_EINVAL;
+    static FdPerDevice attr16;
+    if (!attr16.get(dev_)) {
+      if (hipFuncSetAttribute((const void*)tfmr_tail16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_SMEM) != hipSuccess ||
+          hipFuncSetAttribute((const void*)tfmr_tail16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_SMEM) != hipSuccess)
+        return FDIPT_ELAUNCH;
+      attr16.set(dev_, 1);
+    }
+    if (a.wp) hipLaunchKernelGGL((tfmr_tail16_kernel<true>), dim3(cdiv(a.M, 16)), dim3(FD_THREADS), T16_SMEM, st, a);
+    else hipLaunchKernelGGL((tfmr_tail16_kernel<false>), dim3(cdiv(a.M, 16)), dim3(FD_THREADS), T16_SMEM, st, a);
+    FD_CHECK_LAUNCH();
+    return FDIPT_OK;
+  }
   if (a.wp && (!a.bp || !a.pres || !a.pout || (a.ld_pres & 3) || (a.ld_pout & 3))) return FDIPT_EINVAL;
   const dim3 grid(cdiv(a.M, 32)), block(FD_THREADS);
   if (a.wp && split) hipLaunchKernelGGL((tfmr_tail_kernel<true, true>), grid, block, TL_SMEM(1), st, a);
