@@ -259,6 +259,8 @@ struct RowBlockArgs {
 enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS, FD_RB_ET4_IMAGES,
        FD_RB_TRANSITION_BB_SPLIT, FD_RB_NODE_EMBED_72_SPLIT, FD_RB_NODE_EMBED_88_SPLIT, FD_RB_TORSION_SPLIT };
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
+// FD_RB_TRANSITION_BB_SPLIT on 16-row blocks (rowblock.hip: transition16_kernel); w0 / w1 / w2 and their lo images are fd_chain_build_image16 images
+int fd_transition16(const RowBlockArgs& a, hipStream_t st);
 
 // post-attention half of one encoder layer in one launch (rowblock.hip): x_a = LN1(x + Wo att + bo); out = LN2(x_a + W2 relu(W1 x_a + b1) + b2)
 struct TfmrTailArgs {

@@ -168,6 +168,7 @@ struct DSplit {  // lo images (W - half(W)) of the node-path layers that run on 
   size_t inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], post, t1, t2, t3, et_init, r4w;
   // 16-row images (fd_chain_build_image16) of the tail's matrices, hi then lo: out_proj, FFN 1, FFN 2 per layer, post_tfmr
   size_t o16[FD_MAX_TL][2], f16[FD_MAX_TL][2], g16[FD_MAX_TL][2], p16[2];
+  size_t tr16[3][2];  // ... of the transition's three matrices (transition16_kernel): hi run t1 | t2 | t3, then the lo run
 };
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
@@ -275,6 +276,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
         for (int l = 0; l < d->tfmr_layers; ++l) { c.o16[l][h] = img(dt, dt); c.f16[l][h] = img(dt, dt); c.g16[l][h] = img(dt, dt); }
         c.p16[h] = img(cs, dt);
       }
+      for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 3; ++i) c.tr16[i][h] = img(cs, cs);
     }
     L.lo_ne0 = img(cs, L.kn_pad); L.lo_ne2 = img(cs, cs); L.lo_ne4 = img(cs, cs); L.lo_tor1 = img(cs, cs); L.lo_tor2 = img(cs, cs);
     L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
@@ -560,6 +563,7 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
           for (int l = 0; l < d->tfmr_layers; ++l)
             if ((rc = i16(k.tf[l].outp, h, c.o16[l][h])) || (rc = i16(k.tf[l].l1, h, c.f16[l][h])) || (rc = i16(k.tf[l].l2, h, c.g16[l][h]))) return rc;
           if ((rc = i16(k.post, h, c.p16[h]))) return rc;
+          if ((rc = i16(k.t1, h, c.tr16[0][h])) || (rc = i16(k.t2, h, c.tr16[1][h])) || (rc = i16(k.t3, h, c.tr16[2][h]))) return rc;
         }
       }
       if (b < d->num_blocks - 1) {  // EdgeTransition per-residue rows: initial_embed and the e_i / e_j columns of the first / final layers
@@ -1098,7 +1102,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         if (warm_all && l + 1 < d->tfmr_layers && seq_fused) {
           tt.warm.p[0] = D + db.ch.inp[l + 1]; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(3 * dt, dt);
           if (split_qkv) { tt.warm.p[1] = D + db.lo.inp[l + 1]; tt.warm.bytes[1] = tt.warm.bytes[0]; }
-        } else if (warm_all && post_here && split_trans) tt.warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.lo.t1}, {tb, 2 * tb, 3 * tb}};  // (t2n | t3n and lo t1 | t2 | t3 are contiguous)
+        } else if (warm_all && post_here && split_trans && tail16_shapes(d, iv) && !sw.no_tail16)
+          tt.warm = L2Warm{{D + db.lo.tr16[0][0], D + db.lo.tr16[0][1], nullptr}, {3 * tb, 3 * tb, 0}};  // (the 16-row images: hi run, lo run)
+        else if (warm_all && post_here && split_trans) tt.warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.lo.t1}, {tb, 2 * tb, 3 * tb}};  // (t2n | t3n and lo t1 | t2 | t3 are contiguous)
         else if (warm_all && post_here) tt.warm = L2Warm{{D + db.ch.t1, D + db.ch.t2n, D + db.ch.t3n}, {tb, tb, tb}};
         else if (warm_all && l + 1 == d->tfmr_layers) { tt.warm.p[0] = D + db.ch.post; tt.warm.bytes[0] = (unsigned)fd_chain_image_bytes(cs, dt); }
         TWICE("tail", fd_tfmr_tail(tt, st));
@@ -1156,6 +1162,11 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         r.warm = L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, split_tors ? D + L.lo_tor1 : nullptr},  // (lo tor1 | tor2 are contiguous)
                         {(unsigned)fd_chain_image_bytes(cs, cs), (unsigned)fd_chain_image_bytes(cs, cs), split_tors ? 2 * (unsigned)fd_chain_image_bytes(cs, cs) : 0u}};
       if (split_trans) { r.w0l = D + db.lo.t1; r.w1l = D + db.lo.t2; r.w2l = D + db.lo.t3; }
+      if (split_trans && tail16_shapes(d, iv) && !sw.no_tail16) {  // 16-row blocks (rowblock.hip: transition16_kernel)
+        r.w0 = D + db.lo.tr16[0][0]; r.w1 = D + db.lo.tr16[1][0]; r.w2 = D + db.lo.tr16[2][0];
+        r.w0l = D + db.lo.tr16[0][1]; r.w1l = D + db.lo.tr16[1][1]; r.w2l = D + db.lo.tr16[2][1];
+        RC(fd_transition16(r, st));
+      } else
       RC(fd_rowblock(split_trans ? FD_RB_TRANSITION_BB_SPLIT : FD_RB_TRANSITION_BB, r, st));
       bb_done = true;
     } else if (con(FD_CHAIN_TRANSITION)) {

@@ -1022,6 +1022,237 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
   fd_l2_warm_done(warm_tok);
 }
 
+// ------------------------------------------------------------------ StructureModuleTransition + LayerNorm + mask + BackboneUpdate on 16-row blocks
+// rowblock_kernel<256,256,256,256, relu | relu | LN | BB | SPLIT> (FD_RB_TRANSITION_BB_SPLIT) in the shape of tfmr_tail16_kernel: three stages
+// 256 -> 256 (ReLU, ReLU, -), + residual, LayerNorm, row mask, then BackboneUpdate (Linear 256 -> 6) and compose_q_update_vec in place
+// (ipa_pytorch.py:365-413,542-545; rigid_utils.py:587-616,1039-1063).  Images: fd_chain_build_image16 (hi, lo) of the three matrices.
+#define TR_D 256
+#define TR_KS (TR_D / 32)
+#define TR_NT (TR_D / 16)
+#define TR_XROW (TR_D * 2 + 16)
+#define TR_XLO (16 * TR_XROW)
+#define TR_NC (11 * TR_D)  // b0 | b1 | b2 | gamma | beta | Wbb [6][256]
+#define TR_SMEM (4 * TR_XLO + TR_NC * 4 + 2 * 4 * 16 * 4 + 4 * 16 * 8 * 4 + 64 + 16)
+__global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* hs = xs + 2 * TR_XLO;
+  float* cst = (float*)(hs + 2 * TR_XLO);
+  float (*red)[4][16] = (float (*)[4][16])(cst + TR_NC);  // [2][4][16]
+  float* red3 = (float*)(red + 2);                         // [4][16][8] partial BackboneUpdate outputs
+  float* pmask = red3 + 4 * 16 * 8;                        // [16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, fg = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  const long grow = row0 + lr < a.M ? row0 + lr : a.M - 1;
+  typedef __attribute__((ext_vector_type(8))) _Float16 t16_h8;
+  hx8 Wh[2][TR_KS], Wl[2][TR_KS];
+  auto w_load = [&](auto BUF, const void* img, const void* img_lo, int T) {
+    constexpr int b = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < TR_KS; ++s) {
+      Wh[b][s] = rb_ld((const char*)img + ((size_t)(T * TR_KS + s) * 64 + lane) * 16);
+      Wl[b][s] = rb_ld((const char*)img_lo + ((size_t)(T * TR_KS + s) * 64 + lane) * 16);
+    }
+  };
+  auto put4 = [&](char* buf, int off, float v0, float v1, float v2, float v3) {
+    const float v[4] = {v0, v1, v2, v3};
+    rb_hx4 pk, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pk[q] = (fd_h)v[q];
+      pl[q] = (fd_h)(v[q] - (float)pk[q]);
+    }
+    *(rb_hx4*)(buf + off) = pk;
+    *(rb_hx4*)(buf + TR_XLO + off) = pl;
+  };
+  constexpr std::integral_constant<int, 0> B0{};
+  constexpr std::integral_constant<int, 1> B1{};
+  w_load(B0, a.w0, a.w0l, wave);
+  {
+    f32x4 xv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 64, c4 = idx % 64;
+      const int gr = row0 + r < a.M ? row0 + r : a.M - 1;
+      xv[k] = *(const f32x4*)(a.in + (long)gr * a.ld_in + 4 * c4);
+    }
+    {
+      constexpr int NCV = TR_NC / FD_THREADS;
+      float cv[NCV];
+#pragma unroll
+      for (int k = 0; k < NCV; ++k) {
+        const int v = tid + k * FD_THREADS, which = v / TR_D, c = v % TR_D;
+        cv[k] = which == 0 ? a.b0[c] : which == 1 ? a.b1[c] : which == 2 ? a.b2[c] : which == 3 ? a.gamma[c] : which == 4 ? a.beta[c] : a.bb_w[v - 5 * TR_D];
+      }
+#pragma unroll
+      for (int k = 0; k < NCV; ++k) cst[tid + k * FD_THREADS] = cv[k];
+    }
+    if (tid < 16) pmask[tid] = a.rowmask_post ? a.rowmask_post[row0 + tid < a.M ? row0 + tid : a.M - 1] : 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / 64, c4 = idx % 64;
+      put4(xs, r * TR_XROW + 8 * c4, xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
+    }
+  }
+  f32x4 rv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) rv[u] = *(const f32x4*)(a.residual + grow * a.ld_res + 16 * (wave + 4 * u) + 4 * fg);
+  const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
+  __syncthreads();
+  hx8 X[TR_KS];
+  const char* xl_base = nullptr;
+  auto x_load = [&](const char* buf) {
+#pragma unroll
+    for (int s = 0; s < TR_KS; ++s) X[s] = rb_ld(buf + lr * TR_XROW + (32 * s + 8 * fg) * 2);
+    xl_base = buf + TR_XLO + lr * TR_XROW + 16 * fg;
+  };
+  f32x4 acc[4];
+  auto mma = [](hx8 w, hx8 x, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t16_h8, w), __builtin_bit_cast(t16_h8, x), c, 0, 0, 0);
+  };
+  auto layer = [&](const void* img, const void* img_lo) {
+    ch_rb_for<4>([&](auto U) {
+      constexpr int u = decltype(U)::value, b = u & 1;
+      const int T = wave + 4 * u;
+      if constexpr (u + 1 < 4) {
+        if constexpr (b == 0) w_load(B1, img, img_lo, T + 4);
+        else w_load(B0, img, img_lo, T + 4);
+      }
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < TR_KS; ++s) c = mma(Wh[b][s], X[s], c);
+      {
+        hx8 xr[3];
+        xr[0] = rb_ld(xl_base);
+        xr[1] = rb_ld(xl_base + 64);
+#pragma unroll
+        for (int s = 0; s < TR_KS; ++s) {
+          if (s + 2 < TR_KS) xr[(s + 2) % 3] = rb_ld(xl_base + 64 * (s + 2));
+          c = mma(Wh[b][s], xr[s % 3], c);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < TR_KS; ++s) c = mma(Wl[b][s], X[s], c);
+      acc[u] = c;
+    });
+  };
+  auto relu_to = [&](char* dst, const float* bias) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+      const f32x4 bv = *(const f32x4*)(bias + f0);
+      put4(dst, lr * TR_XROW + 2 * f0, fmaxf(acc[u][0] + bv[0], 0.f), fmaxf(acc[u][1] + bv[1], 0.f), fmaxf(acc[u][2] + bv[2], 0.f),
+           fmaxf(acc[u][3] + bv[3], 0.f));
+    }
+  };
+  x_load(xs);
+  layer(a.w0, a.w0l);
+  w_load(B0, a.w1, a.w1l, wave);
+  relu_to(hs, cst);
+  __syncthreads();
+  x_load(hs);
+  layer(a.w1, a.w1l);
+  w_load(B0, a.w2, a.w2l, wave);
+  relu_to(xs, cst + TR_D);  // (the input rows are dead: every wave read them before the first barrier of this stage pair)
+  __syncthreads();
+  x_load(xs);
+  layer(a.w2, a.w2l);
+  // ---- + bias + residual, LayerNorm, mask
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const f32x4 bv = *(const f32x4*)(cst + 2 * TR_D + 16 * (wave + 4 * u) + 4 * fg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = acc[u][i] + bv[i] + rv[u][i];
+      acc[u][i] = v;
+      s1 += v;
+    }
+  }
+  // (two passes like the 32-row kernel: mean first, then the centred sum of squares)
+  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  if (fg == 0) red[0][wave][lr] = s1;
+  __syncthreads();
+  const float mu = (red[0][0][lr] + red[0][1][lr] + red[0][2][lr] + red[0][3][lr]) * (1.0f / TR_D);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dlt = acc[u][i] - mu;
+      s2 += dlt * dlt;
+    }
+  s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+  if (fg == 0) red[1][wave][lr] = s2;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[1][0][lr] + red[1][1][lr] + red[1][2][lr] + red[1][3][lr]) * (1.0f / TR_D) + 1e-5f);
+  const float pm = pmask[lr];
+  float pd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+    const f32x4 gm = *(const f32x4*)(cst + 3 * TR_D + f0), bt = *(const f32x4*)(cst + 4 * TR_D + f0);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = ((acc[u][i] - mu) * rstd * gm[i] + bt[i]) * pm;
+    if (row0 + lr < a.M) *(f32x4*)(a.out + (long)(row0 + lr) * a.ld_out + f0) = o;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const f32x4 wv = *(const f32x4*)(cst + 5 * TR_D + k * TR_D + f0);
+      pd[k] += (o[0] * wv[0] + o[1] * wv[1]) + (o[2] * wv[2] + o[3] * wv[3]);
+    }
+  }
+  // ---- BackboneUpdate: this lane's partial dots + the other feature groups + the other waves, then compose_q_update_vec in place
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    pd[k] += __shfl_xor(pd[k], 16, 64);
+    pd[k] += __shfl_xor(pd[k], 32, 64);
+  }
+  if (fg == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red3[(wave * 16 + lr) * 8 + k] = pd[k];
+  }
+  __syncthreads();
+  if (tid < 16 && row0 + tid < a.M) {
+    const long r = row0 + tid;
+    float upd[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      upd[k] = ((red3[tid * 8 + k] + red3[(16 + tid) * 8 + k]) + (red3[(32 + tid) * 8 + k] + red3[(48 + tid) * 8 + k])) + a.bb_b[k];
+    const float m = a.upd_mask ? a.upd_mask[r] : 1.f;
+    const float q0 = a.quat[r * 4], q1 = a.quat[r * 4 + 1], q2 = a.quat[r * 4 + 2], q3 = a.quat[r * 4 + 3];
+    const float dq0 = -q1 * upd[0] - q2 * upd[1] - q3 * upd[2];
+    const float dq1 = q0 * upd[0] + q2 * upd[2] - q3 * upd[1];
+    const float dq2 = q0 * upd[1] - q1 * upd[2] + q3 * upd[0];
+    const float dq3 = q0 * upd[2] + q1 * upd[1] - q2 * upd[0];
+    const float R0 = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3, R1 = 2 * q1 * q2 - 2 * q0 * q3, R2 = 2 * q1 * q3 + 2 * q0 * q2;
+    const float R3 = 2 * q1 * q2 + 2 * q0 * q3, R4 = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3, R5 = 2 * q2 * q3 - 2 * q0 * q1;
+    const float R6 = 2 * q1 * q3 - 2 * q0 * q2, R7 = 2 * q2 * q3 + 2 * q0 * q1, R8 = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+    const float d0 = R0 * upd[3] + R1 * upd[4] + R2 * upd[5];
+    const float d1 = R3 * upd[3] + R4 * upd[4] + R5 * upd[5];
+    const float d2 = R6 * upd[3] + R7 * upd[4] + R8 * upd[5];
+    const float n0 = q0 + dq0 * m, n1 = q1 + dq1 * m, n2 = q2 + dq2 * m, n3 = q3 + dq3 * m;
+    const float nrm = sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+    a.quat[r * 4] = n0 / nrm; a.quat[r * 4 + 1] = n1 / nrm; a.quat[r * 4 + 2] = n2 / nrm; a.quat[r * 4 + 3] = n3 / nrm;
+    fd_store3(a.trans + r * 3, a.trans[r * 3] + d0 * m, a.trans[r * 3 + 1] + d1 * m, a.trans[r * 3 + 2] + d2 * m);
+  }
+  fd_l2_warm_done(warm_tok);
+}
+// images w0 / w1 / w2 (+ lo): fd_chain_build_image16; every pointer of the BackboneUpdate kind is required
+int fd_transition16(const RowBlockArgs& a, hipStream_t st) {
+  if (a.M <= 0 || (a.ld_in & 3) || (a.ld_res & 3) || (a.ld_out & 3) || !a.w0l || !a.w1l || !a.w2l || !a.residual || !a.gamma || !a.beta || !a.bb_w ||
+      !a.bb_b || !a.quat || !a.trans)
+    return FDIPT_EINVAL;
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
+    if (hipFuncSetAttribute((const void*)transition16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
+    attr_dev.set(dev_, 1);
+  }
+  hipLaunchKernelGGL(transition16_kernel, dim3(cdiv(a.M, 16)), dim3(FD_THREADS), TR_SMEM, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.ld & 3) || a.x == a.out) return FDIPT_EINVAL;
   static FdPerDevice attr_dev;
