@@ -49,20 +49,21 @@ int fd_chain_build_image_lo(const float* w, int N, int K, int ldw, void* img, hi
 }
 // Fragment image for v_mfma_f32_16x16x32_f16 (16-row node-path blocks, rowblock.hip: tfmr_tail16_kernel): tiles of 16 output features,
 // k-steps of 32 — element (T, s, lane, e) = W[16 T + lane % 16][32 s + 8 (lane / 16) + e]; lo = 1: the image of W - half(W).
-// Same size as the 32-row image of the matrix.  Needs N % 16 == 0, K % 32 == 0.
-__global__ void chain_image16_kernel(const float* __restrict__ w, int K, int ldw, int NT, int KS, int lo, half_t* __restrict__ img) {
+// Same size as the 32-row image of the matrix.  Needs N % 16 == 0; K is zero-padded to Kpad (a multiple of 32).
+__global__ void chain_image16_kernel(const float* __restrict__ w, int K, int ldw, int NT, int KS, int lo, half_t* __restrict__ img) {  // (columns >= K: zeros)
   const long n = (long)NT * KS * 64 * 8;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const long ts = i >> 9;
     const int s = (int)(ts % KS), T = (int)(ts / KS);
-    const float v = w[(long)(16 * T + (lane & 15)) * ldw + 32 * s + 8 * (lane >> 4) + e];
+    const int kcol = 32 * s + 8 * (lane >> 4) + e;
+    const float v = kcol < K ? w[(long)(16 * T + (lane & 15)) * ldw + kcol] : 0.f;
     img[i] = lo ? f2h(v - h2f(f2h(v))) : f2h(v);
   }
 }
-int fd_chain_build_image16(const float* w, int N, int K, int ldw, int lo, void* img, hipStream_t st) {
-  if ((N & 15) || (K & 31)) return FDIPT_ESIZE;
-  hipLaunchKernelGGL(chain_image16_kernel, dim3(64), dim3(256), 0, st, w, K, ldw, N / 16, K / 32, lo, (half_t*)img);
+int fd_chain_build_image16(const float* w, int N, int K, int Kpad, int ldw, int lo, void* img, hipStream_t st) {
+  if ((N & 15) || (Kpad & 31) || K > Kpad) return FDIPT_ESIZE;
+  hipLaunchKernelGGL(chain_image16_kernel, dim3(64), dim3(256), 0, st, w, K, ldw, N / 16, Kpad / 32, lo, (half_t*)img);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

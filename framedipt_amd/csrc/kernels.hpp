@@ -261,6 +261,8 @@ enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NO
 int fd_rowblock(int kind, const RowBlockArgs& a, hipStream_t st);
 // FD_RB_TRANSITION_BB_SPLIT on 16-row blocks (rowblock.hip: transition16_kernel); w0 / w1 / w2 and their lo images are fd_chain_build_image16 images
 int fd_transition16(const RowBlockArgs& a, hipStream_t st);
+int fd_node_embed16(const RowBlockArgs& a, int k0, hipStream_t st);  // FD_RB_NODE_EMBED_*_SPLIT (first image: K padded to 96)
+int fd_torsion16(const RowBlockArgs& a, hipStream_t st);             // FD_RB_TORSION_SPLIT
 
 // post-attention half of one encoder layer in one launch (rowblock.hip): x_a = LN1(x + Wo att + bo); out = LN2(x_a + W2 relu(W1 x_a + b1) + b2)
 struct TfmrTailArgs {
@@ -281,7 +283,7 @@ struct TfmrTailArgs {
                                   // fd_chain_build_image16 images
 };
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st);
-int fd_chain_build_image16(const float* w, int N, int K, int ldw, int lo, void* img, hipStream_t st);
+int fd_chain_build_image16(const float* w, int N, int K, int Kpad, int ldw, int lo, void* img, hipStream_t st);
 
 struct ChainArgs {
   int M;

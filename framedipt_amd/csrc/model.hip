@@ -183,6 +183,7 @@ struct DLayout {
   size_t ch_ne0, ch_ne2, ch_ne4, ch_tor1, ch_tor2;  // chain images: node embedder, torsion head
   size_t ch_ne2n, ch_ne4n, ch_tor2n;                // ... natural k order (rowblock.hip)
   size_t lo_ne0, lo_ne2, lo_ne4, lo_tor1, lo_tor2;  // lo images: node embedder, torsion head
+  size_t ne16[3][2], tor16[2][2];                   // 16-row images (fd_chain_build_image16; the embedder's first one zero-padded to K = 96), hi / lo
   size_t skip_w32;                                  // ... in fp32 (split operands: the GEMM splits both operands while it stages them)
   size_t skip_w, skip_b;                            // skip_embed of ALL blocks stacked: [num_blocks * c_skip, c_s] operand precision, bias f32
   DBlock blk[FD_MAX_BLOCKS];
@@ -280,6 +281,8 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
         for (int i = 0; i < 3; ++i) c.tr16[i][h] = img(cs, cs);
     }
     L.lo_ne0 = img(cs, L.kn_pad); L.lo_ne2 = img(cs, cs); L.lo_ne4 = img(cs, cs); L.lo_tor1 = img(cs, cs); L.lo_tor2 = img(cs, cs);
+    for (int h = 0; h < 2; ++h) { L.ne16[0][h] = img(cs, 96); L.ne16[1][h] = img(cs, cs); L.ne16[2][h] = img(cs, cs); }
+    for (int h = 0; h < 2; ++h) { L.tor16[0][h] = img(cs, cs); L.tor16[1][h] = img(cs, cs); }
     L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
     L.ch_tor1 = img(d->c_s, d->c_s); L.ch_tor2 = img(d->c_s, d->c_s);
     L.ch_ne2n = img(d->c_s, d->c_s); L.ch_ne4n = img(d->c_s, d->c_s); L.ch_tor2n = img(d->c_s, d->c_s);
@@ -558,7 +561,7 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
           return rc;
       if ((rc = lo(k.post, c.post)) || (rc = lo(k.t1, c.t1)) || (rc = lo(k.t2, c.t2)) || (rc = lo(k.t3, c.t3))) return rc;
       if (tail16_shapes(d, iv)) {  // 16-row images of the tail (tfmr_tail16_kernel)
-        auto i16 = [&](const LinW& l, int h, size_t off) { return fd_chain_build_image16(P + l.w, l.out, l.in, l.in, h, D + off, st); };
+        auto i16 = [&](const LinW& l, int h, size_t off) { return fd_chain_build_image16(P + l.w, l.out, l.in, l.in, l.in, h, D + off, st); };
         for (int h = 0; h < 2; ++h) {
           for (int l = 0; l < d->tfmr_layers; ++l)
             if ((rc = i16(k.tf[l].outp, h, c.o16[l][h])) || (rc = i16(k.tf[l].l1, h, c.f16[l][h])) || (rc = i16(k.tf[l].l2, h, c.g16[l][h]))) return rc;
@@ -579,6 +582,14 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     if ((rc = lo(iv.ne0, L.lo_ne0)) || (rc = lo(iv.ne2, L.lo_ne2)) || (rc = lo(iv.ne4, L.lo_ne4)) || (rc = lo(iv.tor1, L.lo_tor1)) ||
         (rc = lo(iv.tor2, L.lo_tor2)))
       return rc;
+    if (cs == 256 && iv.node_in <= 96)
+      for (int h = 0; h < 2; ++h)
+        if ((rc = fd_chain_build_image16(P + iv.ne0.w, cs, iv.node_in, 96, iv.node_in, h, D + L.ne16[0][h], st)) ||
+            (rc = fd_chain_build_image16(P + iv.ne2.w, cs, cs, cs, cs, h, D + L.ne16[1][h], st)) ||
+            (rc = fd_chain_build_image16(P + iv.ne4.w, cs, cs, cs, cs, h, D + L.ne16[2][h], st)) ||
+            (rc = fd_chain_build_image16(P + iv.tor1.w, cs, cs, cs, cs, h, D + L.tor16[0][h], st)) ||
+            (rc = fd_chain_build_image16(P + iv.tor2.w, cs, cs, cs, cs, h, D + L.tor16[1][h], st)))
+          return rc;
     if ((rc = fd_chain_build_image(P + iv.ne0.w, cs, iv.node_in, iv.node_in, 0, D + L.ch_ne0, st))) return rc;
     if ((rc = fd_chain_build_image(P + iv.ne2.w, cs, cs, cs, 1, D + L.ch_ne2, st))) return rc;
     if ((rc = fd_chain_build_image(P + iv.ne4.w, cs, cs, cs, 1, D + L.ch_ne4, st))) return rc;
@@ -759,6 +770,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
              split_skip = split_any && (sw.split_mask & 512u), split_pv = split_any && (sw.split_mask & 1024u);
   (void)split_pv;
   const void *rb_l0 = nullptr, *rb_l1 = nullptr, *rb_l2 = nullptr;  // one-shot: lo images for the next rblock() call
+  int rb16 = 0;  // one-shot: the next rblock() call runs on 16-row blocks (1: node embedder, 2: torsion head; its w0 .. / lo pointers are 16-row images)
   auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                     const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
                     float* out, int ld_out) {
@@ -768,6 +780,10 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     r.ld_res = ld_res; r.gamma = lnw ? P + lnw->g : nullptr; r.beta = lnw ? P + lnw->b : nullptr; r.rowmask_post = post;
     r.out = out; r.ld_out = ld_out; r.bb_w = r.bb_b = r.upd_mask = nullptr; r.quat = r.trans = nullptr;
     r.out2 = nullptr; r.ld_out2 = r.split = 0; r.hid_h16 = nullptr;
+    const int k16 = rb16;
+    rb16 = 0;
+    if (k16 == 1) return fd_node_embed16(r, ld_in, st);
+    if (k16 == 2) return fd_torsion16(r, st);
     return fd_rowblock(kind, r, st);
   };
   unsigned short* chain_h16 = nullptr;  // one-shot: the next chain() call also writes a bf16 copy of its output rows
@@ -805,9 +821,11 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
                     feats_fused ? F(w.pi) : nullptr, F(w.pj), st));
   if (rbk && (sw.rb_mask & 1u) && (L.kn_pad == 72 || L.kn_pad == 88)) {
     if (split_embed) { rb_l0 = D + L.lo_ne0; rb_l1 = D + L.lo_ne2; rb_l2 = D + L.lo_ne4; }
+    const bool ne16 = split_embed && cs == 256 && iv.node_in <= 96 && !sw.no_tail16;  // 16-row blocks (rowblock.hip: mlp16_kernel)
+    if (ne16) { rb16 = 1; rb_l0 = D + L.ne16[0][1]; rb_l1 = D + L.ne16[1][1]; rb_l2 = D + L.ne16[2][1]; }
     RC(rblock(split_embed ? (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72_SPLIT : FD_RB_NODE_EMBED_88_SPLIT)
-                    : (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88), F(w.node_feat), L.kn_pad, D + L.ch_ne0, P + iv.ne0.b,
-              D + L.ch_ne2n, P + iv.ne2.b, D + L.ch_ne4n, P + iv.ne4.b, nullptr, 0, &iv.neln, res_mask, F(w.node0), cs));
+                    : (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88), F(w.node_feat), L.kn_pad, ne16 ? D + L.ne16[0][0] : D + L.ch_ne0, P + iv.ne0.b,
+              ne16 ? D + L.ne16[1][0] : D + L.ch_ne2n, P + iv.ne2.b, ne16 ? D + L.ne16[2][0] : D + L.ch_ne4n, P + iv.ne4.b, nullptr, 0, &iv.neln, res_mask, F(w.node0), cs));
   } else if (con(FD_CHAIN_NODE_EMBED_72) && (L.kn_pad == 72 || L.kn_pad == 88)) {
     RC(chain(L.kn_pad == 72 ? FD_CHAIN_NODE_EMBED_72 : FD_CHAIN_NODE_EMBED_88, F(w.node_feat), L.kn_pad, D + L.ch_ne0,
              P + iv.ne0.b, D + L.ch_ne2, P + iv.ne2.b, D + L.ch_ne4, P + iv.ne4.b, nullptr, 0, &iv.neln, nullptr, res_mask,
@@ -1159,7 +1177,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
                         {(unsigned)fd_chain_image_bytes(iv.cb, cs), (unsigned)fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb),
                          split_etrows ? (unsigned)(fd_chain_image_bytes(iv.cb, cs) + fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb)) : 0u}};
       else if (warm_all && b == d->num_blocks - 1)  // ... or the torsion head
-        r.warm = L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, split_tors ? D + L.lo_tor1 : nullptr},  // (lo tor1 | tor2 are contiguous)
+        r.warm = split_tors && cs == 256 && iv.node_in <= 96 && !sw.no_tail16
+            ? L2Warm{{D + L.tor16[0][0], D + L.tor16[0][1], nullptr}, {2 * (unsigned)fd_chain_image_bytes(cs, cs), 2 * (unsigned)fd_chain_image_bytes(cs, cs), 0}}  // (hi run, lo run)
+            : L2Warm{{D + L.ch_tor1, D + L.ch_tor2n, split_tors ? D + L.lo_tor1 : nullptr},  // (lo tor1 | tor2 are contiguous)
                         {(unsigned)fd_chain_image_bytes(cs, cs), (unsigned)fd_chain_image_bytes(cs, cs), split_tors ? 2 * (unsigned)fd_chain_image_bytes(cs, cs) : 0u}};
       if (split_trans) { r.w0l = D + db.lo.t1; r.w1l = D + db.lo.t2; r.w2l = D + db.lo.t3; }
       if (split_trans && tail16_shapes(d, iv) && !sw.no_tail16) {  // 16-row blocks (rowblock.hip: transition16_kernel)
@@ -1288,7 +1308,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // ---- heads: torsion (ipa:332-363), tensor_7, scores (ipa:552-564), backbone (sn:269-273)
   if (rbk && (sw.rb_mask & 8u)) {
     if (split_tors) { rb_l0 = D + L.lo_tor1; rb_l1 = D + L.lo_tor2; }
-    RC(rblock(split_tors ? FD_RB_TORSION_SPLIT : FD_RB_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
+    const bool tor16 = split_tors && cs == 256 && iv.node_in <= 96 && !sw.no_tail16;
+    if (tor16) { rb16 = 2; rb_l0 = D + L.tor16[0][1]; rb_l1 = D + L.tor16[1][1]; }
+    RC(rblock(split_tors ? FD_RB_TORSION_SPLIT : FD_RB_TORSION, node_cur, cs, tor16 ? D + L.tor16[0][0] : D + L.ch_tor1, P + iv.tor1.b, tor16 ? D + L.tor16[1][0] : D + L.ch_tor2n, P + iv.tor2.b, nullptr, nullptr, node_cur,
               cs, nullptr, nullptr, F(w.h_b), cs));
   } else if (con(FD_CHAIN_TORSION)) {
     RC(chain(FD_CHAIN_TORSION, node_cur, cs, D + L.ch_tor1, P + iv.tor1.b, D + L.ch_tor2, P + iv.tor2.b, nullptr, nullptr, node_cur,

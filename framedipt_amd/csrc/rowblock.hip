@@ -1033,7 +1033,11 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
 #define TR_XLO (16 * TR_XROW)
 #define TR_NC (11 * TR_D)  // b0 | b1 | b2 | gamma | beta | Wbb [6][256]
 #define TR_SMEM (4 * TR_XLO + TR_NC * 4 + 2 * 4 * 16 * 4 + 4 * 16 * 8 * 4 + 64 + 16)
-__global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArgs a) {
+// KS0: 32-wide k-steps of the first layer (input width a.k0 <= 32 KS0, zero-padded in LDS); NL: 2 or 3 layers (256 wide; ReLU behind every layer
+// but the last); LN: LayerNorm on the output; BB: BackboneUpdate + compose.  <8, 3, true, true> = the transition, <3, 3, true, false> = the node
+// embedder (72 / 88 input features), <8, 2, false, false> = the torsion head's residual block.
+template <int KS0, int NL, bool LN, bool BB>
+__global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, int k0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;
   char* hs = xs + 2 * TR_XLO;
@@ -1046,14 +1050,16 @@ __global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArg
   const long grow = row0 + lr < a.M ? row0 + lr : a.M - 1;
   typedef __attribute__((ext_vector_type(8))) _Float16 t16_h8;
   hx8 Wh[2][TR_KS], Wl[2][TR_KS];
-  auto w_load = [&](auto BUF, const void* img, const void* img_lo, int T) {
-    constexpr int b = decltype(BUF)::value;
+  auto w_load = [&](auto BUF, auto KSC, const void* img, const void* img_lo, int T) {
+    constexpr int b = decltype(BUF)::value, KS = decltype(KSC)::value;
 #pragma unroll
-    for (int s = 0; s < TR_KS; ++s) {
-      Wh[b][s] = rb_ld((const char*)img + ((size_t)(T * TR_KS + s) * 64 + lane) * 16);
-      Wl[b][s] = rb_ld((const char*)img_lo + ((size_t)(T * TR_KS + s) * 64 + lane) * 16);
+    for (int s = 0; s < KS; ++s) {
+      Wh[b][s] = rb_ld((const char*)img + ((size_t)(T * KS + s) * 64 + lane) * 16);
+      Wl[b][s] = rb_ld((const char*)img_lo + ((size_t)(T * KS + s) * 64 + lane) * 16);
     }
   };
+  constexpr std::integral_constant<int, KS0> K0C{};
+  constexpr std::integral_constant<int, TR_KS> K8C{};
   auto put4 = [&](char* buf, int off, float v0, float v1, float v2, float v3) {
     const float v[4] = {v0, v1, v2, v3};
     rb_hx4 pk, pl;
@@ -1067,14 +1073,17 @@ __global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArg
   };
   constexpr std::integral_constant<int, 0> B0{};
   constexpr std::integral_constant<int, 1> B1{};
-  w_load(B0, a.w0, a.w0l, wave);
+  w_load(B0, K0C, a.w0, a.w0l, wave);
   {
-    f32x4 xv[4];
+    // input rows: k0 / 4 float4 per row (k0 % 4 == 0), columns beyond k0 up to 32 KS0 are zeros
+    constexpr int C4 = KS0 * 8, NV = (16 * C4 + FD_THREADS - 1) / FD_THREADS;
+    f32x4 xv[NV];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int idx = tid + k * FD_THREADS, r = idx / 64, c4 = idx % 64;
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / C4, c4 = idx % C4;
       const int gr = row0 + r < a.M ? row0 + r : a.M - 1;
-      xv[k] = *(const f32x4*)(a.in + (long)gr * a.ld_in + 4 * c4);
+      xv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < 16 * C4 && 4 * c4 < k0) xv[k] = *(const f32x4*)(a.in + (long)gr * a.ld_in + 4 * c4);
     }
     {
       constexpr int NCV = TR_NC / FD_THREADS;
@@ -1082,57 +1091,62 @@ __global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArg
 #pragma unroll
       for (int k = 0; k < NCV; ++k) {
         const int v = tid + k * FD_THREADS, which = v / TR_D, c = v % TR_D;
-        cv[k] = which == 0 ? a.b0[c] : which == 1 ? a.b1[c] : which == 2 ? a.b2[c] : which == 3 ? a.gamma[c] : which == 4 ? a.beta[c] : a.bb_w[v - 5 * TR_D];
+        cv[k] = which == 0 ? a.b0[c] : which == 1 ? a.b1[c] : which == 2 ? (NL == 3 ? a.b2[c] : 0.f) : which == 3 ? (LN ? a.gamma[c] : 1.f)
+                : which == 4 ? (LN ? a.beta[c] : 0.f) : (BB ? a.bb_w[v - 5 * TR_D] : 0.f);
       }
 #pragma unroll
       for (int k = 0; k < NCV; ++k) cst[tid + k * FD_THREADS] = cv[k];
     }
     if (tid < 16) pmask[tid] = a.rowmask_post ? a.rowmask_post[row0 + tid < a.M ? row0 + tid : a.M - 1] : 1.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int idx = tid + k * FD_THREADS, r = idx / 64, c4 = idx % 64;
-      put4(xs, r * TR_XROW + 8 * c4, xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + k * FD_THREADS, r = idx / C4, c4 = idx % C4;
+      if (idx < 16 * C4) put4(xs, r * TR_XROW + 8 * c4, xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
     }
   }
   f32x4 rv[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) rv[u] = *(const f32x4*)(a.residual + grow * a.ld_res + 16 * (wave + 4 * u) + 4 * fg);
+  for (int u = 0; u < 4; ++u) {
+    rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.residual) rv[u] = *(const f32x4*)(a.residual + grow * a.ld_res + 16 * (wave + 4 * u) + 4 * fg);
+  }
   const unsigned warm_tok = fd_l2_warm(a.warm, blockIdx.x, gridDim.x, tid, FD_THREADS);
   __syncthreads();
   hx8 X[TR_KS];
   const char* xl_base = nullptr;
-  auto x_load = [&](const char* buf) {
+  auto x_load = [&](auto KSC, const char* buf) {
 #pragma unroll
-    for (int s = 0; s < TR_KS; ++s) X[s] = rb_ld(buf + lr * TR_XROW + (32 * s + 8 * fg) * 2);
+    for (int s = 0; s < decltype(KSC)::value; ++s) X[s] = rb_ld(buf + lr * TR_XROW + (32 * s + 8 * fg) * 2);
     xl_base = buf + TR_XLO + lr * TR_XROW + 16 * fg;
   };
   f32x4 acc[4];
   auto mma = [](hx8 w, hx8 x, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t16_h8, w), __builtin_bit_cast(t16_h8, x), c, 0, 0, 0);
   };
-  auto layer = [&](const void* img, const void* img_lo) {
+  auto layer = [&](auto KSC, const void* img, const void* img_lo) {
+    constexpr int KS = decltype(KSC)::value;
     ch_rb_for<4>([&](auto U) {
       constexpr int u = decltype(U)::value, b = u & 1;
       const int T = wave + 4 * u;
       if constexpr (u + 1 < 4) {
-        if constexpr (b == 0) w_load(B1, img, img_lo, T + 4);
-        else w_load(B0, img, img_lo, T + 4);
+        if constexpr (b == 0) w_load(B1, KSC, img, img_lo, T + 4);
+        else w_load(B0, KSC, img, img_lo, T + 4);
       }
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < TR_KS; ++s) c = mma(Wh[b][s], X[s], c);
+      for (int s = 0; s < KS; ++s) c = mma(Wh[b][s], X[s], c);
       {
         hx8 xr[3];
         xr[0] = rb_ld(xl_base);
-        xr[1] = rb_ld(xl_base + 64);
+        if (KS > 1) xr[1] = rb_ld(xl_base + 64);
 #pragma unroll
-        for (int s = 0; s < TR_KS; ++s) {
-          if (s + 2 < TR_KS) xr[(s + 2) % 3] = rb_ld(xl_base + 64 * (s + 2));
+        for (int s = 0; s < KS; ++s) {
+          if (s + 2 < KS) xr[(s + 2) % 3] = rb_ld(xl_base + 64 * (s + 2));
           c = mma(Wh[b][s], xr[s % 3], c);
         }
       }
 #pragma unroll
-      for (int s = 0; s < TR_KS; ++s) c = mma(Wl[b][s], X[s], c);
+      for (int s = 0; s < KS; ++s) c = mma(Wl[b][s], X[s], c);
       acc[u] = c;
     });
   };
@@ -1145,23 +1159,25 @@ __global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArg
            fmaxf(acc[u][3] + bv[3], 0.f));
     }
   };
-  x_load(xs);
-  layer(a.w0, a.w0l);
-  w_load(B0, a.w1, a.w1l, wave);
+  x_load(K0C, xs);
+  layer(K0C, a.w0, a.w0l);
+  w_load(B0, K8C, a.w1, a.w1l, wave);
   relu_to(hs, cst);
   __syncthreads();
-  x_load(hs);
-  layer(a.w1, a.w1l);
-  w_load(B0, a.w2, a.w2l, wave);
-  relu_to(xs, cst + TR_D);  // (the input rows are dead: every wave read them before the first barrier of this stage pair)
-  __syncthreads();
-  x_load(xs);
-  layer(a.w2, a.w2l);
+  x_load(K8C, hs);
+  layer(K8C, a.w1, a.w1l);
+  if constexpr (NL == 3) {
+    w_load(B0, K8C, a.w2, a.w2l, wave);
+    relu_to(xs, cst + TR_D);  // (the input rows are dead: every wave read them before the barrier above)
+    __syncthreads();
+    x_load(K8C, xs);
+    layer(K8C, a.w2, a.w2l);
+  }
   // ---- + bias + residual, LayerNorm, mask
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const f32x4 bv = *(const f32x4*)(cst + 2 * TR_D + 16 * (wave + 4 * u) + 4 * fg);
+    const f32x4 bv = *(const f32x4*)(cst + (NL - 1) * TR_D + 16 * (wave + 4 * u) + 4 * fg);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float v = acc[u][i] + bv[i] + rv[u][i];
@@ -1169,22 +1185,24 @@ __global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArg
       s1 += v;
     }
   }
-  // (two passes like the 32-row kernel: mean first, then the centred sum of squares)
-  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-  if (fg == 0) red[0][wave][lr] = s1;
-  __syncthreads();
-  const float mu = (red[0][0][lr] + red[0][1][lr] + red[0][2][lr] + red[0][3][lr]) * (1.0f / TR_D);
+  float mu = 0.f, rstd = 1.f;
+  if constexpr (LN) {  // (two passes like the 32-row kernel: mean first, then the centred sum of squares)
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    if (fg == 0) red[0][wave][lr] = s1;
+    __syncthreads();
+    mu = (red[0][0][lr] + red[0][1][lr] + red[0][2][lr] + red[0][3][lr]) * (1.0f / TR_D);
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float dlt = acc[u][i] - mu;
-      s2 += dlt * dlt;
-    }
-  s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-  if (fg == 0) red[1][wave][lr] = s2;
-  __syncthreads();
-  const float rstd = 1.0f / sqrtf((red[1][0][lr] + red[1][1][lr] + red[1][2][lr] + red[1][3][lr]) * (1.0f / TR_D) + 1e-5f);
+      for (int i = 0; i < 4; ++i) {
+        const float dlt = acc[u][i] - mu;
+        s2 += dlt * dlt;
+      }
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (fg == 0) red[1][wave][lr] = s2;
+    __syncthreads();
+    rstd = 1.0f / sqrtf((red[1][0][lr] + red[1][1][lr] + red[1][2][lr] + red[1][3][lr]) * (1.0f / TR_D) + 1e-5f);
+  }
   const float pm = pmask[lr];
   float pd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1193,13 +1211,19 @@ __global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArg
     const f32x4 gm = *(const f32x4*)(cst + 3 * TR_D + f0), bt = *(const f32x4*)(cst + 4 * TR_D + f0);
     f32x4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = ((acc[u][i] - mu) * rstd * gm[i] + bt[i]) * pm;
+    for (int i = 0; i < 4; ++i) o[i] = LN ? ((acc[u][i] - mu) * rstd * gm[i] + bt[i]) * pm : acc[u][i] * pm;
     if (row0 + lr < a.M) *(f32x4*)(a.out + (long)(row0 + lr) * a.ld_out + f0) = o;
+    if constexpr (BB) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const f32x4 wv = *(const f32x4*)(cst + 5 * TR_D + k * TR_D + f0);
-      pd[k] += (o[0] * wv[0] + o[1] * wv[1]) + (o[2] * wv[2] + o[3] * wv[3]);
+      for (int k = 0; k < 6; ++k) {
+        const f32x4 wv = *(const f32x4*)(cst + 5 * TR_D + k * TR_D + f0);
+        pd[k] += (o[0] * wv[0] + o[1] * wv[1]) + (o[2] * wv[2] + o[3] * wv[3]);
+      }
     }
+  }
+  if constexpr (!BB) {
+    fd_l2_warm_done(warm_tok);
+    return;
   }
   // ---- BackboneUpdate: this lane's partial dots + the other feature groups + the other waves, then compose_q_update_vec in place
 #pragma unroll
@@ -1237,20 +1261,34 @@ __global__ __launch_bounds__(FD_THREADS, 1) void transition16_kernel(RowBlockArg
   }
   fd_l2_warm_done(warm_tok);
 }
-// images w0 / w1 / w2 (+ lo): fd_chain_build_image16; every pointer of the BackboneUpdate kind is required
+// images w0 / w1 / w2 (+ lo): fd_chain_build_image16 (the first one with K padded to 32 KS0)
+template <int KS0, int NL, bool LN, bool BB>
+static int mlp16_launch(const RowBlockArgs& a, int k0, hipStream_t st) {
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
+    if (hipFuncSetAttribute((const void*)mlp16_kernel<KS0, NL, LN, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
+    attr_dev.set(dev_, 1);
+  }
+  hipLaunchKernelGGL((mlp16_kernel<KS0, NL, LN, BB>), dim3(cdiv(a.M, 16)), dim3(FD_THREADS), TR_SMEM, st, a, k0);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+// FD_RB_TRANSITION_BB_SPLIT on 16-row blocks
 int fd_transition16(const RowBlockArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.ld_in & 3) || (a.ld_res & 3) || (a.ld_out & 3) || !a.w0l || !a.w1l || !a.w2l || !a.residual || !a.gamma || !a.beta || !a.bb_w ||
       !a.bb_b || !a.quat || !a.trans)
     return FDIPT_EINVAL;
-  static FdPerDevice attr_dev;
-  const int dev_ = fd_device();
-  if (!attr_dev.get(dev_)) {
-    if (hipFuncSetAttribute((const void*)transition16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
-    attr_dev.set(dev_, 1);
-  }
-  hipLaunchKernelGGL(transition16_kernel, dim3(cdiv(a.M, 16)), dim3(FD_THREADS), TR_SMEM, st, a);
-  FD_CHECK_LAUNCH();
-  return FDIPT_OK;
+  return mlp16_launch<8, 3, true, true>(a, TR_D, st);
+}
+// FD_RB_NODE_EMBED_72 / 88_SPLIT (k0 input features, k0 % 4 == 0, k0 <= 96) and FD_RB_TORSION_SPLIT on 16-row blocks
+int fd_node_embed16(const RowBlockArgs& a, int k0, hipStream_t st) {
+  if (a.M <= 0 || (a.ld_in & 3) || (a.ld_out & 3) || (k0 & 3) || k0 > 96 || !a.w0l || !a.w1l || !a.w2l || !a.gamma || !a.beta) return FDIPT_EINVAL;
+  return mlp16_launch<3, 3, true, false>(a, k0, st);
+}
+int fd_torsion16(const RowBlockArgs& a, hipStream_t st) {
+  if (a.M <= 0 || (a.ld_in & 3) || (a.ld_res & 3) || (a.ld_out & 3) || !a.w0l || !a.w1l) return FDIPT_EINVAL;
+  return mlp16_launch<8, 2, false, false>(a, TR_D, st);
 }
 
 int fd_tfmr_tail(const TfmrTailArgs& a, hipStream_t st) {
