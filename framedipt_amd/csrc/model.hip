@@ -753,7 +753,12 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // bit k enables fused chain kind k (FD_CHAIN_*).  Default: the kinds that beat the GEMM + LayerNorm launches they replace
   // at B*N ~ 2400 rows on MI355X (profiles/r01_chain_vs_gemm.md): the 3-layer chains and the narrow heads; the 320-wide
   // transformer layers (FFN, out_proj, in_proj) and skip_embed stay on the tiled GEMM, which spreads over 10x more CUs.
-  const Switches sw = switches_of(d);
+  Switches sw_ = switches_of(d);
+  // 16-row node-path blocks pay off while they are about one round of the chip (B N <= ~4000 rows: twice the blocks of the 32-row kernels, each
+  // streaming all weights, half the matrix work per block); with every CU busy anyway the 32-row kernels move half the weight bytes (measured: c4
+  // with 64 samples per GPU 1.277 -> 1.246 M).  The choice goes by N alone — a sample's result must not depend on the batch it rides in.
+  if (N > 512) sw_.no_tail16 = true;
+  const Switches sw = sw_;
   const unsigned cmask = sw.chain_mask;
   auto con = [&](int kind) { return chn_all && ((cmask >> kind) & 1u); };
   // row-complete fused MLPs (rowblock.hip) take the multi-layer kinds and the 320-wide transformer layers
