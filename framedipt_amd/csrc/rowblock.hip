@@ -817,7 +817,6 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, fg = lane >> 4;
   const int row0 = blockIdx.x * 16;
   const long grow = row0 + lr < a.M ? row0 + lr : a.M - 1;
-  typedef __attribute__((ext_vector_type(8))) _Float16 t16_h8;
   FD_STAMP(0);
   hx8 Wh[2][T16_KS], Wl[2][T16_KS];
   auto w_load = [&](auto BUF, const void* img, const void* img_lo, int T) {
@@ -885,7 +884,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
   };
   f32x4 acc[5], xa[5];
   auto mma = [](hx8 w, hx8 x, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t16_h8, w), __builtin_bit_cast(t16_h8, x), c, 0, 0, 0);
+    return fd_mfma16(w, x, c);
   };
   // one stage: tiles wave, wave + 4, ... (< NT); the first tile's fragments are in buffer 0, tile u + 1 is requested when tile u starts
   auto layer = [&](const void* img, const void* img_lo, auto NTC) {
@@ -1048,7 +1047,6 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, fg = lane >> 4;
   const int row0 = blockIdx.x * 16;
   const long grow = row0 + lr < a.M ? row0 + lr : a.M - 1;
-  typedef __attribute__((ext_vector_type(8))) _Float16 t16_h8;
   hx8 Wh[2][TR_KS], Wl[2][TR_KS];
   auto w_load = [&](auto BUF, auto KSC, const void* img, const void* img_lo, int T) {
     constexpr int b = decltype(BUF)::value, KS = decltype(KSC)::value;
@@ -1121,7 +1119,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
   };
   f32x4 acc[4];
   auto mma = [](hx8 w, hx8 x, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t16_h8, w), __builtin_bit_cast(t16_h8, x), c, 0, 0, 0);
+    return fd_mfma16(w, x, c);
   };
   auto layer = [&](auto KSC, const void* img, const void* img_lo) {
     constexpr int KS = decltype(KSC)::value;
