@@ -52,6 +52,9 @@ int main(int argc, char** argv) {
       for (int b = 0; b < nb; ++b) s += (double)(h[(size_t)b * 16 + k] - h[(size_t)b * 16 + k - 1]);
       printf("  %-30s %8.0f cyc\n", names[k], s / nb);
     }
+    if (a.rows16) {  // per-tile stamps of the last stage (wave 0): tile u end - stage start (stamp 6)
+      for (int u = 0; u < 5; ++u) { double s = 0; for (int b = 0; b < nb; ++b) s += (double)(h[(size_t)b * 16 + 9 + u] - h[(size_t)b * 16 + 6]); printf("  stage 3, tile %d done at      %8.0f cyc\n", u, s / nb); }
+    }
   }
 #endif
   return 0;
