@@ -912,9 +912,10 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
 #pragma unroll
       for (int s = 0; s < T16_KS; ++s) c = mma(Wl[b][s], X[s], c);
       acc[u] = c;
-      // tile boundary.  hipcc's schedule of this loop is fickle: pinned here, the plain variant's stages take 6.5 k cycles instead of 10.8 k
-      // (23.0 -> 20.9 us in the forward) — and the POST variant and mlp16_kernel get slower (26.6 -> 37.6, 15.7 -> 17.9 us), so only here
-      if constexpr (!POST) __builtin_amdgcn_sched_barrier(0);
+      // tile boundary.  hipcc's schedule of this loop is fickle: left alone it interleaves the tiles' products and loads and a stage takes
+      // 10.8 k cycles; with a compiler-level fence here (an LDS-counter wait that nothing is waiting for + a memory clobber) 6.5 k: 23.0 / 26.6
+      // -> 19.4 / 23.6 us per call in the forward.  (`sched_barrier(0)` alone: 21.2 / 37.6; the same fence in mlp16_kernel: no gain.)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     });
   };
   constexpr std::integral_constant<int, T16_NT> NT_D{};
