@@ -78,6 +78,7 @@ static Switches switches_of(const FdiptDims* d) {
   if (f & FDIPT_KF_UNFUSED_NODE) s.no_rowblock = s.no_chain = s.no_splitk = true;
   if (f & FDIPT_KF_NO_SPLIT) s.no_split = true;
   if (f & FDIPT_KF_NO_MERGE) s.no_merge = true;
+  if (f & FDIPT_KF_ROWS32) s.no_tail16 = true;
   if (f & FDIPT_KF_UNFOLDED)
     s.no_et_bias = s.no_ee_bias = s.feats_unfused = s.torf_unfused = s.init_unfused = s.skip_per_block = s.post_unfused =
         s.et4_rows_unfused = true;

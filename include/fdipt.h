@@ -54,7 +54,9 @@ extern "C" {
                                     ~8 % faster, 5x the error of the predicted frames / psi (precision modes)      */
 #define FDIPT_KF_NO_MERGE 64     /* IPA projections in the reference's formulation (k and v explicit) instead of the merged one
                                     (keys = values = the node rows, W_k folded into the query, W_v into the output projection)  */
-#define FDIPT_KF_ALL 127
+#define FDIPT_KF_ROWS32 128      /* node path: the 32-row-block kernels (the default for N > 512) instead of the 16-row ones (tails, transition,
+                                    node embedder, torsion head) for every N                                                  */
+#define FDIPT_KF_ALL 255
 
 typedef void* fdipt_stream_t; /* hipStream_t */
 

@@ -369,3 +369,30 @@ def test_merged_projections_equal_the_reference_formulation():
     assert np.abs(a["rigids"][..., 4:] - b["rigids"][..., 4:]).max() < 1e-4
     for o in (a, b):  # and each within the fp16 bounds of the reference golden
         assert kabsch_free_rmsd(o["atom37"], G["out_atom37"]) < 5e-4
+
+
+@gpu
+@pytest.mark.parametrize("name", ["fwd_full_denovo_n128", "fwd_full_denovo_n300_t50"])
+def test_sixteen_row_node_path_kernels_equal_the_32_row_ones(name):
+    """The 16-row-block kernels of the node path (tfmr_tail16_kernel, mlp16_kernel: v_mfma_f32_16x16x32_f16, default for N <= 512) against the
+    32-row ones (FDIPT_KF_ROWS32) in the same library: the same products in a different grouping of the k index, so the two forwards differ by
+    fp32 summation order only — node representation after every block within 2e-5 relative, frames within 2e-5 A."""
+    from framedipt_amd import _lib
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    G = load_golden(name + ".npz")
+    outs = {}
+    for kf in (0, _lib.KF_ROWS32):
+        conf = config.base_config()
+        d = SE3Diffuser(conf.diffuser, device="cuda")
+        net = ScoreNetwork(conf.model, d, precision="fp16", kernel_flags=kf).load_synthetic(int(G["weight_seed"]), float(G["bb_gain"])).to("cuda")
+        out = net(_feats(G), trace=True)
+        outs[kf] = {k: v.cpu().numpy().copy() for k, v in out.items()}
+    a, b = outs[0], outs[_lib.KF_ROWS32]
+    assert not np.array_equal(a["trace_node"][1], b["trace_node"][1])  # (two different sets of kernels did run)
+    for blk in range(1, 5):
+        rel = np.linalg.norm(a["trace_node"][blk] - b["trace_node"][blk]) / np.linalg.norm(b["trace_node"][blk])
+        assert rel < 2e-5, (blk, rel)
+    assert np.abs(a["rigids"][..., 4:] - b["rigids"][..., 4:]).max() < 2e-5
+    assert np.abs(a["psi"] - b["psi"]).max() < 2e-4  # (unit vectors: a small un-normalised length amplifies the 1e-5 differences)
