@@ -255,6 +255,10 @@ struct RowBlockArgs {
   const float* upd_mask;        // [M] or NULL
   float *quat, *trans;          // [M,4], [M,3]
   L2Warm warm = {};             // weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
+  // fd_node_embed16 only: one more Linear (256 -> 256, split operands, fd_chain_build_image16 images) on the output rows -> out2 [M, ld_out2]
+  // (skip_embed of all trunk blocks stacked)
+  const void *w3 = nullptr, *w3l = nullptr;
+  const float* b3 = nullptr;
 };
 enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS, FD_RB_ET4_IMAGES,
        FD_RB_TRANSITION_BB_SPLIT, FD_RB_NODE_EMBED_72_SPLIT, FD_RB_NODE_EMBED_88_SPLIT, FD_RB_TORSION_SPLIT };

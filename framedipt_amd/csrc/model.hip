@@ -184,6 +184,7 @@ struct DLayout {
   size_t ch_ne0, ch_ne2, ch_ne4, ch_tor1, ch_tor2;  // chain images: node embedder, torsion head
   size_t ch_ne2n, ch_ne4n, ch_tor2n;                // ... natural k order (rowblock.hip)
   size_t lo_ne0, lo_ne2, lo_ne4, lo_tor1, lo_tor2;  // lo images: node embedder, torsion head
+  size_t skip16[2];                                 // ... of the stacked skip_embed matrices [num_blocks * c_skip = 256, c_s] (fused into the node embedder)
   size_t ne16[3][2], tor16[2][2];                   // 16-row images (fd_chain_build_image16; the embedder's first one zero-padded to K = 96), hi / lo
   size_t skip_w32;                                  // ... in fp32 (split operands: the GEMM splits both operands while it stages them)
   size_t skip_w, skip_b;                            // skip_embed of ALL blocks stacked: [num_blocks * c_skip, c_s] operand precision, bias f32
@@ -284,6 +285,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.lo_ne0 = img(cs, L.kn_pad); L.lo_ne2 = img(cs, cs); L.lo_ne4 = img(cs, cs); L.lo_tor1 = img(cs, cs); L.lo_tor2 = img(cs, cs);
     for (int h = 0; h < 2; ++h) { L.ne16[0][h] = img(cs, 96); L.ne16[1][h] = img(cs, cs); L.ne16[2][h] = img(cs, cs); }
     for (int h = 0; h < 2; ++h) { L.tor16[0][h] = img(cs, cs); L.tor16[1][h] = img(cs, cs); }
+    for (int h = 0; h < 2; ++h) L.skip16[h] = img(cs, cs);
     L.ch_ne0 = img(d->c_s, L.kn_pad); L.ch_ne2 = img(d->c_s, d->c_s); L.ch_ne4 = img(d->c_s, d->c_s);
     L.ch_tor1 = img(d->c_s, d->c_s); L.ch_tor2 = img(d->c_s, d->c_s);
     L.ch_ne2n = img(d->c_s, d->c_s); L.ch_ne4n = img(d->c_s, d->c_s); L.ch_tor2n = img(d->c_s, d->c_s);
@@ -583,6 +585,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     if ((rc = lo(iv.ne0, L.lo_ne0)) || (rc = lo(iv.ne2, L.lo_ne2)) || (rc = lo(iv.ne4, L.lo_ne4)) || (rc = lo(iv.tor1, L.lo_tor1)) ||
         (rc = lo(iv.tor2, L.lo_tor2)))
       return rc;
+    if (cs == 256 && d->num_blocks * d->c_skip == 256)  // (skip_w32 was stacked block by block above)
+      for (int h = 0; h < 2; ++h)
+        if ((rc = fd_chain_build_image16((const float*)(D + L.skip_w32), 256, cs, cs, cs, h, D + L.skip16[h], st))) return rc;
     if (cs == 256 && iv.node_in <= 96)
       for (int h = 0; h < 2; ++h)
         if ((rc = fd_chain_build_image16(P + iv.ne0.w, cs, iv.node_in, 96, iv.node_in, h, D + L.ne16[0][h], st)) ||
@@ -776,6 +781,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
              split_skip = split_any && (sw.split_mask & 512u), split_pv = split_any && (sw.split_mask & 1024u);
   (void)split_pv;
   const void *rb_l0 = nullptr, *rb_l1 = nullptr, *rb_l2 = nullptr;  // one-shot: lo images for the next rblock() call
+  const void *rb_w3 = nullptr, *rb_w3l = nullptr; const float* rb_b3 = nullptr; float* rb_out2 = nullptr; int rb_ld2 = 0;  // one-shot: fused skip layer (fd_node_embed16)
+  bool skip_fused = false;
   int rb16 = 0;  // one-shot: the next rblock() call runs on 16-row blocks (1: node embedder, 2: torsion head; its w0 .. / lo pointers are 16-row images)
   auto rblock = [&](int kind, const float* in, int ld_in, const void* w0, const float* b0, const void* w1, const float* b1,
                     const void* w2, const float* b2, const float* resid, int ld_res, const LNW* lnw, const float* post,
@@ -788,6 +795,14 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     r.out2 = nullptr; r.ld_out2 = r.split = 0; r.hid_h16 = nullptr;
     const int k16 = rb16;
     rb16 = 0;
+    if (k16 == 1 && rb_w3) {
+      r.w3 = rb_w3; r.w3l = rb_w3l; r.b3 = rb_b3; r.out2 = rb_out2; r.ld_out2 = rb_ld2; rb_w3 = rb_w3l = nullptr;
+      // (the kernel touches its own last stage's images while it starts: they were last read a whole step ago)
+      if (!sw.no_l2_warm) {  // ... and so were its own hi / lo runs (ne16: three images each; skip16 hi | lo are contiguous)
+        const unsigned run = (unsigned)(fd_chain_image_bytes(256, 96) + 2 * fd_chain_image_bytes(256, 256));
+        r.warm = L2Warm{{w0, r.w0l, r.w3}, {run, run, 2 * (unsigned)fd_chain_image_bytes(256, 256)}};
+      }
+    }
     if (k16 == 1) return fd_node_embed16(r, ld_in, st);
     if (k16 == 2) return fd_torsion16(r, st);
     return fd_rowblock(kind, r, st);
@@ -829,6 +844,12 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     if (split_embed) { rb_l0 = D + L.lo_ne0; rb_l1 = D + L.lo_ne2; rb_l2 = D + L.lo_ne4; }
     const bool ne16 = split_embed && cs == 256 && iv.node_in <= 96 && !sw.no_tail16;  // 16-row blocks (rowblock.hip: mlp16_kernel)
     if (ne16) { rb16 = 1; rb_l0 = D + L.ne16[0][1]; rb_l1 = D + L.ne16[1][1]; rb_l2 = D + L.ne16[2][1]; }
+    // skip_embed(init_node) of all blocks as a fourth layer of the same launch (the GEMM below is then skipped)
+    if (ne16 && split_any && (sw.split_mask & 512u) && d->num_blocks * d->c_skip == 256 && bf && iv.feat_dim >= 1024 && !sw.no_splitk && !sw.skip_per_block &&
+        op.kind == OP_ALL) {
+      rb_w3 = D + L.skip16[0]; rb_w3l = D + L.skip16[1]; rb_b3 = (const float*)(D + L.skip_b); rb_out2 = F(w.skip_all); rb_ld2 = d->num_blocks * d->c_skip;
+      skip_fused = true;
+    }
     RC(rblock(split_embed ? (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72_SPLIT : FD_RB_NODE_EMBED_88_SPLIT)
                     : (L.kn_pad == 72 ? FD_RB_NODE_EMBED_72 : FD_RB_NODE_EMBED_88), F(w.node_feat), L.kn_pad, ne16 ? D + L.ne16[0][0] : D + L.ch_ne0, P + iv.ne0.b,
               ne16 ? D + L.ne16[1][0] : D + L.ch_ne2n, P + iv.ne2.b, ne16 ? D + L.ne16[2][0] : D + L.ch_ne4n, P + iv.ne4.b, nullptr, 0, &iv.neln, res_mask, F(w.node0), cs));
@@ -897,7 +918,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // skip_embed(init_node) of every block depends on the embedder output only: one GEMM launch for all blocks, copied behind the
   // LayerNorm output by the LayerNorm kernel (FDIPT_SKIP_PER_BLOCK: one launch per block as before)
   const bool skip_batched = bf && iv.feat_dim >= 1024 && !sw.no_splitk && !sw.skip_per_block && op.kind == OP_ALL;
-  if (skip_batched && split_skip && (cs & 7) == 0)
+  if (skip_batched && skip_fused) {
+  } else if (skip_batched && split_skip && (cs & 7) == 0)
     RC(fd_linear_splitk_split(R, d->num_blocks * d->c_skip, cs, 1, F(w.node0), cs, (const float*)(D + L.skip_w32), cs, (const float*)(D + L.skip_b),
                               nullptr, F(w.skip_all), 0, d->num_blocks * d->c_skip, st));
   else if (skip_batched)

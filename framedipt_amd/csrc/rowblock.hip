@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
 // KS0: 32-wide k-steps of the first layer (input width a.k0 <= 32 KS0, zero-padded in LDS); NL: 2 or 3 layers (256 wide; ReLU behind every layer
 // but the last); LN: LayerNorm on the output; BB: BackboneUpdate + compose.  <8, 3, true, true> = the transition, <3, 3, true, false> = the node
 // embedder (72 / 88 input features), <8, 2, false, false> = the torsion head's residual block.
-template <int KS0, int NL, bool LN, bool BB>
+// SKIP: one more 256 -> 256 layer (w3 / w3l / b3) on the output rows -> out2.
+template <int KS0, int NL, bool LN, bool BB, bool SKIP = false>
 __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, int k0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;
@@ -1223,6 +1224,29 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
       }
     }
   }
+  if constexpr (SKIP) {  // skip_embed of every trunk block on the rows just produced (they never leave the CU for it)
+    w_load(B0, K8C, a.w3, a.w3l, wave);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+      const f32x4 gm = *(const f32x4*)(cst + 3 * TR_D + f0), bt = *(const f32x4*)(cst + 4 * TR_D + f0);
+      put4(hs, lr * TR_XROW + 2 * f0, LN ? ((acc[u][0] - mu) * rstd * gm[0] + bt[0]) * pm : acc[u][0] * pm,
+           LN ? ((acc[u][1] - mu) * rstd * gm[1] + bt[1]) * pm : acc[u][1] * pm, LN ? ((acc[u][2] - mu) * rstd * gm[2] + bt[2]) * pm : acc[u][2] * pm,
+           LN ? ((acc[u][3] - mu) * rstd * gm[3] + bt[3]) * pm : acc[u][3] * pm);  // (hs: dead since the second layer read it)
+    }
+    __syncthreads();
+    x_load(K8C, hs);
+    layer(K8C, a.w3, a.w3l);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+      const f32x4 bv = *(const f32x4*)(a.b3 + f0);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = acc[u][i] + bv[i];
+      if (row0 + lr < a.M) *(f32x4*)(a.out2 + (long)(row0 + lr) * a.ld_out2 + f0) = o;
+    }
+  }
   if constexpr (!BB) {
     fd_l2_warm_done(warm_tok);
     return;
@@ -1264,15 +1288,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
   fd_l2_warm_done(warm_tok);
 }
 // images w0 / w1 / w2 (+ lo): fd_chain_build_image16 (the first one with K padded to 32 KS0)
-template <int KS0, int NL, bool LN, bool BB>
+template <int KS0, int NL, bool LN, bool BB, bool SKIP = false>
 static int mlp16_launch(const RowBlockArgs& a, int k0, hipStream_t st) {
   static FdPerDevice attr_dev;
   const int dev_ = fd_device();
   if (!attr_dev.get(dev_)) {
-    if (hipFuncSetAttribute((const void*)mlp16_kernel<KS0, NL, LN, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)mlp16_kernel<KS0, NL, LN, BB, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
     attr_dev.set(dev_, 1);
   }
-  hipLaunchKernelGGL((mlp16_kernel<KS0, NL, LN, BB>), dim3(cdiv(a.M, 16)), dim3(FD_THREADS), TR_SMEM, st, a, k0);
+  hipLaunchKernelGGL((mlp16_kernel<KS0, NL, LN, BB, SKIP>), dim3(cdiv(a.M, 16)), dim3(FD_THREADS), TR_SMEM, st, a, k0);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -1286,6 +1310,10 @@ int fd_transition16(const RowBlockArgs& a, hipStream_t st) {
 // FD_RB_NODE_EMBED_72 / 88_SPLIT (k0 input features, k0 % 4 == 0, k0 <= 96) and FD_RB_TORSION_SPLIT on 16-row blocks
 int fd_node_embed16(const RowBlockArgs& a, int k0, hipStream_t st) {
   if (a.M <= 0 || (a.ld_in & 3) || (a.ld_out & 3) || (k0 & 3) || k0 > 96 || !a.w0l || !a.w1l || !a.w2l || !a.gamma || !a.beta) return FDIPT_EINVAL;
+  if (a.w3) {
+    if (!a.w3l || !a.b3 || !a.out2 || (a.ld_out2 & 3)) return FDIPT_EINVAL;
+    return mlp16_launch<3, 3, true, false, true>(a, k0, st);
+  }
   return mlp16_launch<3, 3, true, false>(a, k0, st);
 }
 int fd_torsion16(const RowBlockArgs& a, hipStream_t st) {
