@@ -281,7 +281,7 @@ def main():
         def new_loop():
             if streams > 1:
                 return inference.StreamedLoops(net, diff, feats, streams, T, 0.01, noise_tape=tape, reserve_cus=a.reserve_cus, aux_traj=True,
-                                               noise_scale=0.1, inpainting=inp)
+                                               noise_scale=0.1, inpainting=inp, experimental=True)
             return inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp,
                                          noise_tape=tape)
         # timed steps: the whole schedule, or K steps spread evenly over it (first and last included)

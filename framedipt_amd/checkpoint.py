@@ -56,12 +56,16 @@ def _stub_for(module: str, name: str):
 
 # Globals a FrameDiPT checkpoint may name besides the omegaconf classes: the tensor-rebuild helpers of torch.save, the containers
 # of a state dict / optimizer state, the enums / typing objects an omegaconf 2.x container pickles.  Everything else is refused:
-# unpickling executes the callables a pickle names, so an untrusted ``.pth`` must not get to choose them.
+# unpickling executes the callables a pickle names, so an untrusted ``.pth`` must not get to choose them.  Deliberately absent:
+# ``builtins.getattr`` / ``builtins.object`` (with a rebuild helper in reach, ``getattr(f, "__globals__")`` walks to ``sys.modules`` and
+# from there to ``os.system``), ``pathlib`` (its classes touch the file system), and any dotted name (protocol 4 resolves
+# ``a.b.c`` attribute by attribute, i.e. it is ``getattr`` again).  ``omegaconf.*`` names ALWAYS become inert stand-ins that only keep
+# the pickled state — also when the real package is installed: its classes are not needed to read the configuration out of the state.
 _ALLOWED_GLOBALS = {
     ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "set"),
     ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "str"), ("builtins", "bool"), ("builtins", "complex"),
-    ("builtins", "slice"), ("builtins", "object"), ("builtins", "getattr"), ("typing", "Any"), ("typing", "Union"), ("typing", "Optional"),
-    ("typing", "Dict"), ("typing", "List"), ("typing", "Tuple"), ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"), ("pathlib", "Path"),
+    ("builtins", "slice"), ("typing", "Any"), ("typing", "Union"), ("typing", "Optional"),
+    ("typing", "Dict"), ("typing", "List"), ("typing", "Tuple"),
     ("enum", "Enum"), ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
     ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"), ("_codecs", "encode"),
     ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
@@ -75,11 +79,13 @@ _TORCH_DTYPES = {"float32", "float64", "float16", "bfloat16", "int64", "int32", 
 
 class _ShimUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
+        if "." in name or not name.isidentifier():
+            raise pickle.UnpicklingError(f"checkpoint names the dotted global {module}.{name}: refused (attribute walks are getattr in disguise; "
+                                         "see framedipt_amd/checkpoint.py:_ALLOWED_GLOBALS)")
         if module == "omegaconf" or module.startswith("omegaconf."):
-            try:
-                return super().find_class(module, name)  # the real package, if present
-            except (ImportError, AttributeError):
-                return _stub_for(module, name)
+            if not all(p.isidentifier() for p in module.split(".")):
+                raise pickle.UnpicklingError(f"checkpoint names the global {module}.{name}: refused")
+            return _stub_for(module, name)  # never the real class: only the pickled state is read (to_plain)
         if module == "__builtin__":  # protocol-2 spelling of builtins
             module = "builtins"
         if (module, name) in _ALLOWED_GLOBALS or (module == "torch" and (name in _TORCH_DTYPES or name.endswith(("Storage", "Tensor")))):
@@ -188,10 +194,10 @@ def apply_checkpoint_conf(cfg, ckpt_conf: dict, seed=None, conf_overrides: dict 
     (the caller's overrides, inference.py:117,146-147) is merged last and wins over the checkpoint's values."""
     from .config import to_conf
     cfg = to_conf(merge(dict(cfg), {"model": ckpt_conf.get("model", {})}))
-    if conf_overrides:
-        cfg = to_conf(merge(dict(cfg), conf_overrides))
     if "diffuser" in ckpt_conf and "r3" in ckpt_conf["diffuser"]:
         cfg.diffuser.r3 = to_conf(dict(ckpt_conf["diffuser"]["r3"]))
+    if conf_overrides:  # (after the checkpoint's diffuser.r3, as the reference: an override of e.g. diffuser.r3.min_b wins)
+        cfg = to_conf(merge(dict(cfg), conf_overrides))
     m = cfg.model
     # fields the library reads from the ipa / embed sub-configs (config/base.yaml interpolations)
     m.ipa.setdefault("c_s", m.node_embed_size)

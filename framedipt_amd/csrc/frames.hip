@@ -357,7 +357,8 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
   const long total = (long)B * N;
   const long r_first = (long)blockIdx.x * RPB;
   const int b_first = (int)((r_first < total ? r_first : total - 1) / N);
-  const bool use_tab = N >= RPB;  // a block then spans at most two samples; tiny N evaluates the weights per lane
+  // a block then spans at most two samples; tiny N evaluates the weights per lane; the cached-score path (x.score_table) has no series
+  const bool use_tab = N >= RPB && !x.score_table;
   if (use_tab) {
     const int b1 = b_first + 1 < B ? b_first + 1 : B - 1;
     const double s0 = sigma[b_first], s1 = sigma[b1];

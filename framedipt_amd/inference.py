@@ -172,8 +172,9 @@ class StreamedLoops:
 
     MAX_STREAMS = 2   # experimental feature, verified for two streams only (see below)
     MAX_LENGTH = 384  # ... and for N <= 384 only
+    OPT_IN_ENV = "FDIPT_EXPERIMENTAL_STREAMS"  # more than one stream is an explicit opt-in: experimental=True or this variable set to 1
 
-    def __init__(self, model, diffuser, data_init, n_streams, num_t, min_t, noise_tape=None, reserve_cus=48, **kw):
+    def __init__(self, model, diffuser, data_init, n_streams, num_t, min_t, noise_tape=None, reserve_cus=48, experimental=False, **kw):
         # Soak results (tools/soak_streams.sh, tools/streams_stat.py; trajectories against the single-stream run):
         #   * N = 128 / 300, two streams, any number of reserved CUs: 0 mismatching runs of ~400;
         #   * N = 300, three or four streams: 15 - 40 % of the runs differ in one sample from some step on;
@@ -182,14 +183,18 @@ class StreamedLoops:
         # that step are bit-identical), while the other stream's EdgeTransition runs on the rest of the chip; a library built with
         # `-mllvm -amdgpu-waitcnt-forcezero` does not show it; not localised further.  The single-stream path is bit-reproducible at every
         # size.  So: refused beyond what the soaks cover rather than offered.
+        import os
+        B = data_init["rigids_t"].shape[0]
+        requested, n_streams = n_streams, max(1, min(n_streams, B))  # (the limits apply to what would actually run)
         if n_streams > self.MAX_STREAMS:
-            raise ValueError(f"streams={n_streams}: sub-batch streams are verified bit-identical to the single-stream run for at most "
+            raise ValueError(f"streams={requested}: sub-batch streams are verified bit-identical to the single-stream run for at most "
                              f"{self.MAX_STREAMS} streams")
         if n_streams > 1 and data_init["rigids_t"].shape[1] > self.MAX_LENGTH:
-            raise ValueError(f"streams={n_streams} at N = {data_init['rigids_t'].shape[1]}: sub-batch streams are verified bit-identical to "
+            raise ValueError(f"streams={requested} at N = {data_init['rigids_t'].shape[1]}: sub-batch streams are verified bit-identical to "
                              f"the single-stream run for N <= {self.MAX_LENGTH} only")
-        B = data_init["rigids_t"].shape[0]
-        n_streams = max(1, min(n_streams, B))
+        if n_streams > 1 and not (experimental or os.environ.get(self.OPT_IN_ENV) == "1"):
+            raise ValueError(f"streams={requested}: concurrent sub-batch streams are an experimental feature with an open correctness item beyond "
+                             f"the verified range (DESIGN.md, concurrency): opt in with experimental_streams=True or {self.OPT_IN_ENV}=1")
         cuts = [round(i * B / n_streams) for i in range(n_streams + 1)]
         self.dev = model.device
         if noise_tape is None:
@@ -240,15 +245,16 @@ class StreamedLoops:
 
 def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None,
-                 return_device=False, streams=1):
+                 return_device=False, streams=1, experimental_streams=False):
     """Same arguments / returned keys as the reference.  ``noise_tape=(z_rot, z_trans)`` ([num_t-1,B,N,3] float64
     N(0,1) draws) overrides the global ``np.random`` stream (sample-sharded runs).  ``data_init`` tensors carry a
     leading batch dimension B >= 1 (the reference always passes B = 1).  ``streams=n``: the batch runs as n sub-batches on n HIP
-    streams (same results; the latency-bound node path of one sub-batch overlaps the pair kernels of the other)."""
+    streams (same results; the latency-bound node path of one sub-batch overlaps the pair kernels of the other) — experimental: needs
+    ``experimental_streams=True`` (or FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``)."""
     if streams > 1 and data_init["rigids_t"].shape[0] > 1:  # sub-batches on their own HIP streams (same results)
         loop = StreamedLoops(model, diffuser, data_init, streams, num_t, min_t, noise_tape=noise_tape, center=center, aux_traj=aux_traj,
                              self_condition=self_condition, noise_scale=noise_scale, embed_self_conditioning=embed_self_conditioning,
-                             inpainting=inpainting, input_aatype=input_aatype)
+                             inpainting=inpainting, input_aatype=input_aatype, experimental=experimental_streams)
     else:
         loop = ReverseLoop(model, diffuser, data_init, num_t, min_t, center, aux_traj, self_condition, noise_scale,
                            embed_self_conditioning, inpainting, input_aatype, noise_tape)

@@ -23,7 +23,8 @@ def run_rank(dataset, diffuser, run_batch, rank: int, world: int, out_dir: str, 
              max_batch: int = 8, keep=("prot_traj",), final_only: bool = True, mixed: bool = True):
     """Run this rank's share of ``dataset``.  ``run_batch(feats, tape) -> dict of arrays with a batch axis at dim 1`` (the
     keys of ``inference_fn``).  ``mixed``: samples of similar (not only equal) length share a batch, padded with res_mask = 0
-    rows (sharding.batches_mixed / stack_items_padded); results are cut back to each sample's own length.
+    rows (sharding.batches_mixed / stack_items_padded; a batch never spans two kernel-selection classes, so a sample's bits do not
+    depend on its batch mates); results are cut back to each sample's own length.
     Returns the list of records written by this rank."""
     from . import sharding
     os.makedirs(out_dir, exist_ok=True)

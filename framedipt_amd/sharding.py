@@ -117,14 +117,29 @@ def stack_items_padded(items, multiple: int = 4):
     return feats, tape, lengths
 
 
+# Lengths at which the library switches kernels (csrc: the o_pair row variants at 320 / 640, the attention / sequence-attention key-tile
+# variants at 384 / 512 / 768, the 16-row node-path kernels up to 512, the register-attention limit 1024).  Inside one class a sample's
+# real residues are bit-identical however far it is padded; across a boundary they agree to tolerance only (different summation orders).
+KERNEL_CLASS_BOUNDS = (320, 384, 512, 640, 768, 1024)
+
+
+def kernel_class(n: int, multiple: int = 4) -> int:
+    """Kernel-selection class of a sample of ``n`` residues once padded to a multiple of ``multiple`` (stack_items_padded)."""
+    n_pad = -(-int(n) // multiple) * multiple
+    return sum(n_pad > b for b in KERNEL_CLASS_BOUNDS)
+
+
 def batches_mixed(lengths, max_batch: int, max_waste: float = 0.15):
     """Group local item positions into batches of at most ``max_batch`` samples of SIMILAR length: positions sorted by length,
-    a batch is closed when it is full or when padding its shortest member to its longest would waste more than ``max_waste`` of
-    the pair work (1 - (n_min / n_max)^2).  Equal lengths always share a batch."""
+    a batch is closed when it is full, when padding its shortest member to its longest would waste more than ``max_waste`` of
+    the pair work (1 - (n_min / n_max)^2), or when the next sample belongs to another kernel-selection class (``kernel_class``): a
+    sample then runs on the kernels its own (4-padded) length selects whatever batch / shard / world size it rides in, which keeps
+    sharded runs bit-reproducible.  Equal lengths always share a batch."""
     order = sorted(range(len(lengths)), key=lambda p: (lengths[p], p))
     out, cur = [], []
     for p in order:
-        if cur and (len(cur) == max_batch or 1.0 - (lengths[cur[0]] / lengths[p]) ** 2 > max_waste):
+        if cur and (len(cur) == max_batch or 1.0 - (lengths[cur[0]] / lengths[p]) ** 2 > max_waste
+                    or kernel_class(lengths[cur[0]]) != kernel_class(lengths[p])):
             out.append(cur)
             cur = []
         cur.append(p)

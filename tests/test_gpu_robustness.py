@@ -138,7 +138,9 @@ def test_streamed_sub_batches_match_the_single_stream_trajectory():
     np.random.seed(11)
     tape = draw_noise_tape(d, T - 1, B, N)
     one = inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
-    two = inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape, streams=2)
+    with pytest.raises(ValueError, match="opt in"):  # more than one stream is never silently allowed
+        inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape, streams=2)
+    two = inference_fn(net, d, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape, streams=2, experimental_streams=True)
     assert sorted(one) == sorted(two)
     for k in one:
         host = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)  # noqa: E731
@@ -160,7 +162,12 @@ def test_sub_batch_streams_are_refused_beyond_the_verified_range():
         ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": 4}), d, "cuda")
         feats, tape = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, 3, 0.01) for i in range(4)])
         with pytest.raises(ValueError, match="verified bit-identical"):
-            inference_fn(net, d, feats, num_t=3, min_t=0.01, noise_tape=tape, streams=streams)
+            inference_fn(net, d, feats, num_t=3, min_t=0.01, noise_tape=tape, streams=streams, experimental_streams=True)
+    # the limits apply to the streams that would actually run: a 2-sample batch asked for 3 streams runs on 2 (refused only for its length) ...
+    one = {k: (v[:1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 4 else v) for k, v in feats.items()}
+    from framedipt_amd.inference import StreamedLoops
+    lp = StreamedLoops(net, d, one, 2, 3, 0.01, noise_tape=tuple(z[:, :1] for z in tape))  # ... and B = 1 at N = 388 is a single stream: allowed
+    assert len(lp.loops) == 1
 
 
 def test_edge_transition_clock_probe():

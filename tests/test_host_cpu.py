@@ -429,3 +429,60 @@ def test_checkpoint_loader_refuses_foreign_globals(tmp_path):
     cfg = checkpoint.apply_checkpoint_conf(config.base_config(), {"model": {"ipa": {"num_blocks": 2}}},
                                            conf_overrides={"model": {"ipa": {"num_blocks": 3}}})
     assert cfg.model.ipa.num_blocks == 3
+
+
+def test_checkpoint_loader_refuses_getattr_gadgets(tmp_path):
+    """The allow-list must not contain a way to walk attributes: ``getattr(_rebuild_tensor_v2, "__globals__")`` reaches ``sys.modules`` and
+    ``os.system`` through allowed names only (round-3 advisor finding); protocol-4 dotted names are the same walk; ``omegaconf.*`` names
+    never resolve to real attributes (``omegaconf.omegaconf`` + ``os.system``), they become inert stand-ins."""
+    import io
+    import pickle
+    import pickletools  # noqa: F401  (documented aid for reading the hand-written streams below)
+
+    from framedipt_amd import checkpoint, config
+
+    def load(b):
+        return checkpoint._ShimUnpickler(io.BytesIO(b)).load()
+
+    # (1) GLOBAL builtins getattr / builtins object are refused
+    for mod, name in (("builtins", "getattr"), ("builtins", "object"), ("pathlib", "Path"), ("pathlib", "PosixPath")):
+        with pytest.raises(pickle.UnpicklingError, match="refused"):
+            load(b"c" + mod.encode() + b"\n" + name.encode() + b"\n.")
+    # (2) the gadget itself: getattr(torch._utils._rebuild_tensor_v2, "__globals__")
+    gadget = (b"cbuiltins\ngetattr\n(ctorch._utils\n_rebuild_tensor_v2\nV__globals__\ntR.")
+    with pytest.raises(pickle.UnpicklingError, match="refused"):
+        load(gadget)
+    # (3) protocol-4 dotted names: STACK_GLOBAL with "torch._utils" / "_rebuild_tensor_v2.__globals__", and through the omegaconf branch
+    def stack_global(mod, name):
+        return (b"\x80\x04" + b"\x8c" + bytes([len(mod)]) + mod.encode() + b"\x8c" + bytes([len(name)]) + name.encode() + b"\x93.")
+    for mod, name in (("torch._utils", "_rebuild_tensor_v2.__globals__"), ("omegaconf.omegaconf", "os.system"), ("omegaconf", "omegaconf.os.system")):
+        with pytest.raises(pickle.UnpicklingError, match="refused"):
+            load(stack_global(mod, name))
+    # (4) an omegaconf name is a stand-in, never a resolved attribute — also when it names something a real package would export
+    cls = load(stack_global("omegaconf.omegaconf", "os"))
+    assert getattr(cls, "_fd_stub", False) and isinstance(cls, type)
+    # (5) an override of diffuser.r3 wins over the checkpoint's diffuser.r3 (Inference._load_ckpt assigns r3 first, merges overrides last)
+    r3 = dict(config.base_config().diffuser.r3)
+    r3["min_b"] = 0.2
+    cfg = checkpoint.apply_checkpoint_conf(config.base_config(), {"diffuser": {"r3": r3}}, conf_overrides={"diffuser": {"r3": {"min_b": 0.3}}})
+    assert cfg.diffuser.r3.min_b == 0.3
+    cfg = checkpoint.apply_checkpoint_conf(config.base_config(), {"diffuser": {"r3": r3}})
+    assert cfg.diffuser.r3.min_b == 0.2
+
+
+def test_mixed_batches_stay_inside_one_kernel_selection_class():
+    """sharding.batches_mixed: a batch never spans a length at which the library switches kernels (so a sample's bits do not depend on
+    its batch mates: round-3 advisor finding), equal lengths share a batch, every position appears once."""
+    from framedipt_amd import sharding
+    rng = np.random.default_rng(0)
+    lengths = [int(x) for x in rng.integers(290, 800, 200)] + [300] * 5 + [384, 385, 388, 512, 513, 640, 641]
+    for max_batch, waste in ((8, 0.15), (4, 0.05), (64, 0.9)):
+        groups = sharding.batches_mixed(lengths, max_batch, waste)
+        assert sorted(p for g in groups for p in g) == list(range(len(lengths)))
+        for g in groups:
+            assert 1 <= len(g) <= max_batch
+            n_pad = -(-max(lengths[p] for p in g) // 4) * 4
+            classes = {sharding.kernel_class(lengths[p]) for p in g} | {sharding.kernel_class(n_pad)}
+            assert len(classes) == 1, (g, [lengths[p] for p in g])
+    assert sharding.kernel_class(384) == sharding.kernel_class(381) != sharding.kernel_class(385)
+    assert sharding.kernel_class(300) == sharding.kernel_class(320) != sharding.kernel_class(321)

@@ -1,3 +1,5 @@
+import os
+os.environ["FDIPT_EXPERIMENTAL_STREAMS"] = "1"  # (investigation tool)
 import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from framedipt_amd import config, sharding

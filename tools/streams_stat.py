@@ -1,5 +1,7 @@
 """Which sub-batch stream counts reproduce the single-stream trajectory bit for bit, how often, and where they first differ.
     python tools/streams_stat.py N B T reps [kernel_flags]"""
+import os
+os.environ["FDIPT_EXPERIMENTAL_STREAMS"] = "1"  # (investigation tool)
 import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from framedipt_amd import config, sharding
