@@ -715,6 +715,7 @@ __global__ void points_kernel(PointsArgs a) {
 __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* vs = (unsigned short*)smem;  // [H/2][72][16] bf16: hi rows 0..35, lo rows 36..71, permuted key slot
+  float* kps = (float*)(smem + (size_t)(a.H >> 1) * 72 * 16 * 2);  // kpf: [H/2][16 keys][24] global-frame key points (fp32)
   const int tid = threadIdx.x, kk = tid >> 4, sub = tid & 15;
   const int ng = (a.N + 15) >> 4, HH = a.H >> 1;
   const int half = blockIdx.x & 1, bg = blockIdx.x >> 1, b = bg / ng, g = bg - b * ng;
@@ -769,6 +770,9 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
           vs[(hl * 72 + rw) * 16 + slot] = vh;
           vs[(hl * 72 + 36 + rw) * 16 + slot] = f2h(g3[c] - h2f(vh));
         }
+      } else if (a.kpf) {  // a key point: staged for the fragment image below
+#pragma unroll
+        for (int c = 0; c < 3; ++c) kps[(hl * 16 + kk) * 24 + 3 * e + c] = g3[c];
       }
     }
     fd_store3(dst, g3[0], g3[1], g3[2]);  // (not one dwordx3 store: common.hpp)
@@ -779,6 +783,45 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
     const int hl = u / 144, rem = u - hl * 144, rw = rem >> 1, hf = rem & 1;
     const uint4 val = *(const uint4*)(vs + (hl * 72 + rw) * 16 + 8 * hf);
     *(uint4*)(a.vpt + (((((long)b * a.H + half * HH + hl) * 3 + (rw >> 5)) * ks + g) * 64 + hf * 32 + (rw & 31)) * 8) = val;
+  }
+  if (a.kpf) {
+    // key-point fragment image (kernels.hpp: fd_kpf layout): 8 units of 16 B per (head, key) — fp16 hi / lo thirds of the 24 coordinates
+    // and the mask / norm unit X; the last group of a sample also writes the all-padding group up to Np when there is one
+    const int ntl = a.Np >> 5;
+    const int g_end = g == ng - 1 ? (a.Np >> 4) : g + 1;
+    for (int gg = g; gg < g_end; ++gg)
+      for (int u = tid; u < HH * 128; u += 256) {
+        const int un = u & 7, k16 = (u >> 3) & 15, hl = u >> 7, f = un >> 1, hf = un & 1, hh = half * HH + hl;
+        const int keyu = 16 * gg + k16;
+        const bool lv = gg == g && keyu < a.N;
+        const float* kv = kps + (hl * 16 + k16) * 24;
+        unsigned short o[8];
+        if (f == 3 && hf == 1) {
+          float kn = 0.f;
+          if (lv)
+#pragma unroll
+            for (int c = 0; c < 24; ++c) kn = fmaf(kv[c], kv[c], kn);
+          const float m = lv ? a.res_mask[(long)b * a.N + keyu] : 0.f;
+          const float t0 = -0.5f * a.gamma[hh] * kn;
+          const unsigned short p0 = f2f16(t0);
+          const float t1 = t0 - f162f(p0);
+          const unsigned short p1 = f2f16(t1);
+          const unsigned short p2 = f2f16(t1 - f162f(p1));
+          o[0] = f2f16(2.f * m); o[1] = f2f16(m); o[2] = f2f16(lv ? 0.f : -60000.f); o[3] = p0; o[4] = p1; o[5] = p2; o[6] = o[7] = 0;
+        } else {
+          const int c0 = f < 2 ? 8 * hf : 16;
+          const bool lo = f == 1 || (f == 2 && hf == 1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = lv ? kv[c0 + e] : 0.f;
+            const unsigned short xh = f2f16(x);
+            o[e] = lo ? f2f16(x - f162f(xh)) : xh;
+          }
+        }
+        uint4 val;
+        val.x = o[0] | ((unsigned)o[1] << 16); val.y = o[2] | ((unsigned)o[3] << 16); val.z = o[4] | ((unsigned)o[5] << 16); val.w = o[6] | ((unsigned)o[7] << 16);
+        *(uint4*)(a.kpf + ((((((long)b * a.H + hh) * ntl + (keyu >> 5)) * FD_KPF_FRAGS + f) * 64 + hf * 32 + (keyu & 31)) << 3)) = val;
+      }
   }
   if (a.node) {
     // merged projection: this 16-group of keys of the node-row images (c_s = 256): block half 0 writes the K image rows, half 1 the
@@ -827,12 +870,13 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
 
 int fd_points(const PointsArgs& a, hipStream_t st) {
   if (a.vpt && a.Pv == 12 && (a.H & 1) == 0 && (a.H / 2) * (2 * a.Pq + a.Pv) <= 128 && (a.ld & 0) == 0 && !FD_DEV_ENV("FDIPT_POINTS_V1")) {
-    const size_t smem = (size_t)(a.H / 2) * 72 * 16 * 2;
+    if (a.kpf && (a.Pq != 8 || !a.gamma || !a.res_mask)) return FDIPT_EINVAL;
+    const size_t smem = (size_t)(a.H / 2) * 72 * 16 * 2 + (a.kpf ? (size_t)(a.H / 2) * 16 * 24 * 4 : 0);
     hipLaunchKernelGGL(points16_kernel, dim3(2 * a.B * ((a.N + 15) / 16)), dim3(256), smem, st, a);
     FD_CHECK_LAUNCH();
     return FDIPT_OK;
   }
-  if (a.node) return FDIPT_EINVAL;  // (the node-row images ride on the 16-keys-per-block kernel only)
+  if (a.node || a.kpf) return FDIPT_EINVAL;  // (the node-row / key-point images ride on the 16-keys-per-block kernel only)
   hipLaunchKernelGGL(points_kernel, dim3(a.B * a.N), dim3(256), 0, st, a);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;

@@ -5,9 +5,10 @@
 // so every lane holds only N/8 scores.  Operands come pre-formatted from ipa_proj_kernel (gemm.hip):
 //   scalar logits    S^T[key, query] = Kb_tile * Qb^T            bf16 MFMA, A (K fragments, 1 KB linear loads) straight
 //                    from HBM/L2, B = Q regs
-//   point logits     -1/2 |q_pt - k_pt|^2 = q.k - |k|^2/2 - |q|^2/2  as a 26-deep fp32 MFMA (exact fp32 FMA chain):
-//                    A = [k_pts | -|k|^2/2 | 1] rows straight from HBM, B = [q_pts | 1 | -|q|^2/2] registers
-//   mask             m_i m_j as one more fp32 MFMA step (padded keys carry a -1e25 marker)
+//   point logits     -1/2 |q_pt - k_pt|^2 = q.k - |k|^2/2 - |q|^2/2; the last term is constant along a softmax row and dropped, the
+//                    rest runs on fp16 hi / lo parts as five fp16 MFMAs (2^-22 relative): A = the key-point fragment image
+//                    points16_kernel writes (kernels.hpp: fd_kpf layout; linear 1 KB loads), B = query points in registers
+//   mask             1e5 m_i m_j as one more fp16 MFMA (exact: 2 m_j * 32768 m_i + m_j * 34464 m_i; padded keys carry a marker)
 //   softmax          registers + lane^32 shuffle, cross-wave max / sum through 2 x 128 floats of LDS
 //   o = a v          P fragments are exchanged through LDS once; wave w then owns d tiles {2w, 2w+1} over ALL keys,
 //                    A = Vt rows (V transposed, key-permuted) straight from HBM/L2 — no LDS staging, no reduction
@@ -92,36 +93,40 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   }
   const float mi = a.res_mask[rb + i];
   const float gam = a.gamma[h];
-  float qB[13];  // B operand of the point product (k index 2s+hi), pre-multiplied by the head's point weight gamma
+  // B operands of the mask / point products (IEEE fp16; pairing with the key-point fragment image: kernels.hpp, fd_kpf layout).  With
+  // q = gamma * (the query's 24 global-frame point coordinates), thirds q0 | q1 | q2, h / l = fp16 hi / lo parts, lane half hi:
+  //   Bq01h = h(q0) | h(q1)     Bq01l = l(q0) | l(q1)     Bq2h = h(q2) | h(q2)     Bq2x = l(q2) | [0,0,0,1,1,1,0,0]
+  //   Bm    = 0 | [32768 m_i, 34464 m_i, 60000, 0, ...]   (2 m_j * 32768 m_i + m_j * 34464 m_i = 1e5 m_i m_j exactly)
+  f16x8 Bq01h, Bq01l, Bq2h, Bq2x, Bm;
   {
     const float* qpr = a.qp + ((rb + i) * H + h) * 24;
-    float qn = 0.f;
 #pragma unroll
-    for (int c = 0; c < 24; ++c) qn += qpr[c] * qpr[c];
-#pragma unroll
-    for (int s = 0; s < 12; ++s) qB[s] = gam * qpr[2 * s + hi];
-    qB[12] = gam * (hi ? -0.5f * qn : 1.0f);
+    for (int e = 0; e < 8; ++e) {
+      const float v = gam * qpr[8 * hi + e], v2 = gam * qpr[16 + e];
+      const _Float16 vh = (_Float16)v, v2h = (_Float16)v2;
+      Bq01h[e] = vh;
+      Bq01l[e] = (_Float16)(v - (float)vh);
+      Bq2h[e] = v2h;
+      Bq2x[e] = hi ? (_Float16)((e >= 3 && e < 6) ? 1.f : 0.f) : (_Float16)(v2 - (float)v2h);
+      Bm[e] = (_Float16)0.f;
+    }
+    if (hi) { Bm[0] = (_Float16)(32768.f * mi); Bm[1] = (_Float16)(34464.f * mi); Bm[2] = (_Float16)60000.f; }
   }
   FD_STAMP(1);
   // ---- phase 1: logits of this wave's key tiles t = wave, wave+4, ...  The global operands of tile u+1 (K rows as A
   // fragments, key points, bias row pieces, mask) are fetched while tile u runs through the matrix cores.
   struct TileIn {
     hx8 k[16];
-    f32x4 kp[6];
+    f16x8 kf[FD_KPF_FRAGS];
     f32x4 bv[4];
-    float mA;
   };
   auto tile_load = [&](TileIn& ti, int t) {
-    const int jA_raw = 32 * t + li;          // key owned by this lane as an A-operand ROW
-    const bool vA = jA_raw < N;
-    const int jA = vA ? jA_raw : N - 1;
     const half_t* kr = a.Kb + ((kvh * nt + t) * 16 * 64 + lane) * 8;  // fragment order (padded keys are zero rows)
 #pragma unroll
     for (int s = 0; s < 16; ++s) ti.k[s] = a3_ld(kr + s * 512);
-    const float* kpr = a.kp + ((rb + jA) * H + h) * 24;
+    const half_t* pr = a.kpf + ((bh * nt + t) * (FD_KPF_FRAGS * 64) + lane) * 8;  // key-point fragments (padded keys: marker in X)
 #pragma unroll
-    for (int c4 = 0; c4 < 6; ++c4) ti.kp[c4] = *(const f32x4*)(kpr + 4 * c4);
-    ti.mA = vA ? a.res_mask[rb + jA] : -1e25f;   // padded keys: marker so that the logit becomes -1e30
+    for (int f = 0; f < FD_KPF_FRAGS; ++f) ti.kf[f] = __builtin_bit_cast(f16x8, *(const u16x8*)(pr + f * 512));
     const float* bt = a.bias + (((bh * nt + qt) * nt + t) * 32 + li) * 32 + 4 * hi;  // fd_bias_frag_off: this query's row of the tile
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -144,24 +149,19 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       if (!DB) tile_load(tin[0], t);
       const TileIn& ti = tin[DB ? (u & 1) : 0];
       // ONE accumulator for the three terms: it starts at -1e5, the mask product 1e5 m_i m_j brings an unmasked pair back
-      // to exactly 0 (a masked one stays at -1e5, a padded key goes to -1e30) BEFORE the small terms are added, so nothing
-      // is lost to the large constant; then gamma * (q.k - |k|^2/2 - |q|^2/2) as a 26-deep fp32 MFMA chain, then Q K^T
+      // to exactly 0 (a masked one stays at -1e5, a padded key goes to -3.6e9) BEFORE the small terms are added, so nothing
+      // is lost to the large constant (the mask product is its own MFMA: every partial sum of it is exactly representable);
+      // then gamma (q.k - |k|^2 / 2) on fp16 hi / lo parts (h.h + l.h + h.l: 2^-22 relative, five MFMAs of 32 cycles where the
+      // 26-deep fp32 chain of rounds 1 - 3 took thirteen of 64), then Q K^T
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = -1e5f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 0.f : ti.mA, hi ? 0.f : 1e5f * mi, acc, 0, 0, 0);
-      float kpv[24];
-#pragma unroll
-      for (int c4 = 0; c4 < 6; ++c4) {
-        kpv[4 * c4] = ti.kp[c4][0]; kpv[4 * c4 + 1] = ti.kp[c4][1]; kpv[4 * c4 + 2] = ti.kp[c4][2]; kpv[4 * c4 + 3] = ti.kp[c4][3];
-      }
-      float kn = 0.f;
-#pragma unroll
-      for (int c = 0; c < 24; ++c) kn += kpv[c] * kpv[c];
-#pragma unroll
-      for (int s = 0; s < 12; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? kpv[2 * s + 1] : kpv[2 * s], qB[s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? 1.0f : -0.5f * kn, qB[12], acc, 0, 0, 0);
+      acc = fd_mfma32_f16(ti.kf[3], Bm, acc);
+      acc = fd_mfma32_f16(ti.kf[0], Bq01h, acc);
+      acc = fd_mfma32_f16(ti.kf[1], Bq01h, acc);
+      acc = fd_mfma32_f16(ti.kf[0], Bq01l, acc);
+      acc = fd_mfma32_f16(ti.kf[2], Bq2h, acc);
+      acc = fd_mfma32_f16(ti.kf[3], Bq2x, acc);
 #pragma unroll
       for (int s = 0; s < 16; ++s)
         acc = fd_mfma32(ti.k[s], QLDS ? __builtin_bit_cast(hx8, Qs[s * 64 + lane]) : Qf[QLDS ? 0 : s], acc);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
 }
 
 int fd_attention3_supported(const Attn3Args& a) {
-  return a.N >= 1 && a.N <= A3_NTW_MAX * 4 * 32 && a.H <= 8 && a.Np == ((a.N + 31) / 32) * 32 && a.vpt != nullptr;
+  return a.N >= 1 && a.N <= A3_NTW_MAX * 4 * 32 && a.H <= 8 && (a.H & 1) == 0 && a.Np == ((a.N + 31) / 32) * 32 && a.vpt != nullptr;
 }
 
 template <int NTW, int LB, bool DB>
@@ -389,6 +389,7 @@ static int a3_launch(const Attn3Args& a, dim3 grid, size_t smem, hipStream_t st)
 int fd_attention3(const Attn3Args& a, hipStream_t st) {
   const int nt = (a.N + 31) / 32;
   if (!fd_attention3_supported(a)) return FDIPT_ESIZE;
+  if (!a.kpf) return FDIPT_EINVAL;
   // reduction buffers 1 KB + o_pt tile 12 KB + P fragments 64 B per key, then ONE region for the Q fragments (16 KB, the variants
   // that keep them in LDS) and / or the P_lo fragments (64 B per key, split P V): they are never live together
   const size_t pf = (size_t)2 * nt * 64 * 16, base = 2 * 128 * 4 + (size_t)32 * 96 * 4 + pf + 16;

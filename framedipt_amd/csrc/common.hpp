@@ -57,6 +57,13 @@ __device__ __forceinline__ f32x4 fd_mfma16(hx8 a, hx8 b, f32x4 c) {  // 16x16x32
 #endif
 }
 
+// IEEE fp16 fragments in EVERY build: the point logits of attention3 run on fp16 hi / lo parts (22 significant bits) also in the
+// bf16 build — bf16 hi / lo would carry 16
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ f32x16 fd_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ half_t f2f16(float f) { return __builtin_bit_cast(half_t, (_Float16)f); }
+__device__ __forceinline__ float f162f(half_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+
 #define FD_WAVE 64
 #define FD_THREADS 256
 

@@ -106,7 +106,20 @@ struct PointsArgs {
   const float* node = nullptr;
   int ld_node = 0;
   unsigned short *nKb = nullptr, *nVt = nullptr, *nVt_lo = nullptr;
+  // optional (points16_kernel only; Pq == 8): the key points as attention3's point-logit A fragments (fd_kpf layout below), IEEE fp16
+  // hi / lo parts; needs the head weights gamma [H] and res_mask [B,N]
+  unsigned short* kpf = nullptr;
+  const float* gamma = nullptr;
+  const float* res_mask = nullptr;
 };
+// Key-point fragment image of attention3 (Attn3Args.kpf): [B*H][Np/32][4][64][8] fp16.  With k = the 24 global-frame coordinates of a
+// key's 8 points (thirds k0 = [0,8), k1 = [8,16), k2 = [16,24)), h / l = fp16 hi / lo parts (k = h + l to 2^-22), lane = 32 hf + key % 32:
+//   fragment 0: hf 0 -> h(k0), hf 1 -> h(k1)        fragment 1: hf 0 -> l(k0), hf 1 -> l(k1)
+//   fragment 2: hf 0 -> h(k2), hf 1 -> l(k2)        fragment 3: hf 0 -> h(k2), hf 1 -> X
+//   X = [2 m_j, m_j, pad ? -60000 : 0, a, b, c, 0, 0],  a + b + c = -gamma_h |k|^2 / 2 (three fp16 parts), m_j = res_mask, pad = key >= N
+// The query side (registers of the attention kernel) pairs them so that six fp16 MFMAs give 1e5 (m_i m_j - 1) + gamma (q.k - |k|^2 / 2):
+// the term -gamma |q|^2 / 2 of -gamma |q - k|^2 / 2 is constant along a softmax row and drops out.
+#define FD_KPF_FRAGS 4
 
 // Pair bias of the IPA attention, tiled for BOTH sides: [sample*head][query tile][key tile][query in tile][32 keys].
 // The producers (pair_bias2_kernel, the EdgeTransition epilogue) hold one query and 32 consecutive keys per wave and write
@@ -197,6 +210,7 @@ struct Attn3Args {
   const float* res_mask;          // [B,N]
   const float *qp, *kp, *vp;      // [B,N,H,8,3], [B,N,H,8,3], [B,N,H,12,3] global-frame points (scaled units)
   const half_t* vpt;              // v_pts hi/lo fragment image (PointsArgs.vpt)
+  const half_t* kpf = nullptr;    // key-point fragment image (PointsArgs.kpf): required
   const float* gamma;             // [H]
   const float *rot, *trans;       // [B,N,9], [B,N,3]
   float* probs;                   // [B,H,N,N]

@@ -630,7 +630,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, skip_all, vt_lo, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, skip_all, vt_lo, kpf, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -670,6 +670,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.r4 = take(R * (size_t)1024 * 4);  // edge_transition4: [A1 | Af | B1 | Bf] rows, then their fold-fragment images
   w.a1img = take(fd_et4_a_image_bytes(B, N));
   w.b1img = take(fd_et4_b_image_bytes(B, N));
+  w.kpf = take((size_t)B * H * ((((size_t)N + 31) / 32)) * FD_KPF_FRAGS * 1024);  // key-point fragment image (attention3 point logits)
   w.total = o;
 }
 
@@ -685,9 +686,9 @@ size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N) {
   if (getenv("FDIPT_DUMP_LAYOUT")) {  // (dev) workspace layout for buffer-level diffs (tools/conc_victim_check.py)
     const char* names[] = {"node_feat", "pte", "pi", "pj", "h_a", "h_b", "node0", "node", "z", "quat", "trans", "dmask", "rot", "proj", "qp", "kp", "vp",
                            "bias", "probs", "feats", "ipa_out", "tf_in", "qkv", "att", "x_a", "x_b", "ff", "e", "upd", "psi_un", "a1", "af", "qb", "kb",
-                           "vt", "pts", "seqimg", "ipa_parts", "e_bf", "vpt", "r4", "a1img", "b1img", "skip_all", "vt_lo", "total"};
+                           "vt", "pts", "seqimg", "ipa_parts", "e_bf", "vpt", "r4", "a1img", "b1img", "skip_all", "vt_lo", "kpf", "total"};
     const size_t* offs = &w.node_feat;
-    for (int i = 0; i < 46; ++i) fprintf(stderr, "FDIPT_LAYOUT %s %zu\n", names[i], offs[i]);
+    for (int i = 0; i < 47; ++i) fprintf(stderr, "FDIPT_LAYOUT %s %zu\n", names[i], offs[i]);
   }
 #endif
   return w.total;
@@ -943,7 +944,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     Attn3Args a3;
     a3.B = B; a3.N = N; a3.H = H; a3.Np = Np; a3.Qb = (const half_t*)(W + w.qb); a3.Kb = (const half_t*)(W + w.kb);
     a3.Vt = (const half_t*)(W + w.vt); a3.Vt_lo = nullptr; a3.bias = F(w.bias); a3.res_mask = res_mask; a3.qp = F(w.qp); a3.kp = F(w.kp);
-    a3.vp = F(w.vp); a3.vpt = (const half_t*)(W + w.vpt); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
+    a3.vp = F(w.vp); a3.vpt = (const half_t*)(W + w.vpt); a3.kpf = (const half_t*)(W + w.kpf); a3.gamma = (const float*)(D + db.gamma); a3.rot = F(w.rot); a3.trans = F(w.trans);
     a3.probs = F(w.probs); a3.probs_h16 = nullptr; a3.out_h16 = nullptr; a3.out = F(w.feats); a3.out_ld = iv.feat_dim; a3.pt_off = H * C;
     OPairArgs oa;
     oa.B = B; oa.N = N; oa.H = H; oa.CZ = cz; oa.CD = cz / 4; oa.z = W + w.z; oa.probs = F(w.probs); oa.probs_h16 = nullptr; oa.probs_np = 0; oa.out_h16 = nullptr;
@@ -954,6 +955,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     pa.B = B; pa.N = N; pa.H = H; pa.Pq = Pq; pa.Pv = Pv; pa.quat = F(w.quat); pa.trans = F(w.trans);
     pa.qp = F(w.qp); pa.kp = F(w.kp); pa.vp = F(w.vp); pa.rot = F(w.rot);
     pa.vpt = (use_a3 && Pv == 12) ? (unsigned short*)(W + w.vpt) : nullptr; pa.Np = Np;
+    if (use_a3) { pa.kpf = (unsigned short*)(W + w.kpf); pa.gamma = (const float*)(D + db.gamma); pa.res_mask = res_mask; }
     // padded keys and rows 72..95 of the value-point image are never written: zero once per forward (on the launch that zeroes
     // the padded keys of Kb / Vt when the second-generation projection runs)
     const size_t vpt_bytes = (size_t)B * H * 96 * Np * 2;

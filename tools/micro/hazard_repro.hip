@@ -162,7 +162,7 @@ static void cell(const char* name, int pattern, int mem, int reserve, double sec
   hipMemset(d_bad, 0, 512);
   if (pattern >= 0) fill_ops(d_ops, pattern);
   const int nblk = 256 - reserve;
-  const int iters = 1200;  // ~300 us per aggressor launch
+  const int iters = 450;  // ~300 us per aggressor launch at the ~1.55 GHz random operands sustain (1024 cycles per iteration and SIMD)
   hipFuncSetAttribute((const void*)aggressor_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
   hipFuncSetAttribute((const void*)aggressor_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
   long launches = 0;
@@ -188,6 +188,67 @@ static void cell(const char* name, int pattern, int mem, int reserve, double sec
   fflush(stdout);
 }
 
+// second aggressor family: a pure memory streamer (the EdgeTransition weight-stream pattern, tools/micro/wstream_bench.hip) —
+//   MODE 0: LDS-DMA (global_load_lds_dwordx4 through m0, inline asm as in the library), 64 KB chunks, one chunk ahead, s_waitcnt vmcnt(16)
+//   MODE 1: plain global_load_dwordx4 into registers at the same cadence
+//   MODE 2: LDS-DMA, and the wave ENDS with its last chunk still in flight (no final s_waitcnt)
+//   MODE 3: "touch" loads whose result nobody waits for until the end of the kernel (the library's L2 warm-up hand-over)
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void stream_kernel(unsigned* out, const char* gsrc, int passes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int REGION = 512 * 1024, CHUNK = 64 * 1024, NCH = REGION / CHUNK;
+  const int tid = threadIdx.x;
+  u32x4 sink = {0, 0, 0, 0};
+  unsigned tok = 0;
+  const int n = passes * NCH;
+  for (int c = 0; c < n; ++c) {
+    const size_t off = ((size_t)c * CHUNK) & (REGION - 1);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const size_t a = (off + (size_t)(u * 256 + tid) * 16) & (REGION - 1);
+      if (MODE == 0 || MODE == 2) {
+        const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)(smem + ((c & 1) << 16) + (u * 256 + (tid & ~63)) * 16));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(gsrc + a) : "memory", "m0");
+      } else if (MODE == 3) {
+        asm volatile("global_load_dword %0, %1, off" : "+v"(tok) : "v"(gsrc + a) : "memory");
+      } else {
+        u32x4 t;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(gsrc + a) : "memory");
+        asm volatile("" : "+v"(t));
+        if (u == 15) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sink += t; }
+      }
+    }
+    if (MODE == 0 || MODE == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  }
+  if (MODE != 2) asm volatile("s_waitcnt vmcnt(0)" : : "v"(tok) : "memory");
+  if (MODE != 2) __syncthreads();
+  if (sink[0] == 0x12345u) out[tid] = sink[1] + ((unsigned*)smem)[tid] + tok;
+}
+
+#ifdef HAZARD_LIB
+extern "C" int hz_streamer(int mode, int nblk, int passes, unsigned* out, const void* gsrc, void* stream) {
+#define HZ_ST(M)                                                                                                          \
+  case M:                                                                                                                 \
+    hipFuncSetAttribute((const void*)stream_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);              \
+    hipLaunchKernelGGL((stream_kernel<M>), dim3(nblk), dim3(256), 131072, (hipStream_t)stream, out, (const char*)gsrc, passes); \
+    break;
+  switch (mode) { HZ_ST(0) HZ_ST(1) HZ_ST(2) HZ_ST(3) default: return -1; }
+  return (int)hipGetLastError();
+}
+// the same two kernels behind a C ABI (hipcc -shared -fPIC -DHAZARD_LIB -> libhazard.so) for tools/hazard_lib_repro.py, which crosses
+// them with the library's own rot_score_kernel / forward: {stand-alone, library} victim x {stand-alone, library} aggressor
+extern "C" int hz_victim(int n_items, const float* q, double sigma, double* res, const double* expect, unsigned* bad, void* stream) {
+  launch_victim<256, 0>((hipStream_t)stream, n_items, q, sigma, res, expect, bad);
+  return (int)hipGetLastError();
+}
+extern "C" int hz_aggressor(int nblk, int iters, const void* ops, float* out, int mem, const void* gsrc, size_t gwords, void* stream) {
+  hipFuncSetAttribute((const void*)aggressor_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  hipFuncSetAttribute((const void*)aggressor_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  if (mem) hipLaunchKernelGGL((aggressor_kernel<1>), dim3(nblk), dim3(512), 152 * 1024, (hipStream_t)stream, (const u32x4*)ops, out, iters, (const u32x4*)gsrc, gwords);
+  else hipLaunchKernelGGL((aggressor_kernel<0>), dim3(nblk), dim3(512), 152 * 1024, (hipStream_t)stream, (const u32x4*)ops, out, iters, (const u32x4*)gsrc, gwords);
+  return (int)hipGetLastError();
+}
+#else
 int main(int argc, char** argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
   u32x4 *d_ops, *d_g; float *d_out, *d_q; double *d_res, *d_expect; unsigned* d_bad;
@@ -216,3 +277,4 @@ int main(int argc, char** argv) {
   }
   return 0;
 }
+#endif
