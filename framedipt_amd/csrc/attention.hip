@@ -741,6 +741,30 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
       px[it] = row[a.kv_off + c]; py[it] = row[a.kv_off + HPkv + c]; pz[it] = row[a.kv_off + 2 * HPkv + c];
     }
   }
+  // merged projection: this block's node-row pieces (block half 0: two 8-channel units of the K image rows, half 1: two V units = 8
+  // keys of one channel each) are requested with the point operands — one memory round trip for the whole block
+  constexpr int NC = 256;
+  float nx[16];
+  if (a.node) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u = tid + 256 * q;
+      if (half == 0) {
+        const int cg = u & 31, rr = 16 * g + (u >> 5);
+        const float* xp = a.node + ((long)b * a.N + (rr < a.N ? rr : a.N - 1)) * a.ld_node + 8 * cg;
+        const float4 x0 = *(const float4*)xp, x1 = *(const float4*)(xp + 4);
+        nx[8 * q] = x0.x; nx[8 * q + 1] = x0.y; nx[8 * q + 2] = x0.z; nx[8 * q + 3] = x0.w;
+        nx[8 * q + 4] = x1.x; nx[8 * q + 5] = x1.y; nx[8 * q + 6] = x1.z; nx[8 * q + 7] = x1.w;
+      } else {
+        const int ln = u & 63, hf = ln >> 5, cc = 32 * (u >> 6) + (ln & 31);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {  // slot 8 hf + e of the 16-group -> key (inverse of pt_perm16)
+          const int sl = 8 * hf + e, pos = 8 * ((sl >> 2) & 1) + 4 * (sl >> 3) + (sl & 3), ky = 16 * g + pos;
+          nx[8 * q + e] = a.node[((long)b * a.N + (ky < a.N ? ky : a.N - 1)) * a.ld_node + cc];
+        }
+      }
+    }
+  }
   if (!live)  // keys beyond the sample: their slots of the image stay zero
     for (int v = sub; v < HH * 72; v += 16) vs[v * 16 + pt_perm16(kk)] = 0;
   const float w = q4[0], x = q4[1], y = q4[2], z = q4[3];
@@ -791,7 +815,7 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
     const int g_end = g == ng - 1 ? (a.Np >> 4) : g + 1;
     for (int gg = g; gg < g_end; ++gg)
       for (int u = tid; u < HH * 128; u += 256) {
-        const int un = u & 7, k16 = (u >> 3) & 15, hl = u >> 7, f = un >> 1, hf = un & 1, hh = half * HH + hl;
+        const int k16 = u & 15, un = (u >> 4) & 7, hl = u >> 7, f = un >> 1, hf = un & 1, hh = half * HH + hl;  // (16 lanes = 256 B of one unit row)
         const int keyu = 16 * gg + k16;
         const bool lv = gg == g && keyu < a.N;
         const float* kv = kps + (hl * 16 + k16) * 24;
@@ -825,41 +849,36 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
   }
   if (a.node) {
     // merged projection: this 16-group of keys of the node-row images (c_s = 256): block half 0 writes the K image rows, half 1 the
-    // V_hi / V_lo units; the last group of a sample also covers the padded groups up to Np (zeros)
-    constexpr int C = 256;
+    // V_hi / V_lo units (operands requested at the top); the last group of a sample also covers the padded groups up to Np (zeros)
     const int ntl = a.Np >> 5;
     const int g_end = g == ng - 1 ? (a.Np >> 4) : g + 1;
     for (int gg = g; gg < g_end; ++gg) {
-      if (half == 0) {
-        for (int u = tid; u < 16 * (C / 8); u += 256) {
-          const int cg = u & 31, r = 16 * gg + (u >> 5);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int u = tid + 256 * q;
+        if (half == 0) {
+          const int cg = u & 31, rr = 16 * gg + (u >> 5);
           uint4 o = make_uint4(0, 0, 0, 0);
-          if (r < a.N) {
-            const float* x = a.node + ((long)b * a.N + r) * a.ld_node + 8 * cg;
-            const float4 x0 = *(const float4*)x, x1 = *(const float4*)(x + 4);
-            o = make_uint4(fd_cvt_pk(x0.x, x0.y), fd_cvt_pk(x0.z, x0.w), fd_cvt_pk(x1.x, x1.y), fd_cvt_pk(x1.z, x1.w));
-          }
-          *(uint4*)(a.nKb + ((((long)b * ntl + (r >> 5)) * (C >> 4) + (cg >> 1)) * 64 + (cg & 1) * 32 + (r & 31)) * 8) = o;
-        }
-      } else {
-        for (int u = tid; u < (C / 32) * 64; u += 256) {
-          const int lane = u & 63, hf = lane >> 5, c5 = lane & 31, dt = u >> 6, cc = 32 * dt + c5;
+          if (rr < a.N) o = make_uint4(fd_cvt_pk(nx[8 * q], nx[8 * q + 1]), fd_cvt_pk(nx[8 * q + 2], nx[8 * q + 3]), fd_cvt_pk(nx[8 * q + 4], nx[8 * q + 5]),
+                                       fd_cvt_pk(nx[8 * q + 6], nx[8 * q + 7]));
+          *(uint4*)(a.nKb + ((((long)b * ntl + (rr >> 5)) * (NC >> 4) + (cg >> 1)) * 64 + (cg & 1) * 32 + (rr & 31)) * 8) = o;
+        } else {
+          const int ln = u & 63, hf = ln >> 5, dt = u >> 6;
           float xv[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {  // slot 8 hf + e of the 16-group -> key (inverse of pt_perm16)
-            const int slot = 8 * hf + e, pos = 8 * ((slot >> 2) & 1) + 4 * (slot >> 3) + (slot & 3);
-            const int key = 16 * gg + pos;
-            xv[e] = key < a.N ? a.node[((long)b * a.N + key) * a.ld_node + cc] : 0.f;
+          for (int e = 0; e < 8; ++e) {
+            const int sl = 8 * hf + e, pos = 8 * ((sl >> 2) & 1) + 4 * (sl >> 3) + (sl & 3);
+            xv[e] = 16 * gg + pos < a.N ? nx[8 * q + e] : 0.f;
           }
           uint4 oh, ol;
           unsigned* ph = (unsigned*)&oh;
           unsigned* pl = (unsigned*)&ol;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            ph[q] = fd_cvt_pk(xv[2 * q], xv[2 * q + 1]);
-            pl[q] = fd_cvt_pk(xv[2 * q] - h2f(f2h(xv[2 * q])), xv[2 * q + 1] - h2f(f2h(xv[2 * q + 1])));
+          for (int qq = 0; qq < 4; ++qq) {
+            ph[qq] = fd_cvt_pk(xv[2 * qq], xv[2 * qq + 1]);
+            pl[qq] = fd_cvt_pk(xv[2 * qq] - h2f(f2h(xv[2 * qq])), xv[2 * qq + 1] - h2f(f2h(xv[2 * qq + 1])));
           }
-          const long v = (((long)b * (C / 32) + dt) * (2 * ntl) + gg) * 64 + lane;
+          const long v = (((long)b * (NC / 32) + dt) * (2 * ntl) + gg) * 64 + ln;
           *(uint4*)(a.nVt + v * 8) = oh;
           if (a.nVt_lo) *(uint4*)(a.nVt_lo + v * 8) = ol;
         }

@@ -54,6 +54,7 @@ class ReverseLoop:
         # self.inpainting / model_conf.input_aatype), the atom37 frames of the trajectory with inference_fn's arguments
         # (experiments/utils.py:376-388)
         to_dev = lambda x: None if x is None else x.to(device=dev, dtype=torch.int32).contiguous()  # noqa: E731
+        self._inpainting, self._input_aatype = inpainting, input_aatype
         self.aatype = to_dev(preprocess_aatype(data_init.get("aatype"), self.fixed, inpainting, input_aatype))
         self.net_aatype = to_dev(preprocess_aatype(data_init.get("aatype"), self.fixed, model.inpainting,
                                                    model._model_conf.input_aatype))
@@ -243,14 +244,109 @@ class StreamedLoops:
         return {k: cat([p[k] for p in parts]) for k in parts[0]}  # (every returned array carries the batch on axis 1)
 
 
+class GraphedTrajectory:
+    """A whole trajectory — priming forward + ``num_t`` reverse steps, ~70 kernel launches each — captured ONCE as a HIP graph and
+    replayed for every later batch of the same shape (``inference_fn(graph=True)``).
+
+    Today the step is kernel-bound (the host needs 1.45 ms to enqueue a 2.25 ms step at N = 300, B = 8: ``tools/graph_step.py``), so a
+    replay is not faster than the eager loop; the option exists so that the Python / ctypes enqueue cost (65 % of the GPU step) cannot
+    become the bound as the kernels get faster, and for hosts with slow or busy cores.  Everything a step touches lives in buffers of
+    the ``ReverseLoop`` this object owns (state, masks, noise tape, per-step scalars, trajectories), so a new batch is loaded by
+    copying its inputs INTO those buffers (``load``), never by rebinding them.  Same results as the eager loop, bit for bit
+    (tests/test_gpu_round4.py::test_graphed_trajectory_matches_the_eager_loop).  Capture needs every kernel of the trajectory to have
+    run once in the process (lazy per-device launch attributes): the first ``graph=True`` call of a shape therefore runs eagerly and the
+    second one captures."""
+
+    def __init__(self, model, diffuser, data_init, num_t, min_t, noise_tape, **kw):
+        self.dev = model.device
+        with torch.cuda.device(self.dev):
+            self.loop = lp = ReverseLoop(model, diffuser, data_init, num_t, min_t, noise_tape=noise_tape,
+                                         state=model.new_batch_state(data_init["seq_idx"]), **kw)
+            self.x_T = lp.rigids_t  # (the tensor the first step reads; ReverseLoop.step rebinds the attribute, not the buffer)
+            self.graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # (allocator warm-up for the few torch ops of the last step)
+                tmp = lp.diffuse_mask[..., None] * lp.st.rigids[..., 4:] + lp.fixed_mask[..., None] * lp.rigid_traj[1][..., 4:]
+                del tmp
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(self.graph):
+                lp.prime()
+                for k in range(num_t):
+                    lp.step(k)
+        self.replays = 0
+
+    def load(self, data_init, noise_tape):
+        """Copy a new batch's inputs into the captured buffers (same B, N, seq_idx, aatype presence as at capture)."""
+        lp, dev = self.loop, self.dev
+        f32 = lambda x: x.to(device=dev, dtype=torch.float32)  # noqa: E731
+        with torch.cuda.device(dev):
+            res_mask, fixed = f32(data_init["res_mask"]), f32(data_init["fixed_mask"])
+            lp.res_mask.copy_(res_mask)
+            lp.fixed.copy_(fixed)
+            lp.fixed_mask.copy_(fixed * res_mask)
+            lp.diffuse_mask.copy_((1 - fixed) * res_mask)
+            for mine, (inp, ia) in ((lp.aatype, (lp._inpainting, lp._input_aatype)),
+                                    (lp.net_aatype, (lp.model.inpainting, lp.model._model_conf.input_aatype))):
+                new = preprocess_aatype(data_init.get("aatype"), fixed, inp, ia)
+                if (mine is None) != (new is None):
+                    raise ValueError("graph replay: the batch differs from the captured one in whether residue types are given")
+                if mine is not None:
+                    mine.copy_(new.to(device=dev, dtype=torch.int32))
+            same = (lp.aatype is None and lp.net_aatype is None) or (
+                lp.aatype is not None and lp.net_aatype is not None and bool(torch.equal(lp.aatype, lp.net_aatype)))
+            if same != lp.bb0_from_forward:  # (decides whether rigid_0_traj rows come from the forward or from a backbone launch)
+                raise ValueError("graph replay: the batch differs from the captured one in how its x_0 backbone rows are built")
+            lp.gt_tors = data_init["torsion_angles_sin_cos"]
+            lp.gt_psi.copy_(f32(lp.gt_tors[..., 2, :]))
+            self.x_T.copy_(f32(data_init["rigids_t"]))
+            lp.rigid_traj[0].copy_(self.x_T)
+            lp.sc_ca.copy_(f32(data_init["sc_ca_t"]))
+            lp.z_rot.copy_(torch.as_tensor(np.ascontiguousarray(noise_tape[0], dtype=np.float64), device=dev))
+            lp.z_trans.copy_(torch.as_tensor(np.ascontiguousarray(noise_tape[1], dtype=np.float64), device=dev))
+
+    def run(self, data_init=None, noise_tape=None, return_device=False):
+        if data_init is not None:
+            self.load(data_init, noise_tape)
+        with torch.cuda.device(self.dev):
+            self.graph.replay()
+        self.replays += 1
+        return self.loop.results(return_device)
+
+
+def _graph_key(model, data_init, num_t, min_t, flags):
+    rig, seq = data_init["rigids_t"], data_init["seq_idx"]
+    return (tuple(rig.shape), seq.detach().cpu().numpy().tobytes(), int(num_t), float(min_t), data_init.get("aatype") is None) + tuple(flags)
+
+
 def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None,
-                 return_device=False, streams=1, experimental_streams=False):
+                 return_device=False, streams=1, experimental_streams=False, graph=False):
     """Same arguments / returned keys as the reference.  ``noise_tape=(z_rot, z_trans)`` ([num_t-1,B,N,3] float64
     N(0,1) draws) overrides the global ``np.random`` stream (sample-sharded runs).  ``data_init`` tensors carry a
     leading batch dimension B >= 1 (the reference always passes B = 1).  ``streams=n``: the batch runs as n sub-batches on n HIP
     streams (same results; the latency-bound node path of one sub-batch overlaps the pair kernels of the other) — experimental: needs
-    ``experimental_streams=True`` (or FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``)."""
+    ``experimental_streams=True`` (or FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``).
+    ``graph=True``: the trajectory of this shape is captured once as a HIP graph and replayed for later batches (``GraphedTrajectory``)."""
+    if graph:
+        # whole-trajectory HIP graph, cached per (model, shape, seq_idx, schedule, options): first call of a shape eager (it also runs every
+        # kernel once, which capture needs), second call captures, later calls replay
+        if streams > 1:
+            raise ValueError("graph=True replays one stream's launches: not combined with streams > 1")
+        if noise_tape is None:
+            n_noisy = int(np.sum(np.linspace(min_t, 1.0, num_t)[::-1] > min_t))
+            noise_tape = draw_noise_tape(diffuser, n_noisy, data_init["rigids_t"].shape[0], data_init["rigids_t"].shape[1])
+        cache = model.__dict__.setdefault("_graphed_trajectories", {})
+        key = _graph_key(model, data_init, num_t, min_t, (center, aux_traj, self_condition, float(noise_scale), embed_self_conditioning,
+                                                            inpainting, input_aatype, id(diffuser)))
+        if key in cache:
+            if cache[key] is None:
+                cache[key] = GraphedTrajectory(model, diffuser, data_init, num_t, min_t, noise_tape, center=center, aux_traj=aux_traj,
+                                               self_condition=self_condition, noise_scale=noise_scale,
+                                               embed_self_conditioning=embed_self_conditioning, inpainting=inpainting, input_aatype=input_aatype)
+                return cache[key].run(return_device=return_device)  # (captured on this very batch: its buffers hold it already)
+            return cache[key].run(data_init, noise_tape, return_device)
+        cache[key] = None  # (seen once: the next call of this shape captures)
     if streams > 1 and data_init["rigids_t"].shape[0] > 1:  # sub-batches on their own HIP streams (same results)
         loop = StreamedLoops(model, diffuser, data_init, streams, num_t, min_t, noise_tape=noise_tape, center=center, aux_traj=aux_traj,
                              self_condition=self_condition, noise_scale=noise_scale, embed_self_conditioning=embed_self_conditioning,

@@ -1,0 +1,155 @@
+"""GPU parity tests (-m gpu) added in round 4: the benchmarked batch (B = 8, N = 300) in the parity suite, the fp16 margin at a second
+weight seed and at bb_gain 0.5 (tests/golden/make_goldens_r4.py), per-step numbers of the literal bf16 build, the attention's
+fp16 hi / lo point logits against an fp32 evaluation of the reference formula, whole-trajectory HIP graphs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import kabsch_free_rmsd, load_golden
+from test_gpu_parity import _feats, _net, _teacher_forced_steps
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_batch_of_eight_n300():
+    """bench.py's batch in the parity suite: 8 DIFFERENT x_t at N = 300 in the fp16 mode — every sample of the batch is torch.equal to its
+    own B = 1 run (a sample's bits do not depend on its batch mates), and sample 0 is the reference golden fwd_full_denovo_n300_t50."""
+    G = load_golden("fwd_full_denovo_n300_t50.npz")
+    net, d, conf = _net("full_denovo_n300_t50", G, "fp16")
+    f1 = _feats(G)
+    gen = torch.Generator().manual_seed(21)
+    B, N = 8, f1["rigids_t"].shape[1]
+    rig = [f1["rigids_t"].float()]
+    sc = [f1["sc_ca_t"].float()]
+    for k in range(1, B):  # other noisy frames / self-conditioning inputs of the same length
+        q = torch.nn.functional.normalize(torch.randn(1, N, 4, generator=gen), dim=-1)
+        rig.append(torch.cat([q, 12.0 * torch.randn(1, N, 3, generator=gen)], -1).cuda())
+        sc.append((8.0 * torch.randn(1, N, 3, generator=gen)).cuda())
+    keys = ("rigids", "psi", "rot_score", "trans_score", "atom37")
+    singles = []
+    for k in range(B):
+        f = dict(f1)
+        f["rigids_t"], f["sc_ca_t"] = rig[k].to(f1["rigids_t"].dtype), sc[k].to(f1["sc_ca_t"].dtype)
+        singles.append({kk: v.clone() for kk, v in net(f).items() if kk in keys})
+    fb = {k: torch.cat([v] * B, 0) for k, v in f1.items()}
+    fb["rigids_t"] = torch.cat(rig, 0).to(f1["rigids_t"].dtype)
+    fb["sc_ca_t"] = torch.cat(sc, 0).to(f1["sc_ca_t"].dtype)
+    out = net(fb)
+    for k in range(B):
+        for kk in keys:
+            assert torch.equal(out[kk][k], singles[k][kk][0]), (k, kk, float((out[kk][k] - singles[k][kk][0]).abs().max()))
+    # the batch did hold eight different samples
+    assert len({float(out["rigids"][k, 5, 4]) for k in range(B)}) == B
+    o0 = {kk: out[kk][:1].cpu().numpy() for kk in keys}
+    assert np.abs(o0["rigids"][..., 4:] - G["out_rigids"][..., 4:]).max() < 5e-4
+    assert kabsch_free_rmsd(o0["atom37"], G["out_atom37"]) < 3e-4
+
+
+# Where does the fp16 mode's per-step margin break (round-3 review)?  Measured on the MI355X (teacher-forced, N = 300, T = 5; worst step of
+# x_{t-1} / of the x_0 prediction):
+#   bb_gain 0.3, weight seed 7 (round 3's fixture): 0.78e-3 / 0.77e-3 A        bb_gain 0.3, weight seed 11: 0.37e-3 / 0.38e-3 A
+#   bb_gain 0.5, weight seed 7: 1.45e-3 / 0.98e-3 A — the bar breaks between gain 0.3 and 0.5 for this seed (one step, t = 0.2575, exceeds it)
+# (fp32 mode on the same fixtures: <= 5e-5 A.)  The bound of the mode is therefore stated per fixture: < 1e-3 A up to trained-weight scale
+# 0.3, < 2e-3 A at 0.5 (precision modes).
+FP16_MARGIN = {"full_denovo_n300_T5_gain03_seed11": 1.0e-3, "full_denovo_n300_T5_gain05": 2.0e-3}
+
+
+@pytest.mark.parametrize("name", sorted(FP16_MARGIN))
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_teacher_forced_margin_second_seed_and_gain05(name, prec):
+    r = _teacher_forced_steps(name, prec)
+    fmt = lambda v: " ".join(f"{x:.2e}" for x in v)  # noqa: E731
+    print(f"{prec} {name}: x_(t-1) per step [{fmt(r[:, 1])}] A, x_0 prediction [{fmt(r[:, 2])}] A")
+    bound = 1e-4 if prec == "fp32" else FP16_MARGIN[name]
+    assert r[:, 1].max() < bound and r[:, 2].max() < bound
+
+
+def test_bf16_build_per_step_numbers():
+    """The literal bf16 build (BASELINE configs[1]; lib/libfdipt_hip_bf16.so) per STEP, teacher-forced on traj_full_denovo_n64_T20: the numbers
+    bench.py quotes for `--bf16` (round 1's 5e-3 ... 1.2e-2 A predate the split operands).  A subprocess: a process binds one library."""
+    lib = os.path.join(ROOT, "framedipt_amd", "lib", "libfdipt_hip_bf16.so")
+    assert os.path.exists(lib), "run __graft_entry__.build() first"
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_parity import _teacher_forced_steps
+r = _teacher_forced_steps("full_denovo_n64_T20", "bf16")
+print("BF16STEP", float(r[:, 1].max()), float(r[:, 2].max()), float(np.median(r[:, 1])))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDIPT_LIB=lib), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst, worst0, med = (float(v) for v in next(l for l in r.stdout.splitlines() if l.startswith("BF16STEP")).split()[1:])
+    print(f"bf16 build, N = 64, T = 20 teacher-forced: x_(t-1) worst step {worst:.2e} A (median {med:.2e}), x_0 prediction worst {worst0:.2e} A")
+    assert worst < 5e-3 and worst0 < 5e-3  # bf16's own, looser bound (8 significand bits); the fp16 build holds 1e-3 on the same fixture
+
+
+def test_attention_point_logits_hi_lo_against_fp32_formula():
+    """The attention's point term on fp16 hi / lo MFMAs (csrc/attention3.hip; -gamma |q - k|^2 / 2 with the row-constant -gamma |q|^2 / 2
+    dropped) against the fp32 mode of the same module (LDS-score kernel: squared point distances summed directly in fp32, the
+    reference's own arithmetic, ipa_pytorch.py:255-283): the IPA module's output, block 0, N = 300, on a chain walk ~100 A wide (the
+    cancellation in q.k - |k|^2 / 2 grows with the coordinates), within the rounding of the fp16 Q K^T / P V operands."""
+    import ctypes as C
+
+    from framedipt_amd import _lib
+    from framedipt_amd.model.score_network import BatchState
+    G = load_golden("fwd_full_denovo_n300_t50.npz")
+    net, d, conf = _net("full_denovo_n300_t50", G, "fp16")
+    lib = _lib.load()
+    B, N, H = 1, 300, 8
+    gen = torch.Generator().manual_seed(3)
+    node = torch.randn(B, N, 256, generator=gen).cuda()
+    z = (0.5 * torch.randn(B, N, N, 128, generator=gen)).cuda().half().contiguous()
+    q = torch.nn.functional.normalize(torch.randn(B, N, 4, generator=gen), dim=-1)
+    walk = torch.cumsum(3.8 * torch.nn.functional.normalize(torch.randn(B, N, 3, generator=gen), dim=-1), 1)  # a 3.8 A chain walk
+    rig = torch.cat([q, walk - walk.mean(1, keepdim=True)], -1).cuda().contiguous()
+    mask = torch.ones(B, N).cuda()
+    out = torch.empty(B, N, 256).cuda()
+    st = BatchState(net, torch.arange(N)[None].cuda())
+    P = _lib.ptr
+    dm, pr, dr = C.byref(net.dims), P(net.params), P(net.derived)
+    _lib.check(lib.fdipt_ipa_attention_fwd(dm, pr, dr, 0, B, N, P(node), P(z), P(rig), P(mask), P(out), P(st.ws), st.ws_bytes, _lib.stream_ptr()))
+    out2 = torch.empty_like(out)
+    _lib.check(lib.fdipt_ipa_attention_fwd(dm, pr, dr, 0, B, N, P(node), P(z), P(rig), P(mask), P(out2), P(st.ws), st.ws_bytes, _lib.stream_ptr()))
+    assert torch.equal(out, out2) and bool(torch.isfinite(out).all())
+    # the same module in the fp32 mode (LDS-score kernel, VALU point distances in fp32: the reference's own arithmetic)
+    net32, _, _ = _net("full_denovo_n300_t50", G, "fp32")
+    st32 = BatchState(net32, torch.arange(N)[None].cuda())
+    z32 = z.float().contiguous()
+    out32 = torch.empty_like(out)
+    _lib.check(lib.fdipt_ipa_attention_fwd(C.byref(net32.dims), P(net32.params), P(net32.derived), 0, B, N, P(node), P(z32), P(rig), P(mask), P(out32),
+                                           P(st32.ws), st32.ws_bytes, _lib.stream_ptr()))
+    rel = float((out - out32).norm() / out32.norm())
+    print(f"IPA module, block 0, N = 300, 100 A wide structure: fp16 mode (hi / lo point logits) vs fp32 mode, relative {rel:.2e}")
+    assert rel < 1e-3
+
+
+def test_graphed_trajectory_matches_the_eager_loop():
+    """inference_fn(graph=True): the first call of a shape runs eagerly, the second captures the whole trajectory (priming forward + every
+    reverse step) as ONE HIP graph, later calls load their inputs into the captured buffers and replay — every returned array equal to the
+    eager loop's, bit for bit, for three different batches."""
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.inference import GraphedTrajectory, inference_fn
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    N, B, T = 64, 2, 6
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": 3 * B}), d, "cuda")
+    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1)
+    for rnd in range(3):
+        feats, tape = sharding.stack_items([sharding.seeded_item(ds, rnd * B + i, 5, d, T, 0.01) for i in range(B)])
+        ref = inference_fn(net, d, feats, noise_tape=tape, **kw)
+        got = inference_fn(net, d, feats, noise_tape=tape, graph=True, **kw)
+        assert sorted(ref) == sorted(got)
+        host = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)  # noqa: E731
+        for k in ref:
+            np.testing.assert_array_equal(host(ref[k]), host(got[k]), err_msg=f"round {rnd}: {k}")
+    cached = [g for g in net._graphed_trajectories.values() if isinstance(g, GraphedTrajectory)]
+    assert len(cached) == 1 and cached[0].replays == 2  # (call 2 captured + replayed, call 3 loaded + replayed)

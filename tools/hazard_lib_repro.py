@@ -5,11 +5,17 @@
 victims (stream A, launched back to back, every launch compared bit for bit with a quiet launch of the same inputs, on the device):
   lib   the library's rot_score_kernel through fdipt_igso3_rot_score (B*N residues, random unit quaternions, sigma of t = 0.5)
   own   tools/micro/hazard_repro.hip's float64 series kernel (no library code)
+  int   the same kernel with an integer hash chain instead of the float64 series
+  valu / bperm / load / lds   victims that isolate one instruction class, checked in registers (hazard_repro.hip: victim2_kernel): VALU only,
+        + ds_bpermute butterfly, global loads of a known pattern, LDS write / read round trips; trans / fmath / f64: transcendental unit,
+        library float math (division, atan2f, sinf), float64; histogram = 16-lane quarter of the wave
 aggressors (stream B):
   fwd   full score-network forwards of a B-sample batch with FdiptForwardArgs.reserve_cus = reserve_cus (the case the soak of round 3 failed in)
   mfma  hazard_repro.hip's persistent MFMA power kernel on 256 - reserve_cus CUs (random operands, with a global read stream)
   dma / ld / dmanw / touch   hazard_repro.hip's memory streamer on 256 - reserve_cus CUs: LDS-DMA (global_load_lds_dwordx4, the library's
         weight-stream idiom) / plain global_load_dwordx4 / LDS-DMA with the wave ending while its last chunk is in flight / unwaited touch loads
+  expco   v_exp_f32 chains only (transcendental unit), small blocks: co-resident with the victim
+  mfmaco  the same MFMA kernel with 8 KB of LDS and 256-thread blocks, 2 blocks per CU: victim waves SHARE its SIMDs (co-residency)
   et / ipa / points   one module of the library in a loop through its C-ABI entry (fdipt_edge_transition_fwd: fold rows + EdgeTransition;
         fdipt_ipa_attention_fwd: projection, points, pair bias, attention, o_pair, output projection; fdipt_ipa_project_points: projection + points)
   none  quiet
@@ -36,6 +42,10 @@ lib = _lib.load()
 hz = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libhazard.so"))
 hz.hz_victim.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 hz.hz_aggressor.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+hz.hz_victim_int.argtypes = hz.hz_victim.argtypes
+hz.hz_aggressor_co.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+hz.hz_victim2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_void_p, C.c_int, C.c_void_p]
+hz.hz_exp_aggressor.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 hz.hz_streamer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 P = _lib.ptr
 conf = config.base_config()
@@ -87,6 +97,9 @@ def module(what):
         _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, 1, B, N, P(m_node), P(mask), P(m_z), P(m_z2), P(mst.ws), mst.ws_bytes, sp))
 
 
+V2 = {"valu": 0, "bperm": 1, "load": 2, "lds": 3, "trans": 4, "fmath": 5, "f64": 6}
+pat = torch.empty(1 << 22, dtype=torch.int32).cuda()  # 16 MB pattern for the load victim
+hz.hz_victim2(0, 0, 0, P(pat), pat.numel(), P(hbad), 1, None)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 torch.cuda.synchronize()
 
@@ -102,8 +115,11 @@ def run(cell):
     with torch.cuda.stream(sa):
         if vic == "lib":
             victim_lib(ref)
+        elif vic in V2:
+            hbad.zero_()
         else:
-            hz.hz_victim(n_items, P(hq), 0.6, P(hres), None, P(hbad), _lib.stream_ptr())
+            hv = hz.hz_victim_int if vic == "int" else hz.hz_victim
+            hv(n_items, P(hq), 0.6, P(hres), None, P(hbad), _lib.stream_ptr())
             hexp[:3] = hres[:3]
             hbad.zero_()
     torch.cuda.synchronize()
@@ -119,18 +135,26 @@ def run(cell):
             elif agg in ("dma", "ld", "dmanw", "touch"):
                 for _ in range(8):
                     hz.hz_streamer({"dma": 0, "ld": 1, "dmanw": 2, "touch": 3}[agg], 256 - RES, 40, P(aout), P(gsrc), _lib.stream_ptr())
+            elif agg == "expco":  # transcendental-unit load only, co-resident with the victim
+                for _ in range(8):
+                    hz.hz_exp_aggressor(1024, 4000, P(aout), _lib.stream_ptr())
+            elif agg == "mfmaco":
+                for _ in range(8):
+                    hz.hz_aggressor_co(512, 256, 450, P(ops), P(aout), 8192, _lib.stream_ptr())
             elif agg == "mfma":
                 for _ in range(8):
                     hz.hz_aggressor(256 - RES, 450, P(ops), P(aout), 1, P(gsrc), gsrc.numel() // 4, _lib.stream_ptr())
         with torch.cuda.stream(sa):
             for _ in range(48):
-                if vic == "lib":
+                if vic in V2:
+                    hz.hz_victim2(V2[vic], (n_items + 15) // 16, 512, P(pat), pat.numel(), P(hbad), 0, _lib.stream_ptr())
+                elif vic == "lib":
                     victim_lib(score)
                     diff = (score.view(torch.int64) != ref.view(torch.int64)).any(-1).reshape(-1)
                     cnt += diff
                     launches_bad += diff.any()
                 else:
-                    hz.hz_victim(n_items, P(hq), 0.6, P(hres), P(hexp), P(hbad), _lib.stream_ptr())
+                    hv(n_items, P(hq), 0.6, P(hres), P(hexp), P(hbad), _lib.stream_ptr())
             launches += 48
         sa.synchronize()
         sb.synchronize()
@@ -143,7 +167,7 @@ def run(cell):
               f"(residue index mod 4) {hist}, first residues {[(int(i) // N, int(i) % N) for i in idx[:6]]}", flush=True)
     else:
         hb = hbad.cpu().numpy()
-        print(f"{cell:10s} N={N} B={B} reserve={RES}: victim launches {launches}, bad values {int(hb[0])}, (item mod 4) {[int(x) for x in hb[1:5]]}", flush=True)
+        print(f"{cell:10s} N={N} B={B} reserve={RES}: victim launches {launches}, bad values {int(hb[0])}, (item mod 4 / wave quarter) {[int(x) for x in hb[1:5]]}", flush=True)
 
 
 for cell in CELLS:

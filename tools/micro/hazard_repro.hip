@@ -188,6 +188,82 @@ static void cell(const char* name, int pattern, int mem, int reserve, double sec
   fflush(stdout);
 }
 
+// ---- victims that isolate one instruction class each (every check is IN-REGISTER: two evaluations of the same function, or a loaded
+// value against the function of its address; mismatches are counted per 16-lane quarter of the wave in bad[1 + lane / 16])
+//   KIND 0: VALU only (integer hash chain twice, compared)            KIND 1: + a 16-lane ds_bpermute butterfly on both chains
+//   KIND 2: global loads of a pattern (value = hash(index)) checked against the recomputed hash
+//   KIND 3: LDS round trips (ds_write_b32 / ds_read_b32 of hash values, wave-private rows) checked against the registers
+//   KIND 4: transcendental unit (v_exp / v_rcp / v_sqrt / v_sin)    KIND 5: library float math (division, atan2f, sinf)    KIND 6: float64 (fma, division, sqrt)
+template <int KIND>
+__global__ __launch_bounds__(256) void victim2_kernel(int rounds, const unsigned* __restrict__ pattern, unsigned pat_mask, unsigned* __restrict__ bad) {
+  __shared__ unsigned lrow[256 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned a = 0x9E3779B9u ^ (unsigned)(blockIdx.x * 256 + tid), b = a;
+  unsigned nbad = 0;
+  for (int r = 0; r < rounds; ++r) {
+    // two copies of the same chain; the opaque asm keeps the compiler from merging them
+    a = (a ^ (unsigned)r) * 0x85EBCA6Bu; a = (a << 13) | (a >> 19); a *= 0xC2B2AE35u;
+    asm volatile("" : "+v"(b));
+    b = (b ^ (unsigned)r) * 0x85EBCA6Bu; b = (b << 13) | (b >> 19); b *= 0xC2B2AE35u;
+    if (KIND == 1) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); asm volatile("" : "+v"(b)); b += __shfl_xor(b, o, 64); }
+    }
+    if (KIND == 2) {
+      const unsigned idx = a & pat_mask;
+      const unsigned v = pattern[idx];
+      const unsigned want = (idx * 0x9E3779B1u) ^ 0x5bd1e995u;
+      nbad += v != want;
+    }
+    if (KIND == 3) {
+      lrow[tid * 4 + (r & 3)] = a;
+      asm volatile("" ::: "memory");
+      const unsigned back = lrow[tid * 4 + (r & 3)];
+      nbad += back != a;
+    }
+    if (KIND == 4) {  // transcendental unit: v_exp_f32 / v_rcp_f32 / v_sqrt_f32 / v_sin_f32 on a value derived from the chain, twice
+      const float x = 0.5f + (float)(a & 0xFFFF) * (1.0f / 65536.0f), y = 0.5f + (float)(b & 0xFFFF) * (1.0f / 65536.0f);
+      const float fx = __builtin_amdgcn_sinf(__builtin_amdgcn_sqrtf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x))));
+      asm volatile("" : "+v"(b));
+      const float fy = __builtin_amdgcn_sinf(__builtin_amdgcn_sqrtf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y))));
+      a ^= __float_as_uint(fx); b ^= __float_as_uint(fy);
+    }
+    if (KIND == 5) {  // library float math: division (v_div_scale / v_div_fmas with the denormal mode switched around it), atan2f, sinf
+      const float x = 0.5f + (float)(a & 0xFFFF) * (1.0f / 65536.0f), y = 0.5f + (float)(b & 0xFFFF) * (1.0f / 65536.0f);
+      const float fx = atan2f(x, 1.25f - x) / sinf(x * 977.f) + sqrtf(x);
+      asm volatile("" : "+v"(b));
+      const float fy = atan2f(y, 1.25f - y) / sinf(y * 977.f) + sqrtf(y);
+      a ^= __float_as_uint(fx); b ^= __float_as_uint(fy);
+    }
+    if (KIND == 6) {  // float64: fma, division, sqrt
+      const double x = 0.5 + (double)(a & 0xFFFF) * (1.0 / 65536.0), y = 0.5 + (double)(b & 0xFFFF) * (1.0 / 65536.0);
+      const double fx = fma(x, 1.000000119, 0.25) / (x * x + 0.75) + sqrt(x);
+      asm volatile("" : "+v"(b));
+      const double fy = fma(y, 1.000000119, 0.25) / (y * y + 0.75) + sqrt(y);
+      a ^= (unsigned)__double_as_longlong(fx) ^ (unsigned)(__double_as_longlong(fx) >> 32);
+      b ^= (unsigned)__double_as_longlong(fy) ^ (unsigned)(__double_as_longlong(fy) >> 32);
+    }
+    nbad += a != b;
+  }
+  if (nbad) { atomicAdd(&bad[0], nbad); atomicAdd(&bad[1 + (lane >> 4)], nbad); }
+}
+// aggressor: transcendental-unit load only (v_exp_f32 chains), small footprint: co-resident with the victim's waves
+__global__ __launch_bounds__(256) void exp_aggressor_kernel(float* out, int iters) {
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = 0.001f * (float)(threadIdx.x + 256 * k + 1);
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_amdgcn_exp2f(v[k] * 0.5f - 1.0f);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += v[k];
+  if (s == 1.2345e-30f) out[threadIdx.x] = s;
+}
+__global__ void pattern_fill_kernel(unsigned* p, unsigned n) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = (i * 0x9E3779B1u) ^ 0x5bd1e995u;
+}
+
 // second aggressor family: a pure memory streamer (the EdgeTransition weight-stream pattern, tools/micro/wstream_bench.hip) —
 //   MODE 0: LDS-DMA (global_load_lds_dwordx4 through m0, inline asm as in the library), 64 KB chunks, one chunk ahead, s_waitcnt vmcnt(16)
 //   MODE 1: plain global_load_dwordx4 into registers at the same cadence
@@ -226,6 +302,24 @@ __global__ __launch_bounds__(256, 1) void stream_kernel(unsigned* out, const cha
 }
 
 #ifdef HAZARD_LIB
+extern "C" int hz_victim2(int kind, int nblk, int rounds, unsigned* pattern, unsigned pat_words, unsigned* bad, int fill, void* stream) {
+  if (fill) { hipLaunchKernelGGL(pattern_fill_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, pattern, pat_words); return (int)hipGetLastError(); }
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((victim2_kernel<0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    case 1: hipLaunchKernelGGL((victim2_kernel<1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    case 2: hipLaunchKernelGGL((victim2_kernel<2>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    case 3: hipLaunchKernelGGL((victim2_kernel<3>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    case 4: hipLaunchKernelGGL((victim2_kernel<4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    case 5: hipLaunchKernelGGL((victim2_kernel<5>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    case 6: hipLaunchKernelGGL((victim2_kernel<6>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+extern "C" int hz_exp_aggressor(int nblk, int iters, float* out, void* stream) {
+  hipLaunchKernelGGL(exp_aggressor_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, out, iters);
+  return (int)hipGetLastError();
+}
 extern "C" int hz_streamer(int mode, int nblk, int passes, unsigned* out, const void* gsrc, void* stream) {
 #define HZ_ST(M)                                                                                                          \
   case M:                                                                                                                 \
@@ -239,6 +333,18 @@ extern "C" int hz_streamer(int mode, int nblk, int passes, unsigned* out, const 
 // them with the library's own rot_score_kernel / forward: {stand-alone, library} victim x {stand-alone, library} aggressor
 extern "C" int hz_victim(int n_items, const float* q, double sigma, double* res, const double* expect, unsigned* bad, void* stream) {
   launch_victim<256, 0>((hipStream_t)stream, n_items, q, sigma, res, expect, bad);
+  return (int)hipGetLastError();
+}
+extern "C" int hz_victim_int(int n_items, const float* q, double sigma, double* res, const double* expect, unsigned* bad, void* stream) {
+  launch_victim<256, 1>((hipStream_t)stream, n_items, q, sigma, res, expect, bad);
+  return (int)hipGetLastError();
+}
+// the MFMA aggressor with a caller-chosen LDS footprint and block size: lds_bytes = 0 and 256 threads leaves room for victim waves on the
+// SAME SIMDs (co-residency), which the 152 KB / 512-thread form excludes by construction
+extern "C" int hz_aggressor_co(int nblk, int threads, int iters, const void* ops, float* out, int lds_bytes, void* stream) {
+  if (lds_bytes < 8192) lds_bytes = 8192;
+  hipFuncSetAttribute((const void*)aggressor_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  hipLaunchKernelGGL((aggressor_kernel<0>), dim3(nblk), dim3(threads), lds_bytes, (hipStream_t)stream, (const u32x4*)ops, out, iters, (const u32x4*)ops, (size_t)1024);
   return (int)hipGetLastError();
 }
 extern "C" int hz_aggressor(int nblk, int iters, const void* ops, float* out, int mem, const void* gsrc, size_t gwords, void* stream) {
