@@ -466,16 +466,20 @@ __device__ __forceinline__ void om_for(F&& f) {
     f(std::integral_constant<int, N_ - 1>{});
   }
 }
-template <int OM_NK, int LB, int NH = 1>
+// SB (round 4): ONE Zt buffer (two barriers per chunk instead of one), the cross-wave exchange tile `red` overlays it, and the down_z
+// fragments are requested after the main loop instead of at the top: 24 KB of LDS and <= 128 registers -> FOUR blocks per CU instead
+// of three.  A row is a latency chain (HBM round trip, five chunk hand-overs, a serial tail on one wave) whose matrix work is 2 % of
+// its time: what hides it is other rows on the same CU.
+template <int OM_NK, int LB, int NH = 1, bool SB = false>
 __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a, int Np) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CZ = 128, H = 8, CD = 32;
   const int N = a.N, nch = Np / OM_JC;
   const int prow = Np * 2 + 16;                             // bytes per attention-weight row (bf16)
-  char* zt = smem;                                          // [2][CZ][OM_ZROW]
-  char* pb = zt + 2 * CZ * OM_ZROW;                         // [8][prow] bf16 attention weights of this (b, i)
-  float* red = (float*)(pb + 8 * prow);                     // [8][CZ]
-  float* psum = red + 8 * CZ;                               // [8]
+  char* zt = smem;                                          // [2][CZ][OM_ZROW] ([1] with SB)
+  char* pb = zt + (SB ? 1 : 2) * CZ * OM_ZROW;              // [8][prow] bf16 attention weights of this (b, i)
+  float* red = SB ? (float*)zt : (float*)(pb + 8 * prow);   // [8][CZ] (SB: the Zt buffer is dead when it is written)
+  float* psum = SB ? (float*)(pb + 8 * prow) : red + 8 * CZ;  // [8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   const int i = blockIdx.x, b = blockIdx.y;
   const long rb = (long)b * N;
@@ -496,13 +500,14 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
   // down_z as B fragments (wave 0 only): requested now, used at the very end
   hx8 wdf[8], wdl[8];
   const bool dz_split = a.wdz_img_lo != nullptr;  // split operands for the down-projection (per-residue product: see OPairArgs)
-  if (wave == 0) {
+  auto wdz_load = [&]() {
 #pragma unroll
     for (int s = 0; s < 8; ++s) wdf[s] = __builtin_bit_cast(hx8, *(const u16x8*)((const char*)a.wdz_img + (s * 64 + lane) * 16));
     if (dz_split)
 #pragma unroll
       for (int s = 0; s < 8; ++s) wdl[s] = __builtin_bit_cast(hx8, *(const u16x8*)((const char*)a.wdz_img_lo + (s * 64 + lane) * 16));
-  }
+  };
+  if (!SB && wave == 0) wdz_load();
   // attention weights -> bf16 rows (zero for padded keys) and sum_j a[h,i,j] (= 1 up to rounding and masking) in one pass:
   // 32 threads per head
   if (a.probs_h16) {  // already bf16 rows [b, i, h, probs_np] (attention3): 4 keys (8 B) per load, 32 threads per head
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
     auto chunk = [&](auto CH) {
       constexpr int ch = decltype(CH)::value;
       if (ch0 + ch < nch) {
-        const char* zs = zt + (ch & 1) * CZ * OM_ZROW + (32 * wave + li) * OM_ZROW + 16 * hi;
+        const char* zs = zt + (SB ? 0 : (ch & 1)) * CZ * OM_ZROW + (32 * wave + li) * OM_ZROW + 16 * hi;
 #pragma unroll
         for (int s = 0; s < OM_JC / 16; ++s) {
           u16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -567,12 +572,16 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
           const u16x8 bfr = *(const u16x8*)(zs + 32 * s);
           acc = fd_mfma32(__builtin_bit_cast(hx8, af), __builtin_bit_cast(hx8, bfr), acc);
         }
-        if (ch + 1 < OM_NK / 4 && ch0 + ch + 1 < nch) scatter(std::integral_constant<int, (ch + 1 < OM_NK / 4 ? ch + 1 : 0)>{}, (ch + 1) & 1);
+        if (ch + 1 < OM_NK / 4 && ch0 + ch + 1 < nch) {
+          if (SB) __syncthreads();  // (every wave is done with the buffer)
+          scatter(std::integral_constant<int, (ch + 1 < OM_NK / 4 ? ch + 1 : 0)>{}, SB ? 0 : (ch + 1) & 1);
+        }
         __syncthreads();
       }
     };
     om_for<OM_NK / 4>(chunk);
   }
+  if (SB && wave == 0) wdz_load();  // (in flight across the exchange barrier)
   // D[h, Zt row]: lane (row 32 wave + li, hi) holds heads 4 hi + r in registers r < 4; row 16 e + cg = channel 8 cg + e
   {
     const int zrow_i = 32 * wave + li, ch_i = 8 * (zrow_i & 15) + (zrow_i >> 4);
@@ -638,7 +647,13 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
 #define OM_PAD 0  // (tools/micro/opair_bench.hip: extra dynamic LDS = fewer blocks per CU)
 #endif
     const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4 + OM_PAD;
-    if (a.N <= 320) hipLaunchKernelGGL((opair_mfma_kernel<20, 2>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+#ifndef OM_SB
+#define OM_SB 1   // N <= 320: the four-blocks-per-CU form (tools/micro/opair_bench.hip -DOM_SB=0: three blocks, double-buffered Zt)
+#endif
+    if (a.N <= 320 && OM_SB) {
+      const size_t smem_sb = (size_t)128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + 64 + OM_PAD;
+      hipLaunchKernelGGL((opair_mfma_kernel<20, OM_SB == 1 ? 4 : OM_SB, 1, true>), dim3(a.N, a.B), dim3(FD_THREADS), smem_sb, st, a, Np);
+    } else if (a.N <= 320) hipLaunchKernelGGL((opair_mfma_kernel<20, 2>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
 #ifndef OM_MID
 #define OM_MID 0
 #endif

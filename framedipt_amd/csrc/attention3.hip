@@ -21,6 +21,12 @@
 #include "kernels.hpp"
 
 #define A3_C 256
+// (dev) ablations for the concurrency bisection of tools/hazard_lib_repro.py: FDIPT_VARIANT builds with -DA3_ABL=bits —
+//   1: softmax without the transcendental unit (no v_exp_f32)   2: no logit MFMAs   4: no P V / value-point MFMAs (phase 4 skipped)
+//   8: no LDS Q fragments (zeros)   16: s_waitcnt vmcnt(0) lgkmcnt(0) + s_nop at the very end of the kernel
+#ifndef A3_ABL
+#define A3_ABL 0
+#endif
 #define A3_NTW_MAX 8  // key tiles per wave -> N <= 8 * 4 * 32 = 1024
 
 __device__ __forceinline__ hx8 a3_pack8(const float* v) {
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = -1e5f;
+      if (!(A3_ABL & 2)) {
       acc = fd_mfma32_f16(ti.kf[3], Bm, acc);
       acc = fd_mfma32_f16(ti.kf[0], Bq01h, acc);
       acc = fd_mfma32_f16(ti.kf[1], Bq01h, acc);
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
 #pragma unroll
       for (int s = 0; s < 16; ++s)
         acc = fd_mfma32(ti.k[s], QLDS ? __builtin_bit_cast(hx8, Qs[s * 64 + lane]) : Qf[QLDS ? 0 : s], acc);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -190,7 +198,8 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
     if (wave + 4 * u < nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f((S[u][r] - mx) * 1.4426950408889634f);  // exp(x): one multiply + v_exp_f32 (expf adds range fix-ups)
+        const float e = (A3_ABL & 1) ? fmaxf(1.0f + (S[u][r] - mx) * 0.01f, 0.f)
+                                     : __builtin_amdgcn_exp2f((S[u][r] - mx) * 1.4426950408889634f);  // exp(x): one multiply + v_exp_f32 (expf adds range fix-ups)
         S[u][r] = e;
         sum += e;
       }
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   // ---- phase 4: O^T[d, query] for d tiles {2w, 2w+1} over all keys (A = Vt fragments from HBM/L2, B = P from LDS); waves
   // 0..2 also take one 32-row tile of the v_pts image (rows = point coordinates as bf16 high + low parts): o_pt on the
   // matrix core, sum_j a v_pts_j to ~2^-17 relative in v_pts (the weights are the same bf16 P as for o)
-  {
+  if (!(A3_ABL & 4)) {
     constexpr int KSM = 2 * 4 * A3_NTW;  // k-steps of 16 keys at the maximum N
     const int ks = 2 * nt;
     hx8 Va[DB ? 2 : 1][KSM];
@@ -364,6 +373,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
     }
   }
   FD_STAMP(7);
+  if (A3_ABL & 16) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 }
 
 int fd_attention3_supported(const Attn3Args& a) {

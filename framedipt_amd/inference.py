@@ -34,6 +34,20 @@ def _backbone(net, n, t7, rot, trans, psi, aatype, atom37):
                "backbone_atoms")
 
 
+def get_atom_positions_from_rigids(model, rigids, psi_torsions, aatype=None) -> np.ndarray:
+    """``experiments/utils.py:415-437``: backbone atom37 positions [B,N,37,3] (NumPy) of frames given as tensor_7 [B,N,7] (or a
+    ``Rigid``), psi torsions [B,N,2] and residue types [B,N] (None: alanine), through the backbone kernel."""
+    t7 = rigids.to_tensor_7() if hasattr(rigids, "to_tensor_7") else rigids
+    dev = model.device
+    with torch.cuda.device(dev):
+        t7 = t7.to(device=dev, dtype=torch.float32).contiguous()
+        psi = psi_torsions.to(device=dev, dtype=torch.float32).contiguous()
+        aa = None if aatype is None else aatype.to(device=dev, dtype=torch.int32).contiguous()
+        atom37 = torch.empty(t7.shape[:-1] + (37, 3), dtype=torch.float32, device=dev)
+        _backbone(model, int(np.prod(t7.shape[:-1])), t7, None, None, psi, aa, atom37)
+        return atom37.cpu().numpy()
+
+
 class ReverseLoop:
     """Device-resident state of one batch of trajectories; ``prime()`` then ``step(k)`` for k = 0..num_t-1."""
 

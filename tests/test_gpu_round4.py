@@ -153,3 +153,49 @@ def test_graphed_trajectory_matches_the_eager_loop():
             np.testing.assert_array_equal(host(ref[k]), host(got[k]), err_msg=f"round {rnd}: {k}")
     cached = [g for g in net._graphed_trajectories.values() if isinstance(g, GraphedTrajectory)]
     assert len(cached) == 1 and cached[0].replays == 2  # (call 2 captured + replayed, call 3 loaded + replayed)
+
+
+def test_run_sharded_inpainting_entry_two_ranks(tmp_path):
+    """BASELINE configs[2] at the file level (experiments/inference.py:244-389,480-556): ``run_sharded --download-dir`` builds a
+    ``ConditionalSampler`` over processed structures (the three TCR-pMHC complexes of the reference's own test data, ~810 residues, 5 chains),
+    runs mixed-length batches and writes the reference's directory layout through ``framedipt_amd.output``; two ranks (on this box's one GPU:
+    FDIPT_ONE_GPU=1) leave a file tree byte-identical to the one-rank run."""
+    import json
+    import pickle
+
+    import pandas as pd
+    F = load_golden("features.npz")
+    data = tmp_path / "data"
+    (data / "processed").mkdir(parents=True)
+    rows = []
+    for name in ("1fyt", "5ksa", "7t2d"):
+        cf = {k[len(name) + 4:]: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in F.items() if k.startswith(name + "_in_")}
+        with open(data / "processed" / f"{name}.pkl", "wb") as f:
+            pickle.dump(cf, f)
+        n = int(np.sum(np.asarray(cf["max_modeled_idxs"]) - np.asarray(cf["min_modeled_idxs"]) + 1))  # modelled residues of the five chains (810 / 820 / 801)
+        rows.append({"pdb_name": f"{name}-assembly1", "processed_path": str(data / "processed" / f"{name}.pkl"), "modeled_seq_len": n})
+    pd.DataFrame(rows).to_csv(data / "processed" / "metadata.csv", index=False)
+    trees = {}
+    for world, port in ((2, "29651"), (1, "29652")):
+        out_dir = tmp_path / f"w{world}"
+        env = dict(os.environ, FDIPT_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", port, "-m", "framedipt_amd.run_sharded", "--out-dir", str(out_dir), "--download-dir", str(data),
+               "--samples-per-structure", "2", "--num-t", "3", "--max-batch", "4", "--precision", "fp16"]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        with open(out_dir / "manifest.json") as f:
+            man = json.load(f)
+        assert man["n_items"] == 6 and man["world_size"] == world
+        if world == 2:
+            assert {s["rank"] for s in man["samples"]} == {0, 1}
+        files = sorted(str(p.relative_to(out_dir)) for p in out_dir.rglob("*") if p.is_file() and p.suffix in (".pdb", ".csv"))
+        trees[world] = {f: (out_dir / f).read_bytes() for f in files}
+    assert sorted(trees[1]) == sorted(trees[2])
+    # per structure: ground truth + diffusion_info.csv + two samples
+    assert len(trees[1]) == 3 * 4, sorted(trees[1])
+    for f in trees[1]:
+        assert trees[1][f] == trees[2][f], f
+    some = next(f for f in trees[1] if f.endswith("sample_1_1.pdb"))
+    text = trees[1][some].decode()
+    assert text.startswith("MODEL     1") and text.rstrip().endswith("END") and "100.00" in text

@@ -8,7 +8,8 @@ victims (stream A, launched back to back, every launch compared bit for bit with
   int   the same kernel with an integer hash chain instead of the float64 series
   valu / bperm / load / lds   victims that isolate one instruction class, checked in registers (hazard_repro.hip: victim2_kernel): VALU only,
         + ds_bpermute butterfly, global loads of a known pattern, LDS write / read round trips; trans / fmath / f64: transcendental unit,
-        library float math (division, atan2f, sinf), float64; histogram = 16-lane quarter of the wave
+        library float math (division, atan2f, sinf), float64; tid: the work-item id register v0 against the EXEC-derived lane index;
+        histogram = 16-lane quarter of the wave
 aggressors (stream B):
   fwd   full score-network forwards of a B-sample batch with FdiptForwardArgs.reserve_cus = reserve_cus (the case the soak of round 3 failed in)
   mfma  hazard_repro.hip's persistent MFMA power kernel on 256 - reserve_cus CUs (random operands, with a global read stream)
@@ -61,7 +62,7 @@ score, ref = torch.empty(B, N, 3, dtype=torch.float64).cuda(), torch.empty(B, N,
 # stand-alone victim buffers
 hq = torch.tensor([0.9238795, 0.2209424, -0.1913417, 0.2514080, 0.3826834, -0.5334021, 0.6532815, 0.3753303], dtype=torch.float32).cuda()
 n_items = B * N
-hres, hexp, hbad = torch.empty(n_items * 3 + 8, dtype=torch.float64).cuda(), torch.empty(8, dtype=torch.float64).cuda(), torch.zeros(128, dtype=torch.int32).cuda()
+hres, hexp, hbad = torch.empty(n_items * 3 + 8, dtype=torch.float64).cuda(), torch.empty(8, dtype=torch.float64).cuda(), torch.zeros(2048, dtype=torch.int32).cuda()
 # aggressor: forwards
 ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": B}), d, "cuda")
 feats, _ = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, 6, 0.01) for i in range(B)])
@@ -97,7 +98,7 @@ def module(what):
         _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, 1, B, N, P(m_node), P(mask), P(m_z), P(m_z2), P(mst.ws), mst.ws_bytes, sp))
 
 
-V2 = {"valu": 0, "bperm": 1, "load": 2, "lds": 3, "trans": 4, "fmath": 5, "f64": 6}
+V2 = {"valu": 0, "bperm": 1, "load": 2, "lds": 3, "trans": 4, "fmath": 5, "f64": 6, "tid": 7}
 pat = torch.empty(1 << 22, dtype=torch.int32).cuda()  # 16 MB pattern for the load victim
 hz.hz_victim2(0, 0, 0, P(pat), pat.numel(), P(hbad), 1, None)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
@@ -119,9 +120,10 @@ def run(cell):
             hbad.zero_()
         else:
             hv = hz.hz_victim_int if vic == "int" else hz.hz_victim
+            hbad.zero_()
             hv(n_items, P(hq), 0.6, P(hres), None, P(hbad), _lib.stream_ptr())
             hexp[:3] = hres[:3]
-            hbad.zero_()
+            hbad[:64].zero_()
     torch.cuda.synchronize()
     launches, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < SEC:
@@ -147,7 +149,7 @@ def run(cell):
         with torch.cuda.stream(sa):
             for _ in range(48):
                 if vic in V2:
-                    hz.hz_victim2(V2[vic], (n_items + 15) // 16, 512, P(pat), pat.numel(), P(hbad), 0, _lib.stream_ptr())
+                    hz.hz_victim2(V2[vic], (n_items + 15) // 16, 8 if vic == "tid" else 512, P(pat), pat.numel(), P(hbad), 0, _lib.stream_ptr())
                 elif vic == "lib":
                     victim_lib(score)
                     diff = (score.view(torch.int64) != ref.view(torch.int64)).any(-1).reshape(-1)
@@ -167,7 +169,23 @@ def run(cell):
               f"(residue index mod 4) {hist}, first residues {[(int(i) // N, int(i) % N) for i in idx[:6]]}", flush=True)
     else:
         hb = hbad.cpu().numpy()
-        print(f"{cell:10s} N={N} B={B} reserve={RES}: victim launches {launches}, bad values {int(hb[0])}, (item mod 4 / wave quarter) {[int(x) for x in hb[1:5]]}", flush=True)
+        extra = ""
+        if vic in ("own", "int") and hb[6]:
+            rec = hbad[64:64 + 48].view(torch.int64).cpu().numpy().reshape(8, 3)
+            exp_true = hexp[:3].view(torch.int64).cpu().numpy()
+            extra = "\n    first mismatches (item, component): value | expectation as loaded | re-loaded at L2 | true expectation:\n" + "\n".join(
+                f"      ({int(hb[8 + 4 * k])}, {int(hb[9 + 4 * k])}): {int(rec[k, 0]):#018x} | {int(rec[k, 1]):#018x} | {int(rec[k, 2]):#018x} | {int(exp_true[int(hb[9 + 4 * k])]):#018x}"
+                for k in range(min(int(hb[6]), 8)))
+        if vic in ("own", "int") and hb[7]:
+            rec = hbad[256:256 + 8 * 16 * 6].view(torch.int64).cpu().numpy().reshape(8, 16, 3)
+            def row(r):
+                return (f"pre {int(r[0]) & 0xFFFFFFFFFFFFFFFF:#018x} omega {int(r[1]) & 0xFFFFFFFF:#010x} trips {(int(r[1]) >> 32) & 0xFFFF} item {int(r[2]) & 0xFFFFFF} "
+                        f"tid {(int(r[2]) >> 24) & 0x3FF} hw_id {(int(r[2]) >> 34) & 0xFFFFFFFF:#x}")
+            extra += "\n    per-lane records of the first mismatching item (sub 0..15), against item 7 of the quiet launch:\n" + "\n".join(
+                f"      sub {k:2d}: BAD {row(rec[0, k])}\n              REF {row(rec[7, k])}" for k in range(16))
+        if vic == "tid" and hb[6]:
+            extra = "  first (lane | block << 8, v0): " + str([(int(hb[8 + 2 * k]) & 255, int(hb[8 + 2 * k]) >> 8, int(hb[9 + 2 * k])) for k in range(min(int(hb[6]), 8))])
+        print(f"{cell:10s} N={N} B={B} reserve={RES}: victim launches {launches}, bad values {int(hb[0])}, (item mod 4 / wave quarter) {[int(x) for x in hb[1:5]]}{extra}", flush=True)
 
 
 for cell in CELLS:

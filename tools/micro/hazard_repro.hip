@@ -44,13 +44,17 @@ __global__ __launch_bounds__(THREADS) void victim_kernel(int n_items, const floa
   const float rv[3] = {x * sc, y * sc, z * sc};
   const float omega = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]) + 1e-6f;
   double out[3];
+  unsigned long long pre = 0;  // this lane's contribution before the 16-lane butterfly (recorded on a mismatch)
+  unsigned trips = 0;
   if (INTONLY) {
     unsigned long long hsh = 0x9E3779B97F4A7C15ull ^ (unsigned long long)__float_as_uint(omega);
     for (int l = sub; l < cut; l += 16) {
       hsh ^= (unsigned long long)l * 0xD6E8FEB86659FD93ull;
       hsh = (hsh << 13) | (hsh >> 51);
       hsh *= 0xFF51AFD7ED558CCDull;
+      ++trips;
     }
+    pre = hsh;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) hsh += __shfl_xor(hsh, o, 64);
     out[0] = out[1] = out[2] = __longlong_as_double((long long)((hsh & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(THREADS) void victim_kernel(int n_items, const floa
     const float den = lo * lo;
     double f = 0, ds = 0;
     for (int l = sub; l < cut; l += 16) {
+      ++trips;
       const double wv = wtab[l];
       const float lh = (float)l + 0.5f;
       const float arg = omega * lh;
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(THREADS) void victim_kernel(int n_items, const floa
       const float num = lo * dhi - hi * dlo;
       ds += wv * (double)num / (double)den;
     }
+    pre = (unsigned long long)__double_as_longlong(f);
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
       f += __shfl_xor(f, o, 64);
@@ -76,14 +82,42 @@ __global__ __launch_bounds__(THREADS) void victim_kernel(int n_items, const floa
     for (int c = 0; c < 3; ++c) out[c] = s * (double)rv[c] / (double)omega;
   }
   if (item >= n_items) return;
+  {
+    // per-lane record of an item's 16 lanes: [pre-butterfly contribution | omega bits, trip count | item, lane of the block, sub, hardware id].
+    // Slot 7 = item 7 of a quiet reference launch (expect == NULL); slots 0..3 = the first mismatching items
+    const bool mism = expect && __double_as_longlong(out[0]) != __double_as_longlong(expect[0]);
+    const bool refdump = !expect && item == 7;
+    if (mism || refdump) {
+      unsigned slot = 7;
+      if (mism) {
+        if (sub == 0) slot = atomicAdd(&bad[7], 1u);
+        slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
+      }
+      if (slot < 4 || refdump) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned long long* r = (unsigned long long*)(bad + 256) + ((size_t)slot * 16 + sub) * 3;
+        r[0] = pre;
+        r[1] = (unsigned long long)__float_as_uint(omega) | ((unsigned long long)trips << 32);
+        r[2] = (unsigned long long)item | ((unsigned long long)threadIdx.x << 24) | ((unsigned long long)hw << 34);
+      }
+    }
+  }
   if (sub < 3) {
     res[it * 3 + sub] = out[sub];
-    if (expect && __double_as_longlong(out[sub]) != __double_as_longlong(expect[sub])) {
+    const long long first = expect ? __double_as_longlong(expect[sub]) : 0;
+    if (expect && __double_as_longlong(out[sub]) != first) {
       atomicAdd(&bad[0], 1u);
       atomicAdd(&bad[1 + (item & 3)], 1u);
-      if (atomicAdd(&bad[5], 1u) < 8) { /* keep the first few for the report */
+      if (atomicAdd(&bad[5], 1u) < 8) { /* keep the first few for the report: the value, the expectation as first loaded, and re-loaded at L2 */
         const unsigned slot = atomicAdd(&bad[6], 1u);
-        if (slot < 8) { bad[8 + 4 * slot] = item; bad[9 + 4 * slot] = sub; ((double*)(bad + 48))[slot] = out[sub]; }
+        if (slot < 8) {
+          bad[8 + 4 * slot] = item; bad[9 + 4 * slot] = sub;
+          long long* rec = (long long*)(bad + 64) + 3 * slot;
+          rec[0] = __double_as_longlong(out[sub]);
+          rec[1] = first;
+          rec[2] = (long long)__hip_atomic_load((const unsigned long long*)expect + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
@@ -152,14 +186,14 @@ static void cell(const char* name, int pattern, int mem, int reserve, double sec
   launch_victim<THREADS, INTONLY>(sa, n_items, d_q, sigma, d_res, nullptr, d_bad);
   hipStreamSynchronize(sa);
   hipMemcpy(d_expect, d_res, 24, hipMemcpyDeviceToDevice);
-  hipMemset(d_bad, 0, 512);
+  hipMemset(d_bad, 0, 8192);
   // quiet self-check: every item of the quiet launch equals item 0
   launch_victim<THREADS, INTONLY>(sa, n_items, d_q, sigma, d_res, d_expect, d_bad);
   hipStreamSynchronize(sa);
   unsigned hb[64];
   hipMemcpy(hb, d_bad, 256, hipMemcpyDeviceToHost);
   const unsigned quiet_bad = hb[0];
-  hipMemset(d_bad, 0, 512);
+  hipMemset(d_bad, 0, 8192);
   if (pattern >= 0) fill_ops(d_ops, pattern);
   const int nblk = 256 - reserve;
   const int iters = 450;  // ~300 us per aggressor launch at the ~1.55 GHz random operands sustain (1024 cycles per iteration and SIMD)
@@ -193,6 +227,7 @@ static void cell(const char* name, int pattern, int mem, int reserve, double sec
 //   KIND 0: VALU only (integer hash chain twice, compared)            KIND 1: + a 16-lane ds_bpermute butterfly on both chains
 //   KIND 2: global loads of a pattern (value = hash(index)) checked against the recomputed hash
 //   KIND 3: LDS round trips (ds_write_b32 / ds_read_b32 of hash values, wave-private rows) checked against the registers
+//   KIND 7: the work-item id in v0 (written by the hardware at wave launch) against the EXEC-derived lane index
 //   KIND 4: transcendental unit (v_exp / v_rcp / v_sqrt / v_sin)    KIND 5: library float math (division, atan2f, sinf)    KIND 6: float64 (fma, division, sqrt)
 template <int KIND>
 __global__ __launch_bounds__(256) void victim2_kernel(int rounds, const unsigned* __restrict__ pattern, unsigned pat_mask, unsigned* __restrict__ bad) {
@@ -244,6 +279,16 @@ __global__ __launch_bounds__(256) void victim2_kernel(int rounds, const unsigned
       b ^= (unsigned)__double_as_longlong(fy) ^ (unsigned)(__double_as_longlong(fy) >> 32);
     }
     nbad += a != b;
+  }
+  if (KIND == 7) {
+    // launch-time state: the work-item id the hardware wrote into v0 before the wave started, against the lane index derived from EXEC
+    // (v_mbcnt: independent of v0).  bad[8 ...]: the first few (expected low 6 bits, v0) pairs
+    const unsigned mb = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if ((threadIdx.x & 63u) != mb || threadIdx.x >= 256u) {
+      nbad += 1;
+      const unsigned slot = atomicAdd(&bad[6], 1u);
+      if (slot < 16) { bad[8 + 2 * slot] = mb | (blockIdx.x << 8); bad[9 + 2 * slot] = threadIdx.x; }
+    }
   }
   if (nbad) { atomicAdd(&bad[0], nbad); atomicAdd(&bad[1 + (lane >> 4)], nbad); }
 }
@@ -312,6 +357,7 @@ extern "C" int hz_victim2(int kind, int nblk, int rounds, unsigned* pattern, uns
     case 4: hipLaunchKernelGGL((victim2_kernel<4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
     case 5: hipLaunchKernelGGL((victim2_kernel<5>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
     case 6: hipLaunchKernelGGL((victim2_kernel<6>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
+    case 7: hipLaunchKernelGGL((victim2_kernel<7>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, rounds, pattern, pat_words - 1, bad); break;
     default: return -1;
   }
   return (int)hipGetLastError();
@@ -360,7 +406,7 @@ int main(int argc, char** argv) {
   u32x4 *d_ops, *d_g; float *d_out, *d_q; double *d_res, *d_expect; unsigned* d_bad;
   const size_t gwords = (size_t)64 << 20;  // 1 GB read stream (HBM)
   hipMalloc(&d_ops, (size_t)64 * 8 * 64 * 16); hipMalloc(&d_g, gwords * 16); hipMemset(d_g, 1, gwords * 16);
-  hipMalloc(&d_out, 4096); hipMalloc(&d_q, 64); hipMalloc(&d_res, 2896 * 24 + 64); hipMalloc(&d_expect, 64); hipMalloc(&d_bad, 512);
+  hipMalloc(&d_out, 4096); hipMalloc(&d_q, 64); hipMalloc(&d_res, 2896 * 24 + 64); hipMalloc(&d_expect, 64); hipMalloc(&d_bad, 8192);
   const float hq[8] = {0.9238795f, 0.2209424f, -0.1913417f, 0.2514080f, 0.3826834f, -0.5334021f, 0.6532815f, 0.3753303f};  // two unit quaternions: omega ~ 2.4 rad
   hipMemcpy(d_q, hq, 32, hipMemcpyHostToDevice);
   hipStream_t sa, sb; hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);

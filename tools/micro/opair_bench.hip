@@ -9,6 +9,11 @@ int main(int argc, char** argv) {
   a.B = B; a.N = N; a.H = H; a.CZ = 128; a.CD = 32; a.z = dz((size_t)B * N * N * 128 * 2); a.probs = (const float*)dz((size_t)B * H * N * N * 4);
   a.wdz = (const float*)dz(128 * 32 * 4); a.wdz_img = dz(8192); a.bdz = (const float*)dz(32 * 4); a.out_ld = 2688; a.out = (float*)dz((size_t)B * N * a.out_ld * 4);
   a.off = 2048 + 384;
+  const int Np64 = (N + 63) / 64 * 64;
+  if (argc > 2) {  // product configuration: half-precision weight rows from the attention, split down-projection
+    a.probs_h16 = (const half_t*)dz((size_t)B * N * H * Np64 * 2); a.probs_np = Np64; a.wdz_img_lo = dz(8192);
+    (void)hipMemset((void*)a.z, 0x3c, (size_t)B * N * N * 128 * 2);  // (non-zero operands)
+  }
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
   for (int i = 0; i < 3; ++i) fd_opair(FDIPT_PREC_HALF, a, 0);
   (void)hipEventRecord(t0, 0);
