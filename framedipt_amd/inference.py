@@ -190,14 +190,16 @@ class StreamedLoops:
     OPT_IN_ENV = "FDIPT_EXPERIMENTAL_STREAMS"  # more than one stream is an explicit opt-in: experimental=True or this variable set to 1
 
     def __init__(self, model, diffuser, data_init, n_streams, num_t, min_t, noise_tape=None, reserve_cus=48, experimental=False, **kw):
-        # Soak results (tools/soak_streams.sh, tools/streams_stat.py; trajectories against the single-stream run, DESIGN.md section 5):
+        # Soak results (tools/soak_streams.sh, tools/streams_stat.py; trajectories against the single-stream run):
         #   * N = 128 / 300, two streams, any number of reserved CUs: 0 mismatching runs of ~400;
         #   * N = 300, three or four streams: 15 - 40 % of the runs differ in one sample from some step on;
-        #   * N = 512 / 724 / 1000, two streams: 1 / 12, 3 / 12, up to 11 / 12 mismatching runs depending on `reserve_cus` (end of round 3).
-        # What goes wrong there is ONE residue's rotation score in ONE step (its inputs in memory are intact, the forward's other outputs of
-        # that step are bit-identical), while the other stream's EdgeTransition runs on the rest of the chip; a library built with
-        # `-mllvm -amdgpu-waitcnt-forcezero` does not show it; not localised further.  The single-stream path is bit-reproducible at every
-        # size.  So: refused beyond what the soaks cover rather than offered.
+        #   * N = 512 / 724 / 1000, two streams: 1 / 12, 3 / 12, up to 11 / 12 mismatching runs depending on `reserve_cus`.
+        # Cause (round 4): on these GPUs a wave that runs a half-precision MFMA and lane-masked VALU code disturbs OTHER
+        # waves on its SIMD (their last 16-lane pass is written with the foreign EXEC mask) — reproduced without library code by
+        # tools/micro/hazard_repro.hip.  It needs waves of different kernels on one SIMD, which only concurrent streams / processes
+        # produce; inside the verified range the kernels' footprints happen to keep the small fp64 kernels off the attention's SIMDs.
+        # Nothing in software removes it, so: an explicit opt-in, refused beyond the range the soaks cover.  The single-stream path
+        # is not exposed and is bit-reproducible at every size.
         import os
         B = data_init["rigids_t"].shape[0]
         requested, n_streams = n_streams, max(1, min(n_streams, B))  # (the limits apply to what would actually run)

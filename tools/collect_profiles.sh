@@ -14,8 +14,8 @@ for c in c2 c3 c3e c3w c5; do python "$ROOT/bench.py" --config $c --no-cpu-basel
 python "$ROOT/bench.py" --precision fp32 --steps 6 --warmup 2 --no-cpu-baseline --no-reference-precision > "$OUT/bench_c4_fp32.json" 2>> "$OUT/bench.err"
 python "$ROOT/bench.py" --config c5 --precision fp16 --no-cpu-baseline > "$OUT/bench_c5_fp16.json" 2>> "$OUT/bench.err"
 python "$ROOT/bench.py" --kernel-flags 32 --no-cpu-baseline > "$OUT/bench_c4_nosplit.json" 2>> "$OUT/bench.err"
-python "$ROOT/bench.py" --samples-per-gpu 24 --steps 100 --no-cpu-baseline > "$OUT/bench_c4_b24.json" 2>> "$OUT/bench.err"
-python "$ROOT/bench.py" --samples-per-gpu 64 --steps 40 --no-cpu-baseline > "$OUT/bench_c4_b64.json" 2>> "$OUT/bench.err"
+python "$ROOT/bench.py" --samples-per-gpu 24 --steps 100 --no-cpu-baseline --no-reference-precision > "$OUT/bench_c4_b24.json" 2>> "$OUT/bench.err"
+python "$ROOT/bench.py" --samples-per-gpu 64 --steps 40 --no-cpu-baseline --no-reference-precision > "$OUT/bench_c4_b64.json" 2>> "$OUT/bench.err"
 python "$ROOT/bench.py" --streams 2 --reserve-cus 64 --no-cpu-baseline > "$OUT/bench_c4_streams2.json" 2>> "$OUT/bench.err"
 python "$ROOT/tools/graph_step.py" c2 c4 > "$OUT/hipgraph.txt" 2>&1
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline --no-reference-precision > "$OUT/bench_prof.log" 2>&1

@@ -16,6 +16,13 @@ aggressors (stream B):
   dma / ld / dmanw / touch   hazard_repro.hip's memory streamer on 256 - reserve_cus CUs: LDS-DMA (global_load_lds_dwordx4, the library's
         weight-stream idiom) / plain global_load_dwordx4 / LDS-DMA with the wave ending while its last chunk is in flight / unwaited touch loads
   expco   v_exp_f32 chains only (transcendental unit), small blocks: co-resident with the victim
+  chainv / chaina / agpr4 / chainaa   co-resident MFMA kernels shaped like the attention's logit phase: ONE dependent accumulator chain in
+        VGPRs / in AGPRs, four independent AGPR accumulators, AGPR chain with an AGPR A operand; chainab: B operand from an AGPR; chainaab: both;
+        chainaabv: both with the accumulator in VGPRs; accmov: no MFMA, v_accvgpr_read / write only
+  ldagpr / ldagprmov / ldvgpr   co-resident kernels whose global loads write AGPRs (then an MFMA with that AGPR as A operand / v_accvgpr_read
+        only) or VGPRs (control)
+  exec0 / exec1 / exec2 / exec4 / exec8 / execonly / mfmaonly   co-resident kernel: an MFMA followed after 0 / 1 / 2 / 4 / 8 nop cycles by a scalar
+        write of EXEC (s_and_saveexec, a masked VALU op, s_or exec); the EXEC sequence alone; the MFMA alone
   mfmaco  the same MFMA kernel with 8 KB of LDS and 256-thread blocks, 2 blocks per CU: victim waves SHARE its SIMDs (co-residency)
   et / ipa / points   one module of the library in a loop through its C-ABI entry (fdipt_edge_transition_fwd: fold rows + EdgeTransition;
         fdipt_ipa_attention_fwd: projection, points, pair bias, attention, o_pair, output projection; fdipt_ipa_project_points: projection + points)
@@ -47,6 +54,9 @@ hz.hz_victim_int.argtypes = hz.hz_victim.argtypes
 hz.hz_aggressor_co.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 hz.hz_victim2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_void_p, C.c_int, C.c_void_p]
 hz.hz_exp_aggressor.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+hz.hz_agpr_load_aggressor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+hz.hz_exec_aggressor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+hz.hz_chain_aggressor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 hz.hz_streamer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 P = _lib.ptr
 conf = config.base_config()
@@ -98,6 +108,7 @@ def module(what):
         _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, 1, B, N, P(m_node), P(mask), P(m_z), P(m_z2), P(mst.ws), mst.ws_bytes, sp))
 
 
+CHAINS = {"chainv": 0, "chaina": 1, "agpr4": 2, "chainaa": 3, "chainab": 4, "chainaab": 5, "chainaabv": 6, "accmov": 7}
 V2 = {"valu": 0, "bperm": 1, "load": 2, "lds": 3, "trans": 4, "fmath": 5, "f64": 6, "tid": 7}
 pat = torch.empty(1 << 22, dtype=torch.int32).cuda()  # 16 MB pattern for the load victim
 hz.hz_victim2(0, 0, 0, P(pat), pat.numel(), P(hbad), 1, None)
@@ -140,6 +151,25 @@ def run(cell):
             elif agg == "expco":  # transcendental-unit load only, co-resident with the victim
                 for _ in range(8):
                     hz.hz_exp_aggressor(1024, 4000, P(aout), _lib.stream_ptr())
+            elif agg in ("ldagpr", "ldagprmov", "ldvgpr"):  # global loads into AGPRs (+ MFMA with that AGPR operand / moves only) / into VGPRs (control)
+                for _ in range(8):
+                    hz.hz_agpr_load_aggressor({"ldagpr": 0, "ldagprmov": 1, "ldvgpr": 2}[agg], 512, 600, P(gsrc), 1 << 22, P(aout), _lib.stream_ptr())
+            elif agg.startswith("exec"):  # execG: MFMA, G nop cycles, scalar EXEC write; execonly: no MFMA; mfmaonly: no EXEC write
+                # execG: 32x32x16 f16; exec16x16_G: 16x16x32 f16 (4 passes); execf32_G: 32x32x2 f32 (16 passes)
+                if agg == "execonly": mode, gap = 1, 0
+                elif agg == "mfmaonly": mode, gap = 2, 0
+                elif agg.startswith("exechi_"): mode, gap = 5, int(agg[7:])  # mask keeps lanes 48 - 63 enabled
+                elif agg.startswith("exec16x16_"): mode, gap = 3, int(agg[10:])
+                elif agg.startswith("execf32_"): mode, gap = 4, int(agg[8:])
+                else: mode, gap = 0, int(agg[4:])
+                for _ in range(8):
+                    hz.hz_exec_aggressor(mode, gap, 512, 1500, P(ops), P(aout), _lib.stream_ptr())
+            elif agg == "mfmaonly":
+                for _ in range(8):
+                    hz.hz_exec_aggressor(2, 0, 512, 1500, P(ops), P(aout), _lib.stream_ptr())
+            elif agg in CHAINS:  # co-resident MFMA chains: VGPR / AGPR accumulator, 4 AGPR accumulators, AGPR A / B operands, ...
+                for _ in range(8):
+                    hz.hz_chain_aggressor(CHAINS[agg], 512, 900, P(ops), P(aout), _lib.stream_ptr())
             elif agg == "mfmaco":
                 for _ in range(8):
                     hz.hz_aggressor_co(512, 256, 450, P(ops), P(aout), 8192, _lib.stream_ptr())

@@ -1,13 +1,25 @@
-// Stand-alone reproducer attempt for the concurrency corruption of DESIGN.md section 5 — NO library code.
-//   stream A ("victim"):   a 16-lanes-per-item float64 series kernel shaped like the IGSO(3) rotation score (float32 sinf / cosf of large
-//                          arguments, float64 weights from an LDS table built with exp(), float64 FMAs and divisions, 16-lane butterfly
-//                          through __shfl_xor), every item fed the SAME input so that every result must be bit-identical; checked on device.
-//   stream B ("aggressor"): a persistent fp16 MFMA power kernel (operands in registers, optionally a global read stream beside it) on
-//                          (256 - reserve) CUs: one block per CU, 152 KB of LDS so that no victim block (16 KB of LDS) fits beside it.
-// Sweeps: aggressor operand entropy (zeros / random), CUs left to the victim, victim block size (64 / 256 threads), integer-only victim,
-// aggressor with / without a memory stream.  Prints one line per cell: victim launches, items checked, mismatching items, and the
-// (item mod 4) histogram of the mismatches (the library's failures were all item = 3 mod 4: lanes 48 - 63 of a wave).
-//   hipcc --offload-arch=gfx950 -O3 -w hazard_repro.hip -o hazard_repro && ./hazard_repro [seconds_per_cell=4]
+// Stand-alone reproducer for the concurrency corruption of rounds 2 - 4 — NO library code.
+//   hipcc --offload-arch=gfx950 -O3 -w hazard_repro.hip -o hazard_repro && ./hazard_repro [seconds_per_cell=4] [only]
+//
+// FINDING (round 4, profiles/r04_hazard_*.txt).  Two kernels on two HIP streams whose waves share SIMDs:
+//   victim     a 16-lanes-per-item series kernel shaped like the IGSO(3) rotation score (fp64 or integer-only), every item fed the same
+//              input, every result compared on the device with a quiet launch;
+//   aggressor  exec_aggressor_kernel: a half-precision MFMA (v_mfma_f32_32x32x16_f16 or 16x16x32_f16) followed after GAP wait states by
+//              `s_and_saveexec_b64 (lanes 0-7, 32-39); v_add_u32; s_or_b64 exec` — what hipcc emits for `if (lane % 32 < 8) x = lds[..]`
+//              next to an MFMA.
+// The victim then computes WRONG VALUES in lanes 48 - 63 of a wave (item % 4 == 3): 0.3 % of its launches at GAP 0, 30 % at GAP 2, practically
+// all of them at GAP >= 16; none with the EXEC sequence alone, none with the MFMA alone (but for the kernel's own epilogue branch), none
+// with the fp32 MFMA (v_mfma_f32_32x32x2_f32) at any gap; 100x fewer when the mask keeps lanes 48 - 63 enabled.  The wrong value is
+// deterministic (a stale register: one VALU result of the victim's first instructions is not written in its last 16-lane pass): the
+// victim's write enables of that pass follow the OTHER wave's EXEC[63:48].  In-register double evaluations never see it (both copies
+// are wrong alike or the event falls on launch-time state), memory and LDS traffic do not matter, AGPR operands do not matter
+// (chain_aggressor_kernel: the few failures there come from the epilogue branch behind the last MFMA).
+// The library's failures (a wrong rotation score of one residue next to another stream's forward) are this: bisected with
+// tools/hazard_lib_repro.py to the attention's logit MFMAs and the o_pair kernel, both with lane-masked loads between MFMAs.
+// It needs waves of different kernels on one SIMD: a single stream never co-schedules two kernels, so the product path is not exposed.
+//
+// Older sections below (kept: they are the negative results): a persistent MFMA power kernel that does NOT share CUs with the victim,
+// memory streamers, instruction-class victims with in-register checks.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -309,6 +321,97 @@ __global__ void pattern_fill_kernel(unsigned* p, unsigned n) {
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = (i * 0x9E3779B1u) ^ 0x5bd1e995u;
 }
 
+// aggressor: global loads whose DESTINATION is an AGPR (hipcc emits them in kernels with more than 256 registers: the unpinned attention
+// had 204), consumed by an MFMA (AGPR A operand) or just moved to VGPRs; small blocks, co-resident with the victim
+//   MODE 0: load -> AGPR, then MFMA with that AGPR as A operand     MODE 1: load -> AGPR, v_accvgpr_read only     MODE 2: load -> VGPR, MFMA (control)
+template <int MODE>
+__global__ __launch_bounds__(256) void agpr_load_aggressor_kernel(const u32x4* __restrict__ src, float* __restrict__ out, int iters, unsigned words_mask) {
+  const int tid = threadIdx.x;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  hx8 B = __builtin_bit_cast(hx8, src[tid & 63]);
+  unsigned idx = (blockIdx.x * 256 + tid) & words_mask;
+  u32x4 sink = {0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+    u32x4 t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32x4* p = src + ((idx + (unsigned)k * 4096u) & words_mask);
+      if (MODE == 2) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t[k]) : "v"(p) : "memory");
+      else asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(t[k]) : "v"(p) : "memory");
+    }
+    idx = (idx + 16384u) & words_mask;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (MODE == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(t[k]), "v"(B));
+      else if (MODE == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(t[k]), "v"(B));
+      else { u32x4 v = t[k]; asm volatile("" : "+v"(v)); sink += v; }
+    }
+  }
+  float s = (float)sink[0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  if (s == 1.2345e-30f) out[tid] = s;
+}
+static int launch_agpr_load_aggressor(int mode, int nblk, int iters, const void* src, unsigned words, float* out, void* stream) {
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((agpr_load_aggressor_kernel<0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, out, iters, words - 1); break;
+    case 1: hipLaunchKernelGGL((agpr_load_aggressor_kernel<1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, out, iters, words - 1); break;
+    case 2: hipLaunchKernelGGL((agpr_load_aggressor_kernel<2>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, out, iters, words - 1); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+// aggressor: an MFMA followed by a scalar write of EXEC (what hipcc emits for `if (lane_condition) x = lds[...]` next to an MFMA: the
+// unpinned o_pair kernel had `v_mfma ...; s_and_saveexec_b64 ...` 32 times, the unpinned attention 205 EXEC writes within three instructions
+// of an MFMA).  GAP = number of `s_nop 0` between the MFMA and the EXEC write; the mask keeps lanes 0 - 7 and 32 - 39 (`lane % 32 < 8`).
+//   MODE 0: MFMA, GAP nops, s_and_saveexec / masked v_mov / s_or exec     MODE 1: no MFMA (the EXEC sequence alone)     MODE 2: MFMA alone
+template <int MODE, int GAP>
+__global__ __launch_bounds__(256) void exec_aggressor_kernel(const u32x4* __restrict__ ops, float* __restrict__ out, int iters) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  hx8 A = __builtin_bit_cast(hx8, ops[((blockIdx.x * 4 + wave) % 64 * 8) * 64 + lane]);
+  hx8 B = __builtin_bit_cast(hx8, ops[((blockIdx.x * 4 + wave) % 64 * 8 + 4) * 64 + lane]);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // (MODE 5: the f16 MFMA of MODE 0 with a mask that KEEPS lanes 48 - 63 enabled: if the victim's last pass takes its write enables from
+  //  the aggressor's EXEC[63:48], this one must be harmless)
+  const unsigned long long mask = MODE == 5 ? 0xFFFF0000000000FFull : 0x000000FF000000FFull;
+  unsigned dummy = 0;
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  f32x4_ acc4 = {0.f, 0.f, 0.f, 0.f};
+  float fa = (float)A[0], fb = (float)B[0];
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      unsigned long long save;
+      // MODE 0 / 2: 32x32x16 f16 (8 passes); MODE 3: 16x16x32 f16 (4 passes); MODE 4: 32x32x2 f32 (16 passes)
+      if (MODE == 0 || MODE == 2 || MODE == 5) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B));
+      if (MODE == 3) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4) : "v"(A), "v"(B));
+      if (MODE == 4) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(fa), "v"(fb));
+      // GAP wait states (s_nop k = k + 1 of them) between the MFMA and the EXEC write
+      if (GAP >= 1 && GAP <= 16) asm volatile("s_nop %0" : : "n"(GAP >= 1 && GAP <= 16 ? GAP - 1 : 0));
+      if (GAP > 16) { asm volatile("s_nop 15"); asm volatile("s_nop %0" : : "n"(GAP > 16 ? GAP - 17 : 0)); }
+      if (MODE != 2)
+        asm volatile("s_and_saveexec_b64 %0, %2\n\tv_add_u32 %1, 1, %1\n\ts_or_b64 exec, exec, %0" : "=&s"(save), "+v"(dummy) : "s"(mask) : "exec", "scc");
+    }
+  }
+  float s = (float)dummy + acc4[0] + acc4[1] + acc4[2] + acc4[3];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  if (s == 1.2345e-30f) out[tid] = s;
+}
+static int launch_exec_aggressor(int mode, int gap, int nblk, int iters, const void* ops, float* out, void* stream) {
+#define HZ_EX(M, G) if (mode == M && gap == G) { hipLaunchKernelGGL((exec_aggressor_kernel<M, G>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); return (int)hipGetLastError(); }
+  HZ_EX(0, 0) HZ_EX(0, 1) HZ_EX(0, 2) HZ_EX(0, 4) HZ_EX(0, 6) HZ_EX(0, 8) HZ_EX(0, 10) HZ_EX(0, 12) HZ_EX(0, 16) HZ_EX(0, 24) HZ_EX(1, 0) HZ_EX(2, 0)
+  HZ_EX(5, 2) HZ_EX(5, 16)
+  HZ_EX(3, 0) HZ_EX(3, 2) HZ_EX(3, 4) HZ_EX(3, 6) HZ_EX(3, 8) HZ_EX(4, 2) HZ_EX(4, 8) HZ_EX(4, 14) HZ_EX(4, 16) HZ_EX(4, 18) HZ_EX(4, 20) HZ_EX(4, 24)
+  return -1;
+}
+
 // second aggressor family: a pure memory streamer (the EdgeTransition weight-stream pattern, tools/micro/wstream_bench.hip) —
 //   MODE 0: LDS-DMA (global_load_lds_dwordx4 through m0, inline asm as in the library), 64 KB chunks, one chunk ahead, s_waitcnt vmcnt(16)
 //   MODE 1: plain global_load_dwordx4 into registers at the same cadence
@@ -346,6 +449,90 @@ __global__ __launch_bounds__(256, 1) void stream_kernel(unsigned* out, const cha
   if (sink[0] == 0x12345u) out[tid] = sink[1] + ((unsigned*)smem)[tid] + tok;
 }
 
+// MFMA aggressors shaped like the attention's logit phase (the phase whose removal makes the library's kernel harmless: A3_ABL=2):
+//   ACC 0: ONE accumulator in VGPRs, every MFMA depends on the previous one     ACC 1: the same chain with the accumulator in AGPRs
+//   ACC 2: four independent AGPR accumulators     ACC 3: AGPR chain whose A operand is an AGPR as well     ACC 4: ... whose B operand is
+//   ACC 5: A and B from AGPRs (four fragments each)     ACC 6: the same with the accumulator in VGPRs     ACC 7: no MFMA, v_accvgpr moves only
+template <int ACC>
+__global__ __launch_bounds__(256) void chain_aggressor_kernel(const u32x4* __restrict__ ops, float* __restrict__ out, int iters) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  hx8 A[4], B[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    A[i] = __builtin_bit_cast(hx8, ops[((blockIdx.x * 4 + wave) % 64 * 8 + i) * 64 + lane]);
+    B[i] = __builtin_bit_cast(hx8, ops[(((blockIdx.x * 4 + wave) % 64) * 8 + 4 + i) * 64 + lane]);
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  if (ACC == 0) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[u & 3], B[(u >> 2) & 3], acc[0], 0, 0, 0);
+  } else if (ACC == 1) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[0]) : "v"(A[u & 3]), "v"(B[(u >> 2) & 3]));
+  } else if (ACC == 2) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[u & 3]) : "v"(A[u & 3]), "v"(B[(u >> 2) & 3]));
+  } else if (ACC == 3) {
+    hx8 Aa = A[0];
+    asm volatile("" : "+a"(Aa));
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[0]) : "a"(Aa), "v"(B[(u >> 2) & 3]));
+  } else if (ACC == 4) {  // B operand from an AGPR
+    hx8 Ba = B[0];
+    asm volatile("" : "+a"(Ba));
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[0]) : "v"(A[u & 3]), "a"(Ba));
+  } else if (ACC == 5) {  // A and B operands from AGPRs, four different fragments each
+    hx8 Aa[4], Ba[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Aa[i] = A[i]; Ba[i] = B[i]; asm volatile("" : "+a"(Aa[i]), "+a"(Ba[i])); }
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[0]) : "a"(Aa[u & 3]), "a"(Ba[(u >> 2) & 3]));
+  } else if (ACC == 6) {  // A and B from AGPRs, accumulator in VGPRs
+    hx8 Aa[4], Ba[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Aa[i] = A[i]; Ba[i] = B[i]; asm volatile("" : "+a"(Aa[i]), "+a"(Ba[i])); }
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[0]) : "a"(Aa[u & 3]), "a"(Ba[(u >> 2) & 3]));
+  } else {  // ACC == 7: no MFMA at all, AGPR traffic only (v_accvgpr_read / write chains)
+    hx8 Aa = A[0];
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { asm volatile("" : "+a"(Aa)); asm volatile("" : "+v"(Aa)); }
+    acc[0][0] = (float)Aa[0];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[c][r];
+  if (s == 1.2345e-30f) out[tid] = s;
+}
+static int launch_chain_aggressor(int acc, int nblk, int iters, const void* ops, float* out, void* stream) {
+  switch (acc) {
+    case 0: hipLaunchKernelGGL((chain_aggressor_kernel<0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    case 1: hipLaunchKernelGGL((chain_aggressor_kernel<1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    case 2: hipLaunchKernelGGL((chain_aggressor_kernel<2>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    case 3: hipLaunchKernelGGL((chain_aggressor_kernel<3>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    case 4: hipLaunchKernelGGL((chain_aggressor_kernel<4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    case 5: hipLaunchKernelGGL((chain_aggressor_kernel<5>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    case 6: hipLaunchKernelGGL((chain_aggressor_kernel<6>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    case 7: hipLaunchKernelGGL((chain_aggressor_kernel<7>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ops, out, iters); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
 #ifdef HAZARD_LIB
 extern "C" int hz_victim2(int kind, int nblk, int rounds, unsigned* pattern, unsigned pat_words, unsigned* bad, int fill, void* stream) {
   if (fill) { hipLaunchKernelGGL(pattern_fill_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, pattern, pat_words); return (int)hipGetLastError(); }
@@ -385,6 +572,15 @@ extern "C" int hz_victim_int(int n_items, const float* q, double sigma, double* 
   launch_victim<256, 1>((hipStream_t)stream, n_items, q, sigma, res, expect, bad);
   return (int)hipGetLastError();
 }
+extern "C" int hz_agpr_load_aggressor(int mode, int nblk, int iters, const void* src, unsigned words, float* out, void* stream) {
+  return launch_agpr_load_aggressor(mode, nblk, iters, src, words, out, stream);
+}
+extern "C" int hz_exec_aggressor(int mode, int gap, int nblk, int iters, const void* ops, float* out, void* stream) {
+  return launch_exec_aggressor(mode, gap, nblk, iters, ops, out, stream);
+}
+extern "C" int hz_chain_aggressor(int acc, int nblk, int iters, const void* ops, float* out, void* stream) {
+  return launch_chain_aggressor(acc, nblk, iters, ops, out, stream);
+}
 // the MFMA aggressor with a caller-chosen LDS footprint and block size: lds_bytes = 0 and 256 threads leaves room for victim waves on the
 // SAME SIMDs (co-residency), which the 152 KB / 512-thread form excludes by construction
 extern "C" int hz_aggressor_co(int nblk, int threads, int iters, const void* ops, float* out, int lds_bytes, void* stream) {
@@ -411,6 +607,74 @@ int main(int argc, char** argv) {
   hipMemcpy(d_q, hq, 32, hipMemcpyHostToDevice);
   hipStream_t sa, sb; hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
   char name[160];
+  // ---- MFMA followed by a scalar EXEC write (co-resident): the pattern the library's failures were traced to
+  {
+    fill_ops(d_ops, 1);
+    const int NC = 12;
+    const int cases[NC][2] = {{0, 0}, {0, 2}, {0, 4}, {0, 8}, {0, 10}, {0, 16}, {0, 24}, {5, 16}, {3, 4}, {4, 16}, {1, 0}, {2, 0}};
+    const char* cn[NC] = {"f16 32x32x16; gap 0; masked VALU", "f16 32x32x16; gap 2; masked VALU", "f16 32x32x16; gap 4; masked VALU", "f16 32x32x16; gap 8; masked VALU",
+                          "f16 32x32x16; gap 10; masked VALU", "f16 32x32x16; gap 16; masked VALU", "f16 32x32x16; gap 24; masked VALU",
+                          "f16; gap 16; mask keeps lanes 48-63", "f16 16x16x32; gap 4; masked VALU", "fp32 32x32x2; gap 16; masked VALU",
+                          "no MFMA, EXEC sequence alone", "MFMA alone"};
+    for (int intonly = 0; intonly < 2; ++intonly)
+      for (int c = 0; c < NC; ++c) {
+        const int n_items = 2896;
+        hipDeviceSynchronize();
+        if (intonly) launch_victim<256, 1>(sa, n_items, d_q, 0.6, d_res, nullptr, d_bad); else launch_victim<256, 0>(sa, n_items, d_q, 0.6, d_res, nullptr, d_bad);
+        hipStreamSynchronize(sa);
+        hipMemcpy(d_expect, d_res, 24, hipMemcpyDeviceToDevice);
+        hipMemset(d_bad, 0, 8192);
+        long launches = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+          for (int i = 0; i < 8; ++i) launch_exec_aggressor(cases[c][0], cases[c][1], 512, 1500, d_ops, d_out, sb);
+          for (int i = 0; i < 48; ++i) {
+            if (intonly) launch_victim<256, 1>(sa, n_items, d_q, 0.6, d_res, d_expect, d_bad); else launch_victim<256, 0>(sa, n_items, d_q, 0.6, d_res, d_expect, d_bad);
+          }
+          launches += 48;
+          hipStreamSynchronize(sa);
+          hipStreamSynchronize(sb);
+        }
+        unsigned hb[8];
+        hipMemcpy(hb, d_bad, 32, hipMemcpyDeviceToHost);
+        printf("co-resident | %-7s victim | %-38s victim launches %6ld  items %9ld  BAD %u  [item%%4: %u %u %u %u]\n", intonly ? "integer" : "fp64", cn[c], launches,
+               launches * n_items, hb[0], hb[1], hb[2], hb[3], hb[4]);
+        fflush(stdout);
+      }
+  }
+  // ---- co-resident MFMA aggressors (small blocks, no LDS: the victim's waves share their SIMDs).  The library's failures were traced to
+  // this class (tools/hazard_lib_repro.py): an MFMA that reads its A / B operand from the AGPR half of the register file
+  {
+    const char* an[8] = {"VGPR A/B, compiler-chosen accumulator", "VGPR A/B, AGPR accumulator chain", "VGPR A/B, four AGPR accumulators", "A operand from an AGPR",
+                         "B operand from an AGPR", "A and B from AGPRs", "A and B from AGPRs, VGPR accumulator", "no MFMA, v_accvgpr moves only"};
+    fill_ops(d_ops, 1);
+    for (int intonly = 0; intonly < 2; ++intonly)
+      for (int acc : {1, 3, 4, 5, 6, 7}) {
+        const int n_items = 2896;
+        hipDeviceSynchronize();
+        if (intonly) launch_victim<256, 1>(sa, n_items, d_q, 0.6, d_res, nullptr, d_bad); else launch_victim<256, 0>(sa, n_items, d_q, 0.6, d_res, nullptr, d_bad);
+        hipStreamSynchronize(sa);
+        hipMemcpy(d_expect, d_res, 24, hipMemcpyDeviceToDevice);
+        hipMemset(d_bad, 0, 8192);
+        long launches = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds * 2) {
+          for (int i = 0; i < 8; ++i) launch_chain_aggressor(acc, 512, 900, d_ops, d_out, sb);
+          for (int i = 0; i < 48; ++i) {
+            if (intonly) launch_victim<256, 1>(sa, n_items, d_q, 0.6, d_res, d_expect, d_bad); else launch_victim<256, 0>(sa, n_items, d_q, 0.6, d_res, d_expect, d_bad);
+          }
+          launches += 48;
+          hipStreamSynchronize(sa);
+          hipStreamSynchronize(sb);
+        }
+        unsigned hb[8];
+        hipMemcpy(hb, d_bad, 32, hipMemcpyDeviceToHost);
+        printf("co-resident | %-7s victim | MFMA chain: %-40s victim launches %6ld  items %9ld  BAD %u  [item%%4: %u %u %u %u]\n", intonly ? "integer" : "fp64", an[acc],
+               launches, launches * n_items, hb[0], hb[1], hb[2], hb[3], hb[4]);
+        fflush(stdout);
+      }
+  }
+  if (argc > 2) return 0;  // (second argument: the co-resident section only)
   for (double sigma : {0.25, 1.0}) {
     snprintf(name, sizeof name, "sigma %.2f  fp64 victim 256 thr, NO aggressor", sigma);
     cell<256, 0>(name, -1, 0, 0, seconds * 0.5, sigma, d_ops, d_g, gwords, d_out, d_q, d_res, d_expect, d_bad, sa, sb);
