@@ -247,9 +247,26 @@ def main():
                                                   "length_step": a.length_step, "samples_per_length": a.samples_per_length}), diff, dev)
 
     def run_batch(feats, tape):
-        return inference.inference_fn(net, diff, feats, num_t=a.num_t, min_t=a.min_t, aux_traj=True, noise_scale=a.noise_scale,
-                                      noise_tape=tape, return_device=True, inpainting=inp,
-                                      input_aatype=inp and not a.no_input_aatype)  # (run_rank overlaps the D2H copy with the next batch)
+        def go():
+            return inference.inference_fn(net, diff, feats, num_t=a.num_t, min_t=a.min_t, aux_traj=True, noise_scale=a.noise_scale,
+                                          noise_tape=tape, return_device=True, inpainting=inp,
+                                          input_aatype=inp and not a.no_input_aatype)  # (run_rank overlaps the D2H copy with the next batch)
+        if not (one_gpu and world > 1):
+            return go()
+        # FDIPT_ONE_GPU (tests): the ranks share one GPU.  Kernels of two processes must not be co-resident on it (DESIGN.md section 6:
+        # a half-precision MFMA kernel next to another kernel's waves corrupts single residues — 1 of 12 two-rank soak runs at N = 810
+        # differed in one sample), so the ranks take turns on the device: a file lock around each batch, released once its kernels are done.
+        # Production runs are one process per GPU and never take this path.
+        import fcntl
+        os.makedirs(a.out_dir, exist_ok=True)
+        with open(os.path.join(a.out_dir, ".one_gpu.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                res = go()
+                torch.cuda.synchronize()
+                return res
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
 
     t0 = time.perf_counter()
     recs = run_rank(ds, diff, run_batch, rank, world, a.out_dir, a.seed, a.num_t, a.min_t, a.max_batch, keep=keep,

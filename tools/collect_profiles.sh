@@ -18,7 +18,7 @@ python "$ROOT/bench.py" --samples-per-gpu 24 --steps 100 --no-cpu-baseline --no-
 python "$ROOT/bench.py" --samples-per-gpu 64 --steps 40 --no-cpu-baseline --no-reference-precision > "$OUT/bench_c4_b64.json" 2>> "$OUT/bench.err"
 python "$ROOT/bench.py" --streams 2 --reserve-cus 64 --no-cpu-baseline > "$OUT/bench_c4_streams2.json" 2>> "$OUT/bench.err"
 python "$ROOT/tools/graph_step.py" c2 c4 > "$OUT/hipgraph.txt" 2>&1
-rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline --no-reference-precision > "$OUT/bench_prof.log" 2>&1
+rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline --no-reference-precision --no-all-samples > "$OUT/bench_prof.log" 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 [ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats.md" > /dev/null
 # config 5 (fp32 mode, N = 1000): kernel table of the parity mode's heaviest configuration
@@ -28,7 +28,7 @@ DB=$(find /tmp/prof_c5 -name "*.db" | head -1)
 for spec in "FETCH:FETCH_SIZE" "WRITE:WRITE_SIZE" "MFMA:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=${spec%%:*}; ctr=${spec#*:}
   rm -rf /tmp/prof_$tag
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/prof_$tag -- python "$ROOT/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-reference-precision > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/prof_$tag -- python "$ROOT/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-reference-precision --no-all-samples > /dev/null 2>&1
   CSV=$(find /tmp/prof_$tag -name "*counter_collection.csv" | head -1)
   [ -n "$CSV" ] && python "$ROOT/tools/pmc_summary.py" "$CSV" > "$OUT/pmc_$tag.md"
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turn gpurun_out/final/* (tools/collect_profiles.sh) into the committed artefacts of the round under profiles/ (r03_*)."""
+"""Turn gpurun_out/final/* (tools/collect_profiles.sh) into the committed artefacts of the round under profiles/ (r04_*)."""
 import json
 import os
 import re
@@ -42,17 +42,17 @@ alg_read, alg_write = z_bytes, z_bytes + B * 8 * N * N * 4
 bench = json.load(open(d + "bench.json"))
 et_us = kst[ET]
 
-open(P + "r03_bench_c4_fp16_kernel_stats.md", "w").write(
-    "# Round 3 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (1 x MI355X, config c4: fp16 mode, N=300, B=8)\n\n"
-    "The SAME command as the bench line in r03_bench.json (whole T = 500 trajectory: 5 warm-up steps on a scratch trajectory, priming\n"
+open(P + "r04_bench_c4_fp16_kernel_stats.md", "w").write(
+    "# Round 4 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-reference-precision --no-all-samples` (1 x MI355X, config c4: fp16 mode, N=300, B=8)\n\n"
+    "The command of the bench line in r04_bench.json without its two sub-records (fp32 `reference_precision`, 64-sample `all_samples_one_gpu`: the latter runs the same kernels at 8x the batch and would mix into the averages) (whole T = 500 trajectory: 5 warm-up steps on a scratch trajectory, priming\n"
     "forward + 500 steps timed).  Per-kernel totals over the whole process (prepare-time kernels and the D2H of the trajectories,\n"
     f"`__amd_rocclr_copyBuffer`, included).  edge_transition4_flat_kernel: {et_us:.1f} us average here vs {bench['roofline']['avg_launch_ms'] * 1e3:.1f} us\n"
     "from the HIP events of the bench's timed region.\n\n" + open(d + "kernel_stats.md").read())
 
 if os.path.exists(d + "kernel_stats_c5.md"):
     c5 = json.load(open(d + "bench_c5.json"))
-    open(P + "r03_bench_c5_fp32_kernel_stats.md", "w").write(
-        "# Round 3 — `rocprofv3 --kernel-trace --stats -- python bench.py --config c5 --no-cpu-baseline` (1 x MI355X, config c5: fp32 mode, N = 1000, B = 4)\n\n"
+    open(P + "r04_bench_c5_fp32_kernel_stats.md", "w").write(
+        "# Round 4 — `rocprofv3 --kernel-trace --stats -- python bench.py --config c5 --no-cpu-baseline` (1 x MI355X, config c5: fp32 mode, N = 1000, B = 4)\n\n"
         f"Bench line of the same configuration: {c5['value']:.0f} residue*step/s, {c5['ms_per_step']:.1f} ms per step; `edge_transition_f32ws_kernel` "
         f"{c5['roofline']['avg_launch_ms']:.2f} ms per launch = {c5['roofline']['frac'] * 100:.1f} % of the 157.3 TFLOP/s fp32 matrix peak (`v_mfma_f32_32x32x2_f32`; "
         "round 1: 51 ms = 34 %).\n\n" + open(d + "kernel_stats_c5.md").read())
@@ -76,7 +76,7 @@ frame_rows = (frame_row("reverse_step_kernel", "SE(3) reverse step + atom37 of x
               + frame_row("points16_kernel", "Rigid.apply of the q / k / v points -> MFMA fragment images (x4 per step)", 8 * 28 * 3 * 4 * 2)
               + frame_row("build_feats_kernel", "x_t split, node / pair feature rows", 1024))
 fetch_ee = next((f"2 x {F[k] * 1024 / 1e6:.0f} MB" for k in F if k.startswith(EE)), "below the ten largest of the step")
-hdr = f"""# Round 3 — PMC counters of the bench command (MI355X, config c4: fp16 mode, N=300, B=8)
+hdr = f"""# Round 4 — PMC counters of the bench command (MI355X, config c4: fp16 mode, N=300, B=8)
 
 Separate passes as MI355X_MICROARCH.md prescribes (never combined with sys/hip tracing; tools/collect_profiles.sh):
 `rocprofv3 --kernel-trace --pmc <COUNTERS> --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline`
@@ -130,7 +130,7 @@ memory-side traffic of the PMC passes where the kernel is in their tables (2 x F
 | kernel | us per launch | MFMA busy cycles | utilisation |
 |---|---|---|---|
 """ + "".join(f"| `{k[:70]}` | {kst.get(k, float('nan')):.1f} | {busy[k]:,.0f} | {util[k] * 100:.1f} % |\n" for k in sorted(util, key=lambda k: -busy[k])) + "\n"
-open(P + "r03_pmc_bench_c4_fp16.md", "w").write(hdr + open(d + "pmc_FETCH.md").read() + open(d + "pmc_WRITE.md").read() + open(d + "pmc_MFMA.md").read())
+open(P + "r04_pmc_bench_c4_fp16.md", "w").write(hdr + open(d + "pmc_FETCH.md").read() + open(d + "pmc_WRITE.md").read() + open(d + "pmc_MFMA.md").read())
 
 rec = {"kernel": ET, "workload": {"precision": "fp16", "n_res": N, "samples_per_gpu": B},
        "fetch_size_kib": F[ET], "write_size_kib": W[ET], "read_bytes": 2 * et_f, "write_bytes": et_w, "traffic_bytes": 2 * et_f + et_w,
@@ -138,8 +138,8 @@ rec = {"kernel": ET, "workload": {"precision": "fp16", "n_res": N, "samples_per_
        "infinity_cache_hit_read_bytes_estimate": 2 * et_f - alg_read,
        "sq_valu_mfma_busy_cycles": busy[ET], "grbm_gui_active_sum_xcd": gui[ET], "mfma_utilisation": util[ET],
        "ipa_attn3_mfma_utilisation": util[key(util, A3)],
-       "source": "profiles/r03_pmc_bench_c4_fp16.md (rocprofv3 --pmc, separate passes; gfx950 FETCH x2 correction, calibrated on o_pair)"}
-json.dump(rec, open(P + "r03_pmc_edge_transition.json", "w"), indent=1)
+       "source": "profiles/r04_pmc_bench_c4_fp16.md (rocprofv3 --pmc, separate passes; gfx950 FETCH x2 correction, calibrated on o_pair)"}
+json.dump(rec, open(P + "r04_pmc_edge_transition.json", "w"), indent=1)
 
 lines = {}
 for tag, fn in (("c4_fp16_n300_b8", "bench.json"), ("c2_fp16_n128_b8", "bench_c2.json"), ("c3_fp16_mixed_bucket_of_8_complexes", "bench_c3.json"),
@@ -151,7 +151,7 @@ for tag, fn in (("c4_fp16_n300_b8", "bench.json"), ("c2_fp16_n128_b8", "bench_c2
         lines[tag] = json.load(open(d + fn))
         if tag.startswith("c4_fp16_n300") and lines[tag]["roofline"].get("traffic") is None:
             lines[tag]["roofline"]["traffic"] = {"total": rec["traffic_bytes"], "read": rec["read_bytes"], "write": rec["write_bytes"],
-                                                 "algorithmic": rec["algorithmic_bytes"], "source": "profiles/r03_pmc_edge_transition.json"}
-json.dump(lines, open(P + "r03_bench.json", "w"), indent=1)
+                                                 "algorithmic": rec["algorithmic_bytes"], "source": "profiles/r04_pmc_edge_transition.json"}
+json.dump(lines, open(P + "r04_bench.json", "w"), indent=1)
 print({k: (round(v["value"]), round(v["ms_per_step"], 3), round(v["roofline"]["whole_forward_frac"], 3)) for k, v in lines.items()})
 print("ET util", round(util[ET], 4), "attn3 util", round(util[key(util, A3)], 4), "traffic MB", round(rec["traffic_bytes"] / 1e6))
