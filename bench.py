@@ -187,6 +187,8 @@ def main():
                     "in one batch, a few steps)")
     ap.add_argument("--all-samples-steps", type=int, default=8, help="timed steps of the all_samples_one_gpu sub-record")
     ap.add_argument("--reserve-cus", type=int, default=48, help="with --streams > 1: CUs the persistent pair kernels leave to the other streams")
+    ap.add_argument("--main-cus", type=int, default=0, help="experiment: run everything on a CU-masked stream with this many CUs (tools/cu_streams.py; HISTORY.md round 4)")
+    ap.add_argument("--et-reserve", type=int, default=0, help="experiment: CUs the persistent pair kernels leave free (single stream)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches on this many HIP streams (same results; not the default: the "
                     "roofline kernel's launches are then sub-batch sized and rocprofv3 serialises the streams)")
     a = ap.parse_args()
@@ -222,6 +224,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    if a.main_cus:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import cu_streams  # experiment helper (tools/cu_streams.py): CU-masked HIP streams
+        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        torch.cuda.set_stream(cu_streams.pair(dev, n_cu - a.main_cus).main)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
@@ -294,8 +301,10 @@ def main():
             if streams > 1:
                 return inference.StreamedLoops(net, diff, feats, streams, T, 0.01, noise_tape=tape, reserve_cus=a.reserve_cus, aux_traj=True,
                                                noise_scale=0.1, inpainting=inp, experimental=True)
-            return inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp,
-                                         noise_tape=tape)
+            lp = inference.ReverseLoop(net, diff, feats, num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, inpainting=inp,
+                                       noise_tape=tape)
+            lp.st.reserve_cus = a.et_reserve
+            return lp
         # timed steps: the whole schedule, or K steps spread evenly over it (first and last included)
         steps = list(range(T)) if K == T else sorted({int(round(i * (T - 1) / max(K - 1, 1))) for i in range(K)})
         while len(steps) < K:  # (rounding collisions for K close to T)
