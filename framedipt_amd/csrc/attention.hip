@@ -478,8 +478,9 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
   const int prow = Np * 2 + 16;                             // bytes per attention-weight row (bf16)
   char* zt = smem;                                          // [2][CZ][OM_ZROW] ([1] with SB)
   char* pb = zt + (SB ? 1 : 2) * CZ * OM_ZROW;              // [8][prow] bf16 attention weights of this (b, i)
-  float* red = SB ? (float*)zt : (float*)(pb + 8 * prow);   // [8][CZ] (SB: the Zt buffer is dead when it is written)
-  float* psum = SB ? (float*)(pb + 8 * prow) : red + 8 * CZ;  // [8]
+  constexpr int RS = CZ + 4;                                // floats per `red` row: the tail's b128 reads of 8 head rows then hit 8 bank groups
+  float* red = SB ? (float*)zt : (float*)(pb + 8 * prow);   // [8][RS] (SB: the Zt buffer is dead when it is written)
+  float* psum = SB ? (float*)(pb + 8 * prow) : red + 8 * RS;  // [8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
   const int i = blockIdx.x, b = blockIdx.y;
   const long rb = (long)b * N;
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
   {
     const int zrow_i = 32 * wave + li, ch_i = 8 * (zrow_i & 15) + (zrow_i >> 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(4 * hi + r) * CZ + ch_i] = acc[r];
+    for (int r = 0; r < 4; ++r) red[(4 * hi + r) * RS + ch_i] = acc[r];
   }
   __syncthreads();
   // down_z (ipa_pytorch.py:317-322) on the matrix core: D[h, d] = sum_c az[h, c] Wdz[d, c], 8 k-steps, wave 0
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(FD_THREADS, LB) void opair_mfma_kernel(OPairArgs a,
     for (int s = 0; s < 8; ++s) {
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (li < 8) {
-        const f32x4 x0 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi), x1 = *(const f32x4*)(red + li * CZ + 16 * s + 8 * hi + 4);
+        const f32x4 x0 = *(const f32x4*)(red + li * RS + 16 * s + 8 * hi), x1 = *(const f32x4*)(red + li * RS + 16 * s + 8 * hi + 4);
         v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3]; v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
       }
       hx8 af, al;
@@ -646,7 +647,7 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
 #ifndef OM_PAD
 #define OM_PAD 0  // (tools/micro/opair_bench.hip: extra dynamic LDS = fewer blocks per CU)
 #endif
-    const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 128 + 8) * 4 + OM_PAD;
+    const size_t smem = (size_t)2 * 128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + (size_t)(8 * 132 + 8) * 4 + OM_PAD;
 #ifndef OM_SB
 #define OM_SB 1   // N <= 320: the four-blocks-per-CU form (tools/micro/opair_bench.hip -DOM_SB=0: three blocks, double-buffered Zt)
 #endif

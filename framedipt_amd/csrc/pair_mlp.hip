@@ -890,6 +890,182 @@ __global__ __launch_bounds__(FD_THREADS) void edge_embed_kernel(EdgeEmbedArgs a)
   ln_store<ZT, TM, CZ>(ybuf, a.gamma, a.beta, a.res_mask, p0, n_pairs, N, (ZT*)a.z_out, a.trace, tid);
 }
 
+// edge_embed_f32p_kernel — the fp32 pair embedder (score_network.py:98-105,173-196) for c_z = 128 as a PERSISTENT block with both
+// 128 x 128 weight matrices RESIDENT in LDS (2 x 66 KB in padded rows): edge_embed_kernel<PrecF32> above re-streams the 128 KB of
+// weights through LDS for every 32 pairs (125 k blocks at N = 1000, B = 4) with four barriers per 32-column k-tile and reaches a third
+// of the fp32 matrix peak.  Here a block of four waves (one per SIMD) walks 32-pair tiles; per tile and wave 2 x 64
+// v_mfma_f32_32x32x2_f32 (8.2 k matrix cycles) against six barriers, the table rows of the NEXT tile and the indices of the one after
+// it travel under the products, activations stay in one 32 x 132 fp32 tile.  Same formulas and dtype flow as the reference
+// (fp32 operands, fp32 accumulation; only the summation order over k differs from the tiled kernel: k in pairs (i, i + 4)).
+#define EEP_LDW 132
+#define EEP_WBYTES (128 * EEP_LDW * 4)
+#define EEP_LDS (2 * EEP_WBYTES + 32 * EEP_LDW * 4 + 32 * 4 + 64 * 4)
+__global__ __launch_bounds__(FD_THREADS, 1) void edge_embed_f32p_kernel(EdgeEmbedArgs a, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* W2s = (float*)smem;
+  float* W3s = (float*)(smem + EEP_WBYTES);
+  float* act = (float*)(smem + 2 * EEP_WBYTES);
+  float* ems = act + 32 * EEP_LDW;  // [32] pair masks of the current tile
+  float* edg = ems + 32;            // [num_bins] lower edges
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, hi = lane >> 5, li = lane & 31;
+  const int N = a.N, nb = a.num_bins;
+  const long n_pairs = (long)a.B * N * N;
+  // ---- weights -> LDS once ([out][in] rows, padded to 132 floats: the b128 operand reads below are conflict-free)
+  {
+    const float* w2 = (const float*)a.w2;
+    const float* w3 = (const float*)a.w3;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int v = tid + k * FD_THREADS, r = v >> 5, c = (v & 31) * 4;
+      *(f32x4*)(W2s + r * EEP_LDW + c) = *(const f32x4*)(w2 + r * 128 + c);
+      *(f32x4*)(W3s + r * EEP_LDW + c) = *(const f32x4*)(w3 + r * 128 + c);
+    }
+    if (tid < nb) edg[tid] = a.edges[tid];
+  }
+  __syncthreads();  // edges (and weights) in LDS
+  const float e0 = edg[0], inv_step = 1.0f / (edg[1] - edg[0]);
+  const int ncol = wc * 32 + li;
+  const float b2v = a.b2[ncol], b3v = a.b3[ncol];
+  const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], be0 = a.beta[lane], be1 = a.beta[lane + 64];
+  // gather role of a thread: pair m of the tile (8 lanes per pair), 16 B chunks c0 + 32 q of its 512 B rows
+  const int m = wc * 8 + (lane >> 3), c0 = (lane & 7) * 4;
+  // (32-bit index arithmetic: the launcher refuses B N N >= 2^31; a 64-bit division is a subroutine with branches on this target)
+  struct Idx { int si, sj; float mi, mj, ci[3], cj[3]; unsigned bi, bj, bb; };
+  const unsigned np_u = (unsigned)n_pairs, Nu = (unsigned)N;
+  auto idx_request = [&](int tile, Idx& x) {
+    const unsigned pr = (unsigned)tile * 32u + (unsigned)m, p = pr < np_u ? pr : np_u - 1u;
+    x.bi = p / Nu;
+    const unsigned j = p - x.bi * Nu;
+    x.bb = x.bi / Nu;
+    x.bj = x.bb * Nu + j;
+    x.si = a.seq_idx[x.bi]; x.sj = a.seq_idx[x.bj];
+    x.mi = a.res_mask[x.bi]; x.mj = a.res_mask[x.bj];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x.ci[c] = a.sc_ca[x.bi * 3u + c]; x.cj[c] = a.sc_ca[x.bj * 3u + c]; }
+  };
+  f32x4 tr[4][4];  // [table][chunk] rows of the next tile
+  float em_next = 0.f;
+  auto rows_request = [&](const Idx& x) {
+    const int rel = (int)(x.bb * a.n_rel) + x.si - x.sj + a.rel_off;
+    const float dx = x.ci[0] - x.cj[0], dy = x.ci[1] - x.cj[1], dz = x.ci[2] - x.cj[2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    // calc_distogram (framedipt/data/utils.py:541-550): strict inequalities against the stored edges, last upper edge 1e8.  The
+    // candidate comes from the edge spacing (the edges are a linspace), its neighbours are re-tested, so the result is the one a
+    // full scan finds (the same search as edge_embed2_kernel's)
+    int k0 = (int)((d - e0) * inv_step);
+    k0 = k0 < 1 ? 1 : (k0 > nb - 2 ? nb - 2 : k0);
+    const float ea = edg[k0 - 1], eb = edg[k0], ec = edg[k0 + 1], ed = k0 + 2 < nb ? edg[k0 + 2] : 1e8f;
+    int bin = nb;
+    bin = (d > ea && d < eb) ? k0 - 1 : bin;
+    bin = (d > eb && d < ec) ? k0 : bin;
+    bin = (d > ec && d < ed) ? k0 + 1 : bin;
+    em_next = x.mi * x.mj;
+    const float* s0 = a.pi + (long)x.bi * 128 + c0;
+    const float* s1 = a.pj + (long)x.bj * 128 + c0;
+    const float* s2 = a.rtab + (long)rel * 128 + c0;
+    const float* s3 = a.dtab + (long)bin * 128 + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      tr[0][q] = *(const f32x4*)(s0 + 32 * q);
+      tr[1][q] = *(const f32x4*)(s1 + 32 * q);
+      tr[2][q] = *(const f32x4*)(s2 + 32 * q);
+      tr[3][q] = *(const f32x4*)(s3 + 32 * q);
+    }
+  };
+  int tile = blockIdx.x;
+  Idx ix;
+  if (tile < n_tiles) {
+    idx_request(tile, ix);
+    rows_request(ix);
+    if (tile + (int)gridDim.x < n_tiles) idx_request(tile + gridDim.x, ix);
+  }
+  const float* arow = act + li * EEP_LDW + 4 * hi;
+  const float* w2row = W2s + ncol * EEP_LDW + 4 * hi;
+  const float* w3row = W3s + ncol * EEP_LDW + 4 * hi;
+  auto layer = [&](const float* wrow) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 av[16], wv[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { av[kk] = *(const f32x4*)(arow + 8 * kk); wv[kk] = *(const f32x4*)(wrow + 8 * kk); }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], wv[kk][i], acc, 0, 0, 0);
+    return acc;
+  };
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const long p0 = (long)tile * 32;
+    // ---- layer 1 has no GEMM: h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]) from the rows requested one tile ago
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = fmaxf(tr[0][q][e] + tr[1][q][e] + tr[2][q][e] + tr[3][q][e], 0.f);
+      *(f32x4*)(act + m * EEP_LDW + c0 + 32 * q) = h;
+    }
+    if ((lane & 7) == 0) ems[m] = em_next;
+    const bool more = tile + (int)gridDim.x < n_tiles;
+    if (more) {  // next tile's rows (its indices arrived during the previous tile), then the indices of the tile after it
+      rows_request(ix);
+      if (tile + 2 * (int)gridDim.x < n_tiles) idx_request(tile + 2 * gridDim.x, ix);
+    }
+    __syncthreads();
+    f32x16 acc = layer(w2row);
+    __syncthreads();  // every wave has read h1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) act[c_row(r, lane) * EEP_LDW + ncol] = fmaxf(acc[r] + b2v, 0.f);
+    __syncthreads();
+    acc = layer(w3row);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) act[c_row(r, lane) * EEP_LDW + ncol] = acc[r] + b3v;
+    __syncthreads();
+    // ---- LayerNorm (two-pass statistics as torch's) + pair mask; wave wc owns rows wc, wc + 4, ...
+    {
+      float v0[8], v1[8], s1[8], s2[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = wc + 4 * q;
+        v0[q] = act[r * EEP_LDW + lane];
+        v1[q] = act[r * EEP_LDW + lane + 64];
+        s1[q] = v0[q] + v1[q];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s1[q] += __shfl_xor(s1[q], o, 64);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float mu = s1[q] * (1.0f / 128);
+        v0[q] -= mu;
+        v1[q] -= mu;
+        s2[q] = v0[q] * v0[q] + v1[q] * v1[q];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s2[q] += __shfl_xor(s2[q], o, 64);
+      float* z_out = (float*)a.z_out;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = wc + 4 * q;
+        const long p = p0 + r;
+        const float rstd = 1.0f / sqrtf(s2[q] * (1.0f / 128) + 1e-5f);
+        const float em = ems[r];
+        if (p < n_pairs) {
+          const float o0 = (v0[q] * rstd * g0v + be0) * em, o1 = (v1[q] * rstd * g1v + be1) * em;
+          z_out[p * 128 + lane] = o0;
+          z_out[p * 128 + lane + 64] = o1;
+          if (a.trace) { a.trace[p * 128 + lane] = o0; a.trace[p * 128 + lane + 64] = o1; }
+        }
+      }
+    }
+    __syncthreads();  // act / ems are rewritten by the next tile's gather
+  }
+}
+
 // ------------------------------------------------------------------ host launchers (CZ/CB dispatch)
 template <int CZ, int CB>
 static int launch_et(int precision, const EdgeTransArgs& a, hipStream_t st) {
@@ -941,6 +1117,21 @@ static int launch_ee(int precision, const EdgeEmbedArgs& a, hipStream_t st) {
   const long n_pairs = (long)a.B * a.N * a.N;
   if (precision == FDIPT_PREC_F32) {
     constexpr int TM = 32;
+    if constexpr (CZ == 128) {
+      if (a.num_bins >= 3 && a.num_bins <= 64 && !FD_DEV_ENV("FDIPT_EE_F32_TILED")) {  // persistent kernel, weights resident in LDS
+        static FdPerDevice attr_dev;
+        const int dev_ = fd_device();
+        if (!attr_dev.get(dev_)) {
+          if (hipFuncSetAttribute((const void*)edge_embed_f32p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EEP_LDS) != hipSuccess)
+            return FDIPT_ELAUNCH;
+          attr_dev.set(dev_, 1);
+        }
+        const int n_tiles = (int)cdiv(n_pairs, 32);
+        hipLaunchKernelGGL(edge_embed_f32p_kernel, dim3(n_tiles < fd_cu_count() ? n_tiles : fd_cu_count()), dim3(FD_THREADS), EEP_LDS, st, a, n_tiles);
+        FD_CHECK_LAUNCH();
+        return FDIPT_OK;
+      }
+    }
     hipLaunchKernelGGL((edge_embed_kernel<PrecF32, float, float, TM, 1, 4, CZ>), dim3(cdiv(n_pairs, TM)),
                        dim3(FD_THREADS), 0, st, a);
   } else {

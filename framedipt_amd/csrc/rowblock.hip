@@ -804,7 +804,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 // LayerNorm statistics are lane-local sums + the three other feature groups (lane ^ 16, ^ 32) + the four waves through LDS.
 #define T16_KS (TL_D / 32)
 #define T16_NT (TL_D / 16)
-#define T16_XROW (TL_D * 2 + 16)
+#define T16_XROW (TL_D * 2 + 32)  // 42 chunks of 16 B: the b128 fragment reads of 16 rows x 4 feature groups are conflict-free (41: 2-way, SQ_LDS_BANK_CONFLICT 44 %)
 #define T16_XLO (16 * T16_XROW)
 #define T16_SMEM (4 * T16_XLO + (7 * TL_D + TL_NP) * 4 + 2 * 4 * 16 * 4 + 16)
 template <bool POST>
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
 #define TR_D 256
 #define TR_KS (TR_D / 32)
 #define TR_NT (TR_D / 16)
-#define TR_XROW (TR_D * 2 + 16)
+#define TR_XROW (TR_D * 2 + 32)  // 34 chunks of 16 B: conflict-free b128 fragment reads (see T16_XROW)
 #define TR_XLO (16 * TR_XROW)
 #define TR_NC (11 * TR_D)  // b0 | b1 | b2 | gamma | beta | Wbb [6][256]
 #define TR_SMEM (4 * TR_XLO + TR_NC * 4 + 2 * 4 * 16 * 4 + 4 * 16 * 8 * 4 + 64 + 16)
