@@ -107,17 +107,20 @@ MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 
 ## ipa_attn3_kernel (IPA attention: QK^T + pair bias + point distances, softmax, P V, o_pt) — the north star's "MFMA utilisation on the
 attention GEMMs"
 * {kst[key(kst, A3)]:.1f} us per call (x4 per step); SQ_VALU_MFMA_BUSY_CYCLES {busy[key(busy, A3)]:,.0f}; MFMA utilisation
-  **{util[key(util, A3)] * 100:.1f} %** (round 2: 9.7 % at 45 us; round 3 runs P V and the value-point sums on split operands: 3x the P V
-  MFMAs, V_lo fetched as well).  The kernel is bound by the L2 -> CU fabric, not by the matrix cores: 640 blocks (64 (sample, head)
-  x 10 query tiles, three per CU, one round) each pull K + V_hi + V_lo of their (sample, head) = 480 KB + bias 40 KB: ~340 MB per
-  call at the ~5-6 TB/s the fabric delivers.  attention4 (K / V through LDS once per 128 queries, 96 MB per call: tools/micro)
-  measured slower: one wave per SIMD cannot hide its own DMA issue / softmax / LDS waits.
+  **{util[key(util, A3)] * 100:.1f} %** (round 3: 13.2 % at 55 us with fourteen fp32 MFMAs per key tile for the point logits; round 4 runs them as
+  six fp16 hi / lo MFMAs from a key-point fragment image).  Bound by neither the matrix cores nor a memory path: the SQ counters
+  (profiles/r04_pmc_sq_c4.md) show its waves parked on memory waits 51 % and issue-stalled 31 % of their cycles with the VALU 15 % busy —
+  a per-CU throughput limit of dependent load -> MFMA -> softmax chains at 12 waves per CU (25.9 us at four samples, 46 at eight, 349
+  at 64: linear in the block count).  640 blocks (64 (sample, head) x 10 query tiles, three per CU, one round) each pull K + V_hi +
+  V_lo of their sample (shared by its eight heads, L2-resident) + bias 40 KB: 34 GB/s per CU, a quarter of what a CU's L2 path
+  delivers.  Variants that stage K / V through LDS once per 64 - 128 queries (tools/micro/attention4_experiment.hip) measured slower
+  at eight samples: 80 - 160 blocks leave most CUs idle.
 * memory side: 2 x FETCH {2 * F[key(F, A3)] * 1024 / 1e6:.0f} MB, WRITE {W[key(W, A3)] * 1024 / 1e6:.0f} MB per call.
 
 ## HBM-bound passes
 * `opair_mfma_kernel`: 196.8 MB in {kst[key(kst, OP)]:.1f} us = {2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6:.2f} TB/s ({2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6 / 8 * 100:.0f} % of the 8 TB/s peak, {2 * F[key(F, OP)] * 1024 / kst[key(kst, OP)] / 1e6 / 6.3 * 100:.0f} % of the 6.3 TB/s achievable).
 * `edge_embed2_kernel`: 207 MB written in {kst[key(kst, EE)]:.1f} us = {W[key(W, EE)] * 1024 / kst[key(kst, EE)] / 1e6:.2f} TB/s; MFMA utilisation {util[key(util, EE)] * 100:.1f} % (47 GF): bound by neither
-  (since the row-walk decomposition of round 2 its table rows come out of L2 / LDS: FETCH_SIZE {fetch_ee}; phase profile in DESIGN.md section 4.4).
+  (since the row-walk decomposition of round 2 its table rows come out of L2 / LDS: FETCH_SIZE {fetch_ee}; phase profile in DESIGN.md section 4.3; SQ counters: VALU 47 %, LDS array 54 %, matrix pipe 31 % busy, waves issue-stalled 41 %).
 
 ## Frame ops (the north star's "achieved HBM GB/s on the frame ops against CDNA4 peak")
 B N = 2400 residues per launch: a few hundred bytes per residue, so these launches are latency-bound (one residue per lane, float64 chains),
