@@ -891,43 +891,65 @@ __global__ __launch_bounds__(FD_THREADS) void edge_embed_kernel(EdgeEmbedArgs a)
 }
 
 // edge_embed_f32p_kernel — the fp32 pair embedder (score_network.py:98-105,173-196) for c_z = 128 as a PERSISTENT block with both
-// 128 x 128 weight matrices RESIDENT in LDS (2 x 66 KB in padded rows): edge_embed_kernel<PrecF32> above re-streams the 128 KB of
-// weights through LDS for every 32 pairs (125 k blocks at N = 1000, B = 4) with four barriers per 32-column k-tile and reaches a third
-// of the fp32 matrix peak.  Here a block of four waves (one per SIMD) walks 32-pair tiles; per tile and wave 2 x 64
-// v_mfma_f32_32x32x2_f32 (8.2 k matrix cycles) against six barriers, the table rows of the NEXT tile and the indices of the one after
-// it travel under the products, activations stay in one 32 x 132 fp32 tile.  Same formulas and dtype flow as the reference
-// (fp32 operands, fp32 accumulation; only the summation order over k differs from the tiled kernel: k in pairs (i, i + 4)).
-#define EEP_LDW 132
-#define EEP_WBYTES (128 * EEP_LDW * 4)
-#define EEP_LDS (2 * EEP_WBYTES + 32 * EEP_LDW * 4 + 32 * 4 + 64 * 4)
-__global__ __launch_bounds__(FD_THREADS, 1) void edge_embed_f32p_kernel(EdgeEmbedArgs a, int n_tiles) {
+// 128 x 128 weight matrices RESIDENT in LDS: edge_embed_kernel<PrecF32> above re-streams the 128 KB of weights through LDS for every
+// 32 pairs (125 k blocks at N = 1000, B = 4) with four barriers per 32-column k-tile and reaches a third of the fp32 matrix peak.
+//
+// Here a block has EIGHT waves = two TEAMS of four (one wave of each team per SIMD); a team walks 32-pair tiles through six phases
+//   P0 gather h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]) into its activation tile     P1 layer 2: 64 v_mfma_f32_32x32x2_f32 per wave
+//   P2 h2 = relu(. + b2) back into the tile       P3 layer 3: 64 MFMAs       P4 y = . + b3 into the tile       P5 LayerNorm, mask, stores
+// separated by block barriers, and the second team runs THREE PHASES (half a tile) ahead of the first: each matrix phase of one team
+// (4.1 k cycles of the SIMD's matrix pipe) then faces a gather / epilogue / LayerNorm phase of the other (one team alone — one wave per
+// SIMD — exposes every non-matrix phase: 697 us at N = 300, B = 8, 0.45 of the fp32 matrix peak).
+// LDS is exactly 160 KB: W2 | W3 | two 32 x 128 fp32 activation tiles, all as 512 B rows whose 16 B chunk c sits at c ^ (row & 15)
+// (conflict-free b128 operand reads, b128 gather stores, b32 epilogue stores and LayerNorm reads); the distogram edges live in one
+// register per lane (lane k = edge k, fetched with a lane shuffle), the pair masks in the gathering lanes.  The table rows of a team's
+// NEXT tile and the indices of the one after it travel under its current tile.  Same formulas and dtype flow as the reference (fp32
+// operands, fp32 accumulation, two-pass LayerNorm statistics); only the summation order over k differs from the tiled kernel
+// (k in pairs (i, i + 4) of every 8-group).
+#define EEP_LDS (2 * 128 * 128 * 4 + 2 * 32 * 128 * 4)
+#ifdef EEP_PROF  // phase profile (tools/micro/eep_bench.hip -DEEP_PROF): cycles of wave 0 / wave 4 of block 0 per phase, and in the barriers
+__device__ unsigned long long eep_prof[2][8];
+#endif
+template <int N_, class F>
+__device__ __forceinline__ void eep_for(F&& f) {  // f(integral_constant<0>) ... f(integral_constant<N_ - 1>)
+  if constexpr (N_ > 0) {
+    eep_for<N_ - 1>(f);
+    f(std::integral_constant<int, N_ - 1>{});
+  }
+}
+__device__ __forceinline__ int eep_off(int row, int col) {  // float offset of element (row, col) of a swizzled [rows][128] fp32 tile
+  return row * 128 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3));
+}
+__global__ __launch_bounds__(2 * FD_THREADS, 1) void edge_embed_f32p_kernel(EdgeEmbedArgs a, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* W2s = (float*)smem;
-  float* W3s = (float*)(smem + EEP_WBYTES);
-  float* act = (float*)(smem + 2 * EEP_WBYTES);
-  float* ems = act + 32 * EEP_LDW;  // [32] pair masks of the current tile
-  float* edg = ems + 32;            // [num_bins] lower edges
-  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, hi = lane >> 5, li = lane & 31;
+  float* W3s = W2s + 128 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, team = wave >> 2, wc = wave & 3, hi = lane >> 5, li = lane & 31;
+  float* act = W3s + 128 * 128 + team * (32 * 128);
   const int N = a.N, nb = a.num_bins;
   const long n_pairs = (long)a.B * N * N;
-  // ---- weights -> LDS once ([out][in] rows, padded to 132 floats: the b128 operand reads below are conflict-free)
-  {
+  {  // weights -> LDS once ([out][in] rows, swizzled chunks)
     const float* w2 = (const float*)a.w2;
     const float* w3 = (const float*)a.w3;
 #pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      const int v = tid + k * FD_THREADS, r = v >> 5, c = (v & 31) * 4;
-      *(f32x4*)(W2s + r * EEP_LDW + c) = *(const f32x4*)(w2 + r * 128 + c);
-      *(f32x4*)(W3s + r * EEP_LDW + c) = *(const f32x4*)(w3 + r * 128 + c);
+    for (int k = 0; k < 8; ++k) {
+      const int v = tid + k * 2 * FD_THREADS, r = v >> 5, c = (v & 31) * 4;
+      *(f32x4*)(W2s + eep_off(r, c)) = *(const f32x4*)(w2 + r * 128 + c);
+      *(f32x4*)(W3s + eep_off(r, c)) = *(const f32x4*)(w3 + r * 128 + c);
     }
-    if (tid < nb) edg[tid] = a.edges[tid];
   }
-  __syncthreads();  // edges (and weights) in LDS
-  const float e0 = edg[0], inv_step = 1.0f / (edg[1] - edg[0]);
+  const float edge_reg = lane < nb ? a.edges[lane] : 1e8f;  // lane k holds lower edge k (num_bins <= 64); beyond the last one: 1e8
+  const float e0 = __shfl(edge_reg, 0, 64), inv_step = 1.0f / (__shfl(edge_reg, 1, 64) - e0);
   const int ncol = wc * 32 + li;
   const float b2v = a.b2[ncol], b3v = a.b3[ncol];
-  const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], be0 = a.beta[lane], be1 = a.beta[lane + 64];
-  // gather role of a thread: pair m of the tile (8 lanes per pair), 16 B chunks c0 + 32 q of its 512 B rows
+  const f32x4 gq0 = *(const f32x4*)(a.gamma + 4 * (lane & 15)), gq1 = *(const f32x4*)(a.gamma + 64 + 4 * (lane & 15));
+  const f32x4 bq0 = *(const f32x4*)(a.beta + 4 * (lane & 15)), bq1 = *(const f32x4*)(a.beta + 64 + 4 * (lane & 15));
+  // The per-lane constants above have ARRIVED before the first tile request is issued: the vmcnt counter is in order, and a use of one of
+  // them inside the loop would otherwise be guarded by a wait (hipcc merges the first-iteration state into the loop) that also waits for
+  // the table rows requested a moment earlier.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+  // gather role of a thread: pair m of the team's tile (8 lanes per pair), 16 B chunks (lane & 7) + 8 q of its 512 B rows
   const int m = wc * 8 + (lane >> 3), c0 = (lane & 7) * 4;
   // (32-bit index arithmetic: the launcher refuses B N N >= 2^31; a 64-bit division is a subroutine with branches on this target)
   struct Idx { int si, sj; float mi, mj, ci[3], cj[3]; unsigned bi, bj, bb; };
@@ -943,8 +965,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_embed_f32p_kernel(EdgeEmbe
 #pragma unroll
     for (int c = 0; c < 3; ++c) { x.ci[c] = a.sc_ca[x.bi * 3u + c]; x.cj[c] = a.sc_ca[x.bj * 3u + c]; }
   };
-  f32x4 tr[4][4];  // [table][chunk] rows of the next tile
-  float em_next = 0.f;
+  f32x4 tr[4][4];  // [table][chunk] rows of the team's next tile
+  float em_next = 0.f, em_cur = 0.f;
   auto rows_request = [&](const Idx& x) {
     const int rel = (int)(x.bb * a.n_rel) + x.si - x.sj + a.rel_off;
     const float dx = x.ci[0] - x.cj[0], dy = x.ci[1] - x.cj[1], dz = x.ci[2] - x.cj[2];
@@ -954,7 +976,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_embed_f32p_kernel(EdgeEmbe
     // full scan finds (the same search as edge_embed2_kernel's)
     int k0 = (int)((d - e0) * inv_step);
     k0 = k0 < 1 ? 1 : (k0 > nb - 2 ? nb - 2 : k0);
-    const float ea = edg[k0 - 1], eb = edg[k0], ec = edg[k0 + 1], ed = k0 + 2 < nb ? edg[k0 + 2] : 1e8f;
+    const float ea = __shfl(edge_reg, k0 - 1, 64), eb = __shfl(edge_reg, k0, 64), ec = __shfl(edge_reg, k0 + 1, 64);
+    const float ed_ = __shfl(edge_reg, (k0 + 2) & 63, 64), ed = k0 + 2 < nb ? ed_ : 1e8f;
     int bin = nb;
     bin = (d > ea && d < eb) ? k0 - 1 : bin;
     bin = (d > eb && d < ec) ? k0 : bin;
@@ -972,97 +995,159 @@ __global__ __launch_bounds__(FD_THREADS, 1) void edge_embed_f32p_kernel(EdgeEmbe
       tr[3][q] = *(const f32x4*)(s3 + 32 * q);
     }
   };
-  int tile = blockIdx.x;
+  // the team's tiles: blockIdx.x + (2 i + team) gridDim.x, i = 0, 1, ...
+  const int stride = 2 * (int)gridDim.x;
+  const int tile0 = (int)blockIdx.x + team * (int)gridDim.x;
+  const int n_mine = tile0 < n_tiles ? (n_tiles - tile0 + stride - 1) / stride : 0;
+  const int n_first = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + stride - 1) / stride : 0;  // team 0's count >= team 1's
   Idx ix;
-  if (tile < n_tiles) {
-    idx_request(tile, ix);
+  if (n_mine > 0) {
+    idx_request(tile0, ix);
     rows_request(ix);
-    if (tile + (int)gridDim.x < n_tiles) idx_request(tile + gridDim.x, ix);
+    idx_request(tile0 + (n_mine > 1 ? stride : 0), ix);
   }
-  const float* arow = act + li * EEP_LDW + 4 * hi;
-  const float* w2row = W2s + ncol * EEP_LDW + 4 * hi;
-  const float* w3row = W3s + ncol * EEP_LDW + 4 * hi;
+  const int sw = li & 15;
+  const float* arow = act + li * 128;
+  const float* w2row = W2s + ncol * 128;
+  const float* w3row = W3s + ncol * 128;
+  const int swn = ncol & 15;
   auto layer = [&](const float* wrow) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    f32x4 av[16], wv[16];
+    // operand chunks in two halves of 8 (64 registers in flight: the kernel keeps 64 more for the next tile's table rows)
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      f32x4 av[8], wv[8];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { av[kk] = *(const f32x4*)(arow + 8 * kk); wv[kk] = *(const f32x4*)(wrow + 8 * kk); }
+      for (int k8 = 0; k8 < 8; ++k8) {
+        const int kk = 8 * half + k8;
+        av[k8] = *(const f32x4*)(arow + (((2 * kk + hi) ^ sw) << 2));
+        wv[k8] = *(const f32x4*)(wrow + (((2 * kk + hi) ^ swn) << 2));
+      }
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
+      for (int k8 = 0; k8 < 8; ++k8)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], wv[kk][i], acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k8][i], wv[k8][i], acc, 0, 0, 0);
+    }
     return acc;
   };
-  for (; tile < n_tiles; tile += gridDim.x) {
-    const long p0 = (long)tile * 32;
-    // ---- layer 1 has no GEMM: h1 = relu(Pi[i] + Pj[j] + R[rel] + D[bin]) from the rows requested one tile ago
+  f32x16 acc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 h;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int done = 0;       // tiles of this team whose P0 has run
+  long p0 = 0;        // first pair of the tile in flight
+  auto phase = [&](auto PH) {
+    constexpr int ph = decltype(PH)::value;
+    // issue priority: a wave in a matrix phase re-issues its next (dependent) MFMA the moment the pipe frees and, being served first,
+    // lets the SIMD's other wave issue about one instruction per MFMA (measured: the 32-instruction y store 0.5 k cycles beside a
+    // LayerNorm, 2.4 k beside a matrix phase); with the non-matrix phases at a higher priority they slip into the MFMA shadows
+    __builtin_amdgcn_s_setprio(ph == 1 || ph == 3 ? 0 : 3);
+    if constexpr (ph == 0) {  // gather: h1 from the rows requested one tile ago; request the next tile's rows / the indices after it
+      if (done < n_mine) {
+        p0 = (long)(tile0 + done * stride) * 32;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = fmaxf(tr[0][q][e] + tr[1][q][e] + tr[2][q][e] + tr[3][q][e], 0.f);
-      *(f32x4*)(act + m * EEP_LDW + c0 + 32 * q) = h;
-    }
-    if ((lane & 7) == 0) ems[m] = em_next;
-    const bool more = tile + (int)gridDim.x < n_tiles;
-    if (more) {  // next tile's rows (its indices arrived during the previous tile), then the indices of the tile after it
-      rows_request(ix);
-      if (tile + 2 * (int)gridDim.x < n_tiles) idx_request(tile + 2 * gridDim.x, ix);
-    }
-    __syncthreads();
-    f32x16 acc = layer(w2row);
-    __syncthreads();  // every wave has read h1
+        for (int q = 0; q < 4; ++q) {
+          f32x4 h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) act[c_row(r, lane) * EEP_LDW + ncol] = fmaxf(acc[r] + b2v, 0.f);
-    __syncthreads();
-    acc = layer(w3row);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) act[c_row(r, lane) * EEP_LDW + ncol] = acc[r] + b3v;
-    __syncthreads();
-    // ---- LayerNorm (two-pass statistics as torch's) + pair mask; wave wc owns rows wc, wc + 4, ...
-    {
-      float v0[8], v1[8], s1[8], s2[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = wc + 4 * q;
-        v0[q] = act[r * EEP_LDW + lane];
-        v1[q] = act[r * EEP_LDW + lane + 64];
-        s1[q] = v0[q] + v1[q];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s1[q] += __shfl_xor(s1[q], o, 64);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float mu = s1[q] * (1.0f / 128);
-        v0[q] -= mu;
-        v1[q] -= mu;
-        s2[q] = v0[q] * v0[q] + v1[q] * v1[q];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s2[q] += __shfl_xor(s2[q], o, 64);
-      float* z_out = (float*)a.z_out;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = wc + 4 * q;
-        const long p = p0 + r;
-        const float rstd = 1.0f / sqrtf(s2[q] * (1.0f / 128) + 1e-5f);
-        const float em = ems[r];
-        if (p < n_pairs) {
-          const float o0 = (v0[q] * rstd * g0v + be0) * em, o1 = (v1[q] * rstd * g1v + be1) * em;
-          z_out[p * 128 + lane] = o0;
-          z_out[p * 128 + lane + 64] = o1;
-          if (a.trace) { a.trace[p * 128 + lane] = o0; a.trace[p * 128 + lane + 64] = o1; }
+          for (int e = 0; e < 4; ++e) h[e] = fmaxf(tr[0][q][e] + tr[1][q][e] + tr[2][q][e] + tr[3][q][e], 0.f);
+          *(f32x4*)(act + m * 128 + ((((lane & 7) + 8 * q) ^ (m & 15)) << 2)) = h;
         }
+        em_cur = em_next;
+        // Unconditional (tile indices clamped to the team's last tile: a few redundant requests at the very end): a request under a
+        // branch makes the loaded registers phi values of the join, and hipcc then copies them there — behind an s_waitcnt vmcnt that
+        // exposes the whole round trip (measured: this phase 2.1 k -> 5.6 k cycles).  The fence keeps the products of the old indices
+        // (em_next, rel, bin) in front of the new index loads, so those land in the old registers.
+        rows_request(ix);
+        __builtin_amdgcn_sched_barrier(0);
+        idx_request(tile0 + (done + 2 < n_mine ? done + 2 : n_mine - 1) * stride, ix);
+      }
+    } else if constexpr (ph == 1) {
+      if (done < n_mine) acc = layer(w2row);
+    } else if constexpr (ph == 2) {
+      if (done < n_mine)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[eep_off(c_row(r, lane), ncol)] = fmaxf(acc[r] + b2v, 0.f);
+    } else if constexpr (ph == 3) {
+      if (done < n_mine) acc = layer(w3row);
+    } else if constexpr (ph == 4) {
+      if (done < n_mine)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[eep_off(c_row(r, lane), ncol)] = acc[r] + b3v;
+    } else {
+      if (done < n_mine) {  // LayerNorm (two-pass statistics as torch's) + pair mask; wave wc owns the rows it gathered: 8 wc .. 8 wc + 7
+        // four rows per pass, 16 lanes per row: lane (rp, fl) holds features 4 fl .. + 3 and 64 + 4 fl .. + 3 (two conflict-free b128
+        // reads, two 256 B row segments per store instruction); the statistics need four butterfly steps inside a 16-lane row
+        float* z_out = (float*)a.z_out;
+        const int rp = lane >> 4, fl = lane & 15;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int q = 4 * pass + rp, r = 8 * wc + q;
+          const f32x4 x0 = *(const f32x4*)(act + r * 128 + ((fl ^ (r & 15)) << 2));
+          const f32x4 x1 = *(const f32x4*)(act + r * 128 + (((fl + 16) ^ (r & 15)) << 2));
+          float s1 = ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+          const float mu = s1 * (1.0f / 128);
+          f32x4 d0, d1;
+          float s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            d0[e] = x0[e] - mu;
+            d1[e] = x1[e] - mu;
+            s2 += d0[e] * d0[e] + d1[e] * d1[e];
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+          const float rstd = 1.0f / sqrtf(s2 * (1.0f / 128) + 1e-5f);
+          const float em = __shfl(em_cur, 8 * q, 64);
+          const long p = p0 + r;
+          if (p < n_pairs) {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o0[e] = (d0[e] * rstd * gq0[e] + bq0[e]) * em;
+              o1[e] = (d1[e] * rstd * gq1[e] + bq1[e]) * em;
+            }
+            *(f32x4*)(z_out + p * 128 + 4 * fl) = o0;
+            *(f32x4*)(z_out + p * 128 + 64 + 4 * fl) = o1;
+            if (a.trace) { *(f32x4*)(a.trace + p * 128 + 4 * fl) = o0; *(f32x4*)(a.trace + p * 128 + 64 + 4 * fl) = o1; }
+          }
+        }
+        ++done;
       }
     }
-    __syncthreads();  // act / ems are rewritten by the next tile's gather
+  };
+  __syncthreads();  // weights in LDS
+  // Barrier slots s = 0..5 of a round: team 0 runs phase s of its round-th tile, team 1 phase (s + 3) % 6 — the last three phases of
+  // its previous tile in slots 0..2 (nothing in round 0), the first three of its next one in slots 3..5.  n_first + 1 rounds: the last
+  // one only finishes team 1's last tile.  Every wave executes every barrier.
+  bool started = team == 0;  // team 1 has no tile in flight during slots 0..2 of round 0
+  for (int round = 0; round <= n_first; ++round) {
+    eep_for<6>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+#ifdef EEP_PROF
+      const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+      if (team == 0) {
+        phase(std::integral_constant<int, s>{});
+      } else {
+        constexpr int ph = (s + 3) % 6;
+        if (ph < 3) started = true;
+        if (started) phase(std::integral_constant<int, ph>{});
+      }
+#ifdef EEP_PROF
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+#endif
+      __syncthreads();
+#ifdef EEP_PROF
+      if (blockIdx.x == 0 && (tid & 255) == 0) {
+        eep_prof[team][team == 0 ? s : (s + 3) % 6] += t1_ - t0_;
+        eep_prof[team][6] += __builtin_amdgcn_s_memtime() - t1_;
+      }
+#endif
+    });
   }
 }
 
@@ -1127,7 +1212,7 @@ static int launch_ee(int precision, const EdgeEmbedArgs& a, hipStream_t st) {
           attr_dev.set(dev_, 1);
         }
         const int n_tiles = (int)cdiv(n_pairs, 32);
-        hipLaunchKernelGGL(edge_embed_f32p_kernel, dim3(n_tiles < fd_cu_count() ? n_tiles : fd_cu_count()), dim3(FD_THREADS), EEP_LDS, st, a, n_tiles);
+        hipLaunchKernelGGL(edge_embed_f32p_kernel, dim3(n_tiles < fd_cu_count() ? n_tiles : fd_cu_count()), dim3(2 * FD_THREADS), EEP_LDS, st, a, n_tiles);
         FD_CHECK_LAUNCH();
         return FDIPT_OK;
       }

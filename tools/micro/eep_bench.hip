@@ -39,6 +39,16 @@ int main(int argc, char** argv) {
            P * 65536.0 / (ms / iters) / 1e9);
     (void)hipMemcpy(variant ? ref.data() : got.data(), z + (P / 2) * 128, 4096 * 4, hipMemcpyDeviceToHost);
   }
+#ifdef EEP_PROF
+  {
+    unsigned long long h[2][8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(eep_prof), sizeof(h));
+    const char* nm[7] = {"P0 gather", "P1 layer 2", "P2 relu store", "P3 layer 3", "P4 y store", "P5 LayerNorm", "barrier wait"};
+    const double tiles = (double)((P + 31) / 32) / (2.0 * 256) * 12;  // per team of block 0, over the 12 persistent launches
+    for (int t = 0; t < 2; ++t)
+      for (int k = 0; k < 7; ++k) printf("  team %d %-14s %8.0f cycles per tile\n", t, nm[k], h[t][k] / tiles);
+  }
+#endif
   double md = 0; for (int k = 0; k < 4096; ++k) md = fmax(md, fabs(ref[k] - got[k]));
   printf("max |persistent - tiled| over 32 rows: %.3g\n", md);
   return 0;
