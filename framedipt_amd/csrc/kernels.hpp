@@ -273,6 +273,11 @@ struct RowBlockArgs {
   // (skip_embed of all trunk blocks stacked)
   const void *w3 = nullptr, *w3l = nullptr;
   const float* b3 = nullptr;
+  // fd_transition16 only (round 4): the EdgeTransition row launch folded in — e = initial_embed(out rows) (Linear 256 -> 128) and the
+  // 1024 fold columns [A1 | Af | B1 | Bf] of e (Linear 128 -> 1024), split operands, written as edge_transition4's fold-fragment images
+  // img_a / img_b (img_B, img_N as for FD_RB_ET4_IMAGES).  we0 / we1 (+ lo): fd_chain_build_image16 images; NULL = not folded in.
+  const void *we0 = nullptr, *we0l = nullptr, *we1 = nullptr, *we1l = nullptr;
+  const float *be0 = nullptr, *be1 = nullptr;
 };
 enum { FD_RB_OUTPROJ, FD_RB_FFN, FD_RB_TRANSITION, FD_RB_NODE_EMBED_72, FD_RB_NODE_EMBED_88, FD_RB_TORSION, FD_RB_TRANSITION_BB, FD_RB_ET_ROWS, FD_RB_ET4_ROWS, FD_RB_ET4_IMAGES,
        FD_RB_TRANSITION_BB_SPLIT, FD_RB_NODE_EMBED_72_SPLIT, FD_RB_NODE_EMBED_88_SPLIT, FD_RB_TORSION_SPLIT };

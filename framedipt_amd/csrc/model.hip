@@ -170,6 +170,7 @@ struct DSplit {  // lo images (W - half(W)) of the node-path layers that run on 
   // 16-row images (fd_chain_build_image16) of the tail's matrices, hi then lo: out_proj, FFN 1, FFN 2 per layer, post_tfmr
   size_t o16[FD_MAX_TL][2], f16[FD_MAX_TL][2], g16[FD_MAX_TL][2], p16[2];
   size_t tr16[3][2];  // ... of the transition's three matrices (transition16_kernel): hi run t1 | t2 | t3, then the lo run
+  size_t ei16[2], r416[2];  // ... of EdgeTransition's initial_embed and fold-row matrix r4w (rows folded into the transition launch): hi run, lo run
 };
 struct DChain {  // weight images of the fused node-path chains (chain.hip) of one trunk block
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
@@ -281,6 +282,7 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
       }
       for (int h = 0; h < 2; ++h)
         for (int i = 0; i < 3; ++i) c.tr16[i][h] = img(cs, cs);
+      for (int h = 0; h < 2; ++h) { c.ei16[h] = img(iv.cb, cs); c.r416[h] = img(2 * (iv.hid + d->c_z), iv.cb); }
     }
     L.lo_ne0 = img(cs, L.kn_pad); L.lo_ne2 = img(cs, cs); L.lo_ne4 = img(cs, cs); L.lo_tor1 = img(cs, cs); L.lo_tor2 = img(cs, cs);
     for (int h = 0; h < 2; ++h) { L.ne16[0][h] = img(cs, 96); L.ne16[1][h] = img(cs, cs); L.ne16[2][h] = img(cs, cs); }
@@ -571,6 +573,17 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
           if ((rc = i16(k.post, h, c.p16[h]))) return rc;
           if ((rc = i16(k.t1, h, c.tr16[0][h])) || (rc = i16(k.t2, h, c.tr16[1][h])) || (rc = i16(k.t3, h, c.tr16[2][h]))) return rc;
         }
+      }
+      if (b < d->num_blocks - 1 && tail16_shapes(d, iv) && iv.cb == 128 && (iv.hid & 15) == 0 && (cz & 15) == 0) {
+        // ... and as 16-row images for the transition launch that folds the row launch in (rowblock.hip: mlp16_kernel<.., ETR>)
+        const size_t i1 = fd_chain_image_bytes(iv.hid, iv.cb), i2 = fd_chain_image_bytes(cz, iv.cb);
+        for (int h = 0; h < 2; ++h)
+          if ((rc = fd_chain_build_image16(P + k.et_init.w, iv.cb, cs, cs, cs, h, D + c.ei16[h], st)) ||
+              (rc = fd_chain_build_image16(P + k.et1.w + cz, iv.hid, iv.cb, iv.cb, iv.hid, h, D + c.r416[h], st)) ||
+              (rc = fd_chain_build_image16(P + k.etf.w + cz, cz, iv.cb, iv.cb, iv.hid, h, D + c.r416[h] + i1, st)) ||
+              (rc = fd_chain_build_image16(P + k.et1.w + cz + iv.cb, iv.hid, iv.cb, iv.cb, iv.hid, h, D + c.r416[h] + i1 + i2, st)) ||
+              (rc = fd_chain_build_image16(P + k.etf.w + cz + iv.cb, cz, iv.cb, iv.cb, iv.hid, h, D + c.r416[h] + 2 * i1 + i2, st)))
+            return rc;
       }
       if (b < d->num_blocks - 1) {  // EdgeTransition per-residue rows: initial_embed and the e_i / e_j columns of the first / final layers
         const size_t i1 = fd_chain_image_bytes(iv.hid, iv.cb), i2 = fd_chain_image_bytes(cz, iv.cb);
@@ -939,6 +952,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     const BlockW& k = iv.blk[b];
     const DBlock& db = L.blk[b];
     const int PT = iv.proj_out - 3 * H * C, Np = (N + 31) / 32 * 32;
+    bool etr_done = false;  // EdgeTransition's row launch folded into the transition launch of this block
     // IPA + node path of the block (everything up to the frame update)
     auto trunk = [&]() -> int {
     Attn3Args a3;
@@ -1215,6 +1229,19 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       if (split_trans && tail16_shapes(d, iv) && !sw.no_tail16) {  // 16-row blocks (rowblock.hip: transition16_kernel)
         r.w0 = D + db.lo.tr16[0][0]; r.w1 = D + db.lo.tr16[1][0]; r.w2 = D + db.lo.tr16[2][0];
         r.w0l = D + db.lo.tr16[0][1]; r.w1l = D + db.lo.tr16[1][1]; r.w2l = D + db.lo.tr16[2][1];
+        // EdgeTransition's row launch (e = initial_embed(node), fold columns -> edge_transition4's images) folded into this launch: the
+        // rows it needs are this launch's output rows (same conditions as the `use_et4` row launch below, which is then skipped)
+        if (op.kind == OP_ALL && b < d->num_blocks - 1 && iv.cb == 128 && iv.hid == 384 && cz == 128 && use_regpair(d) && !sw.et3 &&
+            fd_edge_transition4_supported(N) && split_etrows && !sw.et4_rows_unfused) {
+          r.we0 = D + db.lo.ei16[0]; r.we0l = D + db.lo.ei16[1]; r.we1 = D + db.lo.r416[0]; r.we1l = D + db.lo.r416[1];
+          r.be0 = P + k.et_init.b; r.be1 = (const float*)(D + db.ch.r4b);
+          r.img_a = W + w.a1img; r.img_b = W + w.b1img; r.img_B = B; r.img_N = N;
+          if (warm_all) {  // its own later-stage images (hi run, lo run) instead of the row launch's
+            const unsigned run = (unsigned)(fd_chain_image_bytes(iv.cb, cs) + fd_chain_image_bytes(2 * (iv.hid + cz), iv.cb));
+            r.warm = L2Warm{{D + db.lo.ei16[0], D + db.lo.ei16[1], nullptr}, {run, run, 0}};
+          }
+          etr_done = true;
+        }
         RC(fd_transition16(r, st));
       } else
       RC(fd_rowblock(split_trans ? FD_RB_TRANSITION_BB_SPLIT : FD_RB_TRANSITION_BB, r, st));
@@ -1262,7 +1289,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       const bool reg_ok = rbk && iv.cb == 128 && iv.hid == 384 && cz == 128 && use_regpair(d);
       const bool use_et4 = reg_ok && !sw.et3 && fd_edge_transition4_supported(N);
       const bool use_et3 = reg_ok && !use_et4 && fd_edge_transition3_supported(N);
-      if (use_et4) {
+      if (use_et4 && etr_done) {
+        // (the fold-fragment images were written by the transition launch)
+      } else if (use_et4) {
         RowBlockArgs r;
         r.M = R; r.in = node_cur; r.ld_in = cs; r.w0 = D + db.ch.et_init; r.b0 = P + k.et_init.b; r.w1 = D + db.ch.r4w;
         r.b1 = (const float*)(D + db.ch.r4b); r.w2 = nullptr; r.b2 = nullptr; r.residual = nullptr; r.ld_res = 0; r.gamma = r.beta = nullptr;

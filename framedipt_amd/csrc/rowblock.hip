@@ -1040,7 +1040,12 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
 // but the last); LN: LayerNorm on the output; BB: BackboneUpdate + compose.  <8, 3, true, true> = the transition, <3, 3, true, false> = the node
 // embedder (72 / 88 input features), <8, 2, false, false> = the torsion head's residual block.
 // SKIP: one more 256 -> 256 layer (w3 / w3l / b3) on the output rows -> out2.
-template <int KS0, int NL, bool LN, bool BB, bool SKIP = false>
+// ETR: the EdgeTransition row launch folded in (RowBlockArgs.we0 ...): two more stages on the output rows — e = initial_embed(row)
+// (256 -> 128, transposed products like the stages above) and its 1024 fold columns (128 -> 1024) with the MFMA operands exchanged
+// (lane = output column, registers = four consecutive rows: 8 B pieces of edge_transition4's fold-fragment images, the layout
+// rowblock_kernel's IMG epilogue writes from 32-row tiles).  Saves the launch of rowblock_kernel<256,128,0,1024,IMG> (16 us at 2400
+// rows, three times per forward) for ~0.65 MB more weight fragments per block.
+template <int KS0, int NL, bool LN, bool BB, bool SKIP = false, bool ETR = false>
 __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, int k0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;
@@ -1224,8 +1229,8 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
       }
     }
   }
-  if constexpr (SKIP) {  // skip_embed of every trunk block on the rows just produced (they never leave the CU for it)
-    w_load(B0, K8C, a.w3, a.w3l, wave);
+  if constexpr (SKIP || ETR) {  // skip_embed of every trunk block (SKIP) / initial_embed of EdgeTransition (ETR) on the rows just produced (they never leave the CU for it)
+    w_load(B0, K8C, SKIP ? a.w3 : a.we0, SKIP ? a.w3l : a.we0l, wave);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int f0 = 16 * (wave + 4 * u) + 4 * fg;
@@ -1236,6 +1241,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
     }
     __syncthreads();
     x_load(K8C, hs);
+    if constexpr (SKIP) {
     layer(K8C, a.w3, a.w3l);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1246,6 +1252,86 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
       for (int i = 0; i < 4; ++i) o[i] = acc[u][i] + bv[i];
       if (row0 + lr < a.M) *(f32x4*)(a.out2 + (long)(row0 + lr) * a.ld_out2 + f0) = o;
     }
+    }
+  }
+  if constexpr (ETR) {
+    // ---- stage E1: e = initial_embed(out row), 128 features = 8 tiles of 16: tiles wave and wave + 4 (first fragments requested above)
+    f32x4 ea[2];
+    ch_rb_for<2>([&](auto U) {
+      constexpr int u = decltype(U)::value;
+      const int T = wave + 4 * u;
+      if constexpr (u == 0) w_load(B1, K8C, a.we0, a.we0l, T + 4);
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < TR_KS; ++s) c = mma(Wh[u][s], X[s], c);
+      {
+        hx8 xr[3];
+        xr[0] = rb_ld(xl_base);
+        xr[1] = rb_ld(xl_base + 64);
+#pragma unroll
+        for (int s = 0; s < TR_KS; ++s) {
+          if (s + 2 < TR_KS) xr[(s + 2) % 3] = rb_ld(xl_base + 64 * (s + 2));
+          c = mma(Wh[u][s], xr[s % 3], c);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < TR_KS; ++s) c = mma(Wl[u][s], X[s], c);
+      ea[u] = c;
+    });
+    constexpr std::integral_constant<int, 4> K4C{};
+    // fold-tile fragments (4 hi + 4 lo per tile) travel through a ring of FOUR slots — slot j = half (j >> 1) of buffer (j & 1) —
+    // three tiles ahead of their use: with one tile ahead (8 KB per wave in flight) the stage ran at 40 B/clk of the CU's L2 path
+    auto e2_load = [&](auto J, int T) {
+      constexpr int j = decltype(J)::value, b = j & 1, h = j >> 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Wh[b][4 * h + s] = rb_ld((const char*)a.we1 + ((size_t)(T * 4 + s) * 64 + lane) * 16);
+        Wl[b][4 * h + s] = rb_ld((const char*)a.we1l + ((size_t)(T * 4 + s) * 64 + lane) * 16);
+      }
+    };
+    e2_load(std::integral_constant<int, 2>{}, wave);       // (buffer halves 1: free since E1 used fragments 0..7 of both buffers — loaded
+    e2_load(std::integral_constant<int, 3>{}, wave + 4);   //  only after E1's products in program order)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f0 = 16 * (wave + 4 * u) + 4 * fg;
+      const f32x4 bv = *(const f32x4*)(a.be0 + f0);
+      put4(xs, lr * TR_XROW + 2 * f0, ea[u][0] + bv[0], ea[u][1] + bv[1], ea[u][2] + bv[2], ea[u][3] + bv[3]);  // (xs: dead since the last transition layer read it)
+    }
+    e2_load(std::integral_constant<int, 0>{}, wave + 8);
+    __syncthreads();
+    // ---- stage E2: fold columns, 64 tiles of 16: tiles wave + 4 u, operands exchanged: D[row 4 fg + i, column 16 T + lr]
+    x_load(K4C, xs);
+    const int NJ4 = a.img_N >> 2, r0 = row0 + 4 * fg;  // rows r0 .. r0 + 3 (M % 4 == 0: all four valid or none)
+    half_t* ia = (half_t*)a.img_a;
+    half_t* ib = (half_t*)a.img_b;
+    const int rb_ = r0 < a.M ? r0 / a.img_N : 0, jt_ = r0 < a.M ? (r0 - rb_ * a.img_N) >> 2 : 0;
+    float bvs[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bvs[u] = a.be1[16 * (wave + 4 * u) + lr];
+    ch_rb_for<16>([&](auto U) {
+      constexpr int u = decltype(U)::value, j = (u + 2) & 3, b = j & 1, h = j >> 1;  // tile u sits in slot (u + 2) % 4
+      const int T = wave + 4 * u;
+      if constexpr (u + 3 < 16) e2_load(std::integral_constant<int, (u + 5) & 3>{}, T + 12);  // the slot tile u - 1 has just left
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) c = mma(X[s], Wh[b][4 * h + s], c);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) c = mma(rb_ld(xl_base + 64 * s), Wh[b][4 * h + s], c);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) c = mma(X[s], Wl[b][4 * h + s], c);
+      const float bv = bvs[u];
+      const int T32 = T >> 1, f = 16 * (T & 1) + lr;
+      u16x4 o = {0, 0, 0, 0};
+      if (r0 < a.M) o = u16x4{f2h(c[0] + bv), f2h(c[1] + bv), f2h(c[2] + bv), f2h(c[3] + bv)};
+      if (T32 < 16) {
+        if ((r0 >> 3) < ((a.M + 7) >> 3)) *(u16x4*)(ia + ((((long)(r0 >> 3) * 16 + T32) * 32 + f) << 3) + (r0 & 4)) = o;  // (rows beyond M: zeros; the image is padded to 8 rows)
+      } else if (r0 < a.M) {
+        half_t* dst = ib + ((((long)rb_ * NJ4 + jt_) * 16 + (T32 - 16)) * 32 + f) * 8;
+        *(u16x4*)dst = o;
+        if (rb_ > 0) *(u16x4*)(dst - (long)NJ4 * 16 * 32 * 8 + 4) = o;
+        if (rb_ == a.img_B - 1) *(u16x4*)(dst + 4) = u16x4{0, 0, 0, 0};
+      }
+    });
   }
   if constexpr (!BB) {
     fd_l2_warm_done(warm_tok);
@@ -1288,15 +1374,15 @@ __global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, in
   fd_l2_warm_done(warm_tok);
 }
 // images w0 / w1 / w2 (+ lo): fd_chain_build_image16 (the first one with K padded to 32 KS0)
-template <int KS0, int NL, bool LN, bool BB, bool SKIP = false>
+template <int KS0, int NL, bool LN, bool BB, bool SKIP = false, bool ETR = false>
 static int mlp16_launch(const RowBlockArgs& a, int k0, hipStream_t st) {
   static FdPerDevice attr_dev;
   const int dev_ = fd_device();
   if (!attr_dev.get(dev_)) {
-    if (hipFuncSetAttribute((const void*)mlp16_kernel<KS0, NL, LN, BB, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)mlp16_kernel<KS0, NL, LN, BB, SKIP, ETR>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_SMEM) != hipSuccess) return FDIPT_ELAUNCH;
     attr_dev.set(dev_, 1);
   }
-  hipLaunchKernelGGL((mlp16_kernel<KS0, NL, LN, BB, SKIP>), dim3(cdiv(a.M, 16)), dim3(FD_THREADS), TR_SMEM, st, a, k0);
+  hipLaunchKernelGGL((mlp16_kernel<KS0, NL, LN, BB, SKIP, ETR>), dim3(cdiv(a.M, 16)), dim3(FD_THREADS), TR_SMEM, st, a, k0);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -1305,6 +1391,10 @@ int fd_transition16(const RowBlockArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.ld_in & 3) || (a.ld_res & 3) || (a.ld_out & 3) || !a.w0l || !a.w1l || !a.w2l || !a.residual || !a.gamma || !a.beta || !a.bb_w ||
       !a.bb_b || !a.quat || !a.trans)
     return FDIPT_EINVAL;
+  if (a.we0) {  // EdgeTransition rows folded in
+    if (!a.we0l || !a.we1 || !a.we1l || !a.be0 || !a.be1 || !a.img_a || !a.img_b || (a.img_N & 3) || a.M != a.img_B * a.img_N) return FDIPT_EINVAL;
+    return mlp16_launch<8, 3, true, true, false, true>(a, TR_D, st);
+  }
   return mlp16_launch<8, 3, true, true>(a, TR_D, st);
 }
 // FD_RB_NODE_EMBED_72 / 88_SPLIT (k0 input features, k0 % 4 == 0, k0 <= 96) and FD_RB_TORSION_SPLIT on 16-row blocks
