@@ -157,6 +157,39 @@ __device__ __forceinline__ void d_backbone_residue(long r, const float* Rb, cons
   }
 }
 
+// One atom of all_atom.compute_backbone: atom `at` (atom14 index) of residue type aa with frame (Rb, tbv) and psi = (s, co).  The same
+// expressions in the same order as d_backbone_residue evaluates for that atom (only the frames of its own group chain are built).
+__device__ __forceinline__ void d_backbone_atom(int at, int aa, float s, float co, const float* Rb, const float* tbv,
+                                                const BackboneTables* __restrict__ tb, float* p3) {
+  const int g = tb->group_idx[aa * 14 + at];
+  auto frame = [&](int gg, float* R, float* T) {
+    const float* d44 = tb->default_frames + (aa * 8 + gg) * 16;
+    float Rd[9], td[3], Ra[9];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Rd[i * 3 + j] = d44[i * 4 + j];
+      td[i] = d44[i * 4 + 3];
+    }
+    const float a0 = gg == 0 ? 0.f : s, a1 = gg == 0 ? 1.f : co;
+    Ra[0] = 1; Ra[1] = 0; Ra[2] = 0; Ra[3] = 0; Ra[4] = a1; Ra[5] = -a0; Ra[6] = 0; Ra[7] = a0; Ra[8] = a1;
+    const float z3[3] = {0.f, 0.f, 0.f};
+    d_compose(Rd, td, Ra, z3, R, T);
+  };
+  float FRg[9], FTg[3];
+  frame(g < 5 ? g : 4, FRg, FTg);
+  for (int gg = 5; gg <= g; ++gg) {  // chi2..chi4 chained onto chi1 (feats.py:204-212)
+    float Rc[9], Tc[3], Rn[9], Tn[3];
+    frame(gg, Rc, Tc);
+    d_compose(FRg, FTg, Rc, Tc, Rn, Tn);
+    for (int c = 0; c < 9; ++c) FRg[c] = Rn[c];
+    for (int c = 0; c < 3; ++c) FTg[c] = Tn[c];
+  }
+  float Rg[9], tg[3], p[3];
+  d_compose(Rb, tbv, FRg, FTg, Rg, tg);
+  d_rot_vec(Rg, tb->ideal_pos + (aa * 14 + at) * 3, p);
+  const float mk = tb->atom_mask[aa * 14 + at];
+  for (int c = 0; c < 3; ++c) p3[c] = (p[c] + tg[c]) * mk;
+}
+
 // ------------------------------------------------------------------ fused reverse step
 // grid (row blocks, samples): every block recomputes its sample's centre-of-mass sums (cheap: a few fused multiply-adds per
 // residue, the same summation order in every block), then takes rpb residues through the float64 SO(3) exp / log chain (a
@@ -346,6 +379,9 @@ struct ScoreTail {
   // so3.use_cached_score (so3_diffuser.py:389-396): the score norm is looked up instead of evaluated — table [B][n_omega] = the row
   // of _score_norms at each sample's t, edges [n_omega - 1] = discrete_omega[:-1]; index = torch.bucketize(omega, edges)
   const double *score_table = nullptr, *omega_edges = nullptr; int n_omega = 0;
+  // optional backbone atoms of the finished frames (all_atom.compute_backbone; replaces a backbone_kernel launch): the residue's 16
+  // lanes take one atom14 atom each
+  const int32_t* aatype = nullptr; const BackboneTables* tables = nullptr; float *atom37 = nullptr, *atom14 = nullptr;
 };
 __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t, int ld_t,
                                                                const float* __restrict__ quats_0, int ld_0,
@@ -451,6 +487,32 @@ __global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, con
     const float dm = 1.f - x.fixed_mask[r];
     x.psi[r * 2] = dm * (a / dn) + (1.f - dm) * x.gt_psi[r * 2];
     x.psi[r * 2 + 1] = dm * (bq / dn) + (1.f - dm) * x.gt_psi[r * 2 + 1];
+  }
+  if (x.tables && (x.atom37 || x.atom14)) {
+    // backbone atoms of the frame just assembled (quaternion = quats_0, translation = trans / cs, psi as lane 10 stores it): lane `sub`
+    // builds atom14 atom `sub`; atom37 = zeros except N, CA, C, CB, O (atom14 order N, CA, C, O, CB: all_atom.py:168-174)
+    if (x.atom37) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x.atom37[r * 111 + 15 + 6 * sub + c] = 0.f;
+    }
+    if (sub < 14) {
+      const float a = x.hid ? pa : x.psi_un[r * x.ld_psi], bq = x.hid ? pb : x.psi_un[r * x.ld_psi + 1];
+      const float dn = sqrtf(fmaxf(a * a + bq * bq, 1e-8f));
+      const float dm = 1.f - x.fixed_mask[r];
+      const float ps = dm * (a / dn) + (1.f - dm) * x.gt_psi[r * 2], pc = dm * (bq / dn) + (1.f - dm) * x.gt_psi[r * 2 + 1];
+      float Rb[9], tbv[3], p3[3];
+      d_quat_to_rot(quats_0 + r * ld_0, Rb);
+      for (int c = 0; c < 3; ++c) tbv[c] = x.trans[r * 3 + c] / x.cs;
+      int aa = x.aatype ? x.aatype[r] : 0;
+      if (aa == 20) aa = 0;
+      d_backbone_atom(sub, aa, ps, pc, Rb, tbv, x.tables, p3);
+      if (x.atom14)
+        for (int c = 0; c < 3; ++c) fd_st(x.atom14 + (r * 14 + sub) * 3 + c, p3[c]);
+      if (x.atom37 && sub < 5) {
+        const int slot = sub == 3 ? 4 : (sub == 4 ? 3 : sub);
+        for (int c = 0; c < 3; ++c) fd_st(x.atom37 + r * 111 + slot * 3 + c, p3[c]);
+      }
+    }
   }
 }
 
@@ -642,11 +704,13 @@ int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const 
                   int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
                   const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
                   float* ca_out, const float* hid, int ld_hid, int c_hid, const float* torf_w, const float* torf_b,
-                  const double* score_table, const double* omega_edges, int n_omega, hipStream_t st) {
+                  const double* score_table, const double* omega_edges, int n_omega, const int32_t* aatype, const void* bb_tables,
+                  float* atom37, float* atom14, hipStream_t st) {
   if (hid && ((c_hid & 3) || (ld_hid & 3))) return FDIPT_EINVAL;
   if (score_table && (!omega_edges || n_omega < 2)) return FDIPT_EINVAL;
+  if ((atom37 || atom14) && !bb_tables) return FDIPT_EINVAL;
   ScoreTail x = {trans, cs, psi_un, ld_psi, gt_psi, fixed_mask, t, min_b, max_b, rigids, psi, trans_score, ca_out,
-                 hid, torf_w, torf_b, ld_hid, c_hid, score_table, omega_edges, n_omega};
+                 hid, torf_w, torf_b, ld_hid, c_hid, score_table, omega_edges, n_omega, aatype, (const BackboneTables*)bb_tables, atom37, atom14};
   hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, st, B, N, rigids_t, 7,
                      quat, 4, sigma, res_mask, rot_score, x);
   FD_CHECK_LAUNCH();

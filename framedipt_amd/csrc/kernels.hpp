@@ -377,7 +377,8 @@ int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const 
                   int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
                   const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
                   float* ca_out, const float* hid, int ld_hid, int c_hid, const float* torf_w, const float* torf_b,
-                  const double* score_table, const double* omega_edges, int n_omega, hipStream_t st);
+                  const double* score_table, const double* omega_edges, int n_omega, const int32_t* aatype, const void* bb_tables,
+                  float* atom37, float* atom14, hipStream_t st);
 int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
                  const float* res_mask, double* score, hipStream_t st);
 int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,

@@ -1381,15 +1381,17 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // the last torsion layer (Linear(c_s, 2), fp32) rides on the score launch (FDIPT_TORF_UNFUSED: its own GEMM launch)
   const bool torf_fused = (cs & 3) == 0 && !sw.torf_unfused;
   if (!torf_fused) RC(lin32(R, iv.torf, F(w.h_b), cs, F(w.psi_un), 8));
-  // tensor_7 / psi epilogue, R^3 score and IGSO(3) score in one launch (frames.hip)
+  // tensor_7 / psi epilogue, R^3 score and IGSO(3) score in one launch (frames.hip); the backbone atoms of the finished frames ride on it
+  // (one atom per lane of a residue's 16) unless the launch folds are off
+  if ((a->atom37 || a->atom14) && !a->bb_tables) return FDIPT_EINVAL;
+  const bool bb_fold = (a->atom37 || a->atom14) && !sw.torf_unfused;
   RC(fd_score_tail(B, N, a->rigids_t, F(w.quat), F(w.trans), d->coordinate_scaling, F(w.psi_un), 8, a->gt_psi, a->fixed_mask,
                    res_mask, a->so3_sigma, a->t, d->r3_min_b, d->r3_max_b, a->rigids, a->psi, a->rot_score, a->trans_score,
                    a->ca_out, torf_fused ? F(w.h_b) : nullptr, cs, cs, P + iv.torf.w, P + iv.torf.b, a->so3_score_table,
-                   a->so3_omega_edges, a->so3_num_omega, st));
-  if (a->atom37 || a->atom14) {
-    if (!a->bb_tables) return FDIPT_EINVAL;
+                   a->so3_omega_edges, a->so3_num_omega, a->aatype, bb_fold ? a->bb_tables : nullptr, bb_fold ? a->atom37 : nullptr,
+                   bb_fold ? a->atom14 : nullptr, st));
+  if ((a->atom37 || a->atom14) && !bb_fold)
     RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));
-  }
   return FDIPT_OK;
 }
 
