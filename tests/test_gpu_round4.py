@@ -199,3 +199,25 @@ def test_run_sharded_inpainting_entry_two_ranks(tmp_path):
     some = next(f for f in trees[1] if f.endswith("sample_1_1.pdb"))
     text = trees[1][some].decode()
     assert text.startswith("MODEL     1") and text.rstrip().endswith("END") and "100.00" in text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["full_denovo_n64", "full_inpaint_n40"])
+def test_score_launch_atoms_equal_the_backbone_kernel(name):
+    """The forward's atom37 / atom14 (built on the score launch, one atom per lane: frames.hip d_backbone_atom) against the
+    stand-alone backbone kernel (`fdipt_backbone_atoms`, one residue per thread) on the forward's own frames and psi: the same
+    expressions in the same order, so the same bits; and the unfolded forward (FDIPT_KF_UNFOLDED: backbone_kernel launch)
+    agrees with both up to what its differently tiled EdgeTransition rows move the frames."""
+    from framedipt_amd import _lib
+    from framedipt_amd.inference import get_atom_positions_from_rigids
+    from framedipt_amd.model.score_network import preprocess_aatype
+    G = load_golden(f"fwd_{name}.npz")
+    net, _, conf = _net(name, G, "fp16")
+    feats = _feats(G)
+    out = net(feats)
+    aatype = preprocess_aatype(feats.get("aatype"), feats["fixed_mask"].to(torch.float32), net.inpainting, net._model_conf.input_aatype)
+    a37 = get_atom_positions_from_rigids(net, out["rigids"], out["psi"], aatype)
+    assert np.array_equal(a37, out["atom37"].cpu().numpy())
+    net_u, _, _ = _net(name, G, "fp16", _lib.KF_UNFOLDED)
+    out_u = net_u(feats)
+    np.testing.assert_allclose(out_u["atom37"].cpu().numpy(), out["atom37"].cpu().numpy(), atol=3e-3)
