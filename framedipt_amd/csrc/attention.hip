@@ -655,6 +655,16 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
       const size_t smem_sb = (size_t)128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + 64 + OM_PAD;
       hipLaunchKernelGGL((opair_mfma_kernel<20, OM_SB == 1 ? 4 : OM_SB, 1, true>), dim3(a.N, a.B), dim3(FD_THREADS), smem_sb, st, a, Np);
     } else if (a.N <= 320) hipLaunchKernelGGL((opair_mfma_kernel<20, 2>), dim3(a.N, a.B), dim3(FD_THREADS), smem, st, a, Np);
+#ifndef OM_SB_LONG
+#define OM_SB_LONG 1  // N > 320: the four-blocks-per-CU form in two to four passes of 320 keys (round 4, third session: 292 -> 258 us at N = 776, B = 8,
+                      // against <32, 2, 2>: two blocks per CU, 226 registers)
+#endif
+    else if (OM_SB_LONG) {  // (N <= 1024: fd_opair_mfma_eligible)
+      const size_t smem_sb = (size_t)128 * OM_ZROW + (size_t)8 * (Np * 2 + 16) + 64 + OM_PAD;
+      if (a.N <= 640) hipLaunchKernelGGL((opair_mfma_kernel<20, 4, 2, true>), dim3(a.N, a.B), dim3(FD_THREADS), smem_sb, st, a, Np);
+      else if (a.N <= 960) hipLaunchKernelGGL((opair_mfma_kernel<20, 4, 3, true>), dim3(a.N, a.B), dim3(FD_THREADS), smem_sb, st, a, Np);
+      else hipLaunchKernelGGL((opair_mfma_kernel<20, 4, 4, true>), dim3(a.N, a.B), dim3(FD_THREADS), smem_sb, st, a, Np);
+    }
 #ifndef OM_MID
 #define OM_MID 0
 #endif
