@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=48, help="with --streams > 1: CUs the persistent pair kernels leave to the other streams")
     ap.add_argument("--main-cus", type=int, default=0, help="experiment: run everything on a CU-masked stream with this many CUs (tools/cu_streams.py; HISTORY.md round 4)")
     ap.add_argument("--et-reserve", type=int, default=0, help="experiment: CUs the persistent pair kernels leave free (single stream)")
+    ap.add_argument("--eager", action="store_true", help="time the launch-by-launch loop (inference_fn(graph=False)) instead of the default "
+                    "step-graph replays: the host-enqueue-bound comparison line")
+    ap.add_argument("--graph-chunk", type=int, default=None, help="steps per replay of the chunk graph (inference.ReverseLoop.GRAPH_CHUNK)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches on this many HIP streams (same results; not the default: the "
                     "roofline kernel's launches are then sub-batch sized and rocprofv3 serialises the streams)")
     a = ap.parse_args()
@@ -239,6 +242,8 @@ def main():
     from framedipt_amd.sampler import ConditionalSampler, UnconditionalSampler
 
     lib = _lib.load()
+    if a.graph_chunk is not None:
+        inference.ReverseLoop.GRAPH_CHUNK = a.graph_chunk
     inp = cfg["inpaint"]
     conf = config.base_config(inpainting=inp)
     diff = SE3Diffuser(conf.diffuser, device=dev)
@@ -309,8 +314,10 @@ def main():
         steps = list(range(T)) if K == T else sorted({int(round(i * (T - 1) / max(K - 1, 1))) for i in range(K)})
         while len(steps) < K:  # (rounding collisions for K close to T)
             steps = sorted(set(steps) | {next(s for s in range(T) if s not in steps)})
-        # HIP events around every EdgeTransition launch of up to 16 of the timed steps (recorded on the launch stream by the library)
-        sampled = sorted({steps[int(round(i * (K - 1) / 15))] for i in range(16)}) if K > 1 else steps
+        # HIP events around every EdgeTransition launch of a few of the timed steps (recorded on the launch stream by the library):
+        # up to 16 of a whole trajectory, at most 4 when K <= 32
+        n_samp = min(K, 16 if K > 32 else 4)
+        sampled = sorted({steps[int(round(i * (K - 1) / max(n_samp - 1, 1)))] for i in range(n_samp)})
         events = {}
         for k in sampled:
             ev_s, ev_e = (C.c_void_p * nb)(), (C.c_void_p * nb)()
@@ -326,24 +333,44 @@ def main():
             warm.step(k)
         torch.cuda.synchronize()
         del warm
+        t_setup = time.perf_counter()
         loop = new_loop()
         st = loop.st
+        # in-kernel shader-clock probe of the EdgeTransition launches: opt-in, into a caller-owned buffer (FdiptForwardArgs.clock_out),
+        # only on the sampled steps the HIP events bracket
+        clk_dev = torch.zeros(3, dtype=torch.int64, device=dev)
+        # the product path (inference.ReverseLoop, graph=True): steps are replays of a HIP graph captured once per trajectory; the few
+        # event-bracketed steps are enqueued launch by launch through the same step cursor (HIP events recorded inside a graph cannot
+        # be timed on ROCm).  Captures happen here, before the timed region (nothing runs); their cost is reported as graph_capture_ms
+        graphed = streams == 1 and loop.graph and not a.eager
+        if graphed:
+            loop.prepare()
+        elif streams == 1:
+            loop.graph = False
+        setup_s = time.perf_counter() - t_setup
+
+        def bracket(k):
+            st.ev_start, st.ev_stop = events.get(k, (None, None))
+            st.clock_out = clk_dev if k in events else None
         if K < T:
             loop.prime()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        # in-kernel shader-clock probe of the EdgeTransition launches: opt-in, into a caller-owned buffer (FdiptForwardArgs.clock_out),
-        # only on the sampled steps the HIP events bracket
-        clk_dev = torch.zeros(3, dtype=torch.int64, device=dev)
         t0 = time.perf_counter()
-        if K == T:
-            loop.prime()
-        for k in steps:
-            st.ev_start, st.ev_stop = events.get(k, (None, None))
-            st.clock_out = clk_dev if k in events else None
-            loop.step(k)
+        if K == T and streams == 1:
+            loop.run(eager_steps=sampled, before_step=bracket)
+        else:
+            if K == T:
+                loop.prime()
+            for k in steps:
+                bracket(k)
+                if streams == 1:
+                    loop.step(k, eager=k in events)
+                else:
+                    loop.step(k)
+        host_s = time.perf_counter() - t0  # host time to enqueue the region (the GPU runs behind it)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         st.ev_start = st.ev_stop = st.clock_out = None
@@ -370,8 +397,10 @@ def main():
             el, d2h = float(tt[0].item()), (float(tt[1].item()) if d2h is not None else None)
             dist.barrier()
         B_ev = loop.loops[0].B if streams > 1 else B  # samples in the launches the events bracket (first sub-batch)
+        loop_info = argparse.Namespace(capture_seconds=getattr(loop, "capture_seconds", 0.0))
         del loop
-        return el, d2h, d2h_bytes, et_ms, (clk[0], clk[1]), B_ev
+        return el, d2h, d2h_bytes, et_ms, (clk[0], clk[1]), B_ev, {"graph": bool(graphed), "setup_ms": setup_s * 1e3, "host_enqueue_ms_per_step": host_s / K * 1e3,
+                                                              "graph_capture_ms": getattr(loop_info, "capture_seconds", 0.0) * 1e3}
 
     def record(prec, K, el, et_ms, clk, B_ev, kernel_flags, res_per_step=res_per_step, fwd_flops_per_step=fwd_flops_per_step, B=B):
         """value / ms_per_step / roofline of one timed region."""
@@ -405,7 +434,7 @@ def main():
                          "backbone RMSD vs the reference 1.7e-3 A worst / 4e-4 A median (teacher-forced, N=64, T=20: "
                          "tests/test_gpu_round4.py::test_bf16_build_per_step_numbers): outside the 1e-3 A parity bar, a comparison line only",
                  "fp32": "fp32 (v_mfma_f32_32x32x2_f32): the reference's arithmetic"}
-    el, d2h, d2h_bytes, et_ms, clk, B_ev = timed_region(net, prec, K, a.warmup, a.streams)
+    el, d2h, d2h_bytes, et_ms, clk, B_ev, loop_rec = timed_region(net, prec, K, a.warmup, a.streams)
     all_rec = None
     if (world == 1 and a.config == "c4" and prec != "fp32" and a.scaling == "weak" and not a.no_all_samples and a.streams == 1
             and a.n_res is None and a.total_samples > B):
@@ -416,7 +445,7 @@ def main():
         dsa = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": Ba}), diff, dev)
         feats_a, tape_a = sharding.stack_items([sharding.seeded_item(dsa, i, a.seed, diff, T, 0.01) for i in range(Ba)])
         Ka = min(a.all_samples_steps, T)
-        el_a, _, _, et_a, clk_a, Bev_a = timed_region(net, prec, Ka, 2, 1, feats=feats_a, tape=tape_a, B=Ba)
+        el_a, _, _, et_a, clk_a, Bev_a, _ = timed_region(net, prec, Ka, 2, 1, feats=feats_a, tape=tape_a, B=Ba)
         v_a, roof_a = record(prec, Ka, el_a, et_a, clk_a, Bev_a, a.kernel_flags, res_per_step=Ba * N,
                              fwd_flops_per_step=Ba * flops_per_forward(N, inp), B=Ba)
         all_rec = {"dtype": prec, "value": v_a, "unit": "residue*step/s", "samples_per_gpu": Ba, "steps": Ka, "warmup": 2, "ms_per_step": el_a / Ka * 1e3,
@@ -432,7 +461,7 @@ def main():
         torch.cuda.empty_cache()
         net32 = ScoreNetwork(conf.model, diff, inpainting=inp, precision="fp32", kernel_flags=a.kernel_flags).load_synthetic(7).to(dev)
         K32 = min(a.reference_steps, T)
-        el32, _, _, et32, clk32, Bev32 = timed_region(net32, "fp32", K32, 2, 1)
+        el32, _, _, et32, clk32, Bev32, _ = timed_region(net32, "fp32", K32, 2, 1)
         if rank == 0:
             v32, roof32 = record("fp32", K32, el32, et32, clk32, Bev32, a.kernel_flags)
             ref_rec = {"dtype": "fp32", "value": v32, "unit": "residue*step/s", "steps": K32, "warmup": 2, "ms_per_step": el32 / K32 * 1e3,
@@ -454,6 +483,9 @@ def main():
                        "n_res": N, "samples_per_gpu": B, "total_samples": n_total, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective" + (f", {a.streams} sub-batch streams per GPU" if a.streams > 1 else ""),
                        "precision_mode": PREC_MODE[prec], "kernel_flags": a.kernel_flags},
             "roofline": roof,
+            # how the timed steps were enqueued: replays of the step graph (the default product path, inference.ReverseLoop) or launch by
+            # launch (--eager); host time per step to enqueue them; set-up before the timed region (buffers, noise-tape upload, captures)
+            "loop": loop_rec,
         }
         if one_gpu:
             out["one_gpu_test_hook"] = True  # all ranks shared GPU 0 (tests): NOT a multi-GPU measurement
@@ -461,8 +493,13 @@ def main():
             out["results_d2h"] = {"seconds": d2h, "bytes": d2h_bytes, "value_including_d2h": res_per_step * K / (el + d2h)}
         if all_rec is not None:
             out["all_samples_one_gpu"] = all_rec
+            out.update({"all64_value": all_rec["value"], "all64_ms_per_step": all_rec["ms_per_step"],
+                        "all64_roofline_frac": all_rec["roofline"]["frac"], "all64_whole_forward_frac": all_rec["roofline"]["whole_forward_frac"]})
         if ref_rec is not None:
             out["reference_precision"] = ref_rec
+            out.update({"fp32_value": ref_rec["value"], "fp32_ms_per_step": ref_rec["ms_per_step"],
+                        "fp32_roofline_frac": ref_rec["roofline"]["frac"], "fp32_whole_forward_frac": ref_rec["roofline"]["whole_forward_frac"]})
+        out["whole_forward_frac"] = roof["whole_forward_frac"]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(300 if not inp else min(N, 300), config.base_config(), 7)
         print(json.dumps(out), flush=True)

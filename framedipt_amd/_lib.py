@@ -39,7 +39,16 @@ class ForwardArgs(C.Structure):
                           "t_emb", "t_emb_eps", "so3_sigma", "bb_tables", "psi", "rot_score", "trans_score", "rigids",
                           "atom37", "atom14", "trace_node", "trace_edge", "trace_inner")] + [
         ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)), ("ca_out", _P), ("reserve_cus", C.c_int32), ("clock_out", _P),
-                ("so3_score_table", _P), ("so3_omega_edges", _P), ("so3_num_omega", C.c_int32)]
+                ("so3_score_table", _P), ("so3_omega_edges", _P), ("so3_num_omega", C.c_int32), ("step_cursor", _P)]
+
+
+class ReverseIndexed(C.Structure):
+    """FdiptReverseIndexed (include/fdipt.h): one reverse step addressed through a device-side step cursor."""
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32)] + [(n, _P) for n in (
+        "rigid_traj", "rot_score", "trans_score", "diffuse_mask", "z_rot", "z_trans", "t_table")] + [
+        ("dt", C.c_double), ("noise_scale", C.c_double), ("center", C.c_int32), ("diffuse_rot", C.c_int32), ("diffuse_trans", C.c_int32)] + [
+        (n, C.c_double) for n in ("so3_min_sigma", "so3_max_sigma", "r3_min_b", "r3_max_b", "coordinate_scaling")] + [
+        (n, _P) for n in ("psi", "aatype", "bb_tables", "prot_traj", "pred_rigids", "traj_fixed_mask", "trans_traj", "step_cursor")]
 
 
 _lib = None
@@ -65,6 +74,8 @@ SIGNATURES = {
                                           _P, _P, _P, _P, _P]),
     "fdipt_se3_reverse_step_traj": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _d, _d, _d, _i, _i, _i, _d, _d, _d, _d, _d, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fdipt_se3_reverse_step_indexed": (_i, [C.POINTER(ReverseIndexed), _P]),
+    "fdipt_backbone_atoms_indexed": (_i, [_i, _P, _P, _P, _P, _P, _P, _P]),
     "fdipt_se3_forward_step": (_i, [_i, _i, _P, _P, _P, _P, _P, _d, _d, _d, _d, _d, _d, _d, _d, _P, _P, _P, _P]),
     "fdipt_se3_step_log_prob": (_i, [_i, _i, _P, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _d, _d, _d, _d, _P, _P]),
     "fdipt_se3_prior_log_prob": (_i, [_i, _i, _P, _P, _d, _P, _P]),

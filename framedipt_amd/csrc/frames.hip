@@ -216,6 +216,10 @@ struct ReverseArgs {
   const float* pred_rigids;   // [B,N,7] x_0 prediction of this step's forward
   const float* traj_fixed;    // [B,N] fixed_mask * res_mask
   float* trans_traj;          // [B,N,3]
+  // optional step cursor (fdipt_se3_reverse_step_indexed): rigids_t / z_* / atom37 / trans_traj are then bases of step-major arrays,
+  // the step's time is t_table[*cursor], x_{t-1} goes to the row behind x_t, and the last block to finish advances the cursor
+  int32_t* cursor = nullptr;       // [2]: step index, ticket of finished blocks
+  const double* t_table = nullptr;
 };
 
 __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a) {
@@ -223,6 +227,16 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
   __shared__ double com[4];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.N;
+  if (a.cursor) {
+    const long s = a.cursor[0], R = (long)a.B * N;
+    a.rigids_t += s * R * 7;
+    a.rigids_out += (s + 1) * R * 7;
+    a.z_rot += s * R * 3;
+    a.z_trans += s * R * 3;
+    a.t = a.t_table[s];
+    if (a.atom37) a.atom37 += s * R * 111;
+    if (a.trans_traj) a.trans_traj += s * R * 3;
+  }
   // schedules: so3_diffuser.py:299-319, r3_diffuser.py:48-85
   const double emax = exp(a.so3_max_sigma), emin = exp(a.so3_min_sigma);
   const double sig = log(a.t * emax + (1 - a.t) * emin);
@@ -347,6 +361,18 @@ __global__ __launch_bounds__(FD_THREADS) void reverse_step_kernel(ReverseArgs a)
       for (int c = 0; c < 3; ++c) fd_st(a.trans_traj + r * 3 + c, dm * a.pred_rigids[r * 7 + 4 + c] + fm * o[4 + c]);
     }
   }
+  if (a.cursor) {
+    // every block read the cursor before any block can get here; the last one to arrive moves it to the next step (the launches of
+    // that step are ordered behind this kernel by the stream / graph)
+    __syncthreads();
+    if (tid == 0) {
+      const int n_blocks = (int)(gridDim.x * gridDim.y);
+      if (atomicAdd(a.cursor + 1, 1) == n_blocks - 1) {
+        a.cursor[1] = 0;
+        atomicAdd(a.cursor, 1);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ IGSO(3) rotation score
@@ -382,13 +408,26 @@ struct ScoreTail {
   // optional backbone atoms of the finished frames (all_atom.compute_backbone; replaces a backbone_kernel launch): the residue's 16
   // lanes take one atom14 atom each
   const int32_t* aatype = nullptr; const BackboneTables* tables = nullptr; float *atom37 = nullptr, *atom14 = nullptr;
+  // optional step cursor (FdiptForwardArgs.step_cursor): x_t (tensor_7), sigma, t, the score-table rows and atom37 are then bases of
+  // step-major arrays, read / written at row *cursor
+  const int32_t* cursor = nullptr;
 };
-__global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t, int ld_t,
+__global__ __launch_bounds__(FD_THREADS) void rot_score_kernel(int B, int N, const float* __restrict__ quats_t_, int ld_t,
                                                                const float* __restrict__ quats_0, int ld_0,
-                                                               const double* __restrict__ sigma,
+                                                               const double* __restrict__ sigma_,
                                                                const float* __restrict__ res_mask,
                                                                double* __restrict__ score, ScoreTail x) {
   __shared__ double wtab[2][RS_L];
+  const float* __restrict__ quats_t = quats_t_;
+  const double* __restrict__ sigma = sigma_;
+  if (x.cursor) {
+    const long s = x.cursor[0];
+    quats_t += s * B * N * ld_t;
+    sigma += s * B;
+    x.t += s * B;
+    if (x.score_table) x.score_table += s * B * x.n_omega;
+    if (x.atom37) x.atom37 += s * B * N * 111;
+  }
   constexpr int RPB = FD_THREADS / RS_LANES;  // residues per block
   const long total = (long)B * N;
   const long r_first = (long)blockIdx.x * RPB;
@@ -539,9 +578,10 @@ __global__ void trans_score_kernel(int B, int N, const float* __restrict__ trans
 __global__ void backbone_kernel(int n, const float* __restrict__ t7, const float* __restrict__ rot,
                                 const float* __restrict__ trans, int ld_trans, const float* __restrict__ psi,
                                 const int32_t* __restrict__ aatype, const BackboneTables* __restrict__ tb,
-                                float* __restrict__ atom37, float* __restrict__ atom14) {
+                                float* __restrict__ atom37_, float* __restrict__ atom14, const int32_t* __restrict__ cursor) {
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
+  float* __restrict__ atom37 = (cursor && atom37_) ? atom37_ + (long)cursor[0] * n * 111 : atom37_;  // (step cursor: row *cursor)
   float Rb[9], tbv[3];
   if (rot) {
     for (int c = 0; c < 9; ++c) Rb[c] = rot[r * 9 + c];
@@ -580,19 +620,20 @@ int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int
 }
 
 // IpaScore.forward prologue (ipa_pytorch.py:516-524): split tensor_7, scale translations; diffuse_mask = (1-fixed)*res.
-__global__ void split_rigids_kernel(long n, const float* __restrict__ t7, float cs, const float* __restrict__ res_mask,
+__global__ void split_rigids_kernel(long n, const float* __restrict__ t7_, float cs, const float* __restrict__ res_mask,
                                     const float* __restrict__ fixed_mask, float* __restrict__ quat,
-                                    float* __restrict__ trans, float* __restrict__ diffuse_mask) {
+                                    float* __restrict__ trans, float* __restrict__ diffuse_mask, const int32_t* __restrict__ cursor) {
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
+  const float* __restrict__ t7 = cursor ? t7_ + (long)cursor[0] * n * 7 : t7_;  // (step cursor: row *cursor of a step-major array)
   for (int c = 0; c < 4; ++c) quat[r * 4 + c] = t7[r * 7 + c];
   for (int c = 0; c < 3; ++c) fd_st(trans + r * 3 + c, t7[r * 7 + 4 + c] * cs);
   diffuse_mask[r] = (1.f - fixed_mask[r]) * res_mask[r];
 }
 int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,
-                    float* trans, float* dmask, hipStream_t st) {
+                    float* trans, float* dmask, const int32_t* cursor, hipStream_t st) {
   hipLaunchKernelGGL(split_rigids_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, t7, cs, res_mask, fixed_mask, quat, trans,
-                     dmask);
+                     dmask, cursor);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -626,13 +667,20 @@ int fd_finish(long n, const float* quat, const float* trans, float cs, const flo
 struct FeatsExtra {  // optional work folded into the feature kernel's launch (nullptr to skip each part)
   const float *t7, *res_mask; float cs; float *quat, *trans, *dmask;  // split of x_t into quaternion / scaled translation
   const float *w1i, *w1j, *b1; int cz; float *pi, *pj;              // per-residue halves of the first edge-embedder layer
+  const int32_t* cursor;  // optional step cursor: t_emb and t7 are bases of step-major arrays, read at row *cursor
 };
 __global__ void build_feats_kernel(int B, int N, int use_aatype, int E, const int32_t* __restrict__ aatype,
-                                   const float* __restrict__ t_emb, const float* __restrict__ t_emb_eps,
+                                   const float* __restrict__ t_emb_, const float* __restrict__ t_emb_eps,
                                    const float* __restrict__ fixed_mask, const float* __restrict__ idx_emb,
                                    float* __restrict__ node_feat, int ld_node, float* __restrict__ pte, int ld_pte,
                                    FeatsExtra x) {
   __shared__ float pte_s[128];
+  const float* __restrict__ t_emb = t_emb_;
+  if (x.cursor) {
+    const long s = x.cursor[0];
+    t_emb += s * B * E;
+    if (x.t7) x.t7 += s * B * N * 7;
+  }
   const long r = blockIdx.x;
   const int b = (int)(r / N);
   const float fm = fixed_mask[r];
@@ -681,10 +729,10 @@ __global__ void build_feats_kernel(int B, int N, int use_aatype, int E, const in
 int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, const float* t_emb, const float* t_emb_eps,
                    const float* fixed_mask, const float* idx_emb, float* node_feat, int ld_node, float* pte, int ld_pte,
                    const float* t7, const float* res_mask, float cs, float* quat, float* trans, float* dmask, const float* w1i,
-                   const float* w1j, const float* b1, int cz, float* pi, float* pj, hipStream_t st) {
+                   const float* w1j, const float* b1, int cz, float* pi, float* pj, const int32_t* cursor, hipStream_t st) {
   if (use_aatype && (!aatype || !t_emb_eps)) return FDIPT_EINVAL;
   if (pi && (ld_pte > 128 || (ld_pte & 3))) return FDIPT_EINVAL;
-  FeatsExtra x = {t7, res_mask, cs, quat, trans, dmask, w1i, w1j, b1, cz, pi, pj};
+  FeatsExtra x = {t7, res_mask, cs, quat, trans, dmask, w1i, w1j, b1, cz, pi, pj, cursor};
   hipLaunchKernelGGL(build_feats_kernel, dim3(B * N), dim3(128), 0, st, B, N, use_aatype, E, aatype, t_emb, t_emb_eps,
                      fixed_mask, idx_emb, node_feat, ld_node, pte, ld_pte, x);
   FD_CHECK_LAUNCH();
@@ -705,12 +753,13 @@ int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const 
                   const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
                   float* ca_out, const float* hid, int ld_hid, int c_hid, const float* torf_w, const float* torf_b,
                   const double* score_table, const double* omega_edges, int n_omega, const int32_t* aatype, const void* bb_tables,
-                  float* atom37, float* atom14, hipStream_t st) {
+                  float* atom37, float* atom14, const int32_t* cursor, hipStream_t st) {
   if (hid && ((c_hid & 3) || (ld_hid & 3))) return FDIPT_EINVAL;
   if (score_table && (!omega_edges || n_omega < 2)) return FDIPT_EINVAL;
   if ((atom37 || atom14) && !bb_tables) return FDIPT_EINVAL;
   ScoreTail x = {trans, cs, psi_un, ld_psi, gt_psi, fixed_mask, t, min_b, max_b, rigids, psi, trans_score, ca_out,
-                 hid, torf_w, torf_b, ld_hid, c_hid, score_table, omega_edges, n_omega, aatype, (const BackboneTables*)bb_tables, atom37, atom14};
+                 hid, torf_w, torf_b, ld_hid, c_hid, score_table, omega_edges, n_omega, aatype, (const BackboneTables*)bb_tables, atom37, atom14,
+                 cursor};
   hipLaunchKernelGGL(rot_score_kernel, dim3(cdiv((long)B * N, FD_THREADS / RS_LANES)), dim3(FD_THREADS), 0, st, B, N, rigids_t, 7,
                      quat, 4, sigma, res_mask, rot_score, x);
   FD_CHECK_LAUNCH();
@@ -724,9 +773,9 @@ int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int
   return FDIPT_OK;
 }
 int fd_backbone(int n, const float* t7, const float* rot, const float* trans, int ld_trans, const float* psi,
-                const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st) {
+                const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st, const int32_t* cursor) {
   hipLaunchKernelGGL(backbone_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, n, t7, rot, trans, ld_trans, psi, aatype,
-                     (const BackboneTables*)tables, atom37, atom14);
+                     (const BackboneTables*)tables, atom37, atom14, cursor);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
@@ -983,6 +1032,21 @@ int fdipt_se3_reverse_step_traj(int B, int N, const float* rigids_t, const doubl
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+int fdipt_se3_reverse_step_indexed(const FdiptReverseIndexed* x, fdipt_stream_t stream) {
+  if (!x) return FDIPT_EINVAL;
+  if (x->B <= 0 || x->N <= 0) return FDIPT_OK;
+  if (!x->rigid_traj || !x->rot_score || !x->trans_score || !x->z_rot || !x->z_trans || !x->t_table || !x->step_cursor) return FDIPT_EINVAL;
+  if (x->prot_traj && (!x->psi || !x->bb_tables)) return FDIPT_EINVAL;
+  if (x->trans_traj && (!x->pred_rigids || !x->traj_fixed_mask)) return FDIPT_EINVAL;
+  ReverseArgs a = {x->B, x->N, x->rigid_traj, x->rot_score, x->trans_score, x->diffuse_mask, x->z_rot, x->z_trans, 0.0, x->dt,
+                   x->noise_scale, x->center, x->diffuse_rot, x->diffuse_trans, x->so3_min_sigma, x->so3_max_sigma, x->r3_min_b,
+                   x->r3_max_b, x->coordinate_scaling, x->rigid_traj, nullptr, 64, x->psi, x->aatype,
+                   (const BackboneTables*)x->bb_tables, x->prot_traj, x->pred_rigids, x->traj_fixed_mask, x->trans_traj,
+                   x->step_cursor, x->t_table};
+  hipLaunchKernelGGL(reverse_step_kernel, dim3(cdiv(x->N, 64), x->B), dim3(FD_THREADS), 0, (hipStream_t)stream, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 int fdipt_se3_reverse_step(int B, int N, const float* rigids_t, const double* rot_score, const float* trans_score,
                            const float* diffuse_mask, const double* z_rot, const double* z_trans, double t, double dt,
                            double noise_scale, int center, int diffuse_rot, int diffuse_trans, double so3_min_sigma,
@@ -1022,6 +1086,12 @@ int fdipt_backbone_atoms(int n, const float* t7, const float* rot, const float* 
   if (n <= 0) return FDIPT_OK;
   if ((!t7 && !(rot && trans)) || !psi || !tables) return FDIPT_EINVAL;
   return fd_backbone(n, t7, rot, trans, 3, psi, aatype, tables, atom37, atom14, (hipStream_t)s);
+}
+int fdipt_backbone_atoms_indexed(int n, const float* t7, const float* psi, const int32_t* aatype, const void* tables,
+                                 float* atom37_rows, const int32_t* step_cursor, fdipt_stream_t s) {
+  if (n <= 0) return FDIPT_OK;
+  if (!t7 || !psi || !tables || !atom37_rows || !step_cursor) return FDIPT_EINVAL;
+  return fd_backbone(n, t7, nullptr, nullptr, 3, psi, aatype, tables, atom37_rows, nullptr, (hipStream_t)s, step_cursor);
 }
 }  // extern "C"
 

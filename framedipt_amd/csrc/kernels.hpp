@@ -366,22 +366,23 @@ int fd_pair_bias_f32(long n_pairs, int H, int CZ, const float* z, const float* w
 int fd_points(const PointsArgs& a, hipStream_t st);
 int fd_compose_q_update(long n, float* quat, float* trans, const float* upd, int ld_upd, const float* mask, hipStream_t st);
 int fd_split_rigids(long n, const float* t7, float cs, const float* res_mask, const float* fixed_mask, float* quat,
-                    float* trans, float* dmask, hipStream_t st);
+                    float* trans, float* dmask, const int32_t* cursor, hipStream_t st);
 int fd_finish(long n, const float* quat, const float* trans, float cs, const float* psi_un, int ld_psi,
               const float* gt_psi, const float* fixed_mask, float* rigids, float* psi, hipStream_t st);
 int fd_build_feats(int B, int N, int use_aatype, int E, const int32_t* aatype, const float* t_emb, const float* t_emb_eps,
                    const float* fixed_mask, const float* idx_emb, float* node_feat, int ld_node, float* pte, int ld_pte,
                    const float* t7, const float* res_mask, float cs, float* quat, float* trans, float* dmask, const float* w1i,
-                   const float* w1j, const float* b1, int cz, float* pi, float* pj, hipStream_t st);
+                   const float* w1j, const float* b1, int cz, float* pi, float* pj, const int32_t* cursor, hipStream_t st);
 int fd_score_tail(int B, int N, const float* rigids_t, const float* quat, const float* trans, float cs, const float* psi_un,
                   int ld_psi, const float* gt_psi, const float* fixed_mask, const float* res_mask, const double* sigma,
                   const float* t, float min_b, float max_b, float* rigids, float* psi, double* rot_score, float* trans_score,
                   float* ca_out, const float* hid, int ld_hid, int c_hid, const float* torf_w, const float* torf_b,
                   const double* score_table, const double* omega_edges, int n_omega, const int32_t* aatype, const void* bb_tables,
-                  float* atom37, float* atom14, hipStream_t st);
+                  float* atom37, float* atom14, const int32_t* cursor, hipStream_t st);
 int fd_rot_score(int B, int N, const float* qt, int ld_t, const float* q0, int ld_0, const double* sigma,
                  const float* res_mask, double* score, hipStream_t st);
 int fd_trans_score(int B, int N, const float* tt, int ld_t, const float* t0, int ld_0, const float* t, float min_b,
                    float max_b, float cs, const float* res_mask, float* score, hipStream_t st);
 int fd_backbone(int n, const float* t7, const float* rot, const float* trans, int ld_trans, const float* psi,
-                const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st);
+                const int32_t* aatype, const void* tables, float* atom37, float* atom14, hipStream_t st,
+                const int32_t* cursor = nullptr);

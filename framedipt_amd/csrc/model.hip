@@ -853,7 +853,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   RC(fd_build_feats(B, N, d->use_aatype, E, a->aatype, a->t_emb, a->t_emb_eps, a->fixed_mask, a->idx_emb, F(w.node_feat),
                     L.kn_pad, F(w.pte), L.d1_pad, feats_fused ? a->rigids_t : nullptr, res_mask, d->coordinate_scaling, F(w.quat),
                     F(w.trans), F(w.dmask), (const float*)(D + L.w1i), (const float*)(D + L.w1j), (const float*)(D + L.b1), cz,
-                    feats_fused ? F(w.pi) : nullptr, F(w.pj), st));
+                    feats_fused ? F(w.pi) : nullptr, F(w.pj), a->step_cursor, st));
   if (rbk && (sw.rb_mask & 1u) && (L.kn_pad == 72 || L.kn_pad == 88)) {
     if (split_embed) { rb_l0 = D + L.lo_ne0; rb_l1 = D + L.lo_ne2; rb_l2 = D + L.lo_ne4; }
     const bool ne16 = split_embed && cs == 256 && iv.node_in <= 96 && !sw.no_tail16;  // 16-row blocks (rowblock.hip: mlp16_kernel)
@@ -918,7 +918,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // ---- IpaScore trunk (ipa_pytorch.py:509-551)
   if (!feats_fused && a->rigids_t)
     RC(fd_split_rigids(R, a->rigids_t, d->coordinate_scaling, res_mask, a->fixed_mask ? a->fixed_mask : res_mask, F(w.quat),
-                       F(w.trans), F(w.dmask), st));
+                       F(w.trans), F(w.dmask), a->step_cursor, st));
   const float* node_cur = F(w.node0);
   if (op.kind != OP_ALL) {  // per-op entry: the sub-module's inputs come from the caller
     if (!op.node_in) return FDIPT_EINVAL;
@@ -1389,9 +1389,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
                    res_mask, a->so3_sigma, a->t, d->r3_min_b, d->r3_max_b, a->rigids, a->psi, a->rot_score, a->trans_score,
                    a->ca_out, torf_fused ? F(w.h_b) : nullptr, cs, cs, P + iv.torf.w, P + iv.torf.b, a->so3_score_table,
                    a->so3_omega_edges, a->so3_num_omega, a->aatype, bb_fold ? a->bb_tables : nullptr, bb_fold ? a->atom37 : nullptr,
-                   bb_fold ? a->atom14 : nullptr, st));
+                   bb_fold ? a->atom14 : nullptr, a->step_cursor, st));
   if ((a->atom37 || a->atom14) && !bb_fold)
-    RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st));
+    RC(fd_backbone(R, a->rigids, nullptr, nullptr, 0, a->psi, a->aatype, a->bb_tables, a->atom37, a->atom14, st, a->step_cursor));
   return FDIPT_OK;
 }
 

@@ -1,11 +1,13 @@
 """Reverse-diffusion driver with the signature of ``experiments/utils.py:inference_fn`` (:511-626).
 
-Python drives the loop; every step is two C-ABI calls (score-network forward, fused SE(3) reverse step) plus the
-backbone-atom kernel, all enqueued on one HIP stream.  Nothing crosses to the host inside the loop: the state
-(x_t, self-conditioning CA, trajectories) stays in HBM and the noise tape / per-step scalars are uploaded up front
-(the reference does >= 5 device->host syncs per step, SURVEY.md section 0 finding 3).
+Python drives the loop; a step is two C-ABI calls (score-network forward, fused SE(3) reverse step) on one HIP stream, addressed
+through a device-side step cursor so that a step is captured once as a HIP graph and replayed (``ReverseLoop``).  Nothing
+crosses to the host inside the loop: the state (x_t, self-conditioning CA, trajectories) stays in HBM and the noise tape /
+per-step scalars are uploaded up front (the reference does >= 5 device->host syncs per step, SURVEY.md section 0 finding 3).
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import torch
@@ -49,10 +51,22 @@ def get_atom_positions_from_rigids(model, rigids, psi_torsions, aatype=None) -> 
 
 
 class ReverseLoop:
-    """Device-resident state of one batch of trajectories; ``prime()`` then ``step(k)`` for k = 0..num_t-1."""
+    """Device-resident state of one batch of trajectories; ``run()``, or ``prime()`` then ``step(k)`` for k = 0..num_t-1.
+
+    **Step graph (the default, ``graph=True``).**  Every reverse step but the last is the same ~70 kernel launches on different
+    rows of the trajectory arrays.  The library addresses those rows through a device-side step cursor
+    (``FdiptForwardArgs.step_cursor``, ``fdipt_se3_reverse_step_indexed``: the fused reverse step advances it), so the launch
+    arguments of a step do not depend on the step: the first noisy step is enqueued eagerly through the cursor (it also runs every
+    kernel once), the second one is captured as a HIP graph — and ``GRAPH_CHUNK`` consecutive steps as a second graph — and all
+    later steps are replays: one ``hipGraphLaunch`` per chunk instead of ~70 ``hipLaunchKernel`` + 3 ctypes calls per step
+    (1.4 ms of host work per 2.2 ms GPU step at N = 300, B = 8: a slower or busier host made the loop host-bound).  Same kernels,
+    same bits as the eager loop (``graph=False``; tests/test_gpu_round5.py)."""
+
+    GRAPH_CHUNK = 8  # steps per replay of the chunk graph (``run()``); single steps replay the one-step graph
 
     def __init__(self, model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
-                 noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None, state=None):
+                 noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None, state=None,
+                 graph=True):
         self.model, self.diffuser = model, diffuser
         dev = self.dev = model.device
         rig0 = data_init["rigids_t"]
@@ -87,12 +101,14 @@ class ReverseLoop:
         self.center, self.aux_traj, self.noise_scale = center, aux_traj, noise_scale
         self.self_condition, self.embed_sc = self_condition, embed_self_conditioning
         self.reverse_steps = np.linspace(min_t, 1.0, num_t)[::-1]
-        n_noisy = int(np.sum(self.reverse_steps > min_t))
+        # steps that take the reverse SDE step (t > min_t): a prefix of the schedule (it decreases to min_t)
+        n_noisy = self.n_noisy = int(np.sum(self.reverse_steps > min_t))
         t32, temb, sig = model.step_scalars(self.reverse_steps)
         with torch.cuda.device(dev):
             self.t_all = torch.as_tensor(np.repeat(t32[:, None], B, 1), device=dev)
             self.temb_all = torch.as_tensor(np.repeat(temb[:, None, :], B, 1), device=dev)
             self.sig_all = torch.as_tensor(np.repeat(sig[:, None], B, 1), device=dev)
+            self.t_tab = torch.as_tensor(np.ascontiguousarray(self.reverse_steps, dtype=np.float64), device=dev)
             so3 = diffuser._so3_diffuser
             self.tab_all = self.omega_edges = None
             if so3.use_cached_score:  # one row of the score-norm table per step (all samples of a batch share t)
@@ -103,22 +119,34 @@ class ReverseLoop:
                 noise_tape = draw_noise_tape(diffuser, n_noisy, B, N)
             self.z_rot = torch.as_tensor(np.ascontiguousarray(noise_tape[0], dtype=np.float64), device=dev)
             self.z_trans = torch.as_tensor(np.ascontiguousarray(noise_tape[1], dtype=np.float64), device=dev)
-            self.rigids_t = f32(rig0)
             self.sc_ca = f32(data_init["sc_ca_t"])
-            self.rigid_traj = torch.empty(num_t + 1, B, N, 7, device=dev)
-            self.rigid_traj[0] = self.rigids_t
+            self.rigid_traj = torch.empty(num_t + 1, B, N, 7, device=dev)  # row k = x_t of step k (row 0 = x_T), row k + 1 = its x_{t-1}
+            self.rigid_traj[0] = rig0.to(device=dev, dtype=torch.float32)
             self.prot_traj = torch.empty(num_t, B, N, 37, 3, device=dev)
             self.bb0_traj = torch.empty(num_t, B, N, 37, 3, device=dev) if aux_traj else None
             self.trans_traj = torch.empty(num_t, B, N, 3, device=dev) if aux_traj else None
-        self.noisy = 0
+            self.cursor = torch.zeros(2, dtype=torch.int32, device=dev)  # FdiptForwardArgs.step_cursor: {step index, ticket}
+        # step graph: needs the noise rows of step k at row k (any tape drawn for this schedule), and at least a few steps to pay for capture
+        self.graph = bool(graph) and n_noisy >= 3 and self.z_rot.shape[0] >= n_noisy and self.z_trans.shape[0] >= n_noisy
+        self._cursor_host = 0      # host mirror of cursor[0] (every writer of the cursor is ordered on this loop's stream)
+        self._g1 = self._gn = None  # captured one-step / GRAPH_CHUNK-step graphs
+        self.capture_seconds = 0.0
 
+    @property
+    def rigids_t(self):
+        """x_t of the next step to run (the row of the rigid trajectory the last finished step wrote)."""
+        return self.rigid_traj[self._next]
+
+    _next = 0
+
+    # ------------------------------------------------------------------ eager launches (pointers of step k on the host side)
     def _fwd(self, k, want_atoms, sc_update):
         # the forward itself hands the predicted CA positions to the next step's self-conditioning input (read at its start,
         # written at its end: no copy kernel)
         direct = want_atoms and self.bb0_from_forward
         self.st.score_table = None if self.tab_all is None else self.tab_all[k]
         self.st.omega_edges = self.omega_edges
-        self.st.forward(self.rigids_t, self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all[k],
+        self.st.forward(self.rigid_traj[k], self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all[k],
                         self.temb_all[k], self.sig_all[k], direct, ca_out=self.sc_ca if sc_update else None,
                         atom37_out=self.bb0_traj[k] if direct else None)  # rigid_0_traj row: straight into its slot
         if want_atoms and not direct:
@@ -130,27 +158,144 @@ class ReverseLoop:
             with torch.cuda.device(self.dev):
                 self._fwd(0, False, True)
 
-    def step(self, k):
-        """one_step_inference (utils.py:292-412) for reverse step k."""
+    def _step_eager(self, k):
         st, t, n = self.st, self.reverse_steps[k], self.B * self.N
+        self._fwd(k, self.aux_traj, self.embed_sc and t > self.min_t)
+        nxt = self.rigid_traj[k + 1]
+        if t > self.min_t:
+            # x_{t-1} lands in its trajectory slot, which is the next forward's input; its atom37 frame comes out of the
+            # same launch
+            self.diffuser.reverse_device(self.rigid_traj[k], st.rot_score, st.trans_score, self.diffuse_mask,
+                                         self.z_rot[k], self.z_trans[k], t, self.dt, self.center,
+                                         self.noise_scale, rigids_out=nxt,
+                                         atoms=(st.psi, self.aatype, self.model.bb_tables, self.prot_traj[k]),
+                                         traj=(st.rigids, self.fixed_mask, self.trans_traj[k]) if self.aux_traj else None)
+        else:  # last step: take the x_0 prediction, utils.py:373-374
+            nxt.copy_(st.rigids)
+            _backbone(self.model, n, nxt, None, None, st.psi, self.aatype, self.prot_traj[k])
+            if self.aux_traj:  # (on the other steps the reverse-step launch writes this row)
+                self.trans_traj[k] = self.diffuse_mask[..., None] * st.rigids[..., 4:] + self.fixed_mask[..., None] * nxt[..., 4:]
+
+    # ------------------------------------------------------------------ cursor-addressed launches (the same for every noisy step)
+    def _enqueue_indexed(self):
+        """One noisy step (forward, rigid_0_traj row, fused reverse step) on the rows ``cursor[0]`` of the trajectory arrays; the
+        reverse-step launch advances the cursor.  Nothing here depends on the step: this is what the step graphs hold."""
+        lib, st, d = _lib.load(), self.st, self.diffuser
+        direct = self.aux_traj and self.bb0_from_forward
+        st.score_table, st.omega_edges = self.tab_all, self.omega_edges
+        st.forward(self.rigid_traj, self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all, self.temb_all,
+                   self.sig_all, direct, ca_out=self.sc_ca if self.embed_sc else None, atom37_out=self.bb0_traj if direct else None,
+                   step_cursor=self.cursor)
+        if self.aux_traj and not direct:
+            _lib.check(lib.fdipt_backbone_atoms_indexed(self.B * self.N, _lib.ptr(st.rigids), _lib.ptr(st.psi), _lib.ptr(self.aatype),
+                                                        _lib.ptr(self.model.bb_tables), _lib.ptr(self.bb0_traj), _lib.ptr(self.cursor),
+                                                        _lib.stream_ptr()), "backbone_atoms_indexed")
+        so3, r3 = d._so3_diffuser, d._r3_diffuser
+        a = _lib.ReverseIndexed()
+        a.B, a.N = self.B, self.N
+        for name, tns in (("rigid_traj", self.rigid_traj), ("rot_score", st.rot_score), ("trans_score", st.trans_score),
+                          ("diffuse_mask", self.diffuse_mask), ("z_rot", self.z_rot), ("z_trans", self.z_trans), ("t_table", self.t_tab),
+                          ("psi", st.psi), ("aatype", self.aatype), ("bb_tables", self.model.bb_tables), ("prot_traj", self.prot_traj),
+                          ("pred_rigids", st.rigids if self.aux_traj else None), ("traj_fixed_mask", self.fixed_mask if self.aux_traj else None),
+                          ("trans_traj", self.trans_traj), ("step_cursor", self.cursor)):
+            setattr(a, name, _lib.ptr(tns))
+        a.dt, a.noise_scale = float(self.dt), float(self.noise_scale)
+        a.center, a.diffuse_rot, a.diffuse_trans = int(bool(self.center)), int(bool(d._diffuse_rot)), int(bool(d._diffuse_trans))
+        a.so3_min_sigma, a.so3_max_sigma, a.r3_min_b, a.r3_max_b = so3.min_sigma, so3.max_sigma, r3.min_b, r3.max_b
+        a.coordinate_scaling = r3._r3_conf.coordinate_scaling
+        _lib.check(lib.fdipt_se3_reverse_step_indexed(C.byref(a), _lib.stream_ptr()), "se3_reverse_step_indexed")
+
+    def capture_step_graph(self, n_steps=1):
+        """A HIP graph of ``n_steps`` consecutive cursor-addressed steps (nothing runs; whatever ``self.st`` carries — event pairs,
+        the clock probe — is captured with it).  Capture happens on a side stream: the caller's stream may be the null stream."""
+        import time
+        t0 = time.perf_counter()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=self.dev)
+        with torch.cuda.stream(side):
+            g.capture_begin(capture_error_mode="thread_local")
+            try:
+                for _ in range(n_steps):
+                    self._enqueue_indexed()
+            finally:
+                g.capture_end()
+        self.capture_seconds += time.perf_counter() - t0
+        return g
+
+    def _set_cursor(self, k):
+        if self._cursor_host != k:
+            self.cursor[:1].fill_(k)
+            self._cursor_host = k
+
+    # (device, precision, kernel flags, B, N) of the cursor-addressed steps that have run in this process: the kernels' lazy per-device
+    # set-up (raised dynamic-LDS caps) must not fall into a capture, so the first such step of a shape class is enqueued eagerly
+    _WARM: set = set()
+
+    def _warm_key(self):
+        d = self.model.dims
+        return (str(self.dev), int(d.precision), int(d.kernel_flags), self.B, self.N, bool(self.aux_traj), bool(self.bb0_from_forward))
+
+    def prepare(self):
+        """Capture the step graphs now (otherwise: lazily at the first replay).  Nothing runs on the GPU."""
+        if self.graph and self._warm_key() in self._WARM:
+            with torch.cuda.device(self.dev):
+                if self._g1 is None:
+                    self._g1 = self.capture_step_graph(1)
+                if self._gn is None and self.GRAPH_CHUNK > 1 and self.n_noisy >= 2 * self.GRAPH_CHUNK:
+                    self._gn = self.capture_step_graph(self.GRAPH_CHUNK)
+        return self
+
+    def _advance(self, k, n, eager=False):
+        """Steps k .. k+n-1 (all noisy) through the cursor: launch by launch the first time a shape class runs in the process (or with
+        ``eager``: bench.py's event-bracketed steps — events recorded inside a graph cannot be timed on ROCm), graph replays otherwise."""
+        self._set_cursor(k)
+        if eager or self._warm_key() not in self._WARM:
+            for _ in range(n):
+                self._enqueue_indexed()
+            self._WARM.add(self._warm_key())
+        elif n > 1 and n == self.GRAPH_CHUNK:
+            if self._gn is None:
+                self._gn = self.capture_step_graph(n)
+            self._gn.replay()
+        else:
+            if self._g1 is None:
+                self._g1 = self.capture_step_graph(1)
+            for _ in range(n):
+                self._g1.replay()
+        self._cursor_host = k + n
+
+    def step(self, k, eager=False):
+        """one_step_inference (utils.py:292-412) for reverse step k."""
         with torch.cuda.device(self.dev):
-            self._fwd(k, self.aux_traj, self.embed_sc and t > self.min_t)
-            nxt = self.rigid_traj[k + 1]
-            if t > self.min_t:
-                # x_{t-1} lands in its trajectory slot, which is the next forward's input; its atom37 frame comes out of the
-                # same launch
-                self.diffuser.reverse_device(self.rigids_t, st.rot_score, st.trans_score, self.diffuse_mask,
-                                             self.z_rot[self.noisy], self.z_trans[self.noisy], t, self.dt, self.center,
-                                             self.noise_scale, rigids_out=nxt,
-                                             atoms=(st.psi, self.aatype, self.model.bb_tables, self.prot_traj[k]),
-                                             traj=(st.rigids, self.fixed_mask, self.trans_traj[k]) if self.aux_traj else None)
-                self.noisy += 1
-            else:  # last step: take the x_0 prediction, utils.py:373-374
-                nxt.copy_(st.rigids)
-                _backbone(self.model, n, nxt, None, None, st.psi, self.aatype, self.prot_traj[k])
-                if self.aux_traj:  # (on the other steps the reverse-step launch writes this row)
-                    self.trans_traj[k] = self.diffuse_mask[..., None] * st.rigids[..., 4:] + self.fixed_mask[..., None] * nxt[..., 4:]
-            self.rigids_t = nxt
+            if self.graph and k < self.n_noisy:
+                self._advance(k, 1, eager)
+            else:
+                self._step_eager(k)
+        self._next = k + 1
+
+    def run(self, eager_steps=(), before_step=None):
+        """The whole trajectory: priming forward, then every step (graph replays, ``GRAPH_CHUNK`` steps at a time where that many noisy
+        steps remain).  ``eager_steps``: steps to enqueue launch by launch instead, ``before_step(k)`` called ahead of each of them and
+        ``before_step(None)`` behind it (bench.py: HIP events around the dominant kernel's launches of a few steps)."""
+        self.prime()
+        k, eager_steps = 0, set(eager_steps)
+        while k < self.num_t:
+            n = self.GRAPH_CHUNK
+            if (not self.graph or n < 2 or self.n_noisy - k < n or self._warm_key() not in self._WARM
+                    or any(kk in eager_steps for kk in range(k, k + n))):
+                n = 1
+            if n == 1:
+                if k in eager_steps and before_step is not None:
+                    before_step(k)
+                self.step(k, eager=k in eager_steps)
+                if k in eager_steps and before_step is not None:
+                    before_step(None)
+            else:
+                with torch.cuda.device(self.dev):
+                    self._advance(k, n)
+            k += n
+        self._next = self.num_t
+        return self
 
     def results(self, return_device=False):
         st = self.st
@@ -224,7 +369,7 @@ class StreamedLoops:
                 st = model.new_batch_state(sub["seq_idx"])
                 st.reserve_cus = reserve_cus if n_streams > 1 else 0  # the persistent pair kernels leave CUs to the other streams
                 self.loops.append(ReverseLoop(model, diffuser, sub, num_t, min_t, noise_tape=tuple(z[:, lo:hi] for z in noise_tape),
-                                              state=st, **kw))
+                                              state=st, graph=False, **kw))
         torch.cuda.synchronize(self.dev)  # set-up ran on the current stream
         self.st = self.loops[0].st
 
@@ -260,117 +405,24 @@ class StreamedLoops:
         return {k: cat([p[k] for p in parts]) for k in parts[0]}  # (every returned array carries the batch on axis 1)
 
 
-class GraphedTrajectory:
-    """A whole trajectory — priming forward + ``num_t`` reverse steps, ~70 kernel launches each — captured ONCE as a HIP graph and
-    replayed for every later batch of the same shape (``inference_fn(graph=True)``).
-
-    Today the step is kernel-bound (the host needs 1.45 ms to enqueue a 2.25 ms step at N = 300, B = 8: ``tools/graph_step.py``), so a
-    replay is not faster than the eager loop; the option exists so that the Python / ctypes enqueue cost (65 % of the GPU step) cannot
-    become the bound as the kernels get faster, and for hosts with slow or busy cores.  Everything a step touches lives in buffers of
-    the ``ReverseLoop`` this object owns (state, masks, noise tape, per-step scalars, trajectories), so a new batch is loaded by
-    copying its inputs INTO those buffers (``load``), never by rebinding them.  Same results as the eager loop, bit for bit
-    (tests/test_gpu_round4.py::test_graphed_trajectory_matches_the_eager_loop).  Capture needs every kernel of the trajectory to have
-    run once in the process (lazy per-device launch attributes): the first ``graph=True`` call of a shape therefore runs eagerly and the
-    second one captures."""
-
-    def __init__(self, model, diffuser, data_init, num_t, min_t, noise_tape, **kw):
-        self.dev = model.device
-        with torch.cuda.device(self.dev):
-            self.loop = lp = ReverseLoop(model, diffuser, data_init, num_t, min_t, noise_tape=noise_tape,
-                                         state=model.new_batch_state(data_init["seq_idx"]), **kw)
-            self.x_T = lp.rigids_t  # (the tensor the first step reads; ReverseLoop.step rebinds the attribute, not the buffer)
-            self.graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # (allocator warm-up for the few torch ops of the last step)
-                tmp = lp.diffuse_mask[..., None] * lp.st.rigids[..., 4:] + lp.fixed_mask[..., None] * lp.rigid_traj[1][..., 4:]
-                del tmp
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(self.graph):
-                lp.prime()
-                for k in range(num_t):
-                    lp.step(k)
-        self.replays = 0
-
-    def load(self, data_init, noise_tape):
-        """Copy a new batch's inputs into the captured buffers (same B, N, seq_idx, aatype presence as at capture)."""
-        lp, dev = self.loop, self.dev
-        f32 = lambda x: x.to(device=dev, dtype=torch.float32)  # noqa: E731
-        with torch.cuda.device(dev):
-            res_mask, fixed = f32(data_init["res_mask"]), f32(data_init["fixed_mask"])
-            lp.res_mask.copy_(res_mask)
-            lp.fixed.copy_(fixed)
-            lp.fixed_mask.copy_(fixed * res_mask)
-            lp.diffuse_mask.copy_((1 - fixed) * res_mask)
-            for mine, (inp, ia) in ((lp.aatype, (lp._inpainting, lp._input_aatype)),
-                                    (lp.net_aatype, (lp.model.inpainting, lp.model._model_conf.input_aatype))):
-                new = preprocess_aatype(data_init.get("aatype"), fixed, inp, ia)
-                if (mine is None) != (new is None):
-                    raise ValueError("graph replay: the batch differs from the captured one in whether residue types are given")
-                if mine is not None:
-                    mine.copy_(new.to(device=dev, dtype=torch.int32))
-            same = (lp.aatype is None and lp.net_aatype is None) or (
-                lp.aatype is not None and lp.net_aatype is not None and bool(torch.equal(lp.aatype, lp.net_aatype)))
-            if same != lp.bb0_from_forward:  # (decides whether rigid_0_traj rows come from the forward or from a backbone launch)
-                raise ValueError("graph replay: the batch differs from the captured one in how its x_0 backbone rows are built")
-            lp.gt_tors = data_init["torsion_angles_sin_cos"]
-            lp.gt_psi.copy_(f32(lp.gt_tors[..., 2, :]))
-            self.x_T.copy_(f32(data_init["rigids_t"]))
-            lp.rigid_traj[0].copy_(self.x_T)
-            lp.sc_ca.copy_(f32(data_init["sc_ca_t"]))
-            lp.z_rot.copy_(torch.as_tensor(np.ascontiguousarray(noise_tape[0], dtype=np.float64), device=dev))
-            lp.z_trans.copy_(torch.as_tensor(np.ascontiguousarray(noise_tape[1], dtype=np.float64), device=dev))
-
-    def run(self, data_init=None, noise_tape=None, return_device=False):
-        if data_init is not None:
-            self.load(data_init, noise_tape)
-        with torch.cuda.device(self.dev):
-            self.graph.replay()
-        self.replays += 1
-        return self.loop.results(return_device)
-
-
-def _graph_key(model, data_init, num_t, min_t, flags):
-    rig, seq = data_init["rigids_t"], data_init["seq_idx"]
-    return (tuple(rig.shape), seq.detach().cpu().numpy().tobytes(), int(num_t), float(min_t), data_init.get("aatype") is None) + tuple(flags)
-
-
 def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None,
-                 return_device=False, streams=1, experimental_streams=False, graph=False):
+                 return_device=False, streams=1, experimental_streams=False, graph=True):
     """Same arguments / returned keys as the reference.  ``noise_tape=(z_rot, z_trans)`` ([num_t-1,B,N,3] float64
     N(0,1) draws) overrides the global ``np.random`` stream (sample-sharded runs).  ``data_init`` tensors carry a
-    leading batch dimension B >= 1 (the reference always passes B = 1).  ``streams=n``: the batch runs as n sub-batches on n HIP
-    streams (same results; the latency-bound node path of one sub-batch overlaps the pair kernels of the other) — experimental: needs
-    ``experimental_streams=True`` (or FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``).
-    ``graph=True``: the trajectory of this shape is captured once as a HIP graph and replayed for later batches (``GraphedTrajectory``)."""
-    if graph:
-        # whole-trajectory HIP graph, cached per (model, shape, seq_idx, schedule, options): first call of a shape eager (it also runs every
-        # kernel once, which capture needs), second call captures, later calls replay
-        if streams > 1:
-            raise ValueError("graph=True replays one stream's launches: not combined with streams > 1")
-        if noise_tape is None:
-            n_noisy = int(np.sum(np.linspace(min_t, 1.0, num_t)[::-1] > min_t))
-            noise_tape = draw_noise_tape(diffuser, n_noisy, data_init["rigids_t"].shape[0], data_init["rigids_t"].shape[1])
-        cache = model.__dict__.setdefault("_graphed_trajectories", {})
-        key = _graph_key(model, data_init, num_t, min_t, (center, aux_traj, self_condition, float(noise_scale), embed_self_conditioning,
-                                                            inpainting, input_aatype, id(diffuser)))
-        if key in cache:
-            if cache[key] is None:
-                cache[key] = GraphedTrajectory(model, diffuser, data_init, num_t, min_t, noise_tape, center=center, aux_traj=aux_traj,
-                                               self_condition=self_condition, noise_scale=noise_scale,
-                                               embed_self_conditioning=embed_self_conditioning, inpainting=inpainting, input_aatype=input_aatype)
-                return cache[key].run(return_device=return_device)  # (captured on this very batch: its buffers hold it already)
-            return cache[key].run(data_init, noise_tape, return_device)
-        cache[key] = None  # (seen once: the next call of this shape captures)
+    leading batch dimension B >= 1 (the reference always passes B = 1).  ``graph=True`` (default): the steps are replays of a HIP
+    graph captured once per trajectory (``ReverseLoop``: same kernels and bits, ~1/70 of the host work); ``graph=False``: every step
+    enqueued launch by launch.  ``streams=n``: the batch runs as n sub-batches on n HIP streams (same results; the latency-bound
+    node path of one sub-batch overlaps the pair kernels of the other) — experimental: needs ``experimental_streams=True`` (or
+    FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``; eager launches)."""
     if streams > 1 and data_init["rigids_t"].shape[0] > 1:  # sub-batches on their own HIP streams (same results)
         loop = StreamedLoops(model, diffuser, data_init, streams, num_t, min_t, noise_tape=noise_tape, center=center, aux_traj=aux_traj,
                              self_condition=self_condition, noise_scale=noise_scale, embed_self_conditioning=embed_self_conditioning,
                              inpainting=inpainting, input_aatype=input_aatype, experimental=experimental_streams)
+        loop.prime()
+        for k in range(num_t):
+            loop.step(k)
     else:
         loop = ReverseLoop(model, diffuser, data_init, num_t, min_t, center, aux_traj, self_condition, noise_scale,
-                           embed_self_conditioning, inpainting, input_aatype, noise_tape)
-    loop.prime()
-    for k in range(num_t):
-        loop.step(k)
+                           embed_self_conditioning, inpainting, input_aatype, noise_tape, graph=graph).run()
     return loop.results(return_device)

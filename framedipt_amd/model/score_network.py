@@ -84,9 +84,12 @@ class BatchState:
                                          device=dev)
 
     def forward(self, rigids_t, res_mask, fixed_mask, sc_ca_t, aatype, gt_psi, t_dev, t_emb_dev, sigma_dev,
-                want_atoms: bool = True, ca_out=None, atom37_out=None):
+                want_atoms: bool = True, ca_out=None, atom37_out=None, step_cursor=None):
         """All arguments are device tensors (float32 unless noted); outputs land in this state's buffers.
-        ``ca_out`` ([B,N,3], may be ``sc_ca_t`` itself) receives the predicted CA positions for the next step."""
+        ``ca_out`` ([B,N,3], may be ``sc_ca_t`` itself) receives the predicted CA positions for the next step.
+        ``step_cursor`` (device int32[2], FdiptForwardArgs.step_cursor): ``rigids_t``, ``t_dev``, ``t_emb_dev``, ``sigma_dev``,
+        ``self.score_table`` and ``atom37_out`` are then the step-major arrays of a trajectory and the kernels use row
+        ``step_cursor[0]`` of each — the launch arguments no longer depend on the step (``inference.ReverseLoop``'s step graph)."""
         lib = _lib.load()
         net = self.net
         a = _lib.ForwardArgs()
@@ -103,6 +106,7 @@ class BatchState:
         if self.ev_start is not None:
             a.ev_start, a.ev_stop = self.ev_start, self.ev_stop
         a.reserve_cus = self.reserve_cus
+        a.step_cursor = _lib.ptr(step_cursor)
         a.clock_out = _lib.ptr(self.clock_out)
         if self.score_table is not None:
             a.so3_score_table, a.so3_omega_edges = _lib.ptr(self.score_table), _lib.ptr(self.omega_edges)
@@ -186,6 +190,9 @@ class ScoreNetwork:
             _lib.check(lib.fdipt_model_prepare(C.byref(self.dims), _lib.ptr(self.params), _lib.ptr(self.derived),
                                                _lib.stream_ptr()), "model_prepare")
         self._state = None
+        # captured HIP graphs (inference.GraphedTrajectory) bake the old weight / derived-buffer pointers in: drop them
+        self.__dict__.pop("_graphed_trajectories", None)
+        self.weights_version = getattr(self, "weights_version", 0) + 1
 
     # ------------------------------------------------------------------ batch state
     def batch_state(self, seq_idx: torch.Tensor, trace: bool = False, trace_inner: bool = False) -> BatchState:

@@ -11,8 +11,8 @@
  *     are independent, and so are calls on different streams of one device as long as they share no output / workspace buffer
  *     (forwards of TWO sub-batches may be in flight together: FdiptForwardArgs.reserve_cus; verified bit-identical to the
  *     sequential result in long soaks for two streams, NOT for three or more — DESIGN.md section 5 — so the Python host
- *     refuses more than two).  No device-side state survives a call; the only atomics (the optional clock probe) target a
- *     caller-owned buffer.
+ *     refuses more than two).  No device-side state survives a call outside caller-owned buffers; the only atomics
+ *     (the optional clock probe, the optional step cursor of the device-resident loop) target a caller-owned buffer.
  *   - all pointers are DEVICE pointers unless the name ends in _host; the caller (PyTorch) owns
  *     every buffer, including the workspace (query sizes with the *_bytes functions).
  *   - layouts are row-major contiguous, residue-major.  Quaternions are scalar-first (w,x,y,z);
@@ -163,6 +163,14 @@ typedef struct FdiptForwardArgs {
   const double* so3_score_table;
   const double* so3_omega_edges;
   int32_t so3_num_omega;
+  /* optional: step cursor of a device-resident reverse loop (experiments/utils.py:584-602, the `for t in reverse_steps` loop).
+   * NULL (the default): every pointer above is what its comment says.  Non-NULL: a device int32[2] = { step index k, ticket }, and
+   * the per-step inputs / outputs are BASES of step-major arrays of which the kernels read / write row k = step_cursor[0]:
+   *   rigids_t [T+1,B,N,7] (x_t of step k = row k: the rigid trajectory itself), t [T,B], t_emb [T,B,index_embed], so3_sigma [T,B],
+   *   so3_score_table [T,B,so3_num_omega], atom37 [T,B,N,37,3] (rigid_0_traj).
+   * The launch sequence then does not depend on k: a step (this forward + fdipt_se3_reverse_step_indexed, which advances the
+   * cursor) can be captured once as a HIP graph and replayed for every step of every trajectory of the shape. */
+  const int32_t* step_cursor;
 } FdiptForwardArgs;
 
 size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N);
@@ -227,6 +235,38 @@ int fdipt_se3_reverse_step_traj(int B, int N, const float* rigids_t, const doubl
                                 float* rigids_out, float* out_rot, const float* psi, const int32_t* aatype,
                                 const void* tables, float* atom37, const float* pred_rigids, const float* traj_fixed_mask,
                                 float* trans_traj, fdipt_stream_t stream);
+
+/* The same fused step (reverse + backbone frame + trans_traj row) of a device-resident loop, addressed through a step cursor:
+ * one step k = step_cursor[0] of the `for t in reverse_steps` loop (experiments/utils.py:584-602 -> one_step_inference :292-412).
+ * Reads x_t = rigid_traj[k], writes x_{t-1} = rigid_traj[k+1], prot_traj[k], trans_traj[k]; uses z_rot[k], z_trans[k],
+ * t = t_table[k]; the last block to finish sets step_cursor[0] = k + 1 (step_cursor[1] is its ticket, 0 between launches).  The
+ * launch arguments do not depend on k, so a captured HIP graph of a step replays for every k. */
+typedef struct FdiptReverseIndexed {
+  int32_t B, N;
+  float* rigid_traj;             /* [T+1,B,N,7] f32: row 0 = x_T */
+  const double* rot_score;       /* [B,N,3] f64 (the forward's output buffer) */
+  const float* trans_score;      /* [B,N,3] f32 */
+  const float* diffuse_mask;     /* [B,N] f32 or NULL */
+  const double* z_rot;           /* [T-1,B,N,3] f64 N(0,1) */
+  const double* z_trans;         /* [T-1,B,N,3] f64 N(0,1) */
+  const double* t_table;         /* [T] f64: reverse_steps (device) */
+  double dt, noise_scale;
+  int32_t center, diffuse_rot, diffuse_trans;
+  double so3_min_sigma, so3_max_sigma, r3_min_b, r3_max_b, coordinate_scaling;
+  const float* psi;              /* [B,N,2] f32 (forward output) */
+  const int32_t* aatype;         /* [B,N] i32 or NULL */
+  const void* bb_tables;
+  float* prot_traj;              /* [T,B,N,37,3] f32 or NULL */
+  const float* pred_rigids;      /* [B,N,7] f32 (forward output) */
+  const float* traj_fixed_mask;  /* [B,N] f32 */
+  float* trans_traj;             /* [T,B,N,3] f32 or NULL */
+  int32_t* step_cursor;          /* device int32[2] */
+} FdiptReverseIndexed;
+int fdipt_se3_reverse_step_indexed(const FdiptReverseIndexed* args, fdipt_stream_t stream);
+/* compute_backbone of n = B*N frames (tensor_7) into row step_cursor[0] of atom37_rows [T,n,37,3] (rigid_0_traj rows built with the
+ * caller's aatype view, experiments/utils.py:397-402). */
+int fdipt_backbone_atoms_indexed(int n, const float* t7, const float* psi, const int32_t* aatype, const void* tables,
+                                 float* atom37_rows, const int32_t* step_cursor, fdipt_stream_t s);
 
 /* ---------------------------------------------------------------- EigenFold confidence score (f4) */
 /* SE3Diffuser.forward: one-step forward noising q(x_t | x_{t-1}) (framedipt/diffusion/se3_diffuser.py:50-95; r3_diffuser.py:122-161

@@ -1,6 +1,6 @@
 """GPU parity tests (-m gpu) added in round 4: the benchmarked batch (B = 8, N = 300) in the parity suite, the fp16 margin at a second
 weight seed and at bb_gain 0.5 (tests/golden/make_goldens_r4.py), per-step numbers of the literal bf16 build, the attention's
-fp16 hi / lo point logits against an fp32 evaluation of the reference formula, whole-trajectory HIP graphs."""
+fp16 hi / lo point logits against an fp32 evaluation of the reference formula (the HIP-graph tests moved to test_gpu_round5.py)."""
 import os
 import subprocess
 import sys
@@ -126,33 +126,6 @@ def test_attention_point_logits_hi_lo_against_fp32_formula():
     rel = float((out - out32).norm() / out32.norm())
     print(f"IPA module, block 0, N = 300, 100 A wide structure: fp16 mode (hi / lo point logits) vs fp32 mode, relative {rel:.2e}")
     assert rel < 1e-3
-
-
-def test_graphed_trajectory_matches_the_eager_loop():
-    """inference_fn(graph=True): the first call of a shape runs eagerly, the second captures the whole trajectory (priming forward + every
-    reverse step) as ONE HIP graph, later calls load their inputs into the captured buffers and replay — every returned array equal to the
-    eager loop's, bit for bit, for three different batches."""
-    from framedipt_amd import config, sharding
-    from framedipt_amd.diffusion import SE3Diffuser
-    from framedipt_amd.inference import GraphedTrajectory, inference_fn
-    from framedipt_amd.model import ScoreNetwork
-    from framedipt_amd.sampler import UnconditionalSampler
-    N, B, T = 64, 2, 6
-    conf = config.base_config()
-    d = SE3Diffuser(conf.diffuser, device="cuda")
-    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
-    ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": 3 * B}), d, "cuda")
-    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1)
-    for rnd in range(3):
-        feats, tape = sharding.stack_items([sharding.seeded_item(ds, rnd * B + i, 5, d, T, 0.01) for i in range(B)])
-        ref = inference_fn(net, d, feats, noise_tape=tape, **kw)
-        got = inference_fn(net, d, feats, noise_tape=tape, graph=True, **kw)
-        assert sorted(ref) == sorted(got)
-        host = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)  # noqa: E731
-        for k in ref:
-            np.testing.assert_array_equal(host(ref[k]), host(got[k]), err_msg=f"round {rnd}: {k}")
-    cached = [g for g in net._graphed_trajectories.values() if isinstance(g, GraphedTrajectory)]
-    assert len(cached) == 1 and cached[0].replays == 2  # (call 2 captured + replayed, call 3 loaded + replayed)
 
 
 def test_run_sharded_inpainting_entry_two_ranks(tmp_path):

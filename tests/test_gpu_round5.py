@@ -1,0 +1,137 @@
+"""GPU parity tests (-m gpu) added in round 5: the step-cursor launches and the step graph of the reverse loop (the default product
+path) against the launch-by-launch loop, configs 3 and 5 at their own batch sizes, the N > 1024 attention fallback, the shared-GPU
+guard and the verify mode."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(v):
+    return v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+
+def _assert_same(ref, got, what=""):
+    assert sorted(ref) == sorted(got)
+    for k in ref:
+        np.testing.assert_array_equal(_host(ref[k]), _host(got[k]), err_msg=f"{what}: {k}")
+
+
+def _denovo_batch(N, B, T, precision, seed=5, cached_score=False):
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    conf = config.base_config()
+    if cached_score:
+        conf.diffuser.so3.use_cached_score = True
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision=precision).load_synthetic(7).to("cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": N, "max_length": N, "length_step": 1, "samples_per_length": B}), d, "cuda")
+    feats, tape = sharding.stack_items([sharding.seeded_item(ds, i, seed, d, T, 0.01) for i in range(B)])
+    return net, d, feats, tape
+
+
+@pytest.mark.parametrize("N,B,T,precision", [(64, 2, 12, "fp16"), (24, 1, 5, "fp32"), (300, 2, 11, "fp16")])
+def test_step_graph_equals_the_launch_by_launch_loop(N, B, T, precision):
+    """inference_fn's default path — first noisy step enqueued eagerly through the device-side step cursor, every later one a replay of
+    a captured HIP graph (one-step graph and GRAPH_CHUNK-step graph) — returns every array bit-identical to graph=False."""
+    from framedipt_amd.inference import ReverseLoop, inference_fn
+    net, d, feats, tape = _denovo_batch(N, B, T, precision)
+    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
+    ref = inference_fn(net, d, feats, graph=False, **kw)
+    got = inference_fn(net, d, feats, **kw)
+    _assert_same(ref, got, "run()")
+    # chunk graph of 4 steps + single-step replays for the remainder
+    old = ReverseLoop.GRAPH_CHUNK
+    try:
+        ReverseLoop.GRAPH_CHUNK = 4
+        loop = ReverseLoop(net, d, feats, T, 0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape).run()
+        assert loop._g1 is not None or loop._gn is not None
+        _assert_same(ref, loop.results(), "chunk of 4")
+    finally:
+        ReverseLoop.GRAPH_CHUNK = old
+    # aux_traj=False (no rigid_0_traj / trans_traj rows)
+    ref2 = inference_fn(net, d, feats, graph=False, num_t=T, min_t=0.01, noise_scale=0.1, noise_tape=tape)
+    got2 = inference_fn(net, d, feats, num_t=T, min_t=0.01, noise_scale=0.1, noise_tape=tape)
+    _assert_same(ref2, got2, "aux_traj=False")
+
+
+def test_step_graph_steps_out_of_order_and_twice():
+    """step(k) through the graph for k out of sequence (bench.py's K < T: timed steps spread over the schedule): the cursor is set on
+    the stream first; every step reads only row k and writes rows k / k + 1, so re-running a step reproduces its rows."""
+    from framedipt_amd.inference import ReverseLoop
+    T = 9
+    net, d, feats, tape = _denovo_batch(48, 2, T, "fp16")
+    kw = dict(aux_traj=True, noise_scale=0.1, noise_tape=tape)
+    ref = ReverseLoop(net, d, feats, T, 0.01, graph=False, **kw).run()
+    loop = ReverseLoop(net, d, feats, T, 0.01, **kw)
+    loop.prime()
+    for k in range(T):
+        loop.step(k)
+    # re-run steps 5 and 2 from the rows they read (x_t rows are still there); self-conditioning input = the previous step's CA prediction
+    for k in (5, 2):
+        loop.sc_ca.copy_(ref_sc(ref, k))
+        loop.step(k)
+        for name in ("rigid_traj", "prot_traj", "bb0_traj", "trans_traj"):
+            a, b = getattr(ref, name), getattr(loop, name)
+            assert torch.equal(a[k], b[k]), (k, name)
+        assert torch.equal(ref.rigid_traj[k + 1], loop.rigid_traj[k + 1])
+    assert int(loop.cursor[0]) == 3 and int(loop.cursor[1]) == 0
+
+
+def ref_sc(ref, k):
+    """Self-conditioning CA input of step k of a finished loop: the x_0 prediction of step k - 1 (its trans_traj row), or the priming
+    forward's for k = 0 (not reproduced here: k >= 1 only)."""
+    assert k >= 1
+    return ref.trans_traj[k - 1]  # (de novo: diffuse_mask = 1, so the row is the predicted translation itself)
+
+
+def test_step_graph_inpainting_rows_from_the_backbone_launch():
+    """The reference's default inpainting configuration (inference.input_aatype=True, model.input_aatype=False): rigid_0_traj rows come
+    from a backbone launch with the caller's residue types — in the step graph through fdipt_backbone_atoms_indexed."""
+    from framedipt_amd import config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.inference import ReverseLoop, draw_noise_tape
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import ConditionalSampler
+    import bench
+    conf = config.base_config(inpainting=True)
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, inpainting=True, precision="fp16").load_synthetic(7).to("cuda")
+    ds = ConditionalSampler.from_features([("synthetic", bench.synthetic_complex((30, 26), ((10, 22),)))], d, "cuda", samples=2)
+    from framedipt_amd import sharding
+    T = 8
+    feats, tape = sharding.stack_items([sharding.seeded_item(ds, i, 3, d, T, 0.01) for i in range(2)])
+    kw = dict(aux_traj=True, noise_scale=0.1, noise_tape=tape, inpainting=True, input_aatype=True)
+    ref = ReverseLoop(net, d, feats, T, 0.01, graph=False, **kw)
+    assert not ref.bb0_from_forward
+    got = ReverseLoop(net, d, feats, T, 0.01, **kw)
+    _assert_same(ref.run().results(), got.run().results(), "inpainting")
+
+
+def test_step_graph_with_the_cached_rotation_score_table():
+    """so3.use_cached_score: the per-step table rows are addressed through the cursor as well."""
+    from framedipt_amd.inference import inference_fn
+    T = 7
+    net, d, feats, tape = _denovo_batch(32, 2, T, "fp32", cached_score=True)
+    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
+    _assert_same(inference_fn(net, d, feats, graph=False, **kw), inference_fn(net, d, feats, **kw), "cached score")
+
+
+def test_weight_reload_between_trajectories():
+    """A graph holds weight pointers; graphs live in the ReverseLoop of one trajectory, so a reload between two inference_fn calls is
+    picked up (the round-4 whole-trajectory cache on the model is gone)."""
+    from framedipt_amd.inference import inference_fn
+    T = 6
+    net, d, feats, tape = _denovo_batch(32, 1, T, "fp16")
+    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
+    a = inference_fn(net, d, feats, **kw)
+    net.load_synthetic(11)
+    b = inference_fn(net, d, feats, **kw)
+    b_ref = inference_fn(net, d, feats, graph=False, **kw)
+    _assert_same(b_ref, b, "after reload")
+    assert not np.array_equal(a["prot_traj"], b["prot_traj"])
