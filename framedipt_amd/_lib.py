@@ -108,6 +108,7 @@ SIGNATURES = {
     "fdipt_event_record": (_i, [_P, _P]),
     "fdipt_event_elapsed_ms": (_i, [_P, _P, C.POINTER(_f)]),
     "fdipt_version": (C.c_char_p, []),
+    "fdipt_kernel_class_bounds": (_i, [C.POINTER(C.c_int32), _i]),
 }
 
 

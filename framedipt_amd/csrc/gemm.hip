@@ -742,5 +742,15 @@ int fdipt_selftest_mfma(int precision, double* max_err_host) {
 }
 
 const char* fdipt_version(void) { return "fdipt-hip 0.1 (gfx950)"; }
+// Lengths N at which the half-precision forward switches kernel variants (a sample padded within one class keeps its bits):
+// o_pair key passes at 320 / 640 / 960 (attention.hip: fd_opair), attention / sequence-attention key tiles per wave at 384 / 512 / 768
+// (attention3.hip: fd_attention3, attention_seq.hip: fd_seq_attention_run), 16-row node-path kernels up to 512 (model.hip), register
+// attention up to 1024.  framedipt_amd/sharding.py groups mixed-length batches by these classes; tests/test_host_cpu.py compares the lists.
+int fdipt_kernel_class_bounds(int32_t* bounds_host, int capacity) {
+  static const int32_t b[] = {320, 384, 512, 640, 768, 960, 1024};
+  const int n = (int)(sizeof(b) / sizeof(b[0]));
+  for (int i = 0; i < n && i < capacity; ++i) bounds_host[i] = b[i];
+  return n;
+}
 
 }  // extern "C"

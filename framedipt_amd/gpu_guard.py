@@ -1,0 +1,101 @@
+"""Shared-GPU guard.
+
+On the MI355X boxes this library was built on, two compute processes (or two HIP streams) whose kernels share a SIMD can corrupt each
+other's results: a wave that runs a half-precision MFMA next to lane-masked VALU code disturbs other waves on its SIMD (DESIGN.md
+section 6, ``tools/micro/hazard_repro.hip``).  One process per GPU on one compute stream — what ``inference_fn`` / ``run_sharded`` do —
+is not exposed; a foreign compute process on the same device is.  This module looks for one in the KFD process list
+(``/sys/class/kfd/kfd/proc/<pid>/queues/<qid>/gpuid``) and lets the entry points warn or refuse.
+
+Policy: ``FDIPT_SHARED_GPU`` = ``warn`` (default for library calls) | ``refuse`` (default of ``run_sharded``) | ``allow``.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import warnings
+
+KFD = "/sys/class/kfd/kfd"
+_checked: set = set()
+
+
+class SharedGpuError(RuntimeError):
+    pass
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def kfd_gpu_id(pci_domain: int, pci_bus: int, pci_device: int, root: str = KFD):
+    """KFD gpu_id of the device at a PCI address (topology node whose ``location_id`` / ``domain`` match), or None."""
+    for node in glob.glob(os.path.join(root, "topology", "nodes", "*")):
+        gid = _read(os.path.join(node, "gpu_id"))
+        props = _read(os.path.join(node, "properties"))
+        if not gid or gid == "0" or props is None:
+            continue
+        p = dict(line.split(None, 1) for line in props.splitlines() if " " in line)
+        try:
+            loc, dom = int(p.get("location_id", "-1")), int(p.get("domain", "0"))
+        except ValueError:
+            continue
+        if (loc >> 8) == pci_bus and ((loc >> 3) & 31) == pci_device and dom == pci_domain:
+            return int(gid)
+    return None
+
+
+def processes_with_queues(gpu_id: int, root: str = KFD):
+    """PIDs (as the KFD lists them: host PIDs) that own at least one compute / SDMA queue on ``gpu_id``; None if the list is unreadable."""
+    proc = os.path.join(root, "proc")
+    if not os.path.isdir(proc):
+        return None
+    owners = []
+    for d in glob.glob(os.path.join(proc, "*")):
+        for q in glob.glob(os.path.join(d, "queues", "*", "gpuid")):
+            if _read(q) == str(gpu_id):
+                owners.append(os.path.basename(d))
+                break
+    return owners
+
+
+def foreign_compute_processes(device=None, root: str = KFD):
+    """Number of OTHER processes holding queues on the torch device, or None when the KFD list cannot answer (no sysfs access, device
+    not found).  This process is made to own a queue first (one tiny launch), so it is one entry of the list itself — inside a PID
+    namespace the list holds host PIDs and it could not be recognised by name."""
+    import torch
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    pr = torch.cuda.get_device_properties(idx)
+    gid = kfd_gpu_id(getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", 0), root)
+    if gid is None:
+        return None
+    torch.zeros(1, device=f"cuda:{idx}").add_(1)
+    torch.cuda.synchronize(idx)
+    owners = processes_with_queues(gid, root)
+    if not owners:
+        return None
+    return len(owners) - 1
+
+
+def check(device=None, policy: str | None = None, what: str = "framedipt_amd", once: bool = True, root: str = KFD):
+    """Warn (``warn``) or raise ``SharedGpuError`` (``refuse``) when another compute process owns queues on ``device``.
+    Returns the number of foreign processes (None: unknown)."""
+    policy = (policy or os.environ.get("FDIPT_SHARED_GPU") or "warn").lower()
+    key = (str(device), policy)
+    if policy == "allow" or (once and key in _checked):
+        return None
+    _checked.add(key)
+    try:
+        n = foreign_compute_processes(device, root)
+    except Exception:  # noqa: BLE001  (a guard must not take the run down)
+        return None
+    if n:
+        msg = (f"{what}: {n} other compute process(es) hold queues on this GPU.  Kernels of two processes that share a SIMD can corrupt "
+               "each other's results on this hardware (DESIGN.md section 6): run one process per GPU, or set FDIPT_SHARED_GPU=allow "
+               "and use inference_fn(verify=k) to re-check forwards.")
+        if policy == "refuse":
+            raise SharedGpuError(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    return n

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, gpu_guard
 from .model.score_network import preprocess_aatype
 
 
@@ -66,9 +66,11 @@ class ReverseLoop:
 
     def __init__(self, model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None, state=None,
-                 graph=True):
+                 graph=True, verify=0):
         self.model, self.diffuser = model, diffuser
         dev = self.dev = model.device
+        gpu_guard.check(dev, what="inference_fn")  # a foreign compute process on this GPU: warn / refuse (FDIPT_SHARED_GPU)
+        self.verify, self.verified = int(verify or 0), 0
         rig0 = data_init["rigids_t"]
         _lib.require_cuda(rig0, "inference_fn")
         if rig0.dim() == 2:
@@ -158,9 +160,28 @@ class ReverseLoop:
             with torch.cuda.device(self.dev):
                 self._fwd(0, False, True)
 
+    def _verify_forward(self, k):
+        """verify=n: the forward of step k runs twice on the same inputs (the first time without its side effects: no self-conditioning
+        hand-over, no trajectory row) and every output must come back bit-identical — cheap insurance against silent corruption by a
+        foreign process on the GPU.  One host synchronisation per verified step."""
+        st = self.st
+        self.st.score_table = None if self.tab_all is None else self.tab_all[k]
+        self.st.omega_edges = self.omega_edges
+        st.forward(self.rigid_traj[k], self.res_mask, self.fixed, self.sc_ca, self.net_aatype, self.gt_psi, self.t_all[k],
+                   self.temb_all[k], self.sig_all[k], False)
+        return [x.clone() for x in (st.rigids, st.psi, st.rot_score, st.trans_score)]
+
     def _step_eager(self, k):
         st, t, n = self.st, self.reverse_steps[k], self.B * self.N
+        first = self._verify_forward(k) if self.verify and k % self.verify == 0 else None
         self._fwd(k, self.aux_traj, self.embed_sc and t > self.min_t)
+        if first is not None:
+            for name, a, b in zip(("rigids", "psi", "rot_score", "trans_score"), first, (st.rigids, st.psi, st.rot_score, st.trans_score)):
+                if not torch.equal(a, b):
+                    raise _lib.FdiptError(f"verify: two runs of the forward of step {k} differ in `{name}` (max |diff| "
+                                          f"{float((a - b).abs().max()):.3e}): results on this GPU are not reproducible — is another "
+                                          "compute process using it? (DESIGN.md section 6)")
+            self.verified += 1
         nxt = self.rigid_traj[k + 1]
         if t > self.min_t:
             # x_{t-1} lands in its trajectory slot, which is the next forward's input; its atom37 frame comes out of the
@@ -267,7 +288,7 @@ class ReverseLoop:
     def step(self, k, eager=False):
         """one_step_inference (utils.py:292-412) for reverse step k."""
         with torch.cuda.device(self.dev):
-            if self.graph and k < self.n_noisy:
+            if self.graph and k < self.n_noisy and not (self.verify and k % self.verify == 0):
                 self._advance(k, 1, eager)
             else:
                 self._step_eager(k)
@@ -282,7 +303,7 @@ class ReverseLoop:
         while k < self.num_t:
             n = self.GRAPH_CHUNK
             if (not self.graph or n < 2 or self.n_noisy - k < n or self._warm_key() not in self._WARM
-                    or any(kk in eager_steps for kk in range(k, k + n))):
+                    or any(kk in eager_steps or (self.verify and kk % self.verify == 0) for kk in range(k, k + n))):
                 n = 1
             if n == 1:
                 if k in eager_steps and before_step is not None:
@@ -407,12 +428,13 @@ class StreamedLoops:
 
 def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None,
-                 return_device=False, streams=1, experimental_streams=False, graph=True):
+                 return_device=False, streams=1, experimental_streams=False, graph=True, verify=0):
     """Same arguments / returned keys as the reference.  ``noise_tape=(z_rot, z_trans)`` ([num_t-1,B,N,3] float64
     N(0,1) draws) overrides the global ``np.random`` stream (sample-sharded runs).  ``data_init`` tensors carry a
     leading batch dimension B >= 1 (the reference always passes B = 1).  ``graph=True`` (default): the steps are replays of a HIP
     graph captured once per trajectory (``ReverseLoop``: same kernels and bits, ~1/70 of the host work); ``graph=False``: every step
-    enqueued launch by launch.  ``streams=n``: the batch runs as n sub-batches on n HIP streams (same results; the latency-bound
+    enqueued launch by launch.  ``verify=k``: the forward of every k-th step runs twice and must reproduce its bits (``FdiptError``
+    otherwise; one host sync per verified step) — for GPUs shared with other compute processes (``gpu_guard``).  ``streams=n``: the batch runs as n sub-batches on n HIP streams (same results; the latency-bound
     node path of one sub-batch overlaps the pair kernels of the other) — experimental: needs ``experimental_streams=True`` (or
     FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``; eager launches)."""
     if streams > 1 and data_init["rigids_t"].shape[0] > 1:  # sub-batches on their own HIP streams (same results)
@@ -424,5 +446,5 @@ def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj
             loop.step(k)
     else:
         loop = ReverseLoop(model, diffuser, data_init, num_t, min_t, center, aux_traj, self_condition, noise_scale,
-                           embed_self_conditioning, inpainting, input_aatype, noise_tape, graph=graph).run()
+                           embed_self_conditioning, inpainting, input_aatype, noise_tape, graph=graph, verify=verify).run()
     return loop.results(return_device)

@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--redact-min-len", type=int, default=8)
     ap.add_argument("--redact-max-len", type=int, default=14)
     ap.add_argument("--no-input-aatype", action="store_true", help="inference.input_aatype = False (default True: backbone atoms are built with the true residue types)")
+    ap.add_argument("--allow-shared-gpu", action="store_true", help="run although another compute process holds queues on this rank's GPU "
+                    "(refused by default: kernels of two processes on one GPU can corrupt each other's results, DESIGN.md section 6)")
+    ap.add_argument("--verify", type=int, default=0, help="inference_fn(verify=k): the forward of every k-th step runs twice and must reproduce its bits")
     a = ap.parse_args()
 
     import torch
@@ -229,6 +232,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
+    # one process per GPU is the contract: refuse a GPU that another compute process is using (the one-GPU test hook shares it on
+    # purpose and serialises its ranks with a file lock below)
+    from . import gpu_guard
+    if one_gpu or a.allow_shared_gpu:
+        os.environ["FDIPT_SHARED_GPU"] = "allow"
+    else:
+        gpu_guard.check(dev, policy=os.environ.get("FDIPT_SHARED_GPU") or "refuse", what="run_sharded")
     inp = a.download_dir is not None
     conf = config.base_config(inpainting=inp)
     diff = SE3Diffuser(conf.diffuser, device=dev)
@@ -249,7 +259,7 @@ def main():
     def run_batch(feats, tape):
         def go():
             return inference.inference_fn(net, diff, feats, num_t=a.num_t, min_t=a.min_t, aux_traj=True, noise_scale=a.noise_scale,
-                                          noise_tape=tape, return_device=True, inpainting=inp,
+                                          noise_tape=tape, return_device=True, inpainting=inp, verify=a.verify,
                                           input_aatype=inp and not a.no_input_aatype)  # (run_rank overlaps the D2H copy with the next batch)
         if not (one_gpu and world > 1):
             return go()
@@ -257,16 +267,24 @@ def main():
         # a half-precision MFMA kernel next to another kernel's waves corrupts single residues — 1 of 12 two-rank soak runs at N = 810
         # differed in one sample), so the ranks take turns on the device: a file lock around each batch, released once its kernels are done.
         # Production runs are one process per GPU and never take this path.
+        return one_gpu_turn(go)
+
+    def one_gpu_turn(fn):
         import fcntl
         os.makedirs(a.out_dir, exist_ok=True)
         with open(os.path.join(a.out_dir, ".one_gpu.lock"), "w") as lk:
             fcntl.flock(lk, fcntl.LOCK_EX)
             try:
-                res = go()
+                res = fn()
                 torch.cuda.synchronize()
                 return res
             finally:
                 fcntl.flock(lk, fcntl.LOCK_UN)
+
+    if write_item is not None and one_gpu and world > 1:
+        # the writer's ground-truth backbone launch (reference_layout_writer -> get_atom_positions_from_rigids) is GPU work as well
+        plain_write = write_item
+        write_item = lambda *args, **kw: one_gpu_turn(lambda: plain_write(*args, **kw))  # noqa: E731
 
     t0 = time.perf_counter()
     recs = run_rank(ds, diff, run_batch, rank, world, a.out_dir, a.seed, a.num_t, a.min_t, a.max_batch, keep=keep,

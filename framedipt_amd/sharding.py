@@ -117,10 +117,11 @@ def stack_items_padded(items, multiple: int = 4):
     return feats, tape, lengths
 
 
-# Lengths at which the library switches kernels (csrc: the o_pair row variants at 320 / 640, the attention / sequence-attention key-tile
+# Lengths at which the library switches kernels (csrc: the o_pair key passes at 320 / 640 / 960, the attention / sequence-attention key-tile
 # variants at 384 / 512 / 768, the 16-row node-path kernels up to 512, the register-attention limit 1024).  Inside one class a sample's
 # real residues are bit-identical however far it is padded; across a boundary they agree to tolerance only (different summation orders).
-KERNEL_CLASS_BOUNDS = (320, 384, 512, 640, 768, 1024)
+# The library exports the same list (fdipt_kernel_class_bounds, next to the dispatch code); tests/test_host_cpu.py compares the two.
+KERNEL_CLASS_BOUNDS = (320, 384, 512, 640, 768, 960, 1024)
 
 
 def kernel_class(n: int, multiple: int = 4) -> int:

@@ -350,6 +350,10 @@ int fdipt_event_record(void* ev, fdipt_stream_t s);
 int fdipt_event_elapsed_ms(void* start, void* stop, float* ms_host); /* synchronises on `stop` */
 
 const char* fdipt_version(void);
+/* Lengths N at which the half-precision forward switches kernel variants, ascending, into bounds_host[capacity] (host); returns their
+ * number.  Two samples whose lengths (rounded up to 4) fall between the same bounds run the same kernels: padding inside a class does
+ * not change a sample's bits (framedipt_amd/sharding.py: kernel_class). */
+int fdipt_kernel_class_bounds(int32_t* bounds_host, int capacity);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import kabsch_free_rmsd, load_golden
+from test_gpu_parity import _feats, _net
 
 pytestmark = pytest.mark.gpu
 
@@ -135,3 +136,110 @@ def test_weight_reload_between_trajectories():
     b_ref = inference_fn(net, d, feats, graph=False, **kw)
     _assert_same(b_ref, b, "after reload")
     assert not np.array_equal(a["prot_traj"], b["prot_traj"])
+
+
+def _other_inputs(f1, B, seed, masked_tail=0):
+    """B - 1 more samples of the golden's shape: other noisy frames / self-conditioning inputs; with ``masked_tail`` sample k also loses
+    its last 4 k residues (res_mask = 0 rows, as sharding.stack_items_padded pads a shorter member of a mixed-length batch)."""
+    gen = torch.Generator().manual_seed(seed)
+    N = f1["rigids_t"].shape[1]
+    feats = [dict(f1)]
+    for k in range(1, B):
+        f = dict(f1)
+        q = torch.nn.functional.normalize(torch.randn(1, N, 4, generator=gen), dim=-1)
+        f["rigids_t"] = torch.cat([q, 15.0 * torch.randn(1, N, 3, generator=gen)], -1).cuda().to(f1["rigids_t"].dtype)
+        f["sc_ca_t"] = (10.0 * torch.randn(1, N, 3, generator=gen)).cuda().to(f1["sc_ca_t"].dtype)
+        if masked_tail:
+            m = f1["res_mask"].clone()
+            m[:, N - masked_tail * k:] = 0
+            f["res_mask"] = m
+        feats.append(f)
+    return feats
+
+
+def _batch_vs_singles(net, feats, keys=("rigids", "psi", "rot_score", "trans_score", "atom37")):
+    singles = [{kk: v.clone() for kk, v in net(f).items() if kk in keys} for f in feats]
+    fb = {k: torch.cat([f[k] for f in feats], 0) for k in feats[0]}
+    out = net(fb)
+    for k, one in enumerate(singles):
+        for kk in keys:
+            assert torch.equal(out[kk][k], one[kk][0]), (k, kk, float((out[kk][k] - one[kk][0]).abs().max()))
+    assert len({float(out["rigids"][k, 5, 4]) for k in range(len(feats))}) == len(feats)  # (the batch did hold different samples)
+    return out
+
+
+def test_batch_n1000_b4_fp32():
+    """BASELINE configs[4] at its own batch: N = 1000, 4 samples, fp32 mode — four different x_t, each torch.equal to its B = 1 run,
+    sample 0 against the reference golden fwd_full_inpaint_n1000."""
+    G = load_golden("fwd_full_inpaint_n1000.npz")
+    net, d, conf = _net("full_inpaint_n1000", G, "fp32")
+    out = _batch_vs_singles(net, _other_inputs(_feats(G), 4, 31))
+    o0 = {k: out[k][:1].cpu().numpy() for k in ("rigids", "atom37")}
+    np.testing.assert_allclose(o0["rigids"][..., 4:], G["out_rigids"][..., 4:], atol=3e-4)
+    assert kabsch_free_rmsd(o0["atom37"], G["out_atom37"]) < 1e-4
+
+
+def test_batch_n724_b8_fp16_padded_mixed():
+    """BASELINE configs[2]'s shape at the benchmarked batch: eight members of a padded mixed-length batch at N = 724 (sample k's last
+    4 k residues are res_mask = 0 padding), fp16 mode — each torch.equal to its B = 1 run, sample 0 (the full-length member) against the
+    reference golden fwd_full_inpaint_n724_4chain at the fp16 mode's stated bounds."""
+    from test_gpu_sizes import FP16_BOUND
+    G = load_golden("fwd_full_inpaint_n724_4chain.npz")
+    net, d, conf = _net("full_inpaint_n724_4chain", G, "fp16")
+    out = _batch_vs_singles(net, _other_inputs(_feats(G), 8, 32, masked_tail=4))
+    o0 = {k: out[k][:1].cpu().numpy() for k in ("rigids", "atom37")}
+    assert np.abs(o0["rigids"][..., 4:] - G["out_rigids"][..., 4:]).max() < FP16_BOUND["ca"]
+    assert kabsch_free_rmsd(o0["atom37"], G["out_atom37"]) < FP16_BOUND["bb_rmsd"]
+
+
+def test_verify_mode_reruns_forwards_and_detects_a_difference(monkeypatch):
+    """inference_fn(verify=k): the forward of every k-th step runs twice and its outputs are compared bit for bit; same results as without;
+    a forward that does not reproduce (here: the first pass's rotation score is disturbed) raises FdiptError."""
+    from framedipt_amd import _lib
+    from framedipt_amd.inference import ReverseLoop, inference_fn
+    T = 7
+    net, d, feats, tape = _denovo_batch(32, 2, T, "fp16")
+    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape)
+    ref = inference_fn(net, d, feats, **kw)
+    loop = ReverseLoop(net, d, feats, T, 0.01, aux_traj=True, noise_scale=0.1, noise_tape=tape, verify=3).run()
+    assert loop.verified == 3  # steps 0, 3, 6
+    _assert_same(ref, loop.results(), "verify=3")
+    plain = ReverseLoop._verify_forward
+
+    def disturbed(self, k):
+        out = plain(self, k)
+        out[2][0, 5, 1] += 1e-9
+        return out
+    monkeypatch.setattr(ReverseLoop, "_verify_forward", disturbed)
+    with pytest.raises(_lib.FdiptError, match="verify"):
+        inference_fn(net, d, feats, verify=2, **kw)
+
+
+def test_shared_gpu_guard_on_this_box():
+    """gpu_guard.check: alone on the GPU -> 0 foreign processes (or None where the KFD process list is not readable); with a second
+    process holding a queue on the device -> a RuntimeWarning, SharedGpuError under the `refuse` policy."""
+    import subprocess
+    import sys
+    import time
+    import warnings
+
+    from framedipt_amd import gpu_guard
+    n = gpu_guard.check("cuda:0", policy="warn", once=False)
+    if n is None:
+        pytest.skip("KFD process list not readable in this container")
+    assert n == 0
+    child = subprocess.Popen([sys.executable, "-c", "import torch,time,sys; x=torch.zeros(8,device='cuda:0')+1; torch.cuda.synchronize(); "
+                              "print('up',flush=True); time.sleep(60)"], stdout=subprocess.PIPE, text=True)
+    try:
+        assert child.stdout.readline().strip() == "up"
+        time.sleep(0.5)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert gpu_guard.check("cuda:0", policy="warn", once=False) == 1
+        assert any("other compute process" in str(x.message) for x in w)
+        with pytest.raises(gpu_guard.SharedGpuError):
+            gpu_guard.check("cuda:0", policy="refuse", once=False)
+        assert gpu_guard.check("cuda:0", policy="allow", once=False) is None
+    finally:
+        child.kill()
+        child.wait()

@@ -21,6 +21,38 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.fdipt_version()
 
 
+def test_kernel_class_bounds_match_the_library():
+    """sharding.KERNEL_CLASS_BOUNDS (mixed-length batches never span two kernel-selection classes) is the list the library exports."""
+    from framedipt_amd import _lib, sharding
+    lib = _lib.load()
+    buf = (C.c_int32 * 16)()
+    n = lib.fdipt_kernel_class_bounds(buf, 16)
+    assert tuple(buf[:n]) == sharding.KERNEL_CLASS_BOUNDS
+    assert sharding.kernel_class(956) != sharding.kernel_class(964) and sharding.kernel_class(772) == sharding.kernel_class(960)
+
+
+def test_shared_gpu_guard_reads_the_kfd_process_list(tmp_path):
+    """gpu_guard on a fake /sys/class/kfd tree: gpu_id from the PCI address, owners of queues on that gpu_id."""
+    from framedipt_amd import gpu_guard
+    root = tmp_path / "kfd"
+    for node, gid, loc in ((0, 0, 0), (1, 51234, (0x75 << 8) | (0 << 3)), (2, 7777, (0xf5 << 8))):
+        d = root / "topology" / "nodes" / str(node)
+        d.mkdir(parents=True)
+        (d / "gpu_id").write_text(f"{gid}\n")
+        (d / "properties").write_text(f"cpu_cores_count 0\nlocation_id {loc}\ndomain 0\n")
+    assert gpu_guard.kfd_gpu_id(0, 0x75, 0, str(root)) == 51234 and gpu_guard.kfd_gpu_id(0, 0xf5, 0, str(root)) == 7777
+    assert gpu_guard.kfd_gpu_id(0, 0x11, 0, str(root)) is None
+    assert gpu_guard.processes_with_queues(51234, str(root)) is None  # (no proc directory: unknown)
+    for pid, gids in ((100, (51234,)), (200, (7777, 7777)), (300, (51234, 7777)), (400, ())):
+        for q, g in enumerate(gids):
+            d = root / "proc" / str(pid) / "queues" / str(q)
+            d.mkdir(parents=True)
+            (d / "gpuid").write_text(f"{g}\n")
+        (root / "proc" / str(pid)).mkdir(parents=True, exist_ok=True)
+    assert sorted(gpu_guard.processes_with_queues(51234, str(root))) == ["100", "300"]
+    assert sorted(gpu_guard.processes_with_queues(7777, str(root))) == ["200", "300"]
+
+
 def test_inventory_matches_reference_state_dict():
     from framedipt_amd import _lib, config, weights
     from framedipt_amd.model.score_network import dims_from_conf
