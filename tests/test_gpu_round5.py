@@ -243,3 +243,28 @@ def test_shared_gpu_guard_on_this_box():
     finally:
         child.kill()
         child.wait()
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_length_limit_is_refused_loudly(prec):
+    """N <= 1024 is the compiled limit of the attention tilings (both the register kernels and the LDS-score kernels of attention.hip):
+    N = 1024 runs, N = 1100 raises FdiptError (FDIPT_ESIZE) instead of computing something else."""
+    from framedipt_amd import _lib, config
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision=prec).load_synthetic(5).to("cuda")
+    for n, ok in ((1024, True), (1100, False)):
+        ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": 1}), d, "cuda")
+        feats = dict(ds[0][2])
+        feats["t"] = torch.ones(1, device="cuda")
+        if ok:
+            out = net(feats)
+            assert torch.isfinite(out["rigids"]).all() and torch.isfinite(out["rot_score"]).all()
+        else:
+            with pytest.raises(_lib.FdiptError, match="FDIPT_ESIZE"):
+                net(feats)
+        del ds, feats
+        torch.cuda.empty_cache()
