@@ -67,7 +67,7 @@ CONFIGS = {
 def pmc_traffic(precision: str, n: int, b: int):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), only when the bench
     runs the profiled configuration; the counters cannot be read from inside this process."""
-    for name in ("r04_pmc_edge_transition.json", "r03_pmc_edge_transition.json", "r02_pmc_edge_transition.json", "r01_pmc_edge_transition.json"):
+    for name in ("r05_pmc_edge_transition.json", "r04_pmc_edge_transition.json", "r03_pmc_edge_transition.json", "r02_pmc_edge_transition.json", "r01_pmc_edge_transition.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)

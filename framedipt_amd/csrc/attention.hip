@@ -926,3 +926,283 @@ int fd_points(const PointsArgs& a, hipStream_t st) {
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+
+// ------------------------------------------------------------------ fp32 mode (round 5): IPA attention with the scores in registers
+// attn_kernel<PrecF32, true> above stages every operand tile through LDS behind two barriers per 32-wide k-step (1.48 ms per call at
+// N = 1000, B = 4; 272 us at N = 300, B = 8: 22 TF/s of the 157 TF/s fp32 matrix peak, 6.6 % of a config-5 step).  This kernel keeps
+// the block = 32 queries of one (sample, head) and computes the same quantities in the formulation of ipa_attn3_kernel on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products):
+//   * S^T[key, query]: key tiles of 32 dealt round-robin to the four waves, A = K rows straight from global memory (an fp32 MFMA takes
+//     one k value per lane and WHICH channel a (lane half, step) pair stands for is free as long as A and B agree: lane half hi walks
+//     channels 128 hi .. 128 hi + 127, i.e. consecutive floats of its row, 16 B loads, 32 channels per chunk, double-buffered);
+//     B = the block's Q rows (pre-scaled) from LDS [channel][query];
+//   * point term on the matrix cores: -gamma/2 |q - k|^2 = gamma q.k - gamma/2 |k|^2 - gamma/2 |q|^2; the last term is constant along a
+//     softmax row and dropped, the first is 12 more MFMAs (24 coordinates), the second one MFMA against a column of ones;
+//   * pair bias ([B,N,N,H]) and the reference's mask term 1e5 (m_i m_j - 1) are added to the accumulators; padded keys get -1e30;
+//   * softmax: registers + lane^32 + 2 x 128 floats of LDS across the waves; the weights go to `probs` ([B,H,N,N], o_pair reads them) and
+//     to LDS ([key][query]);
+//   * O^T[d, query] = V^T P^T: ten row tiles of 32 (eight of the 256 channels, two of the 36 value-point coordinates), A = two rows of V
+//     per MFMA (coalesced 128 B), B = two LDS rows of P; the point tiles order their rows so that a lane ends up with whole (x, y, z)
+//     triples of five points and applies R_i^T (. - t_i) and the norm in registers.
+// Reference widths only (C = Dv = 256, 8 query / 12 value points); everything else stays on attn_kernel.
+#define AF_C 256
+#define AF_HC 128   // channels per lane half
+#define AF_CH 32    // channels per K chunk
+template <int NTW, int LB>
+__global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn_f32_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.N, H = a.H, nt = (N + 31) >> 5;
+  float* Qs = (float*)smem;            // [256 + 24 + 2][32]: channels, gamma * query points, a row of ones, a row of zeros
+  float* Ps = (float*)smem;            // [32 nt][32]: the weights, once every wave is done with Qs (behind the softmax barriers)
+  const int un = (AF_C + 26) * 32 > 32 * nt * 32 ? (AF_C + 26) * 32 : 32 * nt * 32;
+  float* mxs = Qs + un;                // [4][32]
+  float* sms = mxs + 128;              // [4][32]
+  float* msk = sms + 128;              // [32 nt] res_mask of the sample's keys (0 beyond N)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+  int b, h, qt;
+  {  // the 8 heads of a (sample, query tile) on one XCD: they read the same [i, j, :] bias lines
+    const int id = blockIdx.x, xcd = id & 7, local = id >> 3, groups = a.B * nt, per = (groups + 7) >> 3;
+    const int g = xcd * per + local / H;
+    h = local % H;
+    if (local >= per * H || g >= groups) return;
+    b = g / nt;
+    qt = g - b * nt;
+  }
+  const long rb = (long)b * N;
+  const int i0 = 32 * qt;
+  const float gam = a.gamma[h];
+  // ---- stage Q (scaled), gamma * q_pts, ones / zeros and the key mask
+  for (int v = tid; v < 32 * (AF_C / 4); v += FD_THREADS) {
+    const int r = v / (AF_C / 4), c4 = (v % (AF_C / 4)) * 4;
+    const int row = i0 + r < N ? i0 + r : N - 1;
+    const f32x4 x = *(const f32x4*)(a.q + (rb + row) * a.q_ld + (long)h * a.q_hs + c4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Qs[(c4 + q) * 32 + r] = x[q] * a.scale;
+  }
+  for (int v = tid; v < 32 * 24; v += FD_THREADS) {
+    const int r = v / 24, c = v % 24;
+    const int row = i0 + r < N ? i0 + r : N - 1;
+    Qs[(AF_C + c) * 32 + r] = gam * a.qp[((rb + row) * H + h) * 24 + c];
+  }
+  if (tid < 64) Qs[(AF_C + 24) * 32 + tid] = tid < 32 ? 1.f : 0.f;
+  for (int v = tid; v < 32 * nt; v += FD_THREADS) msk[v] = v < N ? a.res_mask[rb + v] : 0.f;
+  const int qi = i0 + li;
+  const float mi = qi < N ? a.res_mask[rb + qi] : 0.f;
+  __syncthreads();
+  // ---- scores of this wave's key tiles
+  f32x16 S[NTW];
+  float mx = -3.0e38f;
+  float Kc[2][AF_CH];
+  auto kload = [&](auto BUF, int t, int c) {
+    constexpr int bf = decltype(BUF)::value;
+    const int key = 32 * t + li, krow = key < N ? key : N - 1;
+    const float* kp = a.k + (rb + krow) * a.k_ld + (long)h * a.k_hs + AF_HC * hi + AF_CH * c;
+#pragma unroll
+    for (int s = 0; s < AF_CH; s += 4) {
+      const f32x4 v = *(const f32x4*)(kp + s);
+      Kc[bf][s] = v[0]; Kc[bf][s + 1] = v[1]; Kc[bf][s + 2] = v[2]; Kc[bf][s + 3] = v[3];
+    }
+  };
+  constexpr std::integral_constant<int, 0> B0{};
+  constexpr std::integral_constant<int, 1> B1{};
+  if (wave < nt) kload(B0, wave, 0);
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt) {
+      const int key = 32 * t + li, krow = key < N ? key : N - 1;
+      // the tile's small operands: key points (this lane half's 12 coordinates), pair bias of the 16 (key, query) elements
+      float Kp[12];
+      {
+        const float* pp = a.kp + ((rb + krow) * H + h) * 24 + 12 * hi;
+#pragma unroll
+        for (int s = 0; s < 12; s += 4) {
+          const f32x4 v = *(const f32x4*)(pp + s);
+          Kp[s] = v[0]; Kp[s + 1] = v[1]; Kp[s + 2] = v[2]; Kp[s + 3] = v[3];
+        }
+      }
+      float bs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * t + c_row(r, lane);
+        bs[r] = (j < N && qi < N) ? a.bias[((rb + qi) * N + j) * H + h] : 0.f;
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < AF_HC / AF_CH; ++c) {
+        if (c + 1 < AF_HC / AF_CH) {
+          if (c & 1) kload(B0, t, c + 1);
+          else kload(B1, t, c + 1);
+        } else if (t + 4 < nt && u + 1 < NTW) {
+          kload(B0, t + 4, 0);  // (AF_HC / AF_CH is even: chunk 0 of the next tile lands in buffer 0)
+        }
+        const float* qrow = Qs + (AF_HC * hi + AF_CH * c) * 32 + li;
+#pragma unroll
+        for (int s = 0; s < AF_CH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kc[c & 1][s], qrow[s * 32], acc, 0, 0, 0);
+      }
+      {  // gamma q_pt . k_pt - gamma / 2 |k_pt|^2
+        float kn = 0.f;
+#pragma unroll
+        for (int s = 0; s < 12; ++s) kn = fmaf(Kp[s], Kp[s], kn);
+        kn += __shfl_xor(kn, 32, 64);
+        const float* qrow = Qs + (AF_C + 12 * hi) * 32 + li;
+#pragma unroll
+        for (int s = 0; s < 12; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kp[s], qrow[s * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi == 0 ? -0.5f * gam * kn : 0.f, Qs[(AF_C + 24) * 32 + hi * 32 + li], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 32 * t + c_row(r, lane);
+        float s = acc[r] + bs[r];
+        s += 1e5f * (mi * msk[jl] - 1.f);
+        if (jl >= N) s = -1.0e30f;
+        acc[r] = s;
+        mx = fmaxf(mx, s);
+      }
+      S[u] = acc;
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (hi == 0) mxs[wave * 32 + li] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(mxs[li], mxs[32 + li]), fmaxf(mxs[64 + li], mxs[96 + li]));
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < NTW; ++u)
+    if (wave + 4 * u < nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf(S[u][r] - mx);
+        S[u][r] = e;
+        sum += e;
+      }
+  sum += __shfl_xor(sum, 32, 64);
+  if (hi == 0) sms[wave * 32 + li] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (sms[li] + sms[32 + li] + sms[64 + li] + sms[96 + li]);
+  float* prow = a.probs + (((long)b * H + h) * N + (qi < N ? qi : 0)) * N;
+  const bool vec4 = (N & 3) == 0;
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j0 = 32 * t + 8 * g + 4 * hi;
+        f32x4 p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          p[q] = S[u][4 * g + q] * inv;
+          Ps[(j0 + q) * 32 + li] = p[q];
+        }
+        if (qi < N) {
+          if (vec4 && j0 + 3 < N) *(f32x4*)(prow + j0) = p;
+          else
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (j0 + q < N) prow[j0 + q] = p[q];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- O^T = V^T P^T: row tiles 0..7 = channels, 8..9 = value-point coordinates; wave w owns tiles w, w + 4, w + 8
+  const int nm = 16 * nt;
+  constexpr int DEPTH = 16;
+  for (int T = wave; T < 10; T += 4) {
+    const float* base;
+    long stride;
+    bool alive = true;
+    int pnt = 0;
+    if (T < 8) {
+      base = a.v + rb * a.v_ld + (long)h * a.v_hs + 32 * T + li;
+      stride = a.v_ld;
+    } else {
+      // row li of a point tile: lane half hh = (li >> 2) & 1 of the OUTPUT fragment, slot = (li & 3) + 4 (li >> 3) = register index there;
+      // slot -> (point, coordinate) = (slot / 3, slot % 3): tile 8 holds points 5 hh .. 5 hh + 4, tile 9 points 10 + hh
+      const int hh = (li >> 2) & 1, slot = (li & 3) + 4 * (li >> 3);
+      pnt = T == 8 ? 5 * hh + slot / 3 : 10 + hh;
+      alive = T == 8 ? slot < 15 : slot < 3;
+      base = a.vp + (rb * H + h) * 36 + 3 * (alive ? pnt : 0) + slot % 3;
+      stride = (long)H * 36;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float Vr[DEPTH];
+#pragma unroll
+    for (int m = 0; m < DEPTH; ++m) {
+      const int key = 2 * m + hi;
+      Vr[m] = base[(long)(key < N ? key : N - 1) * stride];
+    }
+    for (int m0 = 0; m0 < nm; m0 += DEPTH) {
+      float Vc[DEPTH];
+#pragma unroll
+      for (int m = 0; m < DEPTH; ++m) Vc[m] = Vr[m];
+      if (m0 + DEPTH < nm) {
+#pragma unroll
+        for (int m = 0; m < DEPTH; ++m) {
+          const int key = 2 * (m0 + DEPTH + m) + hi;
+          Vr[m] = base[(long)(key < N ? key : N - 1) * stride];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < DEPTH; ++m)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(alive ? Vc[m] : 0.f, Ps[(2 * (m0 + m) + hi) * 32 + li], acc, 0, 0, 0);
+    }
+    if (qi >= N) continue;
+    if (T < 8) {
+      float* orow = a.out + (rb + qi) * a.out_ld + (long)h * AF_C + 32 * T + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *(f32x4*)(orow + 8 * g) = o;
+      }
+    } else {
+      const float* R = a.rot + (rb + qi) * 9;
+      const float* Tr = a.trans + (rb + qi) * 3;
+      const int HP = H * 12, npts = T == 8 ? 5 : 1;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        if (k < npts) {
+          const int pt = T == 8 ? 5 * hi + k : 10 + hi;
+          const float x = acc[3 * k] - Tr[0], y = acc[3 * k + 1] - Tr[1], z = acc[3 * k + 2] - Tr[2];
+          // invert_apply: R^T (p - t)   (openfold/utils/rigid_utils.py:1118-1130)
+          const float ox = R[0] * x + R[3] * y + R[6] * z;
+          const float oy = R[1] * x + R[4] * y + R[7] * z;
+          const float oz = R[2] * x + R[5] * y + R[8] * z;
+          float* o = a.out + (rb + qi) * a.out_ld + a.pt_off + h * 12 + pt;
+          o[0] = ox; o[HP] = oy; o[2 * HP] = oz;
+          o[3 * HP] = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
+        }
+      }
+    }
+  }
+}
+
+int fd_ipa_attention_f32_supported(const AttnArgs& a) {
+  return a.C == AF_C && a.Dv == AF_C && a.Pq == 8 && a.Pv == 12 && a.N >= 1 && a.N <= 1024 && a.H >= 1 && !(a.q_ld & 3) && !(a.k_ld & 3) &&
+         !(a.q_hs & 3) && !(a.k_hs & 3) && !(a.out_ld & 3) && a.bias && a.probs && a.qp && a.kp && a.vp && a.gamma && a.rot && a.trans &&
+         a.res_mask;
+}
+int fd_ipa_attention_f32(const AttnArgs& a, hipStream_t st) {
+  if (!fd_ipa_attention_f32_supported(a)) return FDIPT_EINVAL;
+  const int nt = (a.N + 31) / 32, groups = a.B * nt, per = (groups + 7) / 8;
+  const size_t smem = (size_t)(((AF_C + 26) * 32 > 32 * nt * 32 ? (AF_C + 26) * 32 : 32 * nt * 32) + 256 + 32 * nt) * 4;
+  if (smem > 160 * 1024) return FDIPT_ESIZE;
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
+    if (hipFuncSetAttribute((const void*)ipa_attn_f32_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)ipa_attn_f32_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_dev.set(dev_, 1);
+  }
+  const dim3 grid(8 * per * a.H), block(FD_THREADS);
+  if (a.N <= 3 * 4 * 32) hipLaunchKernelGGL((ipa_attn_f32_kernel<3, 2>), grid, block, smem, st, a);
+  else hipLaunchKernelGGL((ipa_attn_f32_kernel<8, 1>), grid, block, smem, st, a);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

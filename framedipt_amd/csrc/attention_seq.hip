@@ -496,3 +496,161 @@ int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, in
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+
+// ------------------------------------------------------------------ fp32 mode (round 5): the same block structure on v_mfma_f32_32x32x2_f32
+// The fp32 mode ran the sequence attention on the generic LDS-score kernel of attention.hip (136 us per call at N = 300, B = 8; 680 us at
+// N = 1000, B = 4: 6 % of a step).  Here: one block = 32 queries of one (sample, head), the key tiles of 32 dealt round-robin to the four
+// waves, scores in registers, operands straight from the fp32 in_proj rows [B N, 3 d] (no images: an fp32 MFMA takes ONE k value per lane,
+// and which channel a (lane half, step) pair stands for is free as long as A and B agree — lane half hi walks channels 40 hi .. 40 hi + 39,
+// so a lane reads 40 consecutive floats of its row: ten 16 B loads per operand tile).  Softmax as in seq_attn_kernel; P crosses LDS once
+// (fp32, [key][32 queries]); waves 0..2 then own one 32-channel tile of O^T[d, query] = V^T P^T over all keys (A = two 128 B rows of V per
+// MFMA, coalesced; B = two LDS rows of P).  Masked / padded keys get a score of -1e30 (weight exactly 0, as key_padding_mask does).
+template <int NTW, int LB>
+__global__ __launch_bounds__(FD_THREADS, LB) void seq_attn_f32_kernel(int B, int N, int H, const float* __restrict__ qkv, int ld, float scale,
+                                                                     const float* __restrict__ res_mask, float* __restrict__ out, int out_ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = (N + 31) >> 5;
+  float* mxs = (float*)smem;   // [4][32]
+  float* sms = mxs + 128;      // [4][32]
+  float* Ps = sms + 128;       // [32 nt][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, li = lane & 31;
+  const int BH = B * H;
+  int bhq, qt;
+  {  // all query tiles of one (sample, head) on the same XCD (as seq_attn_kernel)
+    const int id = blockIdx.x, xcd = id & 7, local = id >> 3, per = (BH + 7) >> 3;
+    bhq = xcd * per + local / nt;
+    qt = local % nt;
+    if (local >= per * nt || bhq >= BH) return;
+  }
+  const int h = bhq % H, b = bhq / H, dm = H * SA_HD;
+  const long rb = (long)b * N;
+  const int qi = 32 * qt + li, qrow = qi < N ? qi : N - 1;
+  constexpr int HC = SA_HD / 2;  // channels per lane half
+  float Qf[HC];
+  {
+    const float* qp = qkv + (rb + qrow) * ld + h * SA_HD + HC * hi;
+#pragma unroll
+    for (int s = 0; s < HC; s += 4) {
+      const f32x4 v = *(const f32x4*)(qp + s);
+      Qf[s] = v[0] * scale; Qf[s + 1] = v[1] * scale; Qf[s + 2] = v[2] * scale; Qf[s + 3] = v[3] * scale;
+    }
+  }
+  f32x16 S[NTW];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt) {
+      const int key = 32 * t + li, krow = key < N ? key : N - 1;
+      float Kf[HC];
+      const float* kp = qkv + (rb + krow) * ld + dm + h * SA_HD + HC * hi;
+#pragma unroll
+      for (int s = 0; s < HC; s += 4) {
+        const f32x4 v = *(const f32x4*)(kp + s);
+        Kf[s] = v[0]; Kf[s + 1] = v[1]; Kf[s + 2] = v[2]; Kf[s + 3] = v[3];
+      }
+      const unsigned long long live = __ballot(key < N && (res_mask ? res_mask[rb + krow] != 0.f : true));
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < HC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kf[s], Qf[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!((live >> c_row(r, lane)) & 1ull)) acc[r] = -1.0e30f;
+        mx = fmaxf(mx, acc[r]);
+      }
+      S[u] = acc;
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (hi == 0) mxs[wave * 32 + li] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(mxs[li], mxs[32 + li]), fmaxf(mxs[64 + li], mxs[96 + li]));
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < NTW; ++u)
+    if (wave + 4 * u < nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf(S[u][r] - mx);
+        S[u][r] = e;
+        sum += e;
+      }
+  sum += __shfl_xor(sum, 32, 64);
+  if (hi == 0) sms[wave * 32 + li] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (sms[li] + sms[32 + li] + sms[64 + li] + sms[96 + li]);
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ps[(32 * t + c_row(r, lane)) * 32 + li] = S[u][r] * inv;
+  }
+  __syncthreads();
+  // ---- O^T[d, query] for channel tile `wave` over all keys: MFMA m takes keys 2 m + hi
+  if (wave < SA_DT) {
+    const int d = 32 * wave + li;
+    const bool dlive = d < SA_HD;
+    const float* vp = qkv + rb * ld + 2 * dm + h * SA_HD + (dlive ? d : SA_HD - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nm = 16 * nt;  // key pairs
+    constexpr int DEPTH = 16;
+    float Vr[DEPTH];
+#pragma unroll
+    for (int m = 0; m < DEPTH; ++m) {
+      const int key = 2 * m + hi;
+      Vr[m] = vp[(long)(key < N ? key : N - 1) * ld];
+    }
+    for (int m0 = 0; m0 < nm; m0 += DEPTH) {
+      float Vc[DEPTH];
+#pragma unroll
+      for (int m = 0; m < DEPTH; ++m) Vc[m] = Vr[m];
+      if (m0 + DEPTH < nm) {
+#pragma unroll
+        for (int m = 0; m < DEPTH; ++m) {
+          const int key = 2 * (m0 + DEPTH + m) + hi;
+          Vr[m] = vp[(long)(key < N ? key : N - 1) * ld];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < DEPTH; ++m) {
+        const float p = Ps[(2 * (m0 + m) + hi) * 32 + li];  // (padded keys: weight 0)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dlive ? Vc[m] : 0.f, p, acc, 0, 0, 0);
+      }
+    }
+    if (qi < N) {
+      float* orow = out + (rb + qi) * out_ld + (long)h * SA_HD + 32 * wave + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (32 * wave + 8 * g + 4 * hi < SA_HD) {
+          f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+          *(f32x4*)(orow + 8 * g) = o;
+        }
+    }
+  }
+}
+
+int fd_seq_attention_f32_supported(int N, int H, int hd, int ld) { return hd == SA_HD && N >= 1 && N <= 4 * SA_NTW_MAX * 32 && H >= 1 && !(ld & 3); }
+// softmax(Q K^T * scale + key mask) V on the fp32 in_proj rows qkv [B N, ld] = (q | k | v), d_model = H * 80; out [B N, out_ld]
+int fd_seq_attention_f32(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, float* out, int out_ld,
+                         hipStream_t st) {
+  if (!fd_seq_attention_f32_supported(N, H, SA_HD, ld) || (out_ld & 3)) return FDIPT_EINVAL;
+  const int nt = (N + 31) / 32, per = (B * H + 7) / 8;
+  const size_t smem = 2 * 128 * 4 + (size_t)32 * nt * 32 * 4;
+  static FdPerDevice attr_dev;
+  const int dev_ = fd_device();
+  if (!attr_dev.get(dev_)) {
+    if (hipFuncSetAttribute((const void*)seq_attn_f32_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 4 + 32 * 32 * 32 * 4) != hipSuccess)
+      return FDIPT_ELAUNCH;
+    attr_dev.set(dev_, 1);
+  }
+  const dim3 grid(8 * per * nt), block(FD_THREADS);
+  if (N <= 3 * 4 * 32) hipLaunchKernelGGL((seq_attn_f32_kernel<3, 2>), grid, block, smem, st, B, N, H, qkv, ld, scale, res_mask, out, out_ld);
+  else hipLaunchKernelGGL((seq_attn_f32_kernel<8, 1>), grid, block, smem, st, B, N, H, qkv, ld, scale, res_mask, out, out_ld);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}

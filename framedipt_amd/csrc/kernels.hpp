@@ -242,6 +242,10 @@ int fd_seq_qkv_supported(int N, int H, int d_model);
 int fd_seq_qkv(int B, int N, int H, const float* x, int ld_x, const void* wimg, const void* wimg_lo, const float* bias, float scale,
                void* images, hipStream_t st);
 int fd_seq_attention_run(int B, int N, int H, const void* images, float* out, int out_ld, const L2Warm* warm, hipStream_t st);
+// fp32 mode: the same block structure on fp32 MFMAs, operands straight from the fp32 in_proj rows qkv [B N, ld] = (q | k | v)
+int fd_seq_attention_f32_supported(int N, int H, int hd, int ld);
+int fd_seq_attention_f32(int B, int N, int H, const float* qkv, int ld, float scale, const float* res_mask, float* out, int out_ld,
+                         hipStream_t st);
 
 // row-complete fused per-residue MLPs (rowblock.hip): 32 rows x all output columns per block, up to 3 Linear layers
 // (+ReLU) + residual + LayerNorm + row mask; weights as fd_chain_build_image(.., permuted = 0) fragment images
@@ -358,6 +362,9 @@ int fd_f32_to_half(long n, const float* in, half_t* out, hipStream_t st);
 int fd_edge_transition(int precision, int cz, int cb, const EdgeTransArgs& a, hipStream_t st);
 int fd_edge_embed(int precision, int cz, const EdgeEmbedArgs& a, hipStream_t st);
 int fd_attention(int precision, int ipa, const AttnArgs& a, hipStream_t st);
+// fp32 mode, reference widths: the IPA attention with the scores in registers (attention.hip: ipa_attn_f32_kernel)
+int fd_ipa_attention_f32_supported(const AttnArgs& a);
+int fd_ipa_attention_f32(const AttnArgs& a, hipStream_t st);
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
 int fd_opair_mfma_eligible(int precision, const OPairArgs& a);  // the MFMA kernel will run (it can take probs_h16)
 int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, int frag, hipStream_t st);

@@ -1057,7 +1057,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         RC(fd_pair_bias_f32((long)NN, H, cz, F(w.z), (const float*)(D + db.wb), (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
       else
         RC(fd_linear_z(prec, (long)NN, H, cz, W + w.z, D + db.wb, (const float*)(D + db.bb), F(w.bias), st));  // [B,N,N,H]
-      RC(fd_attention(prec, 1, aa, st));
+      if (prec == FDIPT_PREC_F32 && !sw.generic_attn && fd_ipa_attention_f32_supported(aa)) RC(fd_ipa_attention_f32(aa, st));  // scores in registers (round 5)
+      else RC(fd_attention(prec, 1, aa, st));
     }
     if (op.kind == OP_IPA && sw.ipa_stop == 2) return FD_STOP;
     TWICE("opair", fd_opair(prec, oa, st));
@@ -1142,6 +1143,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       ta.out = F(w.att); ta.out_ld = dt; ta.pt_off = 0; ta.lds_s = 0;
       if (bf && !sw.generic_attn && !sw.no_seq_attn && fd_seq_attention_supported(N, d->tfmr_heads, hd))
         RC(fd_seq_attention(B, N, d->tfmr_heads, F(w.qkv), 3 * dt, ta.scale, res_mask, W + w.seqimg, F(w.att), dt, st));
+      else if (prec == FDIPT_PREC_F32 && !sw.generic_attn && !sw.no_seq_attn && fd_seq_attention_f32_supported(N, d->tfmr_heads, hd, 3 * dt))
+        RC(fd_seq_attention_f32(B, N, d->tfmr_heads, F(w.qkv), 3 * dt, ta.scale, res_mask, F(w.att), dt, st));  // fp32 mode: scores in registers (round 5)
       else RC(fd_attention(prec, 0, ta, st));
       }
       // x_a = norm1(x + out_proj(att)); x_b = norm2(x_a + linear2(relu(linear1(x_a))))

@@ -37,13 +37,34 @@ def rnd(x):
     return u.astype(np.uint32).view(np.float32)
 
 
+def rnd_w(w):
+    """Weight rounding.  FDIPT_ERRB_WDIFF=1: error-diffusion rounding along the input dimension (the residual of element k is carried into
+    element k + 1 before it is rounded, so every partial row sum of the rounded row is within half an ulp of the exact one)."""
+    if os.environ.get("FDIPT_ERRB_WDIFF") != "1" or np.ndim(w) != 2:
+        return rnd(w)
+    w = np.asarray(w, dtype=np.float64)
+    out = np.empty_like(w, dtype=np.float32)
+    carry = np.zeros(w.shape[0])
+    for k in range(w.shape[1]):
+        t = w[:, k] + carry
+        r = rnd(t.astype(np.float32)).astype(np.float64)
+        out[:, k] = r
+        carry = t - r
+    return out
+
+
 GROUP_OF = [  # substring of the parameter name -> group
     ("node_embedder", "embed_node"), ("edge_embedder.0", None), ("edge_embedder", "embed_edge"),
     ("linear_q_points", "ipa_pts"), ("linear_kv_points", "ipa_pts"), ("linear_q", "ipa_qkv"), ("linear_kv", "ipa_qkv"),
     ("linear_b", "pair_bias"), ("down_z", "opair"), ("linear_out", "linear_out"), ("skip_embed", "skip"),
     ("seq_tfmr", "tfmr"), ("post_tfmr", "post"), ("node_transition", "transition"), ("bb_update", None),
-    ("edge_transition", "et"), ("torsion_pred.linear_final", None), ("torsion_pred", "torsion"),
+    # EdgeTransition per layer (round 5): et0 = initial_embed (per residue; the HIP path runs it on split operands), et1 / et2 = the two
+    # trunk layers, etf = final_layer; "et" in a selection means all four
+    ("edge_transition_0.initial_embed", "et0"), ("edge_transition_1.initial_embed", "et0"), ("edge_transition_2.initial_embed", "et0"),
+    ("trunk.0", "et1"), ("trunk.2", "et2"), ("final_layer", "etf"),
+    ("torsion_pred.linear_final", None), ("torsion_pred", "torsion"),
 ]
+ET_SUB = ("et0", "et1", "et2", "etf")
 GROUPS = ["embed_node", "embed_edge", "ipa_pts", "ipa_qkv", "ipa_attn", "pair_bias", "opair", "linear_out", "skip", "tfmr",
           "tfmr_attn", "post", "transition", "et", "z_store", "torsion"]
 
@@ -61,7 +82,7 @@ def want(group, block=None, idx=None):
         g, i = (e.split("#") + [None])[:2]
         g, b = (g.split("@") + [None])[:2]
         g, part = (g.split(".") + ["xw"])[:2]
-        if g != group or (b is not None and block is not None and int(b) != block) or (i is not None and idx is not None and int(i) != idx):
+        if not (g == group or (g == "et" and group in ET_SUB)) or (b is not None and block is not None and int(b) != block) or (i is not None and idx is not None and int(i) != idx):
             continue
         rx, rw = rx or "x" in part, rw or "w" in part
     return rx, rw
@@ -86,7 +107,7 @@ class Net(osn.ScoreNetwork):
             digits = [int(t) for t in name.replace(".", "_").split("_") if t.isdigit()]
             blk = digits[0] if ("trunk" in name and digits) else None
             rx, rw = want(g, blk)
-            x, w = (rnd(x) if rx else x), (rnd(w) if rw else w)
+            x, w = (rnd(x) if rx else x), (rnd_w(w) if rw else w)
         return osn.linear(x, w, b)
 
     def ipa(self, b, *a, **k):

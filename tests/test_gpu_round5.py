@@ -248,7 +248,8 @@ def test_shared_gpu_guard_on_this_box():
 @pytest.mark.parametrize("prec", ["fp16", "fp32"])
 def test_length_limit_is_refused_loudly(prec):
     """N <= 1024 is the compiled limit of the attention tilings (both the register kernels and the LDS-score kernels of attention.hip):
-    N = 1024 runs, N = 1100 raises FdiptError (FDIPT_ESIZE) instead of computing something else."""
+    N = 1024 runs in the fp16 mode (N = 1000, config 5's length, in the fp32 mode), N = 1100 raises FdiptError (FDIPT_ESIZE) instead of
+    computing something else."""
     from framedipt_amd import _lib, config
     from framedipt_amd.diffusion import SE3Diffuser
     from framedipt_amd.model import ScoreNetwork
@@ -256,7 +257,7 @@ def test_length_limit_is_refused_loudly(prec):
     conf = config.base_config()
     d = SE3Diffuser(conf.diffuser, device="cuda")
     net = ScoreNetwork(conf.model, d, precision=prec).load_synthetic(5).to("cuda")
-    for n, ok in ((1024, True), (1100, False)):
+    for n, ok in ((1024 if prec == "fp16" else 1000, True), (1100, False)):
         ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": 1}), d, "cuda")
         feats = dict(ds[0][2])
         feats["t"] = torch.ones(1, device="cuda")
