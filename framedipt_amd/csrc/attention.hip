@@ -852,7 +852,9 @@ __global__ __launch_bounds__(256) void points16_kernel(PointsArgs a) {
 #pragma unroll
             for (int c = 0; c < 24; ++c) kn = fmaf(kv[c], kv[c], kn);
           const float m = lv ? a.res_mask[(long)b * a.N + keyu] : 0.f;
-          const float t0 = -0.5f * a.gamma[hh] * kn;
+          // (saturated at the fp16 range: beyond |k| ~ 360 nm / sqrt(gamma) from the origin — 3.6 um in unscaled units, i.e. inputs that
+          //  are not centred — the three-part norm would overflow to -inf / NaN; such keys keep a finite, still dominating penalty)
+          const float t0 = fmaxf(-0.5f * a.gamma[hh] * kn, -65000.f);
           const unsigned short p0 = f2f16(t0);
           const float t1 = t0 - f162f(p0);
           const unsigned short p1 = f2f16(t1);
