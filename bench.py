@@ -18,8 +18,8 @@ A "step" = one reverse-diffusion step of the whole batch exactly as inference_fn
 caller always passes it, experiments/inference.py:218,331): score-network forward incl. its backbone atoms, fused SE(3)
 reverse step + atom37 frame of x_{t-1}, trajectory writes.  By default K = T: W warm-up steps on a scratch trajectory, then
 the WHOLE trajectory is timed (self-conditioning priming forward + T steps, t = 1 -> min_t, the last step takes the x_0
-branch); with K < T the K timed steps are spread evenly over the schedule (every noise level, incl. the last step), priming
-untimed.  Inputs, weights and the noise tape are resident in HBM before the timed region; value = B*N*K*n_gpus / max-over-ranks.
+branch); with K < T a window of K consecutive steps in the middle of the schedule is timed (priming untimed), issued exactly as
+inference_fn issues them (chunked graph replays).  Inputs, weights and the noise tape are resident in HBM before the timed region; value = B*N*K*n_gpus / max-over-ranks.
 Every sample draws x_T and its noise tape from its own stream (seed + global sample index, framedipt_amd/sharding.py).
 
 Also on the JSON line:
@@ -310,10 +310,11 @@ def main():
                                        noise_tape=tape)
             lp.st.reserve_cus = a.et_reserve
             return lp
-        # timed steps: the whole schedule, or K steps spread evenly over it (first and last included)
-        steps = list(range(T)) if K == T else sorted({int(round(i * (T - 1) / max(K - 1, 1))) for i in range(K)})
-        while len(steps) < K:  # (rounding collisions for K close to T)
-            steps = sorted(set(steps) | {next(s for s in range(T) if s not in steps)})
+        # timed steps: the whole schedule, or a window of K CONSECUTIVE steps in the middle of it (the loop's steady state: chunked graph
+        # replays exactly as inference_fn issues them; the window starts from x_T's frames copied into its first row, so every timed step
+        # works on a valid state and hands it to the next one)
+        k0 = 0 if K == T else max(0, (T - 1 - K) // 2)
+        steps = list(range(k0, k0 + K))
         # HIP events around every EdgeTransition launch of a few of the timed steps (recorded on the launch stream by the library):
         # up to 16 of a whole trajectory, at most 4 when K <= 32
         n_samp = min(K, 16 if K > 32 else 4)
@@ -354,22 +355,23 @@ def main():
             st.clock_out = clk_dev if k in events else None
         if K < T:
             loop.prime()
+            for lp in (loop.loops if streams > 1 else [loop]):
+                lp.rigid_traj[k0].copy_(lp.rigid_traj[0])
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if K == T and streams == 1:
-            loop.run(eager_steps=sampled, before_step=bracket)
+        if streams == 1:
+            if K == T:
+                loop.prime()
+            loop.run_steps(k0, k0 + K, eager_steps=sampled, before_step=bracket)
         else:
             if K == T:
                 loop.prime()
             for k in steps:
                 bracket(k)
-                if streams == 1:
-                    loop.step(k, eager=k in events)
-                else:
-                    loop.step(k)
+                loop.step(k)
         host_s = time.perf_counter() - t0  # host time to enqueue the region (the GPU runs behind it)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -449,7 +451,7 @@ def main():
         v_a, roof_a = record(prec, Ka, el_a, et_a, clk_a, Bev_a, a.kernel_flags, res_per_step=Ba * N,
                              fwd_flops_per_step=Ba * flops_per_forward(N, inp), B=Ba)
         all_rec = {"dtype": prec, "value": v_a, "unit": "residue*step/s", "samples_per_gpu": Ba, "steps": Ka, "warmup": 2, "ms_per_step": el_a / Ka * 1e3,
-                   "roofline": roof_a, "note": f"all {Ba} samples of BASELINE configs[3] batched on ONE GPU, {Ka} steps spread over T={T}; same kernels, "
+                   "roofline": roof_a, "note": f"all {Ba} samples of BASELINE configs[3] batched on ONE GPU, {Ka} consecutive steps of T={T}; same kernels, "
                                                "weights and per-sample seeds as the headline line"}
         del feats_a, tape_a, dsa
         torch.cuda.empty_cache()
@@ -466,7 +468,7 @@ def main():
             v32, roof32 = record("fp32", K32, el32, et32, clk32, Bev32, a.kernel_flags)
             ref_rec = {"dtype": "fp32", "value": v32, "unit": "residue*step/s", "steps": K32, "warmup": 2, "ms_per_step": el32 / K32 * 1e3,
                        "precision_mode": PREC_MODE["fp32"], "roofline": roof32,
-                       "note": f"same workload and schedule, {K32} steps spread over T={T}; per-step backbone RMSD vs the reference ~1e-5 A"}
+                       "note": f"same workload and schedule, {K32} consecutive steps of T={T}; per-step backbone RMSD vs the reference ~1e-5 A"}
         del net32
 
     if rank == 0:
@@ -478,7 +480,7 @@ def main():
             "config": {"workload": f"{a.config}: {'inpainting' if inp else 'de novo'} backbone sampler, "
                                    + (f"{B} different complexes/GPU of N={min(all_len)}..{max(all_len)} (mean {np.mean(all_len):.0f}) padded to {N}, "
                                       if mixed else f"N={N}, {B} samples/GPU ") +
-                                   f"batched, {'whole trajectory (priming forward + all steps)' if K == T else f'{K} steps spread over the schedule'}"
+                                   f"batched, {'whole trajectory (priming forward + all steps)' if K == T else f'{K} consecutive steps from the middle of the schedule'}"
                                    f" of T={T}, aux_traj=True, noise_scale 0.1, 17.4M-param synthetic weights, per-sample seeds",
                        "n_res": N, "samples_per_gpu": B, "total_samples": n_total, "num_t": T, "parallelism": f"sample-sharded x{world}, no collective" + (f", {a.streams} sub-batch streams per GPU" if a.streams > 1 else ""),
                        "precision_mode": PREC_MODE[prec], "kernel_flags": a.kernel_flags},

@@ -294,15 +294,14 @@ class ReverseLoop:
                 self._step_eager(k)
         self._next = k + 1
 
-    def run(self, eager_steps=(), before_step=None):
-        """The whole trajectory: priming forward, then every step (graph replays, ``GRAPH_CHUNK`` steps at a time where that many noisy
-        steps remain).  ``eager_steps``: steps to enqueue launch by launch instead, ``before_step(k)`` called ahead of each of them and
-        ``before_step(None)`` behind it (bench.py: HIP events around the dominant kernel's launches of a few steps)."""
-        self.prime()
-        k, eager_steps = 0, set(eager_steps)
-        while k < self.num_t:
+    def run_steps(self, k_begin, k_end, eager_steps=(), before_step=None):
+        """Steps k_begin .. k_end - 1 in sequence (graph replays, ``GRAPH_CHUNK`` steps at a time where that many noisy steps remain).
+        ``eager_steps``: steps to enqueue launch by launch instead, ``before_step(k)`` called ahead of each of them and ``before_step(None)``
+        behind it (bench.py: HIP events around the dominant kernel's launches of a few steps)."""
+        k, eager_steps = k_begin, set(eager_steps)
+        while k < k_end:
             n = self.GRAPH_CHUNK
-            if (not self.graph or n < 2 or self.n_noisy - k < n or self._warm_key() not in self._WARM
+            if (not self.graph or n < 2 or min(self.n_noisy, k_end) - k < n or self._warm_key() not in self._WARM
                     or any(kk in eager_steps or (self.verify and kk % self.verify == 0) for kk in range(k, k + n))):
                 n = 1
             if n == 1:
@@ -315,8 +314,13 @@ class ReverseLoop:
                 with torch.cuda.device(self.dev):
                     self._advance(k, n)
             k += n
-        self._next = self.num_t
+        self._next = k_end
         return self
+
+    def run(self, eager_steps=(), before_step=None):
+        """The whole trajectory: priming forward, then every step."""
+        self.prime()
+        return self.run_steps(0, self.num_t, eager_steps, before_step)
 
     def results(self, return_device=False):
         st = self.st
