@@ -227,7 +227,7 @@ def test_shared_gpu_guard_on_this_box():
     n = gpu_guard.check("cuda:0", policy="warn", once=False)
     if n is None:
         pytest.skip("KFD process list not readable in this container")
-    assert n == 0
+    base = n  # (0 on an exclusive box; a monitoring agent with a queue on the device would show up here and is not this test's business)
     child = subprocess.Popen([sys.executable, "-c", "import torch,time,sys; x=torch.zeros(8,device='cuda:0')+1; torch.cuda.synchronize(); "
                               "print('up',flush=True); time.sleep(60)"], stdout=subprocess.PIPE, text=True)
     try:
@@ -235,7 +235,7 @@ def test_shared_gpu_guard_on_this_box():
         time.sleep(0.5)
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
-            assert gpu_guard.check("cuda:0", policy="warn", once=False) == 1
+            assert gpu_guard.check("cuda:0", policy="warn", once=False) == base + 1
         assert any("other compute process" in str(x.message) for x in w)
         with pytest.raises(gpu_guard.SharedGpuError):
             gpu_guard.check("cuda:0", policy="refuse", once=False)
