@@ -47,7 +47,7 @@ extern "C" {
  * fdipt_model_prepare and every forward of a model. */
 #define FDIPT_KF_ET3 1           /* EdgeTransition: the 16-pair-wave kernel (default for N % 4 != 0) for every N >= 43   */
 #define FDIPT_KF_GENERIC_PAIR 2  /* EdgeTransition / edge embedder: the any-width LDS-chain kernels                      */
-#define FDIPT_KF_GENERIC_ATTN 4  /* attention: the LDS-score kernels (default for N > 512) for every N                  */
+#define FDIPT_KF_GENERIC_ATTN 4  /* attention: the LDS-score kernels (the fallback for non-reference widths) in both modes */
 #define FDIPT_KF_UNFUSED_NODE 8  /* node path as plain GEMM + LayerNorm launches (default for non-reference widths)     */
 #define FDIPT_KF_UNFOLDED 16     /* launch folds off: pair bias / feature split / torsion head / fills as own launches  */
 #define FDIPT_KF_NO_SPLIT 32     /* node-path layers on plain half-precision operands instead of split (hi + lo) operands:
