@@ -269,3 +269,47 @@ def test_length_limit_is_refused_loudly(prec):
                 net(feats)
         del ds, feats
         torch.cuda.empty_cache()
+
+
+def test_bench_line_of_the_driver_command_shape():
+    """bench.py with the driver's flag shape (--gpus 1 --steps K --warmup W; here on config c2 and without the slow sub-records' defaults
+    changed): ONE JSON line carrying the contract keys, the roofline and loop records, the flat copies of the sub-records' values — and the
+    timed region went through graph replays (the default product path), K consecutive steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3", "--config", "c2", "--no-cpu-baseline",
+           "--reference-steps", "2"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "loop", "whole_forward_frac", "fp32_value", "fp32_whole_forward_frac"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["dtype"] == "fp16" and d["vs_baseline"] is None
+    assert d["loop"]["graph"] is True and d["loop"]["host_enqueue_ms_per_step"] < d["ms_per_step"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["launches_timed"] == 3 * 4 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "12 consecutive steps" in d["config"]["workload"]
+    assert abs(d["value"] - 8 * 128 * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 1e-6
+
+
+def test_batch_of_64_n300_keeps_a_samples_bits():
+    """bench.py's all_samples_one_gpu batch (64 samples at N = 300, fp16 mode): samples 0, 31 and 63 of the batch are torch.equal to their B = 1
+    runs, sample 0 is the reference golden — the 64-sample sub-record times the kernels the parity suite pins."""
+    from test_gpu_sizes import FP16_BOUND
+    G = load_golden("fwd_full_denovo_n300_t50.npz")
+    net, d, conf = _net("full_denovo_n300_t50", G, "fp16")
+    feats = _other_inputs(_feats(G), 64, 77)
+    keys = ("rigids", "psi", "rot_score", "trans_score", "atom37")
+    fb = {k: torch.cat([f[k] for f in feats], 0) for k in feats[0]}
+    out = {k: v.clone() for k, v in net(fb).items() if k in keys}
+    for s in (0, 31, 63):
+        one = net(feats[s])
+        for kk in keys:
+            assert torch.equal(out[kk][s], one[kk][0]), (s, kk, float((out[kk][s] - one[kk][0]).abs().max()))
+    assert kabsch_free_rmsd(out["atom37"][:1].cpu().numpy(), G["out_atom37"]) < FP16_BOUND["bb_rmsd"]
