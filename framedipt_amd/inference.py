@@ -58,9 +58,11 @@ class ReverseLoop:
     (``FdiptForwardArgs.step_cursor``, ``fdipt_se3_reverse_step_indexed``: the fused reverse step advances it), so the launch
     arguments of a step do not depend on the step: the first noisy step is enqueued eagerly through the cursor (it also runs every
     kernel once), the second one is captured as a HIP graph — and ``GRAPH_CHUNK`` consecutive steps as a second graph — and all
-    later steps are replays: one ``hipGraphLaunch`` per chunk instead of ~70 ``hipLaunchKernel`` + 3 ctypes calls per step
-    (1.4 ms of host work per 2.2 ms GPU step at N = 300, B = 8: a slower or busier host made the loop host-bound).  Same kernels,
-    same bits as the eager loop (``graph=False``; tests/test_gpu_round5.py)."""
+    later steps are replays: one ``hipGraphLaunch`` per chunk instead of ~67 ``hipLaunchKernel`` + 3 ctypes calls per step
+    (0.09 ms against 0.24 ms of host work per 2.1 - 2.2 ms GPU step at N = 300, B = 8 on a quiet host; under any per-call overhead —
+    a tracer costs 45 us per launch — only the replayed loop stays GPU-bound: profiles/r05_driver_cmd_repro.md).  Same kernels, same
+    bits as the eager loop (``graph=False``; tests/test_gpu_round5.py, tools/soak_step_graph.py).  The graphs hold pointers into this
+    loop's buffers and its ``BatchState``: they live and die with the loop."""
 
     GRAPH_CHUNK = 8  # steps per replay of the chunk graph (``run()``); single steps replay the one-step graph
 
