@@ -313,3 +313,33 @@ def test_batch_of_64_n300_keeps_a_samples_bits():
         for kk in keys:
             assert torch.equal(out[kk][s], one[kk][0]), (s, kk, float((out[kk][s] - one[kk][0]).abs().max()))
     assert kabsch_free_rmsd(out["atom37"][:1].cpu().numpy(), G["out_atom37"]) < FP16_BOUND["bb_rmsd"]
+
+
+@pytest.mark.parametrize("n,n_pad", [(300, 320), (324, 384), (388, 512), (516, 640), (644, 768), (772, 960), (964, 1024)])
+def test_padding_inside_a_kernel_class_keeps_a_samples_bits(n, n_pad):
+    """sharding.kernel_class / fdipt_kernel_class_bounds: a sample padded (res_mask = 0 rows, identity frames) to any length of its own
+    kernel-selection class gives, on its real residues, the BITS of its unpadded run — one forward in the fp16 mode at the two ends of every
+    class (the dispatch boundaries 320 / 384 / 512 / 640 / 768 / 960 / 1024 of o_pair, attention, sequence attention and the 16-row
+    node path).  This is what lets run_sharded batch different lengths without a sample's result depending on its batch mates."""
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    assert sharding.kernel_class(n) == sharding.kernel_class(n_pad)
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(5).to("cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": 1}), d, "cuda")
+    item = sharding.seeded_item(ds, 0, 13, d, 3, 0.01)
+    feats = dict(item[2])
+    feats["t"] = torch.full((1,), 0.4, device="cuda")
+    gen = torch.Generator().manual_seed(n)
+    feats["sc_ca_t"] = (9.0 * torch.randn(1, n, 3, generator=gen)).cuda().to(feats["sc_ca_t"].dtype)
+    padded, _ = sharding.pad_item(feats, item[3], n_pad)
+    padded["t"] = feats["t"]
+    keys = ("rigids", "psi", "rot_score", "trans_score", "atom37")
+    one = {k: v.clone() for k, v in net(feats).items() if k in keys}
+    two = net(padded)
+    for k in keys:
+        assert torch.equal(two[k][:, :n], one[k]), (k, float((two[k][:, :n] - one[k]).abs().max()))
+    assert float(two["rigids"][:, n:, 4:].abs().max()) < 1e30  # (padded rows: finite, never read back)
