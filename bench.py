@@ -23,9 +23,14 @@ inference_fn issues them (chunked graph replays).  Inputs, weights and the noise
 Every sample draws x_T and its noise tape from its own stream (seed + global sample index, framedipt_amd/sharding.py).
 
 Also on the JSON line:
+  loop         : how the timed steps were issued — the default product path (inference.ReverseLoop: cursor-addressed launches replayed
+                 as HIP graphs; `--eager`: launch by launch), host time per step, set-up and graph capture before the timed region.
   roofline     : the dominant kernel (EdgeTransition, 89 % of the reference FLOPs) timed with HIP events recorded by the library
-                 on the launch stream around its launches in up to 16 steps of the timed region, read back after the region;
-                 achieved = reference-formulation FLOPs per launch / duration (executed FLOPs stated beside it).
+                 on the launch stream around its launches in 4 (K <= 32) or 16 steps of the timed region — those steps are enqueued
+                 launch by launch through the same step cursor (events inside a captured graph cannot be timed on ROCm) —, read back
+                 after the region; achieved = reference-formulation FLOPs per launch / duration (executed FLOPs stated beside it).
+  all_samples_one_gpu : c4 on one GPU only — all 64 samples of BASELINE configs[3] in one batch, a few steps, own roofline.
+  (flat copies: whole_forward_frac, fp32_value / fp32_ms_per_step / fp32_whole_forward_frac, all64_value / ... for parsers that keep top-level keys)
   cpu_baseline : the oracle loop with a torch-CPU forward (oracle/torch_port.py) on this box's host cores: best thread count of a short scan,
                  all physical cores and one thread; bounded sample, rank 0, N = 1 only.
   reference_precision : the same workload in fp32 (the reference's arithmetic) for a few steps: value + roofline of that mode.
