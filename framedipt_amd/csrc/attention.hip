@@ -678,6 +678,66 @@ int fd_opair(int precision, const OPairArgs& a, hipStream_t st) {
   return precision == FDIPT_PREC_F32 ? launch_opair<float>(a, st) : launch_opair<half_t>(a, st);
 }
 
+// ------------------------------------------------------------------ o_pair from the producer-emitted pair_z image (round 6)
+// o_pair[i, h, :] = sum_j a[h, i, j] pair_z[i, j, :] (ipa_pytorch.py:317-322) where pair_z = down_z(z) + b was written by the kernel that
+// produced z (edge embedder epilogue for block 0, EdgeTransition epilogue after: kernels.hpp fd_pz_bytes) — 64 B per pair instead of the
+// 256 B of z that opair_mfma_kernel streams (184 -> 46 MB per call at N = 300, B = 8).  One wave per residue row (b, i): D[h, d] over
+// k-steps of 16 keys; A = the attention weights (half-precision rows [b, i, h, probs_np] from attention3, head rows 0..7 of the 32-row tile),
+// B = two 8 B pieces of the image per lane (key groups 4 s + 2 (lane >> 5) and + 1 of k-step s).  No LDS, no barrier; every load of a pass of
+// OP_KS k-steps is requested before the first MFMA.
+#define OP_KS 20
+__global__ __launch_bounds__(FD_THREADS) void opair_pz_kernel(OPairArgs a, int n_rows, int NJ4) {
+  const int lane = threadIdx.x & 63, li = lane & 31, hi = lane >> 5;
+  const int row = blockIdx.x * (FD_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int ksteps = (a.N + 15) >> 4;
+  const half_t* pr = a.probs_h16 + ((long)row * 8 + (li & 7)) * a.probs_np + 8 * hi;
+  const char* pzr = (const char*)a.pz + (long)row * NJ4 * 256 + li * 8;
+  typedef unsigned long long u64;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  for (int s0 = 0; s0 < ksteps; s0 += OP_KS) {
+    u16x8 af[OP_KS];
+    u64 b0[OP_KS], b1[OP_KS];
+#pragma unroll
+    for (int u = 0; u < OP_KS; ++u) {
+      const int s = s0 + u, g4 = 4 * s + 2 * hi;
+      af[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      b0[u] = b1[u] = 0ull;
+      if (s < ksteps) {
+        if (li < 8) af[u] = *(const u16x8*)(pr + 16 * s);
+        if (g4 < NJ4) b0[u] = *(const u64*)(pzr + (long)g4 * 256);
+        if (g4 + 1 < NJ4) b1[u] = *(const u64*)(pzr + (long)(g4 + 1) * 256);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < OP_KS; ++u) {
+      if (s0 + u < ksteps) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        const hx8 bf = __builtin_bit_cast(hx8, u64x2{b0[u], b1[u]});
+        if (u & 1) acc1 = fd_mfma32(__builtin_bit_cast(hx8, af[u]), bf, acc1);
+        else acc0 = fd_mfma32(__builtin_bit_cast(hx8, af[u]), bf, acc0);
+      }
+    }
+  }
+  // D[h, d]: lane (d = li, hi) holds heads 4 hi + r in registers r < 4
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = acc0[r] + acc1[r];
+    const long o = (long)row * a.out_ld + a.off + (4 * hi + r) * 32 + li;
+    if (a.out_h16) a.out_h16[o] = f2h(v);
+    else a.out[o] = v;
+  }
+}
+int fd_opair_pz(const OPairArgs& a, hipStream_t st) {
+  if (!a.pz || !a.probs_h16 || a.H != 8 || a.CD != 32 || (a.probs_np & 7) || a.probs_np < ((a.N + 15) & ~15)) return FDIPT_EINVAL;
+  const int n_rows = a.B * a.N;
+  hipLaunchKernelGGL(opair_pz_kernel, dim3(cdiv(n_rows, FD_THREADS / 64)), dim3(FD_THREADS), 0, st, a, n_rows, (a.N + 3) >> 2);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
+
 // ------------------------------------------------------------------ projected points -> global frame
 
 __device__ __forceinline__ int pt_perm16(int pos) { return 4 * (pos >> 3) + (pos & 3) + 8 * ((pos & 7) >> 2); }

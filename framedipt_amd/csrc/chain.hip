@@ -47,6 +47,12 @@ int fd_chain_build_image_lo(const float* w, int N, int K, int ldw, void* img, hi
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }
+int fd_chain_build_image_ex(const float* w, int N, int K, int ldw, int permuted, int lo, void* img, hipStream_t st) {
+  const int NT = (N + 31) / 32, KS = (K + 15) / 16;
+  hipLaunchKernelGGL(chain_image_kernel, dim3(64), dim3(256), 0, st, w, N, K, ldw, permuted, NT, KS, 1.0f, lo, (half_t*)img);
+  FD_CHECK_LAUNCH();
+  return FDIPT_OK;
+}
 // Fragment image for v_mfma_f32_16x16x32_f16 (16-row node-path blocks, rowblock.hip: tfmr_tail16_kernel): tiles of 16 output features,
 // k-steps of 32 — element (T, s, lane, e) = W[16 T + lane % 16][32 s + 8 (lane / 16) + e]; lo = 1: the image of W - half(W).
 // Same size as the 32-row image of the matrix.  Needs N % 16 == 0; K is zero-padded to Kpad (a multiple of 32).

@@ -13,6 +13,8 @@
 #include "kernels.hpp"
 
 #define ET2_CZ 128
+#define EE2_WBC 2048     // compact linear_b image of the first block (8 head rows); then a 64 B zero unit, the hi / lo down_z images (8 KB each)
+#define EE2_EPI_IMG (EE2_WBC + 64 + 2 * 8192 + 128)  // ... and the down_z bias [32] f32
 
 // logical (row, 16-byte chunk) -> byte offset inside a weight image (bank-conflict-free ds_read_b128)
 __host__ __device__ __forceinline__ int et2_off_wide(int row, int c, int row_bytes) {
@@ -79,11 +81,15 @@ __device__ __forceinline__ void ee_hand_off(const f32x16& acc, hx8& h0, hx8& h1)
 }
 // LayerNorm epilogue of the embedder in packed fp32 math (one pass: sum and sum of squares; the layer bias is already in Y):
 // same staging / stores / pair-bias emission as ln_epilogue_staged
+// pz_tile (round 6): when set, the epilogue also emits pair_z = down_z(z') + b of the first block's IPA for this row's 32 keys (8 key
+// groups of 256 B, layout fd_pz_bytes; groups >= ng_valid are beyond N): z' is the A operand of these MFMAs, so a lane (d, half) ends
+// up with four consecutive keys per register quad = 8 B of the image; hi + lo weight fragments follow the compact linear_b image in LDS
 template <bool TRACE>
 __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamma_l, const float* beta_l, float em, int li, int hi,
                                                int lane, char* stage, half_t* __restrict__ z_tile, int nvalid,
                                                float* __restrict__ tr_row, bool valid, const char* wb_lds, const f32x4 bbv,
-                                               float* __restrict__ bias_out, int H, long bidx, int ii, int jj, int nt) {
+                                               float* __restrict__ bias_out, int H, long bidx, int ii, int jj, int nt,
+                                               half_t* __restrict__ pz_tile, int ng_valid) {
   ee_f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -139,8 +145,11 @@ __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamm
   const bool full = nvalid == 32;  // wave-uniform: 9 of 10 tiles at N = 300 take the branch-free stores
   if (wb_lds) {
     hx8 wf[8];
+    {  // compact image (8 head rows): lanes >= 8 read the zero unit behind it
+      const int wl = li < 8 ? hi * 128 + li * 16 : EE2_WBC, ws = li < 8 ? 256 : 0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) wf[s] = lds_frag(wb_lds, s * 1024 + lane * 16);
+      for (int s = 0; s < 8; ++s) wf[s] = lds_frag(wb_lds, wl + s * ws);
+    }
     __builtin_amdgcn_sched_barrier(0);
     f32x16 accb;
 #pragma unroll
@@ -156,6 +165,27 @@ __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamm
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (4 * hi + r < H) bo[r * hstride] = accb[r] + bbv[r];
+    }
+    if (pz_tile) {
+      const char* dzh = wb_lds + EE2_WBC + 64;
+      const float bd = *(const float*)(dzh + 2 * 8192 + 4 * li);
+      f32x16 accd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[r] = bd;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {  // hi image, then lo image: 8 fragments each, requested a batch ahead of their MFMAs
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wf[s] = lds_frag(dzh, h2 * 8192 + s * 1024 + lane * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) accd = fd_mfma32(__builtin_bit_cast(hx8, zB[s]), wf[s], accd);
+      }
+      // registers 4 g .. 4 g + 3 = keys 8 g + 4 hi + q of the tile = key group 2 g + hi, channel d = li
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const ee_u32x2 ow = {ee_cvt_pk(accd[4 * g], accd[4 * g + 1]), ee_cvt_pk(accd[4 * g + 2], accd[4 * g + 3])};
+        if (2 * g + hi < ng_valid) *(ee_u32x2*)(pz_tile + ((2 * g + hi) * 32 + li) * 4) = ow;
+      }
     }
   }
   if (full) {
@@ -230,7 +260,8 @@ __device__ unsigned ee2_prof[256 * 8];
 #endif
 #define EE2_MAXB 63      // distogram bins (edges in LDS)
 #define EE2_MAXB_LDS 39  // ... with the table rows in LDS as well (20 KB)
-#define EE2_LDS_BASE (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + 8192 + 256)  // ... + linear_b image of the first block + distogram edges
+#define EE2_LDS_BASE (2 * EE2_IMG + 8 * 8192 + 4 * ET2_CZ * 4 + EE2_EPI_IMG + 256)  // ... + the epilogue's images + distogram edges
+#define EE2_LDS_MAX 163840
 template <bool DLDS, bool TRACE>
 __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedArgs a, const char* __restrict__ img, int nt, int wpg,
                                                                      int rpw, int n_items) {
@@ -242,11 +273,17 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
   const int hi = lane >> 5, li = lane & 31;
   char* stage = smem + 2 * EE2_IMG + wave * 8192;
   float* vec = (float*)(smem + 2 * EE2_IMG + 8 * 8192);  // [b2 | b3 | gamma | beta] x 128
-  char* wbl = (char*)(vec + 4 * ET2_CZ);                 // 8 KB fragment image of linear_b (optional)
-  float* edg = (float*)(wbl + 8192);                     // [num_bins + 1] distogram edges, the last one 1e8
+  char* wbl = (char*)(vec + 4 * ET2_CZ);                 // compact image of linear_b | zero unit | down_z hi | lo | bias (all optional)
+  float* edg = (float*)(wbl + EE2_EPI_IMG);              // [num_bins + 1] distogram edges, the last one 1e8
   float* dl = edg + 64;                                  // DLDS: [num_bins + 1][128] distogram rows of the first layer
   if (tid <= a.num_bins) edg[tid] = tid < a.num_bins ? a.edges[tid] : 1e8f;
-  if (a.wb_img) et2_dma16((const char*)a.wb_img + tid * 16, wbl + (tid & ~63) * 16);
+  if (a.wb_img && tid < EE2_WBC / 16) et2_dma16((const char*)a.wb_img + tid * 16, wbl + (tid & ~63) * 16);
+  if (tid < 16) *(unsigned*)(wbl + EE2_WBC + 4 * tid) = 0u;
+  if (a.pz_out) {
+    et2_dma16((const char*)a.wdz_img + tid * 16, wbl + EE2_WBC + 64 + (tid & ~63) * 16);
+    et2_dma16((const char*)a.wdz_img_lo + tid * 16, wbl + EE2_WBC + 64 + 8192 + (tid & ~63) * 16);
+    if (tid < 32) *(float*)(wbl + EE2_WBC + 64 + 2 * 8192 + 4 * tid) = a.bdz[tid];
+  }
   for (int u = 0; u < 2 * EE2_IMG / 16 / EE2_THREADS; ++u)
     et2_dma16(img + (size_t)(u * EE2_THREADS + tid) * 16, smem + (size_t)(u * EE2_THREADS + (tid & ~63)) * 16);
   if (tid < 4 * ET2_CZ) {
@@ -415,7 +452,8 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
       const long prow = ((long)b * N + i) * N + j0;  // first pair of the tile
       ee_ln_epilogue<TRACE>(Y, vec + 2 * ET2_CZ, vec + 3 * ET2_CZ, msk_cur, li, hi, lane, stage, (half_t*)a.z_out + prow * ET2_CZ, nvalid,
                      TRACE ? a.trace + (prow + (valid ? li : 0)) * ET2_CZ : nullptr, valid, a.wb_img ? wbl : nullptr, bbv,
-                     a.bias_out, a.H, b, i, j0 + li, nt);
+                     a.bias_out, a.H, b, i, j0 + li, nt,
+                     a.pz_out ? a.pz_out + (((long)b * N + i) * ((N + 3) >> 2) + (j0 >> 2)) * 128 : nullptr, (nvalid + 3) >> 2);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       request(i_next, rel_next, EE2_EARLY, 16);
@@ -430,7 +468,8 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
 
 int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
   if (a.num_bins > EE2_MAXB || a.num_bins < 3) return FDIPT_EINVAL;
-  const bool dlds = a.num_bins <= EE2_MAXB_LDS;
+  if (a.pz_out && (!a.wb_img || !a.wdz_img || !a.wdz_img_lo || !a.bdz)) return FDIPT_EINVAL;
+  const bool dlds = a.num_bins <= EE2_MAXB_LDS && EE2_LDS_BASE + (a.num_bins + 1) * ET2_CZ * 4 <= EE2_LDS_MAX;  // (else the distogram rows come from L2)
   const int lds = EE2_LDS_BASE + (dlds ? (a.num_bins + 1) * ET2_CZ * 4 : 0);
   typedef void (*kern_t)(EdgeEmbedArgs, const char*, int, int, int, int);
   static const kern_t kerns[4] = {edge_embed2_kernel<false, false>, edge_embed2_kernel<false, true>, edge_embed2_kernel<true, false>,
@@ -439,8 +478,7 @@ int fd_edge_embed2(const EdgeEmbedArgs& a, const void* img, hipStream_t st) {
   static FdPerDevice attr_dev[4];
   const int dev_ = fd_device();
   if (!attr_dev[kid].get(dev_)) {
-    if (hipFuncSetAttribute((const void*)kerns[kid], hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EE2_LDS_BASE + (EE2_MAXB_LDS + 1) * ET2_CZ * 4) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)kerns[kid], hipFuncAttributeMaxDynamicSharedMemorySize, EE2_LDS_MAX) != hipSuccess)
       return FDIPT_ELAUNCH;
     attr_dev[kid].set(dev_, 1);
   }

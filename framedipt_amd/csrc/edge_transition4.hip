@@ -26,6 +26,9 @@
 #ifndef E4_ABL
 #define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 16 (flat) no LDS fragment reads
 #endif
+#ifndef E4_PZ_ABL
+#define E4_PZ_ABL 0  // timing ablations of the pair_z emission (wrong results): 1 no lo part, 2 lo part from the hi image in LDS (no L2 loads), 4 no pair_z stores
+#endif
 #ifndef E4_D1
 #define E4_D1 3   // weight-fragment ring depths: layer 1, layer 2, final layer
 #endif
@@ -43,18 +46,18 @@
 #define E4_THREADS (64 * E4_WAVES)
 #ifdef E4_FAKE2  // TIMING ONLY (wrong results): the LDS footprint of a two-blocks-per-CU design with the present chunk sizes —
 #define E4_BUF 16384   // the chunks overlap each other and the z rows
-#define E4_WBI 2048
 #else
 #define E4_BUF 32768
-#define E4_WBI 8192
 #endif
+#define E4_WBI (2048 + 64 + 8192)  // linear_b image, compact (8 head rows) | 16 B of zeros (+ pad) | down_z image (hi part) of the next block
 #define E4_L1_FR (12 * 8)    // fragments (1 KB): layer 1, 12 tiles x 8 k-steps (K = 128: z)
 #define E4_L2_FR (12 * 24)   // layer 2, 12 tiles x 24 k-steps
 #define E4_LF_FR (32 * 4)    // final layer, k-major: 32 k-steps (8 z + 24 h2) x 4 tiles
 #define E4_STREAM_BYTES ((E4_L1_FR + E4_L2_FR + E4_LF_FR) * 1024)
 #define E4_ZOFF (2 * E4_BUF)                 // per-wave z rows [8][32 rows x 256 B]
-#define E4_VOFF (E4_ZOFF + E4_WAVES * 8192)         // b2[384] | gamma[128] | beta[128] f32, then linear_b image (8 KB)
-#define E4_SOFF (E4_VOFF + 1536 + 1024 + E4_WBI)  // per-wave output staging [8][32 rows x 64 B]
+#define E4_VOFF (E4_ZOFF + E4_WAVES * 8192)         // b2[384] | gamma[128] | beta[128] | down_z bias [32] f32, then the epilogue's images (E4_WBI)
+#define E4_VEC_BYTES (1536 + 1024 + 128)
+#define E4_SOFF (E4_VOFF + E4_VEC_BYTES + E4_WBI)  // per-wave output staging [8][32 rows x 64 B]
 #define E4_MOFF (E4_SOFF + E4_WAVES * 2048)          // per-lane pair masks of the current tile [512] f32
 #define E4_BOFF (E4_MOFF + E4_THREADS * 4)              // bias of linear_b [8] f32
 #define E4_LDS (E4_BOFF + 32)
@@ -122,11 +125,12 @@ int fd_et4_build_stream(const float* w1, const float* w2, const float* wf, void*
 }
 size_t fd_et4_stream_bytes() { return E4_STREAM_BYTES; }
 
-// linear_b of the NEXT block's attention (ipa_pytorch.py:247,256-257) as 8 fragments [k-step][lane][8]: row = head (H of 32
-// used), k in the hand-off order of the LayerNorm output tiles; `scale` = sqrt(1/3)
+// linear_b of the NEXT block's attention (ipa_pytorch.py:247,256-257) as 8 A fragments of a 32-row tile of which only the H <= 8 head
+// rows exist: [k-step][lane half][8 rows][8] = 2 KB (round 6: the other 24 rows were 6 KB of zeros in LDS; lanes f >= 8 read one shared
+// 16 B zero unit instead), k in the hand-off order of the LayerNorm output tiles; `scale` = sqrt(1/3)
 __global__ void et4_bias_image_kernel(const float* __restrict__ wb, int H, float scale, half_t* __restrict__ img) {
-  for (int g = threadIdx.x; g < 8 * 64; g += blockDim.x) {
-    const int s = g >> 6, lane = g & 63, f = lane & 31, half = lane >> 5;
+  for (int g = threadIdx.x; g < 8 * 16; g += blockDim.x) {
+    const int s = g >> 4, half = (g >> 3) & 1, f = g & 7;
     for (int e = 0; e < 8; ++e)
       img[g * 8 + e] = f < H ? f2h(wb[f * E4_CZ + 32 * (s >> 1) + e4_chain_feat(s & 1, half, e)] * scale) : (half_t)0;
   }
@@ -307,6 +311,7 @@ struct E4Epi {
 };
 struct E4EpiTmp {     // lives inside one epilogue run only
   f32x16 accb;        // pair bias of the next block, accumulated tile by tile
+  f32x16 accd;        // pair_z = down_z(z') of the next block's IPA, transposed: D[pair, d] (PZ kernels)
   f32x2 sa, sc;       // rstd, -mu * rstd (both halves equal)
   float s1, s2;
   long prow;          // this lane's pair (row of z)
@@ -323,8 +328,13 @@ typedef __attribute__((address_space(3))) e4_u32x2* e4_lds_w64;
 __device__ __forceinline__ float e4_both_halves(float x, int lane) {
   return x + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x)));
 }
-template <int SLOT>
-__device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M) {
+// PZ (round 6): the epilogue also emits pair_z = down_z(z') + b of the NEXT block's IPA (ipa_pytorch.py:158,318: o_pair = sum_j a_ij pair_z_ij)
+// as half precision [row][j / 4][32 d][4 j] (ET2Args.pz_out), so that opair_pz_kernel reads 64 B per pair instead of the 256 B of z'.
+// z' is the A operand here (D[pair, d]: a lane ends up with four consecutive j of one row i for its d = 8 B of the image, no transposition);
+// weights hi + lo (the rounding of W_dz is shared by all keys of a row: tests/err_budget.py `opair.w`), hi fragments in LDS, lo
+// fragments DL[8] from L2 (requested with the next tile's fold fragments: no LDS left for them)
+template <int SLOT, bool PZ>
+__device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M, const hx8* DL) {
   const int p = lane & 31, half = lane >> 5;
   if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math); the pair mask is requested here
     // the pair mask comes from LDS (parked there at the start of the tile): a global load here would be waited for with
@@ -359,6 +369,11 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) X.accb[r] = 0.f;
+    if constexpr (PZ) {  // D[pair, d] starts as the bias of down_z (this lane's d = p)
+      const float bd = *(const __attribute__((address_space(3))) float*)(unsigned long)(vec + 4 * (E4_H + 2 * E4_CZ + p));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X.accd[r] = bd;
+    }
   } else if constexpr (SLOT >= 2 && SLOT < 6) {  // one 32-feature tile: normalise, mask, bf16, store, its share of the pair bias
     constexpr int t = SLOT - 2;
     const unsigned gml = vec + 4 * (E4_H + 4 * half + 32 * t);
@@ -400,10 +415,19 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
         for (int k = 0; k < 2; ++k) *(f32x4*)(tr_row + 8 * k) = f32x4{o[2 * k][0], o[2 * k][1], o[2 * k + 1][0], o[2 * k + 1][1]};
       }
     }
-    if (a.wb_img) {  // D[head, pair] += Wb[:, this tile's features] z'
+    if (a.wb_img) {  // D[head, pair] += Wb[:, this tile's features] z'  (compact image: lanes >= 8 read the zero unit)
+      const unsigned wl = p < 8 ? wbi + half * 128 + p * 16 : wbi + 2048, ws = p < 8 ? 256u : 0u;
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2)
-        X.accb = fd_mfma32(e4_frag(wbi + (2 * t + h2) * 1024 + lane * 16), __builtin_bit_cast(hx8, zB[h2]), X.accb);
+        X.accb = fd_mfma32(e4_frag(wl + (2 * t + h2) * ws), __builtin_bit_cast(hx8, zB[h2]), X.accb);
+    }
+    if constexpr (PZ) {  // D[pair, d] += z' Wdz[d, this tile's features]  (hi from LDS, lo from registers)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(wbi + 2048 + 64 + (2 * t + h2) * 1024 + lane * 16), X.accd);
+        if (E4_PZ_ABL & 2) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(wbi + 2048 + 64 + (2 * t + h2) * 1024 + (lane ^ 1) * 16), X.accd);
+        else if (!(E4_PZ_ABL & 1)) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), DL[2 * t + h2], X.accd);
+      }
     }
     // read the staged tile back as 64 B row segments (the LDS operations of one wave execute in order: no barrier) and store
 #pragma unroll
@@ -427,6 +451,17 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
           if (4 * half + r < a.H) bo[r * hstride] = X.accb[r] + bbv[r];
       }
     }
+    if constexpr (PZ) {
+      // registers 4 g .. 4 g + 3 = pairs 8 g + 4 half + q = patch row 2 g + half, columns 4 jt .. + 3: 8 B of the image at [row][jt][d = p]
+      const int NJ4 = a.N >> 2;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 8 * E.t.rt + 2 * g + half;
+        const e4_u32x2 ow = {fd_cvt_pk(X.accd[4 * g], X.accd[4 * g + 1]), fd_cvt_pk(X.accd[4 * g + 2], X.accd[4 * g + 3])};
+        if (E.t.valid && row < M && (!(E4_ABL & 8) || row == -12345) && (!(E4_PZ_ABL & 4) || row == -12345))
+          *(e4_u32x2*)(a.pz_out + (((long)row * NJ4 + E.t.jt) * 32 + p) * 4) = ow;
+      }
+    }
   }
 }
 
@@ -435,7 +470,7 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_ker
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
   const unsigned vec = lds0 + E4_VOFF;          // b2[384] | gamma[128] | beta[128] (f32)
-  const unsigned wbi = lds0 + E4_VOFF + 2560;   // linear_b fragments of the next block
+  const unsigned wbi = lds0 + E4_VOFF + E4_VEC_BYTES;   // linear_b fragments of the next block
   // the lane index is recomputed where needed (v_mbcnt: no register carried through the tile), the wave index is scalar:
   // every register that stays live through layer 2 is a spill, and a spilled dword is 256 B of HBM traffic per wave and tile
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -461,10 +496,8 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_ker
     const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
     e4_dma16(src, vec + (tid0 & ~63) * 16);
   }
-  if (a.wb_img)
-#pragma unroll
-    for (int u = 0; u < 512 / E4_THREADS; ++u)
-      e4_dma16((const char*)a.wb_img + (u * E4_THREADS + tid0) * 16, wbi + (u * E4_THREADS + (tid0 & ~63)) * 16);
+  if (a.wb_img && tid0 < 128) e4_dma16((const char*)a.wb_img + tid0 * 16, wbi + (tid0 & ~63) * 16);  // compact image (2 KB)
+  if (tid0 < 4) *(__attribute__((address_space(3))) unsigned*)(unsigned long)(wbi + 2048 + tid0 * 4) = 0u;  // the zero unit
   // fold fragments of the first layer-1 chunk (tiles 0..2): lanes < 32 read the row image, lanes >= 32 the column image
   // 32-bit byte offset from the row image (the column image follows it in the same workspace): one register, scalar base
   auto fold_ptr = [&](const E4Tile& t, int lane) {
@@ -622,13 +655,13 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_ker
       X.moff = lds0 + E4_MOFF + tid * 4;
       X.boff = lds0 + E4_BOFF;
       const unsigned stg = lds0 + E4_SOFF + wave * 2048;
-      e4_epi<0>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<1>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<2>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<3>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<4>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<5>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<6>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<0, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
+      e4_epi<1, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
+      e4_epi<2, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
+      e4_epi<3, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
+      e4_epi<4, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
+      e4_epi<5, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
+      e4_epi<6, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
     } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
     E4_STAMP(4);
     if (!has_next) break;
@@ -713,11 +746,12 @@ __device__ __forceinline__ void e4_point(const E4Flat& F, int c) {
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   } while (0)
 
+template <bool PZ>
 __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_flat_kernel(ET2Args a, int n_tiles, int n_wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
   const unsigned vec = lds0 + E4_VOFF;
-  const unsigned wbi = lds0 + E4_VOFF + 2560;
+  const unsigned wbi = lds0 + E4_VOFF + E4_VEC_BYTES;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   auto lane_id = [] {
     int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -738,14 +772,17 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
   e4_request_z(a, tc, lane0, lds0 + E4_ZOFF + wave * 8192, M);
 #pragma unroll
   for (int c = 0; c < 3; ++c) e4_dma_chunk<E4_CHUNK>(stream + c * E4_CHUNK, lds0 + c * E4_CHUNK, tid0, wave);
-  if (tid0 < 160) {
-    const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
+  if (tid0 < (PZ ? 168 : 160)) {
+    const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : (tid0 < 160 ? a.beta + 4 * (tid0 - 128) : a.bdz + 4 * (tid0 - 160)));
     e4_dma16(src, vec + (tid0 & ~63) * 16);
   }
-  if (a.wb_img)
+  if (a.wb_img && tid0 < 128) e4_dma16((const char*)a.wb_img + tid0 * 16, wbi + (tid0 & ~63) * 16);  // compact image (2 KB)
+  if (tid0 < 4) *(__attribute__((address_space(3))) unsigned*)(unsigned long)(wbi + 2048 + tid0 * 4) = 0u;  // the zero unit
+  if constexpr (PZ) {  // down_z of the next block: hi image (8 KB) behind the zero unit
 #pragma unroll
     for (int u = 0; u < 512 / E4_THREADS; ++u)
-      e4_dma16((const char*)a.wb_img + (u * E4_THREADS + tid0) * 16, wbi + (u * E4_THREADS + (tid0 & ~63)) * 16);
+      e4_dma16((const char*)a.wdz_img + (u * E4_THREADS + tid0) * 16, wbi + 2048 + 64 + (u * E4_THREADS + (tid0 & ~63)) * 16);
+  }
   auto fold_ptr = [&](const E4Tile& t, int lane) {
     const unsigned fold_b1 = (unsigned)((const char*)a.b1_img - (const char*)a.a1_img);
     const unsigned ob = fold_b1 + (unsigned)((t.b0 * NJ4 + t.jt) * 16) * 512u, oa = (unsigned)(t.rt * 16) * 512u;  // scalar
@@ -877,18 +914,22 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
     for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
     E.t = tc;
     em_req = mask_of(tn, lane);
+    hx8 DL[PZ ? 8 : 1];  // lo fragments of down_z for the epilogue (L2 hits, in flight under its LayerNorm statistics)
+    if constexpr (PZ && !(E4_PZ_ABL & 3))
+#pragma unroll
+      for (int k = 0; k < 8; ++k) DL[k] = e4_gfrag((const char*)a.wdz_img_lo + k * 1024 + lane * 16);
     if (!(E4_ABL & 1)) {
       E4EpiTmp X;
       X.moff = lds0 + E4_MOFF + tid * 4;
       X.boff = lds0 + E4_BOFF;
       const unsigned stg = lds0 + E4_SOFF + wave * 2048;
-      e4_epi<0>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<1>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<2>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<3>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<4>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<5>(E, X, a, lane, vec, wbi, stg, M);
-      e4_epi<6>(E, X, a, lane, vec, wbi, stg, M);
+      e4_epi<0, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<1, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<2, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<3, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<4, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<5, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<6, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
     } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
     E4_STAMP(4);
     if (!has_next) break;
@@ -938,7 +979,8 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   static FdPerDevice attr_dev;
   const int dev_ = fd_device();
   if (!attr_dev.get(dev_)) {
-    if (hipFuncSetAttribute((const void*)edge_transition4_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
       return FDIPT_ELAUNCH;
 #if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)
     if (hipFuncSetAttribute((const void*)edge_transition4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
@@ -955,7 +997,11 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   if (!flat) hipLaunchKernelGGL(edge_transition4_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
   else
 #endif
-    hipLaunchKernelGGL(edge_transition4_flat_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
+  if (a.pz_out) {  // + pair_z of the next block (needs its bias emission: the zero unit / images share its set-up)
+    if (!a.wb_img || !a.wdz_img || !a.wdz_img_lo || !a.bdz) return FDIPT_EINVAL;
+    hipLaunchKernelGGL(edge_transition4_flat_kernel<true>, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
+  } else
+    hipLaunchKernelGGL(edge_transition4_flat_kernel<false>, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
   FD_CHECK_LAUNCH();
   return FDIPT_OK;
 }

@@ -45,6 +45,11 @@ struct EdgeEmbedArgs {
   float* bias_out;
   int H;
   int reserve_cus = 0;  // persistent kernel: CUs left to launches of other streams (FdiptForwardArgs.reserve_cus)
+  // optional (half-precision kernel with wb_img set; round 6): pair_z of the FIRST block's IPA, as ET2Args
+  const void* wdz_img = nullptr;
+  const void* wdz_img_lo = nullptr;
+  const float* bdz = nullptr;
+  half_t* pz_out = nullptr;
 };
 
 struct AttnArgs {
@@ -86,6 +91,7 @@ struct OPairArgs {
   long out_ld;
   int off;
   L2Warm warm = {};  // weights of the kernel launched next (common.hpp: L2 warm-up hand-over)
+  const half_t* pz = nullptr;  // round 6: pair_z image of this block (fd_pz_bytes) written by the producer of z -> opair_pz_kernel (z, wdz* unused)
 };
 
 struct PointsArgs {
@@ -151,7 +157,16 @@ struct ET2Args {
   const void* b1_img;   // [B][N/4][16][32][8] bf16: B1 | Bf rows (e_j columns) of 4 consecutive j (+ the next sample's)
   int reserve_cus = 0;  // persistent kernels: CUs left to launches of other streams (FdiptForwardArgs.reserve_cus)
   unsigned long long* clock = nullptr;  // optional shader-clock probe (FdiptForwardArgs.clock_out)
+  // optional (edge_transition4 with wb_img set; round 6): pair_z = down_z(z') + b of the NEXT block's IPA (ipa_pytorch.py:158,318) from the
+  // same epilogue, as the image opair_pz_kernel reads (fd_pz_bytes): 64 B per pair instead of a second pass over the 256 B of z'
+  const void* wdz_img = nullptr;     // down_z [32, 128] as a fragment image, k in hand-off order (fd_chain_build_image_ex(.., permuted = 1, lo = 0))
+  const void* wdz_img_lo = nullptr;  // ... of Wdz - half(Wdz) (lo = 1)
+  const float* bdz = nullptr;        // [32]
+  half_t* pz_out = nullptr;          // [B*N][N/4][32][4]
 };
+// pair_z image: [flattened residue row b N + i][key group j / 4][channel d < 32][key j % 4] half precision; a 32x32x16 MFMA B fragment of
+// opair_pz_kernel is two 8 B pieces per lane (groups 4 s + 2 (lane >> 5), + 1 of k-step s), its producers write whole 256 B groups
+static inline size_t fd_pz_bytes(int B, int N) { return (size_t)B * N * ((N + 3) / 4) * 256; }
 // edge_transition3.hip: 16-pair waves, two waves per SIMD (any N >= 43)
 int fd_et3_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
 size_t fd_et3_stream_bytes();
@@ -335,6 +350,7 @@ int fd_chain_build_image(const float* w, int N, int K, int ldw, int permuted, vo
 // the same for W - half(W): the lo part of a weight matrix used as split operands (hi image + lo image = 22 significant bits)
 int fd_chain_build_image_lo(const float* w, int N, int K, int ldw, void* img, hipStream_t st);
 int fd_chain_build_image_scaled(const float* w, int N, int K, int ldw, int permuted, float scale, void* img, hipStream_t st);
+int fd_chain_build_image_ex(const float* w, int N, int K, int ldw, int permuted, int lo, void* img, hipStream_t st);  // any (k order, part)
 int fd_chain(int kind, const ChainArgs& a, hipStream_t st);
 
 int fd_linear(int precision, int M, int N, int K, const float* A, int lda, const void* W, int ldw, const float* bias,
@@ -367,6 +383,7 @@ int fd_ipa_attention_f32_supported(const AttnArgs& a);
 int fd_ipa_attention_f32(const AttnArgs& a, hipStream_t st);
 int fd_opair(int precision, const OPairArgs& a, hipStream_t st);
 int fd_opair_mfma_eligible(int precision, const OPairArgs& a);  // the MFMA kernel will run (it can take probs_h16)
+int fd_opair_pz(const OPairArgs& a, hipStream_t st);  // o_pair from the producer-emitted pair_z image (OPairArgs.pz, probs_h16)
 int fd_pair_bias2(int B, int N, int H, const void* z, const void* wb, const float* bb, float* out, int frag, hipStream_t st);
 // fp32 mode: out[p, h] = z[p, :] . Wb[h, :] + bb[h] over the fp32 pair representation (H = 8, c_z = 128), one streaming pass
 int fd_pair_bias_f32(long n_pairs, int H, int CZ, const float* z, const float* wb, const float* bb, float* out, hipStream_t st);

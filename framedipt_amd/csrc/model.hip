@@ -31,7 +31,7 @@ struct Switches {
   bool no_et_bias = false, no_ee_bias = false;  // pair bias as its own pass over z
   bool feats_unfused = false, torf_unfused = false, init_unfused = false, skip_per_block = false, post_unfused = false,
        no_tfmr_tail = false, et4_rows_unfused = false, no_qkv_fuse = false, proj_v1 = false, feats_f32 = false,
-       probs_f32 = false, no_l2_warm = false;
+       probs_f32 = false, no_l2_warm = false, no_pz = false;
   bool no_seq_attn = false;     // (dev) sequence attention on the LDS-score kernel only (IPA attention unchanged)
   bool no_split = false;        // node-path products on plain half-precision operands instead of split (hi + lo) ones
   bool no_merge = false;        // IPA projections in the reference's formulation (k, v explicit) instead of the merged one
@@ -55,7 +55,7 @@ static const Switches& dev_switches() {
     s.skip_per_block = on("FDIPT_SKIP_PER_BLOCK"); s.post_unfused = on("FDIPT_POST_UNFUSED");
     s.no_tfmr_tail = on("FDIPT_NO_TFMR_TAIL"); s.et4_rows_unfused = on("FDIPT_ET4_ROWS_UNFUSED");
     s.no_qkv_fuse = on("FDIPT_NO_QKV_FUSE"); s.proj_v1 = on("FDIPT_PROJ_V1"); s.feats_f32 = on("FDIPT_FEATS_F32");
-    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM"); s.no_split = on("FDIPT_NO_SPLIT"); s.no_seq_attn = on("FDIPT_NO_SEQ_ATTN");
+    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM"); s.no_split = on("FDIPT_NO_SPLIT"); s.no_seq_attn = on("FDIPT_NO_SEQ_ATTN"); s.no_pz = on("FDIPT_NO_PZ");
     if (const char* m = getenv("FDIPT_CHAIN_MASK")) s.chain_mask = (unsigned)strtoul(m, nullptr, 0);
     s.twice = getenv("FDIPT_DBG_TWICE");
     if (const char* m = getenv("FDIPT_SPLITK_NS")) s.splitk_ns = atoi(m);
@@ -176,7 +176,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wq_m, wproj2_img, wproj2_img_lo, bproj2, wout_m, bout_m, wout_img, wout_img_lo, wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo; DChain ch; DSplit lo; };
+struct DBlock { size_t wq_m, wproj2_img, wproj2_img_lo, bproj2, wout_m, bout_m, wout_img, wout_img_lo, wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo, wdz_imgp, wdz_imgp_lo; DChain ch; DSplit lo; };
 struct DLayout {
   size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -246,9 +246,11 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb_img = o; o = al256(o + 8192);  // linear_b as a 32 x 128 MFMA fragment image (edge_transition2 epilogue)
     L.blk[b].wb_img3 = o; o = al256(o + 4096);  // ... as 16 x 128 (edge_transition3 epilogue)
-    L.blk[b].wb_img4 = o; o = al256(o + 8192);  // ... as 32 x 128 in edge_transition4's hand-off order
+    L.blk[b].wb_img4 = o; o = al256(o + 8192);  // ... compact (8 head rows: 2 KB) in the hand-off order of edge_transition4 / edge_embed2
     L.blk[b].wdz_img = o; o = al256(o + 8192);  // down_z [c_z/4, c_z] as a bf16 fragment image (MFMA o_pair kernel)
     L.blk[b].wdz_img_lo = o; o = al256(o + 8192);  // ... and of Wdz - half(Wdz)
+    L.blk[b].wdz_imgp = o; o = al256(o + 8192);     // ... both with k in the hand-off order of the LayerNorm epilogues that emit pair_z (round 6)
+    L.blk[b].wdz_imgp_lo = o; o = al256(o + 8192);
     L.blk[b].wdz_t = o; o = al256(o + (size_t)d->c_z * (d->c_z / 4) * 4);
     L.blk[b].et3 = o;
     if (use_regpair(d) && b < d->num_blocks - 1) o = al256(o + fd_et3_stream_bytes());
@@ -512,7 +514,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
     FD_CHECK_LAUNCH();
     if (cz == 128 && ((rc = fd_chain_build_image(P + k.dz.w, cz / 4, cz, cz, 0, D + db.wdz_img, st)) ||
-                      (rc = fd_chain_build_image_lo(P + k.dz.w, cz / 4, cz, cz, D + db.wdz_img_lo, st))))
+                      (rc = fd_chain_build_image_lo(P + k.dz.w, cz / 4, cz, cz, D + db.wdz_img_lo, st)) ||
+                      (rc = fd_chain_build_image_ex(P + k.dz.w, cz / 4, cz, cz, 1, 0, D + db.wdz_imgp, st)) ||
+                      (rc = fd_chain_build_image_ex(P + k.dz.w, cz / 4, cz, cz, 1, 1, D + db.wdz_imgp_lo, st))))
       return rc;
     if (use_regpair(d) && b < d->num_blocks - 1)
       if ((rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)) ||
@@ -643,7 +647,7 @@ int fdipt_sample_setup(const FdiptDims* d, const float* P, const void* derived, 
 // ------------------------------------------------------------------ workspace
 struct WS {
   size_t node_feat, pte, pi, pj, h_a, h_b, node0, node, z, quat, trans, dmask, rot, proj, qp, kp, vp, bias, probs, feats,
-      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, skip_all, vt_lo, kpf, total;
+      ipa_out, tf_in, qkv, att, x_a, x_b, ff, e, upd, psi_un, a1, af, qb, kb, vt, pts, seqimg, ipa_parts, e_bf, vpt, r4, a1img, b1img, skip_all, vt_lo, kpf, pz, total;
 };
 static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, int B, int N, WS& w) {
   size_t o = 0;
@@ -684,6 +688,7 @@ static void build_ws(const FdiptDims* d, const Inventory& iv, const DLayout& L, 
   w.a1img = take(fd_et4_a_image_bytes(B, N));
   w.b1img = take(fd_et4_b_image_bytes(B, N));
   w.kpf = take((size_t)B * H * ((((size_t)N + 31) / 32)) * FD_KPF_FRAGS * 1024);  // key-point fragment image (attention3 point logits)
+  w.pz = take(use_regpair(d) ? fd_pz_bytes(B, N) : 0);  // pair_z image of the current block (round 6: written by the producer of z)
   w.total = o;
 }
 
@@ -699,9 +704,9 @@ size_t fdipt_forward_workspace_bytes(const FdiptDims* dims, int B, int N) {
   if (getenv("FDIPT_DUMP_LAYOUT")) {  // (dev) workspace layout for buffer-level diffs (tools/conc_victim_check.py)
     const char* names[] = {"node_feat", "pte", "pi", "pj", "h_a", "h_b", "node0", "node", "z", "quat", "trans", "dmask", "rot", "proj", "qp", "kp", "vp",
                            "bias", "probs", "feats", "ipa_out", "tf_in", "qkv", "att", "x_a", "x_b", "ff", "e", "upd", "psi_un", "a1", "af", "qb", "kb",
-                           "vt", "pts", "seqimg", "ipa_parts", "e_bf", "vpt", "r4", "a1img", "b1img", "skip_all", "vt_lo", "kpf", "total"};
+                           "vt", "pts", "seqimg", "ipa_parts", "e_bf", "vpt", "r4", "a1img", "b1img", "skip_all", "vt_lo", "kpf", "pz", "total"};
     const size_t* offs = &w.node_feat;
-    for (int i = 0; i < 47; ++i) fprintf(stderr, "FDIPT_LAYOUT %s %zu\n", names[i], offs[i]);
+    for (int i = 0; i < 48; ++i) fprintf(stderr, "FDIPT_LAYOUT %s %zu\n", names[i], offs[i]);
   }
 #endif
   return w.total;
@@ -843,6 +848,13 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   };
   if (a->trace_inner && (rbk || (bf && iv.feat_dim >= 1024 && !sw.no_splitk))) return FDIPT_EINVAL;  // fused node path: the tensors never exist
   bool ee_bias_done = false;
+  // Round 6: o_pair reads pair_z = down_z(z) + b (32 channels) emitted by the producer of z — the edge embedder's epilogue for block 0, the
+  // EdgeTransition epilogue of block b for block b + 1 — instead of streaming the 128 channels of z once more per block (opair_pz_kernel).
+  // Same conditions as the pair-bias emission of those epilogues, edge_transition4 only (N % 4 == 0); FDIPT_KF_UNFOLDED keeps the pass over z.
+  const bool pz_path = op.kind == OP_ALL && use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H == 8 && N <= 1024 && (N & 3) == 0 &&
+                       !sw.generic_attn && !sw.no_et_bias && !sw.no_ee_bias && !sw.et3 && !sw.no_pz && rbk && iv.cb == 128 && iv.hid == 384 &&
+                       fd_edge_transition4_supported(N);
+  bool pz_ready = false;  // the pair_z image of the coming block's IPA is in the workspace
   // ---- Embedder (score_network.py:129-197)
   // ... with the split of x_t (ipa_pytorch.py:516-524) and the per-residue halves of the first edge-embedder layer in the same
   // launch (FDIPT_FEATS_UNFUSED: three GEMM / element-wise launches more)
@@ -895,8 +907,12 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
     // the first block's pair bias linear_b(z)/sqrt(3) from the embedder's LayerNorm epilogue (saves a pass over z)
     const bool ee_bias = use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H <= 8 && N <= 1024 &&
                          !sw.generic_attn && !sw.no_et_bias && !sw.no_ee_bias;
-    ea.wb_img = ee_bias ? D + L.blk[0].wb_img : nullptr; ea.bb = (const float*)(D + L.blk[0].bb); ea.bias_out = F(w.bias); ea.H = H;
+    ea.wb_img = ee_bias ? D + L.blk[0].wb_img4 : nullptr; ea.bb = (const float*)(D + L.blk[0].bb); ea.bias_out = F(w.bias); ea.H = H;
     ee_bias_done = ee_bias;
+    if (ee_bias && pz_path) {
+      ea.wdz_img = D + L.blk[0].wdz_imgp; ea.wdz_img_lo = D + L.blk[0].wdz_imgp_lo; ea.bdz = P + iv.blk[0].dz.b; ea.pz_out = (half_t*)(W + w.pz);
+      pz_ready = true;
+    }
     if (use_regpair(d)) RC(fd_edge_embed2(ea, D + L.ee2, st));
     else RC(fd_edge_embed(prec, cz, ea, st));
   }
@@ -1061,7 +1077,10 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       else RC(fd_attention(prec, 1, aa, st));
     }
     if (op.kind == OP_IPA && sw.ipa_stop == 2) return FD_STOP;
-    TWICE("opair", fd_opair(prec, oa, st));
+    if (pz_ready && use_a3 && oa.probs_h16) {
+      oa.pz = (const half_t*)(W + w.pz);
+      TWICE("opair", fd_opair_pz(oa, st));
+    } else TWICE("opair", fd_opair(prec, oa, st));
     if (op.kind == OP_IPA && sw.ipa_stop == 3) return FD_STOP;
     // node = LN(node + ipa) lives in tf_in[:, :cs]; tf_in[:, cs:] = skip_embed(init_node)   (ipa:531-535)
     if (op.kind == OP_IPA) {  // per-op entry: linear_out(features) * mask as one GEMM (the forward sums split-K slices in its LayerNorm)
@@ -1325,6 +1344,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
       }
       float* tr_ptr = a->trace_edge ? a->trace_edge + (size_t)(b + 1) * NN * cz : nullptr;
       bias_ready = false;
+      pz_ready = false;
       if (use_et4 || use_et3) {
         ET2Args t2;
         t2.B = B; t2.N = N; t2.z_in = (const half_t*)(W + w.z); t2.z_out = (half_t*)(W + w.z); t2.e = F(w.e);
@@ -1339,6 +1359,11 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         t2.a1_img = W + w.a1img; t2.b1_img = W + w.b1img;
         t2.bb = (const float*)(D + L.blk[b + 1].bb); t2.bias_out = F(w.bias); t2.H = H; t2.reserve_cus = a->reserve_cus;
         bias_ready = emit_bias;
+        pz_ready = false;
+        if (use_et4 && emit_bias && pz_path) {
+          t2.wdz_img = D + L.blk[b + 1].wdz_imgp; t2.wdz_img_lo = D + L.blk[b + 1].wdz_imgp_lo; t2.bdz = P + iv.blk[b + 1].dz.b; t2.pz_out = (half_t*)(W + w.pz);
+          pz_ready = true;
+        }
         t2.clock = a->clock_out;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);
         if (use_et4) RC(fd_edge_transition4(t2, st));

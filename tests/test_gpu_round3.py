@@ -376,7 +376,9 @@ def test_merged_projections_equal_the_reference_formulation():
 def test_sixteen_row_node_path_kernels_equal_the_32_row_ones(name):
     """The 16-row-block kernels of the node path (tfmr_tail16_kernel, mlp16_kernel: v_mfma_f32_16x16x32_f16, default for N <= 512) against the
     32-row ones (FDIPT_KF_ROWS32) in the same library: the same products in a different grouping of the k index, so the two forwards differ by
-    fp32 summation order only — node representation after every block within 2e-5 relative, frames within 2e-5 A."""
+    fp32 summation order only — node representation after every block within 2e-5 relative, frames within 3e-5 A (2e-5 until round 6: the
+    half-precision pair_z image the EdgeTransition epilogue now emits for o_pair is one more rounding stage whose flips pass a summation-order
+    difference on; measured 2.1e-5 A at N = 128)."""
     from framedipt_amd import _lib
     from framedipt_amd import config
     from framedipt_amd.diffusion import SE3Diffuser
@@ -394,5 +396,5 @@ def test_sixteen_row_node_path_kernels_equal_the_32_row_ones(name):
     for blk in range(1, 5):
         rel = np.linalg.norm(a["trace_node"][blk] - b["trace_node"][blk]) / np.linalg.norm(b["trace_node"][blk])
         assert rel < 2e-5, (blk, rel)
-    assert np.abs(a["rigids"][..., 4:] - b["rigids"][..., 4:]).max() < 2e-5
+    assert np.abs(a["rigids"][..., 4:] - b["rigids"][..., 4:]).max() < 3e-5
     assert np.abs(a["psi"] - b["psi"]).max() < 2e-4  # (unit vectors: a small un-normalised length amplifies the 1e-5 differences)
