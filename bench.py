@@ -51,7 +51,12 @@ sys.path.insert(0, ROOT)
 
 ET_FLOPS_PER_PAIR = 688128.0   # 2*(2*384^2 + 384*128): EdgeTransition, reference formulation
 NOMINAL_GHZ = 2.4  # engine clock of PEAK_TFLOPS (MI355X_MICROARCH.md)
-ET4_EXEC_FLOPS_PER_PAIR = 536 * 32 * 32 * 16 * 2 / 32.0  # edge_transition4: 536 MFMAs of 32x32x16 per 32-pair wave tile
+# edge_transition4: 536 MFMAs of 32x32x16 per 32-pair wave tile for the three layers + 24 in the epilogue (round 6: 8 for the next block's
+# pair bias linear_b(z'), 16 for its pair_z = down_z(z') on hi + lo weights).  The reference-formulation count of the launch stays
+# ET_FLOPS_PER_PAIR: the epilogue's products are other modules' work (2 * 128 * (8 + 32) = 10,240 FLOP per pair, FUSED_FLOPS_PER_PAIR)
+# that rides on this launch, so `frac` prices a launch that now does more than it is credited for (`frac_incl_fused` credits it)
+ET4_EXEC_FLOPS_PER_PAIR = (536 + 24) * 32 * 32 * 16 * 2 / 32.0
+FUSED_FLOPS_PER_PAIR = 2.0 * 128 * (8 + 32)  # linear_b (ipa_pytorch.py:247) + down_z (:158,318) of the next block, reference formulation
 PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 
 CONFIGS = {
@@ -72,7 +77,7 @@ CONFIGS = {
 def pmc_traffic(precision: str, n: int, b: int):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (profiles/), only when the bench
     runs the profiled configuration; the counters cannot be read from inside this process."""
-    for name in ("r05_pmc_edge_transition.json", "r04_pmc_edge_transition.json", "r03_pmc_edge_transition.json", "r02_pmc_edge_transition.json", "r01_pmc_edge_transition.json"):
+    for name in ("r06_pmc_edge_transition.json", "r05_pmc_edge_transition.json", "r04_pmc_edge_transition.json", "r03_pmc_edge_transition.json", "r02_pmc_edge_transition.json", "r01_pmc_edge_transition.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -160,7 +165,8 @@ def cpu_baseline(n: int, conf, seed: int, steps: int = 10):
     per_step = el * (steps + 1 / 500) / fwd / steps  # priming forward amortised over the T = 500 steps of a trajectory
     return {"value": n / per_step, "unit": "residue*step/s", "cores": threads, "kind": "port",
             "sample": f"oracle loop with the torch-CPU forward (oracle/torch_port.py), de novo N={n}, B=1, {fwd} forwards + {steps} reverse "
-                      f"steps of the T=500 schedule ({el:.1f} s wall at torch.set_num_threads({threads}), the best of {sorted(scan)} on {cores} logical CPUs)",
+                      f"steps of the T=500 schedule ({el:.1f} s wall at torch.set_num_threads({threads}), the best of {sorted(scan)} on {cores} logical CPUs; "
+                      f"NOT an all-core figure: all {phys} physical cores are SLOWER on this forward, see all_physical_cores)",
             "all_physical_cores": {"value": n / (t_all * 501 / 500), "cores": phys, "sample": f"one forward at {phys} threads: {t_all:.2f} s"},
             "single_thread": {"value": n / (t_one * 501 / 500), "cores": 1, "sample": f"one forward at 1 thread: {t_one:.2f} s"},
             "note": "a baseline, not the target; the reference's own torch-CPU loop measured 213 residue*step/s at N=300 on 8 cores of "
@@ -237,9 +243,16 @@ def main():
         import cu_streams  # experiment helper (tools/cu_streams.py): CU-masked HIP streams
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
         torch.cuda.set_stream(cu_streams.pair(dev, n_cu - a.main_cus).main)
+    n_ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
+        # what the process group itself saw (the SCALE record can answer "did RCCL connect N ranks"): every rank contributes a one
+        ones = torch.ones(1, device="cpu" if one_gpu else dev, dtype=torch.int32)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+        if n_ranks_seen != world or dist.get_world_size() != world:
+            raise SystemExit(f"process group saw {n_ranks_seen} ranks (world size {dist.get_world_size()}), expected {world}")
 
     from framedipt_amd import _lib, config, inference, sharding
     from framedipt_amd.diffusion import SE3Diffuser
@@ -431,12 +444,16 @@ def main():
             # shader clock the kernel's blocks actually ran at (s_memtime / s_memrealtime inside the kernel): power
             # management holds it below the 2.4 GHz of `peak`; frac_at_clock prices the same FLOPs against the matrix
             # peak at that clock
+            "frac_incl_fused": (ET_FLOPS_PER_PAIR + FUSED_FLOPS_PER_PAIR) * B_ev * N * N / et / 1e12 / peak if et4 else None,
             "clock_ghz": ghz, "frac_at_clock": achieved / (peak * ghz / NOMINAL_GHZ) if ghz else None,
             "whole_forward_tflops": fwd_tflops, "whole_forward_frac": fwd_tflops / peak}
 
     PREC_MODE = {"fp16": "fp16 MFMA operands / pair representation (fp16 stands in for the bf16 BASELINE configs[1] names: same MFMA rate, "
                          "three more significand bits), split (hi+lo) operands on every per-residue product and the attention's P V, fp32 "
-                         "accumulation / frames / statistics; per-step backbone RMSD vs the reference < 1e-3 A also at bb_gain 0.3",
+                         "accumulation / frames / statistics; per-step backbone RMSD vs the reference < 1e-3 A up to trained-weight scale bb_gain 0.3 "
+                         "(0.8e-3 A worst step) and a MISS of that bar at bb_gain 0.5 (1.5e-3 A worst step: tests/test_gpu_round4.py asserts the "
+                         "measured value); 14 % of the T=500 schedule (0.011 < t < 0.15, where the reference's own fp32 IGSO(3) series is round-off) "
+                         "is checked by a property fence, not against the reference (tests/test_gpu_sizes.py)",
                  "bf16": "bf16 MFMA operands / pair representation (the -DFDIPT_HALF_BF16 build), split operands as in the fp16 mode; per-step "
                          "backbone RMSD vs the reference 1.7e-3 A worst / 4e-4 A median (teacher-forced, N=64, T=20: "
                          "tests/test_gpu_round4.py::test_bf16_build_per_step_numbers): outside the 1e-3 A parity bar, a comparison line only",
@@ -480,6 +497,7 @@ def main():
         value, roof = record(prec, K, el, et_ms, clk, B_ev, a.kernel_flags)
         out = {
             "metric": "residue*diffusion-steps/sec", "value": value, "unit": "residue*step/s", "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen, "backend": (dist.get_backend() if world > 1 else None),
             "steps": K, "warmup": a.warmup, "ms_per_step": el / K * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "config": {"workload": f"{a.config}: {'inpainting' if inp else 'de novo'} backbone sampler, "

@@ -66,7 +66,9 @@ def foreign_compute_processes(device=None, root: str = KFD):
     not found).  This process is made to own a queue first (one tiny launch), so it is one entry of the list itself — inside a PID
     namespace the list holds host PIDs and it could not be recognised by name."""
     import torch
-    idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    idx = torch.device(device).index if device is not None else None
+    if idx is None:  # no device, or an index-less "cuda": the CURRENT device, not GPU 0
+        idx = torch.cuda.current_device()
     pr = torch.cuda.get_device_properties(idx)
     gid = kfd_gpu_id(getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", 0), root)
     if gid is None:
@@ -76,7 +78,9 @@ def foreign_compute_processes(device=None, root: str = KFD):
     owners = processes_with_queues(gid, root)
     if not owners:
         return None
-    return len(owners) - 1
+    # this process owns a queue after the launch above, so it is one of the owners — but inside a PID namespace the list holds host
+    # PIDs and it cannot be told apart by name: by count, never below zero
+    return max(len(owners) - 1, 0)
 
 
 def check(device=None, policy: str | None = None, what: str = "framedipt_amd", once: bool = True, root: str = KFD):
@@ -86,11 +90,13 @@ def check(device=None, policy: str | None = None, what: str = "framedipt_amd", o
     key = (str(device), policy)
     if policy == "allow" or (once and key in _checked):
         return None
-    _checked.add(key)
     try:
         n = foreign_compute_processes(device, root)
     except Exception:  # noqa: BLE001  (a guard must not take the run down)
         return None
+    # "once" remembers CLEAN checks and issued warnings only: under `refuse` a caller that catches SharedGpuError and retries is refused again
+    if not (n and policy == "refuse"):
+        _checked.add(key)
     if n:
         msg = (f"{what}: {n} other compute process(es) hold queues on this GPU.  Kernels of two processes that share a SIMD can corrupt "
                "each other's results on this hardware (DESIGN.md section 6): run one process per GPU, or set FDIPT_SHARED_GPU=allow "

@@ -243,6 +243,7 @@ class ReverseLoop:
             finally:
                 g.capture_end()
         self.capture_seconds += time.perf_counter() - t0
+        self._captured_weights = getattr(self.model, "weights_version", 0)  # the graphs bake the weight / derived-buffer pointers in
         return g
 
     def _set_cursor(self, k):
@@ -255,8 +256,10 @@ class ReverseLoop:
     _WARM: set = set()
 
     def _warm_key(self):
-        d = self.model.dims
-        return (str(self.dev), int(d.precision), int(d.kernel_flags), self.B, self.N, bool(self.aux_traj), bool(self.bb0_from_forward))
+        # every field of FdiptDims (widths select the fused or the generic kernels) and the options that change which kernels a step
+        # launches (round-5 advisor: a second model with other widths at the same B, N was treated as warm)
+        return (str(self.dev), bytes(self.model.dims), self.B, self.N, bool(self.aux_traj), bool(self.bb0_from_forward),
+                bool(self._inpainting), self.tab_all is not None, bool(self.embed_sc), bool(self.self_condition))
 
     def prepare(self):
         """Capture the step graphs now (otherwise: lazily at the first replay).  Nothing runs on the GPU."""
@@ -272,6 +275,8 @@ class ReverseLoop:
         """Steps k .. k+n-1 (all noisy) through the cursor: launch by launch the first time a shape class runs in the process (or with
         ``eager``: bench.py's event-bracketed steps — events recorded inside a graph cannot be timed on ROCm), graph replays otherwise."""
         self._set_cursor(k)
+        if (self._g1 is not None or self._gn is not None) and self._captured_weights != getattr(self.model, "weights_version", 0):
+            self._g1 = self._gn = None  # the model's weights were (re)loaded behind this loop: its captured graphs point at freed buffers
         if eager or self._warm_key() not in self._WARM:
             for _ in range(n):
                 self._enqueue_indexed()
@@ -444,9 +449,10 @@ def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj
     node path of one sub-batch overlaps the pair kernels of the other) — experimental: needs ``experimental_streams=True`` (or
     FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``; eager launches)."""
     if streams > 1 and data_init["rigids_t"].shape[0] > 1:  # sub-batches on their own HIP streams (same results)
+        # (the sub-loops are eager ReverseLoops: verify= is passed through to them, graph= does not apply)
         loop = StreamedLoops(model, diffuser, data_init, streams, num_t, min_t, noise_tape=noise_tape, center=center, aux_traj=aux_traj,
                              self_condition=self_condition, noise_scale=noise_scale, embed_self_conditioning=embed_self_conditioning,
-                             inpainting=inpainting, input_aatype=input_aatype, experimental=experimental_streams)
+                             inpainting=inpainting, input_aatype=input_aatype, experimental=experimental_streams, verify=verify)
         loop.prime()
         for k in range(num_t):
             loop.step(k)

@@ -190,8 +190,8 @@ class ScoreNetwork:
             _lib.check(lib.fdipt_model_prepare(C.byref(self.dims), _lib.ptr(self.params), _lib.ptr(self.derived),
                                                _lib.stream_ptr()), "model_prepare")
         self._state = None
-        # captured HIP graphs (inference.GraphedTrajectory) bake the old weight / derived-buffer pointers in: drop them
-        self.__dict__.pop("_graphed_trajectories", None)
+        # step graphs captured by a live inference.ReverseLoop bake the old weight / derived-buffer pointers in: the loop compares this
+        # counter with the one it recorded at capture time and drops its graphs when they differ
         self.weights_version = getattr(self, "weights_version", 0) + 1
 
     # ------------------------------------------------------------------ batch state

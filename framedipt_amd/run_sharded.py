@@ -229,16 +229,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
     # one process per GPU is the contract: refuse a GPU that another compute process is using (the one-GPU test hook shares it on
-    # purpose and serialises its ranks with a file lock below)
+    # purpose and serialises its ranks with a file lock below).  BEFORE the rendezvous: a refusing rank then never joins the group and
+    # the launcher tears the job down, instead of the other ranks waiting in the final barrier for its time-out (round-5 advisor)
     from . import gpu_guard
     if one_gpu or a.allow_shared_gpu:
         os.environ["FDIPT_SHARED_GPU"] = "allow"
     else:
         gpu_guard.check(dev, policy=os.environ.get("FDIPT_SHARED_GPU") or "refuse", what="run_sharded")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
     inp = a.download_dir is not None
     conf = config.base_config(inpainting=inp)
     diff = SE3Diffuser(conf.diffuser, device=dev)

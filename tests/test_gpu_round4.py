@@ -51,22 +51,32 @@ def test_batch_of_eight_n300():
 
 
 # Where does the fp16 mode's per-step margin break (round-3 review)?  Measured on the MI355X (teacher-forced, N = 300, T = 5; worst step of
-# x_{t-1} / of the x_0 prediction):
-#   bb_gain 0.3, weight seed 7 (round 3's fixture): 0.78e-3 / 0.77e-3 A        bb_gain 0.3, weight seed 11: 0.37e-3 / 0.38e-3 A
-#   bb_gain 0.5, weight seed 7: 1.45e-3 / 0.98e-3 A — the bar breaks between gain 0.3 and 0.5 for this seed (one step, t = 0.2575, exceeds it)
-# (fp32 mode on the same fixtures: <= 5e-5 A.)  The bound of the mode is therefore stated per fixture: < 1e-3 A up to trained-weight scale
-# 0.3, < 2e-3 A at 0.5 (precision modes).
-FP16_MARGIN = {"full_denovo_n300_T5_gain03_seed11": 1.0e-3, "full_denovo_n300_T5_gain05": 2.0e-3}
+# x_{t-1} / of the x_0 prediction; round 6, `python tools/step_margins.py fp16`):
+#   bb_gain 0.3, weight seed 7 (round 3's fixture): 0.76e-3 / 0.52e-3 A        bb_gain 0.3, weight seed 11: 0.37e-3 / 0.39e-3 A
+#   bb_gain 0.5, weight seed 7: 1.43e-3 / 0.97e-3 A — the bar breaks between gain 0.3 and 0.5 for this seed (one step, t = 0.2575, exceeds it)
+# (fp32 mode on the same fixtures: <= 5e-5 A.)  The bound of the mode is therefore stated per fixture: < 1e-3 A up to trained-weight scale 0.3;
+# at 0.5 the fp16 mode MISSES the north-star bar.  That miss is a documented number, not a loosened bound (round-5 review): the test asserts
+# the measured worst step within +-10 %, so that a regression AND an improvement (which should then move DESIGN.md section 5 and the bench
+# line's precision_mode) both trip it.
+FP16_BOUND = {"full_denovo_n300_T5_gain03_seed11": 1.0e-3}
+FP16_DOCUMENTED_MISS = {"full_denovo_n300_T5_gain05": (1.43e-3, 1.1e-3)}  # (measured worst x_(t-1) step, bound that the x_0 prediction does hold)
 
 
-@pytest.mark.parametrize("name", sorted(FP16_MARGIN))
+@pytest.mark.parametrize("name", sorted(FP16_BOUND) + sorted(FP16_DOCUMENTED_MISS))
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_teacher_forced_margin_second_seed_and_gain05(name, prec):
     r = _teacher_forced_steps(name, prec)
     fmt = lambda v: " ".join(f"{x:.2e}" for x in v)  # noqa: E731
     print(f"{prec} {name}: x_(t-1) per step [{fmt(r[:, 1])}] A, x_0 prediction [{fmt(r[:, 2])}] A")
-    bound = 1e-4 if prec == "fp32" else FP16_MARGIN[name]
-    assert r[:, 1].max() < bound and r[:, 2].max() < bound
+    if prec == "fp32":
+        assert r[:, 1].max() < 1e-4 and r[:, 2].max() < 1e-4
+    elif name in FP16_BOUND:
+        assert r[:, 1].max() < FP16_BOUND[name] and r[:, 2].max() < FP16_BOUND[name]
+    else:  # the documented miss of the 1e-3 A bar: the measured value, both ways
+        miss, x0_bound = FP16_DOCUMENTED_MISS[name]
+        assert 0.9 * miss < r[:, 1].max() < 1.1 * miss, (r[:, 1].max(), "the documented miss moved: update DESIGN.md section 5 and bench.py PREC_MODE")
+        assert (r[:, 1] > 1e-3).sum() == 1  # one step of the five (t = 0.2575) is outside the bar
+        assert r[:, 2].max() < x0_bound
 
 
 def test_bf16_build_per_step_numbers():
