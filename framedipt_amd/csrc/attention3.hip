@@ -35,6 +35,8 @@ __device__ __forceinline__ hx8 a3_pack8(const float* v) {
   for (int e = 0; e < 8; ++e) o[e] = (fd_h)v[e];
   return o;
 }
+// bytes of the LDS region shared by the P fragments (64 B per key) and, after them, the o_pt tile (32 x 96 floats)
+__host__ __device__ __forceinline__ int a3_pf_region(int nt) { return 2 * nt * 64 * 16 > 32 * 96 * 4 ? 2 * nt * 64 * 16 : 32 * 96 * 4; }
 __device__ __forceinline__ hx8 a3_ld(const half_t* p) { return __builtin_bit_cast(hx8, *(const u16x8*)p); }
 
 // NTW: key tiles per wave (N <= 128 NTW).  NTW = 3 (N <= 384): 234 registers -> launch bound 2 -> TWO blocks per CU hide each
@@ -52,9 +54,13 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
   const int N = a.N, H = a.H, nt = (N + 31) / 32, Np = nt * 32;
   float* mxs = (float*)smem;                                 // [4][32]
   float* sms = mxs + 128;                                    // [4][32]
-  float* opr = sms + 128;                                    // [32 queries][96]: o_pt sums, high parts then low parts
-  u16x8* Pfs = (u16x8*)(opr + 32 * 96);                      // [2*nt][64]
-  u16x8* Qs = Pfs + 2 * nt * 64;                             // LB == 3: the Q fragments of the query tile [16][64] (16 KB)
+  u16x8* Pfs = (u16x8*)(sms + 128);                          // [2*nt][64] (the region holds at least 12 KB: a3_pf_region)
+  // Round 6: the o_pt tile OVERLAYS the P fragments (a block-wide barrier separates the last P read from the first o_pt write).  With its
+  // own 12 KB the N = 300 launch asked for 54,288 B per block: three blocks are 162,864 of the CU's 163,840 B, the occupancy API says
+  // "3" — and the hardware ran TWO (LDS is handed out in granules: tools/micro/attn3_bench.hip's dispatch timeline showed 128 of the
+  // 640 blocks of a B = 8 launch starting only when the first ones had finished: 40 us per call for blocks that take 20).
+  float* opr = (float*)Pfs;                                  // [32 queries][96]: o_pt sums, high parts then low parts
+  u16x8* Qs = Pfs + a3_pf_region(nt) / 16;                   // LB == 3: the Q fragments of the query tile [16][64] (16 KB)
   // SPLIT: P_lo fragments [2*nt][64].  They overlay the Q fragments (and extend behind them: the launcher sizes the region as the
   // larger of the two), which nobody reads after phase 1 — two block-wide barriers (softmax) lie between
   u16x8* Pls = Qs;
@@ -340,6 +346,9 @@ __global__ __launch_bounds__(FD_THREADS, LB) void ipa_attn3_kernel(Attn3Args a) 
       v_mma(std::integral_constant<int, 0>{}, acc);
       if constexpr (SPLIT)
         if (wave < 2) v_mma_add(std::integral_constant<int, 0>{}, acc, Pls);  // (tile 2 holds low parts only: P_lo v_lo is below fp32 resolution)
+    }
+    __syncthreads();  // every wave has read its last P fragment: the o_pt tile may overwrite them
+    if (wave < 3) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // D rows 32 wave + 8g + 4hi + q of query li
         f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
@@ -400,9 +409,10 @@ int fd_attention3(const Attn3Args& a, hipStream_t st) {
   const int nt = (a.N + 31) / 32;
   if (!fd_attention3_supported(a)) return FDIPT_ESIZE;
   if (!a.kpf) return FDIPT_EINVAL;
-  // reduction buffers 1 KB + o_pt tile 12 KB + P fragments 64 B per key, then ONE region for the Q fragments (16 KB, the variants
+  // reduction buffers 1 KB + P fragments 64 B per key (>= the 12 KB of the o_pt tile that later overlays them), then ONE region for the Q fragments (16 KB, the variants
   // that keep them in LDS) and / or the P_lo fragments (64 B per key, split P V): they are never live together
-  const size_t pf = (size_t)2 * nt * 64 * 16, base = 2 * 128 * 4 + (size_t)32 * 96 * 4 + pf + 16;
+  // (round 6: the o_pt tile overlays the P fragments: a3_pf_region)
+  const size_t pf = (size_t)2 * nt * 64 * 16, base = 2 * 128 * 4 + (size_t)a3_pf_region(nt) + 16;
   const size_t plo = a.Vt_lo ? pf : 0;
   auto with = [&](bool qlds) { const size_t q = qlds ? 16384 : 0; return base + (q > plo ? q : plo); };
   const int per = (a.B * a.H + 7) / 8;  // see the block mapping in the kernel

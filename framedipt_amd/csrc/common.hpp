@@ -311,8 +311,11 @@ static inline int fd_cu_count() {
 __device__ unsigned long long fd_prof[8192 * 16];
 #define FD_STAMP(k)                                                                                              \
   do {                                                                                                           \
-    if (threadIdx.x == 0)                                                                                        \
+    if (threadIdx.x == 0) {                                                                                      \
       fd_prof[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+      if ((k) < 8) /* slots 8 .. 15: the same instants on the chip-wide 100 MHz clock (s_memtime counters differ between XCDs) */    \
+        fd_prof[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191) * 16 + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                            \
   } while (0)
 #else
 #define FD_STAMP(k) \

@@ -27,7 +27,7 @@
 #define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 16 (flat) no LDS fragment reads
 #endif
 #ifndef E4_PZ_ABL
-#define E4_PZ_ABL 0  // timing ablations of the pair_z emission (wrong results): 1 no lo part, 2 lo part from the hi image in LDS (no L2 loads), 4 no pair_z stores
+#define E4_PZ_ABL 0  // timing ablations of the pair_z emission (wrong results): 1 no lo part, 2 lo part from the hi image in LDS (no L2 loads), 4 no pair_z stores, 8 no hi part
 #endif
 #ifndef E4_D1
 #define E4_D1 3   // weight-fragment ring depths: layer 1, layer 2, final layer
@@ -424,7 +424,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
     if constexpr (PZ) {  // D[pair, d] += z' Wdz[d, this tile's features]  (hi from LDS, lo from registers)
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
-        X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(wbi + 2048 + 64 + (2 * t + h2) * 1024 + lane * 16), X.accd);
+        if (!(E4_PZ_ABL & 8)) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(wbi + 2048 + 64 + (2 * t + h2) * 1024 + lane * 16), X.accd);
         if (E4_PZ_ABL & 2) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(wbi + 2048 + 64 + (2 * t + h2) * 1024 + (lane ^ 1) * 16), X.accd);
         else if (!(E4_PZ_ABL & 1)) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), DL[2 * t + h2], X.accd);
       }
