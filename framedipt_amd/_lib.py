@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("FDIPT_LIB") or os.path.join(_HERE, "lib", "libfdipt_h
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 # FdiptDims.kernel_flags (include/fdipt.h): fallback paths of the half-precision mode, for parity tests
-KF_ET3, KF_GENERIC_PAIR, KF_GENERIC_ATTN, KF_UNFUSED_NODE, KF_UNFOLDED, KF_NO_SPLIT, KF_NO_MERGE, KF_ROWS32 = 1, 2, 4, 8, 16, 32, 64, 128
+KF_ET3, KF_GENERIC_PAIR, KF_GENERIC_ATTN, KF_UNFUSED_NODE, KF_UNFOLDED, KF_NO_SPLIT, KF_NO_MERGE, KF_ROWS32, KF_PASS_Z = 1, 2, 4, 8, 16, 32, 64, 128, 256
 _ERR = {-1: "FDIPT_EINVAL (bad argument)", -2: "FDIPT_ELAUNCH (HIP launch error)",
         -3: "FDIPT_ESIZE (workspace too small or N beyond the compiled tiling)"}
 

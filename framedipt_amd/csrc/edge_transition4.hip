@@ -333,7 +333,10 @@ __device__ __forceinline__ float e4_both_halves(float x, int lane) {
 // z' is the A operand here (D[pair, d]: a lane ends up with four consecutive j of one row i for its d = 8 B of the image, no transposition);
 // weights hi + lo (the rounding of W_dz is shared by all keys of a row: tests/err_budget.py `opair.w`), hi fragments in LDS, lo
 // fragments DL[8] from L2 (requested with the next tile's fold fragments: no LDS left for them)
-template <int SLOT, bool PZ>
+// STZ = false (round 6): z' itself is not stored — the launch behind the LAST trunk block that has an EdgeTransition: the next block's
+// attention takes its pair bias and its pair_z from this epilogue, and nothing else reads z' any more (184 MB of writes, the staging and
+// sixteen 16 B stores per lane and tile less)
+template <int SLOT, bool PZ, bool STZ = true>
 __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M, const hx8* DL) {
   const int p = lane & 31, half = lane >> 5;
   if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math); the pair mask is requested here
@@ -407,7 +410,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
         zB[h2][2 * k] = ow[0];
         zB[h2][2 * k + 1] = ow[1];
         // staging row p (64 B = this tile's 32 features), 16 B chunk g at g ^ ((p >> 2) & 3), 8 B half
-        *(e4_lds_w64)(unsigned long)(stg + p * 64 + ((g ^ ((p >> 2) & 3)) << 4) + 8 * half) = ow;
+        if constexpr (STZ) *(e4_lds_w64)(unsigned long)(stg + p * 64 + ((g ^ ((p >> 2) & 3)) << 4) + 8 * half) = ow;
       }
       if (a.trace && X.valid) {
         float* tr_row = a.trace + X.prow * E4_CZ + 4 * half + 32 * t + 16 * h2;
@@ -430,6 +433,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
       }
     }
     // read the staged tile back as 64 B row segments (the LDS operations of one wave execute in order: no barrier) and store
+    if constexpr (STZ)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int pr = 16 * k + (lane >> 2);
@@ -746,7 +750,7 @@ __device__ __forceinline__ void e4_point(const E4Flat& F, int c) {
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   } while (0)
 
-template <bool PZ>
+template <bool PZ, bool STZ = true>
 __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_flat_kernel(ET2Args a, int n_tiles, int n_wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
@@ -923,13 +927,13 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
       X.moff = lds0 + E4_MOFF + tid * 4;
       X.boff = lds0 + E4_BOFF;
       const unsigned stg = lds0 + E4_SOFF + wave * 2048;
-      e4_epi<0, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<1, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<2, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<3, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<4, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<5, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<6, PZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<0, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<1, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<2, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<3, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<4, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<5, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<6, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
     } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
     E4_STAMP(4);
     if (!has_next) break;
@@ -980,7 +984,8 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   const int dev_ = fd_device();
   if (!attr_dev.get(dev_)) {
     if (hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
+        hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
       return FDIPT_ELAUNCH;
 #if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)
     if (hipFuncSetAttribute((const void*)edge_transition4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
@@ -999,6 +1004,10 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
 #endif
   if (a.pz_out) {  // + pair_z of the next block (needs its bias emission: the zero unit / images share its set-up)
     if (!a.wb_img || !a.wdz_img || !a.wdz_img_lo || !a.bdz) return FDIPT_EINVAL;
+    if (!a.z_out) {  // (only next to both emissions and without a trace: checked by the caller's conditions, and here)
+      if (a.trace) return FDIPT_EINVAL;
+      hipLaunchKernelGGL((edge_transition4_flat_kernel<true, false>), dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
+    } else
     hipLaunchKernelGGL(edge_transition4_flat_kernel<true>, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
   } else
     hipLaunchKernelGGL(edge_transition4_flat_kernel<false>, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);

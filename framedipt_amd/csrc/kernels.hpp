@@ -139,7 +139,7 @@ __host__ __device__ __forceinline__ long fd_bias_frag_off(long bh, int nt, int i
 struct ET2Args {
   int B, N;
   const half_t* z_in;   // [B,N,N,128] bf16
-  half_t* z_out;        // may alias z_in
+  half_t* z_out;        // may alias z_in; NULL (edge_transition4 with pz_out and wb_img only): z' is not stored (nothing reads it)
   const float* e;       // [B*N,128] f32 initial_embed(node)
   const half_t* e_h16; // the same rows in bf16 (edge_transition3: fetched by LDS-DMA)
   const float* a1;      // [B*N,384] f32: W1[:, e_i cols] e_i + b1

@@ -31,7 +31,7 @@ struct Switches {
   bool no_et_bias = false, no_ee_bias = false;  // pair bias as its own pass over z
   bool feats_unfused = false, torf_unfused = false, init_unfused = false, skip_per_block = false, post_unfused = false,
        no_tfmr_tail = false, et4_rows_unfused = false, no_qkv_fuse = false, proj_v1 = false, feats_f32 = false,
-       probs_f32 = false, no_l2_warm = false, no_pz = false;
+       probs_f32 = false, no_l2_warm = false, no_pz = false, keep_last_z = false;
   bool no_seq_attn = false;     // (dev) sequence attention on the LDS-score kernel only (IPA attention unchanged)
   bool no_split = false;        // node-path products on plain half-precision operands instead of split (hi + lo) ones
   bool no_merge = false;        // IPA projections in the reference's formulation (k, v explicit) instead of the merged one
@@ -55,7 +55,7 @@ static const Switches& dev_switches() {
     s.skip_per_block = on("FDIPT_SKIP_PER_BLOCK"); s.post_unfused = on("FDIPT_POST_UNFUSED");
     s.no_tfmr_tail = on("FDIPT_NO_TFMR_TAIL"); s.et4_rows_unfused = on("FDIPT_ET4_ROWS_UNFUSED");
     s.no_qkv_fuse = on("FDIPT_NO_QKV_FUSE"); s.proj_v1 = on("FDIPT_PROJ_V1"); s.feats_f32 = on("FDIPT_FEATS_F32");
-    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM"); s.no_split = on("FDIPT_NO_SPLIT"); s.no_seq_attn = on("FDIPT_NO_SEQ_ATTN"); s.no_pz = on("FDIPT_NO_PZ");
+    s.probs_f32 = on("FDIPT_PROBS_F32"); s.no_l2_warm = on("FDIPT_NO_L2_WARM"); s.no_split = on("FDIPT_NO_SPLIT"); s.no_seq_attn = on("FDIPT_NO_SEQ_ATTN"); s.no_pz = on("FDIPT_NO_PZ"); s.keep_last_z = on("FDIPT_KEEP_LAST_Z");
     if (const char* m = getenv("FDIPT_CHAIN_MASK")) s.chain_mask = (unsigned)strtoul(m, nullptr, 0);
     s.twice = getenv("FDIPT_DBG_TWICE");
     if (const char* m = getenv("FDIPT_SPLITK_NS")) s.splitk_ns = atoi(m);
@@ -79,6 +79,7 @@ static Switches switches_of(const FdiptDims* d) {
   if (f & FDIPT_KF_NO_SPLIT) s.no_split = true;
   if (f & FDIPT_KF_NO_MERGE) s.no_merge = true;
   if (f & FDIPT_KF_ROWS32) s.no_tail16 = true;
+  if (f & FDIPT_KF_PASS_Z) s.no_pz = true;
   if (f & FDIPT_KF_UNFOLDED)
     s.no_et_bias = s.no_ee_bias = s.feats_unfused = s.torf_unfused = s.init_unfused = s.skip_per_block = s.post_unfused =
         s.et4_rows_unfused = true;
@@ -853,7 +854,9 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
   // Same conditions as the pair-bias emission of those epilogues, edge_transition4 only (N % 4 == 0); FDIPT_KF_UNFOLDED keeps the pass over z.
   const bool pz_path = op.kind == OP_ALL && use_regpair(d) && bf && cz == 128 && C == 256 && Pq == 8 && Pv == 12 && H == 8 && N <= 1024 && (N & 3) == 0 &&
                        !sw.generic_attn && !sw.no_et_bias && !sw.no_ee_bias && !sw.et3 && !sw.no_pz && rbk && iv.cb == 128 && iv.hid == 384 &&
-                       fd_edge_transition4_supported(N);
+                       fd_edge_transition4_supported(N) &&
+                       // ... and the consumer will take it: attention3 hands its weights over as half-precision rows (below: N >= 16)
+                       2 * ((N + 31) / 32 * 32) <= 4 * N && !sw.probs_f32 && (H & 1) == 0;
   bool pz_ready = false;  // the pair_z image of the coming block's IPA is in the workspace
   // ---- Embedder (score_network.py:129-197)
   // ... with the split of x_t (ipa_pytorch.py:516-524) and the per-residue halves of the first edge-embedder layer in the same
@@ -1363,6 +1366,8 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         if (use_et4 && emit_bias && pz_path) {
           t2.wdz_img = D + L.blk[b + 1].wdz_imgp; t2.wdz_img_lo = D + L.blk[b + 1].wdz_imgp_lo; t2.bdz = P + iv.blk[b + 1].dz.b; t2.pz_out = (half_t*)(W + w.pz);
           pz_ready = true;
+          // the last EdgeTransition of the trunk: block b + 1 takes bias and pair_z from this epilogue and no launch reads z' itself
+          if (b + 1 == d->num_blocks - 1 && !tr_ptr && !sw.keep_last_z) t2.z_out = nullptr;
         }
         t2.clock = a->clock_out;
         if (a->ev_start && a->ev_start[b]) hipEventRecord((hipEvent_t)a->ev_start[b], st);

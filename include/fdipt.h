@@ -56,7 +56,9 @@ extern "C" {
                                     (keys = values = the node rows, W_k folded into the query, W_v into the output projection)  */
 #define FDIPT_KF_ROWS32 128      /* node path: the 32-row-block kernels (the default for N > 512) instead of the 16-row ones (tails, transition,
                                     node embedder, torsion head) for every N                                                  */
-#define FDIPT_KF_ALL 255
+#define FDIPT_KF_PASS_Z 256      /* o_pair as its own pass over the 128 channels of z (round 5's path: sum_j a z, then down_z) instead of the
+                                    pair_z image emitted by the producers of z (round 6); the last EdgeTransition then keeps its z' store */
+#define FDIPT_KF_ALL 511
 
 typedef void* fdipt_stream_t; /* hipStream_t */
 
