@@ -24,6 +24,13 @@ int main(int argc, char** argv) {
   a.B = B; a.N = N; a.n_rel = n_rel; a.rel_off = N - 1; a.num_bins = NB; a.pi = pi; a.pj = pj; a.rtab = rt; a.dtab = dt; a.edges = ed;
   a.seq_idx = si; a.sc_ca = ca; a.w2 = a.w3 = nullptr; a.b2 = vecs; a.b3 = vecs + 128; a.gamma = vecs + 256; a.beta = vecs + 384;
   a.res_mask = rm; a.z_out = z; a.trace = nullptr; a.wb_img = (argc > 3 && atoi(argv[3]) == 0) ? nullptr : wb; a.bb = bb; a.bias_out = bo; a.H = 8;
+  // round 6: + pair_z of the first block (argv[3] = 2: bias only, as round 5 ran it)
+  if (a.wb_img && !(argc > 3 && atoi(argv[3]) == 2)) {
+    void *dzh, *dzl; half_t* pz;
+    (void)hipMalloc(&dzh, 8192); (void)hipMalloc(&dzl, 8192); (void)hipMalloc(&pz, fd_pz_bytes(B, N));
+    (void)hipMemset(dzh, 0, 8192); (void)hipMemset(dzl, 0, 8192);
+    a.wdz_img = dzh; a.wdz_img_lo = dzl; a.bdz = vecs; a.pz_out = pz;
+  }
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
   for (int i = 0; i < 3; ++i) if (fd_edge_embed2(a, img, 0)) { printf("launch failed\n"); return 1; }
   (void)hipEventRecord(t0, 0);
