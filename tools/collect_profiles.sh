@@ -7,6 +7,7 @@
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/final"
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2> "$OUT/bench.err"   # the driver's exact command
@@ -21,6 +22,10 @@ python "$ROOT/bench.py" --eager --no-cpu-baseline --no-reference-precision --no-
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python "$ROOT/bench.py" --no-cpu-baseline --no-reference-precision --no-all-samples > "$OUT/bench_prof.log" 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 [ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats.md" > /dev/null
+# all 64 samples of configs[3] on the one GPU: the kernel table behind `all_samples_one_gpu`
+rm -rf /tmp/prof_b64 && rocprofv3 --kernel-trace --stats -d /tmp/prof_b64 -- python "$ROOT/bench.py" --samples-per-gpu 64 --steps 18 --warmup 2 --no-cpu-baseline --no-reference-precision --no-all-samples > "$OUT/bench_b64_prof.log" 2>&1
+DB=$(find /tmp/prof_b64 -name "*.db" | head -1)
+[ -n "$DB" ] && python "$ROOT/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats_b64.md" > /dev/null
 # config 5 (fp32 mode, N = 1000): kernel table of the parity mode's heaviest configuration
 rm -rf /tmp/prof_c5 && rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -- python "$ROOT/bench.py" --config c5 --no-cpu-baseline > "$OUT/bench_c5_prof.log" 2>&1
 DB=$(find /tmp/prof_c5 -name "*.db" | head -1)
