@@ -177,7 +177,7 @@ struct DChain {  // weight images of the fused node-path chains (chain.hip) of o
   size_t skip, inp[FD_MAX_TL], outp[FD_MAX_TL], l1[FD_MAX_TL], l2[FD_MAX_TL], l2n[FD_MAX_TL], post, t1, t2, t3, t2n, t3n, et_init, a1, af, a1af, b1f, r4w, r4b;
   // l2: k-permuted (register chaining in chain.hip); l2n: natural k order (rowblock.hip, hidden rows go through LDS)
 };
-struct DBlock { size_t wq_m, wproj2_img, wproj2_img_lo, bproj2, wout_m, bout_m, wout_img, wout_img_lo, wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo, wdz_imgp, wdz_imgp_lo; DChain ch; DSplit lo; };
+struct DBlock { size_t wq_m, wproj2_img, wproj2_img_lo, bproj2, wout_m, bout_m, wout_img, wout_img_lo, wproj, wproj_img, wproj_img_lo, bproj, gamma, wb, bb, wb_img3, wb_img4, et3, et4, wdz_t, wdz_img, wdz_img_lo, wdz_imgp, wdz_imgp_lo; DChain ch; DSplit lo; };
 struct DLayout {
   size_t h16_base;   // bf16 image of the whole fp32 blob (bf16 mode): element offset == fp32 element offset
   size_t ne0_pad;     // [cs, kn_pad] operand precision
@@ -245,7 +245,6 @@ static void build_layout(const FdiptDims* d, const Inventory& iv, DLayout& L) {
     L.blk[b].gamma = o; o = al256(o + (size_t)d->no_heads * 4);
     L.blk[b].wb = o; o = al256(o + (size_t)d->no_heads * d->c_z * L.esz);
     L.blk[b].bb = o; o = al256(o + (size_t)d->no_heads * 4);
-    L.blk[b].wb_img = o; o = al256(o + 8192);  // linear_b as a 32 x 128 MFMA fragment image (edge_transition2 epilogue)
     L.blk[b].wb_img3 = o; o = al256(o + 4096);  // ... as 16 x 128 (edge_transition3 epilogue)
     L.blk[b].wb_img4 = o; o = al256(o + 8192);  // ... compact (8 head rows: 2 KB) in the hand-off order of edge_transition4 / edge_embed2
     L.blk[b].wdz_img = o; o = al256(o + 8192);  // down_z [c_z/4, c_z] as a bf16 fragment image (MFMA o_pair kernel)
@@ -508,8 +507,7 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
     if ((rc = copy_cols(L.esz, H, cz, cz, P + k.lb.w, cz, 0, s3, D + db.wb, st))) return rc;
     if ((rc = copy_cols(4, 1, H, H, P + k.lb.b, H, 0, s3, D + db.bb, st))) return rc;
     if (cz == 128 && H <= 8)
-      if ((rc = fd_chain_build_image_scaled(P + k.lb.w, H, cz, cz, 1, s3, D + db.wb_img, st)) ||
-          (rc = fd_et3_build_bias_image(P + k.lb.w, H, s3, D + db.wb_img3, st)) ||
+      if ((rc = fd_et3_build_bias_image(P + k.lb.w, H, s3, D + db.wb_img3, st)) ||
           (rc = fd_et4_build_bias_image(P + k.lb.w, H, s3, D + db.wb_img4, st)))
         return rc;
     hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, st, cz / 4, cz, P + k.dz.w, (float*)(D + db.wdz_t));
