@@ -49,11 +49,19 @@
 #else
 #define E4_BUF 32768
 #endif
-#define E4_WBI (2048 + 64 + 8192)  // linear_b image, compact (8 head rows) | 16 B of zeros (+ pad) | down_z image (hi part) of the next block
+#define E4_WBI (2048 + 64)  // linear_b image, compact (8 head rows) | 16 B of zeros (+ pad)   (down_z: the stream's last chunk, ring slot 3)
 #define E4_L1_FR (12 * 8)    // fragments (1 KB): layer 1, 12 tiles x 8 k-steps (K = 128: z)
 #define E4_L2_FR (12 * 24)   // layer 2, 12 tiles x 24 k-steps
-#define E4_LF_FR (32 * 4)    // final layer, k-major: 32 k-steps (8 z + 24 h2) x 4 tiles
-#define E4_STREAM_BYTES ((E4_L1_FR + E4_L2_FR + E4_LF_FR) * 1024)
+// Round 6: the reference is final_layer(trunk(x) + x) (ipa_pytorch.py:99): the z part of x meets the SAME weight columns as the first 128
+// features of h2, so z is added to those features when they are handed over (e4_add_z) and the final layer runs 24 k-steps instead of
+// 8 (z) + 24 (h2): 504 products per 32-pair tile instead of 536.  The stream keeps its 512 fragments = 32 chunks (the ring of four chunk
+// slots needs a multiple of four): fragments 480 .. 495 are unused, 496 .. 511 (chunk 31 = ring slot 3, resident through the epilogue)
+// hold down_z of the next block, hi and lo images (fd_et4_set_dz) — the fragments the pair_z emission reads.
+#define E4_LF_FR (24 * 4)    // final layer, k-major: 24 k-steps of (h2 + x) x 4 tiles
+#define E4_DZ_FR0 496        // down_z hi [8] | lo [8]
+#define E4_STREAM_FR 512
+#define E4_STREAM_BYTES (E4_STREAM_FR * 1024)
+static_assert(E4_L1_FR + E4_L2_FR + E4_LF_FR == 480, "480 weight fragments, then one unused chunk and the down_z chunk");
 #define E4_ZOFF (2 * E4_BUF)                 // per-wave z rows [8][32 rows x 256 B]
 #define E4_VOFF (E4_ZOFF + E4_WAVES * 8192)         // b2[384] | gamma[128] | beta[128] | down_z bias [32] f32, then the epilogue's images (E4_WBI)
 #define E4_VEC_BYTES (1536 + 1024 + 128)
@@ -104,11 +112,13 @@ __global__ void et4_build_stream_kernel(const float* __restrict__ w1, const floa
     bool chained;
     if (frag < E4_L1_FR) { src = w1; n = 32 * (frag / 8) + f; s = frag % 8; chained = false; }
     else if (frag < E4_L1_FR + E4_L2_FR) { frag -= E4_L1_FR; src = w2; n = 32 * (frag / 24) + f; s = frag % 24; chained = true; }
-    else {
+    else if (frag < E4_L1_FR + E4_L2_FR + E4_LF_FR) {
       frag -= E4_L1_FR + E4_L2_FR;
       src = wf; n = 32 * (frag & 3) + f; s = frag >> 2;
-      chained = s >= 8;
-      if (chained) s -= 8;
+      chained = true;
+    } else {  // unused chunk / down_z chunk (fd_et4_set_dz): zeros
+      for (int e = 0; e < 8; ++e) stream[(long)g * 8 + e] = 0;
+      continue;
     }
     half_t out[8];
     for (int e = 0; e < 8; ++e) {
@@ -124,6 +134,13 @@ int fd_et4_build_stream(const float* w1, const float* w2, const float* wf, void*
   return FDIPT_OK;
 }
 size_t fd_et4_stream_bytes() { return E4_STREAM_BYTES; }
+// down_z of the NEXT block's IPA into the stream's last chunk: img_hi / img_lo = fd_chain_build_image_ex(Wdz, 32, 128, permuted = 1, lo = 0 / 1), 8 KB each
+int fd_et4_set_dz(void* stream, const void* img_hi, const void* img_lo, hipStream_t st) {
+  char* dst = (char*)stream + (size_t)E4_DZ_FR0 * 1024;
+  if (hipMemcpyAsync(dst, img_hi, 8192, hipMemcpyDeviceToDevice, st) != hipSuccess || hipMemcpyAsync(dst + 8192, img_lo, 8192, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return FDIPT_ELAUNCH;
+  return FDIPT_OK;
+}
 
 // linear_b of the NEXT block's attention (ipa_pytorch.py:247,256-257) as 8 A fragments of a 32-row tile of which only the H <= 8 head
 // rows exist: [k-step][lane half][8 rows][8] = 2 KB (round 6: the other 24 rows were 6 KB of zeros in LDS; lanes f >= 8 read one shared
@@ -331,13 +348,13 @@ __device__ __forceinline__ float e4_both_halves(float x, int lane) {
 // PZ (round 6): the epilogue also emits pair_z = down_z(z') + b of the NEXT block's IPA (ipa_pytorch.py:158,318: o_pair = sum_j a_ij pair_z_ij)
 // as half precision [row][j / 4][32 d][4 j] (ET2Args.pz_out), so that opair_pz_kernel reads 64 B per pair instead of the 256 B of z'.
 // z' is the A operand here (D[pair, d]: a lane ends up with four consecutive j of one row i for its d = 8 B of the image, no transposition);
-// weights hi + lo (the rounding of W_dz is shared by all keys of a row: tests/err_budget.py `opair.w`), hi fragments in LDS, lo
-// fragments DL[8] from L2 (requested with the next tile's fold fragments: no LDS left for them)
+// weights hi + lo (the rounding of W_dz is shared by all keys of a row: tests/err_budget.py `opair.w`); both images arrive as the last
+// chunk of the weight stream (ring slot 3: `dzf`), which nobody overwrites before the next tile's first stream point
 // STZ = false (round 6): z' itself is not stored — the launch behind the LAST trunk block that has an EdgeTransition: the next block's
 // attention takes its pair bias and its pair_z from this epilogue, and nothing else reads z' any more (184 MB of writes, the staging and
 // sixteen 16 B stores per lane and tile less)
 template <int SLOT, bool PZ, bool STZ = true>
-__device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M, const hx8* DL) {
+__device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M, unsigned dzf) {
   const int p = lane & 31, half = lane >> 5;
   if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math); the pair mask is requested here
     // the pair mask comes from LDS (parked there at the start of the tile): a global load here would be waited for with
@@ -427,9 +444,8 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
     if constexpr (PZ) {  // D[pair, d] += z' Wdz[d, this tile's features]  (hi from LDS, lo from registers)
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
-        if (!(E4_PZ_ABL & 8)) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(wbi + 2048 + 64 + (2 * t + h2) * 1024 + lane * 16), X.accd);
-        if (E4_PZ_ABL & 2) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(wbi + 2048 + 64 + (2 * t + h2) * 1024 + (lane ^ 1) * 16), X.accd);
-        else if (!(E4_PZ_ABL & 1)) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), DL[2 * t + h2], X.accd);
+        if (!(E4_PZ_ABL & 8)) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(dzf + (2 * t + h2) * 1024 + lane * 16), X.accd);
+        if (!(E4_PZ_ABL & 1)) X.accd = fd_mfma32(__builtin_bit_cast(hx8, zB[h2]), e4_frag(dzf + 8192 + (2 * t + h2) * 1024 + lane * 16), X.accd);
       }
     }
     // read the staged tile back as 64 B row segments (the LDS operations of one wave execute in order: no barrier) and store
@@ -469,228 +485,6 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
   }
 }
 
-#if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)  // the chunk-synchronous predecessor: development / micro-benchmark builds only
-__global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_kernel(ET2Args a, int n_tiles, int n_wt) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-  const unsigned vec = lds0 + E4_VOFF;          // b2[384] | gamma[128] | beta[128] (f32)
-  const unsigned wbi = lds0 + E4_VOFF + E4_VEC_BYTES;   // linear_b fragments of the next block
-  // the lane index is recomputed where needed (v_mbcnt: no register carried through the tile), the wave index is scalar:
-  // every register that stays live through layer 2 is a spill, and a spilled dword is 256 B of HBM traffic per wave and tile
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  auto lane_id = [] {
-    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
-    return l;
-  };
-  const int lane0 = lane_id(), tid0 = wave * 64 + lane0;
-  const int N = a.N, NJ4 = N >> 2, M = a.B * N;
-  const char* stream = (const char*)a.stream;
-  int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
-#ifdef E4_PROF
-  unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_amdgcn_s_memtime();
-  const unsigned long long span0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  E4Tile tc = e4_tile_of(tile * E4_WAVES + wave, n_wt, N, NJ4);
-  // ---- first tile: z rows, first weight chunk, small vectors
-  e4_request_z(a, tc, lane0, lds0 + E4_ZOFF + wave * 8192, M);
-  e4_dma_chunk<24576>(stream, lds0, tid0, wave);
-  if (tid0 < 160) {
-    const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : a.beta + 4 * (tid0 - 128));
-    e4_dma16(src, vec + (tid0 & ~63) * 16);
-  }
-  if (a.wb_img && tid0 < 128) e4_dma16((const char*)a.wb_img + tid0 * 16, wbi + (tid0 & ~63) * 16);  // compact image (2 KB)
-  if (tid0 < 4) *(__attribute__((address_space(3))) unsigned*)(unsigned long)(wbi + 2048 + tid0 * 4) = 0u;  // the zero unit
-  // fold fragments of the first layer-1 chunk (tiles 0..2): lanes < 32 read the row image, lanes >= 32 the column image
-  // 32-bit byte offset from the row image (the column image follows it in the same workspace): one register, scalar base
-  auto fold_ptr = [&](const E4Tile& t, int lane) {
-    const unsigned fold_b1 = (unsigned)((const char*)a.b1_img - (const char*)a.a1_img);
-    const unsigned ob = fold_b1 + (unsigned)((t.b0 * NJ4 + t.jt) * 16) * 512u, oa = (unsigned)(t.rt * 16) * 512u;  // scalar
-    return oa + (unsigned)(lane >> 5) * (ob - oa) + (lane & 31) * 16;
-  };
-  auto fold_ld = [&](unsigned off) { return e4_gfrag((const char*)a.a1_img + off); };
-  unsigned fold_base = fold_ptr(tc, lane0);
-  // all 12 layer-1 fold fragments are requested a tile ahead: a global load inside a chunk would make the compiler wait for
-  // it with vmcnt, and vmcnt being in order that is a wait for the whole weight DMA of the chunk issued just before
-  hx8 FA[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
-  auto mask_of = [&](const E4Tile& t, int lane) {
-    int row = 8 * t.rt + ((lane & 31) >> 2);
-    if (row > M - 1) row = M - 1;
-    return a.res_mask[row] * a.res_mask[(row / N) * N + 4 * t.jt + (lane & 3)];
-  };
-  if (tid0 < 8) *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_BOFF + tid0 * 4) = (a.wb_img && tid0 < a.H) ? a.bb[tid0] : 0.f;
-  float em_req = mask_of(tc, lane0);  // requested with the tile's operands, parked in LDS after the tile-start wait
-  E4Epi E;
-  e4_dma_wait();
-  *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid0 * 4) = em_req;
-  __syncthreads();
-  E4_STAMP(0);
-#pragma unroll 1
-  for (;;) {
-    // opaque per-iteration copies: keep hipcc from hoisting the loop-invariant LDS / global address arithmetic of the whole
-    // tile body out of the loop (hundreds of values that would stay live across it and spill)
-    const int lane = lane_id(), tid = wave * 64 + lane;
-    const int p = lane & 31, half = lane >> 5;
-    const unsigned zst = lds0 + E4_ZOFF + wave * 8192;
-    const unsigned zrow = zst + p * 256;
-
-    hx8 H1[24], H2[24];
-    size_t soff = 0;
-    // ================= layer 1: 4 chunks x 3 tiles, K = 128 (+ fold)
-    {
-      const hx8 SEL = e4_sel(lane, tc.ns);
-      hx8 Zf[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) Zf[s] = e4_frag(zrow + (((2 * s) ^ (half ^ (p & 15))) << 4));
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((cc + 1) & 1) * E4_BUF, tid, wave);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int T = 3 * cc + u;
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          acc = e4_mfma(FA[T], SEL, acc);
-          e4_tile<8, E4_D1>(acc, lds0 + (cc & 1) * E4_BUF + u * 8192 + lane * 16, Zf);
-          e4_hand_off(acc, H1[2 * T], H1[2 * T + 1]);
-        }
-        e4_dma_wait();
-        __syncthreads();
-        soff += 24576;
-      }
-    }
-    E4_STAMP(1);
-    // ================= layer 2: 12 chunks x 1 tile, K = 384; the accumulator starts as b2
-#pragma unroll
-    for (int T = 0; T < 12; ++T) {
-      if (T < 11) e4_dma_chunk<24576>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid, wave);
-      else e4_dma_chunk<32768>(stream + soff + 24576, lds0 + ((T + 1) & 1) * E4_BUF, tid, wave);  // first final-layer chunk
-      f32x16 acc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv = e4_ldsf4(vec + 4 * (32 * T + 8 * g + 4 * half));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[4 * g + q] = bv[q];
-      }
-      e4_tile<24, E4_D2>(acc, lds0 + (T & 1) * E4_BUF + lane * 16, H1);
-      e4_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
-      e4_dma_wait();
-      __syncthreads();
-      soff += 24576;
-    }
-    E4_STAMP(2);
-    // ================= final layer, k-major over the 4 output tiles: 8 k-steps of z (fragments re-read from the wave's LDS
-    // rows), 24 of h2, then the fold step (Af[i] + Bf[j]); 4 chunks x 8 k-steps
-    const int ntile = tile + gridDim.x;
-    const bool has_next = ntile < n_tiles;
-    const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * E4_WAVES + wave, n_wt, N, NJ4);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) E.Y[t][r] = 0.f;
-    hx8 FL[4];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      if (cc < 3) e4_dma_chunk<32768>(stream + soff + 32768, lds0 + ((cc + 1) & 1) * E4_BUF, tid, wave);
-      else if (has_next) e4_dma_chunk<24576>(stream, lds0, tid, wave);  // the next tile's first chunk: buffer 0 is free since chunk 18
-      // The z rows of the NEXT tile are requested here, two chunks before the tile ends (the wave's LDS rows are free since the
-      // z part of this layer, chunk 0): all CUs reach their tile boundary together, and 16 MB of z requested there arrive as
-      // one HBM burst of several microseconds.  Always issued (the last tile re-requests its own rows) so that the wait
-      // below can count on exactly 8 younger DMA instructions.
-      if (cc == 1) e4_request_z(a, tn, lane_id(), lds0 + E4_ZOFF + wave * 8192, M);
-      if (cc == 2) {
-        const unsigned fb = fold_ptr(tc, lane_id());  // recomputed: carried through layer 2 it would be a spilled register
-#pragma unroll
-        for (int k = 0; k < 4; ++k) FL[k] = fold_ld(fb + (12 + k) * 512);
-      }
-      const unsigned pa = lds0 + (cc & 1) * E4_BUF + lane * 16;
-      constexpr int NF = 32, DEPTH = E4_DF;  // flat ring over the chunk's 32 fragments
-      hx8 r[DEPTH];
-      hx8 zb[2];
-      unsigned zrow2 = 0, zx = 0;  // the z row address again, from an opaque copy (otherwise the 8 layer-1 addresses stay live)
-      if (cc == 0) {
-        const int l2 = lane_id();
-        zrow2 = lds0 + E4_ZOFF + wave * 8192 + (l2 & 31) * 256;
-        zx = (l2 >> 5) ^ (l2 & 15);
-        zb[0] = e4_frag(zrow2 + (zx << 4));
-      }
-#pragma unroll
-      for (int m = 0; m < DEPTH - 1; ++m) r[m] = e4_frag(pa + m * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < NF; ++m) {
-        const int s = m >> 2, t = m & 3;
-        if (m + DEPTH - 1 < NF) r[(m + DEPTH - 1) % DEPTH] = e4_frag(pa + (m + DEPTH - 1) * 1024);
-        if (cc == 0 && t == 0 && s + 1 < 8) zb[(s + 1) & 1] = e4_frag(zrow2 + (((2 * (s + 1)) ^ zx) << 4));
-        E.Y[t] = e4_mfma(r[m % DEPTH], cc == 0 ? zb[s & 1] : H2[8 * (cc - 1) + s], E.Y[t]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (cc < 3) {
-        if (cc == 1) {  // the weight chunk issued at the top of this chunk, not the 8 z DMAs behind it: vmcnt(8)
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_waitcnt(0x0F78);
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          e4_dma_wait();
-        }
-        __syncthreads();
-        soff += 32768;
-      }
-    }
-    {
-      const hx8 SEL = e4_sel(lane, tc.ns);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) E.Y[t] = e4_mfma(FL[t], SEL, E.Y[t]);
-    }
-    E4_STAMP(3);
-    // ================= tile boundary (no barrier: the z rows and the store staging are wave-private): the next tile's operands
-    // are requested, THEN the LayerNorm epilogue of this tile runs under their latency
-    fold_base = fold_ptr(tn, lane);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);  // (the last tile re-reads its own: no branch, no phi)
-    E.t = tc;
-    em_req = mask_of(tn, lane);
-    if (!(E4_ABL & 1)) {
-      E4EpiTmp X;
-      X.moff = lds0 + E4_MOFF + tid * 4;
-      X.boff = lds0 + E4_BOFF;
-      const unsigned stg = lds0 + E4_SOFF + wave * 2048;
-      e4_epi<0, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
-      e4_epi<1, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
-      e4_epi<2, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
-      e4_epi<3, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
-      e4_epi<4, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
-      e4_epi<5, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
-      e4_epi<6, false>(E, X, a, lane, vec, wbi, stg, M, nullptr);
-    } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
-    E4_STAMP(4);
-    if (!has_next) break;
-    tile = ntile;
-    tc = tn;
-    e4_dma_wait();
-    *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid * 4) = em_req;  // (this lane's own slot)
-    __syncthreads();
-    E4_STAMP(5);
-  }
-#ifdef E4_PROF
-  if (tid0 == 0 && blockIdx.x < 256)
-    for (int k = 0; k < 8; ++k) e4_prof[blockIdx.x * 8 + k] = ph[k];
-  if (tid0 == 0 && blockIdx.x < 1024) {
-    e4_span[blockIdx.x * 3] = span0;
-    e4_span[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    e4_span[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hw;
-  }
-#endif
-}
-#endif
-
 // ------------------------------------------------------------------ flat-stream kernel (round 2, end)
 // Same arithmetic, same MFMA order per accumulator (bit-identical results) as edge_transition4_kernel above; what changes is how
 // the 512 weight fragments of a tile reach the matrix cores.  Above: 20 chunks through a 2 x 32 KB ring, a DMA wait + barrier at
@@ -724,10 +518,12 @@ __device__ __forceinline__ void e4_vm_wait(int n) {  // s_waitcnt vmcnt(n) (expc
   __builtin_amdgcn_sched_barrier(0);
 }
 // younger VM instructions (guaranteed ones) than the DMA of chunk c + 1 at the barrier point of chunk c: always the DMA of chunk
-// c + 2; plus the 8 z requests issued at point 26, the 4 final-layer fold loads issued at point 28, the 12 + 2 fold / mask loads of
-// the tile boundary
+// c + 2; plus the 8 z requests issued at point E4_PT_Z, the 4 final-layer fold loads issued at point E4_PT_FL, the 12 + 2 fold / mask
+// loads of the tile boundary
+#define E4_PT_Z 24   // stream point behind which the next tile's z rows are requested
+#define E4_PT_FL 26  // ... the final layer's fold fragments
 __device__ __forceinline__ constexpr int e4_vm_younger(int c) {
-  return E4_DPC + (c == 27 || c == 28 ? 8 : (c == 29 || c == 30 ? 4 : (c == 0 || c == 1 ? 14 : 0)));
+  return E4_DPC + (c == E4_PT_Z + 1 || c == E4_PT_Z + 2 ? 8 : (c == E4_PT_FL + 1 || c == E4_PT_FL + 2 ? 4 : (c == 0 || c == 1 ? 14 : 0)));
 }
 __device__ __forceinline__ constexpr unsigned e4_ring_off(int f) { return (unsigned)(((f >> 4) & 3) * E4_CHUNK + (f & 15) * 1024); }
 struct E4Flat {
@@ -782,11 +578,6 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
   }
   if (a.wb_img && tid0 < 128) e4_dma16((const char*)a.wb_img + tid0 * 16, wbi + (tid0 & ~63) * 16);  // compact image (2 KB)
   if (tid0 < 4) *(__attribute__((address_space(3))) unsigned*)(unsigned long)(wbi + 2048 + tid0 * 4) = 0u;  // the zero unit
-  if constexpr (PZ) {  // down_z of the next block: hi image (8 KB) behind the zero unit
-#pragma unroll
-    for (int u = 0; u < 512 / E4_THREADS; ++u)
-      e4_dma16((const char*)a.wdz_img + (u * E4_THREADS + tid0) * 16, wbi + 2048 + 64 + (u * E4_THREADS + (tid0 & ~63)) * 16);
-  }
   auto fold_ptr = [&](const E4Tile& t, int lane) {
     const unsigned fold_b1 = (unsigned)((const char*)a.b1_img - (const char*)a.a1_img);
     const unsigned ob = fold_b1 + (unsigned)((t.b0 * NJ4 + t.jt) * 16) * 512u, oa = (unsigned)(t.rt * 16) * 512u;  // scalar
@@ -844,7 +635,8 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
       }
     }
     E4_STAMP(1);
-    // ================= layer 2: fragments 96 .. 383 (12 tiles x 24 k-steps); the accumulator starts as b2
+    // ================= layer 2: fragments 96 .. 383 (12 tiles x 24 k-steps); the accumulator starts as b2.  The first four tiles are the
+    // hidden features that face z in the residual trunk(x) + x (ipa_pytorch.py:99): z joins them as they are handed over (e4_add_z)
 #pragma unroll
     for (int T = 0; T < 12; ++T) {
       f32x16 acc;
@@ -861,10 +653,24 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
         E4_STEP(f, H1[s], acc);
       }
       e4_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
+      if (T < 4) {
+        // z in hand-off order: element (half, e) of fragment 2 T + u = feature 32 T + 16 u + 8 (e >> 2) + 4 half + (e & 3): two 8 B pieces of
+        // the lane's z row (16 B unit n of row p at n ^ (p & 15)); packed half-precision adds
+        const int l3 = lane_id();  // (from an opaque copy: the layer-1 row addresses must not stay live)
+        const unsigned zrow3 = lds0 + E4_ZOFF + wave * 8192 + (l3 & 31) * 256 + 8 * (l3 >> 5), zsw = l3 & 15;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          e4_u32x4 zw;
+          const e4_u32x2 z0 = *(e4_lds_w64)(unsigned long)(zrow3 + (((4 * T + 2 * u) ^ zsw) << 4));
+          const e4_u32x2 z1 = *(e4_lds_w64)(unsigned long)(zrow3 + (((4 * T + 2 * u + 1) ^ zsw) << 4));
+          zw[0] = z0[0]; zw[1] = z0[1]; zw[2] = z1[0]; zw[3] = z1[1];
+          H2[2 * T + u] = H2[2 * T + u] + __builtin_bit_cast(hx8, zw);
+        }
+      }
     }
     E4_STAMP(2);
-    // ================= final layer: fragments 384 .. 511, k-major over the 4 output tiles (8 k-steps of z re-read from the wave's
-    // LDS rows, 24 of h2), then the fold step
+    // ================= final layer: fragments 384 .. 479, k-major over the 4 output tiles: 24 k-steps of h2 + x (the z part of x was added
+    // at the hand-over, its e_i / e_j parts arrive through the fold step below); the stream's last two chunks hold no layer weights
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < n_tiles;
     const E4Tile tn = e4_tile_of((has_next ? ntile : tile) * E4_WAVES + wave, n_wt, N, NJ4);
@@ -873,39 +679,26 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
 #pragma unroll
       for (int q = 0; q < 16; ++q) E.Y[t][q] = 0.f;
     hx8 FL[4];
-    {
-      hx8 zb[2];
-      const int l2 = lane_id();  // the z row address again, from an opaque copy (otherwise the 8 layer-1 addresses stay live)
-      const unsigned zrow2 = lds0 + E4_ZOFF + wave * 8192 + (l2 & 31) * 256, zx = (l2 >> 5) ^ (l2 & 15);
-      zb[0] = e4_frag(zrow2 + (zx << 4));
 #pragma unroll
-      for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < 24; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int f = E4_L1_FR + E4_L2_FR + 4 * s + t;
-          if ((f & 15) == 8) e4_point(F, f >> 4);
-          if (t == 0 && s + 1 < 8) zb[(s + 1) & 1] = e4_frag(zrow2 + (((2 * (s + 1)) ^ zx) << 4));
-          E4_STEP(f, zb[s & 1], E.Y[t]);
-        }
+      for (int t = 0; t < 4; ++t) {
+        const int f = E4_L1_FR + E4_L2_FR + 4 * s + t;
+        if ((f & 15) == 8) {
+          e4_point(F, f >> 4);
+          // point E4_PT_Z: the wave's z rows are free since the fourth hand-over of layer 2 — the next tile's are requested here, seven chunks
+          // before the tile ends (always issued, the last tile re-requests its own: the counts of e4_vm_younger stay static)
+          if ((f >> 4) == E4_PT_Z) e4_request_z(a, tn, lane_id(), lds0 + E4_ZOFF + wave * 8192, M);
+          if ((f >> 4) == E4_PT_FL) {
+            const unsigned fb = fold_ptr(tc, lane_id());
 #pragma unroll
-      for (int s = 8; s < 32; ++s)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int f = E4_L1_FR + E4_L2_FR + 4 * s + t;
-          if ((f & 15) == 8) {
-            e4_point(F, f >> 4);
-            // point 26: the wave's z rows are free since fragment 415 — the next tile's are requested here, 5 chunks before the
-            // tile ends (always issued, the last tile re-requests its own: the counts of e4_vm_younger stay static)
-            if ((f >> 4) == 26) e4_request_z(a, tn, lane_id(), lds0 + E4_ZOFF + wave * 8192, M);
-            if ((f >> 4) == 28) {
-              const unsigned fb = fold_ptr(tc, lane_id());
-#pragma unroll
-              for (int k = 0; k < 4; ++k) FL[k] = fold_ld(fb + (12 + k) * 512);
-            }
+            for (int k = 0; k < 4; ++k) FL[k] = fold_ld(fb + (12 + k) * 512);
           }
-          E4_STEP(f, H2[s - 8], E.Y[t]);
         }
-    }
+        E4_STEP(f, H2[s], E.Y[t]);
+      }
+    e4_point(F, 30);  // the unused chunk and the down_z chunk: their stream points without products (the ring keeps turning)
+    e4_point(F, 31);
     {
       const hx8 SEL = e4_sel(lane, tc.ns);
 #pragma unroll
@@ -918,22 +711,18 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
     for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
     E.t = tc;
     em_req = mask_of(tn, lane);
-    hx8 DL[PZ ? 8 : 1];  // lo fragments of down_z for the epilogue (L2 hits, in flight under its LayerNorm statistics)
-    if constexpr (PZ && !(E4_PZ_ABL & 3))
-#pragma unroll
-      for (int k = 0; k < 8; ++k) DL[k] = e4_gfrag((const char*)a.wdz_img_lo + k * 1024 + lane * 16);
     if (!(E4_ABL & 1)) {
       E4EpiTmp X;
       X.moff = lds0 + E4_MOFF + tid * 4;
       X.boff = lds0 + E4_BOFF;
       const unsigned stg = lds0 + E4_SOFF + wave * 2048;
-      e4_epi<0, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<1, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<2, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<3, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<4, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<5, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
-      e4_epi<6, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, DL);
+      e4_epi<0, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
+      e4_epi<1, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
+      e4_epi<2, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
+      e4_epi<3, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
+      e4_epi<4, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
+      e4_epi<5, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
+      e4_epi<6, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
     } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
     E4_STAMP(4);
     if (!has_next) break;
@@ -987,10 +776,6 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
         hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)edge_transition4_flat_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
       return FDIPT_ELAUNCH;
-#if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)
-    if (hipFuncSetAttribute((const void*)edge_transition4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E4_LDS) != hipSuccess)
-      return FDIPT_ELAUNCH;
-#endif
     attr_dev.set(dev_, 1);
   }
   const int n_cu = fd_cu_count();
@@ -998,12 +783,9 @@ int fd_edge_transition4_variant(const ET2Args& a, hipStream_t st, int flat) {
   const int cus = a.reserve_cus > 0 && a.reserve_cus < n_cu - 8 ? (n_cu - a.reserve_cus) & ~7 : n_cu;
   const int slots = cus * (E4_LDS <= 81920 ? 2 : 1);
   const int grid = n_tiles < slots ? n_tiles : slots;
-#if defined(FDIPT_DEV) || defined(E4_KEEP_CHUNK)
-  if (!flat) hipLaunchKernelGGL(edge_transition4_kernel, dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);
-  else
-#endif
+  (void)flat;
   if (a.pz_out) {  // + pair_z of the next block (needs its bias emission: the zero unit / images share its set-up)
-    if (!a.wb_img || !a.wdz_img || !a.wdz_img_lo || !a.bdz) return FDIPT_EINVAL;
+    if (!a.wb_img || !a.bdz) return FDIPT_EINVAL;  // (down_z hi / lo: the stream's last chunk, fd_et4_set_dz)
     if (!a.z_out) {  // (only next to both emissions and without a trace: checked by the caller's conditions, and here)
       if (a.trace) return FDIPT_EINVAL;
       hipLaunchKernelGGL((edge_transition4_flat_kernel<true, false>), dim3(grid), dim3(E4_THREADS), E4_LDS, st, a, n_tiles, n_wt);

@@ -159,8 +159,8 @@ struct ET2Args {
   unsigned long long* clock = nullptr;  // optional shader-clock probe (FdiptForwardArgs.clock_out)
   // optional (edge_transition4 with wb_img set; round 6): pair_z = down_z(z') + b of the NEXT block's IPA (ipa_pytorch.py:158,318) from the
   // same epilogue, as the image opair_pz_kernel reads (fd_pz_bytes): 64 B per pair instead of a second pass over the 256 B of z'
-  const void* wdz_img = nullptr;     // down_z [32, 128] as a fragment image, k in hand-off order (fd_chain_build_image_ex(.., permuted = 1, lo = 0))
-  const void* wdz_img_lo = nullptr;  // ... of Wdz - half(Wdz) (lo = 1)
+  const void* wdz_img = nullptr;     // (edge_embed2 only) down_z [32, 128] as a fragment image, k in hand-off order (fd_chain_build_image_ex(.., permuted = 1, lo = 0));
+  const void* wdz_img_lo = nullptr;  // ... of Wdz - half(Wdz) (lo = 1).  edge_transition4 finds both in the last chunk of its weight stream (fd_et4_set_dz)
   const float* bdz = nullptr;        // [32]
   half_t* pz_out = nullptr;          // [B*N][N/4][32][4]
 };
@@ -175,6 +175,7 @@ int fd_et3_build_bias_image(const float* wb, int H, float scale, void* img, hipS
 int fd_edge_transition3_supported(int N);
 // edge_transition4.hip (default, N % 4 == 0): 32-pair waves (8 i x 4 j patches), e_i / e_j parts folded into one k-step
 int fd_et4_build_stream(const float* w1, const float* w2, const float* wf, void* stream, hipStream_t st);
+int fd_et4_set_dz(void* stream, const void* img_hi, const void* img_lo, hipStream_t st);  // down_z of the next block -> the stream's last chunk
 size_t fd_et4_stream_bytes();
 int fd_et4_build_bias_image(const float* wb, int H, float scale, void* img, hipStream_t st);  // 8 KB, for ET2Args.wb_img
 size_t fd_et4_a_image_bytes(int B, int N);

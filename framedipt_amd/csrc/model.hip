@@ -517,6 +517,9 @@ int fdipt_model_prepare(const FdiptDims* d, const float* P, void* derived, fdipt
                       (rc = fd_chain_build_image_ex(P + k.dz.w, cz / 4, cz, cz, 1, 0, D + db.wdz_imgp, st)) ||
                       (rc = fd_chain_build_image_ex(P + k.dz.w, cz / 4, cz, cz, 1, 1, D + db.wdz_imgp_lo, st))))
       return rc;
+    // ... which ride in the last chunk of the PREVIOUS block's EdgeTransition weight stream (its epilogue emits this block's pair_z; the
+    // stream itself is built in that block's iteration, below: same stream, in order)
+    if (b > 0 && cz == 128 && use_regpair(d) && (rc = fd_et4_set_dz(D + L.blk[b - 1].et4, D + db.wdz_imgp, D + db.wdz_imgp_lo, st))) return rc;
     if (use_regpair(d) && b < d->num_blocks - 1)
       if ((rc = fd_et3_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et3, st)) ||
           (rc = fd_et4_build_stream(P + k.et1.w, P + k.et2.w, P + k.etf.w, D + db.et4, st)))
@@ -1362,7 +1365,7 @@ static int forward_impl(const FdiptDims* d, const float* P, const void* derived,
         bias_ready = emit_bias;
         pz_ready = false;
         if (use_et4 && emit_bias && pz_path) {
-          t2.wdz_img = D + L.blk[b + 1].wdz_imgp; t2.wdz_img_lo = D + L.blk[b + 1].wdz_imgp_lo; t2.bdz = P + iv.blk[b + 1].dz.b; t2.pz_out = (half_t*)(W + w.pz);
+          t2.bdz = P + iv.blk[b + 1].dz.b; t2.pz_out = (half_t*)(W + w.pz);  // (down_z itself: the last chunk of the weight stream)
           pz_ready = true;
           // the last EdgeTransition of the trunk: block b + 1 takes bias and pair_z from this epilogue and no launch reads z' itself
           if (b + 1 == d->num_blocks - 1 && !tr_ptr && !sw.keep_last_z) t2.z_out = nullptr;
