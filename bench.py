@@ -51,11 +51,12 @@ sys.path.insert(0, ROOT)
 
 ET_FLOPS_PER_PAIR = 688128.0   # 2*(2*384^2 + 384*128): EdgeTransition, reference formulation
 NOMINAL_GHZ = 2.4  # engine clock of PEAK_TFLOPS (MI355X_MICROARCH.md)
-# edge_transition4: 536 MFMAs of 32x32x16 per 32-pair wave tile for the three layers + 24 in the epilogue (round 6: 8 for the next block's
-# pair bias linear_b(z'), 16 for its pair_z = down_z(z') on hi + lo weights).  The reference-formulation count of the launch stays
+# edge_transition4: 504 MFMAs of 32x32x16 per 32-pair wave tile for the three layers (round 6: 536 before the z part of the residual
+# trunk(x) + x was merged into the hidden features it shares its final-layer columns with) + 24 in the epilogue (8 for the next block's pair
+# bias linear_b(z'), 16 for its pair_z = down_z(z') on hi + lo weights).  The reference-formulation count of the launch stays
 # ET_FLOPS_PER_PAIR: the epilogue's products are other modules' work (2 * 128 * (8 + 32) = 10,240 FLOP per pair, FUSED_FLOPS_PER_PAIR)
-# that rides on this launch, so `frac` prices a launch that now does more than it is credited for (`frac_incl_fused` credits it)
-ET4_EXEC_FLOPS_PER_PAIR = (536 + 24) * 32 * 32 * 16 * 2 / 32.0
+# that rides on this launch; `frac` prices the launch on the EdgeTransition FLOPs alone, `frac_incl_fused` credits the fused projections
+ET4_EXEC_FLOPS_PER_PAIR = (504 + 24) * 32 * 32 * 16 * 2 / 32.0
 FUSED_FLOPS_PER_PAIR = 2.0 * 128 * (8 + 32)  # linear_b (ipa_pytorch.py:247) + down_z (:158,318) of the next block, reference formulation
 PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 
