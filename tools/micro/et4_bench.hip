@@ -1,4 +1,5 @@
-// Stand-alone timing + in-kernel phase profile of edge_transition4_kernel (build with -DFD_PROF for the profile).
+// Stand-alone timing + in-kernel phase profile of edge_transition4_flat_kernel (build with -DE4_PROF for the profile).  Round 6: the chunk-synchronous
+// predecessor is gone from the library; the two "variants" below are two runs of the flat kernel (run-to-run bit identity), variant 1 with the pair_z emission.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w [-DFD_PROF] [-DE4_ABL=k] tools/micro/et4_bench.hip -o et4_bench
 #define E4_KEEP_CHUNK
 #include "../../framedipt_amd/csrc/edge_transition4.hip"
@@ -24,7 +25,7 @@ __global__ void diff_count(const unsigned* x, const unsigned* y, long n, unsigne
 }
 int main(int argc, char** argv) {
   const int B = 8, N = argc > 1 ? atoi(argv[1]) : 300;
-  const int only = argc > 3 ? atoi(argv[3]) : -1;  // time only this variant (0 chunk-synchronous, 1 flat)
+  const int only = argc > 3 ? atoi(argv[3]) : -1;  // time only this variant (0: pair bias only, 1: + pair_z of the next block)
   const float ds = argc > 4 ? atof(argv[4]) : 1.f;  // data scale (0: all-zero operands, the low-power case)
   const long P = (long)B * N * N, R = (long)B * N;
   half_t *z, *zo[2]; float *b2, *g, *bt, *rm, *w1, *w2, *wf, *wb, *rows, *bo[2]; void* stream;
@@ -52,18 +53,21 @@ int main(int argc, char** argv) {
     (void)hipMemset(bo[0], 0, (size_t)B * 8 * Np * Np * 4); (void)hipMemset(bo[1], 0, (size_t)B * 8 * Np * Np * 4);
     a.wb_img = (argc > 2 && atoi(argv[2]) == 0) ? nullptr : wimg; a.bb = b2; a.H = 8;
   }
+  half_t* pz; float* bdz;
+  (void)hipMalloc(&pz, fd_pz_bytes(B, N)); (void)hipMalloc(&bdz, 128); (void)hipMemset(bdz, 0, 128);
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
-  const double flops = 655360.0 * P;
+  const double flops = 688128.0 * P;  // reference-formulation count (bench.py: ET_FLOPS_PER_PAIR)
   for (int v = 0; v < 2; ++v) {
     if (only >= 0 && v != only) continue;
     a.z_out = zo[v]; a.bias_out = bo[v];
+    a.pz_out = (v == 1 && a.wb_img) ? pz : nullptr; a.bdz = bdz;  // (down_z itself: zeros in the stream's last chunk)
     for (int i = 0; i < 3; ++i) fd_edge_transition4_variant(a, 0, v);
     (void)hipEventRecord(t0, 0);
     const int iters = 20;
     for (int i = 0; i < iters; ++i) fd_edge_transition4_variant(a, 0, v);
     (void)hipEventRecord(t1, 0); (void)hipEventSynchronize(t1);
     float ms; (void)hipEventElapsedTime(&ms, t0, t1);
-    printf("ET4 %s N=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 2500)\n", v ? "flat " : "chunk", N, ms / iters, flops / (ms / iters) / 1e9, flops / (ms / iters) / 1e9 / 25.0);
+    printf("ET4 %s N=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 2500)\n", v ? "flat + pair_z" : "flat", N, ms / iters, flops / (ms / iters) / 1e9, flops / (ms / iters) / 1e9 / 25.0);
   }
   if (only < 0) {
     unsigned long long* d; (void)hipMalloc(&d, 16); (void)hipMemset(d, 0, 16);
@@ -72,7 +76,7 @@ int main(int argc, char** argv) {
     unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
     std::vector<half_t> hz(4096); (void)hipMemcpy(hz.data(), zo[0] + (P / 2) * 128, 8192, hipMemcpyDeviceToHost);
     double sa = 0; for (auto x : hz) sa += fabs((double)(float)__builtin_bit_cast(_Float16, x));
-    printf("flat vs chunk: %llu differing z words of %ld, %llu differing bias words; mean |z'| %.4f\n", h[0], P * 64, h[1], sa / 4096);
+    printf("with vs without pair_z: %llu differing z words of %ld, %llu differing bias words; mean |z'| %.4f\n", h[0], P * 64, h[1], sa / 4096);
   }
 #ifdef E4_PROF
   {
