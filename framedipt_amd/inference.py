@@ -439,7 +439,7 @@ class StreamedLoops:
 
 def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj=False, self_condition=True,
                  noise_scale=1.0, embed_self_conditioning=True, inpainting=False, input_aatype=False, noise_tape=None,
-                 return_device=False, streams=1, experimental_streams=False, graph=True, verify=0):
+                 return_device=False, streams=1, experimental_streams=False, graph=True, verify=0, pad_to_four=True):
     """Same arguments / returned keys as the reference.  ``noise_tape=(z_rot, z_trans)`` ([num_t-1,B,N,3] float64
     N(0,1) draws) overrides the global ``np.random`` stream (sample-sharded runs).  ``data_init`` tensors carry a
     leading batch dimension B >= 1 (the reference always passes B = 1).  ``graph=True`` (default): the steps are replays of a HIP
@@ -448,6 +448,20 @@ def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj
     otherwise; one host sync per verified step) — for GPUs shared with other compute processes (``gpu_guard``).  ``streams=n``: the batch runs as n sub-batches on n HIP streams (same results; the latency-bound
     node path of one sub-batch overlaps the pair kernels of the other) — experimental: needs ``experimental_streams=True`` (or
     FDIPT_EXPERIMENTAL_STREAMS=1), at most two streams, N <= 384 (``StreamedLoops``; eager launches)."""
+    # Round 6: lengths that are no multiple of 4 run the half-precision mode's fall-back pair kernels (edge_transition3, the pass over z for
+    # o_pair): 2.94 ms per step at N = 302 against 2.14 at 304 (eight samples).  ``pad_to_four`` (default) pads such a sample with masked rows
+    # (res_mask = 0, identity frames, zero noise: sharding.pad_item, what run_sharded does to mixed-length batches) and cuts the returned
+    # arrays back to N — the real residues see the same arithmetic as in a run_sharded batch of their kernel class.  The noise tape is drawn
+    # for the REAL residues first (the reference's np.random order is untouched).
+    n_real = int(data_init["rigids_t"].shape[1])
+    n_pad = -(-n_real // 4) * 4
+    padded = bool(pad_to_four) and n_pad != n_real and getattr(model, "precision", _lib.PREC_F32) != _lib.PREC_F32
+    if padded:
+        from . import sharding
+        if noise_tape is None:
+            n_noisy = int(np.sum(np.linspace(min_t, 1.0, num_t)[::-1] > min_t))
+            noise_tape = draw_noise_tape(diffuser, n_noisy, int(data_init["rigids_t"].shape[0]), n_real)
+        data_init, noise_tape = sharding.pad_item(data_init, noise_tape, n_pad)
     if streams > 1 and data_init["rigids_t"].shape[0] > 1:  # sub-batches on their own HIP streams (same results)
         # (the sub-loops are eager ReverseLoops: verify= is passed through to them, graph= does not apply)
         loop = StreamedLoops(model, diffuser, data_init, streams, num_t, min_t, noise_tape=noise_tape, center=center, aux_traj=aux_traj,
@@ -459,4 +473,7 @@ def inference_fn(model, diffuser, data_init, num_t, min_t, center=True, aux_traj
     else:
         loop = ReverseLoop(model, diffuser, data_init, num_t, min_t, center, aux_traj, self_condition, noise_scale,
                            embed_self_conditioning, inpainting, input_aatype, noise_tape, graph=graph, verify=verify).run()
-    return loop.results(return_device)
+    res = loop.results(return_device)
+    if padded:  # (every returned array carries the residues on the axis behind the batch)
+        res = {k: v[:, :, :n_real] for k, v in res.items()}
+    return res

@@ -11,6 +11,10 @@ from test_gpu_robustness import _setup
 pytestmark = pytest.mark.gpu
 
 
+def _host(v):
+    return v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+
 def _forward(G, kernel_flags, trace=False):
     from framedipt_amd import config
     from framedipt_amd.diffusion import SE3Diffuser
@@ -84,3 +88,39 @@ def test_pair_z_path_at_its_size_boundary(n, b):
     np.testing.assert_array_equal(runs[0], runs[1])
     rmsd = np.sqrt(((runs[0] - ref) ** 2).sum(-1).mean(axis=(1, 2))).max()
     assert rmsd < 5e-4, (n, b, rmsd)
+
+
+@pytest.mark.parametrize("n,b", [(30, 2), (45, 1)])
+def test_inference_fn_pads_lengths_that_are_no_multiple_of_four(n, b):
+    """inference_fn(pad_to_four=True, the default) runs a sample of N % 4 != 0 residues with masked pad rows on the fast pair kernels
+    (edge_transition4 + the pair_z path) and returns arrays of the ORIGINAL length: bit-identical to the same sample padded by hand
+    (sharding.pad_item: what run_sharded does), and within the half-precision bounds of the un-padded run on the fall-back kernels."""
+    from framedipt_amd import config, sharding
+    from framedipt_amd.diffusion import SE3Diffuser
+    from framedipt_amd.inference import draw_noise_tape, inference_fn
+    from framedipt_amd.model import ScoreNetwork
+    from framedipt_amd.sampler import UnconditionalSampler
+    conf = config.base_config()
+    d = SE3Diffuser(conf.diffuser, device="cuda")
+    net = ScoreNetwork(conf.model, d, precision="fp16").load_synthetic(7).to("cuda")
+    ds = UnconditionalSampler(config.to_conf({"min_length": n, "max_length": n, "length_step": 1, "samples_per_length": b}), d, "cuda")
+    T = 4
+    feats, tape = sharding.stack_items([sharding.seeded_item(ds, i, 5, d, T, 0.01) for i in range(b)])
+    kw = dict(num_t=T, min_t=0.01, aux_traj=True, noise_scale=0.1)
+    auto = inference_fn(net, d, feats, noise_tape=tape, **kw)
+    for k, v in auto.items():
+        assert v.shape[2] == n, (k, v.shape)
+    n_pad = -(-n // 4) * 4
+    fp, tp = sharding.pad_item(feats, tape, n_pad)
+    hand = inference_fn(net, d, fp, noise_tape=tp, **kw)
+    for k in auto:
+        np.testing.assert_array_equal(_host(auto[k]), _host(hand[k])[:, :, :n], err_msg=k)
+    plain = inference_fn(net, d, feats, noise_tape=tape, pad_to_four=False, **kw)
+    assert kabsch_free_rmsd(np.asarray(auto["prot_traj"][-1]), np.asarray(plain["prot_traj"][-1])) < 1e-3
+    # without a tape the draws follow the reference's np.random order for the REAL residues (the pad rows draw nothing)
+    np.random.seed(11)
+    t_ref = draw_noise_tape(d, T - 1, b, n)
+    np.random.seed(11)
+    a2 = inference_fn(net, d, feats, **kw)
+    a3 = inference_fn(net, d, feats, noise_tape=t_ref, **kw)
+    np.testing.assert_array_equal(np.asarray(a2["prot_traj"]), np.asarray(a3["prot_traj"]))
