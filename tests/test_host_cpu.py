@@ -518,3 +518,19 @@ def test_mixed_batches_stay_inside_one_kernel_selection_class():
             assert len(classes) == 1, (g, [lengths[p] for p in g])
     assert sharding.kernel_class(384) == sharding.kernel_class(381) != sharding.kernel_class(385)
     assert sharding.kernel_class(300) == sharding.kernel_class(320) != sharding.kernel_class(321)
+
+
+def test_kernel_flag_constants_match_the_header():
+    """framedipt_amd._lib.KF_* (what ScoreNetwork(kernel_flags=...) passes in FdiptDims) against the FDIPT_KF_* macros of include/fdipt.h,
+    incl. round 6's FDIPT_KF_PASS_Z; FDIPT_KF_ALL covers every bit."""
+    import os
+    import re
+
+    from framedipt_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define FDIPT_KF_(\w+) (\d+)", open(os.path.join(root, "include", "fdipt.h")).read())}
+    names = [k for k in macros if k != "ALL"]
+    assert len(names) >= 9
+    for k in names:
+        assert getattr(_lib, "KF_" + k) == macros[k], k
+    assert macros["ALL"] == sum(macros[k] for k in names)
