@@ -24,7 +24,8 @@
 #include "kernels.hpp"
 
 #ifndef E4_ABL
-#define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 16 (flat) no LDS fragment reads
+#define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 8 no z' / bias stores, 16 (flat) no LDS fragment reads,
+                  // 32 no LayerNorm arithmetic in the epilogue (statistics and normalisation skipped: conversions, staging, stores, products stay)
 #endif
 #ifndef E4_PZ_ABL
 #define E4_PZ_ABL 0  // timing ablations of the pair_z emission (wrong results): 1 no lo part, 2 lo part from the hi image in LDS (no L2 loads), 4 no pair_z stores, 8 no hi part
@@ -361,6 +362,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
     // vmcnt, i.e. together with the z rows and weights of the next tile requested just before the epilogue
     E.em = *(const __attribute__((address_space(3))) float*)(unsigned long)(X.moff);
     f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
+    if (!(E4_ABL & 32))
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -412,6 +414,7 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
       for (int k = 0; k < 2; ++k) {
         const int g = 2 * h2 + k;
         f32x2 o0 = {E.Y[t][4 * g], E.Y[t][4 * g + 1]}, o1 = {E.Y[t][4 * g + 2], E.Y[t][4 * g + 3]};
+        if (E4_ABL & 32) { o[2 * k] = o0; o[2 * k + 1] = o1; continue; }
         o0 = __builtin_elementwise_fma(o0, X.sa, X.sc);
         o1 = __builtin_elementwise_fma(o1, X.sa, X.sc);
         o[2 * k] = __builtin_elementwise_fma(o0, f32x2{gm[k][0], gm[k][1]}, f32x2{bt[k][0], bt[k][1]});

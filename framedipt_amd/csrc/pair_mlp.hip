@@ -207,6 +207,9 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_kernel(EdgeTransAr
 // The weight tiles of one block in stream order: layer 1 (3 passes x 12 k-tiles), layer 2 (3 x 12), final layer (1 x 12).
 #define ETF_TILES 84
 // phase profile (-DETF_PROF, tools/micro/etf_bench.hip): cycles of wave 0 of the first 256 blocks
+#ifdef ETF_PROF2
+__device__ unsigned long long etf_prof2[16];
+#endif
 #ifdef ETF_PROF
 __device__ unsigned etf_prof[256 * 8];
 #define ETF_STAMP(k)                                             \
@@ -555,6 +558,18 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
   EtfOps o0, o1;
   __syncthreads();
   o0.read(arow, Ws0 + (t0 % 3) * (ETF_WS / 4) + woff);
+#ifdef ETF_PROF2  // where a multiplier's step goes (tools/micro/etf_bench.hip): cycles at the step barrier / per step, wave 0 of every block
+  unsigned long long p2_bar = 0, p2_tot = 0, p2_last = __builtin_amdgcn_s_memtime();
+#define ETF_STEP_BARRIER()                                                         \
+  do {                                                                             \
+    const unsigned long long b0_ = __builtin_amdgcn_s_memtime();                   \
+    __syncthreads();                                                               \
+    const unsigned long long b1_ = __builtin_amdgcn_s_memtime();                   \
+    p2_bar += b1_ - b0_; p2_tot += b1_ - p2_last; p2_last = b1_;                   \
+  } while (0)
+#else
+#define ETF_STEP_BARRIER() __syncthreads()
+#endif
   auto step = [&](int tl, EtfOps& cur, EtfOps& nxt) {
     const int t = t0 + tl, kt = tl % 12;
     const float* an = arow + ((kt + 1) % 12) * 32;
@@ -562,7 +577,7 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
 #define ETF_MMA(i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[(i) >> 2][(i) & 3], cur.w[(i) >> 2][(i) & 3], acc, 0, 0, 0); \
                    __builtin_amdgcn_sched_barrier(0)
 #define ETF_GAP(...) __VA_ARGS__; __builtin_amdgcn_sched_barrier(0)
-    ETF_MMA(0);  ETF_GAP(__syncthreads());
+    ETF_MMA(0);  ETF_GAP(ETF_STEP_BARRIER());
     // one dword of each of the tile's 128 lines (row = wave * 32 + lane, 128 B per row) into ONE register that stays allocated for the
     // whole kernel (`tok`: a dead destination would be re-used by the compiler while the load is still in flight), never waited for: the
     // tile is in L2 when the movers ask for it four steps later (the z stream evicts the weights from the XCD's L2 between two uses)
@@ -598,6 +613,12 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
     step(tl + 4, o0, o1);
     step(tl + 5, o1, o0);
   }
+#ifdef ETF_PROF2
+  if (tid == 0) {
+    atomicAdd(&etf_prof2[0], p2_bar); atomicAdd(&etf_prof2[1], p2_tot); atomicAdd(&etf_prof2[2], (unsigned long long)(NP * 12));
+    atomicAdd(&etf_prof2[8 + 2 * (t0 / 36)], p2_bar); atomicAdd(&etf_prof2[9 + 2 * (t0 / 36)], p2_tot);  // per layer
+  }
+#endif
 }
 // The mover's side of a layer: tile t + 2 (in registers since two steps) -> its LDS slot, tile t + 4 requested (the register roles of
 // etf_layer), all four mover waves every step; `mt` = 0..255.  With the requests ablated the launch takes 3.89 ms, with them 4.45:
@@ -647,6 +668,113 @@ __device__ __forceinline__ void etfs_layer_move(const EtfStream& st, int t0, flo
   }
 }
 
+// ------------------------------------------------------------------ the movers as LDS-DMA (round 6)
+// The decisive ablation above says the cost of the weight stream is the traffic through the VGPR file of the SIMD a mover shares with a
+// multiplier (16 B x 64 lanes x 4 requests written back per wave and step, read again by 4 ds_write_b128), not its latency.
+// `global_load_lds_dwordx4` (the path the half-precision kernel streams its fragments on, edge_transition4.hip) takes the tile from L2 to
+// LDS without touching a VGPR: an instruction writes 64 x 16 B = 1 KB of CONSECUTIVE LDS (M0 + 16 lane) from 64 free global addresses, so
+// the padded slot layout ([128 rows][36 words], 9 pieces of 16 B per row, 18 KB = 18 instructions per tile) comes out of the address
+// arithmetic of the lanes: piece u = 64 i + lane of the slot is (row u / 9, words 4 (u % 9) ..), the ninth piece of a row is padding (its
+// lane asks for the eighth again).  Four mover waves, five instructions each per step (instructions 18, 19 repeat 14, 15: every wave
+// waits with the same count).  Ring of three slots as before, but a tile now needs its slot only from the request on: during step t
+// (behind the step's barrier, which has seen the last operand read of tile t) tile t + 3 is requested into slot t % 3; before a mover
+// arrives at the next barrier it waits until the requests of the PREVIOUS step have landed (vmcnt counts an LDS-DMA down when the data
+// is in LDS): tile t + 2 is complete when step t + 1 reads it - the same two steps of latency budget as the register ring had.
+// The X0 rows of the next row tile still travel through registers (buf0 is the final layer's input until its last step): they are
+// requested right behind the DMAs of the final layer's first step and the two waits that have them in front of the awaited DMAs allow
+// 12 more operations to stay out.
+#ifndef ETF_DMA
+#define ETF_DMA 1
+#endif
+struct EtfDma {
+  unsigned off[5];  // byte offset of this lane's 16 B within the [128][ETF_H] window of a weight tile, per instruction of this wave
+  unsigned ws;      // LDS byte address of this wave's first 1 KB in slot 0 (wave-uniform, an SGPR)
+  // NO vector instruction per request: the multiplier wave of the SIMD issues matrix instructions back to back and a vector-ALU
+  // instruction of the mover gets a turn about once per MFMA (measured with s_memtime: 1.2 k cycles for five requests while each had a
+  // v_readfirstlane and a 64-bit v_add in front of it - the movers were late at every step barrier).  M0 comes out of scalar arithmetic
+  // and the address is SGPR base (tile) + 32-bit VGPR offset (lane), both set up once.
+  __device__ __forceinline__ void init(int mw, int lane, const float* Ws) {
+    ws = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)Ws) + (unsigned)mw * 1024u;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      int i = mw + 4 * j;
+      if (i >= 18) i -= 4;
+      const int u = 64 * i + lane, row = u / 9, c = u % 9;
+      off[j] = (ETF_ABL & 16) ? (unsigned)(row * 32 + 4 * (c < 8 ? c : 7)) * 4u  // (timing only: the tile as 16 KB of consecutive memory)
+                              : (unsigned)(row * ETF_H + 4 * (c < 8 ? c : 7)) * 4u;
+    }
+  }
+  __device__ __forceinline__ void tile(unsigned long src, int slot, int mw) const {
+    const unsigned long sb = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(src >> 32)) << 32) |
+                             (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)src);  // (the builtin returns int: no sign extension)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      // instruction i = mw + 4 j of the slot (18, 19 repeat 14, 15): mw < 2 -> j * 4 KB, else the last one stays at j = 3
+      const unsigned m0v = ws + slot * ETF_WS + ((j == 4 && mw >= 2) ? 3u : (unsigned)j) * 4096u;
+      if (!(ETF_ABL & 4)) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(off[j]), "s"(sb) : "memory", "m0");
+    }
+  }
+};
+#define ETF_VMWAIT(n)                                                                                 \
+  do {                                                                                                \
+    if (!(ETF_ABL & 32) || (n) == 0) asm volatile("s_waitcnt vmcnt(" #n ")" : : : "memory");          \
+  } while (0)  // (ETF_ABL & 32: timing only, nobody waits for the tiles)
+// mover's side of a layer, DMA form: t0 a multiple of 6; `first(k)` runs behind the DMAs of the layer's first step (k = 0) and decides
+// whether 12 more operations stay in front of the awaited DMAs for two steps
+template <int NP>
+__device__ __forceinline__ void etfs_layer_dma(const EtfStream& st, int t0, const EtfDma& D, int mw) {
+  __syncthreads();
+#ifdef ETF_PROF2
+  unsigned long long mv_busy = 0, mv_issue = 0;
+#endif
+  auto step = [&](int t, int k) {
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef ETF_PROF2
+    const unsigned long long m0_ = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    D.tile((ETF_ABL & 16) ? (unsigned long)st.w1 + (unsigned long)((t + 3) % ETF_TILES) * 16384ul : st.addr(t + 3), k % 3, mw);
+#ifdef ETF_PROF2
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long m1_ = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    ETF_VMWAIT(5);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef ETF_PROF2
+    const unsigned long long m2_ = __builtin_amdgcn_s_memtime();
+    mv_issue += m1_ - m0_; mv_busy += m2_ - m0_;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+#pragma unroll 1
+  for (int tl = 0; tl < NP * 12; tl += 6) {
+    step(t0 + tl, 0); step(t0 + tl + 1, 1); step(t0 + tl + 2, 2); step(t0 + tl + 3, 3); step(t0 + tl + 4, 4); step(t0 + tl + 5, 5);
+  }
+#ifdef ETF_PROF2
+  if (threadIdx.x == FD_THREADS) { atomicAdd(&etf_prof2[3], mv_busy); atomicAdd(&etf_prof2[4], mv_issue); atomicAdd(&etf_prof2[5], (unsigned long long)(NP * 12)); }
+#endif
+}
+// the final layer's twelve steps, straight-line (a request inside a rolled loop makes hipcc protect its destination registers against
+// the previous iteration's loads with waits that know nothing of the DMAs in the queue); `request()` = the X0 rows of the next row tile
+// (12 loads) or nothing, behind the DMAs of the first step
+template <class Request>
+__device__ __forceinline__ void etfs_final_dma(const EtfStream& st, const EtfDma& D, int mw, bool more, Request request) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    D.tile((ETF_ABL & 16) ? (unsigned long)st.w1 + (unsigned long)((72 + k + 3) % ETF_TILES) * 16384ul : st.addr(72 + k + 3), k % 3, mw);
+    if (k == 0 && more) request();
+    __builtin_amdgcn_sched_barrier(0);
+    if (k < 2 && more) ETF_VMWAIT(17);
+    else ETF_VMWAIT(5);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <class ZT>
 __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(EdgeTransArgs a, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -663,10 +791,19 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
     const int mt = threadIdx.x - FD_THREADS;
     const ZT* z_in = (const ZT*)a.z_in;
     const EtfStream st = {(const float*)a.w1, (const float*)a.w2, (const float*)a.wf};
+#if ETF_DMA
+    EtfDma D;
+    const int mw = __builtin_amdgcn_readfirstlane(mt >> 6);
+    D.init(mw, mt & 63, Ws);
+    D.tile(st.addr(0), 0, mw);
+    D.tile(st.addr(1), 1, mw);
+    D.tile(st.addr(2), 2, mw);
+#else
     EtfTile g0, g1, g2;
     st.load(g0, 0, mt);
     st.load(g1, 1, mt);
     st.load(g2, 2, mt);
+#endif
     f32x4 xr[12];
     auto request_x0 = [&](long p0) {
 #pragma unroll
@@ -698,6 +835,18 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
     int blk = blockIdx.x;
     request_x0((long)blk * 32);
     store_x0();
+#if ETF_DMA
+    ETF_VMWAIT(0);  // tiles 0 .. 2 are in their slots
+    for (; blk < n_blocks; blk += gridDim.x) {
+      etfs_layer_dma<3>(st, 0, D, mw);
+      etfs_layer_dma<3>(st, 36, D, mw);
+      const long pn = (long)(blk + gridDim.x) * 32;
+      etfs_final_dma(st, D, mw, blk + (int)gridDim.x < n_blocks, [&]() { request_x0(pn); });
+      __syncthreads();
+      store_x0();  // buf0 is free (the next layer 1 starts with a barrier)
+    }
+    ETF_VMWAIT(0);  // the tiles requested beyond the last row tile land before the block gives its LDS back
+#else
     g0.store(Ws, mt);
     g1.store(Ws + ETF_WS / 4, mt);
     st.load(g0, 3, mt);
@@ -711,6 +860,7 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
       store_x0();  // buf0 is free (the next layer 1 starts with a barrier)
     }
     if (ETF_ABL & 8) asm volatile("s_waitcnt vmcnt(0)" : : "v"(g_dummy[0]), "v"(g_dummy[1]), "v"(g_dummy[2]), "v"(g_dummy[3]) : "memory");
+#endif
   } else {
     // ================= multipliers
     const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
@@ -738,6 +888,9 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
     for (; blk < n_blocks; blk += gridDim.x) {
       const long p0 = (long)blk * 32;
       const float em_row = em_next;
+#ifdef ETF_PROF2
+      const unsigned long long tile_t0 = __builtin_amdgcn_s_memtime();
+#endif
       etfs_layer_compute<3>(buf0, st, 0, Ws, tid, tok, [&](int pass, const f32x16& acc) {
         const int n = pass * 128 + ncol;
         const float bv = pass == 0 ? bias1[0] : (pass == 1 ? bias1[1] : bias1[2]);
@@ -759,7 +912,7 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
         for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
       });
       __syncthreads();
-      {
+      if (!(ETF_ABL & 64)) {  // (ETF_ABL & 64: timing only, no LayerNorm and no stores)
         ZT* z_out = (ZT*)a.z_out;
         float v0[8], v1[8], s1[8], s2[8];
 #pragma unroll
@@ -798,6 +951,9 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
           }
         }
       }
+#ifdef ETF_PROF2
+      if (tid == 0) { atomicAdd(&etf_prof2[6], __builtin_amdgcn_s_memtime() - tile_t0); atomicAdd(&etf_prof2[7], 1ull); }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(tok) : "memory");  // the last touches land before the register is released
   }
