@@ -556,6 +556,9 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
   const unsigned vec = lds0 + E4_VOFF;
   const unsigned wbi = lds0 + E4_VOFF + E4_VEC_BYTES;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef E4_PRIO  // experiment: 1 = the first wave of every SIMD at a higher issue priority (runs ahead inside the ring's slack), 2 = the second one
+  if (E4_PRIO == 1 ? wave < 4 : wave >= 4) __builtin_amdgcn_s_setprio(2);
+#endif
   auto lane_id = [] {
     int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(l));

@@ -380,6 +380,62 @@ __device__ __forceinline__ void etf_layer(const float* act, const EtfStream& st,
 // Persistent blocks (one per CU: 151 KB of LDS): a block walks row tiles blk, blk + gridDim.x, ...; the weight stream is cyclic
 // (84 tiles, a multiple of the ring's 3 slots and of the 2 register roles), so the pipeline never drains between tiles, and the
 // next tile's X0 / pair masks are requested before the final layer and stored once it has read buf0 for the last time.
+// LayerNorm of the block's 32 rows in ybuf, times the pair mask, -> z (both fp32 kernels; round 6 form).  A lane owns 16 values of ONE row
+// (row 8 wave + lane / 8, columns 32 q + 4 (lane % 8) ..: its four 16 B pieces of a row, eight lanes = 128 consecutive bytes per piece):
+// the statistics are 15 lane-local additions + three exchange steps among eight neighbouring lanes, the output leaves as four 16 B stores.
+// (Rounds 2 - 5: two columns of eight rows per lane - 2 x 6 butterfly steps x 8 rows of ds_bpermute and sixteen 4 B stores per lane,
+//  ~5.5 k cycles per row tile with the matrix cores idle = 5 % of the launch, tools/micro/etf_bench.hip -DETF_ABL=64.)
+struct EtfLnConst {
+  f32x4 g[4], b[4];
+  __device__ __forceinline__ void load(const float* gamma, const float* beta, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      g[q] = *(const f32x4*)(gamma + 32 * q + 4 * (lane & 7));
+      b[q] = *(const f32x4*)(beta + 32 * q + 4 * (lane & 7));
+    }
+  }
+};
+template <class ZT>
+__device__ __forceinline__ void etf_ln_store(const float* ybuf, const EtfLnConst& C, float em_row, long p0, long n_pairs, ZT* z_out, float* trace,
+                                             int wc, int lane) {
+  const int r = 8 * wc + (lane >> 3), c8 = lane & 7;
+  f32x4 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = *(const f32x4*)(ybuf + r * ETF_LDY + 32 * q + 4 * c8);
+  float s1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s1 += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+  const float mu = s1 * (1.0f / ETF_CZ);
+  float s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[q][i] -= mu;
+    s2 += (v[q][0] * v[q][0] + v[q][1] * v[q][1]) + (v[q][2] * v[q][2] + v[q][3] * v[q][3]);
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) s2 += __shfl_xor(s2, o, 64);
+  const float rstd = 1.0f / sqrtf(s2 * (1.0f / ETF_CZ) + 1e-5f);
+  const float em = __shfl(em_row, r, 64);
+  const long p = p0 + r;
+  if (p < n_pairs) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (v[q][i] * rstd * C.g[q][i] + C.b[q][i]) * em;
+      const long at = p * ETF_CZ + 32 * q + 4 * c8;
+      if constexpr (sizeof(ZT) == 4) *(f32x4*)((float*)z_out + at) = o;
+      else
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z_store<ZT>(z_out + at + i, o[i]);
+      if (trace) *(f32x4*)(trace + at) = o;
+    }
+  }
+}
+
 template <class ZT>
 __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTransArgs a, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -447,7 +503,8 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
 #pragma unroll
   for (int q = 0; q < 3; ++q) { bias1[q] = a.b1[q * 128 + ncol]; bias2[q] = a.b2[q * 128 + ncol]; }
   const float biasf = a.bf[ncol];
-  const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], b0v = a.beta[lane], b1v = a.beta[lane + 64];
+  EtfLnConst lnc;
+    lnc.load(a.gamma, a.beta, lane);
   store_x0();
   g0.store(Ws, tid);
   g1.store(Ws + ETF_WS / 4, tid);
@@ -486,48 +543,7 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
     __syncthreads();
     ETF_STAMP(3);
     store_x0();  // buf0 is free (the next layer 1 starts with a barrier)
-    // LayerNorm of the 32 rows (8 per wave, two columns per lane), times the pair mask, -> z.  The eight rows of a wave are reduced
-    // TOGETHER: every butterfly step is eight independent cross-lane exchanges in flight (row after row, the 2 x 6 dependent
-    // exchanges of a row were ~1.2 k exposed cycles each)
-    {
-      ZT* z_out = (ZT*)a.z_out;
-      float v0[8], v1[8], s1[8], s2[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int m = wc + 4 * q;
-        v0[q] = ybuf[m * ETF_LDY + lane];
-        v1[q] = ybuf[m * ETF_LDY + lane + 64];
-        s1[q] = v0[q] + v1[q];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s1[q] += __shfl_xor(s1[q], o, 64);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float mu = s1[q] * (1.0f / ETF_CZ);
-        v0[q] -= mu;
-        v1[q] -= mu;
-        s2[q] = v0[q] * v0[q] + v1[q] * v1[q];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s2[q] += __shfl_xor(s2[q], o, 64);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int m = wc + 4 * q;
-        const long p = p0 + m;
-        const float rstd = 1.0f / sqrtf(s2[q] * (1.0f / ETF_CZ) + 1e-5f);
-        const float em = __shfl(em_row, m, 64);
-        if (p < n_pairs) {
-          const float o0 = (v0[q] * rstd * g0v + b0v) * em, o1 = (v1[q] * rstd * g1v + b1v) * em;
-          z_store<ZT>(z_out + p * ETF_CZ + lane, o0);
-          z_store<ZT>(z_out + p * ETF_CZ + lane + 64, o1);
-          if (a.trace) { a.trace[p * ETF_CZ + lane] = o0; a.trace[p * ETF_CZ + lane + 64] = o1; }
-        }
-      }
-    }
+    etf_ln_store<ZT>(ybuf, lnc, em_row, p0, n_pairs, (ZT*)a.z_out, a.trace, wc, lane);
     ETF_STAMP(4);
   }
   FD_CLK_END(a.clock);
@@ -568,7 +584,7 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
     p2_bar += b1_ - b0_; p2_tot += b1_ - p2_last; p2_last = b1_;                   \
   } while (0)
 #else
-#define ETF_STEP_BARRIER() __syncthreads()
+#define ETF_STEP_BARRIER() do { if (!(ETF_ABL & 1)) __syncthreads(); } while (0)
 #endif
   auto step = [&](int tl, EtfOps& cur, EtfOps& nxt) {
     const int t = t0 + tl, kt = tl % 12;
@@ -582,24 +598,24 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
     // whole kernel (`tok`: a dead destination would be re-used by the compiler while the load is still in flight), never waited for: the
     // tile is in L2 when the movers ask for it four steps later (the z stream evicts the weights from the XCD's L2 between two uses)
     ETF_MMA(1);  ETF_GAP(if (ETF_TOUCH) asm volatile("global_load_dword %0, %1, off" : "+v"(tok) : "v"(st.addr(t + ETF_TOUCH) + (unsigned long)(wc * 32 + (lane & 31)) * (ETF_H * 4)) : "memory"));
-    ETF_MMA(2);  ETF_GAP(nxt.a[0] = *(const f32x4*)(an));
-    ETF_MMA(3);  ETF_GAP(nxt.w[0] = *(const f32x4*)(wn));
+    ETF_MMA(2);  ETF_GAP(if (!(ETF_ABL & 128)) nxt.a[0] = *(const f32x4*)(an));
+    ETF_MMA(3);  ETF_GAP(if (!(ETF_ABL & 128)) nxt.w[0] = *(const f32x4*)(wn));
     ETF_MMA(4);
-    ETF_MMA(5);  ETF_GAP(nxt.a[1] = *(const f32x4*)(an + 8));
-    ETF_MMA(6);  ETF_GAP(nxt.w[1] = *(const f32x4*)(wn + 8));
+    ETF_MMA(5);  ETF_GAP(if (!(ETF_ABL & 128)) nxt.a[1] = *(const f32x4*)(an + 8));
+    ETF_MMA(6);  ETF_GAP(if (!(ETF_ABL & 128)) nxt.w[1] = *(const f32x4*)(wn + 8));
     ETF_MMA(7);
-    ETF_MMA(8);  ETF_GAP(nxt.a[2] = *(const f32x4*)(an + 16));
-    ETF_MMA(9);  ETF_GAP(nxt.w[2] = *(const f32x4*)(wn + 16));
+    ETF_MMA(8);  ETF_GAP(if (!(ETF_ABL & 128)) nxt.a[2] = *(const f32x4*)(an + 16));
+    ETF_MMA(9);  ETF_GAP(if (!(ETF_ABL & 128)) nxt.w[2] = *(const f32x4*)(wn + 16));
     ETF_MMA(10);
-    ETF_MMA(11); ETF_GAP(nxt.a[3] = *(const f32x4*)(an + 24));
-    ETF_MMA(12); ETF_GAP(nxt.w[3] = *(const f32x4*)(wn + 24));
+    ETF_MMA(11); ETF_GAP(if (!(ETF_ABL & 128)) nxt.a[3] = *(const f32x4*)(an + 24));
+    ETF_MMA(12); ETF_GAP(if (!(ETF_ABL & 128)) nxt.w[3] = *(const f32x4*)(wn + 24));
     ETF_MMA(13);
     ETF_MMA(14);
     ETF_MMA(15);
 #undef ETF_MMA
 #undef ETF_GAP
     if (kt == 11) {
-      epi(tl / 12, acc);
+      if (!(ETF_ABL & 256)) epi(tl / 12, acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
@@ -728,7 +744,7 @@ __device__ __forceinline__ void etfs_layer_dma(const EtfStream& st, int t0, cons
   unsigned long long mv_busy = 0, mv_issue = 0;
 #endif
   auto step = [&](int t, int k) {
-    __syncthreads();
+    if (!(ETF_ABL & 1)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
 #ifdef ETF_PROF2
     const unsigned long long m0_ = __builtin_amdgcn_s_memtime();
@@ -764,7 +780,7 @@ __device__ __forceinline__ void etfs_final_dma(const EtfStream& st, const EtfDma
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
-    __syncthreads();
+    if (!(ETF_ABL & 1)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     D.tile((ETF_ABL & 16) ? (unsigned long)st.w1 + (unsigned long)((72 + k + 3) % ETF_TILES) * 16384ul : st.addr(72 + k + 3), k % 3, mw);
     if (k == 0 && more) request();
@@ -805,24 +821,30 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
     st.load(g2, 2, mt);
 #endif
     f32x4 xr[12];
+    // X0 rows of a row tile: thread -> 16 B column c of the rows mt / 32 + 8 k.  ONE pair of 32-bit divisions per thread (B N^2 < 2^32), the
+    // three other rows by stepping (i, j) eight pairs on: next to a multiplier wave every vector instruction of a mover waits for a turn
+    // (see EtfDma), and the 64-bit divisions of rounds 2 - 5 (two per row) held the first steps of the final layer up by ~190 cycles each.
     auto request_x0 = [&](long p0) {
+      const unsigned uN = (unsigned)N, np = (unsigned)n_pairs, pr0 = (unsigned)p0 + (unsigned)(mt >> 5);
+      unsigned bi = pr0 / uN, jj = pr0 - bi * uN, bb = bi / uN, ii = bi - bb * uN;
+      const int c = (mt & 31) * 4;
 #pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int part = u >> 2, v = mt + (u & 3) * FD_THREADS, mm = v >> 5, c = (v & 31) * 4;
-        const long pr = p0 + mm, p = pr < n_pairs ? pr : n_pairs - 1;
-        const long bi = p / N;
-        const int jj = (int)(p - bi * N);
-        const long bb = bi / N;
-        if (part == 0) {
-          if constexpr (sizeof(ZT) == 4) xr[u] = *(const f32x4*)((const float*)z_in + p * ETF_CZ + c);
-          else
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xr[u][q] = z_load<ZT>(z_in + p * ETF_CZ + c + q);
-        } else {
-          xr[u] = *(const f32x4*)(a.e + (part == 1 ? bi : bb * N + jj) * ETF_CZ + c);
-        }
+      for (int k = 0; k < 4; ++k) {
         // (rows beyond the last pair carry the last pair's values: they are never stored, and a select on the loaded value here would
         //  make the compiler wait for the requests on the spot)
+        const bool in = pr0 + 8u * k < np;
+        const unsigned p_ = in ? pr0 + 8u * k : np - 1, bi_ = in ? bi : (unsigned)a.B * uN - 1, bj_ = in ? bb * uN + jj : (unsigned)a.B * uN - 1;
+        if constexpr (sizeof(ZT) == 4) xr[k] = *(const f32x4*)((const float*)z_in + (long)p_ * ETF_CZ + c);
+        else
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xr[k][q] = z_load<ZT>(z_in + (long)p_ * ETF_CZ + c + q);
+        xr[4 + k] = *(const f32x4*)(a.e + (long)bi_ * ETF_CZ + c);
+        xr[8 + k] = *(const f32x4*)(a.e + (long)bj_ * ETF_CZ + c);
+        jj += 8;
+        while (jj >= uN) {
+          jj -= uN; ++bi; ++ii;
+          if (ii >= uN) { ii = 0; ++bb; }
+        }
       }
     };
     auto store_x0 = [&]() {
@@ -884,7 +906,8 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
 #pragma unroll
     for (int q = 0; q < 3; ++q) { bias1[q] = a.b1[q * 128 + ncol]; bias2[q] = a.b2[q * 128 + ncol]; }
     const float biasf = a.bf[ncol];
-    const float g0v = a.gamma[lane], g1v = a.gamma[lane + 64], b0v = a.beta[lane], b1v = a.beta[lane + 64];
+    EtfLnConst lnc;
+    lnc.load(a.gamma, a.beta, lane);
     for (; blk < n_blocks; blk += gridDim.x) {
       const long p0 = (long)blk * 32;
       const float em_row = em_next;
@@ -912,45 +935,8 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
         for (int r = 0; r < 16; ++r) ybuf[c_row(r, lane) * ETF_LDY + ncol] = acc[r] + biasf;
       });
       __syncthreads();
-      if (!(ETF_ABL & 64)) {  // (ETF_ABL & 64: timing only, no LayerNorm and no stores)
-        ZT* z_out = (ZT*)a.z_out;
-        float v0[8], v1[8], s1[8], s2[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int m = wc + 4 * q;
-          v0[q] = ybuf[m * ETF_LDY + lane];
-          v1[q] = ybuf[m * ETF_LDY + lane + 64];
-          s1[q] = v0[q] + v1[q];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) s1[q] += __shfl_xor(s1[q], o, 64);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float mu = s1[q] * (1.0f / ETF_CZ);
-          v0[q] -= mu;
-          v1[q] -= mu;
-          s2[q] = v0[q] * v0[q] + v1[q] * v1[q];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) s2[q] += __shfl_xor(s2[q], o, 64);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int m = wc + 4 * q;
-          const long p = p0 + m;
-          const float rstd = 1.0f / sqrtf(s2[q] * (1.0f / ETF_CZ) + 1e-5f);
-          const float em = __shfl(em_row, m, 64);
-          if (p < n_pairs) {
-            const float o0 = (v0[q] * rstd * g0v + b0v) * em, o1 = (v1[q] * rstd * g1v + b1v) * em;
-            z_store<ZT>(z_out + p * ETF_CZ + lane, o0);
-            z_store<ZT>(z_out + p * ETF_CZ + lane + 64, o1);
-            if (a.trace) { a.trace[p * ETF_CZ + lane] = o0; a.trace[p * ETF_CZ + lane + 64] = o1; }
-          }
-        }
-      }
+      if (!(ETF_ABL & 64))  // (ETF_ABL & 64: timing only, no LayerNorm and no stores)
+        etf_ln_store<ZT>(ybuf, lnc, em_row, p0, n_pairs, (ZT*)a.z_out, a.trace, wc, lane);
 #ifdef ETF_PROF2
       if (tid == 0) { atomicAdd(&etf_prof2[6], __builtin_amdgcn_s_memtime() - tile_t0); atomicAdd(&etf_prof2[7], 1ull); }
 #endif
