@@ -556,8 +556,8 @@ __global__ __launch_bounds__(FD_THREADS) void edge_transition_f32_kernel(EdgeTra
 // ------------------------------------------------------------------ wave-specialised form (round 2, end)
 // Same arithmetic and accumulation order as edge_transition_f32_kernel above (bit-identical outputs), but the weight stream no longer
 // shares an instruction stream with the matrix cores: a block has EIGHT waves, 0..3 multiply (16 MFMAs + the 8 operand reads of the
-// next tile per step, epilogues, LayerNorm), 4..7 move (per step: the 4 LDS stores of tile t + 2 and the 4 L2 requests of tile t + 4;
-// per row tile: the next tile's X0 rows).  One wave per SIMD issues in order: every ds_write_b128 / global_load between two MFMAs of
+// next tile per step, epilogues, LayerNorm), 4..7 move (round 6: per step five LDS-DMA requests of tile t + 3, see EtfDma; rounds 2 - 5: the
+// 4 LDS stores of tile t + 2 and the 4 L2 requests of tile t + 4; per row tile: the next tile's X0 rows).  One wave per SIMD issues in order: every ds_write_b128 / global_load between two MFMAs of
 // the fused kernel that took longer than the 64 cycles the matrix instruction runs was a bubble (ablations above: 0.8 ms of 4.74 for
 // the stores, 0.6 ms for the requests).  Both roles execute the same sequence of barriers (one per layer entry, one per step, one after the final layer).
 #ifndef ETF_TOUCH
@@ -615,7 +615,14 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
 #undef ETF_MMA
 #undef ETF_GAP
     if (kt == 11) {
-      if (!(ETF_ABL & 256)) epi(tl / 12, acc);
+      if (ETF_ABL & 256) {  // (timing only: the pass epilogue never runs, the accumulators stay alive)
+        float sum_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum_ += acc[r];
+        if (sum_ == 12345.678f) epi(tl / 12, acc);
+      } else {
+        epi(tl / 12, acc);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
@@ -647,8 +654,10 @@ __device__ __forceinline__ void etfs_layer_compute(const float* act, const EtfSt
 //    (7.1 ms while the run-time choice among the three weight pointers made the requests FLAT loads, which count in lgkmcnt: every
 //    barrier then waited for them);
 //  * L2 touches of tile t + 8 from the multiplier waves (ETF_TOUCH): 4.63 ms - the requests are L2 hits already.
-// The decisive ablation (ETF_ABL = 8): the SAME requests into registers nobody ever waits for: 4.44 ms, i.e. nothing gained - it is the
-// request traffic itself (4 KB per wave and step written back into the VGPR file of the SIMD a multiplier wave shares), not its latency.
+// The decisive ablation (ETF_ABL = 8): the SAME requests into registers nobody ever waits for: 4.44 ms, i.e. nothing gained - not the
+// latency.  Rounds 2 - 5 read that as "the traffic through the shared VGPR file"; round 6's s_memtime probe (-DETF_PROF2) found the
+// movers 1.2 k cycles busy ISSUING a step's requests: their address arithmetic waits for a turn at the vector ALU behind the multiplier's
+// back-to-back MFMAs (EtfDma below, ETF_DMA = 1, is the form that has none; this register form stays for A/B as ETF_DMA = 0).
 template <int NP>
 __device__ __forceinline__ void etfs_layer_move(const EtfStream& st, int t0, float* Ws0, EtfTile& g0, EtfTile& g1, EtfTile& g2, int mt,
                                                 f32x4 (&g_dummy)[4]) {
@@ -810,6 +819,10 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
 #if ETF_DMA
     EtfDma D;
     const int mw = __builtin_amdgcn_readfirstlane(mt >> 6);
+#ifndef ETF_MOVER_PRIO
+#define ETF_MOVER_PRIO 0  // 3 (the movers' instructions first, as the non-matrix phases of edge_embed_f32p_kernel): 3.780 against 3.765 ms - with no
+#endif                    // vector instruction left in a step there is nothing to let through
+    if (ETF_MOVER_PRIO) __builtin_amdgcn_s_setprio(ETF_MOVER_PRIO);
     D.init(mw, mt & 63, Ws);
     D.tile(st.addr(0), 0, mw);
     D.tile(st.addr(1), 1, mw);

@@ -1,5 +1,12 @@
-// Stand-alone timing + phase profile of edge_transition_f32_kernel (fp32 mode, pair_mlp.hip); -DETF_PROF for the profile.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w [-DETF_PROF] tools/micro/etf_bench.hip -o etf_bench
+// Stand-alone timing of the fp32 EdgeTransition kernels (fp32 mode, pair_mlp.hip), their in-kernel clock, a bit-exact check of the
+// wave-specialised kernel against the fused 4-wave kernel, and two probes:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w [-DETF_PROF | -DETF_PROF2] [-DETF_DMA=0] [-DETF_ABL=<bits>] tools/micro/etf_bench.hip -o etf_bench
+//   etf_bench N B        timing (zero operands: the matrix cores at their best clock)
+//   etf_bench N B 1      check on random operands (exit code 1 on any differing bit)
+//   -DETF_PROF           phase profile of the fused kernel;  -DETF_PROF2  s_memtime probe of the wave-specialised kernel: cycles per step /
+//                        at the step barrier per layer (multiplier wave 0) and cycles a mover needs to issue a step's requests
+//   -DETF_ABL bits (timing only, results wrong): 1 no step barrier, 4 no weight requests, 16 weight tiles as consecutive memory, 32 nobody
+//                        waits for the tiles, 64 no LayerNorm / stores, 128 no operand reads, 256 no pass epilogues (pair_mlp.hip)
 #include "../../framedipt_amd/csrc/pair_mlp.hip"
 #include <cstdio>
 #include <vector>
