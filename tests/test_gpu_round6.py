@@ -124,3 +124,45 @@ def test_inference_fn_pads_lengths_that_are_no_multiple_of_four(n, b):
     a2 = inference_fn(net, d, feats, **kw)
     a3 = inference_fn(net, d, feats, noise_tape=t_ref, **kw)
     np.testing.assert_array_equal(np.asarray(a2["prot_traj"]), np.asarray(a3["prot_traj"]))
+
+
+@pytest.mark.parametrize("n,b", [(37, 3), (5, 7), (100, 1), (44, 2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("fp16", 4e-3)])
+def test_edge_transition_entry_at_ragged_sizes(prec, tol, n, b):
+    """fdipt_edge_transition_fwd (ipa_pytorch.py:84-102 times the pair mask, :549) against the NumPy oracle's EdgeTransition on random
+    node rows, pair rows and a residue mask with holes, at sizes where the row tiles of the kernels are ragged: B N^2 no multiple of 32 (the
+    fp32 kernel's last 32-pair row tile; its movers' stepped (i, j) arithmetic and its LDS-DMA weight stream run here exactly as in the
+    sampler), N < 8 (several sample rows per tile), N % 4 != 0 (edge_transition3 in half precision) and N % 4 == 0 (edge_transition4)."""
+    import ctypes as C
+    from framedipt_amd import _lib
+    from test_gpu_parity import _net, dev
+    from test_oracle_forward import _model as omodel
+    lib = _lib.load()
+    name = "full_denovo_n64"
+    G = load_golden(f"fwd_{name}.npz")
+    net, d, conf = _net(name, G, prec)
+    onet, _ = omodel(name, G, None)
+    rng = np.random.default_rng(100 * n + b)
+    node = rng.standard_normal((b, n, 256)).astype(np.float32)
+    z = rng.standard_normal((b, n, n, 128)).astype(np.float32)
+    mask = (rng.random((b, n)) > 0.2).astype(np.float32)
+    blk = 1
+    zt = torch.float32 if prec == "fp32" else torch.float16
+    z_d = dev(z).to(zt).contiguous()
+    ref = onet.edge_transition(blk, node, z_d.float().cpu().numpy()) * (mask[:, :, None] * mask[:, None, :])[..., None]
+    st = net.batch_state(dev(np.tile(np.arange(n, dtype=np.int64), (b, 1))))
+    z2 = torch.full_like(z_d, float("nan"))
+    dm, pr, dr = C.byref(net.dims), _lib.ptr(net.params), _lib.ptr(net.derived)
+    node_d, mask_d = dev(node), dev(mask)
+    _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, blk, b, n, _lib.ptr(node_d), _lib.ptr(mask_d), _lib.ptr(z_d), _lib.ptr(z2),
+                                             _lib.ptr(st.ws), st.ws_bytes, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = z2.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    assert err < tol, (prec, n, b, err)
+    # in place (z_out may alias z_in) gives the same bits
+    _lib.check(lib.fdipt_edge_transition_fwd(dm, pr, dr, blk, b, n, _lib.ptr(node_d), _lib.ptr(mask_d), _lib.ptr(z_d), _lib.ptr(z_d),
+                                             _lib.ptr(st.ws), st.ws_bytes, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(z_d.float().cpu().numpy(), got)
