@@ -802,13 +802,16 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail_kernel(TfmrTailArgs a
 // the input staging 7.3 k -> 4.2 k).  Lane = (row lane % 16, feature group lane / 16): D[feature 16 T + 4 fg + i, row]; a lane's four
 // consecutive features make its residual / output accesses 16 B pieces (64 B per row and instruction), so no exchange tile is needed;
 // LayerNorm statistics are lane-local sums + the three other feature groups (lane ^ 16, ^ 32) + the four waves through LDS.
+#ifndef RB16_BLOCKS
+#define RB16_BLOCKS 1  // blocks per CU the 16-row kernels are compiled for.  2 (256 registers; tfmr_tail16 then spills 230 - 300 dwords, mlp16<..ETR> 58): 64 samples
+#endif                 // 15.08 against 14.01 ms per step, eight samples 2.45 against 2.09 (round 6, gpurun_out/r6k) - A/B builds only
 #define T16_KS (TL_D / 32)
 #define T16_NT (TL_D / 16)
 #define T16_XROW (TL_D * 2 + 32)  // 42 chunks of 16 B: the b128 fragment reads of 16 rows x 4 feature groups are conflict-free (41: 2-way, SQ_LDS_BANK_CONFLICT 44 %)
 #define T16_XLO (16 * T16_XROW)
 #define T16_SMEM (4 * T16_XLO + (7 * TL_D + TL_NP) * 4 + 2 * 4 * 16 * 4 + 16)
 template <bool POST>
-__global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs a) {
+__global__ __launch_bounds__(FD_THREADS, RB16_BLOCKS) void tfmr_tail16_kernel(TfmrTailArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                       // att rows, then hidden rows: hi rows | lo rows   [2][16][T16_XROW]
   char* hs = xs + 2 * T16_XLO;           // x_a rows
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(FD_THREADS, 1) void tfmr_tail16_kernel(TfmrTailArgs
 // rowblock_kernel's IMG epilogue writes from 32-row tiles).  Saves the launch of rowblock_kernel<256,128,0,1024,IMG> (16 us at 2400
 // rows, three times per forward) for ~0.65 MB more weight fragments per block.
 template <int KS0, int NL, bool LN, bool BB, bool SKIP = false, bool ETR = false>
-__global__ __launch_bounds__(FD_THREADS, 1) void mlp16_kernel(RowBlockArgs a, int k0) {
+__global__ __launch_bounds__(FD_THREADS, RB16_BLOCKS) void mlp16_kernel(RowBlockArgs a, int k0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;
   char* hs = xs + 2 * TR_XLO;
