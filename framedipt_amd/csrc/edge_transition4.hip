@@ -25,7 +25,7 @@
 
 #ifndef E4_ABL
 #define E4_ABL 0  // timing ablations (tools/micro/et4_bench.hip): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 8 no z' / bias stores, 16 (flat) no LDS fragment reads,
-                  // 32 no LayerNorm arithmetic in the epilogue (statistics and normalisation skipped: conversions, staging, stores, products stay)
+                  // 64 layer 1's chunks are not streamed, 32 no LayerNorm arithmetic in the epilogue (statistics and normalisation skipped: conversions, staging, stores, products stay)
 #endif
 #ifndef E4_PZ_ABL
 #define E4_PZ_ABL 0  // timing ablations of the pair_z emission (wrong results): 1 no lo part, 2 lo part from the hi image in LDS (no L2 loads), 4 no pair_z stores, 8 no hi part
@@ -539,7 +539,8 @@ __device__ __forceinline__ void e4_point(const E4Flat& F, int c) {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   const int cn = (c + 3) & 31;
-  e4_dma_chunk<E4_CHUNK>(F.stream + (size_t)cn * E4_CHUNK, F.lds0 + (unsigned)(cn & 3) * E4_CHUNK, F.tid, F.wave);
+  // (E4_ABL & 64, timing only: layer 1's six chunks are never streamed - the upper bound of what keeping them resident in LDS could buy)
+  if (!(E4_ABL & 64) || cn >= 6) e4_dma_chunk<E4_CHUNK>(F.stream + (size_t)cn * E4_CHUNK, F.lds0 + (unsigned)(cn & 3) * E4_CHUNK, F.tid, F.wave);
 }
 // one k-step of the stream: the operand ring is refilled E4_DR - 1 fragments ahead (not past the tile's last fragment)
 #define E4_STEP(f_, B_, acc_)                                                                                   \
