@@ -817,6 +817,7 @@ __global__ __launch_bounds__(2 * FD_THREADS) void edge_transition_f32ws_kernel(E
     const ZT* z_in = (const ZT*)a.z_in;
     const EtfStream st = {(const float*)a.w1, (const float*)a.w2, (const float*)a.wf};
 #if ETF_DMA
+    static_assert(sizeof(ZT) == 4, "etfs_final_dma counts the 12 X0 requests of an fp32 z (16 B per request) in its vmcnt waits");
     EtfDma D;
     const int mw = __builtin_amdgcn_readfirstlane(mt >> 6);
 #ifndef ETF_MOVER_PRIO
