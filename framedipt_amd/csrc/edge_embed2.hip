@@ -105,19 +105,24 @@ __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamm
   const float mu = s1 * (1.0f / ET2_CZ);
   const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / ET2_CZ) - mu * mu, 0.f) + 1e-5f);
   const ee_f32x2 sa = {rstd, rstd}, sc = {-mu * rstd, -mu * rstd}, em2 = {em, em};
+#ifndef EE2_ABL
+#define EE2_ABL 0  // timing ablations (tools/micro/ee2_bench.hip; results wrong): what an un-transposed layer-3 epilogue could save at most -
+#endif             // 1 gamma / beta without their LDS reads, 2 no staging round trip of the z' tile, 4 layer biases without their LDS reads
   ee_u32x4 zB[8];  // half-precision z' as B fragments
   // (gamma, beta) of a feature group come from LDS one group AHEAD of their use; the interleave is pinned: left alone hipcc
   // emits read -> s_waitcnt lgkmcnt(0) -> use for each of the 16 groups (16 exposed LDS round trips per tile)
   f32x4 gq[2], bq[2];
-  gq[0] = *(const f32x4*)(gamma_l + 4 * hi);
-  bq[0] = *(const f32x4*)(beta_l + 4 * hi);
+  gq[0] = (EE2_ABL & 1) ? f32x4{1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(gamma_l + 4 * hi);
+  bq[0] = (EE2_ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(beta_l + 4 * hi);
 #pragma unroll
   for (int idx = 0; idx < 16; ++idx) {
     const int t = idx >> 2, g = idx & 3, f0 = 32 * t + 8 * g + 4 * hi;
     if (idx + 1 < 16) {
       const int f1 = 32 * ((idx + 1) >> 2) + 8 * ((idx + 1) & 3) + 4 * hi;
-      gq[(idx + 1) & 1] = *(const f32x4*)(gamma_l + f1);
-      bq[(idx + 1) & 1] = *(const f32x4*)(beta_l + f1);
+      if (!(EE2_ABL & 1)) {
+        gq[(idx + 1) & 1] = *(const f32x4*)(gamma_l + f1);
+        bq[(idx + 1) & 1] = *(const f32x4*)(beta_l + f1);
+      }
     }
     const f32x4 gm = gq[idx & 1], bt = bq[idx & 1];
     ee_f32x2 o0 = {Y[t][4 * g], Y[t][4 * g + 1]}, o1 = {Y[t][4 * g + 2], Y[t][4 * g + 3]};
@@ -127,7 +132,7 @@ __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamm
     o1 = __builtin_elementwise_fma(o1, ee_f32x2{gm[2], gm[3]}, ee_f32x2{bt[2], bt[3]}) * em2;
     const ee_u32x2 ow = {ee_cvt_pk(o0[0], o0[1]), ee_cvt_pk(o1[0], o1[1])};
     // features f0..f0+3 = bytes 2 f0 .. 2 f0 + 7 of the pair's row: 16 B unit 4t + g, half hi; unit u of row r at u ^ (r & 15)
-    *(ee_u32x2*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = ow;
+    if (!(EE2_ABL & 2)) *(ee_u32x2*)(stage + li * 256 + (((4 * t + g) ^ (li & 15)) << 4) + 8 * hi) = ow;
     zB[2 * t + (g >> 1)][2 * (g & 1)] = ow[0];
     zB[2 * t + (g >> 1)][2 * (g & 1) + 1] = ow[1];
     if (TRACE && valid) *(f32x4*)(tr_row + f0) = f32x4{o0[0], o0[1], o1[0], o1[1]};
@@ -140,7 +145,7 @@ __device__ __forceinline__ void ee_ln_epilogue(f32x16 (&Y)[4], const float* gamm
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int r = 4 * it + sr;
-    zrow[it] = *(const u16x8*)(stage + r * 256 + ((sc16 ^ (r & 15)) << 4));
+    zrow[it] = (EE2_ABL & 2) ? __builtin_bit_cast(u16x8, zB[it]) : *(const u16x8*)(stage + r * 256 + ((sc16 ^ (r & 15)) << 4));
   }
   const bool full = nvalid == 32;  // wave-uniform: 9 of 10 tiles at N = 300 take the branch-free stores
   if (wb_lds) {
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(EE2_THREADS, 1) void edge_embed2_kernel(EdgeEmbedAr
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {  // starts as the layer bias b3
-          const f32x4 bv = *(const f32x4*)(vec + ET2_CZ + 4 * hi + 32 * t + 8 * g);
+          const f32x4 bv = (EE2_ABL & 4) ? f32x4{0.1f, 0.2f, 0.3f, 0.4f} : *(const f32x4*)(vec + ET2_CZ + 4 * hi + 32 * t + 8 * g);
 #pragma unroll
           for (int q = 0; q < 4; ++q) Y[t][4 * g + q] = bv[q];
         }
