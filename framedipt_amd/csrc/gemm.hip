@@ -605,7 +605,10 @@ __global__ __launch_bounds__(512, 1) void outproj_split_kernel(int M, const floa
   for (int rt = 0; rt < 2; ++rt) { ah[0][rt] = a_frag(0, rt, 0); al[0][rt] = a_frag(0, rt, 1); }
 #pragma unroll
   for (int s = 0; s < KSL; ++s) {
-    if (s + OP_DEPTH - 1 < KSL) {
+#ifndef OP_ABL
+#define OP_ABL 0  // timing ablation (tools/micro/op_bench.hip; results wrong): 1 = no weight stream beyond the first OP_DEPTH - 1 fragments (the
+#endif            // upper bound of what larger row tiles / a weight-stationary split could save)
+    if (s + OP_DEPTH - 1 < KSL && !(OP_ABL & 1)) {
       Wh[(s + OP_DEPTH - 1) % OP_DEPTH] = __builtin_bit_cast(hx8, *(const u16x8*)(wh + (size_t)(s + OP_DEPTH - 1) * 1024));
       Wl[(s + OP_DEPTH - 1) % OP_DEPTH] = __builtin_bit_cast(hx8, *(const u16x8*)(wl + (size_t)(s + OP_DEPTH - 1) * 1024));
     }
