@@ -8,6 +8,11 @@
 
 // C[M,N] = epi(A[M,K] * W[N,K]^T).  Block tile BM x BN (64x64 or 128x128), 4 waves as 2x2, BK = 64, LDS double
 // buffer, next k-tile prefetched into registers while the current one feeds the MFMAs (one barrier per k-tile).
+// LDS row padding of the tile loop.  fp32 (round 6): 4 words - rows stay 16 B aligned and, with a stride of 68 = 4 (mod 32) words, the
+// ds_read_b128 / ds_write_b128 of the loop below are conflict-free (the layout of pair_mlp.hip's fp32 EdgeTransition); rounds 1 - 5 padded
+// by one word and moved every fp32 operand through LDS 4 B at a time (two ds_read_b32 per MFMA, four ds_write_b32 per 16 B loaded).
+template <class P> struct GemmPad { static constexpr int value = P::PAD; };
+template <> struct GemmPad<PrecF32> { static constexpr int value = 4; };
 template <class P, class SrcT, int ROWS>
 struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading dimension ld
   static constexpr int EPV = 16 / sizeof(SrcT);          // elements per 16-byte vector
@@ -27,13 +32,13 @@ struct TilePrefetch {  // ROWS x 64 tile of SrcT, row-major source with leading 
     }
   }
   __device__ __forceinline__ void store(typename P::T* dst, int tid) const {
-    constexpr int LDT = 64 * P::LDMUL + P::PAD;
+    constexpr int LDT = 64 * P::LDMUL + GemmPad<P>::value;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int v = tid + u * FD_THREADS, rr = v / VPR, kk = (v % VPR) * EPV;
       typename P::T* d = dst + rr * LDT + kk;
       if constexpr (sizeof(SrcT) == 4 && sizeof(typename P::T) == 4) {
-        d[0] = r[u][0]; d[1] = r[u][1]; d[2] = r[u][2]; d[3] = r[u][3];
+        *(f32x4*)d = r[u];
       } else if constexpr (sizeof(SrcT) == 4) {
         u16x4 h = {f2h(r[u][0]), f2h(r[u][1]), f2h(r[u][2]), f2h(r[u][3])};
         *(u16x4*)d = h;
@@ -57,7 +62,7 @@ template <class P, class AT, class WT, int BM, int BN, bool SWAP = false>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[BM / 64][BN / 64], int M, int N, int K,
                                           const AT* __restrict__ A, int lda, const WT* __restrict__ W, int ldw,
                                           typename P::T* smem, int m0, int n0, int tid) {
-  constexpr int BKL = 64, LDT = BKL * P::LDMUL + P::PAD;
+  constexpr int BKL = 64, LDT = BKL * P::LDMUL + GemmPad<P>::value;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int STAGE = (BM + BN) * LDT;  // elements per pipeline stage: A tile then W tile
   const int lane = tid & 63, wave = tid >> 6;
@@ -84,6 +89,27 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[BM / 64][BN / 64], int M
       pa.load(A, lda, m0, M, (kt + 1) * BKL, K, tid);
       pw.load(W, ldw, n0, N, (kt + 1) * BKL, K, tid);
     }
+    if constexpr (std::is_same<P, PrecF32>::value) {
+      // fp32: operands as 16 B runs.  Within 8 consecutive k the lane half `hi` reads k0 + 4 hi .. + 3 and MFMA j multiplies the pairs
+      // (k0 + j | k0 + 4 + j) - the same pairing on both operands, so nothing is permuted (only the order of the k sum differs from a
+      // (k, k + 1) walk).  The operand runs of a k-group are read once per row / column tile and shared by the tiles that use them.
+#pragma unroll
+      for (int k = 0; k < BKL; k += 8) {
+        f32x4 av[TM], wv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(Ac + ((wr * TM + i) * 32 + (lane & 31)) * LDT + k + 4 * hi);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) wv[jn] = *(const f32x4*)(Wc + ((wc * TN + jn) * 32 + (lane & 31)) * LDT + k + 4 * hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+              acc[i][jn] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv[jn][j], av[i][j], acc[i][jn], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], wv[jn][j], acc[i][jn], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int k = 0; k < BKL; k += P::KS)
 #pragma unroll
@@ -111,7 +137,7 @@ __global__ __launch_bounds__(FD_THREADS) void linear_kernel(int M, int N, int K,
                                                             const float* __restrict__ residual, int ldr,
                                                             const float* __restrict__ rowmask, int relu,
                                                             float* __restrict__ out, int ldo) {
-  constexpr int LDT = 64 * P::LDMUL + P::PAD;
+  constexpr int LDT = 64 * P::LDMUL + GemmPad<P>::value;
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in each direction
   __shared__ __attribute__((aligned(16))) typename P::T smem[2 * (BM + BN) * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
