@@ -718,6 +718,9 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
     for (int k = 0; k < 12; ++k) FA[k] = fold_ld(fold_base + k * 512);
     E.t = tc;
     em_req = mask_of(tn, lane);
+#ifdef E4_IDLE  // experiment: E4_IDLE x 64 idle cycles per tile and wave - how much of an idle cycle the power-capped clock gives back
+    __builtin_amdgcn_s_sleep(E4_IDLE);
+#endif
     if (!(E4_ABL & 1)) {
       E4EpiTmp X;
       X.moff = lds0 + E4_MOFF + tid * 4;
