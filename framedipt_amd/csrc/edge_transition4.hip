@@ -354,13 +354,13 @@ __device__ __forceinline__ float e4_both_halves(float x, int lane) {
 // STZ = false (round 6): z' itself is not stored — the launch behind the LAST trunk block that has an EdgeTransition: the next block's
 // attention takes its pair bias and its pair_z from this epilogue, and nothing else reads z' any more (184 MB of writes, the staging and
 // sixteen 16 B stores per lane and tile less)
-template <int SLOT, bool PZ, bool STZ = true>
+template <int SLOT, bool PZ, bool STZ = true, bool EMR = true>
 __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, unsigned wbi, unsigned stg, int M, unsigned dzf) {
   const int p = lane & 31, half = lane >> 5;
   if constexpr (SLOT == 0) {  // sums of y and y^2 (packed fp32 math); the pair mask is requested here
     // the pair mask comes from LDS (parked there at the start of the tile): a global load here would be waited for with
     // vmcnt, i.e. together with the z rows and weights of the next tile requested just before the epilogue
-    E.em = *(const __attribute__((address_space(3))) float*)(unsigned long)(X.moff);
+    if constexpr (EMR) E.em = *(const __attribute__((address_space(3))) float*)(unsigned long)(X.moff);
     f32x2 u1 = {0.f, 0.f}, u2 = {0.f, 0.f};
     if (!(E4_ABL & 32))
 #pragma unroll
@@ -488,6 +488,78 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
   }
 }
 
+// E4_PIPE: the same epilogue in two parts with the same arithmetic (bit-identical outputs).  NORM (at the tile's end: slots 0, 1 above, then
+// this for t = 0 .. 3) turns the final layer's 64 fp32 registers into the eight half-precision B fragments of z' (32 registers); EMIT (under
+// the next tile's layer 1) stages a tile, runs its products of the pair bias / pair_z emissions and stores its z' rows.
+template <int t>
+__device__ __forceinline__ void e4_epi_norm(const E4Epi& E, const E4EpiTmp& X, const ET2Args& a, int lane, unsigned vec, e4_u32x4 (&Z)[8]) {
+  const int half = lane >> 5;
+  const unsigned gml = vec + 4 * (E4_H + 4 * half + 32 * t);
+  const unsigned btl = gml + 4 * E4_CZ;
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    f32x4 gm[2], bt[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      gm[k] = e4_ldsf4(gml + 32 * (2 * h2 + k));
+      bt[k] = e4_ldsf4(btl + 32 * (2 * h2 + k));
+    }
+    f32x2 o[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int g = 2 * h2 + k;
+      f32x2 o0 = {E.Y[t][4 * g], E.Y[t][4 * g + 1]}, o1 = {E.Y[t][4 * g + 2], E.Y[t][4 * g + 3]};
+      o0 = __builtin_elementwise_fma(o0, X.sa, X.sc);
+      o1 = __builtin_elementwise_fma(o1, X.sa, X.sc);
+      o[2 * k] = __builtin_elementwise_fma(o0, f32x2{gm[k][0], gm[k][1]}, f32x2{bt[k][0], bt[k][1]});
+      o[2 * k + 1] = __builtin_elementwise_fma(o1, f32x2{gm[k][2], gm[k][3]}, f32x2{bt[k][2], bt[k][3]});
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] *= f32x2{E.em, E.em};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      Z[2 * t + h2][2 * k] = fd_cvt_pk(o[2 * k][0], o[2 * k][1]);
+      Z[2 * t + h2][2 * k + 1] = fd_cvt_pk(o[2 * k + 1][0], o[2 * k + 1][1]);
+    }
+    if (a.trace && X.valid) {
+      float* tr_row = a.trace + X.prow * E4_CZ + 4 * half + 32 * t + 16 * h2;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) *(f32x4*)(tr_row + 8 * k) = f32x4{o[2 * k][0], o[2 * k][1], o[2 * k + 1][0], o[2 * k + 1][1]};
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int t, bool PZ, bool STZ>
+__device__ __forceinline__ void e4_epi_emit(E4EpiTmp& X, const ET2Args& a, int lane, unsigned wbi, unsigned stg, unsigned dzf, const e4_u32x4 (&Z)[8]) {
+  const int p = lane & 31, half = lane >> 5;
+  if constexpr (STZ)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const e4_u32x2 ow = {Z[2 * t + (g >> 1)][2 * (g & 1)], Z[2 * t + (g >> 1)][2 * (g & 1) + 1]};
+      *(e4_lds_w64)(unsigned long)(stg + p * 64 + ((g ^ ((p >> 2) & 3)) << 4) + 8 * half) = ow;
+    }
+  if (a.wb_img) {
+    const unsigned wl = p < 8 ? wbi + half * 128 + p * 16 : wbi + 2048, ws = p < 8 ? 256u : 0u;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) X.accb = fd_mfma32(e4_frag(wl + (2 * t + h2) * ws), __builtin_bit_cast(hx8, Z[2 * t + h2]), X.accb);
+  }
+  if constexpr (PZ) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      X.accd = fd_mfma32(__builtin_bit_cast(hx8, Z[2 * t + h2]), e4_frag(dzf + (2 * t + h2) * 1024 + lane * 16), X.accd);
+      X.accd = fd_mfma32(__builtin_bit_cast(hx8, Z[2 * t + h2]), e4_frag(dzf + 8192 + (2 * t + h2) * 1024 + lane * 16), X.accd);
+    }
+  }
+  if constexpr (STZ)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pr = 16 * k + (lane >> 2);
+      const u16x8 v = *(e4_lds_u16x8)(unsigned long)(stg + pr * 64 + (((lane & 3) ^ ((pr >> 2) & 3)) << 4));
+      if (X.svalid[k]) e4_store_z(a.z_out + X.srow[k] * E4_CZ + 32 * t + 8 * (lane & 3), v);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ------------------------------------------------------------------ flat-stream kernel (round 2, end)
 // Same arithmetic, same MFMA order per accumulator (bit-identical results) as edge_transition4_kernel above; what changes is how
 // the 512 weight fragments of a tile reach the matrix cores.  Above: 20 chunks through a 2 x 32 KB ring, a DMA wait + barrier at
@@ -502,33 +574,61 @@ __device__ __forceinline__ void e4_epi(E4Epi& E, E4EpiTmp& X, const ET2Args& a, 
 #ifndef E4_DR
 #define E4_DR 4
 #endif
+// E4_FINE (round 6, experiment): the ring as SIX 8 KB slots over the 60 chunks that hold weights (the same 2 k cycles between a request and
+// its use, twice the stream points), the down_z fragments (chunk 31 of the image) loaded ONCE per block into the 16 KB behind them, where
+// ring slot 3 was: they then survive the tile boundary (what an epilogue that runs under the next tile's layer 1 needs), and the unused
+// chunk and the per-tile down_z chunk leave the stream.
+#ifndef E4_FINE
+#define E4_FINE 0
+#endif
+#if E4_FINE
+#define E4_CHUNK 8192
+#define E4_NSLOT 6
+#define E4_NCHUNK 60
+#else
 #define E4_CHUNK 16384
+#define E4_NSLOT 4
+#define E4_NCHUNK 32
+#endif
+// E4_PIPE (needs E4_FINE): the LayerNorm epilogue of a tile runs in slices behind the first feature tiles of the NEXT tile's layer 1 (the
+// last tile of a block: at its end, as before); E4_PIPE_T0 = the feature tile behind which the first slice runs
+#ifndef E4_PIPE
+#define E4_PIPE 0
+#endif
+#ifndef E4_PIPE_T0
+#define E4_PIPE_T0 0
+#endif
+static_assert(!E4_PIPE || E4_FINE, "the pipelined epilogue needs the down_z fragments resident (E4_FINE)");
+#define E4_CFR (E4_CHUNK / 1024)               // fragments per chunk
+#define E4_DZ_LDS 49152u                       // down_z hi | lo in LDS: ring slot 3 of the four-slot ring = the 16 KB behind the six 8 KB slots
 #define E4_DPC (E4_CHUNK / (E4_THREADS * 16))  // DMA instructions per chunk and wave
 __device__ __forceinline__ void e4_vm_wait(int n) {  // s_waitcnt vmcnt(n) (expcnt / lgkmcnt untouched); n folds after unrolling
   __builtin_amdgcn_sched_barrier(0);
+#define E4_VMC(k) case k: __builtin_amdgcn_s_waitcnt(0x0F70 | ((k) & 15) | (((k) >> 4) << 14)); break;
   switch (n) {
-    case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
-    case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
-    case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
-    case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
-    case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
-    case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
-    case 14: __builtin_amdgcn_s_waitcnt(0x0F7E); break;
-    case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
-    case 18: __builtin_amdgcn_s_waitcnt(0x4F72); break;
+    E4_VMC(1) E4_VMC(2) E4_VMC(3) E4_VMC(4) E4_VMC(5) E4_VMC(6) E4_VMC(7) E4_VMC(8) E4_VMC(9) E4_VMC(10) E4_VMC(11) E4_VMC(12)
+    E4_VMC(13) E4_VMC(14) E4_VMC(15) E4_VMC(16) E4_VMC(17) E4_VMC(18) E4_VMC(19) E4_VMC(20)
     default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
   }
+#undef E4_VMC
   __builtin_amdgcn_sched_barrier(0);
 }
 // younger VM instructions (guaranteed ones) than the DMA of chunk c + 1 at the barrier point of chunk c: always the DMA of chunk
 // c + 2; plus the 8 z requests issued at point E4_PT_Z, the 4 final-layer fold loads issued at point E4_PT_FL, the 12 + 2 fold / mask
 // loads of the tile boundary
+// (general form: the awaited DMA was issued at point c - (E4_NSLOT - 2); younger are the DMAs of the E4_NSLOT - 3 points behind it and
+//  whatever was issued behind the DMA of a point P with c - (E4_NSLOT - 2) <= P < c; the tile boundary counts as P = -1)
+#if E4_FINE
+#define E4_PT_Z 48
+#define E4_PT_FL 52
+#else
 #define E4_PT_Z 24   // stream point behind which the next tile's z rows are requested
 #define E4_PT_FL 26  // ... the final layer's fold fragments
+#endif
 __device__ __forceinline__ constexpr int e4_vm_younger(int c) {
-  return E4_DPC + (c == E4_PT_Z + 1 || c == E4_PT_Z + 2 ? 8 : (c == E4_PT_FL + 1 || c == E4_PT_FL + 2 ? 4 : (c == 0 || c == 1 ? 14 : 0)));
+  return (E4_NSLOT - 3) * E4_DPC + (c > E4_PT_Z && c <= E4_PT_Z + E4_NSLOT - 2 ? 8 : (c > E4_PT_FL && c <= E4_PT_FL + E4_NSLOT - 2 ? 4 : (c <= E4_NSLOT - 3 ? 14 : 0)));
 }
-__device__ __forceinline__ constexpr unsigned e4_ring_off(int f) { return (unsigned)(((f >> 4) & 3) * E4_CHUNK + (f & 15) * 1024); }
+__device__ __forceinline__ constexpr unsigned e4_ring_off(int f) { return (unsigned)(((f / E4_CFR) % E4_NSLOT) * E4_CHUNK + (f % E4_CFR) * 1024); }
 struct E4Flat {
   const char* stream;
   unsigned lds0, pa;
@@ -538,14 +638,34 @@ __device__ __forceinline__ void e4_point(const E4Flat& F, int c) {
   e4_vm_wait(e4_vm_younger(c));
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  const int cn = (c + 3) & 31;
+  const int cn = (c + E4_NSLOT - 1) % E4_NCHUNK;
   // (E4_ABL & 64, timing only: layer 1's six chunks are never streamed - the upper bound of what keeping them resident in LDS could buy)
-  if (!(E4_ABL & 64) || cn >= 6) e4_dma_chunk<E4_CHUNK>(F.stream + (size_t)cn * E4_CHUNK, F.lds0 + (unsigned)(cn & 3) * E4_CHUNK, F.tid, F.wave);
+  if (!(E4_ABL & 64) || cn * E4_CFR >= 96)
+    e4_dma_chunk<E4_CHUNK>(F.stream + (size_t)cn * E4_CHUNK, F.lds0 + (unsigned)(cn % E4_NSLOT) * E4_CHUNK, F.tid, F.wave);
+}
+// E4_PIPE: the stores of the slices that ran behind feature tile P (issued between stream points P and P + 1) are younger than the DMA a
+// point c awaits for P < c <= P + E4_NSLOT - 2: counted when every lane of the wave stored (full tile, all eight heads), otherwise the
+// plain lower bound over-waits.  Slices: EMIT(t) behind tile E4_PIPE_T0 + t (two z' stores), the pair bias / pair_z stores behind + 4.
+template <bool PZ, bool STZ>
+__device__ __forceinline__ constexpr int e4_pipe_extra(int c) {
+  int n = 0;
+  for (int t = 0; t < 4; ++t)
+    if (E4_PIPE_T0 + t < c && c <= E4_PIPE_T0 + t + E4_NSLOT - 2) n += STZ ? 2 : 0;
+  if (E4_PIPE_T0 + 4 < c && c <= E4_PIPE_T0 + 4 + E4_NSLOT - 2) n += PZ ? 8 : 0;
+  return n;
+}
+__device__ __forceinline__ void e4_point_x(const E4Flat& F, int c, int extra, bool counted) {  // (c and extra fold after unrolling)
+  if (extra > 0 && counted) e4_vm_wait(e4_vm_younger(c) + extra);
+  else e4_vm_wait(e4_vm_younger(c));
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  const int cn = (c + E4_NSLOT - 1) % E4_NCHUNK;
+  e4_dma_chunk<E4_CHUNK>(F.stream + (size_t)cn * E4_CHUNK, F.lds0 + (unsigned)(cn % E4_NSLOT) * E4_CHUNK, F.tid, F.wave);
 }
 // one k-step of the stream: the operand ring is refilled E4_DR - 1 fragments ahead (not past the tile's last fragment)
 #define E4_STEP(f_, B_, acc_)                                                                                   \
   do {                                                                                                          \
-    if ((f_) + E4_DR - 1 < 512 && (!(E4_ABL & 16) || (f_) < 8)) r[((f_) + E4_DR - 1) % E4_DR] = e4_frag(F.pa + e4_ring_off((f_) + E4_DR - 1)); \
+    if ((f_) + E4_DR - 1 < E4_NCHUNK * E4_CFR && (!(E4_ABL & 16) || (f_) < 8)) r[((f_) + E4_DR - 1) % E4_DR] = e4_frag(F.pa + e4_ring_off((f_) + E4_DR - 1)); \
     acc_ = e4_mfma(r[(f_) % E4_DR], B_, acc_);                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   } while (0)
@@ -578,7 +698,10 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
   E4Tile tc = e4_tile_of(tile * E4_WAVES + wave, n_wt, N, NJ4);
   e4_request_z(a, tc, lane0, lds0 + E4_ZOFF + wave * 8192, M);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) e4_dma_chunk<E4_CHUNK>(stream + c * E4_CHUNK, lds0 + c * E4_CHUNK, tid0, wave);
+  for (int c = 0; c < E4_NSLOT - 1; ++c) e4_dma_chunk<E4_CHUNK>(stream + c * E4_CHUNK, lds0 + c * E4_CHUNK, tid0, wave);
+#if E4_FINE
+  if (PZ) e4_dma_chunk<16384>(stream + (size_t)E4_DZ_FR0 * 1024, lds0 + E4_DZ_LDS, tid0, wave);  // down_z hi | lo: resident for the block
+#endif
   if (tid0 < (PZ ? 168 : 160)) {
     const float* src = tid0 < 96 ? a.b2 + 4 * tid0 : (tid0 < 128 ? a.gamma + 4 * (tid0 - 96) : (tid0 < 160 ? a.beta + 4 * (tid0 - 128) : a.bdz + 4 * (tid0 - 160)));
     e4_dma16(src, vec + (tid0 & ~63) * 16);
@@ -603,6 +726,15 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
   if (tid0 < 8) *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_BOFF + tid0 * 4) = (a.wb_img && tid0 < a.H) ? a.bb[tid0] : 0.f;
   float em_req = mask_of(tc, lane0);
   E4Epi E;
+  E4EpiTmp X;           // (E4_PIPE: lives across the tile boundary)
+  bool pend = false;    // E4_PIPE: the previous tile's epilogue is still to run (wave-uniform)
+  bool pend_full = false;  // ... and every lane of the wave will issue every store of it (the counts of e4_pipe_extra hold)
+#define E4_EPI(k, emr) e4_epi<k, PZ, STZ, emr>(E, X, a, lane_id(), vec, wbi, lds0 + E4_SOFF + wave * 2048, M, lds0 + E4_DZ_LDS)
+#if E4_PIPE
+  e4_u32x4 Zq[8];       // z' of the finished tile as half-precision B fragments (between NORM and EMIT)
+#define E4_NORM(t) e4_epi_norm<t>(E, X, a, lane_id(), vec, Zq)
+#define E4_EMIT(t) e4_epi_emit<t, PZ, STZ>(X, a, lane_id(), wbi, lds0 + E4_SOFF + wave * 2048, lds0 + E4_DZ_LDS, Zq)
+#endif
   e4_dma_wait();
   *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid0 * 4) = em_req;
   __syncthreads();
@@ -635,12 +767,36 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           const int f = 8 * T + s;
-          if ((f & 15) == 8) e4_point(F, f >> 4);
+#if E4_PIPE
+          if (f % E4_CFR == E4_CFR / 2) e4_point_x(F, f / E4_CFR, e4_pipe_extra<PZ, STZ>(f / E4_CFR), pend_full);
+#else
+          if (f % E4_CFR == E4_CFR / 2) e4_point(F, f / E4_CFR);
+#endif
           E4_STEP(f, Zf[s], acc);
         }
         e4_hand_off(acc, H1[2 * T], H1[2 * T + 1]);
+        if constexpr (E4_PIPE != 0) {
+#if E4_PIPE
+          if (pend) {
+#ifdef E4_PIPE_PRIO  // a slice's vector / LDS / store instructions ahead of the SIMD's other wave's MFMAs (they otherwise get one turn per MFMA)
+            __builtin_amdgcn_s_setprio(E4_PIPE_PRIO);
+#endif
+            if (T == E4_PIPE_T0) E4_EMIT(0);
+            if (T == E4_PIPE_T0 + 1) E4_EMIT(1);
+            if (T == E4_PIPE_T0 + 2) E4_EMIT(2);
+            if (T == E4_PIPE_T0 + 3) E4_EMIT(3);
+            if (T == E4_PIPE_T0 + 4) E4_EPI(6, false);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef E4_PIPE_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+          }
+#endif
+        }
       }
     }
+    pend = false;
+    pend_full = false;
     E4_STAMP(1);
     // ================= layer 2: fragments 96 .. 383 (12 tiles x 24 k-steps); the accumulator starts as b2.  The first four tiles are the
     // hidden features that face z in the residual trunk(x) + x (ipa_pytorch.py:99): z joins them as they are handed over (e4_add_z)
@@ -656,7 +812,7 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
 #pragma unroll
       for (int s = 0; s < 24; ++s) {
         const int f = E4_L1_FR + 24 * T + s;
-        if ((f & 15) == 8) e4_point(F, f >> 4);
+        if (f % E4_CFR == E4_CFR / 2) e4_point(F, f / E4_CFR);
         E4_STEP(f, H1[s], acc);
       }
       e4_hand_off(acc, H2[2 * T], H2[2 * T + 1]);
@@ -691,12 +847,12 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int f = E4_L1_FR + E4_L2_FR + 4 * s + t;
-        if ((f & 15) == 8) {
-          e4_point(F, f >> 4);
+        if (f % E4_CFR == E4_CFR / 2) {
+          e4_point(F, f / E4_CFR);
           // point E4_PT_Z: the wave's z rows are free since the fourth hand-over of layer 2 — the next tile's are requested here, seven chunks
           // before the tile ends (always issued, the last tile re-requests its own: the counts of e4_vm_younger stay static)
-          if ((f >> 4) == E4_PT_Z) e4_request_z(a, tn, lane_id(), lds0 + E4_ZOFF + wave * 8192, M);
-          if ((f >> 4) == E4_PT_FL) {
+          if (f / E4_CFR == E4_PT_Z) e4_request_z(a, tn, lane_id(), lds0 + E4_ZOFF + wave * 8192, M);
+          if (f / E4_CFR == E4_PT_FL) {
             const unsigned fb = fold_ptr(tc, lane_id());
 #pragma unroll
             for (int k = 0; k < 4; ++k) FL[k] = fold_ld(fb + (12 + k) * 512);
@@ -704,8 +860,10 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
         }
         E4_STEP(f, H2[s], E.Y[t]);
       }
+#if !E4_FINE
     e4_point(F, 30);  // the unused chunk and the down_z chunk: their stream points without products (the ring keeps turning)
     e4_point(F, 31);
+#endif
     {
       const hx8 SEL = e4_sel(lane, tc.ns);
 #pragma unroll
@@ -721,18 +879,23 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
 #ifdef E4_IDLE  // experiment: E4_IDLE x 64 idle cycles per tile and wave - how much of an idle cycle the power-capped clock gives back
     __builtin_amdgcn_s_sleep(E4_IDLE);
 #endif
+    X.moff = lds0 + E4_MOFF + tid * 4;
+    X.boff = lds0 + E4_BOFF;
+#if E4_PIPE
+    {  // statistics and the normalised half-precision z' now (32 registers instead of the final layer's 64); with a next tile its products
+       // and stores run under that tile's layer 1 (E.t, X and Zq stay untouched until then), without one right here
+      E4_EPI(0, true); E4_EPI(1, true);
+      E4_NORM(0); E4_NORM(1); E4_NORM(2); E4_NORM(3);
+      if (has_next) {
+        pend = true;
+        pend_full = PZ && E.t.valid && 8 * E.t.rt + 7 < M && a.wb_img && a.H == 8;
+      } else { E4_EMIT(0); E4_EMIT(1); E4_EMIT(2); E4_EMIT(3); E4_EPI(6, false); }
+    }
+    if (false) {
+#else
     if (!(E4_ABL & 1)) {
-      E4EpiTmp X;
-      X.moff = lds0 + E4_MOFF + tid * 4;
-      X.boff = lds0 + E4_BOFF;
-      const unsigned stg = lds0 + E4_SOFF + wave * 2048;
-      e4_epi<0, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
-      e4_epi<1, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
-      e4_epi<2, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
-      e4_epi<3, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
-      e4_epi<4, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
-      e4_epi<5, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
-      e4_epi<6, PZ, STZ>(E, X, a, lane, vec, wbi, stg, M, lds0 + 3 * E4_CHUNK);
+#endif
+      E4_EPI(0, true); E4_EPI(1, true); E4_EPI(2, true); E4_EPI(3, true); E4_EPI(4, true); E4_EPI(5, true); E4_EPI(6, true);
     } else if (E.Y[0][0] == 1234.5f) a.z_out[tile] = 1;
     E4_STAMP(4);
     if (!has_next) break;

@@ -23,6 +23,11 @@ __global__ void diff_count(const unsigned* x, const unsigned* y, long n, unsigne
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) c += x[i] != y[i];
   if (c) atomicAdd(out, c);
 }
+__global__ void checksum_k(const unsigned* x, long n, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) c += (unsigned long long)x[i] * (2654435761ull * (unsigned long long)i + 1ull);
+  atomicAdd(out, c);
+}
 int main(int argc, char** argv) {
   const int B = 8, N = argc > 1 ? atoi(argv[1]) : 300;
   const int only = argc > 3 ? atoi(argv[3]) : -1;  // time only this variant (0: pair bias only, 1: + pair_z of the next block)
@@ -55,6 +60,13 @@ int main(int argc, char** argv) {
   }
   half_t* pz; float* bdz;
   (void)hipMalloc(&pz, fd_pz_bytes(B, N)); (void)hipMalloc(&bdz, 128); (void)hipMemset(bdz, 0, 128);
+  (void)hipMemset(pz, 0, fd_pz_bytes(B, N));
+  {  // down_z of the "next block": random hi / lo fragment images into the stream's last chunk (what fd_et4_set_dz copies there)
+    half_t* dzi; (void)hipMalloc(&dzi, 16384);
+    fill_h16<<<64, 256>>>(dzi, 4096, 11u, 0.1f * ds); fill_h16<<<64, 256>>>(dzi + 4096, 4096, 12u, 0.0001f * ds);
+    (void)hipMemcpy((char*)stream + (size_t)E4_DZ_FR0 * 1024, dzi, 16384, hipMemcpyDeviceToDevice);
+    fill_f32<<<1, 64>>>(bdz, 32, 13u, 0.1f);
+  }
   hipEvent_t t0, t1; (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
   const double flops = 688128.0 * P;  // reference-formulation count (bench.py: ET_FLOPS_PER_PAIR)
   for (int v = 0; v < 2; ++v) {
@@ -76,6 +88,14 @@ int main(int argc, char** argv) {
     unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
     std::vector<half_t> hz(4096); (void)hipMemcpy(hz.data(), zo[0] + (P / 2) * 128, 8192, hipMemcpyDeviceToHost);
     double sa = 0; for (auto x : hz) sa += fabs((double)(float)__builtin_bit_cast(_Float16, x));
+    {  // checksums of every output of variant 1: equal between two builds of this file = the builds give the same bits
+      unsigned long long* c3; (void)hipMalloc(&c3, 24); (void)hipMemset(c3, 0, 24);
+      checksum_k<<<1024, 256>>>((const unsigned*)zo[1], P * 64, c3);
+      checksum_k<<<1024, 256>>>((const unsigned*)bo[1], (long)B * 8 * Np * Np, c3 + 1);
+      checksum_k<<<1024, 256>>>((const unsigned*)pz, (long)(fd_pz_bytes(B, N) / 4), c3 + 2);
+      unsigned long long hc[3]; (void)hipMemcpy(hc, c3, 24, hipMemcpyDeviceToHost);
+      printf("checksums z' %016llx bias %016llx pair_z %016llx\n", hc[0], hc[1], hc[2]);
+    }
     printf("with vs without pair_z: %llu differing z words of %ld, %llu differing bias words; mean |z'| %.4f\n", h[0], P * 64, h[1], sa / 4096);
   }
 #ifdef E4_PROF
