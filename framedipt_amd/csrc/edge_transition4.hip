@@ -733,7 +733,11 @@ __global__ __launch_bounds__(E4_THREADS, 8 / E4_WAVES) void edge_transition4_fla
 #if E4_PIPE
   e4_u32x4 Zq[8];       // z' of the finished tile as half-precision B fragments (between NORM and EMIT)
 #define E4_NORM(t) e4_epi_norm<t>(E, X, a, lane_id(), vec, Zq)
-#define E4_EMIT(t) e4_epi_emit<t, PZ, STZ>(X, a, lane_id(), wbi, lds0 + E4_SOFF + wave * 2048, lds0 + E4_DZ_LDS, Zq)
+#define E4_EMIT(t)                                                                                                          \
+  do {                                                                                                                      \
+    if (!(E4_ABL & 128)) e4_epi_emit<t, PZ, STZ>(X, a, lane_id(), wbi, lds0 + E4_SOFF + wave * 2048, lds0 + E4_DZ_LDS, Zq);  \
+    else if (Zq[2 * t][0] == 0x12345678u) a.z_out[t] = 1;  /* (E4_ABL & 128, timing only: the emitting part costs nothing) */ \
+  } while (0)
 #endif
   e4_dma_wait();
   *(__attribute__((address_space(3))) float*)(unsigned long)(lds0 + E4_MOFF + tid0 * 4) = em_req;
